@@ -1,0 +1,334 @@
+"""CPU oracle: numpy float64 restatement of spectral-cube's dense hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the product path
+(``spectral_cube_amd``) never does and fails loudly when the HIP library is
+missing.
+
+Every function cites the reference lines it restates (paths relative to
+``/root/reference``).  Parity is PINNED for moments / argmax / spectral_smooth /
+spatial_smooth / spectral_interpolate: ``oracle/gen_golden.py`` runs the real
+reference (imported via ``oracle/ref_env/bootstrap.py``) and asserts these
+functions reproduce it, and ``tests/test_oracle_golden.py`` re-checks them
+against the committed vectors in ``tests/golden/`` plus the reference's own
+hand-written golden tables (spectral_cube/tests/test_moments.py:19-49 etc.).
+Parity is UNPINNED for ``resample_bilinear`` (the reference delegates to the
+third-party ``reproject`` package, which is neither vendored nor installed and
+whose pixel values the reference's tests never check - SURVEY.md section 8c).
+
+Array layout everywhere: C-contiguous ``(nz, ny, nx)``, spectral axis first.
+"""
+import numpy as np
+
+__all__ = [
+    "filled", "moment", "moments012", "moment_cubewise", "argmax", "argmin",
+    "convolve_fill_interp", "spectral_smooth", "spatial_smooth",
+    "spectral_interpolate", "resample_bilinear", "reproject_separable",
+]
+
+
+# --------------------------------------------------------------------------
+# mask -> filled data
+# --------------------------------------------------------------------------
+def filled(data, include=None, fill=np.nan):
+    """``MaskBase._filled`` (spectral_cube/masks.py:197-237).
+
+    ``data.astype(result_type(dtype, 0.0))`` with excluded voxels replaced by
+    *fill*; ``include=None`` means "no mask" (base_class.py:389-417 returns the
+    raw data then).  The dtype is kept (fp32 stays fp32).
+    """
+    dt = np.result_type(data.dtype, 0.0)
+    out = np.array(data, dtype=dt, copy=True)
+    if include is not None:
+        out[~np.asarray(include, dtype=bool)] = fill
+    return out
+
+
+def _nansum_allbadtonan(a, axis):
+    """``allbadtonan(np.nansum)`` (spectral_cube/np_compat.py:3-27)."""
+    res = np.nansum(a, axis=axis)
+    allbad = np.all(np.isnan(a), axis=axis)
+    res = np.asarray(res, dtype=a.dtype)
+    res[allbad] = np.nan
+    return res
+
+
+# --------------------------------------------------------------------------
+# moments
+# --------------------------------------------------------------------------
+def _bcast_cen(pix_cen, shape, axis):
+    """pix_cen may be 1-D along *axis* (spectral) or a full/broadcastable 3-D
+    array (spatial axes, spectral_cube.py:1455-1508)."""
+    pix_cen = np.asarray(pix_cen, dtype=np.float64)
+    if pix_cen.ndim == 1:
+        shp = [1, 1, 1]
+        shp[axis] = shape[axis]
+        pix_cen = pix_cen.reshape(shp)
+    return pix_cen
+
+
+def moment(data, include, order, pix_cen, pix_size, axis=0, world0=None):
+    """``DaskSpectralCubeMixin.moment`` arithmetic
+    (spectral_cube/dask_spectral_cube.py:1083-1123), evaluated eagerly.
+
+    data     fp32/fp64 cube, include bool mask or None
+    pix_cen  offsets from pixel 0 along *axis* (spectral_cube.py:1473-1475)
+    pix_size scalar pixel size along *axis* (spectral_cube.py:1510-1535)
+    world0   added to moment 1 when axis == 0 (dask_spectral_cube.py:1122-1123)
+    Returns float64.
+    """
+    d = filled(data, include, np.nan).astype(np.float64)        # :1083
+    cen = _bcast_cen(pix_cen, d.shape, axis)
+    if order == 0:
+        return _nansum_allbadtonan(d * pix_size, axis)           # :1087-1088
+    denominator = _nansum_allbadtonan(d * pix_size, axis)       # :1090
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mom1 = _nansum_allbadtonan(d * pix_size * cen, axis) / denominator
+        if order > 1:
+            mom1k = np.expand_dims(mom1, axis)                  # :1094-1097
+            out = (_nansum_allbadtonan(d * pix_size * (cen - mom1k) ** order,
+                                       axis) / denominator)     # :1098-1099
+        else:
+            out = mom1
+    if order == 1 and axis == 0 and world0 is not None:
+        out = out + world0                                      # :1122-1123
+    return out
+
+
+def moments012(data, include, pix_cen, pix_size, world0=0.0):
+    """moment 0, 1, 2 along axis 0 in one call (three reference passes)."""
+    return (moment(data, include, 0, pix_cen, pix_size),
+            moment(data, include, 1, pix_cen, pix_size, world0=world0),
+            moment(data, include, 2, pix_cen, pix_size))
+
+
+def moment_cubewise(data, include, order, pix_cen, pix_size, axis=0):
+    """``moment_cubewise`` (spectral_cube/_moments.py:170-193): NumPy-class
+    strategy.  Only moment 0 maps all-bad rays to NaN explicitly; orders >= 1
+    get NaN from 0/0.  Computed in float64 here (numpy >= 2 promotion)."""
+    d = filled(data, include, np.nan).astype(np.float64) * pix_size
+    cen = _bcast_cen(pix_cen, d.shape, axis)
+    if order == 0:
+        return _nansum_allbadtonan(d, axis)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        if order == 1:
+            return np.nansum(d * cen, axis=axis) / np.nansum(d, axis=axis)
+        mom1 = np.expand_dims(moment_cubewise(data, include, 1, pix_cen,
+                                              pix_size, axis), axis)
+        return (np.nansum(d * (cen - mom1) ** order, axis=axis) /
+                np.nansum(d, axis=axis))
+
+
+# --------------------------------------------------------------------------
+# argmax / argmin  (integer maps: bit-exact)
+# --------------------------------------------------------------------------
+def _arg(data, include, axis, fill, fn):
+    d = filled(data, include, fill)
+    # np.nanarg* raise on all-NaN rays; the reference's rays are filled with
+    # +-inf where masked, so only NaN *data* inside the mask can trigger that.
+    # Treat NaN as the fill value (what nanargmax does for partial NaN rays).
+    d = np.where(np.isnan(d), fill, d)
+    return fn(d, axis=axis).astype(np.int64)
+
+
+def argmax(data, include=None, axis=0):
+    """``argmax`` (spectral_cube/spectral_cube.py:793-804;
+    dask_spectral_cube.py:749-757): nanargmax of data filled with -inf.
+    First index wins ties; a fully masked ray gives 0."""
+    return _arg(data, include, axis, -np.inf, np.argmax)
+
+
+def argmin(data, include=None, axis=0):
+    """``argmin`` (spectral_cube/spectral_cube.py:806-819): fill +inf."""
+    return _arg(data, include, axis, np.inf, np.argmin)
+
+
+# --------------------------------------------------------------------------
+# astropy.convolution.convolve semantics (third-party; astropy>=6.1 declared
+# in pyproject.toml:26, 4.3.1 probed here).  Call sites:
+# dask_spectral_cube.py:912-914, 990-993; spectral_cube.py:2833-2837, 3216-3222
+# --------------------------------------------------------------------------
+def convolve_fill_interp(array, kernel, normalize_kernel=True):
+    """``astropy.convolution.convolve(array, kernel, boundary='fill',
+    fill_value=0, nan_treatment='interpolate', normalize_kernel=True)``.
+
+    * true convolution (kernel flipped), direct sum, float64 internally;
+    * out-of-bounds samples are *valid zeros* (they contribute to the weight
+      sum);
+    * if the array contains any NaN: ``out = sum(k*d over non-NaN) /
+      sum(k over non-NaN)``, and where that weight sum is 0 the (NaN) centre
+      sample is returned; otherwise ``out = sum(k*d) / sum(k)``;
+    * result cast back to the input floating dtype.
+    """
+    array = np.asarray(array)
+    kernel = np.asarray(kernel, dtype=np.float64)
+    if array.ndim != kernel.ndim:
+        raise ValueError("array and kernel have differing number of dimensions")
+    if any(s % 2 == 0 for s in kernel.shape):
+        raise ValueError("kernel axes must be odd")
+    a = array.astype(np.float64)
+    pad = [s // 2 for s in kernel.shape]
+    ap = np.pad(a, [(p, p) for p in pad], mode="constant", constant_values=0.0)
+    isn = np.isnan(ap)
+    any_nan = bool(isn.any())
+    v = np.where(isn, 0.0, ap)
+    w = (~isn).astype(np.float64)
+    top = np.zeros(a.shape, dtype=np.float64)
+    bot = np.zeros(a.shape, dtype=np.float64)
+    kflip = kernel[tuple(slice(None, None, -1) for _ in kernel.shape)]
+    for idx in np.ndindex(*kernel.shape):
+        kv = kflip[idx]
+        if kv == 0.0:
+            continue
+        sl = tuple(slice(i, i + n) for i, n in zip(idx, a.shape))
+        top += kv * v[sl]
+        if any_nan:
+            bot += kv * w[sl]
+    ksum = kernel.sum()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        if any_nan:
+            res = np.where(bot != 0.0, top / np.where(bot != 0.0, bot, 1.0), a)
+            if not normalize_kernel:
+                res = res * ksum
+        else:
+            res = top / ksum if normalize_kernel else top
+    if array.dtype.kind == "f":
+        res = res.astype(array.dtype)
+    return res
+
+
+def spectral_smooth(data, include, kernel1d, fill=np.nan):
+    """``DaskSpectralCubeMixin.spectral_smooth``
+    (dask_spectral_cube.py:880-917): convolve the NaN-filled chunk with the
+    kernel reshaped to (n,1,1).  The returned cube keeps the ORIGINAL mask
+    (dask_spectral_cube.py:836-840) - callers re-apply *include* themselves.
+    NaN-awareness is decided per chunk by astropy; the whole cube is one chunk
+    here, which is numerically equivalent (the two branches agree when no NaN
+    is present up to rounding)."""
+    d = filled(data, include, fill)
+    k = np.asarray(kernel1d, dtype=np.float64).reshape(-1, 1, 1)
+    return convolve_fill_interp(d, k)
+
+
+def spatial_smooth(data, include, kernel2d, fill=np.nan):
+    """``DaskSpectralCubeMixin.spatial_smooth``
+    (dask_spectral_cube.py:962-993 + wrapper :540-547): every channel is
+    convolved independently with the 2-D kernel."""
+    d = filled(data, include, fill)
+    k = np.asarray(kernel2d, dtype=np.float64)
+    out = np.empty_like(d)
+    for i in range(d.shape[0]):
+        out[i] = convolve_fill_interp(d[i], k)
+    return out
+
+
+# --------------------------------------------------------------------------
+# spectral_interpolate  (Dask semantics, scipy.interpolate.interp1d linear)
+# --------------------------------------------------------------------------
+def spectral_interpolate(data, include, inaxis, grid, fill_value=None,
+                         out_dtype=None):
+    """``DaskSpectralCubeMixin.spectral_interpolate``
+    (dask_spectral_cube.py:1291-1373) with scipy ``interp1d(kind='linear',
+    bounds_error=False, fill_value=fill_value)`` restated
+    (scipy/interpolate/_interpolate.py ``_call_linear`` + ``_check_bounds``;
+    scipy>=1.8.1 declared in pyproject.toml:52).
+
+    inaxis / grid: spectral coordinates (same unit) of the input channels and
+    of the requested output channels; either may be descending.  Output
+    channel order follows *grid* as given (dask_spectral_cube.py:1366-1367).
+    Returns (newdata, newmask) with newmask = ~isnan(newdata) (:1364).
+    """
+    inaxis = np.asarray(inaxis, dtype=np.float64)
+    grid = np.asarray(grid, dtype=np.float64)
+    d = filled(data, include, np.nan)
+    reverse_in = np.mean(np.diff(inaxis)) < 0                  # :1293-1304
+    reverse_out = np.mean(np.diff(grid)) < 0
+    if reverse_in:
+        inaxis = inaxis[::-1]
+        d = d[::-1]
+    if reverse_out:
+        grid = grid[::-1]
+    if not (np.all(np.diff(grid) > 0) and np.all(np.diff(inaxis) > 0)):
+        raise AssertionError("axes must be monotonic")           # :1315-1316
+    np.testing.assert_allclose(np.diff(grid), np.mean(np.diff(grid)),
+                               err_msg="Output grid must be linear")  # :1318
+    idx = np.searchsorted(inaxis, grid)
+    idx = np.clip(idx, 1, len(inaxis) - 1).astype(int)
+    lo, hi = idx - 1, idx
+    x_lo, x_hi = inaxis[lo], inaxis[hi]
+    y_lo, y_hi = d[lo], d[hi]
+    with np.errstate(invalid="ignore"):
+        slope = (y_hi - y_lo) / (x_hi - x_lo)[:, None, None]
+        y_new = slope * (grid - x_lo)[:, None, None] + y_lo
+    oob = (grid < inaxis[0]) | (grid > inaxis[-1])
+    y_new = np.asarray(y_new, dtype=np.float64)
+    y_new[oob] = np.nan if fill_value is None else fill_value
+    newmask = ~np.isnan(y_new)
+    if reverse_out:
+        y_new = y_new[::-1]
+        newmask = newmask[::-1]
+    if out_dtype is not None:
+        y_new = y_new.astype(out_dtype)
+    return y_new, newmask
+
+
+# --------------------------------------------------------------------------
+# reprojection (PARITY UNPINNED - see module docstring)
+# --------------------------------------------------------------------------
+def resample_bilinear(plane_or_cube, xs, ys):
+    """Bilinear resampling of every channel at source pixel coordinates
+    ``(xs, ys)`` (0-based, pixel centres at integers), following the
+    published behaviour of ``reproject.reproject_interp(order='bilinear')``
+    (call site spectral_cube/spectral_cube.py:2726-2732): output pixels whose
+    source position falls outside ``[-0.5, n-0.5]`` are NaN (footprint 0);
+    inside that range the image is edge-replicated by half a pixel; NaN input
+    samples propagate.
+    Returns (data, footprint)."""
+    a = np.asarray(plane_or_cube)
+    cube = a if a.ndim == 3 else a[None]
+    nz, ny, nx = cube.shape
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        inside = ((xs >= -0.5) & (xs <= nx - 0.5) &
+                  (ys >= -0.5) & (ys <= ny - 0.5))
+    inside &= np.isfinite(xs) & np.isfinite(ys)
+    xc = np.clip(np.where(inside, xs, 0.0), 0.0, nx - 1.0)
+    yc = np.clip(np.where(inside, ys, 0.0), 0.0, ny - 1.0)
+    x0 = np.minimum(np.floor(xc).astype(np.int64), max(nx - 2, 0))
+    y0 = np.minimum(np.floor(yc).astype(np.int64), max(ny - 2, 0))
+    x1 = np.minimum(x0 + 1, nx - 1)
+    y1 = np.minimum(y0 + 1, ny - 1)
+    fx = xc - x0
+    fy = yc - y0
+    out = np.empty((nz,) + xs.shape, dtype=np.float64)
+    for k in range(nz):
+        p = cube[k].astype(np.float64)
+        v = ((1 - fy) * ((1 - fx) * p[y0, x0] + fx * p[y0, x1]) +
+             fy * ((1 - fx) * p[y1, x0] + fx * p[y1, x1]))
+        out[k] = np.where(inside, v, np.nan)
+    foot = np.broadcast_to(inside, out.shape).copy()
+    if a.ndim == 2:
+        return out[0], foot[0]
+    return out, foot
+
+
+def reproject_separable(cube, xs, ys, zs=None):
+    """Spatial bilinear resample, optionally composed with a linear resample
+    along z at fractional channel positions *zs* (trilinear with a separable
+    coordinate map: what reproject_interp does for cube headers whose spectral
+    and celestial axes are independent)."""
+    out, foot = resample_bilinear(cube, xs, ys)
+    if zs is None:
+        return out, foot
+    nz = out.shape[0]
+    zs = np.asarray(zs, dtype=np.float64)
+    inside = (zs >= -0.5) & (zs <= nz - 0.5)
+    zc = np.clip(np.where(inside, zs, 0.0), 0.0, nz - 1.0)
+    z0 = np.minimum(np.floor(zc).astype(np.int64), max(nz - 2, 0))
+    z1 = np.minimum(z0 + 1, nz - 1)
+    fz = (zc - z0)[:, None, None]
+    res = (1 - fz) * out[z0] + fz * out[z1]
+    res[~inside] = np.nan
+    f = foot[z0] & foot[z1] & inside[:, None, None]
+    return res, f
