@@ -1,0 +1,240 @@
+/*
+ * spcube_hip.h - C ABI of libspcube_hip.so, the MI355X (gfx950) engine behind
+ * spectral-cube's dense hot path.
+ *
+ * The reference (radio-astro-tools/spectral-cube) is pure Python and has no
+ * FFI; the operator seams this library is bound at are listed per entry point
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative spc_status otherwise;
+ *     spc_last_error() gives a thread-local message; nothing throws;
+ *   - the caller owns every buffer; "d_" pointers are device (HBM) addresses
+ *     obtained from spc_malloc (or any hipMalloc), "h_" pointers are host;
+ *   - cubes are C-contiguous (nz, ny, nx) float32, spectral axis first, x
+ *     fastest; row/plane strides are given in ELEMENTS so that a (y) row strip
+ *     of a larger cube can be processed in place;
+ *   - every launch takes a device index and a stream handle (hipStream_t as
+ *     void*, NULL = default stream); there is no global mutable state, so dask
+ *     `threads` workers and one-process-per-GPU drivers may call concurrently;
+ *   - no torch / numpy types cross this boundary.
+ */
+#ifndef SPCUBE_HIP_H
+#define SPCUBE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPC_ABI_VERSION 1
+
+typedef enum {
+    SPC_OK = 0,
+    SPC_ERR_INVALID = -1,     /* bad argument (shape, pointer, flag) */
+    SPC_ERR_HIP = -2,         /* HIP runtime error, see spc_last_error() */
+    SPC_ERR_UNSUPPORTED = -3, /* valid request this build cannot serve */
+    SPC_ERR_NOMEM = -4,
+    SPC_ERR_COMM = -5         /* RCCL error */
+} spc_status;
+
+/* ---- mask specification ------------------------------------------------
+ * Restates MaskBase.include / _filled (spectral_cube/masks.py:105-116,
+ * 197-237) for the mask kinds that can be evaluated on the fly:
+ *   BooleanArrayMask (masks.py:457-584)  -> SPC_MASK_ARRAY (uint8, !=0 = include)
+ *   LazyMask(np.isfinite) (io/fits.py:214) -> SPC_MASK_FINITE
+ *   LazyComparisonMask cube > x etc. (masks.py:670-758) -> SPC_MASK_GT/GE/LT/LE
+ * Flags are AND-ed (CompositeMask 'and', masks.py:425-435).  Other
+ * compositions are materialised to a uint8 array by the host.
+ * A voxel is "valid" when it is included AND its value is not NaN (NaN-filled
+ * data fed to nansum, dask_spectral_cube.py:1083). */
+#define SPC_MASK_NONE   0u
+#define SPC_MASK_ARRAY  1u
+#define SPC_MASK_FINITE 2u
+#define SPC_MASK_GT     4u   /* data >  thr_lo */
+#define SPC_MASK_GE     8u   /* data >= thr_lo */
+#define SPC_MASK_LT     16u  /* data <  thr_hi */
+#define SPC_MASK_LE     32u  /* data <= thr_hi */
+
+typedef struct {
+    uint32_t flags;
+    float thr_lo;
+    float thr_hi;
+    const uint8_t* d_array;      /* device ptr, may be NULL unless SPC_MASK_ARRAY */
+    int64_t row_stride;          /* elements; 0 = same as the cube's */
+    int64_t plane_stride;        /* elements; 0 = same as the cube's */
+} spc_mask;
+
+/* cube view: d_data points at voxel (0,0,0) of the (sub)cube */
+typedef struct {
+    const float* d_data;
+    int64_t nz, ny, nx;
+    int64_t row_stride;          /* elements between (z,y,x) and (z,y+1,x) */
+    int64_t plane_stride;        /* elements between (z,y,x) and (z+1,y,x) */
+} spc_cube_f32;
+
+/* ---- library / device management -------------------------------------- */
+int spc_abi_version(void);
+const char* spc_last_error(void);
+int spc_device_count(int* count);
+typedef struct {
+    char name[128];
+    char arch[64];               /* e.g. "gfx950:sramecc+:xnack-" */
+    int compute_units;
+    int wavefront_size;
+    int64_t total_mem;
+    int64_t free_mem;
+    int clock_khz;
+} spc_device_info;
+int spc_get_device_info(int device, spc_device_info* info);
+
+int spc_malloc(int device, size_t bytes, void** d_ptr);
+int spc_free(int device, void* d_ptr);
+int spc_host_alloc(size_t bytes, void** h_ptr);       /* pinned */
+int spc_host_free(void* h_ptr);
+int spc_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);
+int spc_memcpy_d2h(int device, void* h_dst, const void* d_src, size_t bytes, void* stream);
+int spc_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes, void* stream);
+/* strided 3-D copies (host chunk (nz,cy,cx) <-> device strip); pitches in bytes */
+int spc_memcpy3d_h2d(int device, void* d_dst, size_t d_row_pitch, size_t d_plane_pitch,
+                     const void* h_src, size_t h_row_pitch, size_t h_plane_pitch,
+                     size_t row_bytes, size_t ny, size_t nz, void* stream);
+int spc_memset(int device, void* d_ptr, int value, size_t bytes, void* stream);
+int spc_stream_create(int device, void** stream);
+int spc_stream_destroy(int device, void* stream);
+int spc_stream_sync(int device, void* stream);
+int spc_device_sync(int device);
+int spc_event_create(int device, void** event);
+int spc_event_destroy(int device, void* event);
+int spc_event_record(int device, void* event, void* stream);
+int spc_event_sync(int device, void* event);
+int spc_event_elapsed_ms(int device, void* start, void* stop, float* ms);
+
+/* ---- moments ------------------------------------------------------------
+ * Replaces DaskSpectralCubeMixin.moment (spectral_cube/dask_spectral_cube.py
+ * :1031-1132, arithmetic :1083-1104 and nansum_allbadtonan :54-59),
+ * moment_cubewise/_slicewise/_raywise (spectral_cube/_moments.py:30-193),
+ * allbadtonan (np_compat.py:3-27) and argmax/argmin
+ * (spectral_cube/spectral_cube.py:793-819) for axis 0, in ONE pass:
+ *   S0 = sum v, S1 = sum v*c[z], S2 = sum v*c[z]^2 over valid voxels (fp64)
+ *   m0 = dv*S0 (NaN when no valid voxel), m1 = S1/S0 + m1_add,
+ *   m2 = S2/S0 - (S1/S0)^2
+ * d_cen: nz doubles in device memory = pix_cen[z] - c_ref (spectral_cube.py
+ * :1473-1475); the host folds c_ref and world(chan 0) into m1_add
+ * (dask_spectral_cube.py:1122-1123).  Any output pointer may be NULL.
+ * argmax/argmin: first index on ties, 0 for rays without valid voxel.
+ * d_workspace: spc_moments_workspace_bytes() bytes (may be NULL if 0). */
+typedef struct {
+    double* d_m0; double* d_m1; double* d_m2;   /* (ny,nx) float64 */
+    double* d_mu;      /* S1/S0 without m1_add (input of spc_moment_order_f32) */
+    double* d_s0;      /* raw S0 */
+    int64_t* d_argmax; int64_t* d_argmin;       /* (ny,nx) int64 */
+    float* d_vmax; float* d_vmin;               /* max/min over valid voxels (NaN if none) */
+    int32_t* d_nvalid;
+    int64_t out_row_stride;                     /* elements; 0 = nx */
+} spc_moment_outputs;
+
+size_t spc_moments_workspace_bytes(int64_t nz, int64_t ny, int64_t nx);
+int spc_moments_f32(int device, void* stream, const spc_cube_f32* cube,
+                    const spc_mask* mask, const double* d_cen, double dv,
+                    double m1_add, const spc_moment_outputs* out,
+                    void* d_workspace, size_t workspace_bytes);
+
+/* general order N >= 2 second pass:  out = sum v*(c - mu)^N / S0
+ * (dask_spectral_cube.py:1094-1099; _moments.py:185-193).  d_mu, d_s0 come
+ * from spc_moments_f32. */
+int spc_moment_order_f32(int device, void* stream, const spc_cube_f32* cube,
+                         const spc_mask* mask, const double* d_cen, int order,
+                         const double* d_mu, const double* d_s0, double* d_out,
+                         int64_t out_row_stride);
+
+/* moments along a spatial axis (axis = 1 or 2), reference golden tables
+ * spectral_cube/tests/test_moments.py:19-49.  d_cen is a (ny,nx) float64 map
+ * of offsets along that axis (spectral_cube.py:1476-1503), pix_size the pixel
+ * scale (spectral_cube.py:1530-1533).  Outputs have shape (nz,nx) for axis 1
+ * and (nz,ny) for axis 2, C-contiguous. */
+int spc_moments_spatial_f32(int device, void* stream, const spc_cube_f32* cube,
+                            const spc_mask* mask, int axis, const double* d_cen,
+                            double pix_size, double* d_m0, double* d_m1,
+                            double* d_m2);
+
+/* ---- NaN-aware convolution (astropy.convolution.convolve semantics:
+ * boundary='fill', fill_value=0, nan_treatment='interpolate',
+ * normalize_kernel=True) ---------------------------------------------------
+ * spectral: replaces the chunk function of DaskSpectralCubeMixin.
+ * spectral_smooth (dask_spectral_cube.py:880-917; NumPy twin
+ * spectral_cube.py:3186-3222).  h_kernel: ntaps (odd) doubles on the HOST.
+ * Input voxels failing the mask are treated as NaN (the reference convolves
+ * the NaN-filled chunk).  Output float32, same shape. */
+int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube,
+                          const spc_mask* mask, const double* h_kernel, int ntaps,
+                          float* d_out, int64_t out_row_stride,
+                          int64_t out_plane_stride);
+
+/* fused spectral_smooth -> moments (legal because the Dask smooth is lazy and
+ * keeps the ORIGINAL mask, dask_spectral_cube.py:836-840): the smoothed cube
+ * is never written.  Semantics = spc_spectral_conv_f32 followed by
+ * spc_moments_f32 with the same mask re-applied to the smoothed values. */
+int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* cube,
+                                  const spc_mask* mask, const double* h_kernel,
+                                  int ntaps, const double* d_cen, double dv,
+                                  double m1_add, const spc_moment_outputs* out);
+
+/* spatial: replaces the per-channel 2-D convolution of spatial_smooth
+ * (dask_spectral_cube.py:962-993 + :540-547; NumPy twin spectral_cube.py
+ * :2808-2842).  Separable form: kernel2d = outer(h_ky, h_kx) (exact for
+ * Gaussian2DKernel).  Non-separable kernels: spc_spatial_conv2d_f32. */
+int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
+                             const spc_mask* mask, const double* h_ky, int nky,
+                             const double* h_kx, int nkx, float* d_out,
+                             int64_t out_row_stride, int64_t out_plane_stride);
+int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube,
+                           const spc_mask* mask, const double* h_kernel, int nky,
+                           int nkx, float* d_out, int64_t out_row_stride,
+                           int64_t out_plane_stride);
+
+/* ---- resampling -----------------------------------------------------------
+ * spectral lerp: replaces interp_wrapper / scipy interp1d(kind='linear') of
+ * DaskSpectralCubeMixin.spectral_interpolate (dask_spectral_cube.py:1342-1353).
+ * For output channel j: lo = d_lo[j] (int32 input channel), and
+ *   out = (in[lo+1]-in[lo]) * d_inv_dx[j] * d_t[j] + in[lo]      (float64 maths)
+ * d_lo[j] < 0 marks out-of-range channels which receive `fill`.
+ * NaN in either bracketing sample gives NaN (scipy semantics). */
+int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube,
+                          const spc_mask* mask, int64_t nz_out, const int32_t* d_lo,
+                          const double* d_t, const double* d_inv_dx, float fill,
+                          float* d_out, int64_t out_row_stride,
+                          int64_t out_plane_stride);
+
+/* bilinear spatial resample: replaces the inner resampler of
+ * reproject.reproject_interp(order='bilinear') called from
+ * BaseSpectralCube.reproject (spectral_cube.py:2700-2732).  d_xs, d_ys:
+ * (ny_out,nx_out) float64 source pixel coordinates (0-based).  Output pixels
+ * whose source falls outside [-0.5, n-0.5] are NaN and get footprint 0.
+ * d_footprint (uint8, (ny_out,nx_out)) may be NULL. */
+int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube,
+                              const spc_mask* mask, float fill, int64_t ny_out,
+                              int64_t nx_out, const double* d_xs, const double* d_ys,
+                              float* d_out, int64_t out_row_stride,
+                              int64_t out_plane_stride, uint8_t* d_footprint);
+
+/* ---- multi-GPU stitch (RCCL over xGMI) -----------------------------------
+ * One process per GPU; each rank owns a row strip of the 2-D map.  The id is
+ * created on rank 0 (spc_comm_unique_id) and distributed by the host
+ * launcher (torch.distributed store / file), then every rank calls
+ * spc_comm_init.  spc_allgather_rows gathers equal-sized strips. */
+#define SPC_COMM_ID_BYTES 128
+int spc_comm_unique_id(uint8_t id[SPC_COMM_ID_BYTES]);
+int spc_comm_init(int device, const uint8_t id[SPC_COMM_ID_BYTES], int nranks,
+                  int rank, void** comm);
+int spc_comm_destroy(void* comm);
+int spc_allgather_rows(void* comm, void* stream, const void* d_send, void* d_recv,
+                       size_t bytes_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPCUBE_HIP_H */

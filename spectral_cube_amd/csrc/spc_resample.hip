@@ -1,0 +1,202 @@
+// Spectral linear interpolation and spatial bilinear resampling.
+//
+// spc_spectral_lerp_f32 replaces interp_wrapper / scipy.interpolate.interp1d
+// (kind='linear', bounds_error=False) inside DaskSpectralCubeMixin.
+// spectral_interpolate (spectral_cube/dask_spectral_cube.py:1342-1353).
+// spc_resample_bilinear_f32 replaces the resampler of reproject.
+// reproject_interp(order='bilinear') called by BaseSpectralCube.reproject
+// (spectral_cube/spectral_cube.py:2726-2732).
+//
+// Both are pure HBM streams: lanes run along x (coalesced), each lane keeps
+// its bracketing input samples in registers while the (wave-uniform) output
+// channel index advances, so every input plane is read once.
+#include "spc_common.h"
+#include <algorithm>
+
+namespace {
+
+struct LerpArgs {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    MaskDev mask;
+    int64_t nz_out;
+    const int32_t* lo;
+    const double* t;
+    const double* inv_dx;
+    float fill;
+    float* out;
+    int64_t out_row_stride, out_plane_stride;
+    int64_t jchunk;
+};
+
+__device__ __forceinline__ float load_filled(const float* p, const uint8_t* pm, const MaskDev& m, int64_t off, int64_t moff) {
+    const float v = p[off];
+    bool inc = spc_pred(m.flags, m.thr_lo, m.thr_hi, v);
+    if (pm) inc = inc && pm[moff] != 0;
+    return inc ? v : NAN;
+}
+
+__global__ __launch_bounds__(256) void spectral_lerp_kernel(const LerpArgs A) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= A.ny * A.nx) return;
+    const int64_t y = col / A.nx, x = col - y * A.nx;
+    const float* p = A.cube + y * A.row_stride + x;
+    const uint8_t* pm = (A.mask.flags & SPC_MASK_ARRAY) ? A.mask.arr + y * A.mask.row_stride + x : nullptr;
+    float* po = A.out + y * A.out_row_stride + x;
+    const int64_t jb = (int64_t)blockIdx.y * A.jchunk;
+    const int64_t je = min(A.nz_out, jb + A.jchunk);
+    int cur = -2;
+    float ylo = 0.f, yhi = 0.f;
+    for (int64_t j = jb; j < je; ++j) {
+        const int lo = A.lo[j];          // wave-uniform
+        float res;
+        if (lo < 0) {
+            res = A.fill;
+        } else {
+            if (lo != cur) {
+                if (lo == cur + 1) ylo = yhi;
+                else ylo = load_filled(p, pm, A.mask, (int64_t)lo * A.plane_stride, (int64_t)lo * A.mask.plane_stride);
+                yhi = load_filled(p, pm, A.mask, (int64_t)(lo + 1) * A.plane_stride, (int64_t)(lo + 1) * A.mask.plane_stride);
+                cur = lo;
+            }
+            // scipy: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x_new - x_lo) + y_lo
+            const float diff = yhi - ylo;                 // float32 like numpy's f32 - f32
+            res = (float)((double)diff * A.inv_dx[j] * A.t[j] + (double)ylo);
+        }
+        po[j * A.out_plane_stride] = res;
+    }
+}
+
+struct BilArgs {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    MaskDev mask;
+    float fill;
+    int64_t ny_out, nx_out;
+    const double* xs;
+    const double* ys;
+    float* out;
+    int64_t out_row_stride, out_plane_stride;
+    uint8_t* footprint;
+    int64_t zchunk;
+};
+
+__global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
+    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= A.ny_out * A.nx_out) return;
+    const int64_t yo = pix / A.nx_out, xo = pix - yo * A.nx_out;
+    const double xs = A.xs[pix], ys = A.ys[pix];
+    const bool inside = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
+    if (blockIdx.y == 0 && A.footprint) A.footprint[pix] = inside ? 1 : 0;
+    const int64_t zb = (int64_t)blockIdx.y * A.zchunk;
+    const int64_t ze = min(A.nz, zb + A.zchunk);
+    float* po = A.out + yo * A.out_row_stride + xo;
+    if (!inside) {
+        for (int64_t z = zb; z < ze; ++z) po[z * A.out_plane_stride] = NAN;
+        return;
+    }
+    const double xc = fmin(fmax(xs, 0.0), (double)(A.nx - 1));
+    const double yc = fmin(fmax(ys, 0.0), (double)(A.ny - 1));
+    int64_t x0 = (int64_t)floor(xc), y0 = (int64_t)floor(yc);
+    x0 = min(x0, max(A.nx - 2, (int64_t)0));
+    y0 = min(y0, max(A.ny - 2, (int64_t)0));
+    const int64_t x1 = min(x0 + 1, A.nx - 1), y1 = min(y0 + 1, A.ny - 1);
+    const float fx = (float)(xc - (double)x0), fy = (float)(yc - (double)y0);
+    const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
+    const int64_t o00 = y0 * A.row_stride + x0, o01 = y0 * A.row_stride + x1;
+    const int64_t o10 = y1 * A.row_stride + x0, o11 = y1 * A.row_stride + x1;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    const int64_t m00 = y0 * A.mask.row_stride + x0, m01 = y0 * A.mask.row_stride + x1;
+    const int64_t m10 = y1 * A.mask.row_stride + x0, m11 = y1 * A.mask.row_stride + x1;
+    const bool anymask = A.mask.flags != 0;
+    for (int64_t z = zb; z < ze; ++z) {
+        const float* p = A.cube + z * A.plane_stride;
+        float a = p[o00], b = p[o01], c = p[o10], d = p[o11];
+        if (anymask) {
+            const uint8_t* pm = arr ? A.mask.arr + z * A.mask.plane_stride : nullptr;
+            // excluded voxels are replaced by the cube's fill value (spectral_cube.py:2709-2712)
+            bool i0 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, a);
+            bool i1 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, b);
+            bool i2 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
+            bool i3 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, d);
+            if (arr) { i0 = i0 && pm[m00]; i1 = i1 && pm[m01]; i2 = i2 && pm[m10]; i3 = i3 && pm[m11]; }
+            a = i0 ? a : A.fill; b = i1 ? b : A.fill; c = i2 ? c : A.fill; d = i3 ? d : A.fill;
+        }
+        // zero-weight neighbours must not leak NaN/inf (0*NaN) into exact hits
+        float r = 0.f;
+        if (w00 != 0.f) r = fmaf(w00, a, r);
+        if (w01 != 0.f) r = fmaf(w01, b, r);
+        if (w10 != 0.f) r = fmaf(w10, c, r);
+        if (w11 != 0.f) r = fmaf(w11, d, r);
+        po[z * A.out_plane_stride] = r;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                          int64_t nz_out, const int32_t* d_lo, const double* d_t, const double* d_inv_dx,
+                          float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(nz_out > 0, "nz_out must be positive");
+    SPC_REQUIRE(d_lo && d_t && d_inv_dx && d_out, "NULL pointer argument");
+    SPC_REQUIRE(cube->nz >= 2, "need at least 2 input channels");
+    LerpArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.nz_out = nz_out; A.lo = d_lo; A.t = d_t; A.inv_dx = d_inv_dx; A.fill = fill;
+    A.out = d_out;
+    A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
+    const int64_t ncols = cube->ny * cube->nx;
+    const int64_t nblocks = (ncols + 255) / 256;
+    int nsplit = 1;
+    if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, nz_out / 16));
+    A.jchunk = (nz_out + nsplit - 1) / nsplit;
+    nsplit = (int)((nz_out + A.jchunk - 1) / A.jchunk);
+    hipLaunchKernelGGL(spectral_lerp_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0,
+                       (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                              float fill, int64_t ny_out, int64_t nx_out, const double* d_xs,
+                              const double* d_ys, float* d_out, int64_t out_row_stride,
+                              int64_t out_plane_stride, uint8_t* d_footprint) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
+    SPC_REQUIRE(d_xs && d_ys && d_out, "NULL pointer argument");
+    BilArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.fill = fill; A.ny_out = ny_out; A.nx_out = nx_out; A.xs = d_xs; A.ys = d_ys;
+    A.out = d_out;
+    A.out_row_stride = out_row_stride ? out_row_stride : nx_out;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : ny_out * A.out_row_stride;
+    A.footprint = d_footprint;
+    const int64_t npix = ny_out * nx_out;
+    const int64_t nblocks = (npix + 255) / 256;
+    int nsplit = 1;
+    if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, cube->nz / 8));
+    A.zchunk = (cube->nz + nsplit - 1) / nsplit;
+    nsplit = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
+    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0,
+                       (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+}  // extern "C"

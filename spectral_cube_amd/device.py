@@ -1,0 +1,143 @@
+"""HBM buffers, streams and events on top of the C ABI (no torch, no numpy
+device arrays - plain pointers owned by small RAII objects)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class Stream:
+    def __init__(self, device=0):
+        self.device = device
+        h = C.c_void_p()
+        _lib.call("spc_stream_create", device, C.byref(h))
+        self.handle = h
+
+    def synchronize(self):
+        _lib.call("spc_stream_sync", self.device, self.handle)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.call("spc_stream_destroy", self.device, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def _sh(stream):
+    return stream.handle if isinstance(stream, Stream) else stream
+
+
+class Event:
+    def __init__(self, device=0):
+        self.device = device
+        h = C.c_void_p()
+        _lib.call("spc_event_create", device, C.byref(h))
+        self.handle = h
+
+    def record(self, stream=None):
+        _lib.call("spc_event_record", self.device, self.handle, _sh(stream))
+
+    def synchronize(self):
+        _lib.call("spc_event_sync", self.device, self.handle)
+
+    def elapsed_ms(self, later):
+        ms = C.c_float(0)
+        _lib.call("spc_event_elapsed_ms", self.device, self.handle, later.handle, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.call("spc_event_destroy", self.device, self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def synchronize(device=0):
+    _lib.call("spc_device_sync", device)
+
+
+class DeviceArray:
+    """C-contiguous n-d array resident in HBM."""
+
+    def __init__(self, shape, dtype, device=0, ptr=None, owner=None):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape)) if not isinstance(shape, tuple) else tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self._owner = owner          # keeps a parent buffer alive for views
+        self._owns = ptr is None
+        if ptr is None:
+            p = C.c_void_p()
+            _lib.call("spc_malloc", device, max(self.nbytes, 1), C.byref(p))
+            self.ptr = p.value
+        else:
+            self.ptr = int(ptr)
+
+    # ---- construction / transfer ------------------------------------------
+    @classmethod
+    def from_numpy(cls, arr, device=0, stream=None, dtype=None):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        out = cls(a.shape, a.dtype, device)
+        out.upload(a, stream)
+        return out
+
+    @classmethod
+    def zeros(cls, shape, dtype, device=0, stream=None):
+        out = cls(shape, dtype, device)
+        _lib.call("spc_memset", device, C.c_void_p(out.ptr), 0, out.nbytes, _sh(stream))
+        return out
+
+    def upload(self, arr, stream=None):
+        a = np.ascontiguousarray(arr, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError("upload size mismatch: %d vs %d bytes" % (a.nbytes, self.nbytes))
+        _lib.call("spc_memcpy_h2d", self.device, C.c_void_p(self.ptr), a.ctypes.data_as(C.c_void_p),
+                  self.nbytes, _sh(stream))
+        if stream is not None:
+            _lib.call("spc_stream_sync", self.device, _sh(stream))   # `a` may be a temporary
+
+    def get(self, stream=None):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if stream is not None:
+            _lib.call("spc_stream_sync", self.device, _sh(stream))
+        _lib.call("spc_memcpy_d2h", self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                  self.nbytes, None)
+        return out
+
+    def view_rows(self, axis_len_before, start, stop):
+        raise NotImplementedError
+
+    def reshape(self, shape):
+        shape = tuple(int(s) for s in shape)
+        if int(np.prod(shape, dtype=np.int64)) * self.dtype.itemsize != self.nbytes:
+            raise ValueError("cannot reshape")
+        return DeviceArray(shape, self.dtype, self.device, ptr=self.ptr, owner=self)
+
+    def free(self):
+        if self._owns and self.ptr:
+            _lib.call("spc_free", self.device, C.c_void_p(self.ptr))
+        self.ptr = 0
+        self._owner = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s, device=%d, ptr=0x%x)" % (
+            self.shape, self.dtype, self.device, self.ptr or 0)
+
+
+def device_info(device=0):
+    info = _lib.SpcDeviceInfo()
+    _lib.call("spc_get_device_info", device, C.byref(info))
+    return dict(name=info.name.decode(), arch=info.arch.decode(), compute_units=info.compute_units,
+                wavefront_size=info.wavefront_size, total_mem=info.total_mem,
+                free_mem=info.free_mem, clock_khz=info.clock_khz)

@@ -1,0 +1,264 @@
+"""Functional layer over the C ABI: one Python function per entry point of
+include/spcube_hip.h, operating on :class:`DeviceArray` cubes.
+
+Each function names the reference code it stands in for (paths relative to the
+reference tree).  There is no CPU fallback here.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, _sh
+
+
+@dataclass
+class MaskSpec:
+    """Device-evaluable mask (AND of the enabled terms); see SPC_MASK_* in
+    include/spcube_hip.h and spectral_cube/masks.py:105-116, 425-435."""
+    flags: int = 0
+    thr_lo: float = 0.0
+    thr_hi: float = 0.0
+    array: Optional[DeviceArray] = None      # uint8, same shape as the cube
+
+    def to_c(self):
+        m = _lib.SpcMask()
+        m.flags = self.flags
+        m.thr_lo = self.thr_lo
+        m.thr_hi = self.thr_hi
+        if self.flags & _lib.MASK_ARRAY:
+            if self.array is None:
+                raise ValueError("MASK_ARRAY set without an array")
+            m.d_array = self.array.ptr
+        m.row_stride = 0
+        m.plane_stride = 0
+        return m
+
+
+def _cube_c(cube):
+    if cube.dtype != np.float32 or len(cube.shape) != 3:
+        raise TypeError("cube must be a float32 DeviceArray of shape (nz, ny, nx)")
+    c = _lib.SpcCube()
+    c.d_data = cube.ptr
+    c.nz, c.ny, c.nx = cube.shape
+    c.row_stride = cube.shape[2]
+    c.plane_stride = cube.shape[1] * cube.shape[2]
+    return c
+
+
+def _mask_c(mask, cube):
+    if mask is None:
+        mask = MaskSpec()
+    if mask.array is not None:
+        if mask.array.shape != cube.shape or mask.array.dtype.itemsize != 1:
+            raise ValueError("mask array must be 1-byte and match the cube shape")
+    return mask.to_c()
+
+
+def _kern(k):
+    k = np.ascontiguousarray(k, dtype=np.float64).ravel()
+    return k, k.ctypes.data_as(C.POINTER(C.c_double))
+
+
+_WANT_ALL = ("m0", "m1", "m2")
+
+
+def _moment_outputs(shape2d, device, want, out=None):
+    types = dict(m0=np.float64, m1=np.float64, m2=np.float64, mu=np.float64, s0=np.float64,
+                 argmax=np.int64, argmin=np.int64, vmax=np.float32, vmin=np.float32,
+                 nvalid=np.int32)
+    bufs = {}
+    o = _lib.SpcMomentOutputs()
+    for name in want:
+        if name not in types:
+            raise ValueError("unknown moment output %r" % name)
+        if out is not None and name in out:
+            bufs[name] = out[name]
+            if bufs[name].shape != tuple(shape2d) or bufs[name].dtype != np.dtype(types[name]):
+                raise ValueError("preallocated output %r has wrong shape/dtype" % name)
+        else:
+            bufs[name] = DeviceArray(shape2d, types[name], device)
+        setattr(o, "d_" + name, bufs[name].ptr)
+    o.out_row_stride = 0
+    return o, bufs
+
+
+def moments(cube, cen, dv=1.0, m1_add=0.0, mask=None, want=_WANT_ALL, stream=None, workspace=None,
+            out=None):
+    """Fused masked moment 0/1/2 (+argmax/argmin/max/min/count) along axis 0.
+
+    Stands in for DaskSpectralCubeMixin.moment arithmetic
+    (spectral_cube/dask_spectral_cube.py:1083-1104), moment_cubewise /
+    slicewise / raywise (spectral_cube/_moments.py:30-193), allbadtonan
+    (np_compat.py:3-27) and argmax/argmin (spectral_cube.py:793-819).
+
+    cen: DeviceArray of nz float64 = pix_cen[z] - c_ref.  Returns a dict of
+    (ny, nx) DeviceArrays for the names in *want*.
+    """
+    nz, ny, nx = cube.shape
+    if cen.dtype != np.float64 or cen.shape != (nz,):
+        raise TypeError("cen must be a float64 DeviceArray of length nz")
+    o, bufs = _moment_outputs((ny, nx), cube.device, want, out)
+    need = _lib.load().spc_moments_workspace_bytes(nz, ny, nx)
+    ws = workspace
+    if need and (ws is None or ws.nbytes < need):
+        ws = DeviceArray((need,), np.uint8, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_moments_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), C.c_void_p(cen.ptr),
+              float(dv), float(m1_add), C.byref(o), C.c_void_p(ws.ptr if ws is not None else 0),
+              ws.nbytes if ws is not None else 0)
+    bufs["_workspace"] = ws
+    return bufs
+
+
+def moment_order(cube, cen, order, mu, s0, mask=None, stream=None):
+    """sum v*(c-mu)^order / S0 - second pass for order > 2
+    (dask_spectral_cube.py:1094-1099)."""
+    nz, ny, nx = cube.shape
+    out = DeviceArray((ny, nx), np.float64, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_moment_order_f32", cube.device, _sh(stream), C.byref(c), C.byref(m),
+              C.c_void_p(cen.ptr), int(order), C.c_void_p(mu.ptr), C.c_void_p(s0.ptr),
+              C.c_void_p(out.ptr), 0)
+    return out
+
+
+def moments_spatial(cube, cen2d, axis, pix_size, mask=None, want=_WANT_ALL, stream=None):
+    """moment 0/1/2 along a spatial axis (golden tables
+    spectral_cube/tests/test_moments.py:19-49)."""
+    nz, ny, nx = cube.shape
+    if axis not in (1, 2):
+        raise ValueError("axis must be 1 or 2")
+    shape = (nz, nx) if axis == 1 else (nz, ny)
+    bufs = {n: DeviceArray(shape, np.float64, cube.device) for n in want}
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    ptr = lambda n: C.c_void_p(bufs[n].ptr) if n in bufs else None  # noqa: E731
+    _lib.call("spc_moments_spatial_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis),
+              C.c_void_p(cen2d.ptr), float(pix_size), ptr("m0"), ptr("m1"), ptr("m2"))
+    return bufs
+
+
+def spectral_conv(cube, kernel1d, mask=None, out=None, stream=None):
+    """NaN-aware convolution along the spectral axis = chunk function of
+    spectral_smooth (dask_spectral_cube.py:880-917)."""
+    if out is None:
+        out = DeviceArray(cube.shape, np.float32, cube.device)
+    k, kp = _kern(kernel1d)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_spectral_conv_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), kp, len(k),
+              C.c_void_p(out.ptr), 0, 0)
+    return out
+
+
+def spectral_conv_moments(cube, kernel1d, cen, dv=1.0, m1_add=0.0, mask=None, want=_WANT_ALL,
+                          stream=None, out=None):
+    """fused spectral_smooth -> moment (smoothed cube never written)."""
+    nz, ny, nx = cube.shape
+    o, bufs = _moment_outputs((ny, nx), cube.device, want, out)
+    k, kp = _kern(kernel1d)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_spectral_conv_moments_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), kp,
+              len(k), C.c_void_p(cen.ptr), float(dv), float(m1_add), C.byref(o))
+    return bufs
+
+
+def separable_factors(kernel2d, rtol=1e-12):
+    """Return (ky, kx) with outer(ky, kx) == kernel2d, or None."""
+    k = np.asarray(kernel2d, dtype=np.float64)
+    iy, ix = np.unravel_index(np.argmax(np.abs(k)), k.shape)
+    piv = k[iy, ix]
+    if piv == 0:
+        return None
+    ky = k[:, ix].copy()
+    kx = k[iy, :] / piv
+    if np.allclose(np.outer(ky, kx), k, rtol=rtol, atol=rtol * abs(piv)):
+        return ky, kx
+    return None
+
+
+def spatial_conv(cube, kernel2d, mask=None, out=None, stream=None):
+    """NaN-aware per-channel 2-D convolution = chunk function of
+    spatial_smooth (dask_spectral_cube.py:962-993, :540-547)."""
+    if out is None:
+        out = DeviceArray(cube.shape, np.float32, cube.device)
+    k2 = np.ascontiguousarray(kernel2d, dtype=np.float64)
+    if k2.ndim != 2:
+        raise ValueError("kernel must be 2-D")
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    sep = separable_factors(k2)
+    if sep is not None:
+        (ky, kyp), (kx, kxp) = _kern(sep[0]), _kern(sep[1])
+        _lib.call("spc_spatial_conv_sep_f32", cube.device, _sh(stream), C.byref(c), C.byref(m),
+                  kyp, len(ky), kxp, len(kx), C.c_void_p(out.ptr), 0, 0)
+    else:
+        k, kp = _kern(k2)
+        _lib.call("spc_spatial_conv2d_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), kp,
+                  k2.shape[0], k2.shape[1], C.c_void_p(out.ptr), 0, 0)
+    return out
+
+
+def lerp_plan(inaxis, grid, fill_value=None):
+    """Host-side plan for spectral_lerp restating scipy interp1d's index
+    arithmetic (dask_spectral_cube.py:1291-1353).  Returns
+    (lo int32, t float64, inv_dx float64, reverse_in, reverse_out, fill)."""
+    inaxis = np.asarray(inaxis, dtype=np.float64)
+    grid = np.asarray(grid, dtype=np.float64)
+    reverse_in = np.mean(np.diff(inaxis)) < 0
+    reverse_out = np.mean(np.diff(grid)) < 0
+    if reverse_in:
+        inaxis = inaxis[::-1]
+    if reverse_out:
+        grid = grid[::-1]
+    if not (np.all(np.diff(grid) > 0) and np.all(np.diff(inaxis) > 0)):
+        raise AssertionError("spectral axes must be strictly monotonic")
+    np.testing.assert_allclose(np.diff(grid), np.mean(np.diff(grid)),
+                               err_msg="Output grid must be linear")
+    idx = np.clip(np.searchsorted(inaxis, grid), 1, len(inaxis) - 1)
+    lo = (idx - 1).astype(np.int32)
+    t = grid - inaxis[lo]
+    inv_dx = 1.0 / (inaxis[lo + 1] - inaxis[lo])
+    oob = (grid < inaxis[0]) | (grid > inaxis[-1])
+    lo[oob] = -1
+    fill = np.nan if fill_value is None else float(fill_value)
+    return lo, t, inv_dx, bool(reverse_in), bool(reverse_out), fill
+
+
+def spectral_lerp(cube, lo, t, inv_dx, fill=np.nan, mask=None, out=None, stream=None):
+    """per-spaxel linear interpolation onto nz_out channels (chunk function
+    of spectral_interpolate, dask_spectral_cube.py:1342-1353).  *cube* must
+    already be in ascending spectral order."""
+    nz_out = len(lo)
+    dev = cube.device
+    d_lo = DeviceArray.from_numpy(np.asarray(lo, dtype=np.int32), dev)
+    d_t = DeviceArray.from_numpy(np.asarray(t, dtype=np.float64), dev)
+    d_inv = DeviceArray.from_numpy(np.asarray(inv_dx, dtype=np.float64), dev)
+    if out is None:
+        out = DeviceArray((nz_out,) + cube.shape[1:], np.float32, dev)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_spectral_lerp_f32", dev, _sh(stream), C.byref(c), C.byref(m), nz_out,
+              C.c_void_p(d_lo.ptr), C.c_void_p(d_t.ptr), C.c_void_p(d_inv.ptr), float(fill),
+              C.c_void_p(out.ptr), 0, 0)
+    out._plan = (d_lo, d_t, d_inv)     # keep alive until the stream has consumed them
+    return out
+
+
+def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_footprint=True):
+    """bilinear spatial resample of every channel at (xs, ys) source pixel
+    coordinates (resampler of reproject_interp, spectral_cube.py:2726-2732)."""
+    dev = cube.device
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    ys = np.ascontiguousarray(ys, dtype=np.float64)
+    if xs.shape != ys.shape or xs.ndim != 2:
+        raise ValueError("xs, ys must be 2-D maps of identical shape")
+    ny_out, nx_out = xs.shape
+    d_xs, d_ys = DeviceArray.from_numpy(xs, dev), DeviceArray.from_numpy(ys, dev)
+    out = DeviceArray((cube.shape[0], ny_out, nx_out), np.float32, dev)
+    foot = DeviceArray((ny_out, nx_out), np.uint8, dev) if want_footprint else None
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_resample_bilinear_f32", dev, _sh(stream), C.byref(c), C.byref(m), float(fill),
+              ny_out, nx_out, C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr), C.c_void_p(out.ptr), 0, 0,
+              C.c_void_p(foot.ptr) if foot is not None else None)
+    out._plan = (d_xs, d_ys)
+    return out, foot

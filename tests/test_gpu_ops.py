@@ -1,0 +1,273 @@
+"""GPU parity: every C-ABI kernel against the oracle on seeded inputs.
+
+Tolerances: outputs within 1e-5 * scale of the float64
+oracle, NaN patterns identical, integer maps bit-exact.
+"""
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close, golden
+from spectral_cube_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype=None):
+    from spectral_cube_amd.device import DeviceArray
+    return DeviceArray.from_numpy(np.asarray(a), 0, dtype=dtype)
+
+
+def _mspec(include=None, flags=0, lo=0.0, hi=0.0):
+    from spectral_cube_amd import _lib
+    from spectral_cube_amd.ops import MaskSpec
+    if include is not None:
+        return MaskSpec(flags | _lib.MASK_ARRAY, lo, hi, _dev(include.astype(np.uint8)))
+    return MaskSpec(flags, lo, hi, None)
+
+
+def _cube(shape, seed, nan_block=True):
+    d = synth.gaussian_line_cube(shape, seed)
+    if nan_block and shape[1] >= 16 and shape[2] >= 16:
+        synth.add_nan_block(d, 8, 8, 4)
+    return d
+
+
+SHAPES = [(128, 64, 64), (37, 5, 7), (300, 33, 129), (64, 16, 256), (5, 3, 2), (1, 4, 4)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("masked", [False, True])
+def test_moments_vs_oracle(gpu, shape, masked):
+    from spectral_cube_amd import ops
+    nz = shape[0]
+    d = _cube(shape, 100 + nz)
+    inc = synth.boolean_mask(d, 5).astype(bool) if masked else None
+    v = synth.spectral_axis(nz)
+    cen = v - v[0]
+    cref = cen[nz // 2]
+    dv, world0 = 500.0, v[0]
+    r = ops.moments(_dev(d), _dev(cen - cref), dv=dv, m1_add=cref + world0,
+                    mask=_mspec(inc), want=("m0", "m1", "m2", "argmax", "argmin", "nvalid", "vmax", "vmin"))
+    e0, e1, e2 = O.moments012(d, inc, cen, dv, world0)
+    with np.errstate(all="ignore"):
+        assert_close(r["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="m0")
+        assert_close(r["m1"].get(), e1, atol=1e-5 * dv * max(nz, 2), what="m1")
+        # one-pass variance: compare where the ray carries signal
+        m2 = r["m2"].get()
+        assert np.array_equal(np.isnan(m2), np.isnan(e2))
+        okm = np.isfinite(e2)
+        scale = max(np.nanmax(np.abs(e2[okm])) if okm.any() else 1.0, (dv * nz) ** 2 * 1e-3)
+        wc = okm & (np.abs(e0) > 1e-3 * np.nanmax(np.abs(e0)))
+        assert np.all(np.abs(m2[wc] - e2[wc]) <= 1e-5 * scale)
+    assert np.array_equal(r["argmax"].get(), O.argmax(d, inc))
+    assert np.array_equal(r["argmin"].get(), O.argmin(d, inc))
+    f = O.filled(d, inc)
+    assert np.array_equal(r["nvalid"].get(), (~np.isnan(f)).sum(axis=0))
+    with np.errstate(all="ignore"), __import__("warnings").catch_warnings():
+        __import__("warnings").simplefilter("ignore")
+        assert_close(r["vmax"].get(), np.nanmax(f, axis=0), what="vmax")
+        assert_close(r["vmin"].get(), np.nanmin(f, axis=0), what="vmin")
+
+
+def test_moments_golden_c1(gpu):
+    """BASELINE config C1 against the REAL reference's output (Dask class)."""
+    from spectral_cube_amd import _lib, ops
+    g = golden("c1_moments.npz")
+    shape = tuple(g["shape"])
+    d = synth.gaussian_line_cube(shape, int(g["seed"]))
+    synth.add_nan_block(d, 8, 8, 8)
+    assert synth.sha256(d) == str(g["sha256"])
+    inc = np.unpackbits(g["include_packed"])[:d.size].reshape(shape).astype(bool)
+    cen, dv, world0 = g["cen0"], float(g["size0"]), g["world0"]
+    cref = cen[shape[0] // 2]
+    want = ("m0", "m1", "m2", "argmax", "argmin")
+    # (a) materialised boolean mask
+    r = ops.moments(_dev(d), _dev(cen - cref), dv=dv, m1_add=cref + float(world0.flat[0]),
+                    mask=_mspec(inc), want=want)
+    # (b) the same mask evaluated on the fly: LazyMask(x > median) & block mask
+    blk = np.ones(shape, dtype=np.uint8)
+    blk[:, :8, :8] = 0
+    r2 = ops.moments(_dev(d), _dev(cen - cref), dv=dv, m1_add=cref + float(world0.flat[0]),
+                     mask=_mspec(blk.astype(bool), flags=_lib.MASK_GT | _lib.MASK_FINITE, lo=float(g["median"])),
+                     want=want)
+    span = dv * shape[0]
+    for res in (r, r2):
+        assert_close(res["m0"].get(), g["mom0"], atol=1e-5 * np.nanmax(np.abs(g["mom0"])), what="m0")
+        assert_close(res["m1"].get(), g["mom1"], atol=1e-5 * span, what="m1")
+        assert_close(res["m2"].get(), g["mom2"], atol=1e-5 * np.nanmax(np.abs(g["mom2"])), what="m2")
+        assert np.array_equal(res["argmax"].get(), g["argmax"])
+        assert np.array_equal(res["argmin"].get(), g["argmin"])
+
+
+@pytest.mark.parametrize("order", [3, 4])
+def test_moment_order(gpu, order):
+    from spectral_cube_amd import ops
+    shape = (48, 9, 11)
+    d = _cube(shape, 7, nan_block=False)
+    inc = synth.boolean_mask(d, 6).astype(bool)
+    cen = np.arange(48.0) * 2.0
+    r = ops.moments(_dev(d), _dev(cen), mask=_mspec(inc), want=("mu", "s0"))
+    out = ops.moment_order(_dev(d), _dev(cen), order, r["mu"], r["s0"], mask=_mspec(inc)).get()
+    exp = O.moment(d, inc, order, cen, 1.0)
+    with np.errstate(all="ignore"):
+        assert_close(out, exp, rtol=1e-9, atol=1e-9 * np.nanmax(np.abs(exp)), what="order %d" % order)
+
+
+@pytest.mark.parametrize("axis", [1, 2])
+def test_moments_spatial_axes(gpu, axis):
+    from spectral_cube_amd import ops
+    g = golden("moment_cube.npz")
+    d = g["data"].astype(np.float32)
+    for tag, inc in (("u", None), ("m", g["include"])):
+        r = ops.moments_spatial(_dev(d), _dev(g["cen%d" % axis]), axis, float(g["size%d" % axis]),
+                                mask=_mspec(inc))
+        for o, name in enumerate(("m0", "m1", "m2")):
+            exp = g["mom_%s_o%d_a%d" % (tag, o, axis)]
+            with np.errstate(all="ignore"):
+                assert_close(r[name].get(), exp, rtol=1e-6, atol=1e-6 * np.nanmax(np.abs(exp)),
+                             what="%s axis %d %s" % (name, axis, tag))
+    # a bigger seeded cube against the oracle
+    shape = (6, 70, 130)
+    d = _cube(shape, 3)
+    inc = synth.boolean_mask(d, 9).astype(bool)
+    cen = np.cumsum(np.full(shape[1:], 0.01), axis=axis - 1)
+    r = ops.moments_spatial(_dev(d), _dev(cen), axis, 0.01, mask=_mspec(inc))
+    for o, name in enumerate(("m0", "m1", "m2")):
+        exp = O.moment(d, inc, o, cen[None], 0.01, axis=axis)
+        with np.errstate(all="ignore"):
+            assert_close(r[name].get(), exp, rtol=1e-9, atol=1e-7 * np.nanmax(np.abs(exp)), what=name)
+
+
+def _kernels():
+    g = golden("kernels.npz")
+    return {"g1": g["g1_1.000000"], "g4": g["g1_4.000000"], "g0.7": g["g1_0.700000"],
+            "asym": np.array([0.05, 0.1, 0.4, 0.25, 0.15, 0.03, 0.02]),
+            "box5": g["box1_5"], "wide": np.hanning(81) + 0.01, "one": np.array([2.0])}
+
+
+@pytest.mark.parametrize("kname", ["g1", "g4", "g0.7", "asym", "box5", "wide", "one"])
+@pytest.mark.parametrize("shape", [(96, 9, 13), (40, 6, 5), (700, 4, 64)])
+def test_spectral_conv_vs_oracle(gpu, kname, shape):
+    from spectral_cube_amd import ops
+    k = _kernels()[kname]
+    rng = np.random.default_rng(21)
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[3:5, 1, 1] = np.nan
+    d[:, 2, 3] = np.nan
+    inc = rng.random(shape) > 0.3
+    inc[10:10 + len(k) + 3, 4, 4] = False
+    inc[:, 0, 0] = False
+    for m in (None, inc):
+        out = ops.spectral_conv(_dev(d), k, mask=_mspec(m)).get()
+        exp = O.spectral_smooth(d, m, k)
+        assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="spectral conv %s" % kname)
+
+
+def test_spectral_conv_golden(gpu):
+    from spectral_cube_amd import ops
+    g = golden("spectral_smooth.npz")
+    out = ops.spectral_conv(_dev(g["delta522"].astype(np.float32)), g["delta522_k"]).get()
+    assert_close(out, g["delta522_out"], atol=1e-6, what="522 delta")
+    d, inc = g["ss_data"], g["ss_include"]
+    for name in ("g2", "asym"):
+        out = ops.spectral_conv(_dev(d), g["ss_%s_k" % name], mask=_mspec(inc)).get()
+        exp = g["ss_%s_out" % name]
+        assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="ss " + name)
+
+
+@pytest.mark.parametrize("kname", ["g4", "asym", "g1"])
+def test_spectral_conv_moments_fused(gpu, kname):
+    from spectral_cube_amd import ops
+    k = _kernels()[kname]
+    shape = (160, 12, 20)
+    d = _cube(shape, 31, nan_block=False)
+    d[5:9, 3, 3] = np.nan
+    inc = synth.boolean_mask(d, 8).astype(bool)
+    v = synth.spectral_axis(shape[0])
+    cen = v - v[0]
+    cref = cen[shape[0] // 2]
+    for m in (None, inc):
+        sm = O.spectral_smooth(d, m, k)
+        # the smoothed cube carries the ORIGINAL mask (mask staleness)
+        e0, e1, e2 = O.moments012(sm, m, cen, 500.0, v[0])
+        r = ops.spectral_conv_moments(_dev(d), k, _dev(cen - cref), dv=500.0, m1_add=cref + v[0],
+                                      mask=_mspec(m), want=("m0", "m1", "m2", "argmax"))
+        with np.errstate(all="ignore"):
+            assert_close(r["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="fused m0")
+            assert_close(r["m1"].get(), e1, atol=1e-5 * 500.0 * shape[0], what="fused m1")
+            m2 = r["m2"].get()
+            assert np.array_equal(np.isnan(m2), np.isnan(e2))
+            wc = np.isfinite(e2) & (np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0)))
+            assert np.all(np.abs(m2[wc] - e2[wc]) <= 1e-4 * np.nanmax(np.abs(e2[wc])))
+        am = r["argmax"].get()
+        ea = O.argmax(sm, m)
+        # fp32 rounding can flip near-ties between neighbouring channels
+        assert (am != ea).mean() < 0.02
+
+
+@pytest.mark.parametrize("sig", ["3.397288", "1.500000", "0.700000"])
+@pytest.mark.parametrize("shape", [(3, 40, 37), (2, 300, 500), (5, 9, 7)])
+def test_spatial_conv_sep_vs_oracle(gpu, sig, shape):
+    from spectral_cube_amd import ops
+    g = golden("kernels.npz")
+    k2 = g["g2_" + sig]
+    rng = np.random.default_rng(22)
+    d = rng.standard_normal(shape).astype(np.float32)
+    if shape[1] > 30:
+        d[0, 5:9, 5:9] = np.nan
+        d[1, 10:30, 8:30] = np.nan
+    inc = rng.random(shape) > 0.2
+    for m in (None, inc):
+        out = ops.spatial_conv(_dev(d), k2, mask=_mspec(m)).get()
+        exp = O.spatial_smooth(d, m, k2)
+        assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="spatial conv")
+
+
+def test_spatial_conv_golden(gpu):
+    from spectral_cube_amd import ops
+    g = golden("spatial_smooth.npz")
+    adv = g["adv"].astype(np.float32)
+    out = ops.spatial_conv(_dev(adv), g["adv_g2d_k"]).get()
+    np.testing.assert_allclose(out, g["adv_g2d_out"], atol=1e-6)
+    out = ops.spatial_conv(_dev(adv), g["adv_t2d_k"]).get()      # non-separable Tophat
+    np.testing.assert_allclose(out, g["adv_t2d_out"], atol=1e-6)
+    out = ops.spatial_conv(_dev(g["sp_data"]), g["sp_k"], mask=_mspec(g["sp_include"])).get()
+    assert_close(out, g["sp_out"], atol=1e-5 * np.nanmax(np.abs(g["sp_out"])), what="sp golden")
+
+
+def test_spectral_lerp(gpu):
+    from spectral_cube_amd import ops
+    g = golden("spectral_interpolate.npz")
+    d, inc = g["rnd_data"], g["rnd_include"]
+    for grid, exp in ((g["rnd_grid"], g["rnd_out"]), (g["rnd_in"], g["rnd_exact_out"])):
+        lo, t, inv, rin, rout, fill = ops.lerp_plan(g["rnd_in"], grid)
+        assert not rin and not rout
+        out = ops.spectral_lerp(_dev(d), lo, t, inv, fill, mask=_mspec(inc)).get()
+        assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="lerp golden")
+    # bigger seeded case vs oracle, fill_value given
+    shape = (50, 17, 33)
+    d = _cube(shape, 41, nan_block=False)
+    x = synth.spectral_axis(shape[0])
+    grid = np.linspace(x[0] - 700.0, x[-1] + 300.0, 123)
+    lo, t, inv, _, _, fill = ops.lerp_plan(x, grid, fill_value=42)
+    out = ops.spectral_lerp(_dev(d), lo, t, inv, fill).get()
+    exp, _ = O.spectral_interpolate(d, None, x, grid, fill_value=42)
+    assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="lerp oracle")
+
+
+def test_resample_bilinear(gpu):
+    from spectral_cube_amd import ops
+    g = golden("wcs.npz")
+    xs, ys = g["rp_xs"], g["rp_ys"]
+    rng = np.random.default_rng(5)
+    d = rng.standard_normal((4, 48, 40)).astype(np.float32)
+    d[1, 10:12, 10:12] = np.nan
+    out, foot = ops.resample_bilinear(_dev(d), xs, ys)
+    exp, ef = O.resample_bilinear(d, xs, ys)
+    assert_close(out.get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="bilinear")
+    assert np.array_equal(foot.get().astype(bool), ef[0])
+    # identity map reproduces the cube exactly
+    yy, xx = np.mgrid[0:48, 0:40]
+    out, _ = ops.resample_bilinear(_dev(d), xx.astype(float), yy.astype(float))
+    assert_close(out.get(), d, what="identity")
