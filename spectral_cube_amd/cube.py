@@ -1,0 +1,559 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+``SpectralCube`` keeps the reference's method names, argument meaning and
+error behaviour for
+
+    moment / moment0 / moment1 / moment2 / linewidth_sigma / linewidth_fwhm
+    argmax / argmin / max / min (axis=0)
+    spectral_smooth / spatial_smooth / spectral_interpolate / reproject
+    with_mask / with_fill_value / filled_data / spectral_axis
+
+(reference: spectral_cube/spectral_cube.py:1614-1763, 793-819, 2649-2842,
+3186-3332; spectral_cube/dask_spectral_cube.py:880-993, 1031-1132, 1250-1373)
+while every voxel is touched only by the HIP kernels behind the C ABI
+(include/spcube_hip.h).  There is no CPU fallback: without the library or a
+GPU the compute methods raise ``HipLibraryError``.
+
+Differences by design: results of cube->cube operations are
+float32 device-resident cubes (the Dask class keeps float32 too; only
+spectral_interpolate returns float64 there); 2-D maps are float64 like the
+reference; units are plain strings unless astropy is importable; the 1e8-voxel
+``warn_slow`` guard (utils.py:41-75) is not enforced because nothing is
+materialised on the host.
+"""
+import operator
+import warnings
+
+import numpy as np
+
+from . import _lib, masks as M, ops
+from .device import DeviceArray
+from .kernels import kernel_array
+from .wcs import SimpleWCS, pix_cen_spatial, pix_size, reproject_pixel_map
+
+SIGMA2FWHM = 2. * np.sqrt(2. * np.log(2.))      # spectral_cube.py:66
+
+
+class VarianceWarning(UserWarning):
+    pass
+
+
+class SmoothingWarning(UserWarning):
+    pass
+
+
+class UnitsError(ValueError):
+    """stands in for astropy.units.UnitsError"""
+
+
+class BeamUnitsError(Exception):
+    """spectral_cube.utils.BeamUnitsError (base_class.py:134-137)"""
+
+
+_VARIANCE_MSG = ("Note that the second moment returned will be a "
+                 "variance map. To get a linewidth map, use the "
+                 "SpectralCube.linewidth_fwhm() or "
+                 "SpectralCube.linewidth_sigma() methods instead.")
+
+
+def _unit_mul(a, b):
+    a, b = (a or "").strip(), (b or "").strip()
+    return (a + " " + b).strip()
+
+
+def _unit_pow(a, n):
+    a = (a or "").strip()
+    if not a or n == 1:
+        return a
+    return "(%s)%d" % (a, n) if " " in a or "/" in a else "%s%d" % (a, n)
+
+
+class Projection(np.ndarray):
+    """2-D result map (stands in for lower_dimensional_structures.Projection
+    :246-292): an ndarray carrying unit, wcs and meta."""
+
+    def __new__(cls, value, unit="", wcs=None, meta=None):
+        obj = np.asarray(value).view(cls)
+        obj.unit = unit
+        obj.wcs = wcs
+        obj.meta = dict(meta or {})
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is None:
+            return
+        self.unit = getattr(obj, "unit", "")
+        self.wcs = getattr(obj, "wcs", None)
+        self.meta = getattr(obj, "meta", {})
+
+    @property
+    def value(self):
+        return np.asarray(self)
+
+    def quantity(self):
+        """astropy Quantity when astropy is importable."""
+        from astropy import units as u
+        return u.Quantity(np.asarray(self), u.Unit(self.unit))
+
+
+class SpectralCube:
+    """(nz, ny, nx) float32 cube with a lazily lowered mask, device resident."""
+
+    def __init__(self, data=None, wcs=None, mask=None, meta=None, fill_value=np.nan,
+                 header=None, unit=None, device=0, allow_huge_operations=False, _dev=None,
+                 _lazy=None, _shape=None, _data_id=None):
+        if data is None and _dev is None and _lazy is None:
+            raise ValueError("data is required")
+        if data is not None:
+            data = np.asarray(data)
+            if data.ndim != 3:
+                raise ValueError("SpectralCube needs a 3-D (spectral, y, x) array")
+        self._data = data                 # host ndarray or None
+        self._dev = _dev                  # DeviceArray float32 or None
+        self._lazy = _lazy                # pending (op, parent, args) - see spectral_smooth
+        self._shape = tuple(data.shape) if data is not None else (
+            tuple(_dev.shape) if _dev is not None else tuple(_shape))
+        if wcs is None and header is not None:
+            wcs = SimpleWCS(header)
+        elif wcs is not None and not isinstance(wcs, SimpleWCS):
+            wcs = SimpleWCS(wcs)
+        self._wcs = wcs
+        self._header = dict(wcs.header) if wcs is not None else {}
+        self._mask = mask
+        self._meta = dict(meta or {})
+        self._fill_value = fill_value
+        if unit is None:
+            unit = str(self._header.get("BUNIT", "")).strip()
+        self._unit = unit
+        self.device = device
+        self.allow_huge_operations = allow_huge_operations
+        self._mask_cache = None
+        self._cen_cache = {}
+        # cubes that share the same voxel values (with_mask, with_fill_value) share
+        # this token; lazy masks use it to decide whether their predicate may be
+        # evaluated by the kernel on the data it is reading
+        self._data_id = _data_id if _data_id is not None else object()
+
+    # ---- construction helpers ------------------------------------------------
+    @classmethod
+    def read(cls, data, header, device=0, **kw):
+        """In-memory analogue of ``SpectralCube.read(hdu)``: like the FITS
+        reader (spectral_cube/io/fits.py:214) it attaches
+        ``LazyMask(np.isfinite)``."""
+        cube = cls(np.asarray(data), header=header, device=device, **kw)
+        cube._mask = M.LazyMask(np.isfinite, cube=cube)
+        return cube
+
+    @classmethod
+    def from_device(cls, dev, wcs=None, header=None, mask=None, **kw):
+        if dev.dtype != np.float32 or len(dev.shape) != 3:
+            raise TypeError("device cube must be float32 (nz, ny, nx)")
+        return cls(None, wcs=wcs, header=header, mask=mask, device=dev.device, _dev=dev, **kw)
+
+    def _new_cube_with(self, data=None, dev=None, wcs=None, mask=None, meta=None, fill_value=None,
+                       lazy=None, shape=None, unit=None, same_data=False):
+        return SpectralCube(data, wcs=self._wcs if wcs is None else wcs,
+                            mask=self._mask if mask is None else mask,
+                            meta=self._meta if meta is None else meta,
+                            fill_value=self._fill_value if fill_value is None else fill_value,
+                            unit=self._unit if unit is None else unit, device=self.device,
+                            allow_huge_operations=self.allow_huge_operations, _dev=dev,
+                            _lazy=lazy, _shape=shape, _data_id=self._data_id if same_data else None)
+
+    # ---- identity used by lazy masks -------------------------------------------
+    def _host_data(self):
+        if self._data is None:
+            self._data = self._device_data().get()
+        return self._data
+
+    def _is_same_data(self, data):
+        return getattr(data, "_data_id", None) is self._data_id
+
+    # ---- basic properties --------------------------------------------------------
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def ndim(self):
+        return 3
+
+    @property
+    def size(self):
+        return int(np.prod(self._shape, dtype=np.int64))
+
+    @property
+    def unit(self):
+        return self._unit
+
+    @property
+    def wcs(self):
+        return self._wcs
+
+    @property
+    def header(self):
+        return self._header
+
+    @property
+    def meta(self):
+        return self._meta
+
+    @property
+    def mask(self):
+        return self._mask
+
+    @property
+    def fill_value(self):
+        return self._fill_value
+
+    @property
+    def spectral_axis(self):
+        """world coordinate of every channel, in CUNIT3 (base_class.py:276-281)."""
+        return self._wcs.spectral_pix2world(np.arange(self._shape[0]))
+
+    @property
+    def spectral_unit(self):
+        return self._wcs.spectral_unit if self._wcs is not None else ""
+
+    def with_mask(self, mask, inherit_mask=True):
+        """spectral_cube.py:1390-1441: AND the new mask with the existing one."""
+        if isinstance(mask, np.ndarray):
+            np.broadcast_shapes(mask.shape, self._shape)
+            mask = M.BooleanArrayMask(mask, self._wcs, shape=self._shape)
+        if self._mask is not None and inherit_mask:
+            mask = self._mask & mask
+        out = self._new_cube_with(data=self._data, dev=self._dev, mask=mask, lazy=self._lazy,
+                                  shape=self._shape, same_data=True)
+        return out
+
+    def with_fill_value(self, fill_value):
+        out = self._new_cube_with(data=self._data, dev=self._dev, fill_value=fill_value,
+                                  lazy=self._lazy, shape=self._shape, same_data=True)
+        out._mask_cache = self._mask_cache
+        return out
+
+    def _cmp(self, op, value):
+        value = getattr(value, "value", value)
+        return M.LazyComparisonMask(op, value, cube=self)
+
+    def __gt__(self, value):
+        return self._cmp(operator.gt, value)
+
+    def __ge__(self, value):
+        return self._cmp(operator.ge, value)
+
+    def __lt__(self, value):
+        return self._cmp(operator.lt, value)
+
+    def __le__(self, value):
+        return self._cmp(operator.le, value)
+
+    # ---- data access -----------------------------------------------------------------
+    def _device_data(self):
+        """float32 DeviceArray of the cube values (uploads / materialises lazily)."""
+        if self._dev is None:
+            if self._lazy is not None:
+                self._dev = self._lazy()
+                self._lazy = None
+            else:
+                _lib.require_gpu()
+                self._dev = DeviceArray.from_numpy(self._data, self.device, dtype=np.float32)
+        return self._dev
+
+    def _mask_spec(self):
+        """lower the mask tree once and keep the uint8 array resident in HBM."""
+        if self._mask_cache is None:
+            flags, lo, hi, arr = M.lower_mask(self._mask, self, self._shape)
+            darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
+            self._mask_cache = ops.MaskSpec(flags, lo, hi, darr)
+        return self._mask_cache
+
+    @property
+    def filled_data(self):
+        """host copy with excluded voxels replaced by fill_value
+        (base_class.py:389-417 / masks.py:197-237)."""
+        d = self._host_data()
+        if self._mask is None:
+            return d
+        return self._mask._filled(d, fill=self._fill_value)
+
+    unitless_filled_data = filled_data
+
+    @property
+    def unmasked_data(self):
+        return self._host_data()
+
+    # ---- coordinates fed to the kernels -------------------
+    def _pix_size_slice(self, axis):
+        return pix_size(self._wcs, axis)
+
+    def _pix_cen_axis(self, axis):
+        if axis not in self._cen_cache:
+            if axis == 0:
+                spec = self.spectral_axis
+                self._cen_cache[0] = spec - spec[0]          # spectral_cube.py:1473-1475
+            else:
+                y, x = pix_cen_spatial(self._wcs, self._shape)
+                self._cen_cache[1], self._cen_cache[2] = y, x
+        return self._cen_cache[axis]
+
+    # ---- moments -----------------------------------------------------------------------
+    def _moment_device(self, want, fused_kernel=None):
+        nz = self._shape[0]
+        cen = self._pix_cen_axis(0)
+        cref = cen[nz // 2]
+        spec0 = self.spectral_axis[0]
+        d_cen = DeviceArray.from_numpy(cen - cref, self.device)
+        dv = self._pix_size_slice(0)
+        if fused_kernel is not None:
+            parent, karr = fused_kernel
+            return ops.spectral_conv_moments(parent._device_data(), karr, d_cen, dv=dv,
+                                             m1_add=cref + spec0, mask=parent._mask_spec(), want=want)
+        return ops.moments(self._device_data(), d_cen, dv=dv, m1_add=cref + spec0,
+                           mask=self._mask_spec(), want=want)
+
+    def _fusable(self):
+        """pending spectral_smooth whose parent shares this cube's mask object:
+        smooth -> moment can run fused (dask_spectral_cube.py:836-840 keeps the
+        original mask, so the semantics are identical)."""
+        lz = self._lazy
+        if (lz is not None and getattr(lz, "op", None) == "spectral_smooth" and self._dev is None
+                and lz.parent._mask is self._mask and lz.fusable):
+            return (lz.parent, lz.kernel)
+        return None
+
+    def moment(self, order=0, axis=0, how="auto", **kwargs):
+        """Compute moments along an axis (spectral_cube.py:1614-1720;
+        dask_spectral_cube.py:1031-1132).  ``how`` is accepted for interface
+        compatibility; every strategy maps onto the same one-pass HIP kernel."""
+        if how not in ("auto", "cube", "slice", "ray"):
+            raise ValueError("Invalid how. Must be in %r" % sorted(["auto", "cube", "slice", "ray"]))
+        if axis not in (0, 1, 2):
+            raise ValueError("Cubes have 3 axes.")
+        order = int(order)
+        if order < 0:
+            raise ValueError("order must be >= 0")
+        if axis == 0 and order == 2:
+            warnings.warn(_VARIANCE_MSG, VarianceWarning)
+        if axis == 0:
+            key = {0: "m0", 1: "m1", 2: "m2"}.get(order)
+            if key is not None:
+                out = self._moment_device((key,), self._fusable())[key].get()
+            else:
+                r = self._moment_device(("mu", "s0"))
+                cen = self._pix_cen_axis(0)
+                cref = cen[self._shape[0] // 2]
+                d_cen = DeviceArray.from_numpy(cen - cref, self.device)
+                out = ops.moment_order(self._device_data(), d_cen, order, r["mu"], r["s0"],
+                                       mask=self._mask_spec()).get()
+                # dv cancels: sum(I dv (c-M1)^N) / sum(I dv)
+            axunit = self.spectral_unit
+        else:
+            cen = self._pix_cen_axis(axis)
+            d_cen = DeviceArray.from_numpy(cen, self.device)
+            size = self._pix_size_slice(axis)
+            key = {0: "m0", 1: "m1", 2: "m2"}.get(order)
+            if key is None:
+                raise NotImplementedError("moments of order > 2 along spatial axes are not built yet")
+            out = ops.moments_spatial(self._device_data(), d_cen, axis, size, mask=self._mask_spec(),
+                                      want=(key,))[key].get()
+            axunit = self._wcs.cunit[2 - axis] if self._wcs is not None else ""
+        if order == 0:
+            unit = _unit_mul(self._unit, axunit)
+        else:
+            unit = _unit_pow(axunit, max(order, 1))
+        meta = {"moment_order": order, "moment_axis": axis}
+        meta.update(self._meta)
+        new_wcs = self._wcs.drop_spectral() if (self._wcs is not None and axis == 0) else None
+        return Projection(out, unit=unit, wcs=new_wcs, meta=meta)
+
+    def moment0(self, axis=0, how="auto"):
+        return self.moment(axis=axis, order=0, how=how)
+
+    def moment1(self, axis=0, how="auto"):
+        return self.moment(axis=axis, order=1, how=how)
+
+    def moment2(self, axis=0, how="auto"):
+        return self.moment(axis=axis, order=2, how=how)
+
+    def moments012(self, keep_on_device=False):
+        """moment 0, 1 and 2 along the spectral axis from ONE pass over the cube
+        (the reference needs three graph executions, dask_spectral_cube.py
+        :1090,1097,1104)."""
+        r = self._moment_device(("m0", "m1", "m2"), self._fusable())
+        if keep_on_device:
+            return r["m0"], r["m1"], r["m2"]
+        return tuple(self._wrap0(r[k].get(), o) for o, k in enumerate(("m0", "m1", "m2")))
+
+    def _wrap0(self, arr, order):
+        unit = _unit_mul(self._unit, self.spectral_unit) if order == 0 else _unit_pow(self.spectral_unit, max(order, 1))
+        meta = {"moment_order": order, "moment_axis": 0}
+        meta.update(self._meta)
+        return Projection(arr, unit=unit, wcs=self._wcs.drop_spectral() if self._wcs is not None else None,
+                          meta=meta)
+
+    def linewidth_sigma(self, how="auto"):
+        """sqrt(moment 2), no VarianceWarning (spectral_cube.py:1746-1753)."""
+        with np.errstate(invalid="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore", VarianceWarning)
+            m2 = self.moment(order=2, axis=0, how=how)
+            out = np.sqrt(m2)
+        return Projection(out, unit=self.spectral_unit, wcs=m2.wcs, meta=m2.meta)
+
+    def linewidth_fwhm(self, how="auto"):
+        """linewidth_sigma * sqrt(8 ln 2) (spectral_cube.py:1755-1763)."""
+        s = self.linewidth_sigma(how=how)
+        return Projection(np.asarray(s) * SIGMA2FWHM, unit=s.unit, wcs=s.wcs, meta=s.meta)
+
+    def _extremum(self, key, axis, how):
+        if axis != 0:
+            raise NotImplementedError("only the spectral axis is built on the GPU path")
+        return self._moment_device((key,))[key].get()
+
+    def argmax(self, axis=0, how="auto", **kwargs):
+        """index of the maximum along the spectral axis (spectral_cube.py:793-804);
+        first index on ties, 0 for fully masked rays; int64."""
+        return self._extremum("argmax", axis, how)
+
+    def argmin(self, axis=0, how="auto", **kwargs):
+        return self._extremum("argmin", axis, how)
+
+    def max(self, axis=0, how="auto", **kwargs):
+        return Projection(self._extremum("vmax", axis, how), unit=self._unit)
+
+    def min(self, axis=0, how="auto", **kwargs):
+        return Projection(self._extremum("vmin", axis, how), unit=self._unit)
+
+    # ---- smoothing ---------------------------------------------------------------------------
+    def spectral_smooth(self, kernel, convolve=None, **kwargs):
+        """Smooth along the spectral axis; the mask is left unchanged
+        (dask_spectral_cube.py:880-917).  Lazy like the Dask class: a following
+        ``moment`` runs fused with the stencil, any other access materialises."""
+        karr = kernel_array(kernel, 1)
+        if convolve is not None:
+            raise NotImplementedError("custom `convolve` callables cannot run on the device; "
+                                      "the HIP stencil implements astropy.convolution.convolve")
+        parent = self
+
+        class _Lazy:
+            op = "spectral_smooth"
+            fusable = len(karr) <= 65
+
+            def __init__(self):
+                self.parent, self.kernel = parent, karr
+
+            def __call__(self):
+                return ops.spectral_conv(parent._device_data(), karr, mask=parent._mask_spec())
+
+        return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
+
+    def spatial_smooth(self, kernel, convolve=None, raise_error_jybm=True, **kwargs):
+        """Smooth every channel with a 2-D kernel (dask_spectral_cube.py:962-993)."""
+        self.check_jybeam_smoothing(raise_error_jybm=raise_error_jybm)
+        karr = kernel_array(kernel, 2)
+        if convolve is not None:
+            raise NotImplementedError("custom `convolve` callables cannot run on the device")
+        parent = self
+
+        class _Lazy:
+            op = "spatial_smooth"
+            fusable = False
+
+            def __call__(self):
+                return ops.spatial_conv(parent._device_data(), karr, mask=parent._mask_spec())
+
+        return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
+
+    def check_jybeam_smoothing(self, raise_error_jybm=True):
+        """base_class.py:116-140"""
+        if str(self._unit).replace(" ", "").upper() in ("JY/BEAM", "JYBEAM-1", "JY/BM"):
+            if raise_error_jybm:
+                raise BeamUnitsError("Attempting to change the spatial resolution of a cube with "
+                                     "Jy/beam units. To ignore this error, set "
+                                     "`raise_error_jybm=False`.")
+
+    # ---- regridding -----------------------------------------------------------------------------
+    def spectral_interpolate(self, spectral_grid, suppress_smooth_warning=False, fill_value=None,
+                             force_rechunk=True):
+        """Resample onto a linear spectral grid, Dask semantics
+        (dask_spectral_cube.py:1250-1373): NaN outside the input range (or
+        ``fill_value``), NaN when either bracketing channel is NaN/masked,
+        new mask = ~isnan(result)."""
+        grid = np.asarray(getattr(spectral_grid, "value", spectral_grid), dtype=np.float64)
+        inaxis = self.spectral_axis
+        lo, t, inv_dx, rin, rout, fill = ops.lerp_plan(inaxis, grid, fill_value)
+        g_sorted = grid[::-1] if rout else grid
+        in_sorted = inaxis[::-1] if rin else inaxis
+        indiff = np.mean(np.diff(in_sorted))
+        outdiff = np.mean(np.diff(g_sorted))
+        if outdiff > 2 * indiff and not suppress_smooth_warning:
+            warnings.warn("Input grid has too small a spacing. The data should "
+                          "be smoothed prior to resampling.", SmoothingWarning)
+        nz = self._shape[0]
+        if rin:          # cubedata[::-1]: channel k of the flipped cube is nz-1-k
+            lo_dev = np.where(lo >= 0, nz - 2 - lo, -1).astype(np.int32)
+            # bracketing pair (lo, lo+1) of the flipped axis = (nz-1-lo, nz-2-lo) here:
+            # interpolate from the upper neighbour downwards
+            t_dev = (in_sorted[np.clip(lo, 0, nz - 2) + 1] - g_sorted)
+            plan = (lo_dev, np.where(lo >= 0, t_dev, 0.0), inv_dx)
+        else:
+            plan = (lo, t, inv_dx)
+        if rout:
+            plan = tuple(p[::-1].copy() for p in plan)
+        parent = self
+
+        def run():
+            return ops.spectral_lerp(parent._device_data(), plan[0], plan[1], plan[2], fill,
+                                     mask=parent._mask_spec())
+
+        crval = g_sorted[0] if not rout else g_sorted[-1]
+        cdelt = outdiff if not rout else -outdiff
+        newwcs = self._wcs.with_spectral(crval, cdelt, 1.0)
+        out = self._new_cube_with(lazy=_Thunk(run), shape=(len(grid),) + self._shape[1:], wcs=newwcs,
+                                  mask=False)
+        out._mask = M.NotNaNMask(out)
+        return out
+
+    def reproject(self, header, order="bilinear", use_memmap=False, filled=True, **kwargs):
+        """Spatially reproject onto the celestial WCS of *header*
+        (spectral_cube.py:2649-2746).  Bilinear only; the pixel map comes from
+        this package's WCS (validated against astropy.wcs)."""
+        if order not in ("bilinear", 1):
+            raise NotImplementedError("only order='bilinear' is built on the GPU path")
+        newwcs = header if isinstance(header, SimpleWCS) else SimpleWCS(header)
+        hdr = newwcs.header
+        if "NAXIS1" in hdr and "NAXIS2" in hdr:
+            ny_out, nx_out = int(hdr["NAXIS2"]), int(hdr["NAXIS1"])
+        else:
+            ny_out, nx_out = self._shape[1:]
+        xs, ys = reproject_pixel_map(self._wcs, newwcs, (ny_out, nx_out))
+        xs = np.where(np.isfinite(xs), xs, -1e30)
+        ys = np.where(np.isfinite(ys), ys, -1e30)
+        mask = self._mask_spec() if filled else None
+        dev, foot = ops.resample_bilinear(self._device_data(), xs, ys, fill=float(self._fill_value),
+                                          mask=mask)
+        footprint = foot.get().astype(bool)
+        if not footprint.any():
+            raise ValueError("All values in reprojected cube are nan.  This can be caused"
+                             " by an error in which coordinates do not 'round-trip'.  Try "
+                             "setting ``roundtrip_coords=False``.  You might also check "
+                             "whether the WCS transformation produces valid pixel->world "
+                             "and world->pixel coordinates in each axis.")
+        out = self._new_cube_with(dev=dev, wcs=newwcs, mask=False, shape=dev.shape)
+        out._mask = M.BooleanArrayMask(footprint[None], newwcs, shape=dev.shape)
+        out._footprint = footprint
+        return out
+
+    def __repr__(self):
+        return "SpectralCube(hip) with shape=%s%s" % (self._shape, " and unit=%s" % self._unit if self._unit else "")
+
+
+class _Thunk:
+    op = "thunk"
+    fusable = False
+
+    def __init__(self, fn):
+        self._fn = fn
+
+    def __call__(self):
+        return self._fn()

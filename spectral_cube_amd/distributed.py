@@ -1,0 +1,146 @@
+"""Multi-GPU driver: (y, x) row-strip sharding + one all-gather of the 2-D map.
+
+Every row of SURVEY.md section 8(a) is independent per spaxel, so a cube
+shards over contiguous row strips ``(nz, ny/G, nx)`` - one process per GPU, no
+collective on the data path.  The only exchange is the stitch of the final
+2-D map strips: ONE all-gather (RCCL over xGMI on GPUs; a gloo all-gather of
+host arrays in the CPU tests).  The reference has no counterpart (its
+parallelism is dask chunking, dask_spectral_cube.py:259-312).
+
+torch.distributed is used here only as the rendezvous / bootstrap plumbing the
+launcher (`python -m torch.distributed.run`) already provides; the RCCL calls
+themselves go through the C ABI (spc_comm_init / spc_allgather_rows).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, _sh
+
+
+def strip_bounds(ny, world_size, rank):
+    """Rows [y0, y1) owned by *rank*: equal strips of ceil(ny/world) rows, the
+    last ones possibly short/empty (the gather pads them)."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank %d / world %d" % (rank, world_size))
+    rows = -(-ny // world_size)
+    y0 = min(ny, rank * rows)
+    y1 = min(ny, y0 + rows)
+    return y0, y1
+
+
+def strip_rows(ny, world_size):
+    return -(-ny // world_size)
+
+
+class HostGatherComm:
+    """all-gather of host strips through torch.distributed (gloo).  Used by the
+    world_size-2 CPU tests and as the loud, explicitly reported stitch fallback
+    of bench.py when RCCL cannot initialise."""
+
+    kind = "gloo-host"
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+
+    def allgather_rows(self, strip, ny_total):
+        import torch
+        strip = np.ascontiguousarray(strip)
+        rows = strip_rows(ny_total, self.world_size)
+        pad = np.full((rows,) + strip.shape[1:], np.nan if strip.dtype.kind == "f" else 0, dtype=strip.dtype)
+        pad[:strip.shape[0]] = strip
+        t = torch.from_numpy(pad)
+        outs = [torch.empty_like(t) for _ in range(self.world_size)]
+        self._dist.all_gather(outs, t, group=self.group)
+        full = np.concatenate([o.numpy() for o in outs], axis=0)
+        return full[:ny_total]
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+
+class RcclComm:
+    """device all-gather through libspcube_hip.so -> RCCL (xGMI)."""
+
+    kind = "rccl"
+
+    def __init__(self, device, rank, world_size, bcast_bytes):
+        """bcast_bytes(payload_or_None) -> bytes: broadcast rank 0's payload to
+        all ranks (any host mechanism: torch.distributed, a shared file...)."""
+        self.device, self.rank, self.world_size = device, rank, world_size
+        ident = None
+        if rank == 0:
+            buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+            _lib.call("spc_comm_unique_id", buf)
+            ident = bytes(buf)
+        ident = bcast_bytes(ident)
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(ident)
+        h = C.c_void_p()
+        _lib.call("spc_comm_init", device, buf, world_size, rank, C.byref(h))
+        self._h = h
+
+    def allgather_rows_device(self, strip_dev, recv_dev, stream=None):
+        """strip_dev: (rows, nx) DeviceArray, identical shape on every rank;
+        recv_dev: (world*rows, nx)."""
+        if recv_dev.nbytes != strip_dev.nbytes * self.world_size:
+            raise ValueError("receive buffer must hold world_size strips")
+        _lib.call("spc_allgather_rows", self._h, _sh(stream), C.c_void_p(strip_dev.ptr),
+                  C.c_void_p(recv_dev.ptr), strip_dev.nbytes)
+        return recv_dev
+
+    def allgather_rows(self, strip_dev, ny_total, stream=None):
+        rows = strip_rows(ny_total, self.world_size)
+        if strip_dev.shape[0] != rows:
+            raise ValueError("RcclComm needs equal strips (pad the last rank to %d rows)" % rows)
+        recv = DeviceArray((rows * self.world_size,) + tuple(strip_dev.shape[1:]), strip_dev.dtype, self.device)
+        self.allgather_rows_device(strip_dev, recv, stream)
+        return recv
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.call("spc_comm_destroy", self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def torch_bcast_bytes(group=None):
+    """bootstrap helper: broadcast bytes from rank 0 over torch.distributed."""
+    import torch.distributed as dist
+
+    def bcast(payload):
+        obj = [payload]
+        dist.broadcast_object_list(obj, src=0, group=group)
+        return obj[0]
+    return bcast
+
+
+def sharded_moments(strip_cube, ny_total, comm, orders=(0, 1, 2)):
+    """moment maps of a cube sharded by row strips: every rank computes the
+    maps of ITS strip with the fused HIP kernel, then one all-gather stitches
+    them.  Returns {order: (ny_total, nx) float64 ndarray} on every rank."""
+    keys = {0: "m0", 1: "m1", 2: "m2"}
+    want = tuple(keys[o] for o in orders)
+    r = strip_cube._moment_device(want)
+    out = {}
+    for o in orders:
+        strip = r[keys[o]]
+        if isinstance(comm, RcclComm):
+            rows = strip_rows(ny_total, comm.world_size)
+            if strip.shape[0] != rows:       # pad a short last strip on the host
+                padded = np.full((rows, strip.shape[1]), np.nan)
+                padded[:strip.shape[0]] = strip.get()
+                strip = DeviceArray.from_numpy(padded, strip.device)
+            out[o] = comm.allgather_rows(strip, ny_total).get()[:ny_total]
+        else:
+            out[o] = comm.allgather_rows(strip.get() if isinstance(strip, DeviceArray) else strip, ny_total)
+    return out

@@ -1,0 +1,308 @@
+"""Minimal FITS WCS for the hot path (pure numpy; astropy is not required on
+the GPU box).
+
+Covers what the kernels' host-side inputs need:
+a LINEAR spectral axis and a celestial pair with CDELT / PCi_j / CDi_j /
+CROTA2 linear part and a zenithal (TAN, SIN, ARC, STG, ZEA) or CAR
+projection (FITS WCS paper II).  Validated against astropy.wcs through the
+committed vectors in tests/golden/wcs.npz.
+
+It stands in for the astropy.wcs calls made by
+``spectral_cube/base_class.py:178-241`` (world), ``spectral_cube.py:1455-1535``
+(_pix_cen, _pix_size_slice) and ``wcs_utils.py:28-45`` (drop_axis).
+"""
+import copy
+
+import numpy as np
+
+_D2R = np.pi / 180.0
+_R2D = 180.0 / np.pi
+_ZENITHAL = ("TAN", "SIN", "ARC", "STG", "ZEA")
+
+
+def parse_header(header):
+    """Accept a dict-like, an astropy Header, or FITS header text (80-char
+    cards or newline separated ``KEY = value / comment`` lines)."""
+    if header is None:
+        return {}
+    if isinstance(header, SimpleWCS):
+        return dict(header.header)
+    if hasattr(header, "keys") and not isinstance(header, str):
+        return {str(k).upper(): header[k] for k in header.keys() if k not in ("", "COMMENT", "HISTORY")}
+    text = str(header)
+    if "\n" in text:
+        cards = text.split("\n")
+    else:
+        cards = [text[i:i + 80] for i in range(0, len(text), 80)]
+    out = {}
+    for card in cards:
+        if "=" not in card[:10] and "=" not in card.split("/")[0]:
+            continue
+        key, _, rest = card.partition("=")
+        key = key.strip().upper()
+        if not key or key in ("COMMENT", "HISTORY", "END"):
+            continue
+        rest = rest.strip()
+        if rest.startswith("'"):
+            end = rest.find("'", 1)
+            val = rest[1:end].strip() if end > 0 else rest[1:].strip()
+        else:
+            val = rest.split("/")[0].strip()
+            if val in ("T", "F"):
+                val = (val == "T")
+            else:
+                try:
+                    val = int(val)
+                except ValueError:
+                    try:
+                        val = float(val.replace("D", "E"))
+                    except ValueError:
+                        pass
+        out[key] = val
+    return out
+
+
+class SimpleWCS:
+    """3-axis (x, y, spectral) or 2-axis (x, y) FITS WCS."""
+
+    def __init__(self, header=None, naxis=None):
+        h = parse_header(header)
+        self.header = h
+        n = int(naxis or h.get("WCSAXES", h.get("NAXIS", 3)))
+        self.naxis = n = min(n, 3)
+        g = h.get
+        self.ctype = [str(g("CTYPE%d" % (i + 1), "")) for i in range(n)]
+        self.cunit = [str(g("CUNIT%d" % (i + 1), "")).strip() for i in range(n)]
+        self.crval = np.array([float(g("CRVAL%d" % (i + 1), 0.0)) for i in range(n)])
+        self.crpix = np.array([float(g("CRPIX%d" % (i + 1), 0.0)) for i in range(n)])
+        self.cdelt = np.array([float(g("CDELT%d" % (i + 1), 1.0)) for i in range(n)])
+        pc = np.eye(n)
+        has_cd = any(("CD%d_%d" % (i + 1, j + 1)) in h for i in range(n) for j in range(n))
+        if has_cd:
+            cd = np.zeros((n, n))
+            for i in range(n):
+                for j in range(n):
+                    cd[i, j] = float(g("CD%d_%d" % (i + 1, j + 1), 0.0))
+            self.cdelt = np.ones(n)
+            pc = cd
+        else:
+            for i in range(n):
+                for j in range(n):
+                    pc[i, j] = float(g("PC%d_%d" % (i + 1, j + 1), g("PC%03d%03d" % (i + 1, j + 1), pc[i, j])))
+            if "CROTA2" in h and not any(k.startswith("PC") for k in h):
+                rho = float(h["CROTA2"]) * _D2R
+                lam = self.cdelt[1] / self.cdelt[0]
+                pc[0, 0], pc[0, 1] = np.cos(rho), -lam * np.sin(rho)
+                pc[1, 0], pc[1, 1] = np.sin(rho) / lam, np.cos(rho)
+        self.pc = pc
+        self.shape_hint = tuple(int(g("NAXIS%d" % (i + 1), 0)) for i in range(n))[::-1]
+        self.proj = self.ctype[0][5:8] if len(self.ctype[0]) >= 8 else ""
+        if self.proj and self.proj not in _ZENITHAL + ("CAR",):
+            raise NotImplementedError("projection %r not supported by SimpleWCS" % self.proj)
+        self.lonpole = g("LONPOLE", None)
+        self.latpole = float(g("LATPOLE", 90.0))
+        for i in (0, 1):
+            if i < n and self.cunit[i] not in ("", "deg"):
+                raise NotImplementedError("celestial CUNIT must be deg")
+        self._setup_pole()
+
+    # -- FITS paper II section 2.4: celestial coordinates of the native pole
+    def _setup_pole(self):
+        if self.naxis < 2 or not self.proj:
+            return
+        a0, d0 = self.crval[0] * _D2R, self.crval[1] * _D2R
+        th0 = (90.0 if self.proj in _ZENITHAL else 0.0) * _D2R
+        ph0 = 0.0
+        if self.lonpole is None:
+            lonpole = 0.0 if d0 >= th0 else 180.0
+        else:
+            lonpole = float(self.lonpole)
+        php = lonpole * _D2R
+        if abs(th0 - np.pi / 2) < 1e-12:
+            ap, dp = a0, d0
+        else:
+            ct0, st0 = np.cos(th0), np.sin(th0)
+            dphi = php - ph0
+            base = np.arctan2(st0, ct0 * np.cos(dphi))
+            den = np.sqrt(1.0 - (ct0 * np.sin(dphi)) ** 2)
+            arg = np.clip(np.sin(d0) / den, -1.0, 1.0)
+            cands = [base + np.arccos(arg), base - np.arccos(arg)]
+            cands = [c for c in cands if -np.pi / 2 - 1e-12 <= c <= np.pi / 2 + 1e-12]
+            if not cands:
+                raise ValueError("invalid LONPOLE/LATPOLE for this header")
+            dp = min(cands, key=lambda c: abs(c - self.latpole * _D2R))
+            if abs(abs(dp) - np.pi / 2) < 1e-12:
+                ap = a0 + (dphi - np.pi if dp > 0 else -dphi)
+            else:
+                sa = np.sin(dphi) * ct0 / np.cos(d0)
+                ca = (st0 - np.sin(dp) * np.sin(d0)) / (np.cos(dp) * np.cos(d0))
+                ap = a0 - np.arctan2(sa, ca)
+        self._ap, self._dp, self._php = ap, dp, php
+
+    # ------------------------------------------------------------------
+    @property
+    def pixel_scale_matrix(self):
+        return self.cdelt[:, None] * self.pc
+
+    def _lin2(self):
+        return (self.cdelt[:, None] * self.pc)[:2, :2]
+
+    def celestial_pix2world(self, px, py):
+        """0-based pixel -> (lon, lat) degrees."""
+        px = np.asarray(px, dtype=np.float64)
+        py = np.asarray(py, dtype=np.float64)
+        m = self._lin2()
+        dx, dy = px + 1.0 - self.crpix[0], py + 1.0 - self.crpix[1]
+        x = m[0, 0] * dx + m[0, 1] * dy
+        y = m[1, 0] * dx + m[1, 1] * dy
+        if self.proj == "CAR":
+            phi, theta = x * _D2R, y * _D2R
+        else:
+            r = np.hypot(x, y)
+            phi = np.arctan2(x, -y)
+            rr = r * _D2R
+            if self.proj == "TAN":
+                theta = np.arctan2(1.0, rr)
+            elif self.proj == "SIN":
+                theta = np.arccos(np.clip(rr, -1.0, 1.0))
+            elif self.proj == "ARC":
+                theta = np.pi / 2 - rr
+            elif self.proj == "STG":
+                theta = np.pi / 2 - 2.0 * np.arctan(rr / 2.0)
+            else:  # ZEA
+                theta = np.pi / 2 - 2.0 * np.arcsin(np.clip(rr / 2.0, -1.0, 1.0))
+        ap, dp, php = self._ap, self._dp, self._php
+        dphi = phi - php
+        st, ct = np.sin(theta), np.cos(theta)
+        lon = ap + np.arctan2(-ct * np.sin(dphi), st * np.cos(dp) - ct * np.sin(dp) * np.cos(dphi))
+        lat = np.arcsin(np.clip(st * np.sin(dp) + ct * np.cos(dp) * np.cos(dphi), -1.0, 1.0))
+        lon = np.mod(lon * _R2D, 360.0)
+        return lon, lat * _R2D
+
+    def celestial_world2pix(self, lon, lat):
+        """(lon, lat) degrees -> 0-based pixel; NaN where not projectable."""
+        lon = np.asarray(lon, dtype=np.float64) * _D2R
+        lat = np.asarray(lat, dtype=np.float64) * _D2R
+        ap, dp, php = self._ap, self._dp, self._php
+        da = lon - ap
+        sl, cl = np.sin(lat), np.cos(lat)
+        # native unit vector (accurate near the native pole, unlike asin())
+        xn = -cl * np.sin(da)
+        yn = sl * np.cos(dp) - cl * np.sin(dp) * np.cos(da)
+        zn = sl * np.sin(dp) + cl * np.cos(dp) * np.cos(da)
+        rho = np.hypot(xn, yn)
+        phi = php + np.arctan2(xn, yn)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if self.proj == "CAR":
+                phi = np.mod(phi + np.pi, 2 * np.pi) - np.pi
+                x, y = phi * _R2D, np.arctan2(zn, rho) * _R2D
+            else:
+                if self.proj == "TAN":
+                    r = np.where(zn > 0, _R2D * rho / zn, np.nan)
+                elif self.proj == "SIN":
+                    r = np.where(zn >= 0, _R2D * rho, np.nan)
+                elif self.proj == "ARC":
+                    r = _R2D * np.arctan2(rho, zn)
+                elif self.proj == "STG":
+                    r = 2.0 * _R2D * rho / (1.0 + zn)
+                else:  # ZEA
+                    r = 2.0 * _R2D * rho / np.sqrt(2.0 * (1.0 + zn))
+                x, y = r * np.sin(phi), -r * np.cos(phi)
+        minv = np.linalg.inv(self._lin2())
+        dx = minv[0, 0] * x + minv[0, 1] * y
+        dy = minv[1, 0] * x + minv[1, 1] * y
+        return dx + self.crpix[0] - 1.0, dy + self.crpix[1] - 1.0
+
+    # -- spectral ---------------------------------------------------------
+    def spectral_pix2world(self, pz):
+        if self.naxis < 3:
+            raise ValueError("no spectral axis")
+        pz = np.asarray(pz, dtype=np.float64)
+        if abs(self.pc[2, 0]) + abs(self.pc[2, 1]) + abs(self.pc[0, 2]) + abs(self.pc[1, 2]) > 0:
+            raise NotImplementedError("spectral and celestial axes must be separable")
+        return self.crval[2] + self.cdelt[2] * self.pc[2, 2] * (pz + 1.0 - self.crpix[2])
+
+    @property
+    def spectral_unit(self):
+        return self.cunit[2] if self.naxis >= 3 else ""
+
+    def drop_spectral(self):
+        """``wcs_utils.drop_axis(wcs, 2)`` (wcs_utils.py:28-45)."""
+        out = copy.deepcopy(self)
+        out.naxis = 2
+        out.ctype, out.cunit = out.ctype[:2], out.cunit[:2]
+        out.crval, out.crpix, out.cdelt = out.crval[:2], out.crpix[:2], out.cdelt[:2]
+        out.pc = out.pc[:2, :2]
+        out.header = {k: v for k, v in self.header.items() if not k.endswith("3") and "3_" not in k and "_3" not in k}
+        return out
+
+    def with_spectral(self, crval, cdelt, crpix=1.0, cunit=None):
+        out = copy.deepcopy(self)
+        out.crval = out.crval.copy(); out.cdelt = out.cdelt.copy(); out.crpix = out.crpix.copy()
+        out.crval[2], out.cdelt[2], out.crpix[2] = crval, cdelt, crpix
+        out.pc = out.pc.copy(); out.pc[2, 2] = 1.0
+        if cunit is not None:
+            out.cunit = list(out.cunit); out.cunit[2] = cunit
+        out.header = dict(out.header)
+        out.header.update(CRVAL3=float(crval), CDELT3=float(cdelt), CRPIX3=float(crpix))
+        return out
+
+    def to_header(self):
+        h = {"WCSAXES": self.naxis}
+        for i in range(self.naxis):
+            h["CTYPE%d" % (i + 1)] = self.ctype[i]
+            h["CUNIT%d" % (i + 1)] = self.cunit[i]
+            h["CRVAL%d" % (i + 1)] = float(self.crval[i])
+            h["CRPIX%d" % (i + 1)] = float(self.crpix[i])
+            h["CDELT%d" % (i + 1)] = float(self.cdelt[i])
+            for j in range(self.naxis):
+                if self.pc[i, j] != (1.0 if i == j else 0.0):
+                    h["PC%d_%d" % (i + 1, j + 1)] = float(self.pc[i, j])
+        return h
+
+
+def angular_separation(lon1, lat1, lon2, lat2):
+    """Vincenty formula, radians (astropy.coordinates.angular_separation, used
+    by spectral_cube.py:1482-1486)."""
+    sdlon, cdlon = np.sin(lon2 - lon1), np.cos(lon2 - lon1)
+    slat1, slat2, clat1, clat2 = np.sin(lat1), np.sin(lat2), np.cos(lat1), np.cos(lat2)
+    num1 = clat2 * sdlon
+    num2 = clat1 * slat2 - slat1 * clat2 * cdlon
+    den = slat1 * slat2 + clat1 * clat2 * cdlon
+    return np.arctan2(np.hypot(num1, num2), den)
+
+
+def pix_cen_spatial(wcs, shape):
+    """y and x offset maps of ``_pix_cen`` (spectral_cube.py:1476-1496):
+    cumulative angular separations (degrees) from pixel 0 along each axis."""
+    nz, ny, nx = shape
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    lon, lat = wcs.celestial_pix2world(xx, yy)
+    lon, lat = lon * _D2R, lat * _D2R
+    dx = angular_separation(lon[:, :-1], lat[:, :-1], lon[:, 1:], lat[:, :-1])
+    dy = angular_separation(lon[:-1, :], lat[:-1, :], lon[1:, :], lat[1:, :])
+    x = np.zeros((ny, nx))
+    y = np.zeros((ny, nx))
+    x[:, 1:] = np.cumsum(np.degrees(dx), axis=1)
+    y[1:, :] = np.cumsum(np.degrees(dy), axis=0)
+    return y, x
+
+
+def pix_size(wcs, axis):
+    """``_pix_size_slice`` (spectral_cube.py:1510-1535) in the header's units."""
+    psm = wcs.pixel_scale_matrix
+    if axis == 0:
+        return abs(psm[2, 2])
+    if axis in (1, 2):
+        return float(np.sum(psm[2 - axis, :] ** 2) ** 0.5)
+    raise ValueError("Cubes have 3 axes.")
+
+
+def reproject_pixel_map(wcs_in, wcs_out, shape_out):
+    """source pixel coordinates (xs, ys) in *wcs_in* of every output pixel of
+    *wcs_out*: what reproject_interp computes through astropy.wcs
+    (pixel_to_world on the target, world_to_pixel on the source)."""
+    ny, nx = shape_out
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    lon, lat = wcs_out.celestial_pix2world(xx, yy)
+    return wcs_in.celestial_world2pix(lon, lat)

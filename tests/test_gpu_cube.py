@@ -1,0 +1,260 @@
+"""GPU parity through the SpectralCube operator interface: the reference's own
+golden tables / vectors, written like the reference's tests
+(spectral_cube/tests/test_moments.py, test_regrid.py, test_spectral_cube.py)."""
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close, golden
+from spectral_cube_amd import (SpectralCube, BooleanArrayMask, LazyMask, Gaussian1DKernel,
+                               Gaussian2DKernel, Tophat2DKernel, CustomKernel, VarianceWarning,
+                               SimpleWCS, synth)
+from test_oracle_golden import MOMENTS
+
+pytestmark = pytest.mark.gpu
+
+
+def moment_cube():
+    g = golden("moment_cube.npz")
+    return SpectralCube.read(g["data"], str(g["header"])), g
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("how", ["cube", "slice", "auto", "ray"])
+def test_reference(gpu, order, axis, how):
+    """spectral_cube/tests/test_moments.py:93-102 (golden tables :19-49)."""
+    sc, g = moment_cube()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", VarianceWarning)
+        mom = sc.moment(order=order, axis=axis, how=how)
+    np.testing.assert_allclose(mom, MOMENTS[order][axis], rtol=2e-7)
+    np.testing.assert_allclose(mom, g["mom_u_o%d_a%d" % (order, axis)], rtol=1e-9)
+    assert mom.dtype == np.float64
+    assert mom.meta["moment_order"] == order and mom.meta["moment_axis"] == axis
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_consistent_mask_handling(gpu, order, axis):
+    """test_moments.py:105-115: mask `> 4 K`."""
+    sc, g = moment_cube()
+    sc = sc.with_mask(sc > 4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", VarianceWarning)
+        mom = sc.moment(order=order, axis=axis)
+    assert_close(mom, g["mom_m_o%d_a%d" % (order, axis)], rtol=1e-9, what="masked moment")
+
+
+def test_convenience_methods_and_linewidth(gpu):
+    """test_moments.py:118-145."""
+    sc, g = moment_cube()
+    np.testing.assert_allclose(sc.moment0(axis=0), MOMENTS[0][0], rtol=2e-7)
+    np.testing.assert_allclose(sc.moment1(axis=2), MOMENTS[1][2], rtol=2e-7)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        np.testing.assert_allclose(sc.moment2(), MOMENTS[2][0], rtol=2e-7)
+    assert len(w) == 1 and w[0].category == VarianceWarning
+    assert str(w[0].message) == ("Note that the second moment returned will be a "
+                                 "variance map. To get a linewidth map, use the "
+                                 "SpectralCube.linewidth_fwhm() or "
+                                 "SpectralCube.linewidth_sigma() methods instead.")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        np.testing.assert_allclose(sc.linewidth_sigma(), MOMENTS[2][0] ** 0.5, rtol=2e-7)
+        np.testing.assert_allclose(sc.linewidth_fwhm(), MOMENTS[2][0] ** 0.5 * 2.3548200450309493, rtol=2e-7)
+    assert len(w) == 0
+    assert sc.moment0().unit == "K m/s" and sc.moment1().unit == "m/s"
+
+
+def c1_cube():
+    g = golden("c1_moments.npz")
+    shape = tuple(g["shape"])
+    d = synth.gaussian_line_cube(shape, int(g["seed"]))
+    synth.add_nan_block(d, 8, 8, 8)
+    sc = SpectralCube.read(d, str(g["header"]))
+    med = float(g["median"])
+    sc = sc.with_mask(LazyMask(lambda x: x > med, cube=sc))        # opaque lambda: host-evaluated
+    blk = np.ones(shape, dtype=bool)
+    blk[:, :8, :8] = False
+    return sc.with_mask(BooleanArrayMask(blk, sc.wcs)), g, d
+
+
+def test_c1_config_against_reference_output(gpu):
+    """BASELINE configs[0]: 128x64x64, LazyMask 50 % valid, moment 0/1/2."""
+    sc, g, d = c1_cube()
+    span = float(g["size0"]) * g["shape"][0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", VarianceWarning)
+        moms = [sc.moment(order=o) for o in range(3)]
+    fused = sc.moments012()
+    for res in (moms, fused):
+        assert_close(res[0], g["mom0"], atol=1e-5 * np.nanmax(np.abs(g["mom0"])), what="m0")
+        assert_close(res[1], g["mom1"], atol=1e-5 * span, what="m1")
+        assert_close(res[2], g["mom2"], atol=1e-5 * np.nanmax(np.abs(g["mom2"])), what="m2")
+    # the kernel carries fp64 sums: agreement is in fact ~1e-12, not just 1e-5
+    ok = np.isfinite(g["mom1"])
+    assert np.abs(moms[1][ok] - g["mom1"][ok]).max() < 1e-9 * span
+    assert np.array_equal(sc.argmax(), g["argmax"]) and sc.argmax().dtype == np.int64
+    assert np.array_equal(sc.argmin(), g["argmin"])
+    assert_close(sc.linewidth_sigma(), g["linewidth_sigma"], atol=1e-6 * np.nanmax(g["linewidth_sigma"]))
+    assert_close(sc.linewidth_fwhm(), g["linewidth_fwhm"], atol=1e-6 * np.nanmax(g["linewidth_fwhm"]))
+    # the same mask as a device predicate (cube > median) gives the same maps
+    sc2 = SpectralCube.read(d, str(g["header"]))
+    blk = np.ones(d.shape, dtype=bool)
+    blk[:, :8, :8] = False
+    sc2 = sc2.with_mask(sc2 > float(g["median"])).with_mask(blk)
+    assert sc2._mask_spec().flags == 1 | 2 | 4
+    assert_close(sc2.moment1(), g["mom1"], atol=1e-9 * span, what="predicate m1")
+
+
+def test_moment_order_3(gpu):
+    sc, g, d = c1_cube()
+    inc = np.asarray(sc.mask.include())
+    m3 = sc.moment(order=3)
+    exp = O.moment(d, inc, 3, g["cen0"], float(g["size0"]))
+    with np.errstate(all="ignore"):
+        assert_close(m3, exp, rtol=1e-7, atol=1e-9 * np.nanmax(np.abs(exp)), what="order 3")
+    assert m3.unit == "(km/s)3"
+
+
+def hdr_generic(nz, ny, nx):
+    return {"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "CTYPE3": "VOPT", "CDELT1": -5.5e-4,
+            "CDELT2": 5.5e-4, "CDELT3": 1.288, "CUNIT3": "km/s", "CRPIX1": nx / 2, "CRPIX2": ny / 2,
+            "CRPIX3": 1.0, "CRVAL1": 23.18, "CRVAL2": 30.57, "CRVAL3": -321.2, "BUNIT": "K",
+            "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nz}
+
+
+def test_spectral_smooth(gpu):
+    """test_regrid.py:138-172 + generated vectors; mask unchanged; fused moment."""
+    g = golden("spectral_smooth.npz")
+    cube = SpectralCube.read(g["delta522"], hdr_generic(5, 2, 2))
+    kernel = Gaussian1DKernel(1.0)
+    assert kernel.array.size == 9
+    result = cube.spectral_smooth(kernel=kernel)
+    np.testing.assert_almost_equal(result.filled_data[:, 0, 0], kernel.array[2:-2], 4)
+    assert_close(result.filled_data, g["delta522_out"], atol=1e-6)
+    d, inc = g["ss_data"], g["ss_include"]
+    for name, kobj in (("g2", Gaussian1DKernel(2.0)), ("asym", CustomKernel(g["ss_asym_k"]))):
+        sc = SpectralCube.read(d, hdr_generic(*d.shape)).with_mask(BooleanArrayMask(inc))
+        sm = sc.spectral_smooth(kobj)
+        assert sm.mask is sc.mask
+        # smooth -> moment1, fused (never materialised) ...
+        m1 = sm.moment1()
+        assert sm._dev is None, "fused path must not materialise the smoothed cube"
+        span = 1.288 * d.shape[0]
+        assert_close(m1, g["ss_%s_m1" % name] , atol=2e-5 * span, what="fused smooth->m1")
+        # ... and materialised
+        raw = sm._device_data().get()
+        assert raw.dtype == np.float32
+        exp = g["ss_%s_out" % name]
+        assert_close(raw, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="smooth " + name)
+        m1b = sm.moment1()
+        assert_close(m1b, g["ss_%s_m1" % name], atol=2e-5 * span, what="materialised smooth->m1")
+
+
+def test_spatial_smooth(gpu):
+    """test_spectral_cube.py:2363-2421."""
+    g = golden("spatial_smooth.npz")
+    cube = SpectralCube.read(g["adv"], hdr_generic(4, 3, 2))
+    g2d = cube.spatial_smooth(Gaussian2DKernel(3)).filled_data
+    np.testing.assert_almost_equal(g2d[0], [[0.0585795, 0.0588712], [0.0612525, 0.0614312], [0.0576757, 0.057723]])
+    np.testing.assert_almost_equal(g2d[2], [[0.027322, 0.027257], [0.0280423, 0.02803], [0.0259688, 0.0260123]])
+    t2d = cube.spatial_smooth(Tophat2DKernel(3)).filled_data
+    np.testing.assert_almost_equal(t2d[0], np.full((3, 2), 0.1265607))
+    np.testing.assert_almost_equal(t2d[2], np.full((3, 2), 0.0585135))
+    sc = SpectralCube.read(g["sp_data"], hdr_generic(*g["sp_data"].shape)).with_mask(g["sp_include"])
+    out = sc.spatial_smooth(Gaussian2DKernel(1.5))._device_data().get()
+    assert_close(out, g["sp_out"], atol=1e-5 * np.nanmax(np.abs(g["sp_out"])), what="spatial smooth")
+    assert sc.spatial_smooth(Gaussian2DKernel(1.5)).unit == "K"            # :2386-2398
+
+
+def test_spectral_interpolate(gpu):
+    """test_regrid.py:234-361."""
+    g = golden("spectral_interpolate.npz")
+    h = hdr_generic(5, 2, 2)
+    cube = SpectralCube.read(g["delta522"], h)
+    np.testing.assert_allclose(cube.spectral_axis, g["mid_in"], rtol=1e-12)
+    sg = (cube.spectral_axis[1:] + cube.spectral_axis[:-1]) / 2.
+    result = cube.spectral_interpolate(spectral_grid=sg)
+    np.testing.assert_almost_equal(result.filled_data[:, 0, 0], [0.0, 0.5, 0.5, 0.0])
+    np.testing.assert_allclose(result.spectral_axis, sg, rtol=1e-12)
+    sg2 = cube.spectral_axis[0] - (cube.spectral_axis[1] - cube.spectral_axis[0]) * np.linspace(1, 4, 4)
+    r2 = cube.spectral_interpolate(spectral_grid=sg2, fill_value=42)
+    np.testing.assert_almost_equal(r2.filled_data[:, 0, 0], np.ones(4) * 42)
+    r3 = cube.spectral_interpolate(spectral_grid=cube.spectral_axis[::-1])
+    np.testing.assert_almost_equal(cube.spectral_axis[::-1], r3.spectral_axis)
+    assert_close(r3.filled_data, g["rev_out"], atol=1e-6)
+    # masked + reversed input axis (test_regrid.py:319-346)
+    hh = dict(h, CDELT3=-h["CDELT3"])
+    c2 = SpectralCube.read(g["delta522"], hh)
+    mask = np.ones(c2.shape, dtype=bool)
+    mask[:2] = False
+    mc = c2.with_mask(mask)
+    sgr = (c2.spectral_axis[1:] + c2.spectral_axis[:-1]) / 2.
+    r4 = mc.spectral_interpolate(spectral_grid=sgr[::-1])
+    np.testing.assert_almost_equal(r4.filled_data[:, 0, 0], [0.0, 0.5, np.nan, np.nan])
+    assert np.array_equal(r4.mask.include(), ~np.isnan(r4.filled_data))
+    # generated vectors: upsampling with NaNs, out-of-range ends, exact hits
+    d, inc = g["rnd_data"], g["rnd_include"]
+    hr = dict(hdr_generic(*d.shape), CRVAL3=float(g["rnd_in"][0]), CDELT3=float(g["rnd_in"][1] - g["rnd_in"][0]))
+    sc = SpectralCube.read(d, hr).with_mask(inc)
+    np.testing.assert_allclose(sc.spectral_axis, g["rnd_in"], rtol=1e-9)
+    out = sc.spectral_interpolate(g["rnd_grid"], suppress_smooth_warning=True).filled_data
+    assert_close(out, g["rnd_out"], atol=1e-5 * np.nanmax(np.abs(g["rnd_out"])), what="interp random")
+    out = sc.spectral_interpolate(sc.spectral_axis).filled_data
+    assert_close(out, g["rnd_exact_out"], atol=1e-5 * np.nanmax(np.abs(g["rnd_exact_out"])), what="exact")
+    # reversed input axis against the oracle on a seeded cube
+    d = synth.gaussian_line_cube((40, 6, 7), 5)
+    hq = dict(hdr_generic(40, 6, 7), CDELT3=-0.7, CRVAL3=10.0)
+    sq = SpectralCube.read(d, hq)
+    grid = np.linspace(sq.spectral_axis.min() - 1.0, sq.spectral_axis.max() + 0.3, 91)
+    for gr in (grid, grid[::-1]):
+        got = sq.spectral_interpolate(gr, suppress_smooth_warning=True).filled_data
+        exp, _ = O.spectral_interpolate(d, None, sq.spectral_axis, gr)
+        assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="reversed in")
+
+
+def test_reproject(gpu):
+    """test_regrid.py:99-135 checks shape and WCS only; values vs the oracle
+    (PARITY UNPINNED for pixel values, see oracle/oracle_np.py)."""
+    g = golden("wcs.npz")
+    rng = np.random.default_rng(8)
+    d = rng.standard_normal((4, 48, 40)).astype(np.float32)
+    cube = SpectralCube.read(d, str(g["rp_hdr_in"]))
+    hdr_out = SimpleWCS(str(g["rp_hdr_out"]))
+    hdr_out.header.update(NAXIS1=40, NAXIS2=48)
+    result = cube.reproject(hdr_out)
+    assert result.shape == (4, 48, 40)
+    assert result.wcs.pc[0, 1] == hdr_out.pc[0, 1]
+    exp, foot = O.resample_bilinear(d, g["rp_xs"], g["rp_ys"])
+    assert_close(result._device_data().get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="reproject")
+    assert np.array_equal(result.mask.include()[0], foot[0])
+    far = SimpleWCS(dict(hdr_out.header, CRVAL1=10.0))
+    with pytest.raises(ValueError, match="All values in reprojected cube are nan"):
+        cube.reproject(far)
+
+
+def test_dask_chunk_functions(gpu):
+    """drop-in chunk functions for apply_function_parallel_* (accepts_chunks=True)."""
+    from spectral_cube_amd import dask_adapter as A
+    rng = np.random.default_rng(10)
+    chunk = rng.standard_normal((50, 8, 9)).astype(np.float32)
+    chunk[rng.random(chunk.shape) < 0.1] = np.nan          # NaN-filled masked data
+    k = Gaussian1DKernel(2.0)
+    out = A.SpectralSmoothChunk(k)(chunk)
+    assert out.shape == chunk.shape and out.dtype == chunk.dtype
+    exp = O.convolve_fill_interp(chunk, k.array.reshape(-1, 1, 1))
+    assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="chunk spectral smooth")
+    k2 = Gaussian2DKernel(1.0)
+    out = A.SpatialSmoothChunk(k2)(chunk[:4])
+    exp = O.spatial_smooth(chunk[:4], None, k2.array)
+    assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="chunk spatial smooth")
+    cen = np.arange(50.0) * 0.5
+    for order in range(3):
+        out = A.MomentChunk(order, cen, 0.5, world0=-7.0)(chunk)
+        exp = O.moment(chunk, None, order, cen, 0.5, world0=-7.0)
+        with np.errstate(all="ignore"):
+            assert_close(out, exp, rtol=1e-7, atol=1e-9 * np.nanmax(np.abs(exp)), what="chunk moment")

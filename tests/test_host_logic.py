@@ -1,0 +1,222 @@
+"""CPU: host-side logic (no compute calls): C-ABI exports, kernels, WCS, mask
+lowering, interpolation planning, API error behaviour."""
+import os
+import pickle
+import re
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import REPO, golden
+from spectral_cube_amd import (_lib, kernels as K, masks as M, ops, SpectralCube, SimpleWCS,
+                               HipLibraryError)
+from spectral_cube_amd.wcs import pix_cen_spatial, pix_size, reproject_pixel_map
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(REPO, "include", "spcube_hip.h")).read()
+    declared = set(re.findall(r"\b(spc_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"spc_status"}
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libspcube_hip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.spc_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    cube = SpectralCube(np.zeros((4, 3, 2), dtype=np.float32),
+                        header={"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD",
+                                "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 1.0, "CUNIT3": "km/s",
+                                "CRPIX1": 1, "CRPIX2": 1, "CRPIX3": 1})
+    with pytest.raises(HipLibraryError):
+        cube.moment0()
+    with pytest.raises(HipLibraryError):
+        cube.spectral_smooth(K.Gaussian1DKernel(1.0)).filled_data
+
+
+def test_invalid_arguments_are_reported_not_crashed():
+    import ctypes as C
+    lib = _lib.load()
+    c = _lib.SpcCube()          # NULL data pointer
+    o = _lib.SpcMomentOutputs()
+    rc = lib.spc_moments_f32(0, None, C.byref(c), None, None, 1.0, 0.0, C.byref(o), None, 0)
+    assert rc == _lib.SPC_ERR_INVALID and b"NULL" in lib.spc_last_error()
+    with pytest.raises(_lib.HipInvalidArgument):
+        _lib.check(rc)
+
+
+def test_kernels_match_astropy_arrays():
+    g = golden("kernels.npz")
+    for s in (0.7, 1.0, 1.5, 2.0, 3.0, 4.0, 8 / 2.3548200450309493):
+        np.testing.assert_allclose(K.Gaussian1DKernel(s).array, g["g1_%.6f" % s], rtol=1e-13)
+        np.testing.assert_allclose(K.Gaussian2DKernel(s).array, g["g2_%.6f" % s], rtol=1e-13)
+    assert K.Gaussian1DKernel(4).array.size == 33
+    assert K.Gaussian2DKernel(8 / 2.35482).array.shape == (29, 29)
+    for w in (3, 5, 8):
+        np.testing.assert_allclose(K.Box1DKernel(w).array, g["box1_%d" % w], rtol=1e-13)
+    for r in (2, 3):
+        np.testing.assert_allclose(K.Tophat2DKernel(r).array, g["tophat2_%d" % r], rtol=1e-13)
+    np.testing.assert_allclose(K.Gaussian2DKernel(2.0, x_size=9, y_size=13).array, g["g2_xs9_ys13"], rtol=1e-13)
+    ky, kx = ops.separable_factors(K.Gaussian2DKernel(3.397).array)
+    np.testing.assert_allclose(np.outer(ky, kx), K.Gaussian2DKernel(3.397).array, rtol=1e-12)
+    assert ops.separable_factors(K.Tophat2DKernel(3).array) is None
+    with pytest.raises(ValueError):
+        K.CustomKernel(np.ones(4))
+
+
+def test_wcs_against_astropy_vectors():
+    g = golden("wcs.npz")
+    px, py = g["px"], g["py"]
+    for i in range(int(g["n"])):
+        w = SimpleWCS(str(g["hdr%d" % i]))
+        lon, lat = w.celestial_pix2world(px, py)
+        assert np.abs((lon - g["lon%d" % i] + 180) % 360 - 180).max() < 1e-11
+        assert np.abs(lat - g["lat%d" % i]).max() < 1e-11
+        bx, by = w.celestial_world2pix(g["lon%d" % i], g["lat%d" % i])
+        assert np.abs(bx - px).max() < 1e-8 and np.abs(by - py).max() < 1e-8
+        np.testing.assert_allclose(w.spectral_pix2world(np.arange(8)), g["specax_%d" % i], rtol=1e-14)
+        assert w.spectral_unit == "km/s"
+        cy, cx = pix_cen_spatial(w, (8, 48, 40))
+        np.testing.assert_allclose(cy, g["cen1_%d" % i], atol=1e-12)
+        np.testing.assert_allclose(cx, g["cen2_%d" % i], atol=1e-12)
+        np.testing.assert_allclose([pix_size(w, a) for a in range(3)], g["size_%d" % i], rtol=1e-13)
+        cube = SpectralCube(np.zeros((8, 48, 40), np.float32), wcs=w)
+        np.testing.assert_allclose(cube._pix_cen_axis(0), g["cen0_%d" % i], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(cube.spectral_axis[0], g["world0_%d" % i].flat[0], rtol=1e-14)
+    wi, wo = SimpleWCS(str(g["rp_hdr_in"])), SimpleWCS(str(g["rp_hdr_out"]))
+    xs, ys = reproject_pixel_map(wi, wo, (48, 40))
+    assert np.abs(xs - g["rp_xs"]).max() < 1e-7 and np.abs(ys - g["rp_ys"]).max() < 1e-7
+
+
+def _cube(shape=(6, 5, 4), seed=0):
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[0, 0, 0] = np.nan
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3,
+           "CDELT2": 1e-3, "CDELT3": 0.5, "CUNIT3": "km/s", "CRPIX1": 1, "CRPIX2": 1,
+           "CRPIX3": 1, "CRVAL3": -3.0, "BUNIT": "K"}
+    return SpectralCube.read(d, hdr), d
+
+
+def test_mask_algebra_matches_numpy():
+    cube, d = _cube()
+    b = np.random.default_rng(1).random(d.shape) > 0.4
+    with np.errstate(invalid="ignore"):
+        m = (cube > 0.1) & M.BooleanArrayMask(b)
+        np.testing.assert_array_equal(m.include(), (d > np.float32(0.1)) & b)
+        np.testing.assert_array_equal((m | (cube < -1)).include(), ((d > np.float32(0.1)) & b) | (d < -1))
+        np.testing.assert_array_equal((~m).include(), ~((d > np.float32(0.1)) & b))
+        np.testing.assert_array_equal((m ^ M.BooleanArrayMask(b)).include(), ((d > np.float32(0.1)) & b) ^ b)
+    f = cube.with_mask(b).filled_data
+    exp = np.where(b & np.isfinite(d), d, np.nan)
+    np.testing.assert_array_equal(np.isnan(f), np.isnan(exp))
+    with pytest.raises(ValueError):
+        M.BooleanArrayMask(np.ones((2, 2), bool), shape=(3, 3, 3))
+    with pytest.raises(ValueError):
+        M.CompositeMask(m, m, "nand")
+
+
+def test_mask_lowering_to_device_terms():
+    cube, d = _cube()
+    # FITS-style finite mask alone -> predicate only, no array traffic
+    flags, lo, hi, arr = M.lower_mask(cube.mask, cube, cube.shape)
+    assert flags == _lib.MASK_FINITE and arr is None
+    c2 = cube.with_mask(cube > 0.25)
+    flags, lo, hi, arr = M.lower_mask(c2.mask, c2, c2.shape)
+    assert flags == _lib.MASK_FINITE | _lib.MASK_GT and lo == 0.25 and arr is None
+    c3 = c2.with_mask(cube < 1.5).with_mask(cube >= 0.25)          # GT beats GE at equal threshold
+    flags, lo, hi, arr = M.lower_mask(c3.mask, c3, c3.shape)
+    assert flags == _lib.MASK_FINITE | _lib.MASK_GT | _lib.MASK_LT and (lo, hi) == (0.25, 1.5)
+    b = np.random.default_rng(2).random(d.shape) > 0.5
+    c4 = c2.with_mask(b)
+    flags, lo, hi, arr = M.lower_mask(c4.mask, c4, c4.shape)
+    assert flags & _lib.MASK_ARRAY and arr.dtype == np.uint8 and np.array_equal(arr.astype(bool), b)
+    # an OR cannot run on the device: it is materialised, bit-identical
+    c5 = cube.with_mask((cube > 1.0) | (cube < -1.0), inherit_mask=False)
+    flags, lo, hi, arr = M.lower_mask(c5.mask, c5, c5.shape)
+    with np.errstate(invalid="ignore"):
+        assert flags == _lib.MASK_ARRAY and np.array_equal(arr.astype(bool), (d > 1) | (d < -1))
+    # a lazy mask bound to ANOTHER cube's data must not run on this cube's data
+    other, d2 = _cube(seed=9)
+    c6 = SpectralCube(d, wcs=cube.wcs, mask=M.LazyMask(np.isfinite, cube=other))
+    flags, lo, hi, arr = M.lower_mask(c6.mask, c6, c6.shape)
+    assert flags == _lib.MASK_ARRAY and np.array_equal(arr.astype(bool), np.isfinite(d2))
+    # weak python thresholds compare in float32, like numpy does
+    c7 = cube.with_mask(cube > 0.1)
+    flags, lo, hi, arr = M.lower_mask(c7.mask, c7, c7.shape)
+    assert lo == float(np.float32(0.1))
+    c8 = cube.with_mask(cube > np.float64(0.1))           # typed float64: not exactly representable
+    flags, lo, hi, arr = M.lower_mask(c8.mask, c8, c8.shape)
+    assert flags & _lib.MASK_ARRAY
+
+
+def test_lerp_plan_matches_oracle_indexing():
+    import oracle_np as O
+    x = np.linspace(-5, 5, 11)
+    grid = np.linspace(-6.2, 5.9, 23)
+    lo, t, inv, rin, rout, fill = ops.lerp_plan(x, grid)
+    d = np.random.default_rng(4).standard_normal((11, 2, 2))
+    exp, _ = O.spectral_interpolate(d, None, x, grid)
+    got = np.where(lo[:, None, None] >= 0,
+                   (d[np.clip(lo, 0, 9) + 1] - d[np.clip(lo, 0, 9)]) * (inv * t)[:, None, None] + d[np.clip(lo, 0, 9)],
+                   np.nan)
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-14)
+    with pytest.raises(AssertionError):
+        ops.lerp_plan(x, np.array([0.0, 1.0, 3.0]))         # non-linear output grid
+    assert ops.lerp_plan(x[::-1], grid)[3] and ops.lerp_plan(x, grid[::-1])[4]
+
+
+def test_cube_api_error_behaviour():
+    cube, d = _cube()
+    with pytest.raises(ValueError, match="Invalid how"):
+        cube.moment(order=1, how="banana")
+    with pytest.raises(ValueError, match="Cubes have 3 axes"):
+        cube.moment(order=0, axis=3)
+
+    class Q:     # kernel whose array carries a unit (dask_spectral_cube.py:908-910)
+        class array:
+            unit = "K"
+    from spectral_cube_amd import UnitsError, BeamUnitsError
+    with pytest.raises(UnitsError, match="The convolution kernel should be defined without a unit."):
+        cube.spectral_smooth(Q())
+    jy = SpectralCube(d, wcs=cube.wcs, unit="Jy/beam")
+    with pytest.raises(BeamUnitsError):
+        jy.spatial_smooth(K.Gaussian2DKernel(1.0))
+    jy.spatial_smooth(K.Gaussian2DKernel(1.0), raise_error_jybm=False)     # lazy: no GPU touched
+    assert cube.spectral_unit == "km/s" and cube.unit == "K"
+    np.testing.assert_allclose(cube.spectral_axis, -3.0 + 0.5 * np.arange(6))
+    sm = cube.spectral_smooth(K.Gaussian1DKernel(1.0))
+    assert sm.mask is cube.mask and sm.shape == cube.shape              # mask unchanged, lazy
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        try:
+            cube.moment(order=2)
+        except HipLibraryError:
+            pass
+    assert len(w) == 1 and str(w[0].message).startswith("Note that the second moment returned will be a variance map.")
+
+
+def test_chunk_functions_are_picklable():
+    from spectral_cube_amd import dask_adapter as A
+    fns = [A.SpectralSmoothChunk(K.Gaussian1DKernel(2.0)), A.SpatialSmoothChunk(K.Gaussian2DKernel(1.0)),
+           A.MomentChunk(1, np.arange(8.0), 0.5, world0=3.0),
+           A.SpectralInterpolateChunk(np.arange(8.0), np.linspace(0, 7, 15))]
+    for fn in fns:
+        clone = pickle.loads(pickle.dumps(fn))
+        assert type(clone) is type(fn)
+    empty = np.zeros((0, 3, 3), np.float32)
+    assert fns[0](empty) is empty and fns[1](empty) is empty          # dask_spectral_cube.py:600-610
+
+
+def test_strip_bounds_cover_all_rows():
+    from spectral_cube_amd.distributed import strip_bounds
+    for ny in (1, 7, 64, 1000):
+        for ws in (1, 2, 3, 8):
+            rows = [strip_bounds(ny, ws, r) for r in range(ws)]
+            assert rows[0][0] == 0 and rows[-1][1] == ny
+            assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
