@@ -37,33 +37,37 @@ def parse():
 
 
 def fill_cube_on_device(cube, mask, shape, seed, y_offset):
-    """Seeded synthetic strip generated plane-block by plane-block on the host
-    and staged to HBM (never timed).  Data: Gaussian line per spaxel + noise
-    (spectral_cube_amd.synth); mask: data > 2*noise with a
-    1 % flip and one fully masked 8x8 block."""
+    """Seeded synthetic strip generated row-block by row-block on the host
+    (thread pool; every block has its own seed) and staged to HBM - never
+    timed.  Data: Gaussian line per spaxel + noise (spectral_cube_amd.synth,
+    SURVEY.md section 8d); mask: data > 2*noise with a 1 % flip, one fully
+    masked 8x8 block and one NaN-input block."""
     import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
     import numpy as np
     from spectral_cube_amd import _lib, synth
     nz, ny, nx = shape
-    rows = 32
-    for y0 in range(0, ny, rows):
+    rows = 16
+
+    def one(y0):
         y1 = min(ny, y0 + rows)
         blk = synth.gaussian_line_cube((nz, y1 - y0, nx), seed + 1000 * (y_offset + y0), chunk_rows=rows)
         m = synth.boolean_mask(blk, seed + 1000 * (y_offset + y0))
-        if y_offset + y0 == 0:
-            m[:, :8, :8] = 0
-        else:
-            pass
-        if y0 == 0 and y_offset == 0 and y1 - y0 >= 16 and nx >= 16:
+        if not (y_offset == 0 and y0 == 0):
+            # boolean_mask() blanks an 8x8 block in every strip; keep only the first one
+            m[:, :8, :8] = (blk[:, :8, :8] > 1.0).view(np.uint8)
+        elif y1 - y0 >= 16 and nx >= 16:
             blk[:, 8:16, 8:16] = np.nan                     # NaN-input block
-        # strided H2D: block rows y0:y1 of every plane
+        # strided H2D: rows y0:y1 of every plane
         _lib.call("spc_memcpy3d_h2d", cube.device, C.c_void_p(cube.ptr + y0 * nx * 4), nx * 4, ny * nx * 4,
                   blk.ctypes.data_as(C.c_void_p), nx * 4, (y1 - y0) * nx * 4, nx * 4, y1 - y0, nz, None)
         _lib.call("spc_memcpy3d_h2d", mask.device, C.c_void_p(mask.ptr + y0 * nx), nx, ny * nx,
                   m.ctypes.data_as(C.c_void_p), nx, (y1 - y0) * nx, nx, y1 - y0, nz, None)
-        if y0 == 0:
-            first = (blk.copy(), m.copy())
-    return first
+        return (blk, m) if y0 == 0 else (None, float(m.mean()))
+
+    with ThreadPoolExecutor(min(32, len(os.sched_getaffinity(0)))) as ex:
+        res = list(ex.map(one, range(0, ny, rows)))
+    return res[0]
 
 
 def cpu_baseline(shape, seconds):
@@ -90,17 +94,20 @@ def cpu_baseline(shape, seconds):
         blk, inc = item
         return [O.moment(blk, inc, o, cen, 500.0, world0=-1.0) for o in (0, 1, 2)]
 
+    cores = min(cores, 64)                                  # numpy stops scaling long before 256 threads
     items = [make(i) for i in range(cores)]
     t0 = time.perf_counter()
     work(items[0])
     t1 = time.perf_counter() - t0                           # single-thread time per strip
-    rounds = max(1, int(seconds / max(t1, 1e-3)))           # each round keeps every core busy
-    rounds = min(rounds, 64)
+    rounds = 0
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
-        for _ in range(rounds):
-            list(ex.map(work, items))
-        dt = time.perf_counter() - t0
+        while True:
+            list(ex.map(work, items))                       # every core gets one strip per round
+            rounds += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or rounds >= 64:
+                break
     vox = rounds * cores * nz * rows * nx
     return {"value": vox / dt / 1e6, "unit": "Mvoxel/s", "cores": cores, "kind": "port",
             "single_thread_value": nz * rows * nx / t1 / 1e6,
@@ -261,7 +268,7 @@ def main():
                                    "moment0+moment1+moment2 (one kernel launch, three float64 maps)" % shape,
                        "mask_valid_fraction": float(first_blk[1].mean()), "stitch": stitch,
                        "sharding": "row strips of a %dx%dx%d cube" % (nz, ny * world, nx) if world > 1 else "none",
-                       "device": device_info(device)["name"]},
+                       "device": device_info(device)["name"] or device_info(device)["arch"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "kernel": "moments_kernel<VEC=4,ZW=4,U=8,ARR,noEXT,NT>",

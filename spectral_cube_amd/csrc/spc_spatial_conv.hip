@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "spc_spatial_conv_impl.h"
+#include <vector>
 
 namespace spc_spconv {
 extern template int launch_sep<9>(const SpArgs&, hipStream_t, dim3, bool);
@@ -117,17 +118,18 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, c
     hipStream_t st = (hipStream_t)stream;
     const int n = nky * nkx;
     float* d_k = nullptr;
-    SPC_HIP(hipMallocAsync((void**)&d_k, sizeof(float) * n, st));
-    float* hk = (float*)malloc(sizeof(float) * n);
+    SPC_HIP(hipMalloc((void**)&d_k, sizeof(float) * n));
+    std::vector<float> hk(n);
     for (int i = 0; i < n; ++i) hk[i] = (float)h_kernel[i];
-    hipError_t e = hipMemcpyAsync(d_k, hk, sizeof(float) * n, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    free(hk);
+    hipError_t e = hipMemcpy(d_k, hk.data(), sizeof(float) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + 3) / 4), (unsigned)cube->nz);
+        hipLaunchKernelGGL(spatial_conv2d_kernel, grid, dim3(256), 0, st, A, d_k, nky, nkx);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d_k);
     SPC_HIP(e);
-    dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + 3) / 4), (unsigned)cube->nz);
-    hipLaunchKernelGGL(spatial_conv2d_kernel, grid, dim3(256), 0, st, A, d_k, nky, nkx);
-    SPC_LAUNCH_CHECK();
-    SPC_HIP(hipFreeAsync(d_k, st));
     return SPC_OK;
 }
 

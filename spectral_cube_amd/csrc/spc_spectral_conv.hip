@@ -22,6 +22,7 @@
 #include <alloca.h>
 
 #include "spc_spectral_conv_impl.h"
+#include <vector>
 
 namespace spc_sconv {
 extern template int launch<9>(const ConvArgs&, hipStream_t, dim3, bool, bool, bool);
@@ -150,16 +151,20 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
     hipStream_t st = (hipStream_t)stream;
     if (R) return launch_ring<false>(R, A, st, grid, (A.mask.flags & SPC_MASK_ARRAY) != 0, false);
-    // wide kernels: generic path with the taps in device memory
+    // wide kernels: generic path with the taps in device memory (rare fallback:
+    // plain synchronous allocation/copy, released after the kernel has drained)
     float* d_k = nullptr;
-    SPC_HIP(hipMallocAsync((void**)&d_k, sizeof(float) * ntaps, st));
-    float* hk = (float*)alloca(sizeof(float) * ntaps);
+    SPC_HIP(hipMalloc((void**)&d_k, sizeof(float) * ntaps));
+    std::vector<float> hk(ntaps);
     for (int i = 0; i < ntaps; ++i) hk[i] = (float)h_kernel[i];
-    SPC_HIP(hipMemcpyAsync(d_k, hk, sizeof(float) * ntaps, hipMemcpyHostToDevice, st));
-    SPC_HIP(hipStreamSynchronize(st));  // hk lives on this stack frame
-    hipLaunchKernelGGL(spectral_conv_generic_kernel, grid, dim3(256), 0, st, A, d_k, ntaps);
-    SPC_LAUNCH_CHECK();
-    SPC_HIP(hipFreeAsync(d_k, st));
+    hipError_t e = hipMemcpy(d_k, hk.data(), sizeof(float) * ntaps, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(spectral_conv_generic_kernel, grid, dim3(256), 0, st, A, d_k, ntaps);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d_k);
+    SPC_HIP(e);
     return SPC_OK;
 }
 

@@ -25,8 +25,9 @@ def assert_close(a, b, rtol=0.0, atol=0.0, what=""):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (what, a.shape, b.shape)
-    assert np.array_equal(np.isnan(a), np.isnan(b)), what + ": NaN pattern differs (%d vs %d NaN)" % (
-        np.isnan(a).sum(), np.isnan(b).sum())
+    nan_diff = np.isnan(a) != np.isnan(b)
+    assert not nan_diff.any(), what + ": NaN pattern differs (%d vs %d NaN), first at %s" % (
+        np.isnan(a).sum(), np.isnan(b).sum(), np.argwhere(nan_diff)[:4].tolist() + np.argwhere(nan_diff)[-2:].tolist())
     fin = np.isfinite(a) & np.isfinite(b)
     err = np.abs(a[fin] - b[fin]) - (atol + rtol * np.abs(b[fin]))
     assert err.size == 0 or err.max() <= 0, "%s: max excess error %.3e" % (what, err.max())

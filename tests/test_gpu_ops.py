@@ -156,7 +156,7 @@ def test_spectral_conv_vs_oracle(gpu, kname, shape):
     d[3:5, 1, 1] = np.nan
     d[:, 2, 3] = np.nan
     inc = rng.random(shape) > 0.3
-    inc[10:10 + len(k) + 3, 4, 4] = False
+    inc[10:10 + len(k) + 3, 3, 4] = False
     inc[:, 0, 0] = False
     for m in (None, inc):
         out = ops.spectral_conv(_dev(d), k, mask=_mspec(m)).get()
@@ -206,7 +206,7 @@ def test_spectral_conv_moments_fused(gpu, kname):
         assert (am != ea).mean() < 0.02
 
 
-@pytest.mark.parametrize("sig", ["3.397288", "1.500000", "0.700000"])
+@pytest.mark.parametrize("sig", ["3.397287", "1.500000", "0.700000"])
 @pytest.mark.parametrize("shape", [(3, 40, 37), (2, 300, 500), (5, 9, 7)])
 def test_spatial_conv_sep_vs_oracle(gpu, sig, shape):
     from spectral_cube_amd import ops
