@@ -230,6 +230,14 @@ def main():
     k_ms = float(np.mean(kt))
     alg_bytes = vox_rank * 5 + ny * nx * 24          # 4 B data + 1 B mask per voxel, 3 fp64 maps out
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed under profiles/ (separate
+    # rocprofv3 --pmc runs of this same command; FETCH_SIZE x2 gfx950 correction)
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(REPO, "profiles", "r01_moments_c2_pmc.json")
+    if os.path.exists(pmc_file) and shape == (1024, 1024, 1024):
+        with open(pmc_file) as fh:
+            traffic = json.load(fh)["hbm_traffic_bytes_per_launch"]
+        traffic_src = "profiles/r01_moments_c2_pmc.json"
 
     # ---- verification of the timed outputs (first rows vs the oracle; never timed) ----
     verify = None
@@ -270,7 +278,8 @@ def main():
                        "sharding": "row strips of a %dx%dx%d cube" % (nz, ny * world, nx) if world > 1 else "none",
                        "device": device_info(device)["name"] or device_info(device)["arch"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "kernel": "moments_kernel<VEC=4,ZW=4,U=8,ARR,noEXT,NT>",
                          "kernel_ms": k_ms, "algorithmic_bytes": alg_bytes},
             "cpu_baseline": cpu,
