@@ -22,13 +22,13 @@
 #include <alloca.h>
 
 #include "spc_spectral_conv_impl.h"
+#include <cstdlib>
 #include <vector>
 
 namespace spc_sconv {
-extern template int launch<9>(const ConvArgs&, hipStream_t, dim3, bool, bool, bool);
-extern template int launch<17>(const ConvArgs&, hipStream_t, dim3, bool, bool, bool);
-extern template int launch<33>(const ConvArgs&, hipStream_t, dim3, bool, bool, bool);
-extern template int launch<65>(const ConvArgs&, hipStream_t, dim3, bool, bool, bool);
+extern template int launch<9>(const ConvArgs&, hipStream_t, int, bool);
+extern template int launch<17>(const ConvArgs&, hipStream_t, int, bool);
+extern template int launch<33>(const ConvArgs&, hipStream_t, int, bool);
 }
 using namespace spc_sconv;
 
@@ -74,22 +74,36 @@ __global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvAr
     }
 }
 
-int pick_ring(int ntaps) {
-    const int rings[] = {9, 17, 33, 65};
+// ring kernels need a non-zero centre tap (see the empty-window note in
+// spc_spectral_conv_impl.h); anything else goes to the generic kernel
+int pick_ring(const double* k, int ntaps) {
+    if (k[ntaps / 2] == 0.0) return 0;
+    // (a 63-tap ring compiles for > 10 minutes; wider kernels use the generic kernel)
+    const int rings[] = {9, 17, 33};
     for (int r : rings) if (ntaps <= r) return r;
     return 0;
 }
 
-template <bool FUSE>
-int launch_ring(int R, const ConvArgs& A, hipStream_t st, dim3 grid, bool arr, bool ext) {
+int launch_ring(int R, const ConvArgs& A, hipStream_t st, int vec, bool fuse) {
     switch (R) {
-        case 9: return spc_sconv::launch<9>(A, st, grid, arr, FUSE, ext);
-        case 17: return spc_sconv::launch<17>(A, st, grid, arr, FUSE, ext);
-        case 33: return spc_sconv::launch<33>(A, st, grid, arr, FUSE, ext);
-        case 65: return spc_sconv::launch<65>(A, st, grid, arr, FUSE, ext);
+        case 9: return spc_sconv::launch<9>(A, st, vec, fuse);
+        case 17: return spc_sconv::launch<17>(A, st, vec, fuse);
+        case 33: return spc_sconv::launch<33>(A, st, vec, fuse);
     }
     spc_set_error("no ring kernel for R=%d", R);
     return SPC_ERR_UNSUPPORTED;
+}
+
+// two spaxels per lane need 8-byte aligned rows everywhere
+int pick_vec(const spc_cube_f32* c, const MaskDev& m, const float* out, int64_t out_row, int64_t out_plane) {
+    const char* env = getenv("SPC_CONV_VEC");
+    if (env && atoi(env) == 1) return 1;
+    bool ok = (c->nx % 2 == 0) && (c->row_stride % 2 == 0) && (c->plane_stride % 2 == 0) &&
+              (((uintptr_t)c->d_data) % 8 == 0);
+    if (m.flags & SPC_MASK_ARRAY)
+        ok = ok && (m.row_stride % 2 == 0) && (m.plane_stride % 2 == 0) && (((uintptr_t)m.arr) % 2 == 0);
+    if (out) ok = ok && (out_row % 2 == 0) && (out_plane % 2 == 0) && (((uintptr_t)out) % 8 == 0);
+    return ok ? 2 : 1;
 }
 
 int fill_common(ConvArgs& A, const spc_cube_f32* cube, const spc_mask* mask, const double* h_kernel,
@@ -99,10 +113,15 @@ int fill_common(ConvArgs& A, const spc_cube_f32* cube, const spc_mask* mask, con
     A.cube = cube->d_data;
     A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
-    for (int i = 0; i < kMaxTaps; ++i) A.k[i] = 0.f;
+    for (int i = 0; i < 64; ++i) A.k[i] = 0.f;
+    for (int i = 0; i < 130; ++i) A.kPS[i] = 0.f;
     if (R) {
         const int pad = (R - ntaps) / 2;
         for (int i = 0; i < ntaps; ++i) A.k[pad + i] = (float)h_kernel[i];
+        double acc = 0.0;                      // prefix / suffix sums of the float32 taps
+        for (int i = 0; i < R; ++i) { acc += (double)A.k[i]; A.kPS[2 * i] = (float)acc; }
+        acc = 0.0;
+        for (int i = R - 1; i >= 0; --i) { A.kPS[2 * i + 1] = (float)acc; acc += (double)A.k[i]; }
     }
     return SPC_OK;
 }
@@ -130,7 +149,7 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     rc = check_kernel(h_kernel, ntaps);
     if (rc) return rc;
     SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
-    const int R = pick_ring(ntaps);
+    const int R = pick_ring(h_kernel, ntaps);
     ConvArgs A{};
     rc = fill_common(A, cube, mask, h_kernel, ntaps, R);
     if (rc) return rc;
@@ -150,7 +169,12 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     nsplit = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
     hipStream_t st = (hipStream_t)stream;
-    if (R) return launch_ring<false>(R, A, st, grid, (A.mask.flags & SPC_MASK_ARRAY) != 0, false);
+    if (R) {
+        SPC_REQUIRE(cube->ny * cube->row_stride < (1LL << 29) && cube->ny * A.out_row_stride < (1LL << 29),
+                    "image plane too large for 32-bit buffer offsets");
+        const int vec = pick_vec(cube, A.mask, d_out, A.out_row_stride, A.out_plane_stride);
+        return launch_ring(R, A, st, vec, false);
+    }
     // wide kernels: generic path with the taps in device memory (rare fallback:
     // plain synchronous allocation/copy, released after the kernel has drained)
     float* d_k = nullptr;
@@ -177,7 +201,7 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
     rc = check_kernel(h_kernel, ntaps);
     if (rc) return rc;
     SPC_REQUIRE(out != nullptr && d_cen != nullptr, "NULL pointer argument");
-    const int R = pick_ring(ntaps);
+    const int R = pick_ring(h_kernel, ntaps);
     if (!R) {
         spc_set_error("fused smooth->moments supports up to %d taps (got %d); "
                       "materialise with spc_spectral_conv_f32 instead", kMaxTaps, ntaps);
@@ -191,10 +215,9 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
     A.mo = *out;
     A.mo_row_stride = out->out_row_stride ? out->out_row_stride : cube->nx;
     A.zchunk = cube->nz;
-    const int64_t ncols = cube->ny * cube->nx;
-    dim3 grid((unsigned)((ncols + 255) / 256), 1);
-    const bool ext = out->d_argmax || out->d_argmin || out->d_vmax || out->d_vmin;
-    return launch_ring<true>(R, A, (hipStream_t)stream, grid, (A.mask.flags & SPC_MASK_ARRAY) != 0, ext);
+    SPC_REQUIRE(cube->ny * cube->row_stride < (1LL << 29), "image plane too large for 32-bit buffer offsets");
+    const int vec = pick_vec(cube, A.mask, nullptr, 0, 0);
+    return launch_ring(R, A, (hipStream_t)stream, vec, true);
 }
 
 }  // extern "C"

@@ -1,14 +1,41 @@
 // Kernel templates of the ring-streaming spectral stencil; included by the
 // per-ring-size translation units spc_spectral_conv_r*.hip (one TU per R so
 // `make -j` builds the fully unrolled kernels in parallel).
+//
+// Ring streaming.  One lane owns VEC (1 or 2) adjacent spaxels and marches over
+// z.  The R = 2H+1 outputs that the newest input still contributes to live in R
+// (num, den) accumulator registers.  Every input is loaded ONCE; at step s it
+// is FMA-ed into all R slots (slot m holds the output of age a = (s-m) mod R
+// and takes weight k[2H-a]), then the oldest output (slot (s+1) mod R)
+// completes and is emitted.  The loop is unrolled by R ("one revolution") so
+// slots and weights are static registers.
+//
+// What bounds it: VALU issue, not HBM.  Measured on MI355X
+// (tests/micro/valu_rate.hip): a wave64 VALU instruction occupies its SIMD for
+// ~4 cycles whether it is v_fmac_f32, v_pk_fma_f32 or v_fma_f64.  Hence:
+//   * the FMAs are in-place `v_fmac_f32` inline asm with the weight in an SGPR:
+//     left alone, LLVM sinks each slot's FMA chain to its emission point (R-long
+//     dependent chains, twice the registers);
+//   * the NaN-renormalising denominator den = sum of the weights of the VALID
+//     samples is only FMA-ed in revolutions where some lane of the wavefront saw
+//     an invalid sample.  In an all-valid revolution each slot receives a known run
+//     of weights, i.e. a prefix / suffix sum of the kernel (kPS), added once per
+//     output instead of R FMAs;
+//   * ONE unrolled body with wave-uniform run-time flags: two specialised bodies
+//     (or a per-step validity branch) make the register allocator duplicate /
+//     copy the whole ring (measured: 2x VGPRs or 2R v_mov per step);
+//   * loads/stores go through buffer descriptors built from readfirstlane'd
+//     plane bases (no per-load 64-bit VGPR address, no waterfall loops).
+// Experiments that did NOT pay (kept out of the tree, numbers in DESIGN.md):
+// two spaxels per lane with v_pk_fma_f32 (register file -> occupancy 1),
+// per-step prefetch ring + per-step validity vote (phi copies of the ring).
 #pragma once
 #include "spc_common.h"
 #include <algorithm>
 
 namespace spc_sconv {
 
-
-constexpr int kMaxTaps = 65;
+constexpr int kMaxTaps = 63;                   // ring <= 63: the uniform-den vector has 64 lanes
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 struct ConvArgs {
@@ -23,7 +50,10 @@ struct ConvArgs {
     double dv, m1_add;
     spc_moment_outputs mo;
     int64_t mo_row_stride;
-    float k[kMaxTaps];         // padded to R taps, centred
+    alignas(8) float k[64];    // taps padded to R, centred
+    // kPS[2s]   = k[0] + ... + k[s]      (what a slot completing at step s collected this revolution)
+    // kPS[2s+1] = k[s+1] + ... + k[R-1]  (what a slot restarted at step s+1 will still collect)
+    float kPS[130];
 };
 
 // fused-moment running state of one spaxel
@@ -34,73 +64,124 @@ struct MomState {
     int imax = 0, imin = 0;
 };
 
-// One revolution of the ring: R consecutive input channels i0 .. i0+R-1.
-// FAST = every input is inside [0,nz) and every completing output inside
-// [zb,ze): no range predicates, which keeps the scalar register pressure low.
-template <int R, bool ARR, bool FUSE, bool EXT, bool SYM, bool FAST>
-__device__ __forceinline__ void ring_revolution(const ConvArgs& A, float2v (&acc)[R],
-                                                unsigned long long& inc_hist, MomState& ms,
-                                                const float* p, const uint8_t* pm, float* po,
-                                                int64_t i0, int64_t zb, int64_t ze) {
-    constexpr int H = R / 2;
-    const uint32_t flags = A.mask.flags;
-    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
-    float v[R];
-    unsigned char mk[R];
-    if (FAST) {
-        const float* q = p + i0 * A.plane_stride;
-        const uint8_t* qm = ARR ? pm + i0 * A.mask.plane_stride : nullptr;
-#pragma unroll
-        for (int s = 0; s < R; ++s) {
-            v[s] = __builtin_nontemporal_load(q);
-            q += A.plane_stride;
-            if (ARR) { mk[s] = __builtin_nontemporal_load(qm); qm += A.mask.plane_stride; }
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < R; ++s) {
-            const int64_t ic = min(max(i0 + s, (int64_t)0), A.nz - 1);
-            v[s] = p[ic * A.plane_stride];
-            if (ARR) mk[s] = pm[ic * A.mask.plane_stride];
-        }
+// ---- in-place FMA / MUL with a scalar (SGPR) weight -------------------------------------
+// VEC = 1: v_fmac_f32 acc, s_w, x
+// VEC = 2: v_pk_fma_f32 acc, s[w_pair], x, acc with op_sel picking ONE half of the pair for
+//          both packed lanes (so R weights need only R SGPRs, not 2R)
+__device__ __forceinline__ void fma_w(float& acc, const ConvArgs& A, int j, float x) {
+    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(A.k[j]), "v"(x));
+}
+__device__ __forceinline__ void mul_w(float& acc, const ConvArgs& A, int j, float x) {
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(acc) : "s"(A.k[j]), "v"(x));
+}
+__device__ __forceinline__ void fma_w(float2v& acc, const ConvArgs& A, int j, float2v x) {
+    const float2v wp = *reinterpret_cast<const float2v*>(&A.k[j & ~1]);
+    if (j & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wp), "v"(x));
+    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wp), "v"(x));
+}
+__device__ __forceinline__ void mul_w(float2v& acc, const ConvArgs& A, int j, float2v x) {
+    const float2v wp = *reinterpret_cast<const float2v*>(&A.k[j & ~1]);
+    if (j & 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(acc) : "s"(wp), "v"(x));
+    else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "s"(wp), "v"(x));
+}
+
+// Buffer descriptor over one plane.  The base must be wave-uniform AND provably
+// so, otherwise hipcc wraps every buffer op in a waterfall loop (guide T20):
+// pass both halves through readfirstlane.
+__device__ __forceinline__ auto plane_srd(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff,
+                                             0x00020000);
+}
+
+template <int VEC> struct Ld;
+template <> struct Ld<1> {
+    using T = float;
+    static __device__ __forceinline__ T data(const float* plane, int voff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_srd(plane), voff, 0, /*nt*/ 2));
     }
+    static __device__ __forceinline__ unsigned mask(const uint8_t* plane, int moff) {
+        return __builtin_amdgcn_raw_buffer_load_b8(plane_srd(plane), moff, 0, 2);
+    }
+    static __device__ __forceinline__ void store(float* plane, int voff, T v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), plane_srd(plane), voff, 0, 0);
+    }
+};
+template <> struct Ld<2> {
+    using T = float2v;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ T data(const float* plane, int voff) {
+        return __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(plane_srd(plane), voff, 0, 2));
+    }
+    static __device__ __forceinline__ unsigned mask(const uint8_t* plane, int moff) {
+        return __builtin_amdgcn_raw_buffer_load_b16(plane_srd(plane), moff, 0, 2);
+    }
+    static __device__ __forceinline__ void store(float* plane, int voff, T v) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), plane_srd(plane), voff, 0, 0);
+    }
+};
+
+// The R x R update + emission part of one revolution.
+//   v[s]  : classified input: the value when valid, NaN when invalid, 0 when out of range
+//   incb  : (FUSE only) bit s = sample s is in range and included by the mask
+// ALLV (wave-uniform, run-time): the wavefront's R samples are all valid ->
+// numerator FMAs only.
+template <int R, bool ARR, bool FUSE, bool EXT, bool SYM>
+__device__ __forceinline__ void ring_body(const ConvArgs& A, float (&num)[R], float (&den)[R],
+                                          const float (&v)[R], unsigned long long incb,
+                                          unsigned long long& inc_hist, MomState& ms, int voff_out, int i0,
+                                          int zb, int ze, const bool ALLV) {
+    constexpr int H = R / 2;
+    // slot 0 always restarts at step 0; after a GENERAL revolution its den is stale
+    if (ALLV) den[0] = 0.f;
+    // prefix/suffix sums are fetched one step ahead through an opaque index so that the
+    // 2R scalar loads are not all hoisted to the top (they would not fit the SGPR file)
+    int zo = 0;
+    float kp = 0.f, ks = 0.f, kp_n = 0.f, ks_n = 0.f;
+    if (ALLV) { asm volatile("" : "+s"(zo)); kp_n = A.kPS[zo]; ks_n = A.kPS[1 + zo]; }
 #pragma unroll
     for (int s = 0; s < R; ++s) {
-        const int64_t i = i0 + s;
-        const bool inr = FAST ? true : ((i >= 0) && (i < A.nz));
-        bool inc = spc_pred(flags, tlo, thi, v[s]);
-        if (ARR) inc = inc && (mk[s] != 0);
-        inc = inc && inr;
-        // out-of-range samples are VALID ZEROS (boundary='fill', fill_value=0)
-        const bool ok = inr ? (inc && (v[s] == v[s])) : true;
-        float2v x2;
-        x2.x = (ok && inr) ? v[s] : 0.f;
-        x2.y = ok ? 1.f : 0.f;
-        inc_hist = (inc_hist << 1) | (inc ? 1ull : 0ull);
+        if (ALLV) {
+            kp = kp_n; ks = ks_n;
+            if (s + 1 < R) { asm volatile("" : "+s"(zo)); kp_n = A.kPS[2 * (s + 1) + zo]; ks_n = A.kPS[2 * (s + 1) + 1 + zo]; }
+        }
+        const bool ok = v[s] == v[s];
+        const float x = ok ? v[s] : 0.f;
 #pragma unroll
         for (int m = 0; m < R; ++m) {
-            const int a = (s - m + R) % R;      // age of the output living in slot m
-            // symmetric kernels: half the distinct weights -> they all stay in SGPRs
-            const float wgt = A.k[SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a];
-            const float2v w2 = float2v{wgt, wgt};
-            if (a == 0) acc[m] = w2 * x2;
-            else acc[m] = __builtin_elementwise_fma(w2, x2, acc[m]);
-            // pin the update here: without it LLVM sinks each slot's whole FMA
-            // chain down to its emission point -> R-long DEPENDENT chains with
-            // all R inputs live (200 VGPRs) instead of R independent FMAs/step
-            asm volatile("" : "+v"(acc[m]));
+            const int a = (s - m + R) % R;          // age of the output living in slot m
+            // symmetric kernels: half the distinct weights, all of them stay in SGPRs
+            const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
+            if (a == 0) mul_w(num[m], A, j, x);
+            else fma_w(num[m], A, j, x);
         }
-        // the output that just received its last contribution
-        const int64_t o = i - H;
-        if (FAST || (o >= zb && o < ze)) {
-            const float2v r = acc[(s + 1) % R];
-            const bool inc_o = ((inc_hist >> H) & 1ull) != 0ull;
-            float res;
-            if (r.y != 0.f) res = r.x * __builtin_amdgcn_rcpf(r.y);  // 1 ulp; tolerance is 1e-5
-            else res = inc_o ? p[o * A.plane_stride] : NAN;  // astropy: empty window -> (filled) centre sample
+        if (!ALLV) {
+            const float okf = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int a = (s - m + R) % R;
+                const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
+                if (a == 0) mul_w(den[m], A, j, okf);
+                else fma_w(den[m], A, j, okf);
+            }
+        }
+        if (FUSE) inc_hist = (inc_hist << 1) | ((incb >> s) & 1ull);
+        // ---- the output that just received its last contribution
+        const int e = (s + 1) % R;
+        const int o = i0 + s - H;
+        if (o >= zb && o < ze) {
+            const float dtot = ALLV ? den[e] + kp : den[e];
+            // astropy returns the (filled) centre sample for an empty window; the host
+            // only dispatches kernels with a non-zero centre tap here, for which an empty
+            // window implies an invalid centre, i.e. NaN.  rcp: 1 ulp, tolerance is 1e-5
+            const float res = (ALLV || dtot != 0.f) ? num[e] * __builtin_amdgcn_rcpf(dtot) : NAN;
             if (!FUSE) {
-                po[o * A.out_plane_stride] = res;
+                const auto ro = plane_srd(A.out + (int64_t)o * A.out_plane_stride);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res), ro, voff_out, 0, 0);
             } else {
+                const bool inc_o = ((inc_hist >> H) & 1ull) != 0ull;
                 const bool okm = inc_o && (res == res);
                 const double wd = okm ? (double)res : 0.0;
                 const double c = A.cen[o];
@@ -116,34 +197,59 @@ __device__ __forceinline__ void ring_revolution(const ConvArgs& A, float2v (&acc
                 }
             }
         }
+        // all-valid revolution: the slot restarts at step s+1 and will collect the
+        // weights k[R-1] .. k[s+1] (ages 0 .. R-2-s) before this revolution ends
+        if (ALLV) den[e] = (s < R - 1) ? ks : 0.f;
     }
 }
 
 template <int R, bool ARR, bool FUSE, bool EXT, bool SYM>
 __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
     constexpr int H = R / 2;
+    static_assert(R <= kMaxTaps, "ring too large for the 64-bit include word");
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ny * A.nx) return;
     const int64_t y = col / A.nx, x = col - y * A.nx;
-    const int64_t zb = (int64_t)blockIdx.y * A.zchunk;
-    const int64_t ze = min(A.nz, zb + A.zchunk);
-    const float* p = A.cube + y * A.row_stride + x;
-    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + x : nullptr;
-    float* po = FUSE ? nullptr : A.out + y * A.out_row_stride + x;
-
-    float2v acc[R];
+    const int nz = (int)A.nz;
+    const int zb = (int)(blockIdx.y * A.zchunk);
+    const int ze = min(nz, zb + (int)A.zchunk);
+    const int voff_out = FUSE ? 0 : (int)((y * A.out_row_stride + x) * 4);
+    const uint32_t flags = A.mask.flags;
+    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
+    const int voff = (int)((y * A.row_stride + x) * 4);              // < 2 GiB per plane (checked on the host)
+    const int moff = ARR ? (int)(y * A.mask.row_stride + x) : 0;
+    float num[R], den[R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) acc[m] = float2v{0.f, 0.f};
+    for (int m = 0; m < R; ++m) { num[m] = 0.f; den[m] = 0.f; }
     unsigned long long inc_hist = 0ull;  // include bit of the last 64 inputs (bit 0 = newest)
     MomState ms;
 
-    const int64_t T = (ze - zb) + 2 * H;  // number of input steps
-    for (int64_t t0 = 0; t0 < T; t0 += R) {
-        const int64_t i0 = zb - H + t0;
-        // all inputs in range and all R completing outputs (i0-H .. i0+R-1-H) wanted?
-        const bool fast = (i0 - H >= zb) && (i0 + R - 1 < A.nz) && (i0 + R - 1 - H < ze);
-        if (fast) ring_revolution<R, ARR, FUSE, EXT, SYM, true>(A, acc, inc_hist, ms, p, pm, po, i0, zb, ze);
-        else ring_revolution<R, ARR, FUSE, EXT, SYM, false>(A, acc, inc_hist, ms, p, pm, po, i0, zb, ze);
+    const int T = (ze - zb) + 2 * H;      // number of input steps
+    for (int t0 = 0; t0 < T; t0 += R) {
+        const int i0 = __builtin_amdgcn_readfirstlane(zb - H + t0);   // first input channel of this revolution
+        float v[R];
+        unsigned mk[R];
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const int64_t ic = min(max(i0 + s, 0), nz - 1);                  // clamped, uniform
+            v[s] = Ld<1>::data(A.cube + ic * A.plane_stride, voff);
+            if (ARR) mk[s] = Ld<1>::mask(A.mask.arr + ic * A.mask.plane_stride, moff);
+        }
+        // ---- classify: value | NaN (invalid) | 0 (out of range = valid zero, boundary='fill')
+        unsigned long long incb = 0ull;
+        bool bad = false;
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const bool in = (i0 + s >= 0) && (i0 + s < nz);                  // uniform
+            bool inc = spc_pred(flags, tlo, thi, v[s]);
+            if (ARR) inc = inc && (mk[s] != 0);
+            const bool ok = inc && (v[s] == v[s]);
+            bad = bad || (in && !ok);
+            v[s] = in ? (ok ? v[s] : NAN) : 0.f;
+            if (FUSE) incb |= ((in && inc) ? 1ull : 0ull) << s;
+        }
+        const bool allv = !__any(bad);
+        ring_body<R, ARR, FUSE, EXT, SYM>(A, num, den, v, incb, inc_hist, ms, voff_out, i0, zb, ze, allv);
     }
 
     if (FUSE) {
@@ -163,7 +269,6 @@ __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
     }
 }
 
-
 template <int R, bool FUSE, bool SYM>
 int launch_rs(const ConvArgs& A, hipStream_t st, dim3 grid, bool arr, bool ext) {
     dim3 block(256);
@@ -178,18 +283,18 @@ int launch_rs(const ConvArgs& A, hipStream_t st, dim3 grid, bool arr, bool ext) 
     return SPC_OK;
 }
 
-template <int R, bool FUSE>
-int launch_r(const ConvArgs& A, hipStream_t st, dim3 grid, bool arr, bool ext) {
-    bool sym = true;
-    for (int i = 0; i < R / 2; ++i) sym = sym && (A.k[i] == A.k[R - 1 - i]);
-    return sym ? launch_rs<R, FUSE, true>(A, st, grid, arr, ext) : launch_rs<R, FUSE, false>(A, st, grid, arr, ext);
-}
-
-
 // entry point instantiated once per ring size in spc_spectral_conv_r<R>.hip
 template <int R>
-int launch(const ConvArgs& A, hipStream_t st, dim3 grid, bool arr, bool fuse, bool ext) {
-    return fuse ? launch_r<R, true>(A, st, grid, arr, ext) : launch_r<R, false>(A, st, grid, arr, ext);
+int launch(const ConvArgs& A, hipStream_t st, int /*vec*/, bool fuse) {
+    bool sym = true;
+    for (int i = 0; i < R / 2; ++i) sym = sym && (A.k[i] == A.k[R - 1 - i]);
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    const bool ext = fuse && (A.mo.d_argmax || A.mo.d_argmin || A.mo.d_vmax || A.mo.d_vmin);
+    const int64_t ncols = A.ny * A.nx;
+    const int64_t nsplit = (A.nz + A.zchunk - 1) / A.zchunk;
+    dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)nsplit);
+    if (fuse) return sym ? launch_rs<R, true, true>(A, st, grid, arr, ext) : launch_rs<R, true, false>(A, st, grid, arr, ext);
+    return sym ? launch_rs<R, false, true>(A, st, grid, arr, ext) : launch_rs<R, false, false>(A, st, grid, arr, ext);
 }
 
 }  // namespace spc_sconv

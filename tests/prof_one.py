@@ -1,0 +1,27 @@
+"""Scratch: run ONE op a few times (for rocprofv3 counter passes)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
+import numpy as np
+from spectral_cube_amd import ops, _lib
+from spectral_cube_amd.device import DeviceArray, synchronize
+op = sys.argv[1]
+shape = tuple(int(s) for s in sys.argv[2:5]) if len(sys.argv) > 4 else (1024, 1024, 1024)
+reps = int(os.environ.get("REPS", 3))
+nz, ny, nx = shape
+rng = np.random.default_rng(0)
+cube = DeviceArray(shape, np.float32)
+for z in range(nz):
+    plane = rng.standard_normal((ny, nx), dtype=np.float32)
+    _lib.call("spc_memcpy_h2d", 0, C.c_void_p(cube.ptr + z * plane.nbytes), plane.ctypes.data_as(C.c_void_p), plane.nbytes, None)
+cen = DeviceArray.from_numpy((np.arange(nz) - nz // 2) * 500.0)
+g = np.exp(-0.5 * (np.arange(-16, 17) / 4.0) ** 2); g /= g.sum()
+g29 = np.exp(-0.5 * (np.arange(-14, 15) / 3.397) ** 2); g29 /= g29.sum()
+out = DeviceArray(shape, np.float32)
+for _ in range(reps):
+    if op == "sconv": ops.spectral_conv(cube, g, out=out)
+    elif op == "sconv_fused": ops.spectral_conv_moments(cube, g, cen)
+    elif op == "spconv": ops.spatial_conv(cube, np.outer(g29, g29), out=out)
+    elif op == "moments": ops.moments(cube, cen)
+synchronize()
+print("done", op)

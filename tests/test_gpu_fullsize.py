@@ -1,0 +1,174 @@
+"""GPU parity at BASELINE.json's FULL sizes through size-independent
+properties: the full-size cube is a small seeded tile replicated on the device
+(D2D doubling, seconds), so the expected full-size result follows from the
+oracle's result on the tile by periodicity / linearity.  What this exercises
+that the small parity tests cannot: 64-bit offsets, >4 GiB planes-of-cube
+addressing, grid limits and multi-round scheduling at 1e9-1.7e10 voxels.
+"""
+import ctypes as C
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close
+from spectral_cube_amd import _lib, ops, synth, Gaussian1DKernel, Gaussian2DKernel
+from spectral_cube_amd.device import DeviceArray, device_info
+
+pytestmark = pytest.mark.gpu
+
+
+def _need(nbytes):
+    free = device_info(0)["free_mem"]
+    if free < nbytes * 1.05:
+        pytest.skip("needs %.0f GiB of HBM, %.0f GiB free" % (nbytes / 2**30, free / 2**30))
+
+
+def _replicate_rows(dev, tile, itemsize):
+    """dev: (nz, ny, nx) device array; tile: host (nz, ty, nx).  Fill rows by
+    uploading the tile once and doubling it along y with strided D2D copies."""
+    nz, ny, nx = dev.shape
+    ty = tile.shape[1]
+    assert ny % ty == 0
+    row = nx * itemsize
+    _lib.call("spc_memcpy3d_h2d", 0, C.c_void_p(dev.ptr), row, ny * row, tile.ctypes.data_as(C.c_void_p),
+              row, ty * row, row, ty, nz, None)
+    lib = _lib.load()
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    have = ty
+    while have < ny:
+        n = min(have, ny - have)
+        # hipMemcpy2D: nz "rows" of n*row bytes with pitch ny*row
+        rc = hip.hipMemcpy2D(C.c_void_p(dev.ptr + have * row), C.c_size_t(ny * row), C.c_void_p(dev.ptr),
+                             C.c_size_t(ny * row), C.c_size_t(n * row), C.c_size_t(nz), 3)
+        assert rc == 0, rc
+        have += n
+
+
+def _replicate_planes(dev, tile, itemsize):
+    """fill (nz, ny, nx) with tile (tz, ny, nx) repeated along z (D2D doubling)."""
+    nz, ny, nx = dev.shape
+    tz = tile.shape[0]
+    assert nz % tz == 0
+    plane = ny * nx * itemsize
+    _lib.call("spc_memcpy_h2d", 0, C.c_void_p(dev.ptr), tile.ctypes.data_as(C.c_void_p), tz * plane, None)
+    have = tz
+    while have < nz:
+        n = min(have, nz - have)
+        _lib.call("spc_memcpy_d2d", 0, C.c_void_p(dev.ptr + have * plane), C.c_void_p(dev.ptr), n * plane, None)
+        have += n
+
+
+def test_c2_moments_1024cubed_periodic_rows(gpu):
+    """configs[1]: 1024^3 fp32 + uint8 mask, fused moment 0/1/2 + argmax."""
+    shape, ty = (1024, 1024, 1024), 8
+    _need(shape[0] * shape[1] * shape[2] * 5)
+    tile = synth.gaussian_line_cube((shape[0], ty, shape[2]), synth.SEEDS["C2"], chunk_rows=ty)
+    tile[:, 2, 16:24] = np.nan
+    tmask = synth.boolean_mask(tile, synth.SEEDS["C2"])
+    cube, mask = DeviceArray(shape, np.float32), DeviceArray(shape, np.uint8)
+    _replicate_rows(cube, tile, 4)
+    _replicate_rows(mask, tmask, 1)
+    v = synth.spectral_axis(shape[0])
+    cen = v - v[0]
+    cref = cen[shape[0] // 2]
+    r = ops.moments(cube, DeviceArray.from_numpy(cen - cref), dv=500.0, m1_add=cref + v[0],
+                    mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mask), want=("m0", "m1", "m2", "argmax"))
+    e = O.moments012(tile, tmask.astype(bool), cen, 500.0, v[0])
+    ea = O.argmax(tile, tmask.astype(bool))
+    scales = (np.nanmax(np.abs(e[0])), 500.0 * shape[0], np.nanmax(np.abs(e[2])))
+    for k, exp, sc in zip(("m0", "m1", "m2"), e, scales):
+        got = r[k].get().reshape(shape[1] // ty, ty, shape[2])
+        assert np.array_equal(np.isnan(got[0]), np.isnan(exp))
+        assert np.array_equal(np.isnan(got), np.isnan(got[:1]).repeat(got.shape[0], 0))
+        ok = np.isfinite(exp)
+        assert np.abs(got[0][ok] - exp[ok]).max() <= 1e-5 * sc, k
+        assert np.array_equal(got[:, ok], got[:1, ok].repeat(got.shape[0], 0)), k + " not periodic"
+    am = r["argmax"].get().reshape(shape[1] // ty, ty, shape[2])
+    assert np.array_equal(am[0], ea) and np.array_equal(am, am[:1].repeat(am.shape[0], 0))
+
+
+def test_c3_spectral_smooth_moment1_2048cubed(gpu):
+    """configs[2]: 2048^3 fp32, spectral_smooth(Gaussian sigma=4) then moment1 (fused)."""
+    shape, ty = (2048, 2048, 2048), 2
+    _need(shape[0] * shape[1] * shape[2] * 4)
+    tile = synth.gaussian_line_cube((shape[0], ty, shape[2]), synth.SEEDS["C3"], chunk_rows=ty)
+    tile[100:140, 0, 5] = np.nan                     # a NaN run longer than the kernel
+    cube = DeviceArray(shape, np.float32)
+    _replicate_rows(cube, tile, 4)
+    k = Gaussian1DKernel(4).array
+    assert k.size == 33
+    v = synth.spectral_axis(shape[0])
+    cen = v - v[0]
+    cref = cen[shape[0] // 2]
+    r = ops.spectral_conv_moments(cube, k, DeviceArray.from_numpy(cen - cref), dv=500.0, m1_add=cref + v[0],
+                                  mask=ops.MaskSpec(_lib.MASK_FINITE), want=("m1",))
+    sm = O.spectral_smooth(tile, np.isfinite(tile), k)
+    exp = O.moment(sm, np.isfinite(tile), 1, cen, 500.0, world0=v[0])
+    got = r["m1"].get().reshape(shape[1] // ty, ty, shape[2])
+    assert_close(got[0], exp, atol=1e-5 * 500.0 * shape[0], what="C3 m1")
+    assert np.array_equal(got, got[:1].repeat(got.shape[0], 0)), "not periodic"
+
+
+def test_c4_spatial_smooth_moment0_4096x2048x2048(gpu):
+    """configs[3]: 4096x2048x2048 fp32 + uint8 mask, spatial_smooth FWHM=8 px
+    (29x29 Gaussian) then moment0.  Planes repeat with period 2, so the smoothed
+    cube is periodic in z and moment0 = (nz/2) * sum of the two smoothed planes."""
+    shape, tz = (4096, 2048, 2048), 2
+    _need(shape[0] * shape[1] * shape[2] * 9)
+    rng = np.random.default_rng(synth.SEEDS["C4"])
+    tile = rng.standard_normal((tz,) + shape[1:], dtype=np.float32) + 2.0
+    tmask = (rng.random((tz,) + shape[1:], dtype=np.float32) > 0.2).view(np.uint8)
+    tmask[:, :8, :8] = 0
+    cube, mask = DeviceArray(shape, np.float32), DeviceArray(shape, np.uint8)
+    _replicate_planes(cube, tile, 4)
+    _replicate_planes(mask, tmask, 1)
+    k2 = Gaussian2DKernel(8 / 2.3548200450309493).array
+    assert k2.shape == (29, 29)
+    mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=mask)
+    sm = ops.spatial_conv(cube, k2, mask=mspec)
+    cen = DeviceArray.from_numpy(np.zeros(shape[0]))
+    # the smoothed cube keeps the ORIGINAL mask
+    m0 = ops.moments(sm, cen, dv=500.0, mask=mspec, want=("m0",))["m0"].get()
+    # oracle on the 2-plane tile (windowed to keep the direct 841-tap numpy sum cheap)
+    win = (slice(None), slice(0, 96), slice(0, 160))
+    pad = 14
+    sub = (slice(None), slice(0, 96 + pad), slice(0, 160 + pad))
+    exp_sm = O.spatial_smooth(tile[sub], tmask[sub].astype(bool), k2)[win]
+    inc = tmask[win].astype(bool)
+    exp_m0 = (shape[0] // tz) * 500.0 * np.where(inc, exp_sm, 0.0).sum(axis=0)
+    exp_m0[~inc.any(axis=0)] = np.nan
+    got_planes = np.empty((tz, 96, 160), np.float32)
+    for z in range(tz):      # two smoothed planes from the far end of the cube (z = nz-2, nz-1)
+        row = np.empty((96, 2048), np.float32)
+        _lib.call("spc_memcpy_d2h", 0, row.ctypes.data_as(C.c_void_p),
+                  C.c_void_p(sm.ptr + ((shape[0] - tz + z) * shape[1] * shape[2]) * 4), row.nbytes, None)
+        got_planes[z] = row[:, :160]
+    assert_close(got_planes, exp_sm, atol=1e-5 * np.nanmax(np.abs(exp_sm)), what="C4 smoothed planes")
+    assert_close(m0[:96, :160], exp_m0, atol=2e-5 * np.nanmax(np.abs(exp_m0)), what="C4 moment0")
+
+
+def test_c5_spectral_interpolate_2048_to_4096(gpu):
+    """configs[4] (first half): 2048x1024x1024 -> 4096 channels."""
+    shape, ty = (2048, 1024, 1024), 2
+    _need(shape[0] * shape[1] * shape[2] * 12)
+    tile = synth.gaussian_line_cube((shape[0], ty, shape[2]), synth.SEEDS["C5"], chunk_rows=ty)
+    tile[700, 1, 9] = np.nan
+    cube = DeviceArray(shape, np.float32)
+    _replicate_rows(cube, tile, 4)
+    v = synth.spectral_axis(shape[0])
+    grid = np.linspace(v[0], v[-1], 4096)
+    lo, t, inv, rin, rout, fill = ops.lerp_plan(v, grid)
+    out = ops.spectral_lerp(cube, lo, t, inv, fill)
+    exp, _ = O.spectral_interpolate(tile, None, v, grid)
+    # compare rows 0..ty-1 and the last tile (rows ny-ty..ny-1) of a few channels + all channels of one row
+    full = np.empty((4096, 1024), np.float32)          # row y = ny - 1 of every output channel
+    lib = C.CDLL("libamdhip64.so")
+    rowb = 1024 * 4
+    rc = lib.hipMemcpy2D(full.ctypes.data_as(C.c_void_p), C.c_size_t(rowb),
+                         C.c_void_p(out.ptr + (shape[1] - 1) * rowb), C.c_size_t(shape[1] * rowb),
+                         C.c_size_t(rowb), C.c_size_t(4096), 2)
+    assert rc == 0
+    assert_close(full, exp[:, ty - 1, :], atol=1e-5 * np.nanmax(np.abs(exp)), what="C5 lerp last row")

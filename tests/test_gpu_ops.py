@@ -143,10 +143,12 @@ def _kernels():
     g = golden("kernels.npz")
     return {"g1": g["g1_1.000000"], "g4": g["g1_4.000000"], "g0.7": g["g1_0.700000"],
             "asym": np.array([0.05, 0.1, 0.4, 0.25, 0.15, 0.03, 0.02]),
-            "box5": g["box1_5"], "wide": np.hanning(81) + 0.01, "one": np.array([2.0])}
+            "box5": g["box1_5"], "wide": np.hanning(81) + 0.01, "one": np.array([2.0]),
+            "g7": g["g1_3.397287"] if "g1_3.397287" in g.files else g["g1_3.000000"],
+            "r33": np.hanning(33) + 0.02, "r63": np.hanning(63) + 0.02, "zc": np.array([0.5, 0.0, 0.5])}
 
 
-@pytest.mark.parametrize("kname", ["g1", "g4", "g0.7", "asym", "box5", "wide", "one"])
+@pytest.mark.parametrize("kname", ["g1", "g4", "g0.7", "asym", "box5", "wide", "one", "g7", "r33", "r63", "zc"])
 @pytest.mark.parametrize("shape", [(96, 9, 13), (40, 6, 5), (700, 4, 64)])
 def test_spectral_conv_vs_oracle(gpu, kname, shape):
     from spectral_cube_amd import ops
