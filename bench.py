@@ -128,7 +128,11 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    # launched by torch.distributed.run (even with one rank): take the distributed path,
+    # so that a 1-GPU box can exercise rendezvous + RCCL init + the all-gather stitch
+    distributed = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ
+                                and os.environ.get("SPC_BENCH_FORCE_DIST", "0") == "1")
+    if distributed:
         # torch first: its bundled HIP/RCCL runtime is then the single runtime of the
         # process (libspcube_hip.so binds to the already loaded sonames)
         import torch
@@ -161,7 +165,7 @@ def main():
 
     comm, stitch = None, "none"
     recv = None
-    if world > 1:
+    if distributed:
         try:
             comm = RcclComm(device, rank, world, torch_bcast_bytes())
             stitch = "rccl"
@@ -179,16 +183,15 @@ def main():
             stitch = "gloo-host-fallback"
         # one contiguous send buffer holding the three strips, one receive buffer
         send = DeviceArray((3, ny, nx), np.float64, device)
-        out = {k: send.reshape((3 * ny, nx)).reshape((3, ny, nx)) for k in ("m0",)}  # placeholder
         out = {}
         for i, k in enumerate(("m0", "m1", "m2")):
             out[k] = DeviceArray((ny, nx), np.float64, device, ptr=send.ptr + i * ny * nx * 8, owner=send)
-        recv = DeviceArray((world, 3, ny, nx), np.float64, device)
+        recv = DeviceArray((world, 3, ny, nx), np.float64, device)   # map k of the full cube = recv[:, k] stacked along y
 
     def step():
         ops.moments(cube, d_cen, dv=500.0, m1_add=cref + v[0], mask=mask, want=("m0", "m1", "m2"),
                     stream=stream, workspace=ws, out=out)
-        if world > 1:
+        if distributed:
             if stitch == "rccl":
                 comm.allgather_rows_device(send, recv, stream)
             else:

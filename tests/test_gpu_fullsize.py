@@ -104,11 +104,19 @@ def test_c3_spectral_smooth_moment1_2048cubed(gpu):
     cen = v - v[0]
     cref = cen[shape[0] // 2]
     r = ops.spectral_conv_moments(cube, k, DeviceArray.from_numpy(cen - cref), dv=500.0, m1_add=cref + v[0],
-                                  mask=ops.MaskSpec(_lib.MASK_FINITE), want=("m1",))
-    sm = O.spectral_smooth(tile, np.isfinite(tile), k)
-    exp = O.moment(sm, np.isfinite(tile), 1, cen, 500.0, world0=v[0])
+                                  mask=ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_GT, 1.0), want=("m1",))
+    with np.errstate(invalid="ignore"):
+        inc = np.isfinite(tile) & (tile > np.float32(1.0))     # data > 2*noise keeps the line, like C2's mask
+    sm = O.spectral_smooth(tile, inc, k)
+    exp = O.moment(sm, inc, 1, cen, 500.0, world0=v[0])
     got = r["m1"].get().reshape(shape[1] // ty, ty, shape[2])
-    assert_close(got[0], exp, atol=1e-5 * 500.0 * shape[0], what="C3 m1")
+    assert np.array_equal(np.isnan(got[0]), np.isnan(exp))
+    # moment 1 = S1/S0 is ill-conditioned where the unmasked noise sums to S0 ~ 0
+    # (SURVEY.md section 7 "parity metric"): compare the well-conditioned spaxels
+    s0 = O.moment(sm, inc, 0, cen, 1.0)
+    wc = np.abs(s0) > 5.0
+    assert wc.mean() > 0.5
+    assert np.abs(got[0][wc] - exp[wc]).max() <= 1e-5 * 500.0 * shape[0]
     assert np.array_equal(got, got[:1].repeat(got.shape[0], 0)), "not periodic"
 
 
