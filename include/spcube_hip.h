@@ -177,11 +177,14 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube,
 /* fused spectral_smooth -> moments (legal because the Dask smooth is lazy and
  * keeps the ORIGINAL mask, dask_spectral_cube.py:836-840): the smoothed cube
  * is never written.  Semantics = spc_spectral_conv_f32 followed by
- * spc_moments_f32 with the same mask re-applied to the smoothed values. */
+ * spc_moments_f32 with the same mask re-applied to the smoothed values.
+ * h_cen: optional HOST copy of d_cen (nz doubles, may be NULL); when it shows
+ * the axis is linear the kernel derives the offsets from the channel index
+ * instead of loading them (every FITS spectral axis is linear). */
 int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* cube,
                                   const spc_mask* mask, const double* h_kernel,
-                                  int ntaps, const double* d_cen, double dv,
-                                  double m1_add, const spc_moment_outputs* out);
+                                  int ntaps, const double* d_cen, const double* h_cen,
+                                  double dv, double m1_add, const spc_moment_outputs* out);
 
 /* spatial: replaces the per-channel 2-D convolution of spatial_smooth
  * (dask_spectral_cube.py:962-993 + :540-547; NumPy twin spectral_cube.py

@@ -96,7 +96,7 @@ SIGNATURES = {
     "spc_moment_order_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _vp, _i, _vp, _vp, _vp, _i64]),
     "spc_moments_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _d, _vp, _vp, _vp]),
     "spc_spectral_conv_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _i64, _i64]),
-    "spc_spectral_conv_moments_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _d, _d,
+    "spc_spectral_conv_moments_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _P(_d), _d, _d,
                                            _P(SpcMomentOutputs)]),
     "spc_spatial_conv_sep_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _P(_d), _i,
                                       _vp, _i64, _i64]),

@@ -36,34 +36,69 @@ __device__ __forceinline__ float load_filled(const float* p, const uint8_t* pm, 
     return inc ? v : NAN;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+template <int VEC> struct LV { using F = float; };
+template <> struct LV<4> { using F = f32x4; };
+__device__ __forceinline__ float lget(const float& v, int) { return v; }
+__device__ __forceinline__ float lget(const f32x4& v, int i) { return v[i]; }
+__device__ __forceinline__ void lset(float& v, int, float x) { v = x; }
+__device__ __forceinline__ void lset(f32x4& v, int i, float x) { v[i] = x; }
+
+// VEC consecutive x per lane (16-byte loads/stores when the rows allow it)
+template <int VEC>
+__device__ __forceinline__ typename LV<VEC>::F load_filled_v(const float* p, const uint8_t* pm, const MaskDev& m,
+                                                             int64_t off, int64_t moff) {
+    using F = typename LV<VEC>::F;
+    F v = __builtin_nontemporal_load(reinterpret_cast<const F*>(p + off));
+    if (m.flags) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const float x = lget(v, i);
+            bool inc = spc_pred(m.flags, m.thr_lo, m.thr_hi, x);
+            if (pm) inc = inc && pm[moff + i] != 0;
+            lset(v, i, inc ? x : NAN);
+        }
+    }
+    return v;
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void spectral_lerp_kernel(const LerpArgs A) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= A.ny * A.nx) return;
-    const int64_t y = col / A.nx, x = col - y * A.nx;
+    using F = typename LV<VEC>::F;
+    const int64_t gpr = A.nx / VEC;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.ny * gpr) return;
+    const int64_t y = g / gpr, x = (g - y * gpr) * VEC;
     const float* p = A.cube + y * A.row_stride + x;
     const uint8_t* pm = (A.mask.flags & SPC_MASK_ARRAY) ? A.mask.arr + y * A.mask.row_stride + x : nullptr;
     float* po = A.out + y * A.out_row_stride + x;
     const int64_t jb = (int64_t)blockIdx.y * A.jchunk;
     const int64_t je = min(A.nz_out, jb + A.jchunk);
     int cur = -2;
-    float ylo = 0.f, yhi = 0.f;
+    F ylo{}, yhi{};
     for (int64_t j = jb; j < je; ++j) {
         const int lo = A.lo[j];          // wave-uniform
-        float res;
+        F res;
         if (lo < 0) {
-            res = A.fill;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) lset(res, i, A.fill);
         } else {
             if (lo != cur) {
                 if (lo == cur + 1) ylo = yhi;
-                else ylo = load_filled(p, pm, A.mask, (int64_t)lo * A.plane_stride, (int64_t)lo * A.mask.plane_stride);
-                yhi = load_filled(p, pm, A.mask, (int64_t)(lo + 1) * A.plane_stride, (int64_t)(lo + 1) * A.mask.plane_stride);
+                else ylo = load_filled_v<VEC>(p, pm, A.mask, (int64_t)lo * A.plane_stride, (int64_t)lo * A.mask.plane_stride);
+                yhi = load_filled_v<VEC>(p, pm, A.mask, (int64_t)(lo + 1) * A.plane_stride, (int64_t)(lo + 1) * A.mask.plane_stride);
                 cur = lo;
             }
             // scipy: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x_new - x_lo) + y_lo
-            const float diff = yhi - ylo;                 // float32 like numpy's f32 - f32
-            res = (float)((double)diff * A.inv_dx[j] * A.t[j] + (double)ylo);
+            const double wj = A.inv_dx[j] * A.t[j];
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                const float diff = lget(yhi, i) - lget(ylo, i);       // float32 like numpy's f32 - f32
+                lset(res, i, (float)((double)diff * wj + (double)lget(ylo, i)));
+            }
         }
-        po[j * A.out_plane_stride] = res;
+        __builtin_nontemporal_store(res, reinterpret_cast<F*>(po + j * A.out_plane_stride));
     }
 }
 
@@ -155,14 +190,18 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube, co
     A.out = d_out;
     A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
     A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
-    const int64_t ncols = cube->ny * cube->nx;
+    const bool v4 = (cube->nx % 4 == 0) && (cube->row_stride % 4 == 0) && (cube->plane_stride % 4 == 0) &&
+                    (A.out_row_stride % 4 == 0) && (A.out_plane_stride % 4 == 0) &&
+                    (((uintptr_t)cube->d_data) % 16 == 0) && (((uintptr_t)d_out) % 16 == 0);
+    const int64_t ncols = cube->ny * (cube->nx / (v4 ? 4 : 1));
     const int64_t nblocks = (ncols + 255) / 256;
     int nsplit = 1;
     if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, nz_out / 16));
     A.jchunk = (nz_out + nsplit - 1) / nsplit;
     nsplit = (int)((nz_out + A.jchunk - 1) / A.jchunk);
-    hipLaunchKernelGGL(spectral_lerp_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0,
-                       (hipStream_t)stream, A);
+    dim3 grid((unsigned)nblocks, (unsigned)nsplit);
+    if (v4) hipLaunchKernelGGL(spectral_lerp_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(spectral_lerp_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }

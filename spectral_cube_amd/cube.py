@@ -308,7 +308,8 @@ class SpectralCube:
         if fused_kernel is not None:
             parent, karr = fused_kernel
             return ops.spectral_conv_moments(parent._device_data(), karr, d_cen, dv=dv,
-                                             m1_add=cref + spec0, mask=parent._mask_spec(), want=want)
+                                             m1_add=cref + spec0, mask=parent._mask_spec(), want=want,
+                                             cen_host=cen - cref)
         return ops.moments(self._device_data(), d_cen, dv=dv, m1_add=cref + spec0,
                            mask=self._mask_spec(), want=want)
 

@@ -153,14 +153,19 @@ def spectral_conv(cube, kernel1d, mask=None, out=None, stream=None):
 
 
 def spectral_conv_moments(cube, kernel1d, cen, dv=1.0, m1_add=0.0, mask=None, want=_WANT_ALL,
-                          stream=None, out=None):
-    """fused spectral_smooth -> moment (smoothed cube never written)."""
+                          stream=None, out=None, cen_host=None):
+    """fused spectral_smooth -> moment (smoothed cube never written).
+    cen_host: optional host copy of *cen* (lets the kernel use the linear-axis form)."""
     nz, ny, nx = cube.shape
     o, bufs = _moment_outputs((ny, nx), cube.device, want, out)
     k, kp = _kern(kernel1d)
     c, m = _cube_c(cube), _mask_c(mask, cube)
+    hc = None
+    if cen_host is not None:
+        cen_host = np.ascontiguousarray(cen_host, dtype=np.float64)
+        hc = cen_host.ctypes.data_as(C.POINTER(C.c_double))
     _lib.call("spc_spectral_conv_moments_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), kp,
-              len(k), C.c_void_p(cen.ptr), float(dv), float(m1_add), C.byref(o))
+              len(k), C.c_void_p(cen.ptr), hc, float(dv), float(m1_add), C.byref(o))
     return bufs
 
 

@@ -104,7 +104,8 @@ def test_c3_spectral_smooth_moment1_2048cubed(gpu):
     cen = v - v[0]
     cref = cen[shape[0] // 2]
     r = ops.spectral_conv_moments(cube, k, DeviceArray.from_numpy(cen - cref), dv=500.0, m1_add=cref + v[0],
-                                  mask=ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_GT, 1.0), want=("m1",))
+                                  mask=ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_GT, 1.0), want=("m1",),
+                                  cen_host=cen - cref)
     with np.errstate(invalid="ignore"):
         inc = np.isfinite(tile) & (tile > np.float32(1.0))     # data > 2*noise keeps the line, like C2's mask
     sm = O.spectral_smooth(tile, inc, k)

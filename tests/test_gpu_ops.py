@@ -194,7 +194,8 @@ def test_spectral_conv_moments_fused(gpu, kname):
         # the smoothed cube carries the ORIGINAL mask (mask staleness)
         e0, e1, e2 = O.moments012(sm, m, cen, 500.0, v[0])
         r = ops.spectral_conv_moments(_dev(d), k, _dev(cen - cref), dv=500.0, m1_add=cref + v[0],
-                                      mask=_mspec(m), want=("m0", "m1", "m2", "argmax"))
+                                      mask=_mspec(m), want=("m0", "m1", "m2", "argmax"),
+                                      cen_host=(cen - cref) if kname != "asym" else None)   # linear-axis and table forms
         with np.errstate(all="ignore"):
             assert_close(r["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="fused m0")
             assert_close(r["m1"].get(), e1, atol=1e-5 * 500.0 * shape[0], what="fused m1")
