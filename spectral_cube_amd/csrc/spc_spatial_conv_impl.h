@@ -20,21 +20,182 @@ struct SpArgs {
     int64_t out_row_stride, out_plane_stride;
     int64_t ychunk;                           // output rows per blockIdx.z slice
     int txo;                                  // output columns per strip
-    float ky[kMaxTaps];                       // padded to RY, centred
-    float kx[kMaxTaps];                       // padded to RX, centred
+    // all-valid fast pass: one byte per (plane, 480-column strip) tile, 0 = done by the fast kernel
+    unsigned char* status;
+    int fast_nstrips;
+    float inv_ksum;                           // 1 / (sum(ky) * sum(kx))
+    alignas(8) float ky[kMaxTaps + 1];        // padded to RY, centred (read pairwise as 64-bit scalars)
+    alignas(8) float kx[kMaxTaps + 1];        // padded to RX, centred
 };
+
+// packed FMA / MUL with ONE half of an SGPR pair broadcast to both lanes (see
+// spc_spectral_conv_impl.h): R weights live in R SGPRs
+__device__ __forceinline__ void pk_fma_w(float2v& acc, const float* karr, int j, float2v x) {
+    const float2v wp = *reinterpret_cast<const float2v*>(&karr[j & ~1]);
+    if (j & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wp), "v"(x));
+    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wp), "v"(x));
+}
+__device__ __forceinline__ void pk_mul_w(float2v& acc, const float* karr, int j, float2v x) {
+    const float2v wp = *reinterpret_cast<const float2v*>(&karr[j & ~1]);
+    if (j & 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(acc) : "s"(wp), "v"(x));
+    else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "s"(wp), "v"(x));
+}
+
+constexpr int kFastCols = 512;                // input columns per block of the fast kernel (2 per lane)
+constexpr int fast_txo(int R) { return ((kFastCols - 2 * (R / 2)) / 16) * 16; }
+
+// ---- all-valid fast kernel -----------------------------------------------------------
+// Speculative first pass for planes without invalid samples: out = (Gy * Gx * d) / (sum ky *
+// sum kx), astropy's NaN-free branch.  One block = one channel x a strip of 480 output
+// columns, streaming down the rows.
+//   y pass: lane <-> 2 adjacent input columns, register ring of R packed numerators, one
+//           v_pk_fma_f32 per tap and column pair; finished rows go to LDS (float rows,
+//           9-per-8 padded, pitch chosen so that a wave's tasks never share a bank);
+//   x pass: after every revolution (R rows), a task = (row pair, run of 8 columns): the two
+//           rows are packed into one v_pk_fma_f32 per tap (same scalar weight for both), i.e.
+//           14.5 FMA instructions per voxel in each direction instead of 29 + 29.
+// A block that meets an invalid sample marks its tile dirty and quits; the general kernel then
+// redoes the dirty tiles.
+template <int R>
+__global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs A) {
+    constexpr int H = R / 2;
+    constexpr int kTxoF = fast_txo(R);
+    constexpr int kPitchF = 590;                          // floats per LDS row; 2*pitch = 28 (mod 32)
+    constexpr int kRows = R + (R & 1);                    // rows per revolution rounded up to pairs
+    static_assert(kPitchF >= kFastCols + kFastCols / 8, "LDS row too short");
+    __shared__ float yrow[kRows * kPitchF];
+
+    const int t = threadIdx.x;
+    const int64_t z = blockIdx.y;
+    const int strip = blockIdx.x;
+    const int64_t x0 = (int64_t)strip * kTxoF;            // first output column of the strip
+    const int64_t xin = x0 - H + 2 * t;                   // first of this lane's two input columns
+    const bool col_in = (xin >= 0) && (xin + 1 < A.nx);
+    const int64_t xc = min(max(xin, (int64_t)0), A.nx - 2);
+    const float* p = A.cube + z * A.plane_stride + xc;
+    const uint32_t flags = A.mask.flags;
+    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
+    const int ny = (int)A.ny;
+    const int c0 = 2 * t, c1 = 2 * t + 1;
+    const int ph0 = c0 + (c0 >> 3), ph1 = c1 + (c1 >> 3);
+
+    float2v num[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) num[m] = float2v{0.f, 0.f};
+
+    const int T = ny + 2 * H;
+    for (int t0 = 0; t0 < T; t0 += R) {
+        const int i0 = t0 - H;                            // first input row of this revolution
+        float2v v[R];
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const int64_t ic = min(max(i0 + s, 0), ny - 1);
+            v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
+        }
+        bool bad = false;
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float r = v[s][c];
+                bad = bad || (in && !(spc_pred(flags, tlo, thi, r) && (r == r)));
+            }
+            if (!in) v[s] = float2v{0.f, 0.f};           // out of bounds = valid zero
+        }
+        if (__syncthreads_or(bad ? 1 : 0)) {             // block-uniform: hand the tile to the general kernel
+            if (t == 0) A.status[z * A.fast_nstrips + strip] = 1;
+            return;
+        }
+        // ---- y pass
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int a = (s - m + R) % R;
+                if (a == 0) pk_mul_w(num[m], A.ky, 2 * H - a, v[s]);
+                else pk_fma_w(num[m], A.ky, 2 * H - a, v[s]);
+            }
+            const float2v done = num[(s + 1) % R];       // row o = i0 + s - H
+            yrow[s * kPitchF + ph0] = done.x;
+            yrow[s * kPitchF + ph1] = done.y;
+        }
+        __syncthreads();
+        // ---- x pass: task = (row pair, run of kRun output columns)
+        constexpr int nrun = kTxoF / kRun;
+        for (int task = t; task < (kRows / 2) * nrun; task += kThreads) {
+            const int pr = task / nrun;
+            const int j = task - pr * nrun;
+            const int sa = 2 * pr, sb = 2 * pr + 1;
+            const int oa = i0 + sa - H, ob = oa + 1;
+            const bool wa = (oa >= 0) && (oa < ny), wb = (sb < R) && (ob >= 0) && (ob < ny);
+            if (!wa && !wb) continue;
+            const float* ra = yrow + sa * kPitchF;
+            const float* rb = yrow + (sb < R ? sb : sa) * kPitchF;
+            float2v r[kRun];
+#pragma unroll
+            for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < kRun + 2 * H; ++i) {
+                const int c = kRun * j + i;
+                const int ph = c + (c >> 3);
+                const float2v in = float2v{ra[ph], rb[ph]};
+#pragma unroll
+                for (int k = 0; k < kRun; ++k) {
+                    const int widx = k + 2 * H - i;
+                    if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], A.kx, widx, in);
+                }
+            }
+            const int64_t xo = x0 + kRun * j;
+            float* da = A.out + z * A.out_plane_stride + (int64_t)oa * A.out_row_stride + xo;
+            float* db = da + A.out_row_stride;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            if (xo + kRun <= A.nx) {
+                if (wa) {
+                    __builtin_nontemporal_store(f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da));
+                    __builtin_nontemporal_store(f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da + 4));
+                }
+                if (wb) {
+                    __builtin_nontemporal_store(f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db));
+                    __builtin_nontemporal_store(f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db + 4));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < kRun; ++k) {
+                    if (xo + k < A.nx) {
+                        if (wa) da[k] = r[k].x * A.inv_ksum;
+                        if (wb) db[k] = r[k].y * A.inv_ksum;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 
 __device__ __forceinline__ int lds_phys(int t) { return t + (t >> 3); }   // 9-per-8 padding
 
 template <int RY, int RX, bool ARR, bool SYM>
 __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
     constexpr int HY = RY / 2, HX = RX / 2;
-    constexpr int kPitch = kThreads + kThreads / 8 + 2;   // float2 per LDS row
+    // float2 per LDS row.  Pitch = 28 (mod 32): a 32-lane group of the x pass spans parts of
+    // two rows (28 runs per row); with this pitch the second row's runs continue the first
+    // row's 18-dword bank progression instead of landing on the same banks (the previous
+    // pitch of 290 made every x-pass ds_read_b64 2-way conflicted - SQ_LDS_BANK_CONFLICT
+    // was twice SQ_ACTIVE_INST_LDS)
+    constexpr int kPitch = (RY <= 33) ? 316 : 290;     // the 65-tap ring only fits LDS with the short pitch
+    static_assert(kPitch >= kThreads + kThreads / 8, "LDS row too short");
     __shared__ float2v yres[RY * kPitch];
 
     const int t = threadIdx.x;
     const int64_t z = blockIdx.y;
     const int64_t x0 = (int64_t)blockIdx.x * A.txo;       // first output column of the strip
+    if (A.status) {   // both fast tiles this strip overlaps were finished by the all-valid kernel
+        const int ft = fast_txo(RX);
+        const int f0 = (int)(x0 / ft), f1 = (int)(min(x0 + A.txo, A.nx) - 1) / ft;
+        if (A.status[z * A.fast_nstrips + f0] == 0 && A.status[z * A.fast_nstrips + f1] == 0) return;
+    }
     const int64_t yb = (int64_t)blockIdx.z * A.ychunk;
     const int64_t ye = min(A.ny, yb + A.ychunk);
     const int64_t xin = x0 - HX + t;                      // input column of this lane (y pass)
@@ -44,7 +205,8 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
     const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + xc : nullptr;
     const uint32_t flags = A.mask.flags;
     const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
-    const int nrun = A.txo / kRun;
+    constexpr int kTxo = ((kThreads - 2 * HX) / kRun) * kRun;   // output columns per strip (== A.txo)
+    constexpr int nrun = kTxo / kRun;                           // compile-time: no integer division per task
 
     float2v acc[RY];
 #pragma unroll
@@ -160,6 +322,13 @@ template <int R>
 int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
     const bool sym = is_sym(A.ky, R) && is_sym(A.kx, R);
     dim3 block(kThreads);
+    if constexpr (R <= 33) {
+        if (A.status) {      // speculative all-valid pass (the general kernel below redoes dirty tiles)
+            dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1);
+            hipLaunchKernelGGL((spatial_sep_fast_kernel<R>), fgrid, block, 0, st, A);
+            SPC_LAUNCH_CHECK();
+        }
+    }
     if (arr) {
         if (sym) hipLaunchKernelGGL((spatial_sep_kernel<R, R, true, true>), grid, block, 0, st, A);
         else hipLaunchKernelGGL((spatial_sep_kernel<R, R, true, false>), grid, block, 0, st, A);

@@ -227,6 +227,45 @@ def test_spatial_conv_sep_vs_oracle(gpu, sig, shape):
         assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="spatial conv")
 
 
+@pytest.mark.parametrize("sig", ["3.397287", "1.500000"])
+def test_spatial_conv_fast_path_clean_and_dirty_tiles(gpu, sig):
+    """nx >= 64, no mask array: the speculative all-valid kernel runs first; plane 0 is clean
+    (stays with the fast kernel), plane 1 has one NaN (tile handed to the general kernel),
+    plane 2 is clean again.  960 columns = two fast strips, the NaN sits in the second."""
+    from spectral_cube_amd import ops
+    k2 = golden("kernels.npz")["g2_" + sig]
+    rng = np.random.default_rng(23)
+    d = rng.standard_normal((3, 70, 960)).astype(np.float32)
+    d[1, 33, 700] = np.nan
+    out = ops.spatial_conv(_dev(d), k2).get()
+    g1 = golden("kernels.npz")["g1_" + sig]
+    # separable float64 reference for the clean planes (841-tap direct sums would take minutes here)
+    def sep(p):
+        pad = len(g1) // 2
+        a = np.pad(p.astype(np.float64), pad)
+        t = sum(g1[::-1][i] * a[i:i + p.shape[0], :] for i in range(len(g1)))
+        o = sum(g1[::-1][i] * t[:, i:i + p.shape[1]] for i in range(len(g1)))
+        return o / (g1.sum() ** 2)
+    for z in (0, 2):
+        exp = sep(d[z])
+        assert_close(out[z], exp, atol=1e-5 * np.abs(exp).max(), what="clean plane %d" % z)
+    win = (slice(1, 2), slice(10, 60), slice(640, 760))
+    exp = O.spatial_smooth(d[1:2, :, 600:800], None, k2)[:, 10:60, 40:160]
+    assert_close(out[win], exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="dirty plane window")
+
+
+def test_spectral_conv_fast_path_clean_and_dirty_tiles(gpu):
+    """even nx, no mask array: columns 0..127 (tile 0) are clean, tile 1 has a NaN."""
+    from spectral_cube_amd import ops
+    k = _kernels()["g4"]
+    rng = np.random.default_rng(24)
+    d = rng.standard_normal((200, 2, 256)).astype(np.float32)
+    d[50:55, 0, 200] = np.nan
+    out = ops.spectral_conv(_dev(d), k).get()
+    exp = O.spectral_smooth(d, None, k)
+    assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="fast/dirty tiles")
+
+
 def test_spatial_conv_golden(gpu):
     from spectral_cube_amd import ops
     g = golden("spatial_smooth.npz")
