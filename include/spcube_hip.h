@@ -111,6 +111,7 @@ int spc_event_create(int device, void** event);
 int spc_event_destroy(int device, void* event);
 int spc_event_record(int device, void* event, void* stream);
 int spc_event_sync(int device, void* event);
+int spc_stream_wait_event(int device, void* stream, void* event);   /* hipStreamWaitEvent */
 int spc_event_elapsed_ms(int device, void* start, void* stop, float* ms);
 
 /* ---- moments ------------------------------------------------------------

@@ -89,6 +89,7 @@ SIGNATURES = {
     "spc_event_destroy": (_i, [_i, _vp]),
     "spc_event_record": (_i, [_i, _vp, _vp]),
     "spc_event_sync": (_i, [_i, _vp]),
+    "spc_stream_wait_event": (_i, [_i, _vp, _vp]),
     "spc_event_elapsed_ms": (_i, [_i, _vp, _vp, _P(_f)]),
     "spc_moments_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "spc_moments_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _vp, _d, _d,

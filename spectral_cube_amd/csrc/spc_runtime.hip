@@ -174,6 +174,11 @@ int spc_event_sync(int device, void* event) {
     SPC_HIP(hipEventSynchronize((hipEvent_t)event));
     return SPC_OK;
 }
+int spc_stream_wait_event(int device, void* stream, void* event) {
+    SPC_DEVICE(device);
+    SPC_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return SPC_OK;
+}
 int spc_event_elapsed_ms(int device, void* start, void* stop, float* ms) {
     SPC_REQUIRE(ms, "ms is NULL");
     SPC_DEVICE(device);

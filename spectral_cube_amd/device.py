@@ -17,6 +17,10 @@ class Stream:
     def synchronize(self):
         _lib.call("spc_stream_sync", self.device, self.handle)
 
+    def wait_event(self, event):
+        """make later work on this stream wait for *event* (hipStreamWaitEvent)"""
+        _lib.call("spc_stream_wait_event", self.device, self.handle, event.handle)
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
