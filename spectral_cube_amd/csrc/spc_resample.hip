@@ -116,10 +116,17 @@ struct BilArgs {
     int64_t zchunk;
 };
 
+// Lane <-> output pixel of a 16 x 4 tile per wavefront (a 64 x 16 tile per block): the
+// source footprint of a compact tile touches ~3x fewer cache lines per gather than a
+// 64-pixel output row does for a rotated grid, while stores stay 64 B contiguous per row.
 __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
-    const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= A.ny_out * A.nx_out) return;
-    const int64_t yo = pix / A.nx_out, xo = pix - yo * A.nx_out;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tiles_x = (A.nx_out + 63) / 64;
+    const int64_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int64_t xo = bx * 64 + (wave * 16) + (lane & 15);
+    const int64_t yo = by * 4 + (lane >> 4);
+    if (xo >= A.nx_out || yo >= A.ny_out) return;
+    const int64_t pix = yo * A.nx_out + xo;
     const double xs = A.xs[pix], ys = A.ys[pix];
     const bool inside = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
     if (blockIdx.y == 0 && A.footprint) A.footprint[pix] = inside ? 1 : 0;
@@ -144,26 +151,38 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const int64_t m00 = y0 * A.mask.row_stride + x0, m01 = y0 * A.mask.row_stride + x1;
     const int64_t m10 = y1 * A.mask.row_stride + x0, m11 = y1 * A.mask.row_stride + x1;
     const bool anymask = A.mask.flags != 0;
-    for (int64_t z = zb; z < ze; ++z) {
-        const float* p = A.cube + z * A.plane_stride;
-        float a = p[o00], b = p[o01], c = p[o10], d = p[o11];
-        if (anymask) {
-            const uint8_t* pm = arr ? A.mask.arr + z * A.mask.plane_stride : nullptr;
-            // excluded voxels are replaced by the cube's fill value (spectral_cube.py:2709-2712)
-            bool i0 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, a);
-            bool i1 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, b);
-            bool i2 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
-            bool i3 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, d);
-            if (arr) { i0 = i0 && pm[m00]; i1 = i1 && pm[m01]; i2 = i2 && pm[m10]; i3 = i3 && pm[m11]; }
-            a = i0 ? a : A.fill; b = i1 ? b : A.fill; c = i2 ? c : A.fill; d = i3 ? d : A.fill;
+    constexpr int U = 4;                      // channels in flight per lane (8 measured slower)
+    for (int64_t zq = zb; zq < ze; zq += U) {
+        float a[U], b[U], c[U], d[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t z = min(zq + u, ze - 1);
+            const float* p = A.cube + z * A.plane_stride;
+            a[u] = p[o00]; b[u] = p[o01]; c[u] = p[o10]; d[u] = p[o11];
         }
-        // zero-weight neighbours must not leak NaN/inf (0*NaN) into exact hits
-        float r = 0.f;
-        if (w00 != 0.f) r = fmaf(w00, a, r);
-        if (w01 != 0.f) r = fmaf(w01, b, r);
-        if (w10 != 0.f) r = fmaf(w10, c, r);
-        if (w11 != 0.f) r = fmaf(w11, d, r);
-        po[z * A.out_plane_stride] = r;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t z = zq + u;
+            if (z >= ze) break;
+            float aa = a[u], bb = b[u], cc = c[u], dd = d[u];
+            if (anymask) {
+                const uint8_t* pm = arr ? A.mask.arr + z * A.mask.plane_stride : nullptr;
+                // excluded voxels are replaced by the cube's fill value (spectral_cube.py:2709-2712)
+                bool i0 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, aa);
+                bool i1 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, bb);
+                bool i2 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, cc);
+                bool i3 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, dd);
+                if (arr) { i0 = i0 && pm[m00]; i1 = i1 && pm[m01]; i2 = i2 && pm[m10]; i3 = i3 && pm[m11]; }
+                aa = i0 ? aa : A.fill; bb = i1 ? bb : A.fill; cc = i2 ? cc : A.fill; dd = i3 ? dd : A.fill;
+            }
+            // zero-weight neighbours must not leak NaN/inf (0*NaN) into exact hits
+            float r = 0.f;
+            if (w00 != 0.f) r = fmaf(w00, aa, r);
+            if (w01 != 0.f) r = fmaf(w01, bb, r);
+            if (w10 != 0.f) r = fmaf(w10, cc, r);
+            if (w11 != 0.f) r = fmaf(w11, dd, r);
+            __builtin_nontemporal_store(r, po + z * A.out_plane_stride);
+        }
     }
 }
 
@@ -226,8 +245,7 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     A.out_row_stride = out_row_stride ? out_row_stride : nx_out;
     A.out_plane_stride = out_plane_stride ? out_plane_stride : ny_out * A.out_row_stride;
     A.footprint = d_footprint;
-    const int64_t npix = ny_out * nx_out;
-    const int64_t nblocks = (npix + 255) / 256;
+    const int64_t nblocks = ((nx_out + 63) / 64) * ((ny_out + 3) / 4);      // 64 x 4 pixel tiles
     int nsplit = 1;
     if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, cube->nz / 8));
     A.zchunk = (cube->nz + nsplit - 1) / nsplit;

@@ -331,15 +331,24 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
 #pragma unroll
         for (int s = 0; s < R; ++s) v[s] = ld2_soff(rs, voff, (min(max(i0 + s, 0), nz - 1) - pb) * pbytes);
         bool bad = false;
+        if (flags == 0) {                                // no predicate mask: only NaNs are invalid
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
-            const bool in = (i0 + s >= 0) && (i0 + s < nz);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const float r = v[s][c];
-                bad = bad || (in && !(spc_pred(flags, tlo, thi, r) && (r == r)));
+            for (int s = 0; s < R; ++s) {
+                const bool in = (i0 + s >= 0) && (i0 + s < nz);
+                bad = bad || (in && !((v[s].x == v[s].x) && (v[s].y == v[s].y)));
+                if (!in) v[s] = float2v{0.f, 0.f};      // out of range = valid zero
             }
-            if (!in) v[s] = float2v{0.f, 0.f};          // out of range = valid zero
+        } else {
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const bool in = (i0 + s >= 0) && (i0 + s < nz);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float r = v[s][c];
+                    bad = bad || (in && !(spc_pred(flags, tlo, thi, r) && (r == r)));
+                }
+                if (!in) v[s] = float2v{0.f, 0.f};
+            }
         }
         if (__any(bad && live)) {                        // wave-uniform: hand the tile to the general kernel
             if ((threadIdx.x & 63) == 0) A.status[tile] = 1;
