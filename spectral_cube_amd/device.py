@@ -106,6 +106,8 @@ class DeviceArray:
             _lib.call("spc_stream_sync", self.device, _sh(stream))   # `a` may be a temporary
 
     def get(self, stream=None):
+        if getattr(self, "_is_view", False):
+            raise ValueError("strided row view: copy through the parent array")
         out = np.empty(self.shape, dtype=self.dtype)
         if stream is not None:
             _lib.call("spc_stream_sync", self.device, _sh(stream))
@@ -113,8 +115,21 @@ class DeviceArray:
                   self.nbytes, None)
         return out
 
-    def view_rows(self, axis_len_before, start, stop):
-        raise NotImplementedError
+    def rows(self, y0, y1):
+        """view of rows [y0, y1) of a (nz, ny, nx) array: same row/plane strides as the
+        parent, no copy (what the C ABI's explicit strides are for)."""
+        if len(self.shape) != 3:
+            raise ValueError("rows() needs a (nz, ny, nx) array")
+        nz, ny, nx = self.shape
+        if not (0 <= y0 <= y1 <= ny):
+            raise ValueError("row range out of bounds")
+        v = DeviceArray((nz, y1 - y0, nx), self.dtype, self.device,
+                        ptr=self.ptr + y0 * nx * self.dtype.itemsize, owner=self)
+        v.row_stride = getattr(self, "row_stride", nx)
+        v.plane_stride = getattr(self, "plane_stride", ny * nx)
+        v.nbytes = 0            # not a contiguous buffer: upload()/get() are not available
+        v._is_view = True
+        return v
 
     def reshape(self, shape):
         shape = tuple(int(s) for s in shape)

@@ -34,6 +34,35 @@ def strip_rows(ny, world_size):
     return -(-ny // world_size)
 
 
+def halo_bounds(ny, world_size, rank, halo):
+    """Rows a rank must hold to smooth its strip spatially: the strip plus *halo* rows on
+    each side (clipped at the cube's edges).  Returns (h0, h1, top, nrows): the rank loads
+    rows [h0, h1), its own strip is rows [top, top + nrows) of that extended strip
+    (halo = kernel half width, 14 rows for the 29-tap config C4)."""
+    y0, y1 = strip_bounds(ny, world_size, rank)
+    h0, h1 = max(0, y0 - halo), min(ny, y1 + halo)
+    return h0, h1, y0 - h0, y1 - y0
+
+
+def smooth_moment0_strip(ext_cube, kernel2d, top, nrows, mask=None, dv=1.0, stream=None):
+    """spatial_smooth + moment0 of one rank's extended strip, all on the device.
+
+    ext_cube: (nz, h1-h0, nx) float32 DeviceArray holding the strip and its halo rows;
+    mask: MaskSpec for the same extended strip (or None).  The smoothed halo rows are
+    wrong (they see an artificial boundary) and are simply not reduced: the moment kernel
+    reads rows [top, top+nrows) in place through strides.  Returns the (nrows, nx)
+    float64 moment-0 strip (DeviceArray) - the only thing that is all-gathered.
+    The smoothed cube keeps the ORIGINAL mask (dask_spectral_cube.py:836-840)."""
+    from . import ops
+    sm = ops.spatial_conv(ext_cube, kernel2d, mask=mask, stream=stream)
+    nz = ext_cube.shape[0]
+    cen = DeviceArray.zeros((nz,), np.float64, ext_cube.device)
+    r = ops.moments(sm.rows(top, top + nrows), cen, dv=dv, want=("m0",), stream=stream,
+                    mask=mask.rows(top, top + nrows) if mask is not None else None)
+    r["_smoothed"] = sm
+    return r["m0"]
+
+
 class HostGatherComm:
     """all-gather of host strips through torch.distributed (gloo).  Used by the
     world_size-2 CPU tests and as the loud, explicitly reported stitch fallback

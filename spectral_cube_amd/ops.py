@@ -28,13 +28,20 @@ class MaskSpec:
         m.flags = self.flags
         m.thr_lo = self.thr_lo
         m.thr_hi = self.thr_hi
+        m.row_stride = 0
+        m.plane_stride = 0
         if self.flags & _lib.MASK_ARRAY:
             if self.array is None:
                 raise ValueError("MASK_ARRAY set without an array")
             m.d_array = self.array.ptr
-        m.row_stride = 0
-        m.plane_stride = 0
+            m.row_stride = getattr(self.array, "row_stride", 0)
+            m.plane_stride = getattr(self.array, "plane_stride", 0)
         return m
+
+    def rows(self, y0, y1):
+        """the same mask restricted to rows [y0, y1) (strided view of the array term)"""
+        return MaskSpec(self.flags, self.thr_lo, self.thr_hi,
+                        self.array.rows(y0, y1) if self.array is not None else None)
 
 
 def _cube_c(cube):
@@ -43,8 +50,8 @@ def _cube_c(cube):
     c = _lib.SpcCube()
     c.d_data = cube.ptr
     c.nz, c.ny, c.nx = cube.shape
-    c.row_stride = cube.shape[2]
-    c.plane_stride = cube.shape[1] * cube.shape[2]
+    c.row_stride = getattr(cube, "row_stride", cube.shape[2])          # DeviceArray.rows() views
+    c.plane_stride = getattr(cube, "plane_stride", cube.shape[1] * cube.shape[2])
     return c
 
 

@@ -313,3 +313,31 @@ def test_resample_bilinear(gpu):
     yy, xx = np.mgrid[0:48, 0:40]
     out, _ = ops.resample_bilinear(_dev(d), xx.astype(float), yy.astype(float))
     assert_close(out.get(), d, what="identity")
+
+
+def test_sharded_smooth_moment0_with_halos_matches_unsharded(gpu):
+    """config C4's pipeline (spatial_smooth -> moment0) sharded by row strips with 14-row
+    halos, the strips run one after the other on this GPU: the stitched map must equal the
+    unsharded map (strided row views through the C ABI, mask included)."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.distributed import halo_bounds, smooth_moment0_strip
+    k2 = golden("kernels.npz")["g2_3.397287"]
+    halo = k2.shape[0] // 2
+    rng = np.random.default_rng(31)
+    shape = (6, 96, 128)
+    d = (rng.standard_normal(shape) + 1.5).astype(np.float32)
+    d[2, 40:44, 60:64] = np.nan
+    inc = rng.random(shape) > 0.2
+    for m in (None, inc):
+        full = ops.spatial_conv(_dev(d), k2, mask=_mspec(m))
+        cen = _dev(np.zeros(shape[0]))
+        ref = ops.moments(full, cen, dv=2.0, mask=_mspec(m), want=("m0",))["m0"].get()
+        for ws in (2, 3):
+            strips = []
+            for r in range(ws):
+                h0, h1, top, n = halo_bounds(shape[1], ws, r, halo)
+                ext = _dev(np.ascontiguousarray(d[:, h0:h1]))
+                mext = _mspec(np.ascontiguousarray(m[:, h0:h1]) if m is not None else None)
+                strips.append(smooth_moment0_strip(ext, k2, top, n, mask=mext, dv=2.0).get())
+            got = np.concatenate(strips, axis=0)
+            assert_close(got, ref, atol=1e-5 * np.nanmax(np.abs(ref)), what="sharded smooth+moment0 ws=%d" % ws)

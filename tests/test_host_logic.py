@@ -220,3 +220,25 @@ def test_strip_bounds_cover_all_rows():
             rows = [strip_bounds(ny, ws, r) for r in range(ws)]
             assert rows[0][0] == 0 and rows[-1][1] == ny
             assert all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+
+
+def test_halo_bounds_reproduce_the_unsharded_smoothing():
+    """row-strip sharding of spatial_smooth: smoothing a strip extended by `halo` rows and
+    keeping rows [top, top+nrows) must equal the same rows of the unsharded result."""
+    import oracle_np as O
+    from spectral_cube_amd.distributed import halo_bounds
+    rng = np.random.default_rng(6)
+    d = rng.standard_normal((2, 41, 23)).astype(np.float32)
+    d[0, 20, 5] = np.nan
+    k2 = K.Gaussian2DKernel(1.0).array
+    halo = k2.shape[0] // 2
+    full = O.spatial_smooth(d, None, k2)
+    for ws in (1, 2, 3, 5):
+        got = []
+        for r in range(ws):
+            h0, h1, top, n = halo_bounds(d.shape[1], ws, r, halo)
+            part = O.spatial_smooth(d[:, h0:h1], None, k2)
+            got.append(part[:, top:top + n])
+        got = np.concatenate(got, axis=1)
+        assert np.array_equal(np.isnan(got), np.isnan(full))
+        np.testing.assert_array_equal(got[~np.isnan(full)], full[~np.isnan(full)])
