@@ -77,6 +77,28 @@ __global__ __launch_bounds__(256) void spatial_conv2d_kernel(const SpArgs A, con
     A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
 }
 
+// mask predicate -> |v| <= lim && !(v <= lo) && !(v >= hi); an absent bound is NaN (the negated
+// compare is then true for every v), >= / <= become strict compares against the neighbouring
+// float, a NaN threshold rejects everything (numpy: x > nan is False)
+void canonical_pred(SpArgs& A) {
+    const uint32_t f = A.mask.flags;
+    A.pred_lim = (f & SPC_MASK_FINITE) ? 3.402823466e+38f : INFINITY;
+    A.pred_lo = NAN;
+    A.pred_hi = NAN;
+    if (f & (SPC_MASK_GT | SPC_MASK_GE)) {
+        const float t = A.mask.thr_lo;
+        if (t != t) A.pred_lim = -1.f;
+        else if (f & SPC_MASK_GT) A.pred_lo = t;
+        else A.pred_lo = (t == -INFINITY) ? NAN : nextafterf(t, -INFINITY);
+    }
+    if (f & (SPC_MASK_LT | SPC_MASK_LE)) {
+        const float t = A.mask.thr_hi;
+        if (t != t) A.pred_lim = -1.f;
+        else if (f & SPC_MASK_LT) A.pred_hi = t;
+        else A.pred_hi = (t == INFINITY) ? NAN : nextafterf(t, INFINITY);
+    }
+}
+
 int check_kernel(const double* k, int n, const char* what) {
     SPC_REQUIRE(k != nullptr, "%s kernel pointer is NULL", what);
     SPC_REQUIRE(n >= 1 && (n % 2) == 1, "%s kernel must have an odd number of taps (got %d)", what, n);
@@ -180,7 +202,8 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
     dim3 grid((unsigned)nstrips, (unsigned)cube->nz, (unsigned)nysplit);
     hipStream_t st = (hipStream_t)stream;
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
-    // speculative all-valid fast pass: 8-byte aligned rows, no mask array, whole columns per block
+    // speculative all-valid fast pass: 8-byte aligned rows, a mask that rejects exactly the
+    // non-finite samples (none / isfinite), whole columns per block
     const char* env = getenv("SPC_CONV_FAST");
     const bool want = env ? atoi(env) != 0 : true;
     const bool al = (cube->nx % 2 == 0) && (cube->row_stride % 2 == 0) && (cube->plane_stride % 2 == 0) &&
@@ -188,8 +211,9 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
                     (A.out_plane_stride % 4 == 0) && (((uintptr_t)d_out) % 16 == 0);
     A.status = nullptr;
     A.inv_ksum = (float)(1.0 / sum);
+    canonical_pred(A);
     unsigned char* d_status = nullptr;
-    if (want && al && !arr && nysplit == 1 && R <= 33 && cube->nx >= 64) {
+    if (want && al && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && nysplit == 1 && R <= 33 && cube->nx >= 64) {
         A.fast_nstrips = (int)((cube->nx + fast_txo(R) - 1) / fast_txo(R));
         const size_t nt = (size_t)A.fast_nstrips * (size_t)cube->nz;
         SPC_HIP(hipMallocAsync((void**)&d_status, nt, st));

@@ -24,6 +24,7 @@ struct SpArgs {
     unsigned char* status;
     int fast_nstrips;
     float inv_ksum;                           // 1 / (sum(ky) * sum(kx))
+    float pred_lim, pred_lo, pred_hi;         // canonical predicate: |v| <= lim && !(v <= lo) && !(v >= hi)
     alignas(8) float ky[kMaxTaps + 1];        // padded to RY, centred (read pairwise as 64-bit scalars)
     alignas(8) float kx[kMaxTaps + 1];        // padded to RX, centred
 };
@@ -74,10 +75,10 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     const int64_t x0 = (int64_t)strip * kTxoF;            // first output column of the strip
     const int64_t xin = x0 - H + 2 * t;                   // first of this lane's two input columns
     const bool col_in = (xin >= 0) && (xin + 1 < A.nx);
+    // block-uniform: does any lane of this strip look outside the row?
+    const bool edge_cols = (x0 - H < 0) || (x0 - H + kFastCols > A.nx);
     const int64_t xc = min(max(xin, (int64_t)0), A.nx - 2);
     const float* p = A.cube + z * A.plane_stride + xc;
-    const uint32_t flags = A.mask.flags;
-    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
     const int ny = (int)A.ny;
     const int c0 = 2 * t, c1 = 2 * t + 1;
     const int ph0 = c0 + (c0 >> 3), ph1 = c1 + (c1 >> 3);
@@ -87,39 +88,32 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     for (int m = 0; m < R; ++m) num[m] = float2v{0.f, 0.f};
 
     const int T = ny + 2 * H;
+    // software pipeline: the loads of revolution n+1 are issued right after the y pass of
+    // revolution n has consumed v[], so they are in flight during the LDS x pass
+    float2v v[R];
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+        const int64_t ic = min(max(-H + s, 0), ny - 1);
+        v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
+    }
     for (int t0 = 0; t0 < T; t0 += R) {
         const int i0 = t0 - H;                            // first input row of this revolution
-        float2v v[R];
-#pragma unroll
-        for (int s = 0; s < R; ++s) {
-            const int64_t ic = min(max(i0 + s, 0), ny - 1);
-            v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
-        }
-        bool bad = false;
-        if (flags == 0) {                                // no predicate mask: only NaNs are invalid
+        // Interior revolutions of interior strips (the common case) carry NO per-sample
+        // bookkeeping at all; rows / columns outside the plane (clamped duplicate loads) are
+        // turned into valid zeros only where they can occur, under block-uniform branches.
+        const bool edge = edge_cols || (i0 < 0) || (i0 + R > ny);
+        if (edge) {
 #pragma unroll
             for (int s = 0; s < R; ++s) {
                 const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
-                bad = bad || (in && !((v[s].x == v[s].x) && (v[s].y == v[s].y)));
                 if (!in) v[s] = float2v{0.f, 0.f};       // out of bounds = valid zero
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float r = v[s][c];
-                    bad = bad || (in && !(spc_pred(flags, tlo, thi, r) && (r == r)));
-                }
-                if (!in) v[s] = float2v{0.f, 0.f};
-            }
         }
-        if (__syncthreads_or(bad ? 1 : 0)) {             // block-uniform: hand the tile to the general kernel
-            if (t == 0) A.status[z * A.fast_nstrips + strip] = 1;
-            return;
-        }
-        // ---- y pass
+        // ---- y pass.  The fast pass only runs for masks where exactly the non-finite samples
+        // are invalid (none, or isfinite), and those propagate: chk += 0 * (finished row) is
+        // NaN iff a NaN or Inf went into that row - one packed FMA per row instead of compares
+        // on every sample (an Inf under "no mask" is merely handed to the general kernel).
+        float2v chk = float2v{0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < R; ++s) {
 #pragma unroll
@@ -129,10 +123,22 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
                 else pk_fma_w(num[m], A.ky, 2 * H - a, v[s]);
             }
             const float2v done = num[(s + 1) % R];       // row o = i0 + s - H
+            chk = __builtin_elementwise_fma(done, float2v{0.f, 0.f}, chk);
             yrow[s * kPitchF + ph0] = done.x;
             yrow[s * kPitchF + ph1] = done.y;
         }
-        __syncthreads();
+        const bool bad = !(chk.x == chk.x) || !(chk.y == chk.y);
+        if (__syncthreads_or(bad ? 1 : 0)) {             // block-uniform: hand the tile to the general kernel
+            if (t == 0) A.status[z * A.fast_nstrips + strip] = 1;
+            return;
+        }
+        if (t0 + R < T) {
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const int64_t ic = min(max(i0 + R + s, 0), ny - 1);
+                v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
+            }
+        }
         // ---- x pass: task = (row pair, run of kRun output columns)
         constexpr int nrun = kTxoF / kRun;
         for (int task = t; task < (kRows / 2) * nrun; task += kThreads) {
@@ -188,100 +194,128 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
 
 __device__ __forceinline__ int lds_phys(int t) { return t + (t >> 3); }   // 9-per-8 padding
 
-template <int RY, int RX, bool ARR, bool SYM>
+// ---- general (masked) kernel -----------------------------------------------------------
+// Same march as the fast kernel, but every sample carries (value, validity) packed in one
+// float2 so that ONE v_pk_fma_f32 per tap advances numerator and denominator together:
+//   y pass: lane <-> 1 input column, register ring of R packed (num, den); finished rows go to
+//           LDS as float2;
+//   x pass: task = (row, run of 8 columns), packed (num, den) again, then num / den with
+//           astropy's empty-window rule (the filled centre sample).
+// Interior revolutions of interior strips carry no bounds bookkeeping (block-uniform branch);
+// the mask predicate is canonicalised on the host into |v| <= lim, !(v <= lo), !(v >= hi)
+// (absent bounds are NaN, which makes the negated compares true) - PRED=false kernels skip the
+// two threshold compares.  ISO: kx == ky share their scalar registers.
+template <int R, bool ARR, bool PRED>
+__device__ __forceinline__ float2v classify(float v, unsigned char mk, float lim, float lo, float hi) {
+    bool ok = __builtin_fabsf(v) <= lim;                   // false for NaN (and Inf under isfinite)
+    if (PRED) ok = ok && !(v <= lo) && !(v >= hi);
+    if (ARR) ok = ok && (mk != 0);
+    return ok ? float2v{v, 1.f} : float2v{0.f, 0.f};
+}
+
+template <int R, bool ARR, bool PRED, bool ISO>
 __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
-    constexpr int HY = RY / 2, HX = RX / 2;
+    constexpr int H = R / 2;
     // float2 per LDS row.  Pitch = 28 (mod 32): a 32-lane group of the x pass spans parts of
     // two rows (28 runs per row); with this pitch the second row's runs continue the first
     // row's 18-dword bank progression instead of landing on the same banks (the previous
     // pitch of 290 made every x-pass ds_read_b64 2-way conflicted - SQ_LDS_BANK_CONFLICT
     // was twice SQ_ACTIVE_INST_LDS)
-    constexpr int kPitch = (RY <= 33) ? 316 : 290;     // the 65-tap ring only fits LDS with the short pitch
+    constexpr int kPitch = (R <= 29) ? 316 : 290;       // 33 taps: two blocks per CU only with the short pitch; 65 taps: only fits with it
     static_assert(kPitch >= kThreads + kThreads / 8, "LDS row too short");
-    __shared__ float2v yres[RY * kPitch];
+    __shared__ float2v yres[R * kPitch];
 
     const int t = threadIdx.x;
     const int64_t z = blockIdx.y;
     const int64_t x0 = (int64_t)blockIdx.x * A.txo;       // first output column of the strip
     if (A.status) {   // both fast tiles this strip overlaps were finished by the all-valid kernel
-        const int ft = fast_txo(RX);
+        const int ft = fast_txo(R);
         const int f0 = (int)(x0 / ft), f1 = (int)(min(x0 + A.txo, A.nx) - 1) / ft;
         if (A.status[z * A.fast_nstrips + f0] == 0 && A.status[z * A.fast_nstrips + f1] == 0) return;
     }
-    const int64_t yb = (int64_t)blockIdx.z * A.ychunk;
-    const int64_t ye = min(A.ny, yb + A.ychunk);
-    const int64_t xin = x0 - HX + t;                      // input column of this lane (y pass)
-    const bool col_in = (xin >= 0) && (xin < A.nx) && (t < A.txo + 2 * HX);
+    const int ny = (int)A.ny;
+    const int yb = (int)(blockIdx.z * A.ychunk);
+    const int ye = (int)min((int64_t)ny, (int64_t)yb + A.ychunk);
+    const int64_t xin = x0 - H + t;                       // input column of this lane (y pass)
+    const bool col_in = (xin >= 0) && (xin < A.nx);
+    const bool edge_cols = (x0 - H < 0) || (x0 - H + kThreads > A.nx);     // block-uniform
     const int64_t xc = min(max(xin, (int64_t)0), A.nx - 1);
     const float* p = A.cube + z * A.plane_stride + xc;
     const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + xc : nullptr;
-    const uint32_t flags = A.mask.flags;
-    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
-    constexpr int kTxo = ((kThreads - 2 * HX) / kRun) * kRun;   // output columns per strip (== A.txo)
+    const float lim = A.pred_lim, lo = A.pred_lo, hi = A.pred_hi;
+    constexpr int kTxo = ((kThreads - 2 * H) / kRun) * kRun;    // output columns per strip (== A.txo)
     constexpr int nrun = kTxo / kRun;                           // compile-time: no integer division per task
 
-    float2v acc[RY];
+    float2v acc[R];
 #pragma unroll
-    for (int m = 0; m < RY; ++m) acc[m] = float2v{0.f, 0.f};
+    for (int m = 0; m < R; ++m) acc[m] = float2v{0.f, 0.f};
 
-    const int64_t T = (ye - yb) + 2 * HY;
-    for (int64_t t0 = 0; t0 < T; t0 += RY) {
-        const int64_t i0 = yb - HY + t0;                  // first input row of this revolution
-        float v[RY];
-        unsigned char mk[RY];
+    float v[R];
+    unsigned char mk[R];
+    auto load_rows = [&](int i0) {
+        if ((i0 < 0) || (i0 + R > ny)) {                  // block-uniform: clamp only at the plane's ends
 #pragma unroll
-        for (int s = 0; s < RY; ++s) {
-            const int64_t ic = min(max(i0 + s, (int64_t)0), A.ny - 1);
-            v[s] = p[ic * A.row_stride];
-            if (ARR) mk[s] = pm[ic * A.mask.row_stride];
-        }
-#pragma unroll
-        for (int s = 0; s < RY; ++s) {
-            const int64_t i = i0 + s;
-            const bool inr = col_in && (i >= 0) && (i < A.ny);
-            bool inc = spc_pred(flags, tlo, thi, v[s]);
-            if (ARR) inc = inc && (mk[s] != 0);
-            const bool ok = inr ? (inc && (v[s] == v[s])) : true;   // out of bounds = valid zero
-            float2v x2;
-            x2.x = (ok && inr) ? v[s] : 0.f;
-            x2.y = ok ? 1.f : 0.f;
-#pragma unroll
-            for (int m = 0; m < RY; ++m) {
-                const int a = (s - m + RY) % RY;
-                const float wgt = A.ky[SYM ? (a <= HY ? a : 2 * HY - a) : 2 * HY - a];
-                const float2v w2 = float2v{wgt, wgt};
-                if (a == 0) acc[m] = w2 * x2;
-                else acc[m] = __builtin_elementwise_fma(w2, x2, acc[m]);
-                asm volatile("" : "+v"(acc[m]));            // see spc_spectral_conv.hip
+            for (int s = 0; s < R; ++s) {
+                const int64_t ic = min(max(i0 + s, 0), ny - 1);
+                v[s] = p[ic * A.row_stride];
+                if (ARR) mk[s] = pm[ic * A.mask.row_stride];
             }
-            // row o = i - HY is complete: park it in LDS slot s
-            yres[s * kPitch + lds_phys(t)] = acc[(s + 1) % RY];
+        } else {
+            const float* q = p + (int64_t)i0 * A.row_stride;
+            const uint8_t* qm = ARR ? pm + (int64_t)i0 * A.mask.row_stride : nullptr;
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                v[s] = q[(int64_t)s * A.row_stride];
+                if (ARR) mk[s] = qm[(int64_t)s * A.mask.row_stride];
+            }
+        }
+    };
+
+    const int T = (ye - yb) + 2 * H;
+    load_rows(yb - H);
+    for (int t0 = 0; t0 < T; t0 += R) {
+        const int i0 = yb - H + t0;                       // first input row of this revolution
+        const bool edge = edge_cols || (i0 < 0) || (i0 + R > ny);
+        // ---- y pass
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            float2v x2 = classify<R, ARR, PRED>(v[s], ARR ? mk[s] : (unsigned char)1, lim, lo, hi);
+            if (edge) {                                   // out of bounds = valid zero
+                const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
+                if (!in) x2 = float2v{0.f, 1.f};
+            }
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int a = (s - m + R) % R;
+                if (a == 0) pk_mul_w(acc[m], A.ky, 2 * H - a, x2);
+                else pk_fma_w(acc[m], A.ky, 2 * H - a, x2);
+            }
+            // row o = i0 + s - H is complete: park it in LDS slot s
+            yres[s * kPitch + lds_phys(t)] = acc[(s + 1) % R];
         }
         __syncthreads();
-        // ---- x pass over the RY rows of this revolution
-        for (int task = t; task < RY * nrun; task += kThreads) {
+        if (t0 + R < T) load_rows(i0 + R);                // in flight during the x pass
+        // ---- x pass over the R rows of this revolution
+        for (int task = t; task < R * nrun; task += kThreads) {
             const int s = task / nrun;
             const int j = task - s * nrun;
-            const int64_t o = i0 + s - HY;                // output row
+            const int o = i0 + s - H;                     // output row
             if (o < yb || o >= ye) continue;
             float2v r[kRun];
 #pragma unroll
             for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
             const float2v* src = yres + s * kPitch;
 #pragma unroll
-            for (int i = 0; i < kRun + 2 * HX; ++i) {
+            for (int i = 0; i < kRun + 2 * H; ++i) {
                 const float2v in = src[lds_phys(kRun * j + i)];
 #pragma unroll
                 for (int k = 0; k < kRun; ++k) {
-                    const int widx = k + 2 * HX - i;      // kx index for output k, input i
-                    if (widx >= 0 && widx <= 2 * HX) {
-                        const float wgt = A.kx[SYM ? (widx <= HX ? widx : 2 * HX - widx) : widx];
-                        r[k] = __builtin_elementwise_fma(float2v{wgt, wgt}, in, r[k]);
-                    }
+                    const int widx = k + 2 * H - i;       // kx index for output k, input i
+                    if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
                 }
             }
             const int64_t xo = x0 + kRun * j;
-            float* dst = A.out + z * A.out_plane_stride + o * A.out_row_stride + xo;
+            float* dst = A.out + z * A.out_plane_stride + (int64_t)o * A.out_row_stride + xo;
             float res[kRun];
 #pragma unroll
             for (int k = 0; k < kRun; ++k) {
@@ -291,9 +325,9 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
                     // empty window -> (filled) centre sample, like astropy
                     res[k] = NAN;
                     if (xo + k < A.nx) {
-                        const float c = A.cube[z * A.plane_stride + o * A.row_stride + xo + k];
-                        bool inc = spc_pred(flags, tlo, thi, c);
-                        if (ARR) inc = inc && A.mask.arr[z * A.mask.plane_stride + o * A.mask.row_stride + xo + k] != 0;
+                        const float c = A.cube[z * A.plane_stride + (int64_t)o * A.row_stride + xo + k];
+                        bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
+                        if (ARR) inc = inc && A.mask.arr[z * A.mask.plane_stride + (int64_t)o * A.mask.row_stride + xo + k] != 0;
                         if (inc) res[k] = c;
                     }
                 }
@@ -332,24 +366,28 @@ inline bool is_sym(const float* k, int R) {
 
 template <int R>
 int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
-    const bool sym = is_sym(A.ky, R) && is_sym(A.kx, R);
     dim3 block(kThreads);
+    bool iso = true;
+    for (int i = 0; i < R; ++i) iso = iso && (A.ky[i] == A.kx[i]);
     if constexpr (R <= 33) {
         if (A.status) {      // speculative all-valid pass (the general kernel below redoes dirty tiles)
             dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1);
-            bool iso = true;
-            for (int i = 0; i < R; ++i) iso = iso && (A.ky[i] == A.kx[i]);
             if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true>), fgrid, block, 0, st, A);
             else hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
             SPC_LAUNCH_CHECK();
         }
     }
-    if (arr) {
-        if (sym) hipLaunchKernelGGL((spatial_sep_kernel<R, R, true, true>), grid, block, 0, st, A);
-        else hipLaunchKernelGGL((spatial_sep_kernel<R, R, true, false>), grid, block, 0, st, A);
+    const bool pred = (A.mask.flags & (SPC_MASK_GT | SPC_MASK_GE | SPC_MASK_LT | SPC_MASK_LE)) != 0;
+    // non-isotropic kernels only come in the PRED flavour (a superset: absent bounds are NaN)
+    if (iso && !pred) {
+        if (arr) hipLaunchKernelGGL((spatial_sep_kernel<R, true, false, true>), grid, block, 0, st, A);
+        else hipLaunchKernelGGL((spatial_sep_kernel<R, false, false, true>), grid, block, 0, st, A);
+    } else if (iso) {
+        if (arr) hipLaunchKernelGGL((spatial_sep_kernel<R, true, true, true>), grid, block, 0, st, A);
+        else hipLaunchKernelGGL((spatial_sep_kernel<R, false, true, true>), grid, block, 0, st, A);
     } else {
-        if (sym) hipLaunchKernelGGL((spatial_sep_kernel<R, R, false, true>), grid, block, 0, st, A);
-        else hipLaunchKernelGGL((spatial_sep_kernel<R, R, false, false>), grid, block, 0, st, A);
+        if (arr) hipLaunchKernelGGL((spatial_sep_kernel<R, true, true, false>), grid, block, 0, st, A);
+        else hipLaunchKernelGGL((spatial_sep_kernel<R, false, true, false>), grid, block, 0, st, A);
     }
     SPC_LAUNCH_CHECK();
     return SPC_OK;

@@ -23,5 +23,12 @@ for _ in range(reps):
     elif op == "sconv_fused": ops.spectral_conv_moments(cube, g, cen)
     elif op == "spconv": ops.spatial_conv(cube, np.outer(g29, g29), out=out)
     elif op == "moments": ops.moments(cube, cen)
+    elif op == "spconv_mask":
+        if _ == 0:
+            mp = (rng.random((ny, nx)) > 0.2).astype(np.uint8)
+            maskc = DeviceArray(shape, np.uint8)
+            for z in range(nz):
+                _lib.call("spc_memcpy_h2d", 0, C.c_void_p(maskc.ptr + z * mp.nbytes), mp.ctypes.data_as(C.c_void_p), mp.nbytes, None)
+        ops.spatial_conv(cube, np.outer(g29, g29), out=out, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskc))
 synchronize()
 print("done", op)
