@@ -42,6 +42,33 @@ __device__ __forceinline__ void pk_mul_w(float2v& acc, const float* karr, int j,
     else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "s"(wp), "v"(x));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope
+// fence, i.e. s_waitcnt vmcnt(0): every revolution would drain its output stores (and the
+// prefetched loads) before the next y pass may start.  Global memory is never shared inside a
+// block here, so waiting for the LDS counter is enough.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// A lane of the x pass owns a run of 8 outputs = two 16-byte stores; issued as they are, each
+// store instruction writes the first (second) HALF of every 32-byte sector.  For the short,
+// memory-bound rings neighbouring lanes first swap one half (DPP quad_perm [1,0,3,2]) so that
+// each instruction writes whole sectors: 2.66 -> 2.13 ms (9 taps), 2.44 -> 2.21 ms (17 taps) at
+// 1024^3.  The long rings are not memory-bound and keep the 16 extra VALU ops out.
+constexpr int kPairedStoreMaxR = 17;
+__device__ __forceinline__ float dpp_swap_pair(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+// p = address of this lane's own run; the partner lane (t ^ 1) owns the adjacent run of the same row
+__device__ __forceinline__ void store_run8_paired(float* p, int odd, f32x4 lo, f32x4 hi) {
+    const f32x4 give = odd ? lo : hi;
+    const f32x4 got = f32x4{dpp_swap_pair(give.x), dpp_swap_pair(give.y), dpp_swap_pair(give.z), dpp_swap_pair(give.w)};
+    const f32x4 s1 = odd ? got : lo;                      // even: own [0,4) ; odd: partner's [4,8) just below
+    const f32x4 s2 = odd ? hi : got;                      // even: partner's [0,4) just above ; odd: own [4,8)
+    __builtin_nontemporal_store(s1, reinterpret_cast<f32x4*>(p + (odd ? -4 : 0)));
+    __builtin_nontemporal_store(s2, reinterpret_cast<f32x4*>(p + (odd ? 4 : 8)));
+}
+
 constexpr int kFastCols = 512;                // input columns per block of the fast kernel (2 per lane)
 constexpr int fast_txo(int R) { return ((kFastCols - 2 * (R / 2)) / 16) * 16; }
 
@@ -68,6 +95,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     constexpr int kRows = R + (R & 1);                    // rows per revolution rounded up to pairs
     static_assert(kPitchF >= kFastCols + kFastCols / 8, "LDS row too short");
     __shared__ float yrow[kRows * kPitchF];
+    __shared__ volatile int dirty;                        // set by any lane that meets a non-finite sample
 
     const int t = threadIdx.x;
     const int64_t z = blockIdx.y;
@@ -80,6 +108,17 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     const int64_t xc = min(max(xin, (int64_t)0), A.nx - 2);
     const float* p = A.cube + z * A.plane_stride + xc;
     const int ny = (int)A.ny;
+    // partial last strip: whole waves beyond the columns the x pass will read retire (a retired
+    // wave no longer takes part in the barriers), and the x pass only walks the runs that exist
+    const int nrun_eff = ((int)min((int64_t)kTxoF, A.nx - x0) + kRun - 1) / kRun;
+    const int ncols = nrun_eff * kRun + 2 * H;
+    if (2 * (t & ~63) >= ncols) return;
+    if (t == 0) dirty = 0;
+    lds_barrier();
+    const int nthr = min(kThreads, ((ncols + 127) / 128) * 64);
+    const float inv_nrun = 1.0f / (float)nrun_eff;
+    // lanes t, t^1 hold adjacent runs of one row pair iff the run count is even; whole runs only
+    const bool pairable = ((nrun_eff & 1) == 0) && (x0 + (int64_t)nrun_eff * kRun <= A.nx);
     const int c0 = 2 * t, c1 = 2 * t + 1;
     const int ph0 = c0 + (c0 >> 3), ph1 = c1 + (c1 >> 3);
 
@@ -127,8 +166,9 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
             yrow[s * kPitchF + ph0] = done.x;
             yrow[s * kPitchF + ph1] = done.y;
         }
-        const bool bad = !(chk.x == chk.x) || !(chk.y == chk.y);
-        if (__syncthreads_or(bad ? 1 : 0)) {             // block-uniform: hand the tile to the general kernel
+        if (!(chk.x == chk.x) || !(chk.y == chk.y)) dirty = 1;
+        lds_barrier();
+        if (dirty) {                                      // block-uniform: hand the tile to the general kernel
             if (t == 0) A.status[z * A.fast_nstrips + strip] = 1;
             return;
         }
@@ -140,10 +180,9 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
             }
         }
         // ---- x pass: task = (row pair, run of kRun output columns)
-        constexpr int nrun = kTxoF / kRun;
-        for (int task = t; task < (kRows / 2) * nrun; task += kThreads) {
-            const int pr = task / nrun;
-            const int j = task - pr * nrun;
+        for (int task = t; task < (kRows / 2) * nrun_eff; task += nthr) {
+            const int pr = (int)(((float)task + 0.5f) * inv_nrun);   // exact: task < 2^12, nrun <= 62
+            const int j = task - pr * nrun_eff;
             const int sa = 2 * pr, sb = 2 * pr + 1;
             const int oa = i0 + sa - H, ob = oa + 1;
             const bool wa = (oa >= 0) && (oa < ny), wb = (sb < R) && (ob >= 0) && (ob < ny);
@@ -167,8 +206,12 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
             const int64_t xo = x0 + kRun * j;
             float* da = A.out + z * A.out_plane_stride + (int64_t)oa * A.out_row_stride + xo;
             float* db = da + A.out_row_stride;
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            if (xo + kRun <= A.nx) {
+            if (R <= kPairedStoreMaxR && pairable) {
+                if (wa) store_run8_paired(da, t & 1, f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum,
+                                          f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum);
+                if (wb) store_run8_paired(db, t & 1, f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum,
+                                          f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum);
+            } else if (xo + kRun <= A.nx) {
                 if (wa) {
                     __builtin_nontemporal_store(f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da));
                     __builtin_nontemporal_store(f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da + 4));
@@ -187,7 +230,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -233,6 +276,15 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
         const int f0 = (int)(x0 / ft), f1 = (int)(min(x0 + A.txo, A.nx) - 1) / ft;
         if (A.status[z * A.fast_nstrips + f0] == 0 && A.status[z * A.fast_nstrips + f1] == 0) return;
     }
+    constexpr int kTxo = ((kThreads - 2 * H) / kRun) * kRun;    // output columns per strip (== A.txo)
+    // partial last strip: see the fast kernel
+    const int nrun_eff = ((int)min((int64_t)kTxo, A.nx - x0) + kRun - 1) / kRun;
+    const int ncols = nrun_eff * kRun + 2 * H;
+    if ((t & ~63) >= ncols) return;
+    const int nthr = min(kThreads, (ncols + 63) & ~63);
+    const float inv_nrun = 1.0f / (float)nrun_eff;
+    const bool pairable = ((nrun_eff & 1) == 0) && (x0 + (int64_t)nrun_eff * kRun <= A.nx) &&
+                          (((uintptr_t)(A.out + z * A.out_plane_stride + x0) & 15) == 0) && (A.out_row_stride % 4 == 0);
     const int ny = (int)A.ny;
     const int yb = (int)(blockIdx.z * A.ychunk);
     const int ye = (int)min((int64_t)ny, (int64_t)yb + A.ychunk);
@@ -243,9 +295,6 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
     const float* p = A.cube + z * A.plane_stride + xc;
     const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + xc : nullptr;
     const float lim = A.pred_lim, lo = A.pred_lo, hi = A.pred_hi;
-    constexpr int kTxo = ((kThreads - 2 * H) / kRun) * kRun;    // output columns per strip (== A.txo)
-    constexpr int nrun = kTxo / kRun;                           // compile-time: no integer division per task
-
     float2v acc[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) acc[m] = float2v{0.f, 0.f};
@@ -293,12 +342,12 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
             // row o = i0 + s - H is complete: park it in LDS slot s
             yres[s * kPitch + lds_phys(t)] = acc[(s + 1) % R];
         }
-        __syncthreads();
+        lds_barrier();
         if (t0 + R < T) load_rows(i0 + R);                // in flight during the x pass
         // ---- x pass over the R rows of this revolution
-        for (int task = t; task < R * nrun; task += kThreads) {
-            const int s = task / nrun;
-            const int j = task - s * nrun;
+        for (int task = t; task < R * nrun_eff; task += nthr) {
+            const int s = (int)(((float)task + 0.5f) * inv_nrun);    // exact: task < 2^10, nrun <= 31
+            const int j = task - s * nrun_eff;
             const int o = i0 + s - H;                     // output row
             if (o < yb || o >= ye) continue;
             float2v r[kRun];
@@ -332,8 +381,9 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
                     }
                 }
             }
-            if (xo + kRun <= A.nx && ((((uintptr_t)dst) & 15) == 0)) {
-                typedef float f32x4 __attribute__((ext_vector_type(4)));
+            if (R <= kPairedStoreMaxR && pairable) {
+                store_run8_paired(dst, t & 1, f32x4{res[0], res[1], res[2], res[3]}, f32x4{res[4], res[5], res[6], res[7]});
+            } else if (xo + kRun <= A.nx && ((((uintptr_t)dst) & 15) == 0)) {
                 *reinterpret_cast<f32x4*>(dst) = f32x4{res[0], res[1], res[2], res[3]};
                 *reinterpret_cast<f32x4*>(dst + 4) = f32x4{res[4], res[5], res[6], res[7]};
             } else {
@@ -342,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
                     if (xo + k < A.nx) dst[k] = res[k];
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
