@@ -485,6 +485,47 @@ def case_wcs():
     print("wcs ok")
 
 
+def case_bilinear_scipy():
+    """Pins oracle_np.resample_bilinear against the resampling primitive reproject calls.
+
+    reproject (not installed here) implements reproject_interp(order='bilinear') as: pad the
+    image by one edge-replicated pixel, scipy.ndimage.map_coordinates(padded, coords + 1,
+    order=1, mode='constant', cval=nan), reset outputs whose source position is outside
+    [-0.5, n - 0.5].  Those steps are run here with the installed scipy and the restatement
+    must reproduce them: NaN propagation through zero weights, border replication, footprint."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(77)
+    nz, ny, nx = 3, 19, 23
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[0, 5, 7] = np.nan
+    d[1, 0, :3] = np.nan
+    d[2, -1, -1] = np.nan
+    nyo, nxo = 26, 31
+    yy, xx = np.mgrid[0:nyo, 0:nxo].astype(np.float64)
+    a = np.deg2rad(23.0)
+    xs = 0.9 * (np.cos(a) * (xx - 15) - np.sin(a) * (yy - 13)) + 11.3
+    ys = 0.9 * (np.sin(a) * (xx - 15) + np.cos(a) * (yy - 13)) + 9.1
+    # exact hits (next to NaNs, on the borders) and the half-pixel border zone
+    xs[0, :8] = [7, 6, 8, 7, 0, 22, -0.5, 22.5]
+    ys[0, :8] = [5, 5, 5, 4, 0, 18, -0.25, 18.5]
+    xs[1, :4] = [-0.3, 22.4, 3.0, 2.5]
+    ys[1, :4] = [4.0, 7.7, -0.4, 0.0]
+    exp = np.empty((nz, nyo, nxo))
+    for k in range(nz):
+        padded = np.pad(d[k].astype(np.float64), 1, mode="edge")
+        v = map_coordinates(padded, np.array([ys + 1, xs + 1]), order=1, mode="constant", cval=np.nan)
+        reset = (xs < -0.5) | (xs > nx - 0.5) | (ys < -0.5) | (ys > ny - 0.5)
+        v[reset] = np.nan
+        exp[k] = v
+    got, foot = O.resample_bilinear(d, xs, ys)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)), "bilinear NaN pattern differs from scipy"
+    ok = ~np.isnan(exp)
+    assert np.max(np.abs(got[ok] - exp[ok])) < 1e-12, np.max(np.abs(got[ok] - exp[ok]))
+    np.savez(os.path.join(OUT, "bilinear_scipy.npz"), data=d, xs=xs, ys=ys, expected=exp,
+             footprint=foot[0])
+    print("bilinear vs scipy.ndimage.map_coordinates ok")
+
+
 if __name__ == "__main__":
     case_moment_cube()
     case_c1()
@@ -493,4 +534,5 @@ if __name__ == "__main__":
     case_interp()
     case_kernels()
     case_wcs()
+    case_bilinear_scipy()
     print("ALL GOLDEN VECTORS WRITTEN to", OUT)

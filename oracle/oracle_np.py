@@ -12,9 +12,13 @@ reference (imported via ``oracle/ref_env/bootstrap.py``) and asserts these
 functions reproduce it, and ``tests/test_oracle_golden.py`` re-checks them
 against the committed vectors in ``tests/golden/`` plus the reference's own
 hand-written golden tables (spectral_cube/tests/test_moments.py:19-49 etc.).
-Parity is UNPINNED for ``resample_bilinear`` (the reference delegates to the
-third-party ``reproject`` package, which is neither vendored nor installed and
-whose pixel values the reference's tests never check - SURVEY.md section 8c).
+``resample_bilinear``: the reference delegates to the third-party ``reproject``
+package (neither vendored nor installed; the reference's tests never check its
+pixel values - SURVEY.md section 8c).  Its bilinear resampler is
+``scipy.ndimage.map_coordinates(order=1)`` on the edge-padded image; the
+restatement is pinned against THAT with the scipy installed here
+(``gen_golden.case_bilinear_scipy`` -> tests/golden/bilinear_scipy.npz).  The
+celestial pixel map itself is pinned against astropy.wcs (wcs.npz).
 
 Array layout everywhere: C-contiguous ``(nz, ny, nx)``, spectral axis first.
 """
@@ -273,16 +277,22 @@ def spectral_interpolate(data, include, inaxis, grid, fill_value=None,
 
 
 # --------------------------------------------------------------------------
-# reprojection (PARITY UNPINNED - see module docstring)
+# reprojection (pinned against scipy's map_coordinates - see module docstring)
 # --------------------------------------------------------------------------
 def resample_bilinear(plane_or_cube, xs, ys):
     """Bilinear resampling of every channel at source pixel coordinates
-    ``(xs, ys)`` (0-based, pixel centres at integers), following the
-    published behaviour of ``reproject.reproject_interp(order='bilinear')``
-    (call site spectral_cube/spectral_cube.py:2726-2732): output pixels whose
-    source position falls outside ``[-0.5, n-0.5]`` are NaN (footprint 0);
-    inside that range the image is edge-replicated by half a pixel; NaN input
-    samples propagate.
+    ``(xs, ys)`` (0-based, pixel centres at integers): the resampler behind
+    ``reproject.reproject_interp(order='bilinear')`` (call site
+    spectral_cube/spectral_cube.py:2726-2732).  reproject itself is not in this
+    image; its resampler is published as: pad the image by one edge-replicated
+    pixel, ``scipy.ndimage.map_coordinates(padded, coords + 1, order=1,
+    mode='constant', cval=nan)``, then reset every output whose source
+    position lies outside ``[-0.5, n - 0.5]`` to NaN (footprint 0).  This
+    restates exactly that, and oracle/gen_golden.py pins it against
+    scipy.ndimage.map_coordinates (tests/golden/bilinear_scipy.npz).
+    Consequences reproduced here: a NaN neighbour propagates even with weight 0
+    (exact hits next to a NaN are NaN); within half a pixel of the border both
+    neighbours are the border pixel.
     Returns (data, footprint)."""
     a = np.asarray(plane_or_cube)
     cube = a if a.ndim == 3 else a[None]
@@ -293,20 +303,23 @@ def resample_bilinear(plane_or_cube, xs, ys):
         inside = ((xs >= -0.5) & (xs <= nx - 0.5) &
                   (ys >= -0.5) & (ys <= ny - 0.5))
     inside &= np.isfinite(xs) & np.isfinite(ys)
-    xc = np.clip(np.where(inside, xs, 0.0), 0.0, nx - 1.0)
-    yc = np.clip(np.where(inside, ys, 0.0), 0.0, ny - 1.0)
-    x0 = np.minimum(np.floor(xc).astype(np.int64), max(nx - 2, 0))
-    y0 = np.minimum(np.floor(yc).astype(np.int64), max(ny - 2, 0))
-    x1 = np.minimum(x0 + 1, nx - 1)
-    y1 = np.minimum(y0 + 1, ny - 1)
-    fx = xc - x0
-    fy = yc - y0
+    xq = np.where(inside, xs, 0.0)
+    yq = np.where(inside, ys, 0.0)
+    xf = np.floor(xq)
+    yf = np.floor(yq)
+    fx = xq - xf                                   # weight of the upper neighbour, in [0, 1)
+    fy = yq - yf
+    x0 = xf.astype(np.int64)                       # in [-1, nx - 1]: -1 / nx are the replicated border
+    y0 = yf.astype(np.int64)
+    xa, xb = np.maximum(x0, 0), np.minimum(x0 + 1, nx - 1)
+    ya, yb = np.maximum(y0, 0), np.minimum(y0 + 1, ny - 1)
     out = np.empty((nz,) + xs.shape, dtype=np.float64)
-    for k in range(nz):
-        p = cube[k].astype(np.float64)
-        v = ((1 - fy) * ((1 - fx) * p[y0, x0] + fx * p[y0, x1]) +
-             fy * ((1 - fx) * p[y1, x0] + fx * p[y1, x1]))
-        out[k] = np.where(inside, v, np.nan)
+    with np.errstate(invalid="ignore"):
+        for k in range(nz):
+            p = cube[k].astype(np.float64)
+            v = (p[ya, xa] * ((1 - fy) * (1 - fx)) + p[ya, xb] * ((1 - fy) * fx) +
+                 p[yb, xa] * (fy * (1 - fx)) + p[yb, xb] * (fy * fx))
+            out[k] = np.where(inside, v, np.nan)
     foot = np.broadcast_to(inside, out.shape).copy()
     if a.ndim == 2:
         return out[0], foot[0]

@@ -114,6 +114,10 @@ struct BilArgs {
     int64_t out_row_stride, out_plane_stride;
     uint8_t* footprint;
     int64_t zchunk;
+    // LDS-staged pass: one byte per 32 x 32 output tile, 0 = done by bilinear_lds_kernel
+    unsigned char* status;
+    int64_t tiles32_x;
+    int64_t zchunk_lds;
 };
 
 // Lane <-> output pixel of a 16 x 4 tile per wavefront (a 64 x 16 tile per block): the
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const int64_t xo = bx * 64 + (wave * 16) + (lane & 15);
     const int64_t yo = by * 4 + (lane >> 4);
     if (xo >= A.nx_out || yo >= A.ny_out) return;
+    if (A.status && A.status[(yo >> 5) * A.tiles32_x + (xo >> 5)] == 0) return;   // wave-uniform: tile done via LDS
     const int64_t pix = yo * A.nx_out + xo;
     const double xs = A.xs[pix], ys = A.ys[pix];
     const bool inside = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
@@ -137,13 +142,13 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
         for (int64_t z = zb; z < ze; ++z) po[z * A.out_plane_stride] = NAN;
         return;
     }
-    const double xc = fmin(fmax(xs, 0.0), (double)(A.nx - 1));
-    const double yc = fmin(fmax(ys, 0.0), (double)(A.ny - 1));
-    int64_t x0 = (int64_t)floor(xc), y0 = (int64_t)floor(yc);
-    x0 = min(x0, max(A.nx - 2, (int64_t)0));
-    y0 = min(y0, max(A.ny - 2, (int64_t)0));
-    const int64_t x1 = min(x0 + 1, A.nx - 1), y1 = min(y0 + 1, A.ny - 1);
-    const float fx = (float)(xc - (double)x0), fy = (float)(yc - (double)y0);
+    // reproject's resampler: scipy map_coordinates(order=1) on the image padded by one
+    // edge-replicated pixel.  floor(xs) in [-1, nx-1]; neighbours -1 / nx are the border pixel
+    // itself, so within half a pixel of the border both neighbours coincide.
+    const double xf = floor(xs), yf = floor(ys);
+    const int64_t x0 = max((int64_t)xf, (int64_t)0), y0 = max((int64_t)yf, (int64_t)0);
+    const int64_t x1 = min((int64_t)xf + 1, A.nx - 1), y1 = min((int64_t)yf + 1, A.ny - 1);
+    const float fx = (float)(xs - xf), fy = (float)(ys - yf);
     const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
     const int64_t o00 = y0 * A.row_stride + x0, o01 = y0 * A.row_stride + x1;
     const int64_t o10 = y1 * A.row_stride + x0, o11 = y1 * A.row_stride + x1;
@@ -175,14 +180,185 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
                 if (arr) { i0 = i0 && pm[m00]; i1 = i1 && pm[m01]; i2 = i2 && pm[m10]; i3 = i3 && pm[m11]; }
                 aa = i0 ? aa : A.fill; bb = i1 ? bb : A.fill; cc = i2 ? cc : A.fill; dd = i3 ? dd : A.fill;
             }
-            // zero-weight neighbours must not leak NaN/inf (0*NaN) into exact hits
-            float r = 0.f;
-            if (w00 != 0.f) r = fmaf(w00, aa, r);
-            if (w01 != 0.f) r = fmaf(w01, bb, r);
-            if (w10 != 0.f) r = fmaf(w10, cc, r);
-            if (w11 != 0.f) r = fmaf(w11, dd, r);
+            // plain weighted sum like scipy: a NaN neighbour propagates even with weight 0
+            const float r = fmaf(w11, dd, fmaf(w10, cc, fmaf(w01, bb, w00 * aa)));
             __builtin_nontemporal_store(r, po + z * A.out_plane_stride);
         }
+    }
+}
+
+// ---- LDS-staged bilinear resampling ------------------------------------------------------
+// The gather kernel above is bound by the texture-address path: a rotated 16 x 4 tile makes
+// every one of its 4 loads per channel touch ~14 cache lines.  Here a block owns a 32 x 32
+// output tile for a chunk of channels.  Once per block the pixel map of the tile is turned
+// into (a) the exact source footprint, row by row: [xmin(y), xmax(y)] spans found with LDS
+// atomics, packed by a prefix sum, and (b) per-thread lists of source offsets.  Per channel
+// the footprint (~1.2x the tile area for a rotation) is then read with coalesced row-span
+// loads into LDS, the 4 neighbours of every output pixel come from LDS, and each lane writes
+// 4 adjacent pixels with one 16-byte store.  The per-pixel arithmetic is the gather
+// kernel's, so both give identical bits; a tile whose footprint does not fit (strong
+// down-sampling) is flagged and left to the gather kernel.
+constexpr int kTile = 32;
+constexpr int kRowsMax = 64;                 // source rows a tile may touch
+constexpr int kElemsMax = 2560;              // staged source samples per channel
+constexpr int kFill = kElemsMax / 256;       // samples per thread and channel
+constexpr int kStageU = 4;                   // channels staged per iteration
+
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool ARR, bool ANYMASK>
+__global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
+    __shared__ float stage[kStageU * kElemsMax];
+    __shared__ int s_xmin[kRowsMax], s_xmax[kRowsMax], s_off[kRowsMax + 1];
+    __shared__ int s_ymin, s_ymax;
+    const int t = threadIdx.x;
+    const int64_t bx = blockIdx.x % A.tiles32_x, by = blockIdx.x / A.tiles32_x;
+    const int64_t xo = bx * kTile + (t & 7) * 4;           // first of this lane's 4 adjacent pixels
+    const int64_t yo = by * kTile + (t >> 3);
+
+    bool inside[4];
+    int x0[4], y0[4], dx[4], dy[4];
+    float w00[4], w01[4], w10[4], w11[4];
+    if (t == 0) { s_ymin = 0x7fffffff; s_ymax = -1; }
+    if (t < kRowsMax) { s_xmin[t] = 0x7fffffff; s_xmax[t] = -1; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        inside[q] = false; x0[q] = 0; y0[q] = 0; dx[q] = 0; dy[q] = 0;
+        w00[q] = w01[q] = w10[q] = w11[q] = 0.f;
+        if (xo + q < A.nx_out && yo < A.ny_out) {
+            const int64_t pix = yo * A.nx_out + xo + q;
+            const double xs = A.xs[pix], ys = A.ys[pix];
+            inside[q] = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
+            if (blockIdx.y == 0 && A.footprint) A.footprint[pix] = inside[q] ? 1 : 0;
+            if (inside[q]) {
+                const double xf = floor(xs), yf = floor(ys);      // see bilinear_kernel
+                x0[q] = max((int)xf, 0); y0[q] = max((int)yf, 0);
+                dx[q] = min((int)xf + 1, (int)A.nx - 1) - x0[q];   // 0 inside the replicated border, else 1
+                dy[q] = min((int)yf + 1, (int)A.ny - 1) - y0[q];
+                const float fx = (float)(xs - xf), fy = (float)(ys - yf);
+                w00[q] = (1.f - fy) * (1.f - fx); w01[q] = (1.f - fy) * fx; w10[q] = fy * (1.f - fx); w11[q] = fy * fx;
+                atomicMin(&s_ymin, y0[q]);
+                atomicMax(&s_ymax, y0[q] + dy[q]);
+            }
+        }
+    }
+    __syncthreads();
+    const int ymin = s_ymin;
+    const int nrows = (s_ymax < 0) ? 0 : s_ymax - ymin + 1;
+    const int64_t tile = by * A.tiles32_x + bx;
+    if (nrows > kRowsMax) { if (t == 0) A.status[tile] = 1; return; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (inside[q]) {
+            const int r = y0[q] - ymin;
+            atomicMin(&s_xmin[r], x0[q]);         atomicMax(&s_xmax[r], x0[q] + dx[q]);
+            atomicMin(&s_xmin[r + dy[q]], x0[q]); atomicMax(&s_xmax[r + dy[q]], x0[q] + dx[q]);
+        }
+    }
+    __syncthreads();
+    if (t < 64) {                              // one wave packs the row spans (inclusive scan)
+        int len = (t < nrows && s_xmax[t] >= 0) ? s_xmax[t] - s_xmin[t] + 1 : 0;
+        int acc = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(acc, d, 64);
+            if (t >= d) acc += up;
+        }
+        s_off[t + 1] = acc;
+        if (t == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    const int E = s_off[nrows];
+    if (E > kElemsMax) { if (t == 0) A.status[tile] = 1; return; }
+
+    // per-thread fill list: staged element e = t + 256 k lives in source row ymin + r
+    int foff[kFill], moff[kFill];
+#pragma unroll
+    for (int k = 0; k < kFill; ++k) {
+        const int e = t + 256 * k;
+        foff[k] = -1; moff[k] = 0;
+        if (e < E) {
+            int lo = 0, hi = nrows;            // largest r with s_off[r] <= e
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= e) lo = mid; else hi = mid; }
+            const int xcol = s_xmin[lo] + (e - s_off[lo]);
+            foff[k] = (ymin + lo) * (int)A.row_stride + xcol;
+            if (ARR) moff[k] = (ymin + lo) * (int)A.mask.row_stride + xcol;
+        }
+    }
+    int l0[4], l1[4];                          // LDS index of the (y0, x0) and (y0 + dy, x0) neighbours
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        l0[q] = 0; l1[q] = 0;
+        if (inside[q]) {
+            const int r = y0[q] - ymin;
+            l0[q] = s_off[r] + x0[q] - s_xmin[r];
+            l1[q] = s_off[r + dy[q]] + x0[q] - s_xmin[r + dy[q]];
+        }
+    }
+    const int64_t zb = (int64_t)blockIdx.y * A.zchunk_lds;
+    const int64_t ze = min(A.nz, zb + A.zchunk_lds);
+    if (zb >= ze) return;
+    const bool vec_ok = (xo + 4 <= A.nx_out) && (A.out_row_stride % 4 == 0) && (A.out_plane_stride % 4 == 0) &&
+                        ((((uintptr_t)A.out) & 15) == 0);
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+    float pre[kStageU][kFill];
+    auto fetch = [&](int64_t zq) {
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u) {
+            const int64_t z = min(zq + u, ze - 1);
+            const float* p = A.cube + z * A.plane_stride;
+            const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride : nullptr;
+#pragma unroll
+            for (int k = 0; k < kFill; ++k) {
+                if (256 * k < E) {             // block-uniform
+                    float v = 0.f;
+                    if (foff[k] >= 0) {
+                        v = p[foff[k]];
+                        if (ANYMASK) {
+                            // excluded voxels are replaced by the cube's fill value (spectral_cube.py:2709-2712)
+                            bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v);
+                            if (ARR) inc = inc && pm[moff[k]];
+                            v = inc ? v : A.fill;
+                        }
+                    }
+                    pre[u][k] = v;
+                }
+            }
+        }
+    };
+    fetch(zb);
+    for (int64_t zq = zb; zq < ze; zq += kStageU) {
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u)
+#pragma unroll
+            for (int k = 0; k < kFill; ++k)
+                if (256 * k < E && foff[k] >= 0) stage[u * kElemsMax + t + 256 * k] = pre[u][k];
+        lds_only_barrier();
+        if (zq + kStageU < ze) fetch(zq + kStageU);        // in flight while this group is resampled
+#pragma unroll
+        for (int u = 0; u < kStageU; ++u) {
+            const int64_t z = zq + u;
+            if (z >= ze) break;
+            const float* sp = stage + u * kElemsMax;
+            float r4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float aa = sp[l0[q]], bb = sp[l0[q] + dx[q]], cc = sp[l1[q]], dd = sp[l1[q] + dx[q]];
+                const float r = fmaf(w11[q], dd, fmaf(w10[q], cc, fmaf(w01[q], bb, w00[q] * aa)));
+                r4[q] = inside[q] ? r : NAN;
+            }
+            float* po = A.out + z * A.out_plane_stride + yo * A.out_row_stride + xo;
+            if (yo < A.ny_out) {
+                if (vec_ok) __builtin_nontemporal_store(f32x4{r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<f32x4*>(po));
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (xo + q < A.nx_out) po[q] = r4[q];
+                }
+            }
+        }
+        lds_only_barrier();
     }
 }
 
@@ -250,9 +426,35 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, cube->nz / 8));
     A.zchunk = (cube->nz + nsplit - 1) / nsplit;
     nsplit = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
-    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0,
-                       (hipStream_t)stream, A);
+    hipStream_t st = (hipStream_t)stream;
+    // LDS-staged pass over 32 x 32 tiles first; the gather kernel then only does flagged tiles
+    const char* env = getenv("SPC_BILINEAR_LDS");
+    const bool want = env ? atoi(env) != 0 : true;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    const bool fits = cube->ny * cube->row_stride < (1ll << 31) &&
+                      (!arr || cube->ny * A.mask.row_stride < (1ll << 31));
+    unsigned char* d_status = nullptr;
+    A.status = nullptr;
+    if (want && fits) {
+        A.tiles32_x = (nx_out + kTile - 1) / kTile;
+        const int64_t ntiles = A.tiles32_x * ((ny_out + kTile - 1) / kTile);
+        int ns = 1;
+        if (ntiles < 4096) ns = (int)std::max<int64_t>(1, std::min<int64_t>((4096 + ntiles - 1) / ntiles, cube->nz / 64));
+        A.zchunk_lds = (cube->nz + ns - 1) / ns;
+        A.zchunk_lds = ((A.zchunk_lds + kStageU - 1) / kStageU) * kStageU;
+        ns = (int)((cube->nz + A.zchunk_lds - 1) / A.zchunk_lds);
+        SPC_HIP(hipMallocAsync((void**)&d_status, (size_t)ntiles, st));
+        SPC_HIP(hipMemsetAsync(d_status, 0, (size_t)ntiles, st));
+        A.status = d_status;
+        dim3 g((unsigned)ntiles, (unsigned)ns);
+        if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<true, true>), g, dim3(256), 0, st, A);
+        else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<false, true>), g, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((bilinear_lds_kernel<false, false>), g, dim3(256), 0, st, A);
+        SPC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
     SPC_LAUNCH_CHECK();
+    if (d_status) SPC_HIP(hipFreeAsync(d_status, st));
     return SPC_OK;
 }
 

@@ -221,8 +221,8 @@ def test_spectral_interpolate(gpu):
 
 
 def test_reproject(gpu):
-    """test_regrid.py:99-135 checks shape and WCS only; values vs the oracle
-    (PARITY UNPINNED for pixel values, see oracle/oracle_np.py)."""
+    """test_regrid.py:99-135 checks shape and WCS only; values vs the oracle (pinned against
+    scipy's map_coordinates, the resampler reproject calls - see oracle/oracle_np.py)."""
     g = golden("wcs.npz")
     rng = np.random.default_rng(8)
     d = rng.standard_normal((4, 48, 40)).astype(np.float32)

@@ -309,10 +309,25 @@ def test_resample_bilinear(gpu):
     exp, ef = O.resample_bilinear(d, xs, ys)
     assert_close(out.get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="bilinear")
     assert np.array_equal(foot.get().astype(bool), ef[0])
-    # identity map reproduces the cube exactly
+    # identity map: exact hits reproduce the cube, except that (like scipy's map_coordinates,
+    # which reproject calls) a NaN upper/right neighbour propagates through its zero weight
     yy, xx = np.mgrid[0:48, 0:40]
     out, _ = ops.resample_bilinear(_dev(d), xx.astype(float), yy.astype(float))
-    assert_close(out.get(), d, what="identity")
+    exp, _ = O.resample_bilinear(d, xx.astype(float), yy.astype(float))
+    assert_close(out.get(), exp, what="identity")
+    fin = ~np.isnan(exp)
+    assert np.array_equal(out.get()[fin], d[fin]) and fin.sum() > 0.99 * d.size
+
+
+def test_resample_bilinear_matches_scipy_golden(gpu):
+    """tests/golden/bilinear_scipy.npz: scipy.ndimage.map_coordinates(order=1) on the
+    edge-padded image (the resampler reproject_interp(order='bilinear') calls), with exact hits
+    next to NaNs and the half-pixel border zone.  fp32 weights: tolerance 2e-6 of the data scale."""
+    from spectral_cube_amd import ops
+    g = golden("bilinear_scipy.npz")
+    out, foot = ops.resample_bilinear(_dev(g["data"]), g["xs"], g["ys"])
+    assert_close(out.get(), g["expected"], atol=2e-6 * np.nanmax(np.abs(g["expected"])), what="bilinear vs scipy")
+    assert np.array_equal(foot.get().astype(bool), g["footprint"])
 
 
 def test_sharded_smooth_moment0_with_halos_matches_unsharded(gpu):
@@ -341,3 +356,37 @@ def test_sharded_smooth_moment0_with_halos_matches_unsharded(gpu):
                 strips.append(smooth_moment0_strip(ext, k2, top, n, mask=mext, dv=2.0).get())
             got = np.concatenate(strips, axis=0)
             assert_close(got, ref, atol=1e-5 * np.nanmax(np.abs(ref)), what="sharded smooth+moment0 ws=%d" % ws)
+
+
+@pytest.mark.parametrize("scale,angle", [(1.0, 30.0), (0.6, 75.0), (1.2, -10.0), (3.0, 20.0), (1.0, 0.0)])
+def test_resample_bilinear_lds_and_gather_paths_agree(gpu, monkeypatch, scale, angle):
+    """the LDS-staged tile kernel and the per-pixel gather kernel run the same per-pixel
+    arithmetic: identical bits (NaN pattern included), with masks, for rotations, up- and
+    down-sampling (scale 3 overflows the LDS footprint -> flagged tiles -> gather kernel),
+    ragged output shapes and maps that leave the source; and both match the oracle."""
+    from spectral_cube_amd import ops, _lib
+    rng = np.random.default_rng(17)
+    nz, ny, nx = 9, 150, 170
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[3, 40:45, 50:60] = np.nan
+    inc = rng.random((nz, ny, nx)) > 0.15
+    nyo, nxo = 131, 157
+    yy, xx = np.mgrid[0:nyo, 0:nxo].astype(np.float64)
+    a = np.deg2rad(angle)
+    xs = scale * (np.cos(a) * (xx - nxo / 2) - np.sin(a) * (yy - nyo / 2)) + nx / 2 + 0.123
+    ys = scale * (np.sin(a) * (xx - nxo / 2) + np.cos(a) * (yy - nyo / 2)) + ny / 2 - 0.371
+    for m in (None, _mspec(inc), ops.MaskSpec(_lib.MASK_GT | _lib.MASK_FINITE, -0.5)):
+        monkeypatch.setenv("SPC_BILINEAR_LDS", "1")
+        o1, f1 = ops.resample_bilinear(_dev(d), xs, ys, mask=m, fill=np.nan)
+        monkeypatch.setenv("SPC_BILINEAR_LDS", "0")
+        o2, f2 = ops.resample_bilinear(_dev(d), xs, ys, mask=m, fill=np.nan)
+        o1, o2 = o1.get(), o2.get()
+        assert np.array_equal(f1.get(), f2.get())
+        assert np.array_equal(np.isnan(o1), np.isnan(o2))
+        assert np.array_equal(o1[~np.isnan(o1)], o2[~np.isnan(o2)])
+    filled = np.where(inc, d, np.nan).astype(np.float32)
+    monkeypatch.setenv("SPC_BILINEAR_LDS", "1")
+    o1, f1 = ops.resample_bilinear(_dev(d), xs, ys, mask=_mspec(inc), fill=np.nan)
+    exp, ef = O.resample_bilinear(filled, xs, ys)
+    assert_close(o1.get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="bilinear lds vs oracle")
+    assert np.array_equal(f1.get().astype(bool), ef[0])
