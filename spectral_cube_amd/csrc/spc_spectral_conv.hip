@@ -102,7 +102,7 @@ int launch_ring(int R, ConvArgs& A, hipStream_t st, int vec, bool fuse) {
     const bool want = env ? atoi(env) != 0 : true;
     // (the fast kernel addresses R+1 planes through one descriptor + 32-bit scalar offsets)
     const bool fits = (A.plane_stride * 4 * (R + 1) < (1LL << 31)) && (A.out_plane_stride * 4 * (R + 1) < (1LL << 31));
-    const bool fast = want && fits && vec == 2 && !(A.mask.flags & SPC_MASK_ARRAY) && A.zchunk >= A.nz;
+    const bool fast = want && fits && vec == 2 && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && A.zchunk >= A.nz;
     A.status = nullptr;
     if (!fast) return launch_ring_raw(R, A, st, 0, fuse);
     const size_t ntiles = (size_t)((A.ny * A.nx / 2 + 63) / 64);

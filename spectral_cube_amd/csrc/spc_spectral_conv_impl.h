@@ -306,8 +306,6 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
     const int nz = (int)A.nz;
     const int voff = (int)((y * A.row_stride + x) * 4);
     const int voff_out = FUSE ? 0 : (int)((y * A.out_row_stride + x) * 4);
-    const uint32_t flags = A.mask.flags;
-    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
     const bool EXT = FUSE && (A.mo.d_argmax || A.mo.d_argmin || A.mo.d_vmax || A.mo.d_vmin);
 
     float2v num[R];
@@ -330,30 +328,17 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
         float2v v[R];
 #pragma unroll
         for (int s = 0; s < R; ++s) v[s] = ld2_soff(rs, voff, (min(max(i0 + s, 0), nz - 1) - pb) * pbytes);
-        bool bad = false;
-        if (flags == 0) {                                // no predicate mask: only NaNs are invalid
+        // The fast pass only runs for masks that reject exactly the non-finite samples (none /
+        // isfinite), and those propagate through the FMAs: chk += 0 * (finished output) is NaN
+        // iff a NaN or Inf went into it - one packed FMA per output instead of compares on
+        // every sample.  Planes outside the cube (clamped duplicate loads) become valid zeros
+        // under a wave-uniform branch that only the first / last revolution takes.
+        if ((i0 < 0) || (i0 + R > nz)) {
 #pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const bool in = (i0 + s >= 0) && (i0 + s < nz);
-                bad = bad || (in && !((v[s].x == v[s].x) && (v[s].y == v[s].y)));
-                if (!in) v[s] = float2v{0.f, 0.f};      // out of range = valid zero
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const bool in = (i0 + s >= 0) && (i0 + s < nz);
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float r = v[s][c];
-                    bad = bad || (in && !(spc_pred(flags, tlo, thi, r) && (r == r)));
-                }
-                if (!in) v[s] = float2v{0.f, 0.f};
-            }
+            for (int s = 0; s < R; ++s)
+                if (!((i0 + s >= 0) && (i0 + s < nz))) v[s] = float2v{0.f, 0.f};
         }
-        if (__any(bad && live)) {                        // wave-uniform: hand the tile to the general kernel
-            if ((threadIdx.x & 63) == 0) A.status[tile] = 1;
-            return;
-        }
+        float2v chk = float2v{0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < R; ++s) {
 #pragma unroll
@@ -364,20 +349,21 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
             }
             const int e = (s + 1) % R;
             const int o = i0 + s - H;
+            chk = __builtin_elementwise_fma(num[e], float2v{0.f, 0.f}, chk);
             if (o >= 0 && o < nz) {
                 const float2v res = num[e] * A.inv_ksum;
                 if (!FUSE) {
                     if (live) st2_soff(ro, voff_out, (o - ob) * obytes, res);
                 } else {
                     const double cz = A.cen_linear ? fma((double)o, A.cen_dc, A.cen_c0) : A.cen[o];
+                    const double czz = cz * cz;
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
                         const double wd = (double)res[c];
                         MomState& w = ms[c];
                         w.s0 += wd;
                         w.s1 = fma(wd, cz, w.s1);
-                        w.s2 = fma(wd, cz * cz, w.s2);
-                        w.nvalid += 1;
+                        w.s2 = fma(wd, czz, w.s2);
                         if (EXT) {
                             if (res[c] > w.bmax) { w.bmax = res[c]; w.imax = o; }
                             if (res[c] < w.bmin) { w.bmin = res[c]; w.imin = o; }
@@ -386,12 +372,19 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
                 }
             }
         }
+        // wave-uniform: a non-finite sample went into this revolution's outputs -> the general
+        // kernel redoes the tile (whatever this wave already stored is overwritten)
+        if (__any((!(chk.x == chk.x) || !(chk.y == chk.y)) && live)) {
+            if ((threadIdx.x & 63) == 0) A.status[tile] = 1;
+            return;
+        }
     }
     if (FUSE && live) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int64_t o = y * A.mo_row_stride + x + c;
-            const MomState& w = ms[c];
+            MomState w = ms[c];
+            w.nvalid = nz;                                 // every sample of a clean tile is valid
             const double mu = w.s1 / w.s0;
             if (A.mo.d_m0) A.mo.d_m0[o] = A.dv * w.s0;
             if (A.mo.d_m1) A.mo.d_m1[o] = mu + A.m1_add;
