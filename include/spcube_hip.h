@@ -152,6 +152,33 @@ int spc_moment_order_f32(int device, void* stream, const spc_cube_f32* cube,
                          const double* d_mu, const double* d_s0, double* d_out,
                          int64_t out_row_stride);
 
+/* ---- statistics ------------------------------
+ * One read of the cube gives count / min / max / sum / sum of squares of the
+ * included, non-NaN samples, accumulated in float64.
+ *
+ * spc_stats_global_f32 replaces the per-chunk compute_stats + aggregation of
+ * DaskSpectralCubeMixin.statistics (spectral_cube/dask_spectral_cube.py:769-814)
+ * and the axis=None forms of sum / mean / std / max / min (:641-767).
+ * h_stats (HOST, 5 doubles) = {npts, min, max, sum, sumsq}; min / max are NaN
+ * when nothing is included.  Synchronises the stream. */
+int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube,
+                         const spc_mask* mask, double* h_stats);
+
+/* Reductions along one axis (0, 1 or 2) behind sum / mean / std / max / min with
+ * axis given (dask_spectral_cube.py:641-767; spectral_cube.py:578-791).  Output
+ * maps are C-contiguous with the reduced axis removed: (ny,nx), (nz,nx), (nz,ny).
+ * NULL outputs are skipped.  A ray without included samples gives count 0 and
+ * NaN in the four floating maps (nansum_allbadtonan, nanmin / nanmax of all-NaN). */
+typedef struct spc_stats_outputs {
+    int32_t* d_count;
+    float* d_min;
+    float* d_max;
+    double* d_sum;
+    double* d_sumsq;
+} spc_stats_outputs;
+int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube,
+                       const spc_mask* mask, int axis, const spc_stats_outputs* out);
+
 /* moments along a spatial axis (axis = 1 or 2), reference golden tables
  * spectral_cube/tests/test_moments.py:19-49.  d_cen is a (ny,nx) float64 map
  * of offsets along that axis (spectral_cube.py:1476-1503), pix_size the pixel

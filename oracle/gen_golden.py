@@ -526,6 +526,54 @@ def case_bilinear_scipy():
     print("bilinear vs scipy.ndimage.map_coordinates ok")
 
 
+def case_statistics():
+    """statistics() and sum / mean / std / max / min (axis None, 0, 1, 2) of the Dask class
+    on a masked fp32 cube with NaNs and a fully masked column; plus the reference's own
+    known-answer test (tests/test_dask.py:97-107, the `adv` fixture's values)."""
+    shape = (24, 20, 28)
+    data = synth.gaussian_line_cube(shape, 4242)
+    synth.add_nan_block(data, 3, 3, 3)
+    h = c1_header(*shape)
+    hdu = fits.PrimaryHDU(data=data, header=h)
+    sc = SpectralCube.read(hdu, use_dask=True)
+    med = float(np.nanmedian(data))
+    sc = sc.with_mask(LazyMask(lambda x: x > med, cube=sc))
+    blk = np.ones(shape, dtype=bool)
+    blk[:, 5:8, 9:12] = False                       # fully masked rays along z
+    blk[7, :, :] = False                            # a fully masked channel (rays along y / x)
+    sc = sc.with_mask(BooleanArrayMask(blk, sc.wcs))
+    include = np.asarray(sc.mask.include())
+    store = {"data": data, "include": include}
+    ref = sc.statistics()
+    mine = O.statistics(data, include)
+    for k in ("npts", "min", "max", "sum", "sumsq", "mean", "sigma", "rms"):
+        r = float(val(ref[k]))
+        assert abs(r - mine[k]) <= 2e-6 * abs(r), (k, r, mine[k])
+        store["stat_" + k] = mine[k]
+        store["ref_stat_" + k] = r
+    for op in ("sum", "mean", "std", "max", "min"):
+        for axis in (None, 0, 1, 2):
+            kw = {"ddof": 1} if op == "std" else {}
+            r = np.asarray(val(getattr(sc, op)(axis=axis, **kw)), dtype=np.float64)
+            m = np.asarray(O.reduce(data, include, op, axis=axis, **kw), dtype=np.float64)
+            scale = np.nanmax(np.abs(r)) if np.isfinite(np.nanmax(np.abs(r))) else 1.0
+            close(m, r, rtol=0, atol=3e-6 * scale, what="%s axis=%s" % (op, axis))
+            store["%s_%s" % (op, "all" if axis is None else axis)] = m
+    # the reference's known-answer table (tests/test_dask.py:97-107) for its `adv` fixture:
+    # np.random.seed(96); np.random.random((4, 3, 2))  (spectral_cube/conftest.py:259-271)
+    np.random.seed(96)
+    adv = np.random.random((4, 3, 2))
+    st = O.statistics(adv)
+    table = {"npts": 24, "mean": 0.4941651776136591, "sigma": 0.3021908870982011,
+             "sum": 11.85996426272782, "sumsq": 7.961125988022091, "min": 0.0363300285196364,
+             "max": 0.9662900439556562, "rms": 0.5759458158839716}
+    for k, v in table.items():
+        assert abs(st[k] - v) <= 1e-7 * abs(v), (k, st[k], v)      # assert_quantity_allclose default rtol
+    store["adv_data"] = adv
+    np.savez(os.path.join(OUT, "statistics.npz"), **store)
+    print("statistics ok")
+
+
 if __name__ == "__main__":
     case_moment_cube()
     case_c1()
@@ -535,4 +583,5 @@ if __name__ == "__main__":
     case_kernels()
     case_wcs()
     case_bilinear_scipy()
+    case_statistics()
     print("ALL GOLDEN VECTORS WRITTEN to", OUT)

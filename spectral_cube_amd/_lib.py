@@ -56,6 +56,11 @@ class SpcMomentOutputs(C.Structure):
                 ("d_nvalid", C.c_void_p), ("out_row_stride", C.c_int64)]
 
 
+class SpcStatsOutputs(C.Structure):
+    _fields_ = [("d_count", C.c_void_p), ("d_min", C.c_void_p), ("d_max", C.c_void_p),
+                ("d_sum", C.c_void_p), ("d_sumsq", C.c_void_p)]
+
+
 class SpcDeviceInfo(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 64),
                 ("compute_units", C.c_int), ("wavefront_size", C.c_int),
@@ -106,6 +111,8 @@ SIGNATURES = {
                                    _vp, _i64, _i64]),
     "spc_resample_bilinear_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _i64, _i64, _vp, _vp,
                                        _vp, _i64, _i64, _vp]),
+    "spc_stats_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d)]),
+    "spc_stats_axis_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _P(SpcStatsOutputs)]),
     "spc_comm_unique_id": (_i, [_P(C.c_uint8)]),
     "spc_comm_init": (_i, [_i, _P(C.c_uint8), _i, _i, _P(_vp)]),
     "spc_comm_destroy": (_i, [_vp]),

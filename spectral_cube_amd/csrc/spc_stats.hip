@@ -1,0 +1,322 @@
+// Single-pass statistics: count / min / max / sum / sum of squares of the included samples.
+//
+// spc_stats_global_f32 replaces the per-chunk compute_stats + aggregation of
+// DaskSpectralCubeMixin.statistics (spectral_cube/dask_spectral_cube.py:769-814);
+// spc_stats_axis_f32 replaces the per-axis nan-reductions behind sum / mean / std / max /
+// min (dask_spectral_cube.py:641-767; NumPy class spectral_cube.py:578-791).  The reference
+// makes one pass per statistic (and nanstd two); here every statistic of a call comes out of
+// ONE read of the cube, accumulated in float64.
+//
+//   global : the cube is a linear stream - 16-byte loads, grid-stride, per-thread
+//            accumulators, wave + LDS reduction, one partial record per block; the (few
+//            thousand) partials are finished on the host.
+//   axis 0 / 1 : "march" kernel - a lane owns 4 adjacent x, the 4 waves of a block split the
+//            marched axis (z or y), LDS combine.  Same access pattern as the moment kernel.
+//   axis 2 : one wave per (z, y) row, wave reduction.
+#include "spc_common.h"
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+struct Acc {                      // plain aggregate (lives in LDS too)
+    double sum, ssq;
+    float mn, mx;
+    int cnt;
+};
+__device__ __forceinline__ Acc acc_zero() { return Acc{0.0, 0.0, INFINITY, -INFINITY, 0}; }
+
+__device__ __forceinline__ void acc_add(Acc& a, float v, bool ok) {
+    const double d = ok ? (double)v : 0.0;
+    a.sum += d;
+    a.ssq = fma(d, d, a.ssq);
+    a.mn = ok ? fminf(a.mn, v) : a.mn;
+    a.mx = ok ? fmaxf(a.mx, v) : a.mx;
+    a.cnt += ok ? 1 : 0;
+}
+
+__device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
+    a.sum += b.sum; a.ssq += b.ssq;
+    a.mn = fminf(a.mn, b.mn); a.mx = fmaxf(a.mx, b.mx);
+    a.cnt += b.cnt;
+}
+
+__device__ __forceinline__ Acc acc_wave_reduce(Acc a) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Acc b;
+        b.sum = __shfl_xor(a.sum, d, 64); b.ssq = __shfl_xor(a.ssq, d, 64);
+        b.mn = __shfl_xor(a.mn, d, 64); b.mx = __shfl_xor(a.mx, d, 64);
+        b.cnt = __shfl_xor(a.cnt, d, 64);
+        acc_merge(a, b);
+    }
+    return a;
+}
+
+__device__ __forceinline__ bool included(const MaskDev& m, float v, unsigned mk) {
+    return spc_pred(m.flags, m.thr_lo, m.thr_hi, v) && (v == v) && (mk != 0);
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct StatArgs {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    MaskDev mask;
+    // global
+    int64_t nrows, rowlen;            // the cube as nrows rows of rowlen samples (1 row when contiguous)
+    int64_t row_a, row_b;             // row r -> offset (r / ny) * row_a + (r % ny) * row_b  (r itself when 1 row)
+    double* partial;                  // [gridDim.x][5]
+    // axis
+    int64_t n_outer, outer_stride, n_march, march_stride;
+    int64_t m_outer_stride, m_march_stride;
+    int32_t* o_cnt; float* o_min; float* o_max; double* o_sum; double* o_ssq;
+};
+
+// ---- whole cube -------------------------------------------------------------------------
+template <bool ARR>
+__global__ __launch_bounds__(256) void stats_global_kernel(const StatArgs A) {
+    __shared__ double s_red[4][5];
+    Acc a = acc_zero();
+    const int t = threadIdx.x;
+    constexpr int U = 4;
+    for (int64_t r = 0; r < A.nrows; ++r) {
+        const int64_t off = (A.nrows == 1) ? 0 : (r / A.ny) * A.row_a + (r % A.ny) * A.row_b;
+        const int64_t moff = (A.nrows == 1) ? 0 : (r / A.ny) * A.mask.plane_stride + (r % A.ny) * A.mask.row_stride;
+        const float* p = A.cube + off;
+        const uint8_t* pm = ARR ? A.mask.arr + moff : nullptr;
+        const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
+        const int64_t n4 = al ? A.rowlen / 4 : 0;
+        // 16-byte body, U chunks in flight per thread
+        const int64_t stride = (int64_t)gridDim.x * 256;
+        int64_t i = (int64_t)blockIdx.x * 256 + t;
+        for (; i + (U - 1) * stride < n4; i += U * stride) {
+            f32x4 v[U];
+            uint32_t m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i + u * stride);
+                m[u] = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm) + i + u * stride) : 0x01010101u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc_add(a, v[u][c], included(A.mask, v[u][c], (m[u] >> (8 * c)) & 0xffu));
+        }
+        for (; i < n4; i += stride) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+            const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[i] : 0x01010101u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu));
+        }
+        for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * 256 + t; j < A.rowlen; j += stride) {
+            const float v = p[j];
+            acc_add(a, v, included(A.mask, v, ARR ? pm[j] : 1u));
+        }
+    }
+    a = acc_wave_reduce(a);
+    const int w = t >> 6;
+    if ((t & 63) == 0) {
+        s_red[w][0] = (double)a.cnt; s_red[w][1] = (double)a.mn; s_red[w][2] = (double)a.mx;
+        s_red[w][3] = a.sum; s_red[w][4] = a.ssq;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double* o = A.partial + (int64_t)blockIdx.x * 5;
+        o[0] = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+        o[1] = fmin(fmin(s_red[0][1], s_red[1][1]), fmin(s_red[2][1], s_red[3][1]));
+        o[2] = fmax(fmax(s_red[0][2], s_red[1][2]), fmax(s_red[2][2], s_red[3][2]));
+        o[3] = (s_red[0][3] + s_red[1][3]) + (s_red[2][3] + s_red[3][3]);
+        o[4] = (s_red[0][4] + s_red[1][4]) + (s_red[2][4] + s_red[3][4]);
+    }
+}
+
+__device__ __forceinline__ void write_outputs(const StatArgs& A, int64_t o, const Acc& a) {
+    if (A.o_cnt) A.o_cnt[o] = a.cnt;
+    if (A.o_min) A.o_min[o] = a.cnt ? a.mn : NAN;        // nanmin / nanmax of an all-NaN ray is NaN
+    if (A.o_max) A.o_max[o] = a.cnt ? a.mx : NAN;
+    if (A.o_sum) A.o_sum[o] = a.cnt ? a.sum : NAN;       // nansum_allbadtonan (dask_spectral_cube.py:54-59)
+    if (A.o_ssq) A.o_ssq[o] = a.cnt ? a.ssq : NAN;
+}
+
+// ---- axis 0 (march z) and axis 1 (march y): lanes along x ---------------------------------
+template <int VEC, bool ARR>
+__global__ __launch_bounds__(256) void stats_march_kernel(const StatArgs A) {
+    constexpr int ZW = 4, U = 4;
+    __shared__ Acc s_acc[ZW - 1][64][VEC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t x = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+    const int64_t o = blockIdx.y;
+    const bool live = x < A.nx;
+    const int64_t xc = live ? x : 0;
+    const float* p = A.cube + o * A.outer_stride + xc;
+    const uint8_t* pm = ARR ? A.mask.arr + o * A.m_outer_stride + xc : nullptr;
+    Acc a[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) a[c] = acc_zero();
+    for (int64_t k0 = w; k0 < A.n_march; k0 += ZW * U) {
+        float v[U][VEC];
+        unsigned mk[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = min(k0 + (int64_t)u * ZW, A.n_march - 1);
+            if (VEC == 4) {
+                const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + k * A.march_stride));
+                const uint32_t m = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm + k * A.m_march_stride)) : 0x01010101u;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) { v[u][c] = q[c]; mk[u][c] = (m >> (8 * c)) & 0xffu; }
+            } else {
+                v[u][0] = p[k * A.march_stride];
+                mk[u][0] = ARR ? pm[k * A.m_march_stride] : 1u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = k0 + (int64_t)u * ZW < A.n_march;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) acc_add(a[c], v[u][c], in && included(A.mask, v[u][c], mk[u][c]));
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) s_acc[w - 1][lane][c] = a[c];
+    }
+    __syncthreads();
+    if (w == 0 && live) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+#pragma unroll
+            for (int k = 0; k < ZW - 1; ++k) acc_merge(a[c], s_acc[k][lane][c]);
+            if (x + c < A.nx) write_outputs(A, o * A.nx + x + c, a[c]);
+        }
+    }
+}
+
+// ---- axis 2: one wave per (z, y) row ------------------------------------------------------
+template <bool ARR>
+__global__ __launch_bounds__(256) void stats_rows_kernel(const StatArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.nz * A.ny) return;
+    const int64_t z = r / A.ny, y = r - z * A.ny;
+    const float* p = A.cube + z * A.plane_stride + y * A.row_stride;
+    const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + y * A.mask.row_stride : nullptr;
+    Acc a = acc_zero();
+    const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
+    const int64_t n4 = al ? A.nx / 4 : 0;
+    for (int64_t i = lane; i < n4; i += 64) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+        const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[i] : 0x01010101u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu));
+    }
+    for (int64_t j = n4 * 4 + lane; j < A.nx; j += 64) {
+        const float v = p[j];
+        acc_add(a, v, included(A.mask, v, ARR ? pm[j] : 1u));
+    }
+    a = acc_wave_reduce(a);
+    if (lane == 0) write_outputs(A, r, a);
+}
+
+int fill_common(StatArgs& A, const spc_cube_f32* cube, const spc_mask* mask) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    return SPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                         double* h_stats) {
+    SPC_REQUIRE(h_stats != nullptr, "h_stats is NULL");
+    StatArgs A{};
+    int rc = fill_common(A, cube, mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    const bool contig = (A.row_stride == A.nx) && (A.plane_stride == A.ny * A.nx) &&
+                        (!arr || (A.mask.row_stride == A.nx && A.mask.plane_stride == A.ny * A.nx));
+    if (contig) { A.nrows = 1; A.rowlen = A.nz * A.ny * A.nx; A.row_a = 0; A.row_b = 0; }
+    else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
+    // enough blocks to fill the chip, few enough that the host-side finish is trivial
+    const int64_t per_block = 256 * 4 * 4;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (A.rowlen + per_block - 1) / per_block));
+    double* d_partial = nullptr;
+    SPC_HIP(hipMallocAsync((void**)&d_partial, sizeof(double) * 5 * nblocks, st));
+    A.partial = d_partial;
+    if (arr) hipLaunchKernelGGL(stats_global_kernel<true>, dim3(nblocks), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(stats_global_kernel<false>, dim3(nblocks), dim3(256), 0, st, A);
+    hipError_t e = hipGetLastError();
+    std::vector<double> h((size_t)5 * nblocks);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_partial, sizeof(double) * 5 * nblocks, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFreeAsync(d_partial, st);
+    SPC_HIP(e);
+    double cnt = 0.0, mn = INFINITY, mx = -INFINITY;
+    long double sum = 0.0L, ssq = 0.0L;
+    for (int b = 0; b < nblocks; ++b) {
+        cnt += h[5 * b]; mn = std::min(mn, h[5 * b + 1]); mx = std::max(mx, h[5 * b + 2]);
+        sum += h[5 * b + 3]; ssq += h[5 * b + 4];
+    }
+    h_stats[0] = cnt;
+    h_stats[1] = cnt > 0 ? mn : NAN;
+    h_stats[2] = cnt > 0 ? mx : NAN;
+    h_stats[3] = (double)sum;
+    h_stats[4] = (double)ssq;
+    return SPC_OK;
+}
+
+int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, int axis,
+                       const spc_stats_outputs* out) {
+    SPC_REQUIRE(out != nullptr, "outputs struct is NULL");
+    SPC_REQUIRE(axis >= 0 && axis <= 2, "axis must be 0, 1 or 2");
+    SPC_REQUIRE(out->d_count || out->d_min || out->d_max || out->d_sum || out->d_sumsq, "no output requested");
+    StatArgs A{};
+    int rc = fill_common(A, cube, mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    A.o_cnt = out->d_count; A.o_min = out->d_min; A.o_max = out->d_max; A.o_sum = out->d_sum; A.o_ssq = out->d_sumsq;
+    if (axis == 2) {
+        const int64_t rows = A.nz * A.ny;
+        SPC_REQUIRE((rows + 3) / 4 <= 0x7fffffffLL, "too many rows for one launch");
+        dim3 grid((unsigned)((rows + 3) / 4));
+        if (arr) hipLaunchKernelGGL(stats_rows_kernel<true>, grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(stats_rows_kernel<false>, grid, dim3(256), 0, st, A);
+        SPC_LAUNCH_CHECK();
+        return SPC_OK;
+    }
+    if (axis == 0) {
+        A.n_outer = A.ny; A.outer_stride = A.row_stride; A.n_march = A.nz; A.march_stride = A.plane_stride;
+        A.m_outer_stride = A.mask.row_stride; A.m_march_stride = A.mask.plane_stride;
+    } else {
+        A.n_outer = A.nz; A.outer_stride = A.plane_stride; A.n_march = A.ny; A.march_stride = A.row_stride;
+        A.m_outer_stride = A.mask.plane_stride; A.m_march_stride = A.mask.row_stride;
+    }
+    SPC_REQUIRE(A.n_outer <= 65535, "more than 65535 output rows per call not supported (split the call)");
+    const bool v4 = (A.nx % 4 == 0) && (A.row_stride % 4 == 0) && (A.plane_stride % 4 == 0) &&
+                    ((((uintptr_t)A.cube) & 15) == 0) &&
+                    (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
+    if (v4) {
+        dim3 grid((unsigned)((A.nx + 255) / 256), (unsigned)A.n_outer);
+        if (arr) hipLaunchKernelGGL((stats_march_kernel<4, true>), grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((stats_march_kernel<4, false>), grid, dim3(256), 0, st, A);
+    } else {
+        dim3 grid((unsigned)((A.nx + 63) / 64), (unsigned)A.n_outer);
+        if (arr) hipLaunchKernelGGL((stats_march_kernel<1, true>), grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((stats_march_kernel<1, false>), grid, dim3(256), 0, st, A);
+    }
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+}  // extern "C"

@@ -419,11 +419,69 @@ class SpectralCube:
     def argmin(self, axis=0, how="auto", **kwargs):
         return self._extremum("argmin", axis, how)
 
-    def max(self, axis=0, how="auto", **kwargs):
-        return Projection(self._extremum("vmax", axis, how), unit=self._unit)
+    # ---- statistics / nan-reductions -----------------------------
+    def _reduce(self, op, axis, ddof=0):
+        """sum / mean / std / max / min (dask_spectral_cube.py:641-767): every statistic of a
+        call comes out of ONE pass over the cube (the reference: one pass per statistic, two
+        for nanstd)."""
+        need = {"sum": ("count", "sum"), "mean": ("count", "sum"), "std": ("count", "sum", "sumsq"),
+                "max": ("count", "max"), "min": ("count", "min")}[op]
+        if axis is None:
+            st = ops.stats_global(self._device_data(), mask=self._mask_spec())
+            n = st["npts"]
+            vals = {"count": np.float64(n), "sum": np.float64(st["sum"]), "sumsq": np.float64(st["sumsq"]),
+                    "max": np.float64(st["max"]), "min": np.float64(st["min"])}
+        else:
+            if axis not in (0, 1, 2):
+                raise ValueError("axis must be None, 0, 1 or 2")
+            r = ops.stats_axis(self._device_data(), axis, mask=self._mask_spec(), want=need)
+            vals = {k: r[k].get().astype(np.float64) for k in need}
+        n = vals["count"]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            if op == "sum":
+                out = np.where(n > 0, vals["sum"], np.nan)            # nansum_allbadtonan
+            elif op == "mean":
+                out = np.where(n > 0, vals["sum"] / n, np.nan)
+            elif op == "std":
+                var = (vals["sumsq"] - vals["sum"] * vals["sum"] / n) / (n - ddof)
+                out = np.where((n > 0) & (n - ddof > 0), np.sqrt(np.maximum(var, 0.0)), np.nan)
+            else:
+                out = np.where(n > 0, vals[op], np.nan)
+        if axis is None:
+            return float(out)
+        wcs = self._wcs.drop_spectral() if (axis == 0 and self._wcs is not None) else None
+        return Projection(out, unit=self._unit, wcs=wcs, meta=dict(self._meta))
 
-    def min(self, axis=0, how="auto", **kwargs):
-        return Projection(self._extremum("vmin", axis, how), unit=self._unit)
+    def sum(self, axis=None, how="auto", **kwargs):
+        """nansum_allbadtonan of the masked data (dask_spectral_cube.py:641-647)."""
+        return self._reduce("sum", axis)
+
+    def mean(self, axis=None, how="auto", **kwargs):
+        """nanmean (dask_spectral_cube.py:649-655)."""
+        return self._reduce("mean", axis)
+
+    def std(self, axis=None, how="auto", ddof=0, **kwargs):
+        """nanstd with ddof (dask_spectral_cube.py:695-709)."""
+        return self._reduce("std", axis, ddof=ddof)
+
+    def max(self, axis=None, how="auto", **kwargs):
+        """nanmax (dask_spectral_cube.py:733-739)."""
+        return self._reduce("max", axis)
+
+    def min(self, axis=None, how="auto", **kwargs):
+        """nanmin (dask_spectral_cube.py:741-747)."""
+        return self._reduce("min", axis)
+
+    def statistics(self):
+        """global basic statistics in ONE pass (dask_spectral_cube.py:769-814): npts, min, max,
+        sum, sumsq, mean, sigma (the reference's textbook formula), rms."""
+        st = ops.stats_global(self._device_data(), mask=self._mask_spec())
+        n = st["npts"]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            st["mean"] = st["sum"] / n if n else np.nan
+            st["sigma"] = float(np.sqrt((st["sumsq"] - st["sum"] ** 2 / n) / (n - 1))) if n > 1 else np.nan
+            st["rms"] = float(np.sqrt(st["sumsq"] / n)) if n else np.nan
+        return st
 
     # ---- smoothing ---------------------------------------------------------------------------
     def spectral_smooth(self, kernel, convolve=None, **kwargs):

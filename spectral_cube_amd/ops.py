@@ -274,3 +274,41 @@ def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_fo
               C.c_void_p(foot.ptr) if foot is not None else None)
     out._plan = (d_xs, d_ys)
     return out, foot
+
+
+# ---- statistics ----------------------------------------------
+STAT_KEYS = ("count", "min", "max", "sum", "sumsq")
+_STAT_DTYPES = {"count": np.int32, "min": np.float32, "max": np.float32, "sum": np.float64, "sumsq": np.float64}
+
+
+def stats_global(cube, mask=None, stream=None):
+    """{npts, min, max, sum, sumsq} of the included samples of the whole cube in ONE pass
+    (per-chunk compute_stats + aggregation of statistics(), dask_spectral_cube.py:769-814).
+    Returns python floats; synchronises."""
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    h = (C.c_double * 5)()
+    _lib.call("spc_stats_global_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), h)
+    return {"npts": h[0], "min": h[1], "max": h[2], "sum": h[3], "sumsq": h[4]}
+
+
+def stats_axis(cube, axis, mask=None, want=STAT_KEYS, stream=None, out=None):
+    """count / min / max / sum / sumsq maps along *axis* in ONE pass (the nan-reductions behind
+    sum / mean / std / max / min, dask_spectral_cube.py:641-767).  Returns DeviceArrays
+    (*out*: dict of preallocated ones, reused)."""
+    if axis not in (0, 1, 2):
+        raise ValueError("axis must be 0, 1 or 2")
+    shp = tuple(n for i, n in enumerate(cube.shape) if i != axis)
+    res = {}
+    for k in want:
+        a = out.get(k) if out else None
+        if a is None:
+            a = DeviceArray(shp, _STAT_DTYPES[k], cube.device)
+        elif tuple(a.shape) != shp or a.dtype != _STAT_DTYPES[k]:
+            raise ValueError("out[%r] must be %s %s" % (k, shp, _STAT_DTYPES[k]))
+        res[k] = a
+    o = _lib.SpcStatsOutputs()
+    for k in want:
+        setattr(o, "d_" + k, res[k].ptr)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_stats_axis_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis), C.byref(o))
+    return res

@@ -44,6 +44,17 @@ res.append(row("C2 1024^3 isfinite predicate: fused moment0+1+2", vox, ms, 4))
 outx = dict(out, argmax=DeviceArray(shape[1:], np.int64))
 ms = med_ms(lambda: ops.moments(cube, cen, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mask), out=outx, workspace=ws, want=("m0", "m1", "m2", "argmax")))
 res.append(row("C2 1024^3 u8 mask: moment0+1+2 + argmax", vox, ms, 5))
+# statistics() and the nan-reductions, one pass each
+mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=mask)
+ms = med_ms(lambda: ops.stats_global(cube, mask=mspec))
+res.append(row("C2 1024^3 u8 mask: statistics() (5 stats, one pass)", vox, ms, 5))
+ms = med_ms(lambda: ops.stats_global(cube))
+res.append(row("C2 1024^3 no mask: statistics()", vox, ms, 4))
+so = None
+for ax in (0, 1, 2):
+    so = ops.stats_axis(cube, ax, mask=mspec)
+    ms = med_ms(lambda: ops.stats_axis(cube, ax, mask=mspec, out=so))
+    res.append(row("C2 1024^3 u8 mask: count/min/max/sum/sumsq along axis %d" % ax, vox, ms, 5))
 del cube, mask
 # ---------------- C3: 2048^3, spectral_smooth sigma=4 then moment1
 shape = (2048, 2048, 2048); vox = np.prod(shape, dtype=np.int64)

@@ -261,3 +261,40 @@ def test_dask_chunk_functions(gpu):
         exp = O.moment(chunk, None, order, cen, 0.5, world0=-7.0)
         with np.errstate(all="ignore"):
             assert_close(out, exp, rtol=1e-7, atol=1e-9 * np.nanmax(np.abs(exp)), what="chunk moment")
+
+
+def test_statistics_and_reductions(gpu):
+    """SpectralCube.statistics / sum / mean / std / max / min mirror the Dask class
+    (dask_spectral_cube.py:641-814): golden vectors from the real reference, its known-answer
+    table for the `adv` fixture (tests/test_dask.py:97-107) and test_statistics_withnans."""
+    g = golden("statistics.npz")
+    d, inc = g["data"], g["include"]
+    hdr = str(golden("c1_moments.npz")["header"])
+    cube = SpectralCube.read(d, hdr).with_mask(inc)
+    st = cube.statistics()
+    for k in ("npts", "min", "max", "sum", "sumsq", "mean", "sigma", "rms"):
+        assert st[k] == pytest.approx(float(g["stat_" + k]), rel=1e-9), k
+        assert st[k] == pytest.approx(float(g["ref_stat_" + k]), rel=2e-6), k
+    for op in ("sum", "mean", "std", "max", "min"):
+        for axis in (None, 0, 1, 2):
+            kw = {"ddof": 1} if op == "std" else {}
+            got = np.asarray(getattr(cube, op)(axis=axis, **kw), dtype=np.float64)
+            exp = g["%s_%s" % (op, "all" if axis is None else axis)]
+            scale = np.nanmax(np.abs(exp))
+            assert_close(got, exp, atol=1e-9 * scale, what="%s axis=%s" % (op, axis))
+    # reference known-answer table (float64 fixture cast to this path's fp32: rtol 1e-6)
+    table = {"npts": 24, "mean": 0.4941651776136591, "sigma": 0.3021908870982011,
+             "sum": 11.85996426272782, "sumsq": 7.961125988022091, "min": 0.0363300285196364,
+             "max": 0.9662900439556562, "rms": 0.5759458158839716}
+    adv = g["adv_data"]
+    c2 = SpectralCube(data=adv.astype(np.float32), wcs=None)
+    st = c2.statistics()
+    for k, v in table.items():
+        assert st[k] == pytest.approx(v, rel=1e-6), k
+    # test_statistics_withnans (tests/test_dask.py:110-118): all-NaN channels, stats == reductions
+    a = adv.astype(np.float32).copy()
+    a[:2] = np.nan
+    c3 = SpectralCube(data=a, wcs=None)
+    st = c3.statistics()
+    for key in ("min", "max", "sum"):
+        assert st[key] == getattr(c3, key)()

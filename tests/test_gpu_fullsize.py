@@ -181,3 +181,36 @@ def test_c5_spectral_interpolate_2048_to_4096(gpu):
                          C.c_size_t(rowb), C.c_size_t(4096), 2)
     assert rc == 0
     assert_close(full, exp[:, ty - 1, :], atol=1e-5 * np.nanmax(np.abs(exp)), what="C5 lerp last row")
+
+
+def test_c2_statistics_1024cubed_periodic_rows(gpu):
+    """SURVEY.md section 8f rank 1 at configs[1] size: statistics() and the per-axis reductions
+    of a 1024^3 cube + uint8 mask built from a replicated tile: counts / sums scale with the
+    replication factor, extrema are the tile's, axis-0 maps are periodic in y."""
+    shape, ty = (1024, 1024, 1024), 8
+    _need(shape[0] * shape[1] * shape[2] * 5)
+    tile = synth.gaussian_line_cube((shape[0], ty, shape[2]), synth.SEEDS["C2"], chunk_rows=ty)
+    tile[:, 2, 16:24] = np.nan
+    tmask = synth.boolean_mask(tile, synth.SEEDS["C2"])
+    cube, mask = DeviceArray(shape, np.float32), DeviceArray(shape, np.uint8)
+    _replicate_rows(cube, tile, 4)
+    _replicate_rows(mask, tmask, 1)
+    mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=mask)
+    rep = shape[1] // ty
+    e = O.statistics(tile, tmask.astype(bool))
+    st = ops.stats_global(cube, mask=mspec)
+    assert st["npts"] == e["npts"] * rep
+    assert st["min"] == e["min"] and st["max"] == e["max"]
+    assert st["sum"] == pytest.approx(e["sum"] * rep, rel=1e-10)
+    assert st["sumsq"] == pytest.approx(e["sumsq"] * rep, rel=1e-10)
+    r0 = ops.stats_axis(cube, 0, mask=mspec)
+    e0 = O.reduce(tile, tmask.astype(bool), "sum", axis=0)
+    got = r0["sum"].get()
+    for y0 in (0, 512, shape[1] - ty):
+        assert_close(got[y0:y0 + ty], e0, rtol=1e-12, what="axis-0 sum rows %d" % y0)
+    assert_close(r0["max"].get()[:ty], O.reduce(tile, tmask.astype(bool), "max", axis=0), what="axis-0 max")
+    # axis 1 / 2 totals must agree with the global numbers
+    for ax in (1, 2):
+        r = ops.stats_axis(cube, ax, mask=mspec, want=("count", "sum"))
+        assert int(r["count"].get().astype(np.int64).sum()) == int(st["npts"])
+        assert float(np.nansum(r["sum"].get())) == pytest.approx(st["sum"], rel=1e-10)

@@ -390,3 +390,55 @@ def test_resample_bilinear_lds_and_gather_paths_agree(gpu, monkeypatch, scale, a
     exp, ef = O.resample_bilinear(filled, xs, ys)
     assert_close(o1.get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="bilinear lds vs oracle")
     assert np.array_equal(f1.get().astype(bool), ef[0])
+
+
+def test_stats_global_and_axes(gpu):
+    """spc_stats_global_f32 / spc_stats_axis_f32 against the golden vectors of the Dask class
+    (statistics(), sum/mean/std/max/min; tests/golden/statistics.npz), with a mask array,
+    predicate masks, odd shapes (scalar path) and strided row views."""
+    from spectral_cube_amd import ops, _lib
+    g = golden("statistics.npz")
+    d, inc = g["data"], g["include"]
+    st = ops.stats_global(_dev(d), mask=_mspec(inc))
+    exp = O.statistics(d, inc)
+    assert st["npts"] == exp["npts"]
+    assert st["min"] == exp["min"] and st["max"] == exp["max"]           # exact: selections of fp32 values
+    assert st["sum"] == pytest.approx(exp["sum"], rel=1e-12)              # fp64 accumulation of the same fp32 values
+    assert st["sumsq"] == pytest.approx(exp["sumsq"], rel=1e-12)
+    for axis in (0, 1, 2):
+        r = ops.stats_axis(_dev(d), axis, mask=_mspec(inc))
+        f = O.filled(d, inc, np.nan).astype(np.float64)
+        ok = ~np.isnan(f)
+        cnt = ok.sum(axis=axis)
+        assert np.array_equal(r["count"].get(), cnt)
+        assert_close(r["sum"].get(), O.reduce(d, inc, "sum", axis=axis), rtol=1e-12, what="sum axis %d" % axis)
+        assert_close(r["min"].get(), O.reduce(d, inc, "min", axis=axis), what="min axis %d" % axis)
+        assert_close(r["max"].get(), O.reduce(d, inc, "max", axis=axis), what="max axis %d" % axis)
+        with np.errstate(invalid="ignore"):
+            ssq = np.where(cnt > 0, np.nansum(f * f, axis=axis), np.nan)
+        assert_close(r["sumsq"].get(), ssq, rtol=1e-12, what="sumsq axis %d" % axis)
+    # odd shape -> scalar kernels; predicate mask; NaN and Inf samples
+    rng = np.random.default_rng(3)
+    d2 = rng.standard_normal((13, 11, 37)).astype(np.float32)
+    d2[2, 3, 5] = np.nan
+    d2[4, 1, 7] = np.inf
+    for spec, incl in ((None, None), (ops.MaskSpec(_lib.MASK_FINITE), np.isfinite(d2)),
+                       (ops.MaskSpec(_lib.MASK_GT | _lib.MASK_LE, -0.25, 1.5), (d2 > -0.25) & (d2 <= 1.5))):
+        st = ops.stats_global(_dev(d2), mask=spec)
+        exp = O.statistics(d2, incl)
+        assert st["npts"] == exp["npts"] and st["min"] == exp["min"] and st["max"] == exp["max"]
+        if np.isfinite(exp["sum"]):
+            assert st["sum"] == pytest.approx(exp["sum"], rel=1e-12)
+        for axis in (0, 1, 2):
+            r = ops.stats_axis(_dev(d2), axis, mask=spec, want=("count", "sum", "max"))
+            assert_close(r["sum"].get(), O.reduce(d2, incl, "sum", axis=axis), rtol=1e-12, what="odd sum %d" % axis)
+            assert_close(r["max"].get(), O.reduce(d2, incl, "max", axis=axis), what="odd max %d" % axis)
+    # strided row view == the same rows copied out
+    big = _dev(d)
+    view = big.rows(4, 16)
+    st_v = ops.stats_global(view)
+    st_c = ops.stats_global(_dev(np.ascontiguousarray(d[:, 4:16])))
+    assert all(st_v[k] == pytest.approx(st_c[k], rel=1e-12) for k in st_v)     # (different summation order)
+    # empty selection
+    st = ops.stats_global(_dev(d2), mask=ops.MaskSpec(_lib.MASK_GT | _lib.MASK_FINITE, 1e30))
+    assert st["npts"] == 0 and np.isnan(st["min"]) and np.isnan(st["max"]) and st["sum"] == 0.0
