@@ -71,6 +71,15 @@ __device__ __forceinline__ void store_run8_paired(float* p, int odd, f32x4 lo, f
 
 constexpr int kFastCols = 512;                // input columns per block of the fast kernel (2 per lane)
 constexpr int fast_txo(int R) { return ((kFastCols - 2 * (R / 2)) / 16) * 16; }
+// rows per x-pass phase of the fast kernel: ceil(R / nph) rounded up to an even count (row pairs)
+constexpr int fast_phase_rows(int R, int nph) { return (((R + nph - 1) / nph) + 1) / 2 * 2; }
+// Measured (29 taps, C4): 2 phases halve the LDS footprint (38 KB) but the kernel then needs 208
+// VGPRs; forcing 3 waves/SIMD spills 40 of them into the y pass (45.5 ms vs 37.9 ms), so one phase.
+constexpr int fast_phases(int R) { return 1; }
+#ifndef SPC_FAST_PREFETCH
+#define SPC_FAST_PREFETCH 1
+#endif
+constexpr bool kFastPrefetch = SPC_FAST_PREFETCH != 0;
 
 // ---- all-valid fast kernel -----------------------------------------------------------
 // Speculative first pass for planes without invalid samples: out = (Gy * Gx * d) / (sum ky *
@@ -87,12 +96,12 @@ constexpr int fast_txo(int R) { return ((kFastCols - 2 * (R / 2)) / 16) * 16; }
 // ISO: kx == ky (every Gaussian2DKernel with one stddev): both passes read the SAME scalar
 // weights - with two weight sets the 2 x 30 SGPRs spill and every spill reload is a VALU
 // v_readlane (measured: 755 per revolution next to 1044 FMAs).
-template <int R, bool ISO>
+template <int R, bool ISO, int NPH>
 __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs A) {
     constexpr int H = R / 2;
     constexpr int kTxoF = fast_txo(R);
     constexpr int kPitchF = 590;                          // floats per LDS row; 2*pitch = 28 (mod 32)
-    constexpr int kRows = R + (R & 1);                    // rows per revolution rounded up to pairs
+    constexpr int kRows = fast_phase_rows(R, NPH);        // LDS rows: one phase of the revolution (even)
     static_assert(kPitchF >= kFastCols + kFastCols / 8, "LDS row too short");
     __shared__ float yrow[kRows * kPitchF];
     __shared__ volatile int dirty;                        // set by any lane that meets a non-finite sample
@@ -137,6 +146,13 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     }
     for (int t0 = 0; t0 < T; t0 += R) {
         const int i0 = t0 - H;                            // first input row of this revolution
+        if (!kFastPrefetch && t0 > 0) {
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const int64_t ic = min(max(i0 + s, 0), ny - 1);
+                v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
+            }
+        }
         // Interior revolutions of interior strips (the common case) carry NO per-sample
         // bookkeeping at all; rows / columns outside the plane (clamped duplicate loads) are
         // turned into valid zeros only where they can occur, under block-uniform branches.
@@ -148,89 +164,100 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
                 if (!in) v[s] = float2v{0.f, 0.f};       // out of bounds = valid zero
             }
         }
-        // ---- y pass.  The fast pass only runs for masks where exactly the non-finite samples
-        // are invalid (none, or isfinite), and those propagate: chk += 0 * (finished row) is
-        // NaN iff a NaN or Inf went into that row - one packed FMA per row instead of compares
-        // on every sample (an Inf under "no mask" is merely handed to the general kernel).
+        // ---- y pass in NPH phases, each followed by the x pass over the rows it finished (LDS only
+        // holds one phase's rows: 29 taps, 2 phases: 38 KB instead of 71 KB per block -> the
+        // register file, not LDS, sets the occupancy).  The fast pass only runs for masks where
+        // exactly the non-finite samples are invalid (none, or isfinite), and those propagate:
+        // chk += 0 * (finished row) is NaN iff a NaN or Inf went into that row - one packed FMA per
+        // row instead of compares on every sample (an Inf under "no mask" is merely handed to the
+        // general kernel).
         float2v chk = float2v{0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
+        for (int phs = 0; phs < NPH; ++phs) {
+            constexpr int kPh = fast_phase_rows(R, NPH);
+            const int s0 = phs * kPh, s1 = (phs + 1) * kPh < R ? (phs + 1) * kPh : R;
 #pragma unroll
-            for (int m = 0; m < R; ++m) {
-                const int a = (s - m + R) % R;
-                if (a == 0) pk_mul_w(num[m], A.ky, 2 * H - a, v[s]);
-                else pk_fma_w(num[m], A.ky, 2 * H - a, v[s]);
+            for (int s = s0; s < s1; ++s) {
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                    const int a = (s - m + R) % R;
+                    if (a == 0) pk_mul_w(num[m], A.ky, 2 * H - a, v[s]);
+                    else pk_fma_w(num[m], A.ky, 2 * H - a, v[s]);
+                }
+                const float2v done = num[(s + 1) % R];   // row o = i0 + s - H
+                chk = __builtin_elementwise_fma(done, float2v{0.f, 0.f}, chk);
+                yrow[(s - s0) * kPitchF + ph0] = done.x;
+                yrow[(s - s0) * kPitchF + ph1] = done.y;
             }
-            const float2v done = num[(s + 1) % R];       // row o = i0 + s - H
-            chk = __builtin_elementwise_fma(done, float2v{0.f, 0.f}, chk);
-            yrow[s * kPitchF + ph0] = done.x;
-            yrow[s * kPitchF + ph1] = done.y;
-        }
-        if (!(chk.x == chk.x) || !(chk.y == chk.y)) dirty = 1;
-        lds_barrier();
-        if (dirty) {                                      // block-uniform: hand the tile to the general kernel
-            if (t == 0) A.status[z * A.fast_nstrips + strip] = 1;
-            return;
-        }
-        if (t0 + R < T) {
-#pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const int64_t ic = min(max(i0 + R + s, 0), ny - 1);
-                v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
+            if (phs == NPH - 1 && (!(chk.x == chk.x) || !(chk.y == chk.y))) dirty = 1;
+            lds_barrier();
+            if (phs == NPH - 1 && dirty) {                // block-uniform: hand the tile to the general kernel
+                if (t == 0) A.status[z * A.fast_nstrips + strip] = 1;   // (rows already written are redone)
+                return;
             }
-        }
-        // ---- x pass: task = (row pair, run of kRun output columns)
-        for (int task = t; task < (kRows / 2) * nrun_eff; task += nthr) {
-            const int pr = (int)(((float)task + 0.5f) * inv_nrun);   // exact: task < 2^12, nrun <= 62
-            const int j = task - pr * nrun_eff;
-            const int sa = 2 * pr, sb = 2 * pr + 1;
-            const int oa = i0 + sa - H, ob = oa + 1;
-            const bool wa = (oa >= 0) && (oa < ny), wb = (sb < R) && (ob >= 0) && (ob < ny);
-            if (!wa && !wb) continue;
-            const float* ra = yrow + sa * kPitchF;
-            const float* rb = yrow + (sb < R ? sb : sa) * kPitchF;
-            float2v r[kRun];
+            if (kFastPrefetch && t0 + R < T) {            // this phase's inputs of the NEXT revolution
 #pragma unroll
-            for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < kRun + 2 * H; ++i) {
-                const int c = kRun * j + i;
-                const int ph = c + (c >> 3);
-                const float2v in = float2v{ra[ph], rb[ph]};
-#pragma unroll
-                for (int k = 0; k < kRun; ++k) {
-                    const int widx = k + 2 * H - i;
-                    if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
+                for (int s = s0; s < s1; ++s) {
+                    const int64_t ic = min(max(i0 + R + s, 0), ny - 1);
+                    v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
                 }
             }
-            const int64_t xo = x0 + kRun * j;
-            float* da = A.out + z * A.out_plane_stride + (int64_t)oa * A.out_row_stride + xo;
-            float* db = da + A.out_row_stride;
-            if (R <= kPairedStoreMaxR && pairable) {
-                if (wa) store_run8_paired(da, t & 1, f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum,
-                                          f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum);
-                if (wb) store_run8_paired(db, t & 1, f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum,
-                                          f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum);
-            } else if (xo + kRun <= A.nx) {
-                if (wa) {
-                    __builtin_nontemporal_store(f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da));
-                    __builtin_nontemporal_store(f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da + 4));
-                }
-                if (wb) {
-                    __builtin_nontemporal_store(f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db));
-                    __builtin_nontemporal_store(f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db + 4));
-                }
-            } else {
+            // ---- x pass of this phase: task = (row pair, run of kRun output columns)
+            for (int task = t; task < ((s1 - s0 + 1) / 2) * nrun_eff; task += nthr) {
+                const int pr = (int)(((float)task + 0.5f) * inv_nrun);   // exact: task < 2^12, nrun <= 62
+                const int j = task - pr * nrun_eff;
+                const int sa = 2 * pr, sb = 2 * pr + 1;
+                const int oa = i0 + s0 + sa - H, ob = oa + 1;
+                const bool wa = (oa >= 0) && (oa < ny), wb = (s0 + sb < s1) && (ob >= 0) && (ob < ny);
+                if (!wa && !wb) continue;
+                const float* ra = yrow + sa * kPitchF;
+                const float* rb = yrow + (s0 + sb < s1 ? sb : sa) * kPitchF;
+                float2v r[kRun];
 #pragma unroll
-                for (int k = 0; k < kRun; ++k) {
-                    if (xo + k < A.nx) {
-                        if (wa) da[k] = r[k].x * A.inv_ksum;
-                        if (wb) db[k] = r[k].y * A.inv_ksum;
+                for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < kRun + 2 * H; ++i) {
+                    // (scheduling fence: left alone the compiler hoists all 2 x 36 LDS reads of a task
+                    // to its top and pays for them with 70 VGPRs - one wave per SIMD less)
+                    if (NPH > 1 && (i % 6) == 0) __builtin_amdgcn_sched_barrier(0);
+                    const int c = kRun * j + i;
+                    const int ph = c + (c >> 3);
+                    const float2v in = float2v{ra[ph], rb[ph]};
+#pragma unroll
+                    for (int k = 0; k < kRun; ++k) {
+                        const int widx = k + 2 * H - i;
+                        if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
+                    }
+                }
+                const int64_t xo = x0 + kRun * j;
+                float* da = A.out + z * A.out_plane_stride + (int64_t)oa * A.out_row_stride + xo;
+                float* db = da + A.out_row_stride;
+                if (R <= kPairedStoreMaxR && pairable) {
+                    if (wa) store_run8_paired(da, t & 1, f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum,
+                                              f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum);
+                    if (wb) store_run8_paired(db, t & 1, f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum,
+                                              f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum);
+                } else if (xo + kRun <= A.nx) {
+                    if (wa) {
+                        __builtin_nontemporal_store(f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da));
+                        __builtin_nontemporal_store(f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da + 4));
+                    }
+                    if (wb) {
+                        __builtin_nontemporal_store(f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db));
+                        __builtin_nontemporal_store(f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db + 4));
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kRun; ++k) {
+                        if (xo + k < A.nx) {
+                            if (wa) da[k] = r[k].x * A.inv_ksum;
+                            if (wb) db[k] = r[k].y * A.inv_ksum;
+                        }
                     }
                 }
             }
+            lds_barrier();
         }
-        lds_barrier();
     }
 }
 
@@ -422,8 +449,8 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
     if constexpr (R <= 33) {
         if (A.status) {      // speculative all-valid pass (the general kernel below redoes dirty tiles)
             dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1);
-            if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true>), fgrid, block, 0, st, A);
-            else hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
+            if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true, fast_phases(R)>), fgrid, block, 0, st, A);
+            else hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false, fast_phases(R)>), fgrid, block, 0, st, A);
             SPC_LAUNCH_CHECK();
         }
     }
