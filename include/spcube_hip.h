@@ -152,6 +152,17 @@ int spc_moment_order_f32(int device, void* stream, const spc_cube_f32* cube,
                          const double* d_mu, const double* d_s0, double* d_out,
                          int64_t out_row_stride);
 
+/* ---- FITS payload -> float32 -------------------
+ * Converts n raw big-endian FITS image samples (already in HBM) to native
+ * float32: what astropy.io.fits does on the host behind
+ * spectral_cube/io/fits.py:63-172 (read_data_fits) / :171-260 (load_fits_cube).
+ * bitpix in {8, 16, 32, 64, -32, -64}.  Scaling follows astropy: BITPIX 8/16 in
+ * float32 (raw * BSCALE + BZERO), 32/64 in float64 then rounded, floating types
+ * in their own precision; has_blank/blank: integer BLANK value -> NaN. */
+int spc_fits_to_f32(int device, void* stream, const void* d_raw, int bitpix,
+                    double bscale, double bzero, int has_blank, int64_t blank,
+                    int64_t n, float* d_out);
+
 /* ---- statistics ------------------------------
  * One read of the cube gives count / min / max / sum / sum of squares of the
  * included, non-NaN samples, accumulated in float64.

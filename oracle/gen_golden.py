@@ -574,6 +574,60 @@ def case_statistics():
     print("statistics ok")
 
 
+def case_fits_files():
+    """Small FITS files written by astropy (float32 cube with the C1 header, int16 with
+    BSCALE/BZERO/BLANK, float64, scaled int32, uint8, 4-axis with a degenerate Stokes axis) and
+    the arrays astropy reads back from them: pins oracle_np.fits_decode and the header parser /
+    loader of spectral_cube_amd.io_fits."""
+    import io
+    rng = np.random.default_rng(99)
+    shape = (5, 6, 7)
+    store = {}
+    h = c1_header(*shape)
+
+    def roundtrip(name, hdu):
+        buf = io.BytesIO()
+        hdu.writeto(buf)
+        raw = buf.getvalue()
+        with fits.open(io.BytesIO(raw)) as hl:
+            data = np.array(hl[0].data)                       # astropy applies BSCALE/BZERO/BLANK here
+            hdr = hl[0].header
+        store[name + "_file"] = np.frombuffer(raw, dtype=np.uint8)
+        store[name + "_expected"] = data.astype(np.float32)
+        return raw, data, hdr
+
+    d32 = rng.standard_normal(shape).astype(np.float32)
+    d32[1, 2, 3] = np.nan
+    roundtrip("f32", fits.PrimaryHDU(data=d32, header=h))
+    roundtrip("f64", fits.PrimaryHDU(data=rng.standard_normal(shape), header=h))
+    i16 = rng.integers(-3000, 3000, size=shape).astype(np.int16)
+    i16[0, 0, :3] = -32768
+    hdu = fits.PrimaryHDU(data=i16, header=h)
+    hdu.header["BSCALE"], hdu.header["BZERO"], hdu.header["BLANK"] = 0.0125, 3.5, -32768
+    roundtrip("i16", hdu)
+    i32 = rng.integers(-10**6, 10**6, size=shape).astype(np.int32)
+    hdu = fits.PrimaryHDU(data=i32, header=h)
+    hdu.header["BSCALE"], hdu.header["BZERO"] = 1e-4, -2.0
+    roundtrip("i32", hdu)
+    roundtrip("u8", fits.PrimaryHDU(data=rng.integers(0, 255, size=shape).astype(np.uint8), header=h))
+    h4 = h.copy()
+    h4["NAXIS"] = 4
+    h4["NAXIS4"], h4["CTYPE4"], h4["CRVAL4"], h4["CRPIX4"], h4["CDELT4"] = 1, "STOKES", 1.0, 1.0, 1.0
+    roundtrip("f32_4d", fits.PrimaryHDU(data=d32[None], header=h4))
+    for name in ("f32", "f64", "i16", "i32", "u8"):
+        raw = store[name + "_file"].tobytes()
+        with fits.open(io.BytesIO(raw), do_not_scale_image_data=True) as hl:
+            hdr = hl[0].header
+            off = len(hdr.tostring()) if len(hdr.tostring()) % 2880 == 0 else (len(hdr.tostring()) // 2880 + 1) * 2880
+            mine = O.fits_decode(raw[off:], hdr["BITPIX"], shape, hdr.get("BSCALE", 1.0), hdr.get("BZERO", 0.0),
+                                 hdr.get("BLANK"))
+        exp = store[name + "_expected"]
+        assert np.array_equal(np.isnan(mine), np.isnan(exp)), name
+        assert np.array_equal(mine[~np.isnan(exp)], exp[~np.isnan(exp)]), name       # bit-exact
+    np.savez_compressed(os.path.join(OUT, "fits_files.npz"), **store)
+    print("fits files ok")
+
+
 if __name__ == "__main__":
     case_moment_cube()
     case_c1()
@@ -584,4 +638,5 @@ if __name__ == "__main__":
     case_wcs()
     case_bilinear_scipy()
     case_statistics()
+    case_fits_files()
     print("ALL GOLDEN VECTORS WRITTEN to", OUT)

@@ -28,7 +28,7 @@ __all__ = [
     "filled", "moment", "moments012", "moment_cubewise", "argmax", "argmin",
     "convolve_fill_interp", "spectral_smooth", "spatial_smooth",
     "spectral_interpolate", "resample_bilinear", "reproject_separable",
-    "statistics", "reduce",
+    "statistics", "reduce", "fits_decode",
 ]
 
 
@@ -397,3 +397,33 @@ def reduce(data, include, op, axis=None, ddof=0):
         if op == "min":
             return np.nanmin(d, axis=axis) if d.size else np.nan
     raise ValueError(op)
+
+
+# --------------------------------------------------------------------------
+# FITS payload decoding
+# --------------------------------------------------------------------------
+def fits_decode(raw, bitpix, shape, bscale=1.0, bzero=0.0, blank=None):
+    """What ``astropy.io.fits`` hands to ``read_data_fits`` (spectral_cube/io/
+    fits.py:63-172) for an image HDU, as float32: big-endian payload -> native;
+    BSCALE/BZERO applied in float32 for BITPIX 8/16, float64 for 32/64 and in
+    the file's own precision for floating types; integer BLANK -> NaN when the
+    data are scaled (astropy ``_ImageBaseHDU._get_scaled_image_data``).
+    gen_golden pins this against astropy reading real files."""
+    dt = {8: ">u1", 16: ">i2", 32: ">i4", 64: ">i8", -32: ">f4", -64: ">f8"}[bitpix]
+    a = np.frombuffer(raw, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+    scaled = (bscale != 1.0) or (bzero != 0.0)
+    if bitpix < 0:
+        v = a.astype(a.dtype.newbyteorder("="))
+        if scaled:
+            v = v * v.dtype.type(bscale) + v.dtype.type(bzero)
+        return v.astype(np.float32)
+    if not scaled and blank is None:
+        return a.astype(np.float32)
+    work = np.float32 if bitpix in (8, 16) else np.float64
+    v = a.astype(work)
+    if scaled:
+        v *= work(bscale)
+        v += work(bzero)
+    if blank is not None:
+        v[a == blank] = np.nan
+    return v.astype(np.float32)

@@ -22,6 +22,7 @@ reference; units are plain strings unless astropy is importable; the 1e8-voxel
 materialised on the host.
 """
 import operator
+import os
 import warnings
 
 import numpy as np
@@ -136,11 +137,20 @@ class SpectralCube:
 
     # ---- construction helpers ------------------------------------------------
     @classmethod
-    def read(cls, data, header, device=0, **kw):
-        """In-memory analogue of ``SpectralCube.read(hdu)``: like the FITS
-        reader (spectral_cube/io/fits.py:214) it attaches
-        ``LazyMask(np.isfinite)``."""
-        cube = cls(np.asarray(data), header=header, device=device, **kw)
+    def read(cls, data, header=None, device=0, hdu=None, **kw):
+        """``SpectralCube.read``: a FITS file name (streamed to HBM through pinned staging
+        buffers and decoded on the device, ``io_fits.load_cube``), or an in-memory array +
+        header.  Like the FITS reader (spectral_cube/io/fits.py:171-260) it attaches
+        ``LazyMask(np.isfinite)`` and copies ``BUNIT`` into ``meta``."""
+        if isinstance(data, (str, os.PathLike)):
+            from . import io_fits
+            dev, hdr = io_fits.load_cube(os.fspath(data), device=device, hdu=hdu)
+            meta = dict(kw.pop("meta", None) or {})
+            if "BUNIT" in hdr:
+                meta["BUNIT"] = hdr["BUNIT"]
+            cube = cls(None, header=hdr, device=device, _dev=dev, meta=meta, **kw)
+        else:
+            cube = cls(np.asarray(data), header=header, device=device, **kw)
         cube._mask = M.LazyMask(np.isfinite, cube=cube)
         return cube
 

@@ -1,0 +1,287 @@
+"""FITS cube reader feeding HBM through pinned staging buffers.
+
+Mirrors the part of ``spectral_cube/io/fits.py`` (read_data_fits :63-172, load_fits_cube
+:171-260) that matters for the hot path: primary-HDU (or chosen image-HDU) cubes with 3 axes, or
+4 axes with a degenerate Stokes axis, any BITPIX, BSCALE/BZERO/BLANK, ``BUNIT`` -> meta, and the
+``LazyMask(np.isfinite)`` the reference attaches.  No astropy: the header is parsed here, and the
+payload never passes through numpy arithmetic -
+
+    file --os.preadv (reader threads, GIL released)--> pinned host buffers
+         --spc_memcpy_h2d (async, copy stream)-------> raw staging in HBM
+         --spc_fits_to_f32 (byte swap + BSCALE/BZERO/BLANK at HBM speed)--> (nz, ny, nx) float32
+
+so the host only moves bytes and the PCIe link is the limit.  There is no CPU fallback: without
+the HIP library / a GPU ``load_cube`` raises.
+"""
+import ctypes as C
+import os
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, Event, Stream
+from .wcs import parse_header
+
+BLOCK = 2880
+_BYTES = {8: 1, 16: 2, 32: 4, 64: 8, -32: 4, -64: 8}
+
+
+class FITSReadError(Exception):
+    """spectral_cube.io.fits.FITSReadError"""
+
+
+class FitsImage:
+    """Location and encoding of one image HDU inside a FITS file."""
+
+    def __init__(self, path, header, data_offset):
+        self.path, self.header, self.data_offset = path, header, data_offset
+        self.bitpix = int(header.get("BITPIX", 0))
+        naxis = int(header.get("NAXIS", 0))
+        self.axes = [int(header["NAXIS%d" % (i + 1)]) for i in range(naxis)]       # FITS order: x fastest
+        self.bscale = float(header.get("BSCALE", 1.0))
+        self.bzero = float(header.get("BZERO", 0.0))
+        self.blank = header.get("BLANK", None)
+        if self.bitpix not in _BYTES and naxis:
+            raise FITSReadError("unsupported BITPIX %r" % self.bitpix)
+
+    @property
+    def nsamples(self):
+        return int(np.prod(self.axes, dtype=np.int64)) if self.axes else 0
+
+    @property
+    def nbytes(self):
+        return self.nsamples * _BYTES.get(self.bitpix, 0)
+
+
+def _read_header_block(f):
+    cards = []
+    while True:
+        blk = f.read(BLOCK)
+        if len(blk) < BLOCK:
+            raise FITSReadError("truncated FITS header")
+        text = blk.decode("ascii", "replace")
+        done = False
+        for i in range(0, BLOCK, 80):
+            card = text[i:i + 80]
+            if card.startswith("END") and card[3:].strip() == "":
+                done = True
+                break
+            cards.append(card)
+        if done:
+            return cards
+
+
+def scan_hdus(path):
+    """[(FitsImage)] for every HDU of the file (headers only; payloads are skipped)."""
+    out = []
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        first = True
+        while f.tell() < size:
+            start = f.tell()
+            head = f.read(8)
+            f.seek(start)
+            if first and head != b"SIMPLE  ":
+                raise FITSReadError("%s is not a FITS file" % path)
+            if not first and head != b"XTENSION":
+                break
+            cards = _read_header_block(f)
+            hdr = parse_header("".join(cards))
+            img = FitsImage(path, hdr, f.tell())
+            nbytes = img.nbytes if (first or str(hdr.get("XTENSION", "")).strip() == "IMAGE") else \
+                int(abs(int(hdr.get("BITPIX", 8))) // 8 * int(np.prod([int(hdr.get("NAXIS%d" % (i + 1), 0))
+                    for i in range(int(hdr.get("NAXIS", 0)))], dtype=np.int64)) + int(hdr.get("PCOUNT", 0)))
+            img.is_image = first or str(hdr.get("XTENSION", "")).strip() == "IMAGE"
+            out.append(img)
+            f.seek(img.data_offset + ((nbytes + BLOCK - 1) // BLOCK) * BLOCK)
+            first = False
+    return out
+
+
+def find_image(path, hdu=None):
+    """the HDU ``read_data_fits`` would pick: *hdu* if given, else the first HDU with data."""
+    hdus = scan_hdus(path)
+    if hdu is not None:
+        if not (0 <= hdu < len(hdus)) or not hdus[hdu].is_image or hdus[hdu].nsamples == 0:
+            raise FITSReadError("No data found in HDU {0}. You can try using the hdu= keyword argument "
+                                "to read data from another HDU.".format(hdu))
+        return hdus[hdu]
+    for h in hdus:
+        if h.is_image and h.nsamples:
+            return h
+    raise ValueError("No arrays found")
+
+
+def cube_shape(img):
+    """(nz, ny, nx) of a 3-axis image, or of a 4-axis image whose extra axis is degenerate
+    (load_fits_cube accepts naxis 3 and 4; multi-Stokes files are outside this path)."""
+    ax = list(img.axes)
+    if len(ax) == 4:
+        if ax[3] == 1:
+            ax = ax[:3]
+        elif ax[2] == 1:
+            ax = [ax[0], ax[1], ax[3]]
+        else:
+            raise NotImplementedError("multi-Stokes cubes (StokesSpectralCube) are outside the accelerated path")
+    if len(ax) != 3:
+        raise FITSReadError("Data should be 3- or 4-dimensional")
+    return ax[2], ax[1], ax[0]
+
+
+def cube_header(img):
+    """header with the degenerate 4th axis removed (what _split_stokes/_orient leave behind)."""
+    h = dict(img.header)
+    if len(img.axes) == 4:
+        drop = 4 if img.axes[3] == 1 else 3
+        for k in list(h):
+            if k[-1:] == str(drop) and k[:-1] in ("NAXIS", "CTYPE", "CRVAL", "CRPIX", "CDELT", "CUNIT", "CROTA"):
+                del h[k]
+            elif k.startswith("PC") and "_" in k and str(drop) in k[2:].split("_"):
+                del h[k]
+        if drop == 3:                              # (x, y, stokes, spectral): spectral axis becomes axis 3
+            for base in ("CTYPE", "CRVAL", "CRPIX", "CDELT", "CUNIT"):
+                if base + "4" in img.header:
+                    h[base + "3"] = img.header[base + "4"]
+                    h.pop(base + "4", None)
+        h["NAXIS"] = 3
+        h["WCSAXES"] = 3
+    return h
+
+
+class _Pinned:
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _lib.call("spc_host_alloc", C.c_size_t(nbytes), C.byref(p))
+        self.ptr, self.nbytes = p.value, nbytes
+        self.view = (C.c_uint8 * nbytes).from_address(self.ptr)
+        self.free_evt = None
+
+    def close(self):
+        if self.ptr:
+            _lib.call("spc_host_free", C.c_void_p(self.ptr))
+            self.ptr = 0
+
+
+def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, readers=8, stats=None):
+    """Stream the image payload of *path* into a (nz, ny, nx) float32 DeviceArray.
+
+    chunk_bytes / nbuffers: size and count of the pinned staging buffers; readers: threads
+    filling them with os.preadv.  Returns (DeviceArray, header dict).  *stats*, if a dict,
+    receives {"bytes", "seconds"} of the payload transfer (the PCIe-inclusive rate).
+    Measured on the MI355X box, 4 GiB float32 file in the page cache (profiles/r01_fits_reader.log):
+    1 reader 7.9 GB/s, 4 readers 24 GB/s, 8 readers x 128 MiB buffers 44 GB/s (the PCIe Gen5 x16
+    link), i.e. 1.1e4 Mvoxel/s end to end - two orders below the HBM-resident kernels."""
+    import time
+    _lib.require_gpu()
+    img = find_image(path, hdu)
+    nz, ny, nx = cube_shape(img)
+    bps = _BYTES[img.bitpix]
+    out = DeviceArray((nz, ny, nx), np.float32, device)
+    total = img.nbytes
+    chunk = max(bps * 4, min(chunk_bytes, total) // (bps * 4) * (bps * 4))      # whole samples, 16-byte friendly
+    nchunks = (total + chunk - 1) // chunk
+    nbuf = max(1, min(nbuffers, nchunks))
+    pinned = [_Pinned(chunk) for _ in range(nbuf)]
+    d_raw = [DeviceArray((chunk,), np.uint8, device) for _ in range(nbuf)]
+    stream = Stream(device)
+    fd = os.open(path, os.O_RDONLY)
+    has_blank = img.blank is not None and img.bitpix > 0
+    t0 = time.perf_counter()
+    try:
+        def fill(i):
+            b = pinned[i % nbuf]
+            off, n = i * chunk, min(chunk, total - i * chunk)
+            # split one chunk across the reader threads' pieces
+            got = 0
+            mv = memoryview(b.view)[:n]
+            while got < n:
+                r = os.preadv(fd, [mv[got:]], img.data_offset + off + got)
+                if r <= 0:
+                    raise FITSReadError("truncated FITS payload")
+                got += r
+            return i, n
+
+        with ThreadPoolExecutor(max_workers=max(1, readers)) as pool:
+            pending = {}
+            nxt = 0
+
+            def submit(i):
+                b = pinned[i % nbuf]
+                if b.free_evt is not None:          # the H2D that last used this buffer must be done
+                    b.free_evt.synchronize()
+                    b.free_evt = None
+                pending[i] = pool.submit(fill, i)
+
+            while nxt < min(nbuf, nchunks):
+                submit(nxt)
+                nxt += 1
+            for i in range(nchunks):
+                _, n = pending.pop(i).result()
+                b, raw = pinned[i % nbuf], d_raw[i % nbuf]
+                _lib.call("spc_memcpy_h2d", device, C.c_void_p(raw.ptr), C.c_void_p(b.ptr), C.c_size_t(n), stream.handle)
+                ev = Event(device)
+                ev.record(stream)
+                b.free_evt = ev
+                first = (i * chunk) // bps
+                _lib.call("spc_fits_to_f32", device, stream.handle, C.c_void_p(raw.ptr), img.bitpix,
+                          img.bscale, img.bzero, 1 if has_blank else 0, int(img.blank) if has_blank else 0,
+                          n // bps, C.c_void_p(out.ptr + first * 4))
+                if nxt < nchunks:
+                    submit(nxt)
+                    nxt += 1
+        stream.synchronize()
+    finally:
+        os.close(fd)
+        for b in pinned:
+            b.close()
+    if stats is not None:
+        stats.update(bytes=total, seconds=time.perf_counter() - t0)
+    out._keep = d_raw
+    return out, cube_header(img)
+
+
+# ---- writer (tests / fixtures; the reference writes through astropy, io/fits.py:262-294) ----------
+def _card(key, value, comment=""):
+    if isinstance(value, bool):
+        v = "%20s" % ("T" if value else "F")
+    elif isinstance(value, (int, np.integer)):
+        v = "%20d" % int(value)
+    elif isinstance(value, (float, np.floating)):
+        v = "%20s" % repr(float(value)).upper().replace("E+", "E")
+    else:
+        v = "'%-8s'" % str(value).replace("'", "''")
+    card = "%-8s= %s" % (key[:8], v)
+    if comment:
+        card += " / " + comment
+    return card[:80].ljust(80)
+
+
+def write_fits(path, data, header=None, bitpix=None, bscale=None, bzero=None, blank=None):
+    """Minimal FITS writer: *data* (any numpy array, written big-endian as it is) plus header keys."""
+    data = np.asarray(data)
+    if bitpix is None:
+        bitpix = {np.dtype("f4"): -32, np.dtype("f8"): -64, np.dtype("i2"): 16, np.dtype("i4"): 32,
+                  np.dtype("u1"): 8, np.dtype("i8"): 64}[data.dtype.newbyteorder("=")]
+    cards = [_card("SIMPLE", True), _card("BITPIX", bitpix), _card("NAXIS", data.ndim)]
+    for i, n in enumerate(data.shape[::-1]):
+        cards.append(_card("NAXIS%d" % (i + 1), n))
+    if bscale is not None:
+        cards.append(_card("BSCALE", float(bscale)))
+    if bzero is not None:
+        cards.append(_card("BZERO", float(bzero)))
+    if blank is not None:
+        cards.append(_card("BLANK", int(blank)))
+    for k, v in (parse_header(header) if header is not None else {}).items():
+        if k in ("SIMPLE", "BITPIX", "BSCALE", "BZERO", "BLANK", "EXTEND") or k.startswith("NAXIS"):
+            continue
+        cards.append(_card(k, v))
+    cards.append("END".ljust(80))
+    text = "".join(cards)
+    text += " " * ((-len(text)) % BLOCK)
+    payload = data.astype(data.dtype.newbyteorder(">")).tobytes()
+    with open(path, "wb") as f:
+        f.write(text.encode("ascii"))
+        f.write(payload)
+        f.write(b"\0" * ((-len(payload)) % BLOCK))

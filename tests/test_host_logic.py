@@ -242,3 +242,38 @@ def test_halo_bounds_reproduce_the_unsharded_smoothing():
         got = np.concatenate(got, axis=1)
         assert np.array_equal(np.isnan(got), np.isnan(full))
         np.testing.assert_array_equal(got[~np.isnan(full)], full[~np.isnan(full)])
+
+
+def test_fits_header_scan_and_writer(tmp_path):
+    """io_fits parses the headers of files written by astropy (tests/golden/fits_files.npz,
+    produced by oracle/gen_golden.py) and finds payload offset / BITPIX / scaling; the oracle's
+    decode of that payload equals what astropy read back (bit-exact); the minimal writer
+    round-trips through the scanner."""
+    import oracle_np as O
+    from spectral_cube_amd import io_fits
+    g = golden("fits_files.npz")
+    for name, bitpix in (("f32", -32), ("f64", -64), ("i16", 16), ("i32", 32), ("u8", 8), ("f32_4d", -32)):
+        path = tmp_path / (name + ".fits")
+        path.write_bytes(g[name + "_file"].tobytes())
+        img = io_fits.find_image(str(path))
+        assert img.bitpix == bitpix and io_fits.cube_shape(img) == (5, 6, 7)
+        raw = g[name + "_file"].tobytes()[img.data_offset:]
+        got = O.fits_decode(raw, img.bitpix, (5, 6, 7), img.bscale, img.bzero, img.blank)
+        exp = g[name + "_expected"].reshape(5, 6, 7)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)])
+        hdr = io_fits.cube_header(img)
+        assert hdr["NAXIS"] == 3 and "CTYPE4" not in hdr and hdr["CTYPE3"].startswith("VRAD")
+    assert io_fits.find_image(str(tmp_path / "i16.fits")).blank == -32768
+    # writer -> scanner
+    d = np.arange(24, dtype=np.float32).reshape(2, 3, 4)
+    p = tmp_path / "w.fits"
+    io_fits.write_fits(str(p), d, {"CTYPE3": "VRAD", "CRVAL3": 1.5e3, "BUNIT": "K"})
+    img = io_fits.find_image(str(p))
+    assert io_fits.cube_shape(img) == (2, 3, 4) and img.header["BUNIT"] == "K" and img.header["CRVAL3"] == 1500.0
+    assert p.stat().st_size % 2880 == 0
+    raw = p.read_bytes()[img.data_offset:]
+    assert np.array_equal(O.fits_decode(raw, -32, (2, 3, 4)), d)
+    (tmp_path / "bad.fits").write_bytes(b"not a fits file" * 300)
+    with pytest.raises(io_fits.FITSReadError):
+        io_fits.find_image(str(tmp_path / "bad.fits"))
