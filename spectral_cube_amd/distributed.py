@@ -63,6 +63,19 @@ def smooth_moment0_strip(ext_cube, kernel2d, top, nrows, mask=None, dv=1.0, stre
     return r["m0"]
 
 
+def read_strip(path, rank, world_size, halo=0, device=None, **kw):
+    """Each rank streams ONLY its row strip (plus *halo* rows per side) of a FITS cube into its
+    own GPU (io_fits.load_cube(rows=...)): the reader feeding (y, x) tiles of SURVEY.md
+    section 8e/8f.  Returns (DeviceArray, header, top, nrows) with the rank's own rows at
+    [top, top + nrows) of the loaded strip."""
+    from . import io_fits
+    img = io_fits.find_image(path, kw.get("hdu"))
+    ny = io_fits.cube_shape(img)[1]
+    h0, h1, top, n = halo_bounds(ny, world_size, rank, halo)
+    dev, hdr = io_fits.load_cube(path, device=rank if device is None else device, rows=(h0, h1), **kw)
+    return dev, hdr, top, n
+
+
 class HostGatherComm:
     """all-gather of host strips through torch.distributed (gloo).  Used by the
     world_size-2 CPU tests and as the loud, explicitly reported stitch fallback

@@ -164,11 +164,13 @@ class _Pinned:
             self.ptr = 0
 
 
-def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, readers=8, stats=None):
+def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, readers=8, stats=None, rows=None):
     """Stream the image payload of *path* into a (nz, ny, nx) float32 DeviceArray.
 
     chunk_bytes / nbuffers: size and count of the pinned staging buffers; readers: threads
-    filling them with os.preadv.  Returns (DeviceArray, header dict).  *stats*, if a dict,
+    filling them with os.preadv; rows=(y0, y1): load only that row strip of every plane (the
+    (y, x)-tile sharding of SURVEY.md section 8e; CRPIX2 of the returned header is shifted).
+    Returns (DeviceArray, header dict).  *stats*, if a dict,
     receives {"bytes", "seconds"} of the payload transfer (the PCIe-inclusive rate).
     Measured on the MI355X box, 4 GiB float32 file in the page cache (profiles/r01_fits_reader.log):
     1 reader 7.9 GB/s, 4 readers 24 GB/s, 8 readers x 128 MiB buffers 44 GB/s (the PCIe Gen5 x16
@@ -176,12 +178,23 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
     import time
     _lib.require_gpu()
     img = find_image(path, hdu)
-    nz, ny, nx = cube_shape(img)
+    nz, ny_file, nx = cube_shape(img)
+    y0, y1 = (0, ny_file) if rows is None else (int(rows[0]), int(rows[1]))
+    if not (0 <= y0 < y1 <= ny_file):
+        raise ValueError("rows must satisfy 0 <= y0 < y1 <= %d" % ny_file)
+    ny = y1 - y0
     bps = _BYTES[img.bitpix]
     out = DeviceArray((nz, ny, nx), np.float32, device)
-    total = img.nbytes
-    chunk = max(bps * 4, min(chunk_bytes, total) // (bps * 4) * (bps * 4))      # whole samples, 16-byte friendly
-    nchunks = (total + chunk - 1) // chunk
+    seg = ny * nx * bps                                # one plane's strip: contiguous in the file
+    total = nz * seg
+    if rows is None:                                   # whole planes: the payload is ONE contiguous run
+        chunk = max(bps * 4, min(chunk_bytes, total) // (bps * 4) * (bps * 4))      # whole samples, 16-byte friendly
+        nchunks = (total + chunk - 1) // chunk
+        ppc = 0
+    else:                                              # row strip (multi-GPU sharding): whole strips per chunk
+        ppc = max(1, min(nz, chunk_bytes // seg))      # planes per chunk
+        chunk = ppc * seg
+        nchunks = (nz + ppc - 1) // ppc
     nbuf = max(1, min(nbuffers, nchunks))
     pinned = [_Pinned(chunk) for _ in range(nbuf)]
     d_raw = [DeviceArray((chunk,), np.uint8, device) for _ in range(nbuf)]
@@ -190,18 +203,25 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
     has_blank = img.blank is not None and img.bitpix > 0
     t0 = time.perf_counter()
     try:
-        def fill(i):
-            b = pinned[i % nbuf]
-            off, n = i * chunk, min(chunk, total - i * chunk)
-            # split one chunk across the reader threads' pieces
-            got = 0
-            mv = memoryview(b.view)[:n]
+        def pread_full(mv, offset):
+            got, n = 0, len(mv)
             while got < n:
-                r = os.preadv(fd, [mv[got:]], img.data_offset + off + got)
+                r = os.preadv(fd, [mv[got:]], offset + got)
                 if r <= 0:
                     raise FITSReadError("truncated FITS payload")
                 got += r
-            return i, n
+
+        def fill(i):
+            b = pinned[i % nbuf]
+            if rows is None:
+                off, n = i * chunk, min(chunk, total - i * chunk)
+                pread_full(memoryview(b.view)[:n], img.data_offset + off)
+                return i, n
+            z0, z1 = i * ppc, min(nz, (i + 1) * ppc)
+            mv = memoryview(b.view)
+            for k, z in enumerate(range(z0, z1)):
+                pread_full(mv[k * seg:(k + 1) * seg], img.data_offset + (z * ny_file + y0) * nx * bps)
+            return i, (z1 - z0) * seg
 
         with ThreadPoolExecutor(max_workers=max(1, readers)) as pool:
             pending = {}
@@ -239,7 +259,12 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
     if stats is not None:
         stats.update(bytes=total, seconds=time.perf_counter() - t0)
     out._keep = d_raw
-    return out, cube_header(img)
+    hdr = cube_header(img)
+    if rows is not None:
+        hdr["NAXIS2"] = ny
+        if "CRPIX2" in hdr:
+            hdr["CRPIX2"] = float(hdr["CRPIX2"]) - y0
+    return out, hdr
 
 
 # ---- writer (tests / fixtures; the reference writes through astropy, io/fits.py:262-294) ----------

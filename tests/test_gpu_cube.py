@@ -334,3 +334,15 @@ def test_read_fits_files(gpu, tmp_path):
     assert_close(np.asarray(cube.moment0()), np.asarray(ref.moment0()), what="moment0 of a file-read cube")
     with pytest.raises(io_fits.FITSReadError):
         SpectralCube.read(str(p), hdu=3)
+    # row strips (multi-GPU sharding of the reader): every strip equals the slice, header shifted
+    from spectral_cube_amd.distributed import read_strip, strip_bounds
+    for ws, halo in ((3, 0), (2, 5)):
+        for r in range(ws):
+            dev, h, top, n = read_strip(str(p), r, ws, halo=halo, device=0, chunk_bytes=200 << 10, nbuffers=2)
+            y0, y1 = strip_bounds(d.shape[1], ws, r)
+            lo = max(0, y0 - halo)
+            exp = d[:, lo:min(d.shape[1], y1 + halo)]
+            got = dev.get()
+            assert got.shape == exp.shape and top == y0 - lo and n == y1 - y0
+            assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)])
+            assert h["NAXIS2"] == exp.shape[1]
