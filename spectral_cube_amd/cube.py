@@ -154,6 +154,12 @@ class SpectralCube:
         cube._mask = M.LazyMask(np.isfinite, cube=cube)
         return cube
 
+    def write(self, filename, overwrite=False, format=None):
+        """Write the (unmasked) data as a FITS cube (io/fits.py:262-294): device byte swap,
+        pinned read-back, no host arithmetic."""
+        from . import io_fits
+        io_fits.save_cube(os.fspath(filename), self._device_data(), header=self._header, overwrite=overwrite)
+
     @classmethod
     def from_device(cls, dev, wcs=None, header=None, mask=None, **kw):
         if dev.dtype != np.float32 or len(dev.shape) != 3:

@@ -334,6 +334,19 @@ def test_read_fits_files(gpu, tmp_path):
     assert_close(np.asarray(cube.moment0()), np.asarray(ref.moment0()), what="moment0 of a file-read cube")
     with pytest.raises(io_fits.FITSReadError):
         SpectralCube.read(str(p), hdu=3)
+    # write -> read round trip (device byte swap both ways), small chunks; header survives
+    sm = cube.spectral_smooth(Gaussian1DKernel(1.0))
+    q = tmp_path / "out.fits"
+    from spectral_cube_amd import io_fits as IO
+    IO.save_cube(str(q), sm._device_data(), header=sm.header, chunk_bytes=100 << 10, nbuffers=2)
+    back = SpectralCube.read(str(q))
+    a, b = back._device_data().get(), sm._device_data().get()
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(b)], b[~np.isnan(b)])
+    assert back.header["CTYPE3"] == cube.header["CTYPE3"] and q.stat().st_size % 2880 == 0
+    assert float(back.header["CDELT3"]) == float(cube.header["CDELT3"])
+    with pytest.raises(OSError):
+        sm.write(str(q))
+    sm.write(str(q), overwrite=True)
     # row strips (multi-GPU sharding of the reader): every strip equals the slice, header shifted
     from spectral_cube_amd.distributed import read_strip, strip_bounds
     for ws, halo in ((3, 0), (2, 5)):
