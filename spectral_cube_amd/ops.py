@@ -185,9 +185,17 @@ def separable_factors(kernel2d, rtol=1e-12):
         return None
     ky = k[:, ix].copy()
     kx = k[iy, :] / piv
-    if np.allclose(np.outer(ky, kx), k, rtol=rtol, atol=rtol * abs(piv)):
-        return ky, kx
-    return None
+    if not np.allclose(np.outer(ky, kx), k, rtol=rtol, atol=rtol * abs(piv)):
+        return None
+    if piv > 0:
+        # split the scale evenly: for a symmetric kernel (every Gaussian2DKernel with one stddev)
+        # both factors then coincide, and handing the library IDENTICAL arrays lets it pick the
+        # kernels that keep one set of weights in scalar registers for both passes
+        s = np.sqrt(piv)
+        ky, kx = ky / s, kx * s
+        if ky.shape == kx.shape and np.allclose(ky, kx, rtol=rtol, atol=rtol * np.abs(ky).max()):
+            kx = ky.copy()
+    return ky, kx
 
 
 def spatial_conv(cube, kernel2d, mask=None, out=None, stream=None):
