@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include "../../include/spcube_hip.h"
 
 void spc_set_error(const char* fmt, ...);
@@ -58,6 +59,24 @@ struct SpcDeviceGuard {
         spc_set_error("hipSetDevice(%d) failed", dev);                        \
         return SPC_ERR_HIP;                                                   \
     }
+
+// ---- scratch allocations ------------------------------------------------------------------
+// Synchronous hipMalloc / hipFree on purpose: with the stream-ordered allocator (hipMallocAsync /
+// hipFreeAsync) of this ROCm build, calls that alternate between kernel families intermittently
+// computed on wrong data; hipFree also drains the device, which is
+// what lets a scratch buffer be released right after the last kernel using it was queued.
+static inline hipError_t spc_scratch_alloc(void** p, size_t bytes, hipStream_t) { return hipMalloc(p, bytes ? bytes : 1); }
+static inline hipError_t spc_scratch_free(void* p, hipStream_t) { return p ? hipFree(p) : hipSuccess; }
+
+// ---- tile flags handed from a speculative kernel to the kernel that redoes flagged tiles -----
+// Producer and consumer are queued back to back on one stream; the kernel boundary orders them.
+__device__ __forceinline__ void spc_flag_set(unsigned char* p) { *reinterpret_cast<volatile unsigned char*>(p) = 1; }
+__device__ __forceinline__ unsigned char spc_flag_get(const unsigned char* p) {
+    return *reinterpret_cast<const volatile unsigned char*>(p);
+}
+static inline hipError_t spc_flags_clear(unsigned char* d_flags, size_t n, hipStream_t st) {
+    return n ? hipMemsetAsync(d_flags, 0, n, st) : hipSuccess;
+}
 
 // ---- device-side mask evaluation -----------------------------------------
 struct MaskDev {

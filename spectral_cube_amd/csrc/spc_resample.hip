@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const int64_t xo = bx * 64 + (wave * 16) + (lane & 15);
     const int64_t yo = by * 4 + (lane >> 4);
     if (xo >= A.nx_out || yo >= A.ny_out) return;
-    if (A.status && A.status[(yo >> 5) * A.tiles32_x + (xo >> 5)] == 0) return;   // wave-uniform: tile done via LDS
+    if (A.status && spc_flag_get(A.status + (yo >> 5) * A.tiles32_x + (xo >> 5)) == 0) return;   // wave-uniform: tile done via LDS
     const int64_t pix = yo * A.nx_out + xo;
     const double xs = A.xs[pix], ys = A.ys[pix];
     const bool inside = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
     const int ymin = s_ymin;
     const int nrows = (s_ymax < 0) ? 0 : s_ymax - ymin + 1;
     const int64_t tile = by * A.tiles32_x + bx;
-    if (nrows > kRowsMax) { if (t == 0) A.status[tile] = 1; return; }
+    if (nrows > kRowsMax) { if (t == 0) spc_flag_set(A.status + tile); return; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (inside[q]) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
     }
     __syncthreads();
     const int E = s_off[nrows];
-    if (E > kElemsMax) { if (t == 0) A.status[tile] = 1; return; }
+    if (E > kElemsMax) { if (t == 0) spc_flag_set(A.status + tile); return; }
 
     // per-thread fill list: staged element e = t + 256 k lives in source row ymin + r
     int foff[kFill], moff[kFill];
@@ -443,8 +443,8 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
         A.zchunk_lds = (cube->nz + ns - 1) / ns;
         A.zchunk_lds = ((A.zchunk_lds + kStageU - 1) / kStageU) * kStageU;
         ns = (int)((cube->nz + A.zchunk_lds - 1) / A.zchunk_lds);
-        SPC_HIP(hipMallocAsync((void**)&d_status, (size_t)ntiles, st));
-        SPC_HIP(hipMemsetAsync(d_status, 0, (size_t)ntiles, st));
+        SPC_HIP(spc_scratch_alloc((void**)&d_status, (size_t)ntiles, st));
+        SPC_HIP(spc_flags_clear(d_status, (size_t)ntiles, st));
         A.status = d_status;
         dim3 g((unsigned)ntiles, (unsigned)ns);
         if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<true, true>), g, dim3(256), 0, st, A);
@@ -454,7 +454,7 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     }
     hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
     SPC_LAUNCH_CHECK();
-    if (d_status) SPC_HIP(hipFreeAsync(d_status, st));
+    if (d_status) SPC_HIP(spc_scratch_free(d_status, st));
     return SPC_OK;
 }
 

@@ -216,8 +216,8 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
     if (want && al && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && nysplit == 1 && R <= 33 && cube->nx >= 64) {
         A.fast_nstrips = (int)((cube->nx + fast_txo(R) - 1) / fast_txo(R));
         const size_t nt = (size_t)A.fast_nstrips * (size_t)cube->nz;
-        SPC_HIP(hipMallocAsync((void**)&d_status, nt, st));
-        SPC_HIP(hipMemsetAsync(d_status, 0, nt, st));
+        SPC_HIP(spc_scratch_alloc((void**)&d_status, nt, st));
+        SPC_HIP(spc_flags_clear(d_status, nt, st));
         A.status = d_status;
     }
     switch (R) {
@@ -228,7 +228,7 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
         case 65: rc = launch_sep<65>(A, st, grid, arr); break;
         default: spc_set_error("no ring kernel for R=%d", R); rc = SPC_ERR_UNSUPPORTED;
     }
-    if (d_status) SPC_HIP(hipFreeAsync(d_status, st));
+    if (d_status) SPC_HIP(spc_scratch_free(d_status, st));
     return rc;
 }
 

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
             if (phs == NPH - 1 && (!(chk.x == chk.x) || !(chk.y == chk.y))) dirty = 1;
             lds_barrier();
             if (phs == NPH - 1 && dirty) {                // block-uniform: hand the tile to the general kernel
-                if (t == 0) A.status[z * A.fast_nstrips + strip] = 1;   // (rows already written are redone)
+                if (t == 0) spc_flag_set(A.status + z * A.fast_nstrips + strip);   // (rows already written are redone)
                 return;
             }
             if (kFastPrefetch && t0 + R < T) {            // this phase's inputs of the NEXT revolution
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
     if (A.status) {   // both fast tiles this strip overlaps were finished by the all-valid kernel
         const int ft = fast_txo(R);
         const int f0 = (int)(x0 / ft), f1 = (int)(min(x0 + A.txo, A.nx) - 1) / ft;
-        if (A.status[z * A.fast_nstrips + f0] == 0 && A.status[z * A.fast_nstrips + f1] == 0) return;
+        if (spc_flag_get(A.status + z * A.fast_nstrips + f0) == 0 && spc_flag_get(A.status + z * A.fast_nstrips + f1) == 0) return;
     }
     constexpr int kTxo = ((kThreads - 2 * H) / kRun) * kRun;    // output columns per strip (== A.txo)
     // partial last strip: see the fast kernel

@@ -85,6 +85,142 @@ int pick_ring(const double* k, int ntaps) {
     return 0;
 }
 
+// ---- fused smooth -> moments without the stencil ------------------------------------------
+// With every sample valid the smoothed spectrum is LINEAR in the data (astropy's NaN-free
+// branch: s_o = sum_i k[o + H - i] d_i / sum(k), out-of-range samples are zeros), so
+//   S_n' = sum_o c_o^n s_o = sum_i d_i W_n(i),   W_n(i) = sum_o k[o + H - i] c_o^n / sum(k):
+// the three moment sums of the smoothed cube are weighted sums over the UNSMOOTHED data with
+// per-channel weights computed on the host in float64 (nz x ntaps operations).  The 33-tap
+// stencil (33 packed FMAs per voxel pair, VALU-bound at 49 % of the HBM roofline) becomes
+// three fp64 FMAs per voxel - the plain moment kernel's access pattern and speed.  A spaxel
+// that holds a NaN / Inf is not linear (NaN renormalisation): its 128-column tile is flagged
+// and redone by the general fused kernel.  (The reference rounds the smoothed cube to float32
+// before summing; this path does not - a 1e-7-level difference, inside the 1e-5 tolerance.)
+struct WmArgs {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    const double* w;                  // [nz][3]
+    double dv, m1_add;
+    spc_moment_outputs mo;
+    int64_t mo_row_stride;
+    unsigned char* status;            // one byte per 128 columns (linear spaxel index >> 7)
+};
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void weighted_moments_kernel(const WmArgs A) {
+    constexpr int ZW = 4, U = 4;
+    __shared__ double sh[ZW - 1][4][4][64];            // wave, {s0, s1, s2, chk}, column, lane
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t x = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const int64_t y = blockIdx.y;
+    const bool live = x < A.nx;
+    const float* p = A.cube + y * A.row_stride + (live ? x : 0);
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float chk[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k0 = w; k0 < A.nz; k0 += ZW * U) {
+        f32x4w v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = min(k0 + (int64_t)u * ZW, A.nz - 1);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4w*>(p + k * A.plane_stride));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = k0 + (int64_t)u * ZW;
+            if (k < A.nz) {                                 // wave-uniform
+                const double w0 = A.w[3 * k], w1 = A.w[3 * k + 1], w2 = A.w[3 * k + 2];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double d = (double)v[u][c];
+                    s0[c] = fma(d, w0, s0[c]);
+                    s1[c] = fma(d, w1, s1[c]);
+                    s2[c] = fma(d, w2, s2[c]);
+                    chk[c] = fmaf(v[u][c], 0.f, chk[c]);    // NaN iff a NaN / Inf was read
+                }
+            }
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            sh[w - 1][0][c][lane] = s0[c]; sh[w - 1][1][c][lane] = s1[c];
+            sh[w - 1][2][c][lane] = s2[c]; sh[w - 1][3][c][lane] = (double)chk[c];
+        }
+    }
+    __syncthreads();
+    if (w != 0) return;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int k = 0; k < ZW - 1; ++k) {
+            s0[c] += sh[k][0][c][lane]; s1[c] += sh[k][1][c][lane]; s2[c] += sh[k][2][c][lane];
+            chk[c] += (float)sh[k][3][c][lane];
+        }
+        bad = bad || !(chk[c] == chk[c]);
+    }
+    // a 128-column tile = 32 lanes: if ANY of them is bad the whole tile is left to the general
+    // kernel (no output line is then written by both kernels)
+    const unsigned long long bm = __ballot(bad && live);
+    const bool tile_bad = ((lane < 32) ? (bm & 0xffffffffull) : (bm >> 32)) != 0;
+    if (!live) return;
+    if (tile_bad) { if (bad) spc_flag_set(A.status + ((y * A.nx + x) >> 7)); return; }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t o = y * A.mo_row_stride + x + c;
+        const double mu = s1[c] / s0[c];
+        if (A.mo.d_m0) A.mo.d_m0[o] = A.dv * s0[c];
+        if (A.mo.d_m1) A.mo.d_m1[o] = mu + A.m1_add;
+        if (A.mo.d_m2) A.mo.d_m2[o] = s2[c] / s0[c] - mu * mu;
+        if (A.mo.d_mu) A.mo.d_mu[o] = mu;
+        if (A.mo.d_s0) A.mo.d_s0[o] = s0[c];
+        if (A.mo.d_nvalid) A.mo.d_nvalid[o] = (int32_t)A.nz;
+    }
+}
+
+// returns 1 when the algebraic pass ran (A.status then marks the tiles left to the general kernel)
+int try_weighted_moments(ConvArgs& A, const spc_cube_f32* cube, const double* h_kernel, int ntaps,
+                         const double* h_cen, hipStream_t st, unsigned char** d_status, double** d_w) {
+    const char* env = getenv("SPC_FUSE_ALGEBRAIC");
+    if (env && atoi(env) == 0) return 0;
+    const bool ext = A.mo.d_argmax || A.mo.d_argmin || A.mo.d_vmax || A.mo.d_vmin;
+    const bool al = (cube->nx % 4 == 0) && (cube->row_stride % 4 == 0) && (cube->plane_stride % 4 == 0) &&
+                    ((((uintptr_t)cube->d_data) & 15) == 0);
+    if (ext || !al || (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) != 0 || cube->ny > 65535) return 0;
+    const int64_t nz = cube->nz;
+    std::vector<double> cen((size_t)nz);
+    if (h_cen) std::copy(h_cen, h_cen + nz, cen.begin());
+    else if (hipMemcpy(cen.data(), A.cen, sizeof(double) * nz, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    double ksum = 0.0;
+    for (int j = 0; j < ntaps; ++j) ksum += h_kernel[j];
+    const int H = ntaps / 2;
+    std::vector<double> w((size_t)nz * 3);
+    for (int64_t i = 0; i < nz; ++i) {
+        long double a0 = 0, a1 = 0, a2 = 0;
+        for (int j = 0; j < ntaps; ++j) {
+            const int64_t o = i - H + j;                   // the output that reads input i through tap j
+            if (o < 0 || o >= nz) continue;
+            const long double kj = h_kernel[j], c = cen[(size_t)o];
+            a0 += kj; a1 += kj * c; a2 += kj * c * c;
+        }
+        w[3 * i] = (double)(a0 / ksum); w[3 * i + 1] = (double)(a1 / ksum); w[3 * i + 2] = (double)(a2 / ksum);
+    }
+    const size_t ntiles = (size_t)((A.ny * A.nx / 2 + 63) / 64);
+    if (spc_scratch_alloc((void**)d_status, ntiles, st) != hipSuccess) return 0;
+    if (spc_scratch_alloc((void**)d_w, sizeof(double) * w.size(), st) != hipSuccess) { (void)spc_scratch_free(*d_status, st); *d_status = nullptr; return 0; }
+    (void)spc_flags_clear(*d_status, ntiles, st);
+    // pageable source: the copy is staged before the call returns, so the vector may die afterwards
+    (void)hipMemcpyAsync(*d_w, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, st);
+    (void)hipStreamSynchronize(st);
+    WmArgs W{};
+    W.cube = A.cube; W.nz = A.nz; W.ny = A.ny; W.nx = A.nx; W.row_stride = A.row_stride; W.plane_stride = A.plane_stride;
+    W.w = *d_w; W.dv = A.dv; W.m1_add = A.m1_add; W.mo = A.mo; W.mo_row_stride = A.mo_row_stride; W.status = *d_status;
+    hipLaunchKernelGGL(weighted_moments_kernel, dim3((unsigned)((A.nx + 255) / 256), (unsigned)A.ny), dim3(256), 0, st, W);
+    A.status = *d_status;
+    return 1;
+}
+
 int launch_ring_raw(int R, const ConvArgs& A, hipStream_t st, int fast, bool fuse) {
     switch (R) {
         case 9: return spc_sconv::launch<9>(A, st, fast, fuse);
@@ -107,11 +243,11 @@ int launch_ring(int R, ConvArgs& A, hipStream_t st, int vec, bool fuse) {
     if (!fast) return launch_ring_raw(R, A, st, 0, fuse);
     const size_t ntiles = (size_t)((A.ny * A.nx / 2 + 63) / 64);
     unsigned char* d_status = nullptr;
-    SPC_HIP(hipMallocAsync((void**)&d_status, ntiles, st));
-    SPC_HIP(hipMemsetAsync(d_status, 0, ntiles, st));
+    SPC_HIP(spc_scratch_alloc((void**)&d_status, ntiles, st));
+    SPC_HIP(spc_flags_clear(d_status, ntiles, st));
     A.status = d_status;
     const int rc = launch_ring_raw(R, A, st, 1, fuse);
-    SPC_HIP(hipFreeAsync(d_status, st));
+    SPC_HIP(spc_scratch_free(d_status, st));
     return rc;
 }
 
@@ -247,6 +383,15 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
     A.zchunk = cube->nz;
     SPC_REQUIRE(cube->ny * cube->row_stride < (1LL << 29), "image plane too large for 32-bit buffer offsets");
     const int vec = pick_vec(cube, A.mask, nullptr, 0, 0);
+    unsigned char* d_status = nullptr;
+    double* d_w = nullptr;
+    if (try_weighted_moments(A, cube, h_kernel, ntaps, h_cen, (hipStream_t)stream, &d_status, &d_w)) {
+        SPC_LAUNCH_CHECK();
+        rc = launch_ring_raw(R, A, (hipStream_t)stream, 0, true);      // general kernel: flagged tiles only
+        (void)spc_scratch_free(d_status, (hipStream_t)stream);
+        (void)spc_scratch_free(d_w, (hipStream_t)stream);
+        return rc;
+    }
     return launch_ring(R, A, (hipStream_t)stream, vec, true);
 }
 

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ny * A.nx) return;
     // tiles (128 columns) already finished by the all-valid fast kernel
-    if (A.status && A.status[__builtin_amdgcn_readfirstlane((int)(col >> 7))] == 0) return;
+    if (A.status && spc_flag_get(A.status + __builtin_amdgcn_readfirstlane((int)(col >> 7))) == 0) return;
     const int64_t y = col / A.nx, x = col - y * A.nx;
     const int nz = (int)A.nz;
     const int zb = (int)(blockIdx.y * A.zchunk);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
         // wave-uniform: a non-finite sample went into this revolution's outputs -> the general
         // kernel redoes the tile (whatever this wave already stored is overwritten)
         if (__any((!(chk.x == chk.x) || !(chk.y == chk.y)) && live)) {
-            if ((threadIdx.x & 63) == 0) A.status[tile] = 1;
+            if ((threadIdx.x & 63) == 0) spc_flag_set(A.status + tile);
             return;
         }
     }

@@ -250,7 +250,7 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, con
     const int64_t per_block = 256 * 4 * 4;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (A.rowlen + per_block - 1) / per_block));
     double* d_partial = nullptr;
-    SPC_HIP(hipMallocAsync((void**)&d_partial, sizeof(double) * 5 * nblocks, st));
+    SPC_HIP(spc_scratch_alloc((void**)&d_partial, sizeof(double) * 5 * nblocks, st));
     A.partial = d_partial;
     if (arr) hipLaunchKernelGGL(stats_global_kernel<true>, dim3(nblocks), dim3(256), 0, st, A);
     else hipLaunchKernelGGL(stats_global_kernel<false>, dim3(nblocks), dim3(256), 0, st, A);
@@ -258,7 +258,7 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, con
     std::vector<double> h((size_t)5 * nblocks);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_partial, sizeof(double) * 5 * nblocks, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFreeAsync(d_partial, st);
+    (void)spc_scratch_free(d_partial, st);
     SPC_HIP(e);
     double cnt = 0.0, mn = INFINITY, mx = -INFINITY;
     long double sum = 0.0L, ssq = 0.0L;

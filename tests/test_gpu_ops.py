@@ -442,3 +442,39 @@ def test_stats_global_and_axes(gpu):
     # empty selection
     st = ops.stats_global(_dev(d2), mask=ops.MaskSpec(_lib.MASK_GT | _lib.MASK_FINITE, 1e30))
     assert st["npts"] == 0 and np.isnan(st["min"]) and np.isnan(st["max"]) and st["sum"] == 0.0
+
+
+@pytest.mark.parametrize("kname", ["g4", "g1", "asym", "r33"])
+def test_fused_smooth_moments_algebraic_path(gpu, monkeypatch, kname):
+    """Without an extremum request the fused smooth->moments call uses per-channel weights
+    W_n(i) = sum_o k[o+H-i] c_o^n / sum(k) on the UNSMOOTHED data instead of the stencil; spaxels
+    holding NaN / Inf are not linear and must come out of the general fused kernel (flagged
+    tiles).  Must agree with the oracle, with the stencil path (SPC_FUSE_ALGEBRAIC=0), for a
+    non-uniform spectral axis and an asymmetric kernel."""
+    from spectral_cube_amd import ops, _lib
+    k = _kernels()[kname]
+    shape = (96, 10, 256 + 64)
+    d = _cube(shape, 77, nan_block=False)
+    d[40:44, 2, 5] = np.nan                 # tile 0 of row 2
+    d[10, 7, 300] = np.inf                  # last tile of row 7 (isfinite mask excludes it)
+    cen = np.cumsum(np.linspace(400.0, 600.0, shape[0]))          # NOT linear: table form
+    cref = cen[shape[0] // 2]
+    for spec, inc in ((None, None), (ops.MaskSpec(_lib.MASK_FINITE), np.isfinite(d))):
+        dd = d.copy()
+        if inc is None:
+            dd[10, 7, 300] = 3.0            # (an Inf without a mask propagates everywhere: keep it finite)
+        sm = O.spectral_smooth(dd, inc, k)
+        e0, e1, e2 = O.moments012(sm, inc, cen, 2.0, 100.0)
+        res = {}
+        for alg in ("1", "0"):
+            monkeypatch.setenv("SPC_FUSE_ALGEBRAIC", alg)
+            r = ops.spectral_conv_moments(_dev(dd), k, _dev(cen - cref), dv=2.0, m1_add=cref + 100.0, mask=spec,
+                                          want=("m0", "m1", "m2", "nvalid"), cen_host=cen - cref)
+            res[alg] = {n: r[n].get() for n in ("m0", "m1", "m2", "nvalid")}
+            with np.errstate(all="ignore"):
+                assert_close(res[alg]["m0"], e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="m0 alg=" + alg)
+                assert_close(res[alg]["m1"], e1, atol=1e-5 * (cen[-1] - cen[0]), what="m1 alg=" + alg)
+                wc = np.isfinite(e2) & (np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0)))
+                assert np.all(np.abs(res[alg]["m2"][wc] - e2[wc]) <= 1e-4 * np.nanmax(np.abs(e2[wc])))
+        assert np.array_equal(res["1"]["nvalid"], res["0"]["nvalid"])
+        assert_close(res["1"]["m0"], res["0"]["m0"], atol=2e-6 * np.nanmax(np.abs(e0)), what="algebraic vs stencil m0")
