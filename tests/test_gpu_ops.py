@@ -478,3 +478,16 @@ def test_fused_smooth_moments_algebraic_path(gpu, monkeypatch, kname):
                 assert np.all(np.abs(res[alg]["m2"][wc] - e2[wc]) <= 1e-4 * np.nanmax(np.abs(e2[wc])))
         assert np.array_equal(res["1"]["nvalid"], res["0"]["nvalid"])
         assert_close(res["1"]["m0"], res["0"]["m0"], atol=2e-6 * np.nanmax(np.abs(e0)), what="algebraic vs stencil m0")
+
+
+def test_c_abi_client_reproduces_reference_moment_table(gpu, tmp_path):
+    """tests/c_abi/abi_check.c --gpu: a plain-C program (no Python, no torch) runs the reference's
+    3x3x3 moment cube through spc_moments_f32 and checks the golden table of
+    spectral_cube/tests/test_moments.py:19-43."""
+    import subprocess
+    from test_host_logic import _build_abi_check
+    from spectral_cube_amd import _lib
+    exe = _build_abi_check(tmp_path)
+    r = subprocess.run([exe, _lib.LIB_PATH, "--gpu"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "gpu ok" in r.stdout

@@ -277,3 +277,21 @@ def test_fits_header_scan_and_writer(tmp_path):
     (tmp_path / "bad.fits").write_bytes(b"not a fits file" * 300)
     with pytest.raises(io_fits.FITSReadError):
         io_fits.find_image(str(tmp_path / "bad.fits"))
+
+
+def _build_abi_check(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_check")
+    src = os.path.join(REPO, "tests", "c_abi", "abi_check.c")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-o", exe, src, "-ldl", "-lm"], check=True)
+    return exe
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """include/spcube_hip.h compiles as C99 (-Wall -Wextra -Werror) and a plain-C client finds
+    every entry point, the ABI version, and gets SPC_ERR_INVALID + a message for a NULL cube."""
+    import subprocess
+    exe = _build_abi_check(tmp_path)
+    r = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "all symbols present" in r.stdout
