@@ -4,6 +4,21 @@
 #include "spc_common.h"
 #include <algorithm>
 
+// build-time experiment switches of the all-valid kernel (defaults = what ships; the measured
+// alternatives are recorded next to fast_phases() below)
+#ifndef SPC_FAST_PHASES_29
+#define SPC_FAST_PHASES_29 1     // x-pass phases per revolution for rings >= 29 taps
+#endif
+#ifndef SPC_FAST_PREFETCH
+#define SPC_FAST_PREFETCH 1      // issue the next revolution's row loads before the x pass
+#endif
+#ifndef SPC_XPASS_FENCE
+#define SPC_XPASS_FENCE 0        // scheduling fence every N x-pass taps (0 = none)
+#endif
+#ifndef SPC_NO_EDGE
+#define SPC_NO_EDGE 0
+#endif
+
 namespace spc_spconv {
 
 
@@ -75,10 +90,7 @@ constexpr int fast_txo(int R) { return ((kFastCols - 2 * (R / 2)) / 16) * 16; }
 constexpr int fast_phase_rows(int R, int nph) { return (((R + nph - 1) / nph) + 1) / 2 * 2; }
 // Measured (29 taps, C4): 2 phases halve the LDS footprint (38 KB) but the kernel then needs 208
 // VGPRs; forcing 3 waves/SIMD spills 40 of them into the y pass (45.5 ms vs 37.9 ms), so one phase.
-constexpr int fast_phases(int R) { return 1; }
-#ifndef SPC_FAST_PREFETCH
-#define SPC_FAST_PREFETCH 1
-#endif
+constexpr int fast_phases(int R) { return SPC_FAST_PHASES_29 > 1 && R >= 29 ? SPC_FAST_PHASES_29 : 1; }
 constexpr bool kFastPrefetch = SPC_FAST_PREFETCH != 0;
 
 // ---- all-valid fast kernel -----------------------------------------------------------
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
         // bookkeeping at all; rows / columns outside the plane (clamped duplicate loads) are
         // turned into valid zeros only where they can occur, under block-uniform branches.
         const bool edge = edge_cols || (i0 < 0) || (i0 + R > ny);
-        if (edge) {
+        if (edge && !SPC_NO_EDGE) {
 #pragma unroll
             for (int s = 0; s < R; ++s) {
                 const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
                 for (int i = 0; i < kRun + 2 * H; ++i) {
                     // (scheduling fence: left alone the compiler hoists all 2 x 36 LDS reads of a task
                     // to its top and pays for them with 70 VGPRs - one wave per SIMD less)
-                    if (NPH > 1 && (i % 6) == 0) __builtin_amdgcn_sched_barrier(0);
+                    if (SPC_XPASS_FENCE > 0 && (i % (SPC_XPASS_FENCE > 0 ? SPC_XPASS_FENCE : 1)) == 0) __builtin_amdgcn_sched_barrier(0);
                     const int c = kRun * j + i;
                     const int ph = c + (c >> 3);
                     const float2v in = float2v{ra[ph], rb[ph]};
