@@ -90,6 +90,10 @@ constexpr int fast_txo(int R) { return ((kFastCols - 2 * (R / 2)) / 16) * 16; }
 constexpr int fast_phase_rows(int R, int nph) { return (((R + nph - 1) / nph) + 1) / 2 * 2; }
 // Measured (29 taps, C4): 2 phases halve the LDS footprint (38 KB) but the kernel then needs 208
 // VGPRs; forcing 3 waves/SIMD spills 40 of them into the y pass (45.5 ms vs 37.9 ms), so one phase.
+// Also tried and dropped: a wave-specialised variant (8 waves per block, waves 0-3 run the y pass
+// of revolution n into one LDS buffer while waves 4-7 run the x pass of revolution n-1 out of the
+// other; 142 KB LDS, one block per CU, 163 VGPRs, one barrier per revolution): correct, but
+// 47.6 ms at C4 against 38.2 ms for two independent 4-wave blocks per CU.
 constexpr int fast_phases(int R) { return SPC_FAST_PHASES_29 > 1 && R >= 29 ? SPC_FAST_PHASES_29 : 1; }
 constexpr bool kFastPrefetch = SPC_FAST_PREFETCH != 0;
 
