@@ -120,7 +120,8 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     constexpr int kRows = fast_phase_rows(R, NPH);        // LDS rows: one phase of the revolution (even)
     static_assert(kPitchF >= kFastCols + kFastCols / 8, "LDS row too short");
     __shared__ float yrow[kRows * kPitchF];
-    __shared__ volatile int dirty;                        // set by any lane that meets a non-finite sample
+    __shared__ int dirty;             // set by any lane that meets a non-finite sample (plain LDS word: the
+                                      // barrier asm is a compiler memory barrier; `volatile` made it a FLAT sc0 sc1 access)
 
     const int t = threadIdx.x;
     const int64_t z = blockIdx.y;
