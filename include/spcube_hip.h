@@ -190,6 +190,14 @@ typedef struct spc_stats_outputs {
 int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube,
                        const spc_mask* mask, int axis, const spc_stats_outputs* out);
 
+/* 2-D convolution of one (ny, nx) float64 map with an odd-sized kernel (zero fill outside,
+ * kernel normalised by its sum, true convolution, NaN propagates).  Serves the algebraic
+ * spatial_smooth -> moment path: when every voxel is valid, astropy's convolution
+ * (dask_spectral_cube.py:962-993) commutes with the sums along the spectral axis
+ * (:1083-1104), so the moment sums of the smoothed cube are the smoothed moment sums. */
+int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny, int64_t nx,
+                       const double* h_kernel, int nky, int nkx, double* d_out);
+
 /* moments along a spatial axis (axis = 1 or 2), reference golden tables
  * spectral_cube/tests/test_moments.py:19-49.  d_cen is a (ny,nx) float64 map
  * of offsets along that axis (spectral_cube.py:1476-1503), pix_size the pixel

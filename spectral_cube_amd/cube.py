@@ -339,6 +339,47 @@ class SpectralCube:
             return (lz.parent, lz.kernel)
         return None
 
+    def _moments_of_spatially_smoothed(self, want):
+        """spatial_smooth -> moment without smoothing nz planes.  With every voxel valid astropy's
+        convolution is linear (zero fill, division by the kernel sum: dask_spectral_cube.py:
+        962-993), so it commutes with the sums along the spectral axis (:1083-1104):
+        S_n' = conv2d(S_n).  One pass over the UNSMOOTHED cube gives S0, S1, S2 (float64), three
+        small map convolutions give the moments of the smoothed cube.  Returns None when the
+        shortcut does not apply (mask terms other than isfinite, any invalid voxel, S0 == 0) -
+        the caller then materialises the smoothed cube."""
+        lz = self._lazy
+        if not (lz is not None and getattr(lz, "op", None) == "spatial_smooth" and self._dev is None
+                and lz.parent._mask is self._mask):
+            return None
+        parent = lz.parent
+        spec = parent._mask_spec()
+        if spec.array is not None or (spec.flags & ~_lib.MASK_FINITE):
+            return None
+        nz = self._shape[0]
+        higher = ("m1" in want) or ("m2" in want)
+        r = parent._moment_device(("s0", "nvalid") + (("mu", "m2") if higher else ()))
+        if int(r["nvalid"].get().min()) != nz:
+            return None
+        c0 = ops.map_conv2d(r["s0"], lz.kernel).get()        # S0 never leaves the device
+        if not (np.all(np.isfinite(c0)) and np.all(c0 != 0.0)):   # a NaN / Inf / zero sum anywhere: not this path
+            return None
+        out = {}
+        if "m0" in want:
+            out["m0"] = self._pix_size_slice(0) * c0
+        if higher:
+            s0, mu, m2 = r["s0"].get(), r["mu"].get(), r["m2"].get()
+            if not (np.all(s0 != 0.0) and np.all(np.isfinite(mu)) and np.all(np.isfinite(m2))):
+                return None
+            conv = lambda m: ops.map_conv2d(DeviceArray.from_numpy(m, self.device), lz.kernel).get()   # noqa: E731
+            cen = self._pix_cen_axis(0)
+            cref = cen[nz // 2]
+            mup = conv(mu * s0) / c0
+            if "m1" in want:
+                out["m1"] = mup + cref + self.spectral_axis[0]
+            if "m2" in want:
+                out["m2"] = conv((m2 + mu * mu) * s0) / c0 - mup * mup
+        return out
+
     def moment(self, order=0, axis=0, how="auto", **kwargs):
         """Compute moments along an axis (spectral_cube.py:1614-1720;
         dask_spectral_cube.py:1031-1132).  ``how`` is accepted for interface
@@ -354,7 +395,10 @@ class SpectralCube:
             warnings.warn(_VARIANCE_MSG, VarianceWarning)
         if axis == 0:
             key = {0: "m0", 1: "m1", 2: "m2"}.get(order)
-            if key is not None:
+            alg = self._moments_of_spatially_smoothed((key,)) if key is not None else None
+            if alg is not None:
+                out = alg[key]
+            elif key is not None:
                 out = self._moment_device((key,), self._fusable())[key].get()
             else:
                 r = self._moment_device(("mu", "s0"))
@@ -533,6 +577,9 @@ class SpectralCube:
         class _Lazy:
             op = "spatial_smooth"
             fusable = False
+
+            def __init__(self):
+                self.parent, self.kernel = parent, karr
 
             def __call__(self):
                 return ops.spatial_conv(parent._device_data(), karr, mask=parent._mask_spec())

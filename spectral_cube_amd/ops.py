@@ -320,3 +320,18 @@ def stats_axis(cube, axis, mask=None, want=STAT_KEYS, stream=None, out=None):
     c, m = _cube_c(cube), _mask_c(mask, cube)
     _lib.call("spc_stats_axis_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis), C.byref(o))
     return res
+
+
+def map_conv2d(dmap, kernel2d, stream=None, out=None):
+    """zero-filled, sum-normalised 2-D convolution of one float64 (ny, nx) DeviceArray (the map
+    form of spatial_smooth used by the algebraic smooth -> moment path)."""
+    if dmap.dtype != np.float64 or len(dmap.shape) != 2:
+        raise TypeError("map must be a 2-D float64 DeviceArray")
+    k = np.ascontiguousarray(kernel2d, dtype=np.float64)
+    if k.ndim != 2:
+        raise ValueError("kernel must be 2-D")
+    if out is None:
+        out = DeviceArray(dmap.shape, np.float64, dmap.device)
+    _lib.call("spc_map_conv2d_f64", dmap.device, _sh(stream), C.c_void_p(dmap.ptr), dmap.shape[0], dmap.shape[1],
+              k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], C.c_void_p(out.ptr))
+    return out

@@ -359,3 +359,47 @@ def test_read_fits_files(gpu, tmp_path):
             assert got.shape == exp.shape and top == y0 - lo and n == y1 - y0
             assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)])
             assert h["NAXIS2"] == exp.shape[1]
+
+
+def test_spatial_smooth_then_moment_algebraic(gpu, monkeypatch):
+    """cube.spatial_smooth(k).momentN(): with every voxel valid the moments of the smoothed cube are
+    the smoothed moment sums (S_n' = conv2d(S_n), three map convolutions instead of nz planes);
+    must equal the oracle's smooth-every-plane-then-reduce, and the materialised GPU path; with
+    a NaN or a mask the shortcut must step aside (results again equal to the oracle)."""
+    from spectral_cube_amd import ops
+    g = golden("c1_moments.npz")
+    hdr = str(g["header"])
+    rng = np.random.default_rng(21)
+    shape = (48, 40, 56)
+    d = (synth.gaussian_line_cube(shape, 5) + 2.0).astype(np.float32)
+    k2 = Gaussian2DKernel(1.7)
+    calls = []
+    real = ops.spatial_conv
+    monkeypatch.setattr(ops, "spatial_conv", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    for variant in ("clean", "nan", "masked"):
+        dd = d.copy()
+        inc = None
+        if variant == "nan":
+            dd[7, 9, 11] = np.nan
+        cube = SpectralCube.read(dd, hdr)
+        if variant == "masked":
+            inc = rng.random(shape) > 0.2
+            cube = cube.with_mask(inc)
+        ref = SpectralCube.read(dd, hdr)
+        if inc is not None:
+            ref = ref.with_mask(inc)
+        einc = np.isfinite(dd) if inc is None else (inc & np.isfinite(dd))
+        sm = O.spatial_smooth(dd, einc, k2.array)
+        cen = ref._pix_cen_axis(0)
+        e0, e1, e2 = O.moments012(sm, einc, cen, ref._pix_size_slice(0), ref.spectral_axis[0])
+        del calls[:]
+        smc = cube.spatial_smooth(k2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m0, m1, m2 = np.asarray(smc.moment0()), np.asarray(smc.moment1()), np.asarray(smc.moment2())
+        assert (len(calls) == 0) == (variant == "clean"), (variant, len(calls))    # shortcut only when clean
+        with np.errstate(all="ignore"):
+            assert_close(m0, e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="m0 " + variant)
+            assert_close(m1, e1, atol=1e-5 * abs(cen[-1] - cen[0]), what="m1 " + variant)
+            wc = np.isfinite(e2) & (np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0)))
+            assert np.all(np.abs(m2[wc] - e2[wc]) <= 1e-4 * np.nanmax(np.abs(e2[wc]))), variant
