@@ -186,3 +186,34 @@ def sharded_moments(strip_cube, ny_total, comm, orders=(0, 1, 2)):
         else:
             out[o] = comm.allgather_rows(strip.get() if isinstance(strip, DeviceArray) else strip, ny_total)
     return out
+
+
+def sharded_smooth_moment0(strip_cube, kernel, ny_total, comm):
+    """config C4 (spatial_smooth -> moment0) on row strips WITHOUT halo exchange: when every voxel
+    is valid, smoothing commutes with the sum along the spectral axis, so each rank reduces its
+    own strip (sum map S0 + valid count), ONE all-gather stitches S0, and the 2-D convolution
+    runs on the stitched map (spc_map_conv2d_f64).  A rank that holds an invalid voxel poisons
+    its S0 strip with NaN, which every rank then sees in the stitched map: returns None
+    everywhere -> fall back to halo_bounds / smooth_moment0_strip on extended strips.
+    Returns the (ny_total, nx) float64 moment-0 map (ndarray) on every rank."""
+    from . import ops
+    from .kernels import kernel_array
+    nz = strip_cube.shape[0]
+    r = strip_cube._moment_device(("s0", "nvalid"))
+    s0 = r["s0"]
+    if int(r["nvalid"].get().min()) != nz:
+        s0 = DeviceArray.from_numpy(np.full(s0.shape, np.nan), s0.device)
+    if isinstance(comm, RcclComm):
+        rows = strip_rows(ny_total, comm.world_size)
+        if s0.shape[0] != rows:
+            padded = np.zeros((rows, s0.shape[1]))
+            padded[:s0.shape[0]] = s0.get()
+            s0 = DeviceArray.from_numpy(padded, s0.device)
+        full = comm.allgather_rows(s0, ny_total).get()[:ny_total]
+    else:
+        full = comm.allgather_rows(s0.get(), ny_total)
+    if not np.all(np.isfinite(full)):
+        return None
+    karr = kernel_array(kernel, 2)
+    c0 = ops.map_conv2d(DeviceArray.from_numpy(np.ascontiguousarray(full), strip_cube.device), karr).get()
+    return strip_cube._pix_size_slice(0) * c0

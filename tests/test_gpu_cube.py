@@ -403,3 +403,49 @@ def test_spatial_smooth_then_moment_algebraic(gpu, monkeypatch):
             assert_close(m1, e1, atol=1e-5 * abs(cen[-1] - cen[0]), what="m1 " + variant)
             wc = np.isfinite(e2) & (np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0)))
             assert np.all(np.abs(m2[wc] - e2[wc]) <= 1e-4 * np.nanmax(np.abs(e2[wc]))), variant
+
+
+def test_sharded_smooth_moment0_without_halos(gpu):
+    """distributed.sharded_smooth_moment0: row strips, no halo exchange - each 'rank' (run one after
+    the other on this GPU) reduces its strip, the S0 strips are stitched, the stitched map is
+    convolved; equals smoothing every plane of the whole cube then moment 0 (oracle).  A NaN on
+    one rank poisons the stitched map -> None on every rank."""
+    from spectral_cube_amd.distributed import sharded_smooth_moment0, strip_bounds
+    hdr = str(golden("c1_moments.npz")["header"])
+    shape = (24, 45, 64)
+    d = (synth.gaussian_line_cube(shape, 9) + 1.0).astype(np.float32)
+    k2 = Gaussian2DKernel(1.5)
+    ref = SpectralCube.read(d, hdr)
+    sm = O.spatial_smooth(d, None, k2.array)
+    e0 = O.moment(sm, None, 0, ref._pix_cen_axis(0), ref._pix_size_slice(0))
+
+    class FakeComm:                      # stands in for the all-gather: hands back the stitched map
+        def __init__(self, full):
+            self.full = full
+
+        def allgather_rows(self, strip, ny_total):
+            return self.full
+
+    for ws in (1, 3):
+        for poison in (False, True):
+            dd = d.copy()
+            if poison:
+                dd[3, 40, 5] = np.nan                       # lives on the last rank
+            strips = []
+            for r in range(ws):
+                y0, y1 = strip_bounds(shape[1], ws, r)
+                sc = SpectralCube.read(np.ascontiguousarray(dd[:, y0:y1]), hdr)
+                res = sc._moment_device(("s0", "nvalid"))
+                s0 = res["s0"].get()
+                if int(res["nvalid"].get().min()) != shape[0]:
+                    s0 = np.full_like(s0, np.nan)
+                strips.append(s0)
+            comm = FakeComm(np.concatenate(strips, axis=0))
+            for r in range(ws):
+                y0, y1 = strip_bounds(shape[1], ws, r)
+                sc = SpectralCube.read(np.ascontiguousarray(dd[:, y0:y1]), hdr)
+                got = sharded_smooth_moment0(sc, k2, shape[1], comm)
+                if poison:
+                    assert got is None
+                else:
+                    assert_close(got, e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="halo-free sharded smooth+moment0")
