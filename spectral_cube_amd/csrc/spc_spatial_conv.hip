@@ -99,6 +99,97 @@ void canonical_pred(SpArgs& A) {
     }
 }
 
+// ---- non-separable kernels up to 33 x 33: LDS-tiled direct convolution --------------------------
+// (Tophat2DKernel, rotated elliptical Gaussians = what convolve_to builds.)  A block owns a
+// 64 x 32 output tile of one plane: the input tile with its halo is classified once into LDS as
+// packed (value * valid, valid) pairs, a lane then produces a vertical run of 8 outputs, so each
+// LDS read feeds up to 8 packed FMAs (num and den together); weights are wave-uniform scalar
+// loads.  The run's first and last 7 input rows reach only some of the 8 outputs and are
+// predicated (a zero-padded weight table would turn an Inf sample into NaN for outputs whose
+// window does not contain it).  Measured (15 x 15, 1024^3): 184 ms (per-pixel global loads) -> see
+// DESIGN.md 3.3.
+constexpr int kT2X = 64, kT2Y = 32, kT2Run = 8, kT2MaxK = 33;
+
+template <bool ARR>
+__global__ __launch_bounds__(256) void spatial_conv2d_tiled_kernel(const SpArgs A, const float* kern, int nky, int nkx) {
+    extern __shared__ float2v tile[];                     // (kT2Y + nky - 1) x pitch
+    const int hy = nky / 2, hx = nkx / 2;
+    const int trows = kT2Y + nky - 1, tcols = kT2X + nkx - 1;
+    const int pitch = tcols | 1;                           // odd pitch in float2 units
+    const int64_t z = blockIdx.z;
+    const int64_t X0 = (int64_t)blockIdx.x * kT2X, Y0 = (int64_t)blockIdx.y * kT2Y;
+    const float* p = A.cube + z * A.plane_stride;
+    const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride : nullptr;
+    // true convolution: out[y][x] = sum k[jy][jx] in[y + hy - jy][x + hx - jx]; tile row r holds input
+    // row Y0 - hy + r, tile column c holds input column X0 - hx + c
+    for (int e = threadIdx.x; e < trows * tcols; e += 256) {
+        const int r = e / tcols, c = e - r * tcols;
+        const int64_t iy = Y0 - hy + r, ix = X0 - hx + c;
+        float2v val = float2v{0.f, 1.f};                   // outside the image: a valid zero
+        if (iy >= 0 && iy < A.ny && ix >= 0 && ix < A.nx) {
+            const float v = p[iy * A.row_stride + ix];
+            bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v);
+            if (ARR) ok = ok && pm[iy * A.mask.row_stride + ix] != 0;
+            val = ok ? float2v{v, 1.f} : float2v{0.f, 0.f};
+        }
+        tile[r * pitch + c] = val;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = (threadIdx.x >> 6) * kT2Run;
+    float2v acc[kT2Run];
+#pragma unroll
+    for (int o = 0; o < kT2Run; ++o) acc[o] = float2v{0.f, 0.f};
+    // Output (ty + o, tx) with tap (jy, jx) reads tile[ty + r][tx + nkx - 1 - jx], r = o + nky - 1 - jy in
+    // [0, nky + 7).  Input row r is walked in chunks of 8: one LDS read per row, and the 15 weights
+    // a chunk can touch (kernT[jx][nky - 1 - r0 + 0..14], 7 zeros of padding on both sides, never
+    // multiplied: masks below) come in as wave-uniform scalar loads, so every FMA takes its weight
+    // from an SGPR.  Which (row, output) pairs exist is STATIC inside the first chunk (o <= i) and
+    // the last one (i <= o); in between every pair exists.
+    const int wpitch = nky + 14;
+    auto chunk = [&](const float2v* col, const float* wp, int r0, int mode, int nrows) {
+        float w[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) w[q] = wp[q];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (mode == 1 && i >= nrows) break;              // partial middle chunk (wave-uniform)
+            const float2v in = col[(r0 + i) * pitch];
+#pragma unroll
+            for (int o = 0; o < kT2Run; ++o) {
+                const bool on = (mode == 0) ? (o <= i) : (mode == 2) ? (i <= o) : true;
+                if (on) acc[o] = __builtin_elementwise_fma(float2v{w[7 - i + o], w[7 - i + o]}, in, acc[o]);
+            }
+        }
+    };
+    for (int jx = 0; jx < nkx; ++jx) {
+        const float2v* col = tile + ty * pitch + tx + (nkx - 1 - jx);
+        const float* wcol = kern + (size_t)jx * wpitch;     // padded column jx: wcol[7 + jy] = k[jy][jx]
+        // weight of (row r, output o) = k[nky - 1 - r + o][jx] = wcol[nky + 6 - r + o]; chunk at r0, row i:
+        // wcol[(nky - 1 - r0) + 7 - i + o]
+        chunk(col, wcol + (nky - 1), 0, 0, 8);                              // rows 0..7
+        int r0 = 8;
+        for (; r0 + 8 <= nky - 1; r0 += 8) chunk(col, wcol + (nky - 1 - r0), r0, 1, 8);
+        if (r0 < nky - 1) chunk(col, wcol + (nky - 1 - r0), r0, 1, nky - 1 - r0);   // rows r0 .. nky-2
+        chunk(col, wcol + 0, nky - 1, 2, 8);                                // rows nky-1 .. nky+6
+    }
+    const int64_t x = X0 + tx;
+    if (x >= A.nx) return;
+#pragma unroll
+    for (int o = 0; o < kT2Run; ++o) {
+        const int64_t y = Y0 + ty + o;
+        if (y >= A.ny) break;
+        float res;
+        if (acc[o].y != 0.f) res = acc[o].x / acc[o].y;
+        else {                                                          // empty window -> filled centre sample
+            const float c = p[y * A.row_stride + x];
+            bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
+            if (ARR) inc = inc && pm[y * A.mask.row_stride + x] != 0;
+            res = inc ? c : NAN;
+        }
+        A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
+    }
+}
+
 int check_kernel(const double* k, int n, const char* what) {
     SPC_REQUIRE(k != nullptr, "%s kernel pointer is NULL", what);
     SPC_REQUIRE(n >= 1 && (n % 2) == 1, "%s kernel must have an odd number of taps (got %d)", what, n);
@@ -139,15 +230,33 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, c
     SPC_REQUIRE(cube->nz <= 65535, "nz > 65535 planes per call not supported by the 2-D kernel grid");
     SPC_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
-    const int n = nky * nkx;
+    const char* env = getenv("SPC_CONV2D_TILED");
+    // (the tiled kernel's static row/output masks assume at least 9 rows of taps)
+    const bool tiled = (env ? atoi(env) != 0 : true) && nky >= 9 && nky <= kT2MaxK && nkx <= kT2MaxK &&
+                       (cube->ny + kT2Y - 1) / kT2Y <= 65535;
+    // tiled: transposed columns padded with 7 zeros on both sides, kT[jx][7 + jy] = k[jy][jx]
+    const int n = tiled ? nkx * (nky + 14) : nky * nkx;
+    std::vector<float> hk((size_t)n, 0.f);
+    if (tiled) {
+        for (int jy = 0; jy < nky; ++jy)
+            for (int jx = 0; jx < nkx; ++jx) hk[(size_t)jx * (nky + 14) + 7 + jy] = (float)h_kernel[jy * nkx + jx];
+    } else {
+        for (int i = 0; i < n; ++i) hk[i] = (float)h_kernel[i];
+    }
     float* d_k = nullptr;
     SPC_HIP(hipMalloc((void**)&d_k, sizeof(float) * n));
-    std::vector<float> hk(n);
-    for (int i = 0; i < n; ++i) hk[i] = (float)h_kernel[i];
     hipError_t e = hipMemcpy(d_k, hk.data(), sizeof(float) * n, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + 3) / 4), (unsigned)cube->nz);
-        hipLaunchKernelGGL(spatial_conv2d_kernel, grid, dim3(256), 0, st, A, d_k, nky, nkx);
+        if (tiled) {
+            const int pitch = (kT2X + nkx - 1) | 1;
+            const size_t lds = (size_t)(kT2Y + nky - 1) * pitch * sizeof(float2v);
+            dim3 grid((unsigned)((cube->nx + kT2X - 1) / kT2X), (unsigned)((cube->ny + kT2Y - 1) / kT2Y), (unsigned)cube->nz);
+            if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(spatial_conv2d_tiled_kernel<true>, grid, dim3(256), lds, st, A, d_k, nky, nkx);
+            else hipLaunchKernelGGL(spatial_conv2d_tiled_kernel<false>, grid, dim3(256), lds, st, A, d_k, nky, nkx);
+        } else {
+            dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + 3) / 4), (unsigned)cube->nz);
+            hipLaunchKernelGGL(spatial_conv2d_kernel, grid, dim3(256), 0, st, A, d_k, nky, nkx);
+        }
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }

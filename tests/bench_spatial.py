@@ -36,3 +36,17 @@ for sig, half in ((3.397, 14), (1.0, 4), (2.0, 8), (4.0, 16)):
     print("spatial %2d taps u8 mask     %8.3f ms %7.1f GB/s" % (2 * half + 1, ms, vox * 9 / ms / 1e6), flush=True)
     ms = timeit(lambda: ops.spatial_conv(cube, k2, out=out, mask=ops.MaskSpec(_lib.MASK_GT, 0.5)))
     print("spatial %2d taps GT mask     %8.3f ms %7.1f GB/s" % (2 * half + 1, ms, vox * 8 / ms / 1e6), flush=True)
+if "--nonsep" in sys.argv:
+    yy, xx = np.mgrid[-7:8, -7:8]
+    th = np.deg2rad(30.0)
+    u, v = xx * np.cos(th) + yy * np.sin(th), -xx * np.sin(th) + yy * np.cos(th)
+    k = np.exp(-0.5 * ((u / 3.0) ** 2 + (v / 1.5) ** 2)); k /= k.sum()       # rotated elliptical Gaussian (convolve_to-like)
+    small = DeviceArray((64, ny, nx), np.float32)
+    _lib.call("spc_memcpy_d2d", 0, C.c_void_p(small.ptr), C.c_void_p(cube.ptr), small.nbytes, None)
+    so = DeviceArray(small.shape, np.float32)
+    ms = timeit(lambda: ops.spatial_conv(small, k, out=so), n=2, warm=1)
+    print("non-separable 15x15, 64 planes of %dx%d: %8.3f ms  -> %.1f ms per 1024 planes" % (ny, nx, ms, ms * 16))
+    sm_ = DeviceArray((64, ny, nx), np.uint8)
+    _lib.call("spc_memcpy_d2d", 0, C.c_void_p(sm_.ptr), C.c_void_p(maskc.ptr), sm_.nbytes, None)
+    ms = timeit(lambda: ops.spatial_conv(small, k, out=so, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=sm_)), n=2, warm=1)
+    print("non-separable 15x15 + u8 mask:            %8.3f ms  -> %.1f ms per 1024 planes" % (ms, ms * 16))
