@@ -190,6 +190,18 @@ typedef struct spc_stats_outputs {
 int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube,
                        const spc_mask* mask, int axis, const spc_stats_outputs* out);
 
+/* ---- order statistics along the spectral axis ---
+ * q-th percentile (numpy 'linear' interpolation; q = 50: the median) of the
+ * included, non-NaN samples of every ray: DaskSpectralCubeMixin.median /
+ * percentile (spectral_cube/dask_spectral_cube.py:657-693).  With d_center (a
+ * (ny,nx) float32 map) the statistic is taken of |x - center|, and the result is
+ * multiplied by scale: median absolute deviation -> mad_std (:711-731, astropy
+ * stats.mad_std: scale = 1.482602218505602).  Rays without a valid sample give
+ * NaN.  d_out: (ny,nx) float32, C-contiguous. */
+int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,
+                             const spc_mask* mask, double q, const float* d_center,
+                             float scale, float* d_out);
+
 /* 2-D convolution of one (ny, nx) float64 map with an odd-sized kernel (zero fill outside,
  * kernel normalised by its sum, true convolution, NaN propagates).  Serves the algebraic
  * spatial_smooth -> moment path: when every voxel is valid, astropy's convolution

@@ -628,6 +628,35 @@ def case_fits_files():
     print("fits files ok")
 
 
+def case_order_statistics():
+    """median / percentile / mad_std along the spectral axis of the Dask class on a masked fp32
+    cube with NaNs, fully masked rays, odd and even valid counts."""
+    shape = (25, 12, 16)
+    data = synth.gaussian_line_cube(shape, 777)
+    synth.add_nan_block(data, 2, 3, 3)
+    data[5, 4, 4] = np.nan                                     # even valid count on one ray
+    h = c1_header(*shape)
+    sc = SpectralCube.read(fits.PrimaryHDU(data=data, header=h), use_dask=True)
+    blk = np.ones(shape, dtype=bool)
+    blk[:, 8:10, 10:13] = False                                # fully masked rays
+    blk[::3, 0, :] = False
+    sc = sc.with_mask(BooleanArrayMask(blk, sc.wcs))
+    include = np.asarray(sc.mask.include())
+    store = {"data": data, "include": include}
+    ref = np.asarray(val(sc.median(axis=0)), dtype=np.float64)
+    close(O.median(data, include), ref, rtol=0, atol=0, what="median")          # bit-exact selection / mean of two
+    store["median"] = ref
+    for q in (10.0, 37.5, 90.0):
+        ref = np.asarray(val(sc.percentile(q, axis=0)), dtype=np.float64)
+        close(O.percentile(data, include, q), ref, rtol=1e-6, what="percentile %g" % q)
+        store["p%g" % q] = ref
+    ref = np.asarray(val(sc.mad_std(axis=0)), dtype=np.float64)
+    close(O.mad_std(data, include), ref, rtol=1e-6, what="mad_std")
+    store["mad_std"] = ref
+    np.savez(os.path.join(OUT, "order_stats.npz"), **store)
+    print("order statistics ok")
+
+
 if __name__ == "__main__":
     case_moment_cube()
     case_c1()
@@ -639,4 +668,5 @@ if __name__ == "__main__":
     case_bilinear_scipy()
     case_statistics()
     case_fits_files()
+    case_order_statistics()
     print("ALL GOLDEN VECTORS WRITTEN to", OUT)

@@ -28,7 +28,7 @@ __all__ = [
     "filled", "moment", "moments012", "moment_cubewise", "argmax", "argmin",
     "convolve_fill_interp", "spectral_smooth", "spatial_smooth",
     "spectral_interpolate", "resample_bilinear", "reproject_separable",
-    "statistics", "reduce", "fits_decode",
+    "statistics", "reduce", "fits_decode", "median", "percentile", "mad_std",
 ]
 
 
@@ -427,3 +427,37 @@ def fits_decode(raw, bitpix, shape, bscale=1.0, bzero=0.0, blank=None):
     if blank is not None:
         v[a == blank] = np.nan
     return v.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# order statistics along an axis
+# --------------------------------------------------------------------------
+def median(data, include=None, axis=0):
+    """``DaskSpectralCubeMixin.median`` (spectral_cube/dask_spectral_cube.py:657-
+    671): nanmedian of the NaN-filled data along *axis*; all-NaN rays -> NaN."""
+    import warnings
+    d = filled(data, include, np.nan)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return np.nanmedian(d, axis=axis)
+
+
+def percentile(data, include, q, axis=0):
+    """``percentile`` (dask_spectral_cube.py:673-693): np.nanpercentile (linear
+    interpolation between the two bracketing order statistics)."""
+    import warnings
+    d = filled(data, include, np.nan)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return np.nanpercentile(d, q, axis=axis)
+
+
+def mad_std(data, include=None, axis=0):
+    """``mad_std`` (dask_spectral_cube.py:711-731) = astropy.stats.mad_std(
+    ignore_nan=True): 1.482602218505602 * nanmedian(|x - nanmedian(x)|)."""
+    import warnings
+    d = filled(data, include, np.nan)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        med = np.nanmedian(d, axis=axis, keepdims=True)
+        return 1.482602218505602 * np.nanmedian(np.abs(d - med), axis=axis)

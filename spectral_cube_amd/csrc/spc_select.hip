@@ -1,0 +1,192 @@
+// Order statistics along the spectral axis: median / percentile / mad_std per spaxel
+// (SURVEY.md section 8f rank 4).  Replaces da.nanmedian / np.nanpercentile / astropy
+// stats.mad_std applied per ray by DaskSpectralCubeMixin.median / percentile / mad_std
+// (spectral_cube/dask_spectral_cube.py:657-731), which sort or partition every ray on the host.
+//
+// No sort: the k-th smallest of a ray is found by descending the bits of an order-preserving
+// integer key (sign-flipped IEEE bits), most significant first.  One pass over z counts, for the
+// current prefix, the samples by their next TWO key bits; 16 passes pin the key down exactly.  Two
+// ranks are followed at once (the two order statistics a percentile interpolates between), a
+// lane owns 4 adjacent spaxels (16-byte coalesced loads), all state lives in registers.  Cost:
+// 17 streaming reads of the cube - no scratch memory, any nz.  For mad_std the same kernel runs
+// on |x - centre| with the per-spaxel median as centre.
+#include "spc_common.h"
+#include <algorithm>
+
+namespace {
+
+struct SelArgs {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    MaskDev mask;
+    double q;                 // percentile in [0, 100]
+    const float* center;      // NULL, or (ny, nx) map: select on |x - center|
+    float scale;              // result multiplier (mad_std: 1.4826...)
+    float* out;               // (ny, nx)
+};
+
+__device__ __forceinline__ uint32_t fkey(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float funkey(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+template <int VEC, bool ARR>
+__global__ __launch_bounds__(256) void select_axis0_kernel(const SelArgs A) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gpr = (A.nx + VEC - 1) / VEC;
+    if (g >= A.ny * gpr) return;
+    const int64_t y = g / gpr, x = (g - y * gpr) * VEC;
+    const float* p = A.cube + y * A.row_stride + x;
+    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + x : nullptr;
+    float cen[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) cen[c] = (A.center && x + c < A.nx) ? A.center[y * A.nx + x + c] : 0.f;
+    const bool use_cen = A.center != nullptr;
+
+    // one plane's samples of this lane: selection value and validity (0 / 1)
+    struct Smp { float v[VEC]; int ok[VEC]; };
+    auto load = [&](int64_t z) -> Smp {
+        Smp r;
+        float raw[VEC];
+        unsigned mk[VEC];
+        if (VEC == 4) {
+            const f32x4s q4 = *reinterpret_cast<const f32x4s*>(p + z * A.plane_stride);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) raw[c] = q4[c];
+            if (ARR) {
+                const uint32_t m = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm + z * A.mask.plane_stride));
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) mk[c] = (m >> (8 * c)) & 0xffu;
+            }
+        } else {
+            raw[0] = p[z * A.plane_stride];
+            if (ARR) mk[0] = pm[z * A.mask.plane_stride];
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[c]) && (raw[c] == raw[c]);
+            if (ARR) ok = ok && (mk[c] != 0);
+            const float v = use_cen ? fabsf(raw[c] - cen[c]) : raw[c];
+            r.v[c] = v;
+            r.ok[c] = (ok && (v == v)) ? 1 : 0;
+        }
+        return r;
+    };
+
+    // pass 0: valid counts -> the two ranks of numpy's 'linear' percentile
+    int n[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) n[c] = 0;
+#pragma unroll 2
+    for (int64_t z = 0; z < A.nz; ++z) {
+        const Smp sm = load(z);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) n[c] += sm.ok[c];
+    }
+    int klo[VEC], khi[VEC];
+    double frac[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        const double pos = A.q / 100.0 * (double)(n[c] > 0 ? n[c] - 1 : 0);
+        const double fl = floor(pos);
+        klo[c] = (int)fl;
+        khi[c] = min((int)ceil(pos), max(n[c] - 1, 0));
+        frac[c] = pos - fl;
+    }
+    uint32_t plo[VEC], phi[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) { plo[c] = 0u; phi[c] = 0u; }
+    // two key bits per pass (16 passes): for each followed rank, count the prefix-matching samples
+    // whose digit is 0, 1 or 2 (3 is the rest)
+#pragma unroll 1
+    for (int b = 30; b >= 0; b -= 2) {
+        int clo[VEC][3], chi[VEC][3];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { clo[c][j] = 0; chi[c][j] = 0; }
+#pragma unroll 2
+        for (int64_t z = 0; z < A.nz; ++z) {
+            const Smp sm = load(z);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const uint32_t k = fkey(sm.v[c]);
+                const uint32_t dg = (k >> b) & 3u;
+                // (b + 2 == 32 in the first pass: no prefix yet; a 64-bit shift keeps that well defined)
+                const int mlo = ((((uint64_t)(k ^ plo[c])) >> (b + 2)) == 0u ? 1 : 0) & sm.ok[c];
+                const int mhi = ((((uint64_t)(k ^ phi[c])) >> (b + 2)) == 0u ? 1 : 0) & sm.ok[c];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int is = (dg == (uint32_t)j) ? 1 : 0;
+                    clo[c][j] += mlo & is;
+                    chi[c][j] += mhi & is;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (klo[c] >= clo[c][j] && d == (uint32_t)j) { klo[c] -= clo[c][j]; d = j + 1; }
+            plo[c] |= d << b;
+            d = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) if (khi[c] >= chi[c][j] && d == (uint32_t)j) { khi[c] -= chi[c][j]; d = j + 1; }
+            phi[c] |= d << b;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+        if (x + c >= A.nx) break;
+        float res = NAN;
+        if (n[c] > 0) {
+            const double a = (double)funkey(plo[c]), bb = (double)funkey(phi[c]);
+            // numpy's linear interpolation between the two order statistics (a + (b - a) * t; the
+            // median of an even count is their mean)
+            const double t = frac[c];
+            res = (float)((t == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * t) * (double)A.scale);
+        }
+        A.out[y * A.nx + x + c] = res;
+    }
+}
+
+}  // namespace
+
+extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                        double q, const float* d_center, float scale, float* d_out) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    SPC_REQUIRE(q >= 0.0 && q <= 100.0, "Percentiles must be in the range [0, 100]");
+    SelArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.q = q; A.center = d_center; A.scale = scale; A.out = d_out;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    const bool v4 = (cube->nx % 4 == 0) && (cube->row_stride % 4 == 0) && (cube->plane_stride % 4 == 0) &&
+                    ((((uintptr_t)cube->d_data) & 15) == 0) &&
+                    (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
+    hipStream_t st = (hipStream_t)stream;
+    if (v4) {
+        const int64_t n = cube->ny * (cube->nx / 4);
+        dim3 grid((unsigned)((n + 255) / 256));
+        if (arr) hipLaunchKernelGGL((select_axis0_kernel<4, true>), grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((select_axis0_kernel<4, false>), grid, dim3(256), 0, st, A);
+    } else {
+        const int64_t n = cube->ny * cube->nx;
+        dim3 grid((unsigned)((n + 255) / 256));
+        if (arr) hipLaunchKernelGGL((select_axis0_kernel<1, true>), grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((select_axis0_kernel<1, false>), grid, dim3(256), 0, st, A);
+    }
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}

@@ -335,3 +335,20 @@ def map_conv2d(dmap, kernel2d, stream=None, out=None):
     _lib.call("spc_map_conv2d_f64", dmap.device, _sh(stream), C.c_void_p(dmap.ptr), dmap.shape[0], dmap.shape[1],
               k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], C.c_void_p(out.ptr))
     return out
+
+
+MAD_TO_STD = 1.482602218505602          # 1 / Phi^-1(3/4), astropy.stats.mad_std
+
+
+def percentile_axis0(cube, q, mask=None, center=None, scale=1.0, stream=None, out=None):
+    """q-th percentile along the spectral axis per spaxel (median: q = 50), numpy 'linear'
+    interpolation, NaN / masked samples ignored (dask_spectral_cube.py:657-693); with *center*
+    (a (ny, nx) float32 DeviceArray) of |x - center| times *scale* (mad_std, :711-731)."""
+    if out is None:
+        out = DeviceArray(cube.shape[1:], np.float32, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    if center is not None and (center.dtype != np.float32 or tuple(center.shape) != tuple(cube.shape[1:])):
+        raise TypeError("center must be a float32 (ny, nx) DeviceArray")
+    _lib.call("spc_percentile_axis0_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(q),
+              C.c_void_p(center.ptr) if center is not None else None, float(scale), C.c_void_p(out.ptr))
+    return out

@@ -55,6 +55,12 @@ for ax in (0, 1, 2):
     so = ops.stats_axis(cube, ax, mask=mspec)
     ms = med_ms(lambda: ops.stats_axis(cube, ax, mask=mspec, out=so))
     res.append(row("C2 1024^3 u8 mask: count/min/max/sum/sumsq along axis %d" % ax, vox, ms, 5))
+# order statistics along the spectral axis (33 streaming reads each)
+om = DeviceArray(shape[1:], np.float32)
+ms = med_ms(lambda: ops.percentile_axis0(cube, 50.0, mask=mspec, out=om), n=3, warm=1)
+res.append(row("C2 1024^3 u8 mask: median along the spectral axis", vox, ms, 5))
+ms = med_ms(lambda: ops.percentile_axis0(cube, 50.0, out=om), n=3, warm=1)
+res.append(row("C2 1024^3 no mask: median along the spectral axis", vox, ms, 4))
 del cube, mask
 # ---------------- C3: 2048^3, spectral_smooth sigma=4 then moment1
 shape = (2048, 2048, 2048); vox = np.prod(shape, dtype=np.int64)

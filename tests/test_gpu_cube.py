@@ -449,3 +449,47 @@ def test_sharded_smooth_moment0_without_halos(gpu):
                     assert got is None
                 else:
                     assert_close(got, e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="halo-free sharded smooth+moment0")
+
+
+def test_median_percentile_mad_std(gpu):
+    """SpectralCube.median / percentile / mad_std (axis=0) against the Dask class' vectors: the
+    median is bit-exact (a selection, or the mean of two), percentiles / mad_std within fp32
+    rounding; all-masked rays are NaN; odd shapes use the scalar kernel; plus a long random ray
+    set with ties and infinities against numpy."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    g = golden("order_stats.npz")
+    d, inc = g["data"], g["include"]
+    hdr = str(golden("c1_moments.npz")["header"])
+    cube = SpectralCube.read(d, hdr).with_mask(inc)
+    med = np.asarray(cube.median(axis=0))
+    exp = g["median"]
+    assert np.array_equal(np.isnan(med), np.isnan(exp))
+    assert np.array_equal(med[~np.isnan(exp)], exp[~np.isnan(exp)].astype(np.float32))
+    for q in (10.0, 37.5, 90.0):
+        got = np.asarray(cube.percentile(q, axis=0))
+        assert_close(got, g["p%g" % q], atol=2e-6 * np.nanmax(np.abs(g["p%g" % q])), what="percentile %g" % q)
+    assert_close(np.asarray(cube.mad_std(axis=0)), g["mad_std"], atol=2e-6 * np.nanmax(np.abs(g["mad_std"])), what="mad_std")
+    with pytest.raises(NotImplementedError):
+        cube.median(axis=1)
+    rng = np.random.default_rng(4)
+    big = rng.standard_normal((301, 7, 13)).astype(np.float32)          # odd nx -> scalar kernel
+    big[rng.random(big.shape) < 0.1] = np.nan
+    big[5, 1, 2] = np.inf
+    big[6, 1, 2] = -np.inf
+    big[:, 3, 3] = np.round(big[:, 3, 3])                               # many ties
+    big[:, 4, 4] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        e = np.nanmedian(big, axis=0)
+        e25 = np.nanpercentile(big.astype(np.float64), 25.0, axis=0)
+    got = ops.percentile_axis0(DeviceArray.from_numpy(big), 50.0).get()
+    assert np.array_equal(np.isnan(got), np.isnan(e)) and np.array_equal(got[~np.isnan(e)], e[~np.isnan(e)])
+    got = ops.percentile_axis0(DeviceArray.from_numpy(big), 25.0).get()
+    fin = np.isfinite(e25)
+    assert np.array_equal(np.isnan(got), np.isnan(e25)) and np.allclose(got[fin], e25[fin], rtol=2e-6, atol=1e-6)
+    got = ops.percentile_axis0(DeviceArray.from_numpy(big), 50.0, mask=ops.MaskSpec(_lib.MASK_FINITE)).get()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        e = np.nanmedian(np.where(np.isfinite(big), big, np.nan), axis=0)
+    assert np.array_equal(np.isnan(got), np.isnan(e)) and np.array_equal(got[~np.isnan(e)], e[~np.isnan(e)])
