@@ -657,6 +657,31 @@ def case_order_statistics():
     print("order statistics ok")
 
 
+def case_sigma_clip():
+    """DaskSpectralCube.sigma_clip_spectrally(threshold) on a noise cube with planted outliers."""
+    rng = np.random.default_rng(31)
+    shape = (60, 9, 12)
+    data = rng.standard_normal(shape).astype(np.float32)
+    for _ in range(40):
+        z, y, x = rng.integers(0, shape[0]), rng.integers(0, shape[1]), rng.integers(0, shape[2])
+        data[z, y, x] += rng.choice([-1, 1]) * rng.uniform(6, 30)
+    data[3:6, 2, 2] = np.nan
+    h = c1_header(*shape)
+    sc = SpectralCube.read(fits.PrimaryHDU(data=data, header=h), use_dask=True)
+    store = {"data": data}
+    for thr in (3.0, 2.0):
+        ref = np.asarray(sc.sigma_clip_spectrally(thr)._data.compute(), dtype=np.float32)
+        mine = O.sigma_clip(data, np.isfinite(data), thr)
+        mism = int((np.isnan(ref) != np.isnan(mine)).sum())
+        assert mism <= 2, ("sigma_clip NaN pattern", thr, mism)              # (float32 vs float64 bounds: boundary ties)
+        ok = ~np.isnan(ref) & ~np.isnan(mine)
+        assert np.array_equal(ref[ok], mine[ok])
+        print("  sigma_clip", thr, "clipped", int(np.isnan(ref).sum()), "mismatches", mism)
+        store["clip_%g" % thr] = ref
+    np.savez_compressed(os.path.join(OUT, "sigma_clip.npz"), **store)
+    print("sigma clip ok")
+
+
 if __name__ == "__main__":
     case_moment_cube()
     case_c1()
@@ -669,4 +694,5 @@ if __name__ == "__main__":
     case_statistics()
     case_fits_files()
     case_order_statistics()
+    case_sigma_clip()
     print("ALL GOLDEN VECTORS WRITTEN to", OUT)

@@ -28,7 +28,7 @@ __all__ = [
     "filled", "moment", "moments012", "moment_cubewise", "argmax", "argmin",
     "convolve_fill_interp", "spectral_smooth", "spatial_smooth",
     "spectral_interpolate", "resample_bilinear", "reproject_separable",
-    "statistics", "reduce", "fits_decode", "median", "percentile", "mad_std",
+    "statistics", "reduce", "fits_decode", "median", "percentile", "mad_std", "sigma_clip",
 ]
 
 
@@ -461,3 +461,30 @@ def mad_std(data, include=None, axis=0):
         warnings.simplefilter("ignore", RuntimeWarning)
         med = np.nanmedian(d, axis=axis, keepdims=True)
         return 1.482602218505602 * np.nanmedian(np.abs(d - med), axis=axis)
+
+
+def sigma_clip(data, include=None, sigma=3.0, maxiters=5, cenfunc="median", stdfunc="std",
+               sigma_lower=None, sigma_upper=None):
+    """``astropy.stats.sigma_clip(array, sigma, axis=0, masked=False, copy=True)`` as called by
+    ``sigma_clip_spectrally`` (spectral_cube/dask_spectral_cube.py:851-878): iterate
+    bounds = centre -/+ sigma*std per ray (nan-aware), values outside -> NaN, until a pass
+    clips nothing or *maxiters* passes were made.  float64 internally."""
+    import warnings
+    lo_s = sigma if sigma_lower is None else sigma_lower
+    hi_s = sigma if sigma_upper is None else sigma_upper
+    f = filled(data, include, np.nan).astype(np.float64)
+    it = 0
+    with warnings.catch_warnings(), np.errstate(invalid="ignore"):
+        warnings.simplefilter("ignore", RuntimeWarning)
+        while maxiters is None or it < maxiters:
+            it += 1
+            cen = np.nanmedian(f, axis=0) if cenfunc == "median" else np.nanmean(f, axis=0)
+            if stdfunc == "std":
+                std = np.nanstd(f, axis=0)
+            else:
+                std = 1.482602218505602 * np.nanmedian(np.abs(f - np.nanmedian(f, axis=0)), axis=0)
+            out = (f < cen - lo_s * std) | (f > cen + hi_s * std)
+            if not out.any():
+                break
+            f[out] = np.nan
+    return f.astype(np.float32)

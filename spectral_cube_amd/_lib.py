@@ -112,6 +112,8 @@ SIGNATURES = {
     "spc_resample_bilinear_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _i64, _i64, _vp, _vp,
                                        _vp, _i64, _i64, _vp]),
     "spc_percentile_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
+    "spc_fill_masked_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp, _i64, _i64]),
+    "spc_clip_outside_f32": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _P(C.c_uint64)]),
     "spc_map_conv2d_f64": (_i, [_i, _vp, _vp, _i64, _i64, _P(_d), _i, _i, _vp]),
     "spc_fits_to_f32": (_i, [_i, _vp, _vp, _i, _d, _d, _i, _i64, _i64, _vp]),
     "spc_stats_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d)]),

@@ -251,6 +251,54 @@ __global__ __launch_bounds__(256) void map_conv2d_f64_kernel(const MapConvArgs A
     A.out[y * A.nx + x] = acc;
 }
 
+// ---- sigma clipping support: filled copy + clip pass --------
+// astropy.stats.sigma_clip(axis=0, masked=False) behind DaskSpectralCubeMixin.
+// sigma_clip_spectrally (spectral_cube/dask_spectral_cube.py:851-878) iterates
+//   bounds = centre -/+ sigma * std per ray  ->  values outside become NaN
+// until nothing changes (or maxiters).  The per-ray centre (median: spc_percentile_axis0_f32)
+// and std (spc_stats_axis_f32) come from the kernels above; these two kernels are the
+// elementwise ends: the NaN-filled working copy and the clip itself (with a change counter).
+struct ClipArgs {
+    const float* in;
+    float* out;
+    int64_t nz, ny, nx, row_stride, plane_stride, out_row_stride, out_plane_stride;
+    MaskDev mask;
+    float fill;
+    const float* lo;          // (ny, nx)
+    const float* hi;
+    unsigned long long* nchanged;
+};
+
+template <bool ARR>
+__global__ __launch_bounds__(256) void fill_masked_kernel(const ClipArgs A) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= A.nx) return;
+    for (int64_t z = blockIdx.z; z < A.nz; z += gridDim.z) {
+        const float v = A.in[z * A.plane_stride + y * A.row_stride + x];
+        bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v);
+        if (ARR) ok = ok && A.mask.arr[z * A.mask.plane_stride + y * A.mask.row_stride + x] != 0;
+        A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = ok ? v : A.fill;
+    }
+}
+
+__global__ __launch_bounds__(256) void clip_outside_kernel(const ClipArgs A) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    unsigned long long mine = 0;
+    if (x < A.nx) {
+        const float lo = A.lo[y * A.nx + x], hi = A.hi[y * A.nx + x];
+        for (int64_t z = blockIdx.z; z < A.nz; z += gridDim.z) {
+            float* q = A.out + z * A.out_plane_stride + y * A.out_row_stride + x;
+            const float v = *q;
+            if (v < lo || v > hi) { *q = NAN; ++mine; }      // NaN compares false: already clipped / invalid stay
+        }
+    }
+    // one atomic per wave
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(A.nchanged, mine);
+}
+
 int fill_common(StatArgs& A, const spc_cube_f32* cube, const spc_mask* mask) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
@@ -375,6 +423,54 @@ int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny,
     }
     (void)spc_scratch_free(d_k, st);
     SPC_HIP(e);
+    return SPC_OK;
+}
+
+int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, float fill,
+                        float* d_out, int64_t out_row_stride, int64_t out_plane_stride) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    ClipArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_REQUIRE(cube->ny <= 65535, "more than 65535 rows per call not supported (split the call)");
+    SPC_DEVICE(device);
+    A.in = cube->d_data; A.out = d_out; A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
+    A.fill = fill;
+    dim3 grid((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)std::min<int64_t>(cube->nz, 64));
+    if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(fill_masked_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(fill_masked_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, int64_t ny, int64_t nx,
+                         const float* d_lo, const float* d_hi, uint64_t* h_nchanged) {
+    SPC_REQUIRE(d_cube && d_lo && d_hi && h_nchanged, "NULL pointer argument");
+    SPC_REQUIRE(nz > 0 && ny > 0 && nx > 0 && ny <= 65535, "bad shape");
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* d_n = nullptr;
+    SPC_HIP(spc_scratch_alloc((void**)&d_n, sizeof(unsigned long long), st));
+    hipError_t e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), st);
+    if (e == hipSuccess) {
+        ClipArgs A{};
+        A.out = d_cube; A.nz = nz; A.ny = ny; A.nx = nx; A.out_row_stride = nx; A.out_plane_stride = ny * nx;
+        A.lo = d_lo; A.hi = d_hi; A.nchanged = d_n;
+        dim3 grid((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)std::min<int64_t>(nz, 64));
+        hipLaunchKernelGGL(clip_outside_kernel, grid, dim3(256), 0, st, A);
+        e = hipGetLastError();
+    }
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_n, sizeof h, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)spc_scratch_free(d_n, st);
+    SPC_HIP(e);
+    *h_nchanged = (uint64_t)h;
     return SPC_OK;
 }
 

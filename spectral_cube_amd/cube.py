@@ -560,6 +560,17 @@ class SpectralCube:
         return Projection(out.get(), unit=self._unit,
                           wcs=self._wcs.drop_spectral() if self._wcs is not None else None, meta=dict(self._meta))
 
+    def sigma_clip_spectrally(self, threshold, **kwargs):
+        """astropy's sigma clipper along the spectral axis, clipped (and excluded) values -> NaN
+        (dask_spectral_cube.py:851-878); kwargs: maxiters, cenfunc ('median' | 'mean'), stdfunc
+        ('std' | 'mad_std'), sigma_lower, sigma_upper.  Runs on the device (ops.sigma_clip_axis0)."""
+        allowed = {"maxiters", "cenfunc", "stdfunc", "sigma_lower", "sigma_upper"}
+        extra = set(kwargs) - allowed
+        if extra:
+            raise NotImplementedError("sigma_clip options not built on the device path: %s" % sorted(extra))
+        dev = ops.sigma_clip_axis0(self._device_data(), sigma=float(threshold), mask=self._mask_spec(), **kwargs)
+        return self._new_cube_with(dev=dev)
+
     def statistics(self):
         """global basic statistics in ONE pass (dask_spectral_cube.py:769-814): npts, min, max,
         sum, sumsq, mean, sigma (the reference's textbook formula), rms."""

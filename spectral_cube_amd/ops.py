@@ -352,3 +352,55 @@ def percentile_axis0(cube, q, mask=None, center=None, scale=1.0, stream=None, ou
     _lib.call("spc_percentile_axis0_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(q),
               C.c_void_p(center.ptr) if center is not None else None, float(scale), C.c_void_p(out.ptr))
     return out
+
+
+def fill_masked(cube, mask=None, fill=np.nan, stream=None, out=None):
+    """device copy with excluded voxels replaced by *fill* (MaskBase._filled, masks.py:197-237)."""
+    if out is None:
+        out = DeviceArray(cube.shape, np.float32, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_fill_masked_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(fill), C.c_void_p(out.ptr), 0, 0)
+    return out
+
+
+def sigma_clip_axis0(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc="median",
+                     stdfunc="std", mask=None, stream=None):
+    """astropy.stats.sigma_clip(axis=0, masked=False, copy=True) on the device
+    (DaskSpectralCubeMixin.sigma_clip_spectrally, dask_spectral_cube.py:851-878): returns a new
+    float32 DeviceArray with masked and clipped samples set to NaN.  Every iteration is one
+    selection (median), one statistics pass (std) and one clip pass; it stops when a pass clips
+    nothing or after *maxiters* (None: until convergence)."""
+    lo_s = sigma if sigma_lower is None else sigma_lower
+    hi_s = sigma if sigma_upper is None else sigma_upper
+    if cenfunc not in ("median", "mean") or stdfunc not in ("std", "mad_std"):
+        raise NotImplementedError("cenfunc must be 'median' or 'mean', stdfunc 'std' or 'mad_std' on the device path")
+    work = fill_masked(cube, mask, np.nan, stream)
+    nz, ny, nx = work.shape
+    it = 0
+    while maxiters is None or it < maxiters:
+        it += 1
+        st = stats_axis(work, 0, want=("count", "sum", "sumsq"), stream=stream)
+        n = st["count"].get().astype(np.float64)
+        ssum, ssq = st["sum"].get(), st["sumsq"].get()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean = np.where(n > 0, ssum / n, np.nan)
+            if cenfunc == "median":
+                med_dev = percentile_axis0(work, 50.0, stream=stream)
+                cen = med_dev.get().astype(np.float64)
+            else:
+                med_dev, cen = None, mean
+            if stdfunc == "std":
+                std = np.sqrt(np.maximum(np.where(n > 0, ssq / n - mean * mean, np.nan), 0.0))
+            else:
+                if med_dev is None:
+                    med_dev = percentile_axis0(work, 50.0, stream=stream)
+                std = percentile_axis0(work, 50.0, center=med_dev, scale=MAD_TO_STD, stream=stream).get().astype(np.float64)
+            lo = (cen - lo_s * std).astype(np.float32)
+            hi = (cen + hi_s * std).astype(np.float32)
+        d_lo, d_hi = DeviceArray.from_numpy(lo, work.device), DeviceArray.from_numpy(hi, work.device)
+        nch = C.c_uint64(0)
+        _lib.call("spc_clip_outside_f32", work.device, _sh(stream), C.c_void_p(work.ptr), nz, ny, nx,
+                  C.c_void_p(d_lo.ptr), C.c_void_p(d_hi.ptr), C.byref(nch))
+        if nch.value == 0:
+            break
+    return work

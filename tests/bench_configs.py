@@ -61,6 +61,12 @@ ms = med_ms(lambda: ops.percentile_axis0(cube, 50.0, mask=mspec, out=om), n=3, w
 res.append(row("C2 1024^3 u8 mask: median along the spectral axis", vox, ms, 5))
 ms = med_ms(lambda: ops.percentile_axis0(cube, 50.0, out=om), n=3, warm=1)
 res.append(row("C2 1024^3 no mask: median along the spectral axis", vox, ms, 4))
+import time as _t
+synchronize(); t0 = _t.perf_counter()
+clipped = ops.sigma_clip_axis0(cube, sigma=3.0)
+synchronize(); ms = (_t.perf_counter() - t0) * 1e3
+res.append(row("C2 1024^3: sigma_clip_spectrally(3), astropy defaults (wall clock)", vox, ms, 8))
+del clipped
 del cube, mask
 # ---------------- C3: 2048^3, spectral_smooth sigma=4 then moment1
 shape = (2048, 2048, 2048); vox = np.prod(shape, dtype=np.int64)
