@@ -200,9 +200,9 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
 // down-sampling) is flagged and left to the gather kernel.
 constexpr int kTile = 32;
 constexpr int kRowsMax = 64;                 // source rows a tile may touch
-constexpr int kElemsMax = 2560;              // staged source samples per channel
+constexpr int kElemsMax = 2048;              // staged source samples per channel
 constexpr int kFill = kElemsMax / 256;       // samples per thread and channel
-constexpr int kStageU = 4;                   // channels staged per iteration
+constexpr int kStageU = 8;                   // channels staged per iteration
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
