@@ -1,0 +1,100 @@
+"""Scratch: randomised shapes / masks through every kernel family against the oracle (run on a GPU box:
+python tests/stress_random.py [nrounds] [seed]).  Not part of the pytest suite."""
+import os, sys, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import numpy as np
+import oracle_np as O
+from spectral_cube_amd import ops, _lib
+from spectral_cube_amd.device import DeviceArray
+warnings.simplefilter("ignore")
+nround = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+dev = DeviceArray.from_numpy
+fails = 0
+
+def close(a, b, tol, what):
+    global fails
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    bad = np.isnan(a) != np.isnan(b)
+    fin = np.isfinite(a) & np.isfinite(b)
+    scale = np.max(np.abs(b[fin])) if fin.any() else 1.0
+    err = np.max(np.abs(a[fin] - b[fin])) if fin.any() else 0.0
+    infbad = (np.isinf(a) != np.isinf(b)) | (np.isinf(a) & np.isinf(b) & (np.sign(a) != np.sign(b)))
+    if bad.any() or infbad.any() or err > tol * max(scale, 1e-30):
+        fails += 1
+        print("FAIL", what, "nan-mismatch", int(bad.sum()), "inf-mismatch", int(infbad.sum()), "err", err, "scale", scale, flush=True)
+
+for it in range(nround):
+    nz, ny, nx = int(rng.integers(1, 90)), int(rng.integers(1, 70)), int(rng.integers(1, 300))
+    if rng.random() < 0.3: nx = int(rng.integers(1, 16)) * 4
+    d = (rng.standard_normal((nz, ny, nx)) * 3 + 1).astype(np.float32)
+    d[rng.random(d.shape) < rng.choice([0.0, 0.02, 0.3])] = np.nan
+    kind = rng.integers(0, 3)
+    if kind == 0: inc, spec = None, None
+    elif kind == 1:
+        inc = rng.random(d.shape) > 0.3
+        spec = ops.MaskSpec(_lib.MASK_ARRAY, array=dev(inc.astype(np.uint8)))
+    else:
+        inc = (d > 0.5) & np.isfinite(d); spec = ops.MaskSpec(_lib.MASK_GT | _lib.MASK_FINITE, 0.5)
+    tag = "it%d %s mask%d" % (it, (nz, ny, nx), kind)
+    dd = dev(d)
+    # moments + argmax
+    cen = np.cumsum(rng.uniform(0.5, 1.5, nz)); cref = cen[nz // 2]
+    r = ops.moments(dd, dev(cen - cref), dv=1.3, m1_add=cref + 10.0, mask=spec, want=("m0", "m1", "argmax", "nvalid"))
+    e0, e1, e2 = O.moments012(d, inc, cen, 1.3, 10.0)
+    close(r["m0"].get(), e0, 1e-5, tag + " m0")
+    g1, x1 = r["m1"].get(), e1
+    ok = np.abs(e0) > 1e-3 * np.nanmax(np.abs(e0)) if np.isfinite(e0).any() else np.zeros_like(e0, bool)
+    close(np.where(ok, g1, 0), np.where(ok, x1, 0), 1e-5, tag + " m1")
+    am = r["argmax"].get(); ea = O.argmax(d, inc)
+    if not np.array_equal(am, ea): fails += 1; print("FAIL", tag, "argmax", int((am != ea).sum()), flush=True)
+    # statistics
+    st = ops.stats_global(dd, mask=spec); es = O.statistics(d, inc)
+    if st["npts"] != es["npts"] or (es["npts"] and (st["min"] != es["min"] or st["max"] != es["max"] or abs(st["sum"] - es["sum"]) > 1e-9 * (abs(es["sum"]) + 1))):
+        fails += 1; print("FAIL", tag, "stats_global", st, es, flush=True)
+    for ax in (0, 1, 2):
+        ra = ops.stats_axis(dd, ax, mask=spec, want=("sum", "max"))
+        close(ra["sum"].get(), O.reduce(d, inc, "sum", axis=ax), 1e-10, tag + " sum ax%d" % ax)
+        close(ra["max"].get(), O.reduce(d, inc, "max", axis=ax), 0.0, tag + " max ax%d" % ax)
+    # order statistics
+    close(ops.percentile_axis0(dd, 50.0, mask=spec).get(), O.median(d, inc), 0.0, tag + " median")
+    q = float(rng.uniform(0, 100))
+    close(ops.percentile_axis0(dd, q, mask=spec).get(), O.percentile(d.astype(np.float64), inc, q), 3e-6, tag + " pct")
+    # spectral smoothing (ring sizes + generic), fused moments
+    nt = int(rng.choice([1, 3, 7, 9, 15, 33, 41]))
+    k = np.abs(rng.standard_normal(nt)) + 0.05
+    close(ops.spectral_conv(dd, k, mask=spec).get(), O.spectral_smooth(d, inc, k), 2e-5, tag + " sconv%d" % nt)
+    if nt <= 33:
+        sm = O.spectral_smooth(d, inc, k)
+        f0 = O.moment(sm, inc, 0, cen, 1.3)
+        rf = ops.spectral_conv_moments(dd, k, dev(cen - cref), dv=1.3, m1_add=cref + 10.0, mask=spec, want=("m0",), cen_host=cen - cref)
+        close(rf["m0"].get(), f0, 2e-5, tag + " fused m0 taps%d" % nt)
+    # spatial smoothing: separable and not
+    ky = int(rng.choice([3, 9, 17, 29])); g = np.exp(-0.5 * (np.arange(-(ky // 2), ky // 2 + 1) / (ky / 6.0)) ** 2)
+    k2 = np.outer(g, g)
+    small = d[:min(nz, 3)]
+    sinc = None if inc is None else inc[:min(nz, 3)]
+    sspec = None if spec is None else (ops.MaskSpec(_lib.MASK_ARRAY, array=dev(sinc.astype(np.uint8))) if kind == 1 else spec)
+    close(ops.spatial_conv(dev(small), k2, mask=sspec).get(), O.spatial_smooth(small, sinc, k2), 2e-5, tag + " spconv%d" % ky)
+    kk = int(rng.choice([5, 9, 13]))
+    yy, xx = np.mgrid[-(kk // 2):kk // 2 + 1, -(kk // 2):kk // 2 + 1]
+    kn = np.exp(-0.5 * (((xx + 0.5 * yy) / 2.0) ** 2 + (yy / 1.2) ** 2))
+    close(ops.spatial_conv(dev(small), kn, mask=sspec).get(), O.spatial_smooth(small, sinc, kn), 2e-5, tag + " nonsep%d" % kk)
+    # lerp + bilinear
+    if nz >= 2:
+        xin = np.arange(nz) * 2.0; xout = np.linspace(rng.uniform(-3, nz), rng.uniform(nz, 2 * nz + 3), int(rng.integers(2, 120)))
+        lo, t, inv, _, _, fill = ops.lerp_plan(xin, xout)
+        eo, _ = O.spectral_interpolate(d, inc, xin, xout)
+        close(ops.spectral_lerp(dd, lo, t, inv, fill, mask=spec).get(), eo, 1e-5, tag + " lerp")
+    nyo, nxo = int(rng.integers(1, 80)), int(rng.integers(1, 150))
+    yy, xx = np.mgrid[0:nyo, 0:nxo].astype(np.float64)
+    a = rng.uniform(0, 2 * np.pi); sc = rng.uniform(0.4, 2.5)
+    xs = sc * (np.cos(a) * xx - np.sin(a) * yy) + rng.uniform(-5, nx)
+    ys = sc * (np.sin(a) * xx + np.cos(a) * yy) + rng.uniform(-5, ny)
+    filled = O.filled(d, inc, np.nan)
+    eb, ef = O.resample_bilinear(filled, xs, ys)
+    ob, of = ops.resample_bilinear(dd, xs, ys, mask=spec, fill=np.nan)
+    close(ob.get(), eb, 1e-5, tag + " bilinear")
+    if not np.array_equal(of.get().astype(bool), ef[0]): fails += 1; print("FAIL", tag, "footprint", flush=True)
+print("rounds", nround, "failures", fails)

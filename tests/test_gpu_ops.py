@@ -526,3 +526,17 @@ def test_spatial_conv_nonseparable_tiled(gpu, monkeypatch, nk):
         assert np.max(np.abs(got[fin] - exp[fin])) <= 1e-5 * scale
         assert np.array_equal(np.isnan(got), np.isnan(ref))
         assert np.max(np.abs(got[fin] - ref[fin])) <= 2e-6 * scale
+
+
+def test_randomised_cross_check_against_oracle(gpu):
+    """tests/stress_random.py: random shapes (down to 1 x 1 x 1), NaN densities and mask kinds
+    through every kernel family (moments, argmax, statistics, order statistics, spectral ring /
+    generic / fused, separable and non-separable spatial, lerp, bilinear) against the oracle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "stress_random.py"), "10", "3"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "failures 0" in r.stdout, r.stdout[-3000:]
