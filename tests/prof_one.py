@@ -23,6 +23,14 @@ for _ in range(reps):
     elif op == "sconv_fused": ops.spectral_conv_moments(cube, g, cen)
     elif op == "spconv": ops.spatial_conv(cube, np.outer(g29, g29), out=out)
     elif op == "moments": ops.moments(cube, cen)
+    elif op == "bilinear":
+        yy, xx = np.mgrid[0:ny, 0:nx].astype(np.float64)
+        a = np.deg2rad(30.0)
+        xs = np.cos(a) * (xx - nx / 2) - np.sin(a) * (yy - ny / 2) + nx / 2
+        ys = np.sin(a) * (xx - nx / 2) + np.cos(a) * (yy - ny / 2) + ny / 2
+        ops.resample_bilinear(cube, xs, ys)
+    elif op == "stats": ops.stats_global(cube)
+    elif op == "median": ops.percentile_axis0(cube, 50.0)
     elif op == "spconv_mask":
         if _ == 0:
             mp = (rng.random((ny, nx)) > 0.2).astype(np.uint8)
