@@ -116,7 +116,7 @@ struct BilArgs {
     int64_t zchunk;
     // LDS-staged pass: one byte per 32 x 32 output tile, 0 = done by bilinear_lds_kernel
     unsigned char* status;
-    int64_t tiles32_x;
+    int64_t tiles32_x, ntiles32;
     int64_t zchunk_lds;
 };
 
@@ -212,7 +212,14 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
     __shared__ int s_xmin[kRowsMax], s_xmax[kRowsMax], s_off[kRowsMax + 1];
     __shared__ int s_ymin, s_ymax;
     const int t = threadIdx.x;
-    const int64_t bx = blockIdx.x % A.tiles32_x, by = blockIdx.x / A.tiles32_x;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+    // consecutive block ids would put neighbouring tiles - whose source footprints share cache lines -
+    // on different L2s.  Block b works on tile (b % 8) * ceil(ntiles / 8) + b / 8: every XCD walks a
+    // contiguous band of the tile grid.
+    const int64_t per_xcd = (A.ntiles32 + 7) / 8;
+    const int64_t tile_id = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (tile_id >= A.ntiles32) return;
+    const int64_t bx = tile_id % A.tiles32_x, by = tile_id / A.tiles32_x;
     const int64_t xo = bx * kTile + (t & 7) * 4;           // first of this lane's 4 adjacent pixels
     const int64_t yo = by * kTile + (t >> 3);
 
@@ -438,6 +445,7 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     if (want && fits) {
         A.tiles32_x = (nx_out + kTile - 1) / kTile;
         const int64_t ntiles = A.tiles32_x * ((ny_out + kTile - 1) / kTile);
+        A.ntiles32 = ntiles;
         int ns = 1;
         if (ntiles < 4096) ns = (int)std::max<int64_t>(1, std::min<int64_t>((4096 + ntiles - 1) / ntiles, cube->nz / 64));
         A.zchunk_lds = (cube->nz + ns - 1) / ns;
@@ -446,7 +454,7 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
         SPC_HIP(spc_scratch_alloc((void**)&d_status, (size_t)ntiles, st));
         SPC_HIP(spc_flags_clear(d_status, (size_t)ntiles, st));
         A.status = d_status;
-        dim3 g((unsigned)ntiles, (unsigned)ns);
+        dim3 g((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)ns);
         if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<true, true>), g, dim3(256), 0, st, A);
         else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<false, true>), g, dim3(256), 0, st, A);
         else hipLaunchKernelGGL((bilinear_lds_kernel<false, false>), g, dim3(256), 0, st, A);
