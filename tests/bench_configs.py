@@ -55,6 +55,10 @@ for ax in (0, 1, 2):
     so = ops.stats_axis(cube, ax, mask=mspec)
     ms = med_ms(lambda: ops.stats_axis(cube, ax, mask=mspec, out=so))
     res.append(row("C2 1024^3 u8 mask: count/min/max/sum/sumsq along axis %d" % ax, vox, ms, 5))
+for ax in (1, 2):
+    cen2 = DeviceArray.from_numpy(np.tile((np.arange(shape[ax]) * 1.0)[:, None] if ax == 1 else (np.arange(shape[ax]) * 1.0)[None, :], (1, shape[2]) if ax == 1 else (shape[1], 1)))
+    ms = med_ms(lambda: ops.moments_spatial(cube, cen2, ax, 1.0, mask=mspec), n=3, warm=1)
+    res.append(row("C2 1024^3 u8 mask: moment0+1+2 along spatial axis %d" % ax, vox, ms, 5))
 # order statistics along the spectral axis (33 streaming reads each)
 om = DeviceArray(shape[1:], np.float32)
 ms = med_ms(lambda: ops.percentile_axis0(cube, 50.0, mask=mspec, out=om), n=3, warm=1)
