@@ -100,13 +100,13 @@ def test_moments_golden_c1(gpu):
         assert np.array_equal(res["argmin"].get(), g["argmin"])
 
 
+@pytest.mark.parametrize("shape", [(48, 9, 11), (50, 7, 16)])      # scalar and 16-byte-vector kernels
 @pytest.mark.parametrize("order", [3, 4])
-def test_moment_order(gpu, order):
+def test_moment_order(gpu, order, shape):
     from spectral_cube_amd import ops
-    shape = (48, 9, 11)
     d = _cube(shape, 7, nan_block=False)
     inc = synth.boolean_mask(d, 6).astype(bool)
-    cen = np.arange(48.0) * 2.0
+    cen = np.arange(float(shape[0])) * 2.0
     r = ops.moments(_dev(d), _dev(cen), mask=_mspec(inc), want=("mu", "s0"))
     out = ops.moment_order(_dev(d), _dev(cen), order, r["mu"], r["s0"], mask=_mspec(inc)).get()
     exp = O.moment(d, inc, order, cen, 1.0)
@@ -127,16 +127,17 @@ def test_moments_spatial_axes(gpu, axis):
             with np.errstate(all="ignore"):
                 assert_close(r[name].get(), exp, rtol=1e-6, atol=1e-6 * np.nanmax(np.abs(exp)),
                              what="%s axis %d %s" % (name, axis, tag))
-    # a bigger seeded cube against the oracle
-    shape = (6, 70, 130)
-    d = _cube(shape, 3)
-    inc = synth.boolean_mask(d, 9).astype(bool)
-    cen = np.cumsum(np.full(shape[1:], 0.01), axis=axis - 1)
-    r = ops.moments_spatial(_dev(d), _dev(cen), axis, 0.01, mask=_mspec(inc))
-    for o, name in enumerate(("m0", "m1", "m2")):
-        exp = O.moment(d, inc, o, cen[None], 0.01, axis=axis)
-        with np.errstate(all="ignore"):
-            assert_close(r[name].get(), exp, rtol=1e-9, atol=1e-7 * np.nanmax(np.abs(exp)), what=name)
+    # bigger seeded cubes against the oracle (scalar kernels, and nx % 4 == 0: the 16-byte-vector kernels)
+    for shape in ((6, 70, 130), (5, 37, 128)):
+        d = _cube(shape, 3)
+        inc = synth.boolean_mask(d, 9).astype(bool)
+        cen = np.cumsum(np.full(shape[1:], 0.01), axis=axis - 1)
+        for m in (inc, None):
+            r = ops.moments_spatial(_dev(d), _dev(cen), axis, 0.01, mask=_mspec(m))
+            for o, name in enumerate(("m0", "m1", "m2")):
+                exp = O.moment(d, m, o, cen[None], 0.01, axis=axis)
+                with np.errstate(all="ignore"):
+                    assert_close(r[name].get(), exp, rtol=1e-9, atol=1e-7 * np.nanmax(np.abs(exp)), what=name)
 
 
 def _kernels():
