@@ -50,3 +50,12 @@ if "--nonsep" in sys.argv:
     _lib.call("spc_memcpy_d2d", 0, C.c_void_p(sm_.ptr), C.c_void_p(maskc.ptr), sm_.nbytes, None)
     ms = timeit(lambda: ops.spatial_conv(small, k, out=so, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=sm_)), n=2, warm=1)
     print("non-separable 15x15 + u8 mask:            %8.3f ms  -> %.1f ms per 1024 planes" % (ms, ms * 16))
+if "--wide" in sys.argv:
+    for nt in (41, 65, 81):
+        g = np.exp(-0.5 * (np.arange(-(nt // 2), nt // 2 + 1) / (nt / 8.0)) ** 2); g /= g.sum()
+        ms = timeit(lambda: ops.spectral_conv(cube, g, out=out), n=2, warm=1)
+        print("spectral %2d taps (generic kernel) %8.3f ms %7.1f GB/s" % (nt, ms, vox * 8 / ms / 1e6), flush=True)
+    for nt in (41, 65):
+        g = np.exp(-0.5 * (np.arange(-(nt // 2), nt // 2 + 1) / (nt / 8.0)) ** 2); g /= g.sum()
+        ms = timeit(lambda: ops.spatial_conv(cube, np.outer(g, g), out=out), n=2, warm=1)
+        print("spatial %2d taps separable      %8.3f ms %7.1f GB/s" % (nt, ms, vox * 8 / ms / 1e6), flush=True)
