@@ -447,14 +447,32 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
     if (rc) return rc;
     SPC_REQUIRE(out != nullptr && d_cen != nullptr, "NULL pointer argument");
     const int R = pick_ring(h_kernel, ntaps);
-    if (!R) {
-        spc_set_error("fused smooth->moments supports up to %d taps (got %d); "
-                      "materialise with spc_spectral_conv_f32 instead", kMaxTaps, ntaps);
-        return SPC_ERR_UNSUPPORTED;
-    }
     ConvArgs A{};
     rc = fill_common(A, cube, mask, h_kernel, ntaps, R);
     if (rc) return rc;
+    if (!R) {
+        // no ring (wide kernel): only the algebraic all-valid path can fuse; a flagged tile or an
+        // extremum request sends the caller to the materialised route
+        SPC_DEVICE(device);
+        A.cen = d_cen; A.dv = dv; A.m1_add = m1_add; A.mo = *out;
+        A.mo_row_stride = out->out_row_stride ? out->out_row_stride : cube->nx;
+        unsigned char* d_status = nullptr;
+        double* d_w = nullptr;
+        bool ok = false;
+        if (try_weighted_moments(A, cube, h_kernel, ntaps, h_cen, (hipStream_t)stream, &d_status, &d_w)) {
+            const size_t ntiles = (size_t)((A.ny * A.nx / 2 + 63) / 64);
+            std::vector<unsigned char> hs(ntiles);
+            ok = hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
+                 hipMemcpy(hs.data(), d_status, ntiles, hipMemcpyDeviceToHost) == hipSuccess;
+            for (size_t i = 0; ok && i < ntiles; ++i) ok = hs[i] == 0;
+            (void)spc_scratch_free(d_status, (hipStream_t)stream);
+            (void)spc_scratch_free(d_w, (hipStream_t)stream);
+        }
+        if (ok) return SPC_OK;
+        spc_set_error("fused smooth->moments with %d taps needs an all-valid cube and no extremum outputs "
+                      "(ring kernels go up to %d taps); materialise with spc_spectral_conv_f32 instead", ntaps, 33);
+        return SPC_ERR_UNSUPPORTED;
+    }
     SPC_DEVICE(device);
     A.cen = d_cen; A.dv = dv; A.m1_add = m1_add;
     // linear spectral axis (every FITS axis is): c[z] = c0 + z*dc -> no per-channel loads

@@ -323,9 +323,12 @@ class SpectralCube:
         dv = self._pix_size_slice(0)
         if fused_kernel is not None:
             parent, karr = fused_kernel
-            return ops.spectral_conv_moments(parent._device_data(), karr, d_cen, dv=dv,
-                                             m1_add=cref + spec0, mask=parent._mask_spec(), want=want,
-                                             cen_host=cen - cref)
+            try:
+                return ops.spectral_conv_moments(parent._device_data(), karr, d_cen, dv=dv,
+                                                 m1_add=cref + spec0, mask=parent._mask_spec(), want=want,
+                                                 cen_host=cen - cref)
+            except _lib.HipUnsupported:
+                pass        # e.g. a wide kernel on a cube with invalid samples: materialise, then reduce
         return ops.moments(self._device_data(), d_cen, dv=dv, m1_add=cref + spec0,
                            mask=self._mask_spec(), want=want)
 
@@ -595,7 +598,7 @@ class SpectralCube:
 
         class _Lazy:
             op = "spectral_smooth"
-            fusable = len(karr) <= 65
+            fusable = True
 
             def __init__(self):
                 self.parent, self.kernel = parent, karr
