@@ -190,6 +190,99 @@ __global__ __launch_bounds__(256) void spatial_conv2d_tiled_kernel(const SpArgs 
     }
 }
 
+// ---- very wide separable kernels (more taps than the largest ring, e.g. Gaussian2DKernel(sigma > 8)) ----
+// Two passes through an intermediate (num, den) buffer, a chunk of planes at a time:
+//   y pass: the runs-of-16 scheme of the wide spectral kernel with y as the marched axis - a lane owns
+//           one (z, x) column and produces 16 consecutive rows per run, weights as wave-uniform scalars;
+//   x pass: a block stages one row (+ halo) of the intermediate in LDS, a lane produces one output with
+//           one LDS read per tap (consecutive lanes read consecutive words: conflict free); columns
+//           outside the image are valid zeros of EVERY row: (num, den) = (0, sum(ky)).
+// Was: outer product + per-pixel 2-D loop (81 x 81 taps: 6561 global loads per output).
+template <bool ARR>
+__global__ __launch_bounds__(256) void spatial_wide_ypass_kernel(const SpArgs A, const float* kpad, int ntaps, float2v* inter,
+                                                                   int64_t z0, int64_t nzc) {
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (z - z0) * nx + x
+    if (col >= nzc * A.nx) return;
+    const int64_t zl = col / A.nx, x = col - zl * A.nx, z = z0 + zl;
+    const int H = ntaps / 2;
+    const float* p = A.cube + z * A.plane_stride + x;
+    const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + x : nullptr;
+    float2v* q = inter + zl * A.ny * A.nx + x;
+    const int64_t yb = (int64_t)blockIdx.y * A.ychunk;
+    const int64_t ye = min(A.ny, yb + A.ychunk);
+    for (int64_t o0 = yb; o0 < ye; o0 += 16) {
+        float2v acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[k] = float2v{0.f, 0.f};
+        auto sample = [&](int r) -> float2v {
+            const int64_t i = o0 - H + r;
+            if (i < 0 || i >= A.ny) return float2v{0.f, 1.f};
+            const float v = p[i * A.row_stride];
+            bool ok = (__builtin_fabsf(v) <= A.pred_lim) && !(v <= A.pred_lo) && !(v >= A.pred_hi);
+            if (ARR) ok = ok && pm[i * A.mask.row_stride] != 0;
+            return ok ? float2v{v, 1.f} : float2v{0.f, 0.f};
+        };
+        auto chunk = [&](int r0, int mode, int off, int nrows) {
+            const float* wp = kpad + 15 + (ntaps - 1 - r0) - 7;
+            float w[23];
+#pragma unroll
+            for (int t = 0; t < 23; ++t) w[t] = wp[t];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (mode == 1 && i >= nrows) break;
+                const float2v in = sample(r0 + i);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const bool on = (mode == 0) ? (k <= i + off) : (mode == 2) ? (k >= i + off) : true;
+                    if (on) acc[k] = __builtin_elementwise_fma(float2v{w[7 - i + k], w[7 - i + k]}, in, acc[k]);
+                }
+            }
+        };
+        chunk(0, 0, 0, 8);
+        chunk(8, 0, 8, 8);
+        int r0 = 16;
+        for (; r0 + 8 <= ntaps - 1; r0 += 8) chunk(r0, 1, 0, 8);
+        if (r0 < ntaps - 1) chunk(r0, 1, 0, ntaps - 1 - r0);
+        chunk(ntaps - 1, 2, 0, 8);
+        chunk(ntaps + 7, 2, 8, 8);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (o0 + k < ye) q[(o0 + k) * A.nx] = acc[k];
+    }
+}
+
+template <bool ARR>
+__global__ __launch_bounds__(256) void spatial_wide_xpass_kernel(const SpArgs A, const float* kx, int ntaps, const float2v* inter,
+                                                                   int64_t z0, float sum_ky) {
+    extern __shared__ float2v rowbuf[];                    // 256 + ntaps - 1
+    const int H = ntaps / 2;
+    const int64_t zl = blockIdx.z, y = blockIdx.y, z = z0 + zl;
+    const int64_t X0 = (int64_t)blockIdx.x * 256;
+    const float2v* src = inter + (zl * A.ny + y) * A.nx;
+    for (int c = threadIdx.x; c < 256 + ntaps - 1; c += 256) {
+        const int64_t ix = X0 - H + c;
+        rowbuf[c] = (ix >= 0 && ix < A.nx) ? src[ix] : float2v{0.f, sum_ky};
+    }
+    __syncthreads();
+    const int64_t x = X0 + threadIdx.x;
+    if (x >= A.nx) return;
+    float2v acc = float2v{0.f, 0.f};
+    // out[x] = sum_j kx[j] in[x + H - j]: buffer index threadIdx.x + (ntaps - 1 - j)
+    for (int j = 0; j < ntaps; ++j) {
+        const float w = kx[j];
+        acc = __builtin_elementwise_fma(float2v{w, w}, rowbuf[threadIdx.x + (ntaps - 1 - j)], acc);
+    }
+    float res;
+    if (acc.y != 0.f) res = acc.x / acc.y;
+    else {
+        const float c = A.cube[z * A.plane_stride + y * A.row_stride + x];
+        bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
+        if (ARR) inc = inc && A.mask.arr[z * A.mask.plane_stride + y * A.mask.row_stride + x] != 0;
+        res = inc ? c : NAN;
+    }
+    A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
+}
+
 int check_kernel(const double* k, int n, const char* what) {
     SPC_REQUIRE(k != nullptr, "%s kernel pointer is NULL", what);
     SPC_REQUIRE(n >= 1 && (n % 2) == 1, "%s kernel must have an odd number of taps (got %d)", what, n);
@@ -279,15 +372,51 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
                 "The kernel can't be normalized, because its sum is close to zero");
     const int R = pick_ring(std::max(nky, nkx));
     if (!R) {
-        // very wide kernels: materialise the outer product and use the direct kernel
-        const size_t n = (size_t)nky * nkx;
-        double* k2 = (double*)malloc(sizeof(double) * n);
-        if (!k2) { spc_set_error("out of host memory"); return SPC_ERR_NOMEM; }
-        for (int a = 0; a < nky; ++a)
-            for (int b = 0; b < nkx; ++b) k2[(size_t)a * nkx + b] = h_ky[a] * h_kx[b];
-        rc = spc_spatial_conv2d_f32(device, stream, cube, mask, k2, nky, nkx, d_out, out_row_stride, out_plane_stride);
-        free(k2);
-        return rc;
+        // very wide kernels: two passes through a (num, den) buffer, a chunk of planes at a time
+        SpArgs A{};
+        rc = fill_args(A, cube, mask, d_out, out_row_stride, out_plane_stride);
+        if (rc) return rc;
+        SPC_REQUIRE(cube->ny <= 65535, "more than 65535 rows per call not supported (split the call)");
+        SPC_DEVICE(device);
+        canonical_pred(A);
+        hipStream_t st = (hipStream_t)stream;
+        const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+        // y weights padded by 15 zeros (runs-of-16 scheme needs >= 17 taps: true here, the rings cover less), x plain
+        SPC_REQUIRE(nky >= 17 || nkx >= 17, "internal: wide path called with a short kernel");
+        const int nyp = std::max(nky, 17);                  // a short y kernel is centred in 17 taps of zeros
+        std::vector<float> hk((size_t)(nyp + 30) + nkx, 0.f);
+        for (int j = 0; j < nky; ++j) hk[15 + (nyp - nky) / 2 + j] = (float)h_ky[j];
+        for (int j = 0; j < nkx; ++j) hk[(size_t)(nyp + 30) + j] = (float)h_kx[j];
+        const int64_t plane = cube->ny * cube->nx;
+        const int64_t nzc_max = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cube->nz, 65535), (int64_t)(1ll << 31) / (plane * 8)));   // <= 2 GiB of (num, den)
+        float* d_k = nullptr;
+        float2v* d_inter = nullptr;
+        SPC_HIP(spc_scratch_alloc((void**)&d_k, sizeof(float) * hk.size(), st));
+        hipError_t e = hipMalloc((void**)&d_inter, sizeof(float2v) * (size_t)(nzc_max * plane));
+        if (e != hipSuccess) { (void)spc_scratch_free(d_k, st); (void)hipGetLastError(); spc_set_error("hipMalloc of the (num, den) buffer failed"); return SPC_ERR_NOMEM; }
+        e = hipMemcpyAsync(d_k, hk.data(), sizeof(float) * hk.size(), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        A.ychunk = ((std::max<int64_t>(16, (cube->ny + 3) / 4) + 15) / 16) * 16;      // a few y slices of whole runs
+        const unsigned nys = (unsigned)((cube->ny + A.ychunk - 1) / A.ychunk);
+        for (int64_t z0 = 0; e == hipSuccess && z0 < cube->nz; z0 += nzc_max) {
+            const int64_t nzc = std::min<int64_t>(nzc_max, cube->nz - z0);
+            dim3 gy((unsigned)((nzc * cube->nx + 255) / 256), nys);
+            dim3 gx((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)nzc);
+            const size_t lds = sizeof(float2v) * (size_t)(256 + nkx - 1);
+            if (arr) {
+                hipLaunchKernelGGL(spatial_wide_ypass_kernel<true>, gy, dim3(256), 0, st, A, d_k, nyp, d_inter, z0, nzc);
+                hipLaunchKernelGGL(spatial_wide_xpass_kernel<true>, gx, dim3(256), lds, st, A, d_k + (nyp + 30), nkx, d_inter, z0, (float)sy);
+            } else {
+                hipLaunchKernelGGL(spatial_wide_ypass_kernel<false>, gy, dim3(256), 0, st, A, d_k, nyp, d_inter, z0, nzc);
+                hipLaunchKernelGGL(spatial_wide_xpass_kernel<false>, gx, dim3(256), lds, st, A, d_k + (nyp + 30), nkx, d_inter, z0, (float)sy);
+            }
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_inter);
+        (void)spc_scratch_free(d_k, st);
+        SPC_HIP(e);
+        return SPC_OK;
     }
     SpArgs A{};
     rc = fill_args(A, cube, mask, d_out, out_row_stride, out_plane_stride);

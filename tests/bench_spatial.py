@@ -59,3 +59,10 @@ if "--wide" in sys.argv:
         g = np.exp(-0.5 * (np.arange(-(nt // 2), nt // 2 + 1) / (nt / 8.0)) ** 2); g /= g.sum()
         ms = timeit(lambda: ops.spatial_conv(cube, np.outer(g, g), out=out), n=2, warm=1)
         print("spatial %2d taps separable      %8.3f ms %7.1f GB/s" % (nt, ms, vox * 8 / ms / 1e6), flush=True)
+if "--vwide" in sys.argv:
+    g = np.exp(-0.5 * (np.arange(-40, 41) / 10.0) ** 2); g /= g.sum()
+    small = DeviceArray((128, ny, nx), np.float32)
+    _lib.call("spc_memcpy_d2d", 0, C.c_void_p(small.ptr), C.c_void_p(cube.ptr), small.nbytes, None)
+    so = DeviceArray(small.shape, np.float32)
+    ms = timeit(lambda: ops.spatial_conv(small, np.outer(g, g), out=so), n=2, warm=1)
+    print("spatial 81 taps separable, 128 planes: %8.3f ms -> %.1f ms per 1024 planes" % (ms, ms * 8), flush=True)

@@ -541,3 +541,26 @@ def test_randomised_cross_check_against_oracle(gpu):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "failures 0" in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("nk", [(81, 81), (9, 71), (75, 5)])
+def test_spatial_conv_very_wide_separable(gpu, nk):
+    """separable kernels with more taps than the largest ring (Gaussian2DKernel(sigma > 8)): two-pass
+    (num, den) route - against the oracle with NaNs and a mask array, ragged image."""
+    from spectral_cube_amd import ops
+    nky, nkx = nk
+    gy = np.exp(-0.5 * (np.arange(-(nky // 2), nky // 2 + 1) / (nky / 8.0)) ** 2)
+    gx = np.exp(-0.5 * (np.arange(-(nkx // 2), nkx // 2 + 1) / (nkx / 8.0)) ** 2)
+    k = np.outer(gy, gx)
+    rng = np.random.default_rng(nky + nkx)
+    shape = (3, 90, 301)
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[0, 20:30, 40:60] = np.nan
+    d[2, :, :150] = np.nan
+    inc = rng.random(shape) > 0.3
+    for m in (None, inc):
+        exp = O.spatial_smooth(d, m, k)
+        got = ops.spatial_conv(_dev(d), k, mask=_mspec(m)).get()
+        fin = np.isfinite(exp)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert np.max(np.abs(got[fin] - exp[fin])) <= 2e-5 * np.max(np.abs(exp[fin]))
