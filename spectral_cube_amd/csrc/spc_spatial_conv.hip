@@ -108,7 +108,7 @@ void canonical_pred(SpArgs& A) {
 // predicated (a zero-padded weight table would turn an Inf sample into NaN for outputs whose
 // window does not contain it).  Measured (15 x 15, 1024^3): 184 ms (per-pixel global loads) -> see
 // DESIGN.md 3.3.
-constexpr int kT2X = 64, kT2Y = 32, kT2Run = 8, kT2MaxK = 33;
+constexpr int kT2X = 64, kT2Y = 32, kT2Run = 8, kT2MaxK = 65;       // 65 x 65: 99 KB of LDS, one block per CU
 
 template <bool ARR>
 __global__ __launch_bounds__(256) void spatial_conv2d_tiled_kernel(const SpArgs A, const float* kern, int nky, int nkx) {
@@ -344,6 +344,10 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, c
             const int pitch = (kT2X + nkx - 1) | 1;
             const size_t lds = (size_t)(kT2Y + nky - 1) * pitch * sizeof(float2v);
             dim3 grid((unsigned)((cube->nx + kT2X - 1) / kT2X), (unsigned)((cube->ny + kT2Y - 1) / kT2Y), (unsigned)cube->nz);
+            if (lds > 48 * 1024) {      // dynamic LDS beyond the default limit has to be requested
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_tiled_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_tiled_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            }
             if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(spatial_conv2d_tiled_kernel<true>, grid, dim3(256), lds, st, A, d_k, nky, nkx);
             else hipLaunchKernelGGL(spatial_conv2d_tiled_kernel<false>, grid, dim3(256), lds, st, A, d_k, nky, nkx);
         } else {

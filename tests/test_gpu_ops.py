@@ -494,7 +494,7 @@ def test_c_abi_client_reproduces_reference_moment_table(gpu, tmp_path):
     assert "gpu ok" in r.stdout
 
 
-@pytest.mark.parametrize("nk", [(9, 9), (15, 15), (33, 33), (11, 21), (21, 9)])
+@pytest.mark.parametrize("nk", [(9, 9), (15, 15), (33, 33), (11, 21), (21, 9), (45, 45), (65, 35)])
 def test_spatial_conv_nonseparable_tiled(gpu, monkeypatch, nk):
     """non-separable kernels (rotated elliptical Gaussians = convolve_to's kernels) go through the
     LDS-tiled direct kernel (9..33 taps per axis): against the oracle (astropy semantics: zero fill,
@@ -526,7 +526,7 @@ def test_spatial_conv_nonseparable_tiled(gpu, monkeypatch, nk):
         assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(np.isinf(got), np.isinf(exp))
         assert np.max(np.abs(got[fin] - exp[fin])) <= 1e-5 * scale
         assert np.array_equal(np.isnan(got), np.isnan(ref))
-        assert np.max(np.abs(got[fin] - ref[fin])) <= 2e-6 * scale
+        assert np.max(np.abs(got[fin] - ref[fin])) <= 5e-6 * scale          # two fp32 summation orders over up to 2275 taps
 
 
 def test_randomised_cross_check_against_oracle(gpu):
