@@ -163,6 +163,10 @@ int spc_fits_to_f32(int device, void* stream, const void* d_raw, int bitpix,
                     double bscale, double bzero, int has_blank, int64_t blank,
                     int64_t n, float* d_out);
 
+/* d_data[i] *= factor over n contiguous floats: the Jy/beam rescaling by the ratio of beam
+ * areas in convolve_to (spectral_cube/dask_spectral_cube.py:1450-1457). */
+int spc_scale_f32(int device, void* stream, float* d_data, int64_t n, double factor);
+
 /* ---- statistics ------------------------------
  * One read of the cube gives count / min / max / sum / sum of squares of the
  * included, non-NaN samples, accumulated in float64.

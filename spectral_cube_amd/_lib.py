@@ -115,6 +115,7 @@ SIGNATURES = {
     "spc_fill_masked_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp, _i64, _i64]),
     "spc_clip_outside_f32": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _P(C.c_uint64)]),
     "spc_map_conv2d_f64": (_i, [_i, _vp, _vp, _i64, _i64, _P(_d), _i, _i, _vp]),
+    "spc_scale_f32": (_i, [_i, _vp, _vp, _i64, _d]),
     "spc_fits_to_f32": (_i, [_i, _vp, _vp, _i, _d, _d, _i, _i64, _i64, _vp]),
     "spc_stats_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d)]),
     "spc_stats_axis_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _P(SpcStatsOutputs)]),

@@ -114,3 +114,23 @@ extern "C" int spc_fits_to_f32(int device, void* stream, const void* d_raw, int 
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
+
+
+// out[i] *= factor over n contiguous floats (the Jy/beam rescaling of convolve_to,
+// spectral_cube/dask_spectral_cube.py:1450-1457); NaNs stay NaNs.
+namespace {
+__global__ __launch_bounds__(256) void scale_f32_kernel(float* p, int64_t n, float f) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] *= f;
+}
+}  // namespace
+
+extern "C" int spc_scale_f32(int device, void* stream, float* d_data, int64_t n, double factor) {
+    SPC_REQUIRE(d_data != nullptr && n >= 0, "bad arguments");
+    if (n == 0) return SPC_OK;
+    SPC_DEVICE(device);
+    const unsigned nblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(16384, (n + 1023) / 1024));
+    hipLaunchKernelGGL(scale_f32_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, d_data, n, (float)factor);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}

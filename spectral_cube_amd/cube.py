@@ -21,6 +21,7 @@ reference; units are plain strings unless astropy is importable; the 1e8-voxel
 ``warn_slow`` guard (utils.py:41-75) is not enforced because nothing is
 materialised on the host.
 """
+import math
 import operator
 import os
 import warnings
@@ -627,6 +628,44 @@ class SpectralCube:
                 return ops.spatial_conv(parent._device_data(), karr, mask=parent._mask_spec())
 
         return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
+
+    @property
+    def beam(self):
+        """the restoring beam from BMAJ / BMIN / BPA (None when the header has no beam)."""
+        from .beam import Beam
+        if getattr(self, "_beam", None) is None:
+            self._beam = Beam.from_header(self._header)
+        return self._beam
+
+    def with_beam(self, beam, raise_error_jybm=True):
+        new = self._new_cube_with(data=self._data, dev=self._dev, lazy=self._lazy, shape=self._shape, same_data=True)
+        new._beam = beam
+        new._header = dict(self._header, BMAJ=beam.major, BMIN=beam.minor, BPA=beam.pa)
+        return new
+
+    def convolve_to(self, beam, convolve=None, **kwargs):
+        """Convolve every channel to *beam* (dask_spectral_cube.py:1412-1464): kernel = beam.deconvolve(
+        self.beam).as_kernel(pixscale) through the 2-D stencils (separable when the kernel is, else the
+        LDS-tiled direct kernel), Jy/beam data scaled by the ratio of the beam areas."""
+        if convolve is not None:
+            raise NotImplementedError("custom `convolve` callables cannot run on the device")
+        if self.beam is None:
+            raise ValueError("cube has no beam (BMAJ / BMIN / BPA) to convolve from")
+        if beam == self.beam:
+            warnings.warn("The given beam is identical to the current beam. Skipping convolution.")
+            return self
+        if self._wcs is None:
+            raise ValueError("convolve_to needs the celestial pixel scale of a WCS")
+        psm = self._wcs.pixel_scale_matrix                     # proj_plane_pixel_area(wcs.celestial) ** 0.5
+        pixscale = math.sqrt(abs(psm[0, 0] * psm[1, 1] - psm[0, 1] * psm[1, 0]))
+        karr = beam.deconvolve(self.beam).as_kernel(pixscale)
+        is_jybm = str(self._unit).replace(" ", "").upper() in ("JY/BEAM", "JYBEAM-1", "JY/BM")
+        ratio = beam.sr / self.beam.sr if is_jybm else 1.0
+        dev = ops.spatial_conv(self._device_data(), karr, mask=self._mask_spec())
+        if ratio != 1.0:
+            ops.scale_inplace(dev, ratio)
+        new = self._new_cube_with(dev=dev)
+        return new.with_beam(beam, raise_error_jybm=False)
 
     def check_jybeam_smoothing(self, raise_error_jybm=True):
         """base_class.py:116-140"""

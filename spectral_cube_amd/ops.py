@@ -404,3 +404,11 @@ def sigma_clip_axis0(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxite
         if nch.value == 0:
             break
     return work
+
+
+def scale_inplace(arr, factor, stream=None):
+    """arr *= factor on the device (contiguous float32 DeviceArray)."""
+    if arr.dtype != np.float32 or getattr(arr, "_is_view", False):
+        raise TypeError("scale_inplace needs a contiguous float32 DeviceArray")
+    _lib.call("spc_scale_f32", arr.device, _sh(stream), C.c_void_p(arr.ptr), int(np.prod(arr.shape, dtype=np.int64)), float(factor))
+    return arr

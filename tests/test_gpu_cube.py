@@ -545,3 +545,40 @@ def test_wide_kernel_smooth_then_moment(gpu):
             with np.errstate(all="ignore"):
                 assert_close(m0, e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="m0 sigma %g %s" % (sig, variant))
                 assert_close(m1, e1, atol=1e-5 * abs(cen[-1] - cen[0]), what="m1 sigma %g %s" % (sig, variant))
+
+
+def test_convolve_to(gpu):
+    """convolve_to (dask_spectral_cube.py:1412-1464; radio_beam's conventions restated, see beam.py):
+    a cube whose channels are the current beam's image must come out as the target beam's image
+    (second moments), Jy/beam data are scaled by the ratio of the beam areas, and the result equals the
+    oracle's per-channel astropy-style convolution with the same kernel."""
+    from spectral_cube_amd.beam import Beam, BeamError
+    hdr = dict(SimpleWCS(str(golden("c1_moments.npz")["header"])).header)
+    pix = 1e-3
+    for k_ in [k_ for k_ in hdr if k_.startswith("PC") or k_.startswith("CD")]:
+        hdr.pop(k_)
+    hdr.update(CDELT1=-pix, CDELT2=pix, BUNIT="Jy/beam")
+    cur, tgt = Beam(6 * pix, 4 * pix, 25.0), Beam(11 * pix, 8 * pix, -40.0)
+    hdr.update(BMAJ=cur.major, BMIN=cur.minor, BPA=cur.pa)
+    h = 40
+    yy, xx = np.mgrid[-h:h + 1, -h:h + 1]
+    src = cur.as_kernel(pix, support_scaling=40)
+    c = src.shape[0] // 2
+    img = src[c - h:c + h + 1, c - h:c + h + 1]
+    d = np.stack([img * a for a in (1.0, 2.5, 0.5)]).astype(np.float32)
+    cube = SpectralCube(data=d, header=hdr)
+    out = cube.convolve_to(tgt)
+    res = out._device_data().get()
+    assert out.beam == tgt and out.header["BMAJ"] == tgt.major
+    karr = tgt.deconvolve(cur).as_kernel(pix)
+    exp = O.spatial_smooth(d, None, karr) * (tgt.sr / cur.sr)
+    assert_close(res, exp, atol=2e-5 * np.max(np.abs(exp)), what="convolve_to vs oracle")
+    w = res[0] / res[0].sum()
+    cov = np.array([[np.sum(w * xx * xx), np.sum(w * xx * yy)], [np.sum(w * xx * yy), np.sum(w * yy * yy)]]) * pix * pix
+    np.testing.assert_allclose(cov, tgt.covariance(), rtol=2e-2, atol=2e-2 * tgt.covariance().max())
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        assert cube.convolve_to(Beam(cur.major, cur.minor, cur.pa)) is cube
+        assert any("identical to the current beam" in str(x.message) for x in wlist)
+    with pytest.raises(BeamError):
+        cube.convolve_to(Beam(5 * pix, 3 * pix, 0.0))

@@ -295,3 +295,28 @@ def test_c_abi_from_plain_c(tmp_path):
     r = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert "all symbols present" in r.stdout
+
+
+def test_beam_algebra():
+    """beam.py (convolve_to's host side; radio_beam is not in this image, formulas restated):
+    Gaussian covariances add under convolution, so cov(target) == cov(current) + cov(deconvolved);
+    impossible targets raise; the sampled kernel has the beam's second moments."""
+    from spectral_cube_amd.beam import Beam, BeamError
+    for cur, tgt in ((Beam(3e-3, 2e-3, 20.0), Beam(6e-3, 5e-3, -35.0)), (Beam(2e-3), Beam(4e-3, 2.5e-3, 80.0)),
+                     (Beam(3e-3, 1e-3, 0.0), Beam(5e-3, 3e-3, 0.0))):
+        dec = tgt.deconvolve(cur)
+        np.testing.assert_allclose(cur.covariance() + dec.covariance(), tgt.covariance(), rtol=1e-9, atol=1e-18)
+    with pytest.raises(BeamError):
+        Beam(2e-3, 1e-3, 0.0).deconvolve(Beam(3e-3, 2e-3, 0.0))
+    b = Beam(8e-3, 4e-3, 30.0)
+    pix = 5e-4
+    k = b.as_kernel(pix)
+    assert k.shape[0] == k.shape[1] and k.shape[0] % 2 == 1
+    h = k.shape[0] // 2
+    yy, xx = np.mgrid[-h:h + 1, -h:h + 1]
+    w = k / k.sum()
+    cov = np.array([[np.sum(w * xx * xx), np.sum(w * xx * yy)], [np.sum(w * xx * yy), np.sum(w * yy * yy)]]) * pix * pix
+    np.testing.assert_allclose(cov, b.covariance(), rtol=2e-3, atol=1e-9 * b.covariance().max())
+    assert b.covariance()[0, 1] < 0                          # PA > 0: major axis tilts from +y towards -x
+    assert Beam(3e-3, 3e-3, 10.0) == Beam(3e-3, 3e-3, 70.0) and Beam(3e-3, 2e-3, 10.0) != Beam(3e-3, 2e-3, 70.0)
+    assert b.sr == pytest.approx(np.pi / (4 * np.log(2)) * np.radians(8e-3) * np.radians(4e-3))
