@@ -63,10 +63,14 @@ def fill_cube_on_device(cube, mask, shape, seed, y_offset):
                   blk.ctypes.data_as(C.c_void_p), nx * 4, (y1 - y0) * nx * 4, nx * 4, y1 - y0, nz, None)
         _lib.call("spc_memcpy3d_h2d", mask.device, C.c_void_p(mask.ptr + y0 * nx), nx, ny * nx,
                   m.ctypes.data_as(C.c_void_p), nx, (y1 - y0) * nx, nx, y1 - y0, nz, None)
+        keep.append((blk, m))       # host pages stay mapped until every staged copy has certainly drained (below)
         return (blk, m) if y0 == 0 else (None, float(m.mean()))
 
-    with ThreadPoolExecutor(min(32, len(os.sched_getaffinity(0)))) as ex:
+    keep = []
+    with ThreadPoolExecutor(min(16, len(os.sched_getaffinity(0)))) as ex:
         res = list(ex.map(one, range(0, ny, rows)))
+    _lib.call("spc_device_sync", cube.device)
+    del keep[:]
     return res[0]
 
 

@@ -116,6 +116,10 @@ int spc_memcpy3d_h2d(int device, void* d_dst, size_t d_row_pitch, size_t d_plane
             SPC_HIP(hipMemcpy2D(d, d_row_pitch, s, h_row_pitch, row_bytes, ny, hipMemcpyHostToDevice));
         }
     }
+    // synchronous form: the caller may free h_src as soon as this returns.  An explicit drain, because
+    // with many host threads issuing pageable 2-D copies a "Memory access fault by GPU" on a host address
+    // was seen (bench.py's input staging, ~1 run in 5) - a copy still reading pages the caller had freed.
+    if (!stream) SPC_HIP(hipDeviceSynchronize());
     return SPC_OK;
 }
 
