@@ -86,6 +86,8 @@ static int copy_(int device, void* dst, const void* src, size_t bytes, void* str
         SPC_HIP(hipMemcpyAsync(dst, src, bytes, kind, (hipStream_t)stream));
     } else {
         SPC_HIP(hipMemcpy(dst, src, bytes, kind));
+        // same insurance as in spc_memcpy3d_h2d: the host buffer may be freed right after we return
+        if (kind == hipMemcpyHostToDevice) SPC_HIP(hipDeviceSynchronize());
     }
     return SPC_OK;
 }
