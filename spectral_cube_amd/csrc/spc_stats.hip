@@ -282,16 +282,29 @@ __global__ __launch_bounds__(256) void fill_masked_kernel(const ClipArgs A) {
     }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void clip_outside_kernel(const ClipArgs A) {
-    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // lane = VEC adjacent x of one row, marching over its share of the planes (16-byte accesses when VEC == 4)
+    const int64_t x = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
     const int64_t y = blockIdx.y;
     unsigned long long mine = 0;
     if (x < A.nx) {
-        const float lo = A.lo[y * A.nx + x], hi = A.hi[y * A.nx + x];
+        float lo[VEC], hi[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) { lo[c] = A.lo[y * A.nx + x + c]; hi[c] = A.hi[y * A.nx + x + c]; }
         for (int64_t z = blockIdx.z; z < A.nz; z += gridDim.z) {
             float* q = A.out + z * A.out_plane_stride + y * A.out_row_stride + x;
-            const float v = *q;
-            if (v < lo || v > hi) { *q = NAN; ++mine; }      // NaN compares false: already clipped / invalid stay
+            if (VEC == 4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(q);
+                bool any = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (v[c] < lo[c] || v[c] > hi[c]) { v[c] = NAN; ++mine; any = true; }   // NaN compares false
+                if (any) *reinterpret_cast<f32x4*>(q) = v;
+            } else {
+                const float v = *q;
+                if (v < lo[0] || v > hi[0]) { *q = NAN; ++mine; }
+            }
         }
     }
     // one atomic per wave
@@ -461,8 +474,13 @@ int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, in
         ClipArgs A{};
         A.out = d_cube; A.nz = nz; A.ny = ny; A.nx = nx; A.out_row_stride = nx; A.out_plane_stride = ny * nx;
         A.lo = d_lo; A.hi = d_hi; A.nchanged = d_n;
-        dim3 grid((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)std::min<int64_t>(nz, 64));
-        hipLaunchKernelGGL(clip_outside_kernel, grid, dim3(256), 0, st, A);
+        if (nx % 4 == 0 && ((((uintptr_t)d_cube) & 15) == 0)) {
+            dim3 grid((unsigned)((nx / 4 + 255) / 256), (unsigned)ny, (unsigned)std::min<int64_t>(nz, 64));
+            hipLaunchKernelGGL(clip_outside_kernel<4>, grid, dim3(256), 0, st, A);
+        } else {
+            dim3 grid((unsigned)((nx + 255) / 256), (unsigned)ny, (unsigned)std::min<int64_t>(nz, 64));
+            hipLaunchKernelGGL(clip_outside_kernel<1>, grid, dim3(256), 0, st, A);
+        }
         e = hipGetLastError();
     }
     unsigned long long h = 0;
