@@ -12,6 +12,7 @@
 // on |x - centre| with the per-spaxel median as centre.
 #include "spc_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -155,6 +156,110 @@ __global__ __launch_bounds__(256) void select_axis0_kernel(const SelArgs A) {
     }
 }
 
+// ---- four key bits per pass with per-spaxel histograms in LDS (8 reads of the cube instead of 17) ----
+// Same descent, radix 16: a lane owns 4 adjacent spaxels and, for each of the two followed ranks, a
+// 16-bin histogram per spaxel in LDS (two 16-bit counters per word: nz <= 65535; layout
+// [word][rank][spaxel] so that a wave's updates fall into consecutive banks).  The bins are private to
+// the lane, so the updates are fire-and-forget ds_add and no barrier is ever needed.  The first pass
+// doubles as the valid count.  While both ranks still share their prefix (always, for an odd count)
+// only one histogram is maintained.
+constexpr int kSelSpaxels = 1024;                      // 256 lanes x 4
+
+template <bool ARR>
+__global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
+    __shared__ unsigned int hist[8][2][kSelSpaxels];     // 64 KB
+    const int t = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * 256 + t;
+    const int64_t gpr = A.nx / 4;
+    const bool live = g < A.ny * gpr;
+    const int64_t gg = live ? g : 0;
+    const int64_t y = gg / gpr, x = (gg - y * gpr) * 4;
+    const float* p = A.cube + y * A.row_stride + x;
+    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + x : nullptr;
+    const bool use_cen = A.center != nullptr;
+    float cen[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cen[c] = use_cen ? A.center[y * A.nx + x + c] : 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { hist[w][0][4 * t + c] = 0u; hist[w][1][4 * t + c] = 0u; }
+
+    int n[4] = {0, 0, 0, 0}, klo[4] = {0, 0, 0, 0}, khi[4] = {0, 0, 0, 0};
+    double frac[4] = {0, 0, 0, 0};
+    uint32_t plo[4] = {0, 0, 0, 0}, phi[4] = {0, 0, 0, 0};
+    bool same[4] = {true, true, true, true};
+#pragma unroll 1
+    for (int b = 28; b >= 0; b -= 4) {
+#pragma unroll 2
+        for (int64_t z = 0; z < A.nz; ++z) {
+            const f32x4s q4 = *reinterpret_cast<const f32x4s*>(p + z * A.plane_stride);
+            uint32_t m = 0x01010101u;
+            if (ARR) m = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm + z * A.mask.plane_stride));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float raw = q4[c];
+                bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw) && (raw == raw) && (((m >> (8 * c)) & 0xffu) != 0);
+                const float v = use_cen ? fabsf(raw - cen[c]) : raw;
+                ok = ok && (v == v);
+                const uint32_t k = fkey(v);
+                const uint32_t dg = (k >> b) & 15u;
+                const uint32_t inc = 1u << (16 * (dg & 1u));
+                const bool mlo = ok && ((((uint64_t)(k ^ plo[c])) >> (b + 4)) == 0u);
+                if (mlo) atomicAdd(&hist[dg >> 1][0][4 * t + c], inc);
+                if (!same[c]) {
+                    const bool mhi = ok && ((((uint64_t)(k ^ phi[c])) >> (b + 4)) == 0u);
+                    if (mhi) atomicAdd(&hist[dg >> 1][1][4 * t + c], inc);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned cnt[2][16];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const unsigned a0 = hist[w][0][4 * t + c];
+                const unsigned a1 = same[c] ? a0 : hist[w][1][4 * t + c];
+                cnt[0][2 * w] = a0 & 0xffffu; cnt[0][2 * w + 1] = a0 >> 16;
+                cnt[1][2 * w] = a1 & 0xffffu; cnt[1][2 * w + 1] = a1 >> 16;
+                hist[w][0][4 * t + c] = 0u; hist[w][1][4 * t + c] = 0u;
+            }
+            if (b == 28) {                                   // first pass: every valid sample was counted
+                int tot = 0;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) tot += (int)cnt[0][d];
+                n[c] = tot;
+                const double pos = A.q / 100.0 * (double)(tot > 0 ? tot - 1 : 0);
+                const double fl = floor(pos);
+                klo[c] = (int)fl;
+                khi[c] = min((int)ceil(pos), max(tot - 1, 0));
+                frac[c] = pos - fl;
+            }
+            uint32_t dlo = 15, dhi = 15;
+            bool flo = false, fhi = false;
+#pragma unroll
+            for (int d = 0; d < 15; ++d) {
+                if (!flo) { if (klo[c] < (int)cnt[0][d]) { dlo = d; flo = true; } else klo[c] -= (int)cnt[0][d]; }
+                if (!fhi) { if (khi[c] < (int)cnt[1][d]) { dhi = d; fhi = true; } else khi[c] -= (int)cnt[1][d]; }
+            }
+            plo[c] |= dlo << b;
+            phi[c] |= dhi << b;
+            same[c] = same[c] && (dlo == dhi);
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float res = NAN;
+        if (n[c] > 0) {
+            const double a = (double)funkey(plo[c]), bb = (double)funkey(phi[c]);
+            const double tt = frac[c];
+            res = (float)((tt == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * tt) * (double)A.scale);
+        }
+        A.out[y * A.nx + x + c] = res;
+    }
+}
+
 }  // namespace
 
 extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
@@ -176,7 +281,13 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
                     ((((uintptr_t)cube->d_data) & 15) == 0) &&
                     (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
     hipStream_t st = (hipStream_t)stream;
-    if (v4) {
+    const char* env = getenv("SPC_SELECT_RADIX16");
+    if (v4 && cube->nz <= 65535 && (env ? atoi(env) != 0 : true)) {
+        const int64_t n = cube->ny * (cube->nx / 4);
+        dim3 grid((unsigned)((n + 255) / 256));
+        if (arr) hipLaunchKernelGGL(select16_axis0_kernel<true>, grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(select16_axis0_kernel<false>, grid, dim3(256), 0, st, A);
+    } else if (v4) {
         const int64_t n = cube->ny * (cube->nx / 4);
         dim3 grid((unsigned)((n + 255) / 256));
         if (arr) hipLaunchKernelGGL((select_axis0_kernel<4, true>), grid, dim3(256), 0, st, A);
