@@ -682,7 +682,80 @@ def case_sigma_clip():
     print("sigma clip ok")
 
 
+def case_beams_cube():
+    """Varying-resolution cube (dask_spectral_cube.py:1511-1630): a 6-channel
+    Jy/beam cube with a CASA-style BEAMS table written by astropy (the layout of the reference's
+    conftest prepare_*_beams fixtures), plus an AIPS-flavoured copy with BMAJ/BMIN in 'DEGREES'.
+    radio_beam is absent here (parity of the deconvolution UNPINNED, see spectral_cube_amd/beam.py):
+    the per-channel kernels are built from astropy's own Gaussian2D model the way radio_beam's
+    EllipticalGaussian2DKernel does, from beams deconvolved by spectral_cube_amd.beam, and the
+    expected cube is astropy.convolution.convolve per channel, as the reference's convfunc does.
+    What this pins: the BEAMS table reader against astropy, as_kernel against Gaussian2D, and the
+    per-channel convolve / pass-through / beam-area scaling against astropy.convolution."""
+    import io
+    import math
+    from astropy.modeling.models import Gaussian2D
+    from spectral_cube_amd.beam import Beam, FWHM_TO_SIGMA
+    rng = np.random.default_rng(4242)
+    nz, ny, nx = 6, 24, 20
+    data = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    data[1, 5:8, 4] = np.nan
+    data[3, 20, 10:13] = np.nan
+    h = c1_header(nz, ny, nx)
+    h["BUNIT"] = "Jy/beam"
+    pix = 1.0 / 3600
+    target = Beam(5.0 * pix, 4.5 * pix, 20.0)
+    bmaj = np.array([3.5, 3.0, 3.0, 5.0, np.nan, 2.5], dtype=np.float64) * pix     # chan 2 = chan 1, chan 3 = target
+    bmin = np.array([2.0, 2.5, 2.5, 4.5, 2.0, 2.5], dtype=np.float64) * pix
+    bpa = np.array([0.0, 45.0, 45.0, 20.0, 10.0, 0.0])
+    rec = np.recarray(nz, dtype=[("BMAJ", ">f4"), ("BMIN", ">f4"), ("BPA", ">f4"), ("CHAN", ">i4"), ("POL", ">i4")])
+    rec["BMAJ"], rec["BMIN"], rec["BPA"] = bmaj * 3600, bmin * 3600, bpa
+    rec["CHAN"], rec["POL"] = np.arange(nz), 0
+    tab = fits.BinTableHDU(rec, name="BEAMS")
+    tab.header["TUNIT1"], tab.header["TUNIT2"], tab.header["TUNIT3"] = "arcsec", "arcsec", "deg"
+    buf = io.BytesIO()
+    fits.HDUList([fits.PrimaryHDU(data=data, header=h), tab]).writeto(buf)
+    raw = buf.getvalue()
+    rec2 = rec.copy()
+    rec2["BMAJ"], rec2["BMIN"] = bmaj, bmin
+    tab2 = fits.BinTableHDU(rec2, name="BEAMS")
+    tab2.header["TUNIT1"], tab2.header["TUNIT2"], tab2.header["TUNIT3"] = "DEGREES", "DEGREES", "DEGREES"
+    buf2 = io.BytesIO()
+    fits.HDUList([fits.PrimaryHDU(data=data, header=h), tab2]).writeto(buf2)
+    with fits.open(io.BytesIO(raw)) as hl:                       # what astropy reads back (float32 arcsec)
+        t = hl["BEAMS"].data
+        r_maj, r_min, r_pa = (np.array(t["BMAJ"], dtype=np.float64), np.array(t["BMIN"], dtype=np.float64),
+                              np.array(t["BPA"], dtype=np.float64))
+    expected = np.empty_like(data)
+    kernels = {}
+    for k in range(nz):
+        bm = Beam(r_maj[k] / 3600.0, r_min[k] / 3600.0, r_pa[k])
+        if not bm.isfinite:
+            expected[k] = np.nan                                  # masked-out layer: filled data passed through
+            continue
+        if bm == target:
+            expected[k] = data[k]
+            continue
+        dk = target.deconvolve(bm)
+        smaj, smin = dk.major * FWHM_TO_SIGMA / pix, dk.minor * FWHM_TO_SIGMA / pix
+        size = int(math.ceil(8 * smaj))
+        size += 1 - size % 2
+        model = Gaussian2D(1.0 / (2 * np.pi * smaj * smin), 0, 0, x_stddev=smaj, y_stddev=smin,
+                           theta=math.radians(dk.pa) + math.pi / 2)
+        kern = convolution.Model2DKernel(model, x_size=size, y_size=size)
+        assert np.allclose(kern.array, dk.as_kernel(pix), rtol=1e-12, atol=0), k
+        kernels["kernel_%d" % k] = kern.array
+        expected[k] = convolution.convolve(data[k], kern, normalize_kernel=True) * (target.sr / bm.sr)
+        ko = O.spatial_smooth(data[k:k + 1], None, kern.array)[0] * (target.sr / bm.sr)
+        assert np.allclose(ko, expected[k], rtol=2e-5, atol=2e-6, equal_nan=True), k
+    np.savez_compressed(os.path.join(OUT, "beams_cube.npz"), file_arcsec=np.frombuffer(raw, dtype=np.uint8),
+                        file_degrees=np.frombuffer(buf2.getvalue(), dtype=np.uint8), data=data,
+                        bmaj_arcsec=r_maj, bmin_arcsec=r_min, bpa_deg=r_pa,
+                        target=np.array([target.major, target.minor, target.pa]), expected=expected, **kernels)
+
+
 if __name__ == "__main__":
+    case_beams_cube()
     case_moment_cube()
     case_c1()
     case_adv_argmax()

@@ -42,11 +42,17 @@ class Beam:
         """beam area in steradian: pi / (4 ln 2) * major * minor"""
         return math.pi / (4.0 * math.log(2.0)) * math.radians(self.major) * math.radians(self.minor)
 
+    @property
+    def isfinite(self):
+        return math.isfinite(self.major) and math.isfinite(self.minor) and math.isfinite(self.pa)
+
     def __eq__(self, other):
         if not isinstance(other, Beam):
             return NotImplemented
         same_pa = abs(((self.pa - other.pa + 90.0) % 180.0) - 90.0) < 1e-9 or abs(self.major - self.minor) < 1e-12 * self.major
         return abs(self.major - other.major) <= 1e-12 * self.major and abs(self.minor - other.minor) <= 1e-12 * self.major and same_pa
+
+    __hash__ = None
 
     def __repr__(self):
         return "Beam(major=%g deg, minor=%g deg, pa=%g deg)" % (self.major, self.minor, self.pa)

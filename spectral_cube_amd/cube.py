@@ -29,6 +29,7 @@ import warnings
 import numpy as np
 
 from . import _lib, masks as M, ops
+from .beam import Beam, BeamError
 from .device import DeviceArray
 from .kernels import kernel_array
 from .wcs import SimpleWCS, pix_cen_spatial, pix_size, reproject_pixel_map
@@ -149,10 +150,15 @@ class SpectralCube:
             meta = dict(kw.pop("meta", None) or {})
             if "BUNIT" in hdr:
                 meta["BUNIT"] = hdr["BUNIT"]
+            table = io_fits.read_beams_table(os.fspath(data)) if "beams" not in kw else None
+            if table is not None:            # a BEAMS extension makes it a varying-resolution cube (io/fits.py:216-228)
+                cls, kw = VaryingResolutionSpectralCube, dict(kw, beam_table=table)
             cube = cls(None, header=hdr, device=device, _dev=dev, meta=meta, **kw)
         else:
             cube = cls(np.asarray(data), header=header, device=device, **kw)
-        cube._mask = M.LazyMask(np.isfinite, cube=cube)
+        finite = M.LazyMask(np.isfinite, cube=cube)
+        beam_mask = cube._mask if isinstance(cube, VaryingResolutionSpectralCube) else None
+        cube._mask = finite if beam_mask is None else (finite & beam_mask)
         return cube
 
     def write(self, filename, overwrite=False, format=None):
@@ -749,6 +755,156 @@ class SpectralCube:
 
     def __repr__(self):
         return "SpectralCube(hip) with shape=%s%s" % (self._shape, " and unit=%s" % self._unit if self._unit else "")
+
+
+class BeamWarning(UserWarning):
+    """spectral_cube.utils.BeamWarning"""
+
+
+class NonFiniteBeamsWarning(UserWarning):
+    """spectral_cube.utils.NonFiniteBeamsWarning"""
+
+
+class VaryingResolutionSpectralCube(SpectralCube):
+    """Cube with one beam per channel (spectral_cube.py:3776-3872, the Dask flavour at
+    dask_spectral_cube.py:1467-1645).  What the accelerated path serves is ``convolve_to``: every
+    channel is brought to a common beam with its own deconvolved kernel, runs of channels that share
+    a beam going through the 2-D stencils in one launch.  Channels with non-finite beams are masked
+    out, as the reference does; the beam-area checks around spectral reductions
+    (base_class.py:673-790) are not mirrored."""
+
+    def __init__(self, *args, beams=None, beam_table=None, goodbeams_mask=None, beam_threshold=0.01, **kw):
+        if beams is None and beam_table is None:
+            raise ValueError("Must give either a beam table or a list of beams to "
+                             "initialize a VaryingResolutionSpectralCube")
+        super().__init__(*args, **kw)
+        if beam_table is not None:          # {"BMAJ", "BMIN", "BPA"} in degrees (io_fits.read_beams_table)
+            beams = [Beam(a, b, p) for a, b, p in zip(beam_table["BMAJ"], beam_table["BMIN"], beam_table["BPA"])]
+        beams = list(beams)
+        if len(beams) != self._shape[0]:
+            raise ValueError("Beam list must have same size as spectral dimension")
+        self._beams = beams
+        self.beam_threshold = beam_threshold
+        good = np.array([b.isfinite for b in beams], dtype=bool)
+        if goodbeams_mask is not None:
+            good &= np.asarray(goodbeams_mask, dtype=bool)
+        self._goodbeams_mask = good
+        if not good.all():
+            if goodbeams_mask is None:
+                warnings.warn("There were {0} non-finite beams; layers with non-finite beams will be "
+                              "masked out.".format(int(np.count_nonzero(~good))), NonFiniteBeamsWarning)
+            bm = M.BooleanArrayMask(good[:, None, None], wcs=self._wcs, shape=self._shape)
+            self._mask = bm if self._mask is None else (self._mask & bm)
+
+    @property
+    def beams(self):
+        """the beams of the channels whose beam is good (base_class.py:497-501)"""
+        return [b for b, g in zip(self._beams, self._goodbeams_mask) if g]
+
+    @property
+    def unmasked_beams(self):
+        return self._beams
+
+    @property
+    def goodbeams_mask(self):
+        return self._goodbeams_mask
+
+    @property
+    def beam(self):
+        raise AttributeError("VaryingResolutionSpectralCubes have a `beams` list, not a single `beam`")
+
+    def with_beams(self, beams, goodbeams_mask=None, raise_error_jybm=True):
+        new = self._new_cube_with(data=self._data, dev=self._dev, lazy=self._lazy, shape=self._shape, same_data=True)
+        beams = list(beams)
+        if len(beams) != self._shape[0]:
+            raise ValueError("Beam list must have same size as spectral dimension")
+        new._beams = beams
+        if goodbeams_mask is not None:
+            new._goodbeams_mask = np.asarray(goodbeams_mask, dtype=bool)
+        return new
+
+    def _new_cube_with(self, **kw):
+        new = SpectralCube._new_cube_with(self, **kw)
+        if new._shape[0] == len(self._beams):
+            new.__class__ = VaryingResolutionSpectralCube
+            new._beams = self._beams
+            new._goodbeams_mask = self._goodbeams_mask
+            new.beam_threshold = self.beam_threshold
+        return new
+
+    def write(self, filename, overwrite=False, format=None):
+        """the cube followed by its BEAMS table (hdulist, dask_spectral_cube.py:1493-1509)"""
+        from . import io_fits
+        SpectralCube.write(self, filename, overwrite=overwrite, format=format)
+        io_fits.append_beams_table(os.fspath(filename), [b.major for b in self._beams],
+                                   [b.minor for b in self._beams], [b.pa for b in self._beams])
+
+    def convolve_to(self, beam, allow_smaller=False, convolve=None, **kwargs):
+        """Convolve each channel to *beam* (dask_spectral_cube.py:1511-1630): channel k gets the kernel
+        ``beam.deconvolve(beams[k]).as_kernel(pixscale)`` and, for Jy/beam data, the factor
+        ``beam.sr / beams[k].sr``; channels whose beam is masked, equals the target, or (with
+        ``allow_smaller``) cannot be deconvolved are passed through as filled data.  Returns a
+        single-beam SpectralCube."""
+        if convolve is not None:
+            raise NotImplementedError("custom `convolve` callables cannot run on the device")
+        if self._wcs is None:
+            raise ValueError("convolve_to needs the celestial pixel scale of a WCS")
+        psm = self._wcs.pixel_scale_matrix
+        if psm[0, 1] != 0 or psm[1, 0] != 0:
+            warnings.warn("The beams will produce convolution kernels that are not aware of any "
+                          "misaligment between pixel and world coordinates, and there are off-diagonal "
+                          "elements of the WCS spatial transformation matrix.  Unexpected results are "
+                          "likely.", BeamWarning)
+        pixscale = math.sqrt(abs(psm[0, 0] * psm[1, 1] - psm[0, 1] * psm[1, 0]))
+        is_jybm = str(self._unit).replace(" ", "").upper() in ("JY/BEAM", "JYBEAM-1", "JY/BM")
+        plans = []                                  # per channel: None (pass through) or (source beam, kernel, ratio)
+        for bm, valid in zip(self._beams, self._goodbeams_mask):
+            if not valid or beam == bm:
+                plans.append(None)
+                continue
+            try:
+                dk = beam.deconvolve(bm)
+            except (BeamError, ValueError):
+                if allow_smaller:
+                    plans.append(None)
+                    continue
+                raise
+            if plans and plans[-1] is not None and plans[-1][0] == bm:
+                plans.append(plans[-1])             # same beam as the previous channel: share the launch
+            else:
+                plans.append((bm, dk.as_kernel(pixscale), beam.sr / bm.sr if is_jybm else 1.0))
+        src, spec = self._device_data(), self._mask_spec()
+        out = DeviceArray(self._shape, np.float32, self.device)
+        nz, z0 = self._shape[0], 0
+        while z0 < nz:
+            z1 = z0 + 1
+            while z1 < nz and plans[z1] is plans[z0]:
+                z1 += 1
+            o = out.planes(z0, z1)
+            if plans[z0] is None:
+                ops.fill_masked(src.planes(z0, z1), spec.planes(z0, z1), np.nan, out=o)
+            else:
+                _, karr, ratio = plans[z0]
+                ops.spatial_conv(src.planes(z0, z1), karr, mask=spec.planes(z0, z1), out=o)
+                if ratio != 1.0:
+                    ops.scale_inplace(o, ratio)
+            z0 = z1
+        new = SpectralCube._new_cube_with(self, dev=out)
+        return new.with_beam(beam, raise_error_jybm=False)
+
+    def spectral_interpolate(self, *args, **kwargs):
+        raise AttributeError("VaryingResolutionSpectralCubes can't be spectrally interpolated.  Convolve "
+                             "to a common resolution with `convolve_to` before attempting spectral "
+                             "interpolation.")
+
+    def spectral_smooth(self, *args, **kwargs):
+        raise AttributeError("VaryingResolutionSpectralCubes can't be spectrally smoothed.  Convolve to "
+                             "a common resolution with `convolve_to` before attempting spectral "
+                             "smoothed.")
+
+    def __repr__(self):
+        return "VaryingResolutionSpectralCube(hip) with shape=%s%s" % (
+            self._shape, " and unit=%s" % self._unit if self._unit else "")
 
 
 class _Thunk:

@@ -131,6 +131,23 @@ class DeviceArray:
         v._is_view = True
         return v
 
+    def planes(self, z0, z1):
+        """view of channels [z0, z1) of a (nz, ny, nx) array (no copy).  Of a contiguous parent it
+        is itself contiguous; of a rows() view it keeps the parent's strides."""
+        if len(self.shape) != 3:
+            raise ValueError("planes() needs a (nz, ny, nx) array")
+        nz, ny, nx = self.shape
+        if not (0 <= z0 <= z1 <= nz):
+            raise ValueError("channel range out of bounds")
+        pstride = getattr(self, "plane_stride", ny * nx)
+        v = DeviceArray((z1 - z0, ny, nx), self.dtype, self.device,
+                        ptr=self.ptr + z0 * pstride * self.dtype.itemsize, owner=self)
+        if getattr(self, "_is_view", False):
+            v.row_stride, v.plane_stride = self.row_stride, self.plane_stride
+            v.nbytes = 0
+            v._is_view = True
+        return v
+
     def reshape(self, shape):
         shape = tuple(int(s) for s in shape)
         if int(np.prod(shape, dtype=np.int64)) * self.dtype.itemsize != self.nbytes:

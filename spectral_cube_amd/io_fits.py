@@ -374,3 +374,82 @@ def save_cube(path, dev, header=None, chunk_bytes=128 << 20, nbuffers=4, overwri
         os.close(fd)
         for b in pinned:
             b.close()
+
+
+# ---- CASA-style BEAMS binary table (per-channel beams of a VaryingResolutionSpectralCube) ----------
+_TFORM = {"E": ">f4", "D": ">f8", "J": ">i4", "I": ">i2", "K": ">i8", "B": "u1"}
+_UNIT_DEG = {"arcsec": 1.0 / 3600.0, "arcmin": 1.0 / 60.0, "deg": 1.0, "degree": 1.0, "degrees": 1.0,
+             "rad": 180.0 / np.pi, "mas": 1.0 / 3.6e6}
+
+
+def read_beams_table(path):
+    """The ``BEAMS`` BINTABLE extension of *path* (read_data_fits, spectral_cube/io/fits.py:94-131),
+    or None when the file has none: {"BMAJ", "BMIN" (degrees), "BPA" (degrees), "CHAN", "POL"} as
+    float64 / int arrays.  Units come from the TUNITn of the BMAJ / BMIN columns (arcsec when absent,
+    AIPS's 'DEGREES' accepted); BPA is taken as degrees, as the reference does."""
+    for h in scan_hdus(path):
+        hdr = h.header
+        if str(hdr.get("XTENSION", "")).strip() != "BINTABLE" or str(hdr.get("EXTNAME", "")).strip() != "BEAMS":
+            continue
+        nrow, rowlen, nf = int(hdr["NAXIS2"]), int(hdr["NAXIS1"]), int(hdr["TFIELDS"])
+        fields, units = [], {}
+        for i in range(1, nf + 1):
+            form = str(hdr["TFORM%d" % i]).strip()
+            rep, code = (int(form[:-1]) if form[:-1] else 1), form[-1]
+            if code not in _TFORM or rep != 1:
+                raise FITSReadError("unsupported BEAMS column format %r" % form)
+            name = str(hdr.get("TTYPE%d" % i, "COL%d" % i)).strip()
+            fields.append((name, _TFORM[code]))
+            units[name] = str(hdr.get("TUNIT%d" % i, "arcsec")).strip()
+        dt = np.dtype(fields)
+        if dt.itemsize != rowlen:
+            raise FITSReadError("BEAMS table row length %d does not match its columns (%d)" % (rowlen, dt.itemsize))
+        with open(path, "rb") as f:
+            f.seek(h.data_offset)
+            rec = np.frombuffer(f.read(nrow * rowlen), dtype=dt, count=nrow)
+        out = {}
+        for name in dt.names:
+            col = rec[name]
+            if name in ("BMAJ", "BMIN"):
+                u = units[name].lower()
+                if u not in _UNIT_DEG:
+                    raise FITSReadError("unsupported beam unit %r" % units[name])
+                out[name] = col.astype(np.float64) * _UNIT_DEG[u]
+            elif name == "BPA":
+                out[name] = col.astype(np.float64)
+            else:
+                out[name] = col.astype(np.int64)
+        for need in ("BMAJ", "BMIN", "BPA"):
+            if need not in out:
+                raise FITSReadError("BEAMS table lacks a %s column" % need)
+        return out
+    return None
+
+
+def append_beams_table(path, bmaj_deg, bmin_deg, bpa_deg):
+    """Append a ``BEAMS`` BINTABLE HDU (arcsec / arcsec / deg, float32, + CHAN, POL int32) to an
+    existing FITS file: what beams_to_bintable / VaryingResolutionSpectralCube.hdulist produce
+    (dask_spectral_cube.py:1493-1509)."""
+    n = len(bmaj_deg)
+    rec = np.zeros(n, dtype=[("BMAJ", ">f4"), ("BMIN", ">f4"), ("BPA", ">f4"), ("CHAN", ">i4"), ("POL", ">i4")])
+    rec["BMAJ"] = np.asarray(bmaj_deg, dtype=np.float64) * 3600.0
+    rec["BMIN"] = np.asarray(bmin_deg, dtype=np.float64) * 3600.0
+    rec["BPA"] = bpa_deg
+    rec["CHAN"] = np.arange(n)
+    cards = [_card("XTENSION", "BINTABLE"), _card("BITPIX", 8), _card("NAXIS", 2), _card("NAXIS1", rec.dtype.itemsize),
+             _card("NAXIS2", n), _card("PCOUNT", 0), _card("GCOUNT", 1), _card("TFIELDS", 5)]
+    for i, (name, form, unit) in enumerate((("BMAJ", "1E", "arcsec"), ("BMIN", "1E", "arcsec"), ("BPA", "1E", "deg"),
+                                            ("CHAN", "1J", None), ("POL", "1J", None)), 1):
+        cards += [_card("TTYPE%d" % i, name), _card("TFORM%d" % i, form)]
+        if unit:
+            cards.append(_card("TUNIT%d" % i, unit))
+    cards += [_card("EXTNAME", "BEAMS"), _card("EXTVER", 1), _card("NCHAN", n), _card("NPOL", 1), "END".ljust(80)]
+    text = "".join(cards)
+    text += " " * ((-len(text)) % BLOCK)
+    payload = rec.tobytes()
+    with open(path, "ab") as f:
+        if f.tell() % BLOCK:
+            raise FITSReadError("%s is not padded to a FITS block" % path)
+        f.write(text.encode("ascii"))
+        f.write(payload)
+        f.write(b"\0" * ((-len(payload)) % BLOCK))

@@ -43,6 +43,11 @@ class MaskSpec:
         return MaskSpec(self.flags, self.thr_lo, self.thr_hi,
                         self.array.rows(y0, y1) if self.array is not None else None)
 
+    def planes(self, z0, z1):
+        """the same mask restricted to channels [z0, z1)"""
+        return MaskSpec(self.flags, self.thr_lo, self.thr_hi,
+                        self.array.planes(z0, z1) if self.array is not None else None)
+
 
 def _cube_c(cube):
     if cube.dtype != np.float32 or len(cube.shape) != 3:

@@ -582,3 +582,61 @@ def test_convolve_to(gpu):
         assert any("identical to the current beam" in str(x.message) for x in wlist)
     with pytest.raises(BeamError):
         cube.convolve_to(Beam(5 * pix, 3 * pix, 0.0))
+
+
+def test_varying_resolution_convolve_to(gpu, tmp_path):
+    """VaryingResolutionSpectralCube.convolve_to (dask_spectral_cube.py:1511-1630; written like
+    spectral_cube/tests/test_regrid.py:59-96): a FITS cube with a BEAMS table becomes a
+    varying-resolution cube; every channel is convolved with its own deconvolved kernel and scaled
+    by the beam-area ratio (Jy/beam), the channel whose beam equals the target and the channel with a
+    non-finite beam pass through as filled data.  Expected values: astropy.convolution.convolve per
+    channel (tests/golden/beams_cube.npz)."""
+    from spectral_cube_amd import VaryingResolutionSpectralCube, Beam, BeamError, io_fits
+    g = golden("beams_cube.npz")
+    p = tmp_path / "beams.fits"
+    p.write_bytes(g["file_arcsec"].tobytes())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cube = SpectralCube.read(str(p))
+    assert isinstance(cube, VaryingResolutionSpectralCube) and cube.shape == (6, 24, 20)
+    assert list(cube.goodbeams_mask) == [True, True, True, True, False, True]
+    tgt = Beam(*g["target"])
+    out = cube.convolve_to(tgt)
+    assert type(out) is SpectralCube and out.beam == tgt
+    res, exp = out._device_data().get(), g["expected"]
+    assert np.array_equal(np.isnan(res), np.isnan(exp))
+    assert_close(res, exp, atol=2e-5 * np.nanmax(np.abs(exp)), what="per-channel convolve_to vs astropy")
+    np.testing.assert_array_equal(res[3], g["data"][3])                     # beam == target: untouched
+    assert np.isnan(res[4]).all()                                           # masked-out layer
+    # a target smaller than some channel's beam: error unless allow_smaller, then that channel passes through
+    small = Beam(3.2 / 3600, 3.2 / 3600, 0.0)
+    with pytest.raises((BeamError, ValueError)):
+        cube.convolve_to(small)
+    res2 = cube.convolve_to(small, allow_smaller=True)._device_data().get()
+    np.testing.assert_array_equal(res2[3], g["data"][3])                     # 5 x 4.5 px beam cannot reach 3.2 px
+    assert not np.array_equal(res2[5], g["data"][5])                         # 2.5 px beam can
+    # write -> read keeps the beams
+    q = tmp_path / "copy.fits"
+    cube.write(str(q))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        again = SpectralCube.read(str(q))
+    assert isinstance(again, VaryingResolutionSpectralCube)
+    np.testing.assert_allclose([b.major for b in again.unmasked_beams], [b.major for b in cube.unmasked_beams],
+                               rtol=1e-6, equal_nan=True)
+    # the reference's own delta-cube case (test_regrid.py:59-79): every plane is the normalised kernel
+    d = np.zeros((4, 5, 5), np.float32)
+    d[:, 2, 2] = 1.0
+    pix = 5.555555555555e-4
+    hdr = {"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "CTYPE3": "VRAD", "CDELT1": -pix, "CDELT2": pix,
+           "CDELT3": 1.0, "CRPIX1": 1.0, "CRPIX2": 1.0, "CRPIX3": 1.0, "CRVAL1": 0.0, "CRVAL2": 0.0,
+           "CRVAL3": 0.0, "BUNIT": "K"}
+    beams = [Beam(a / 3600, b / 3600, pa) for a, b, pa in zip((0.4, 0.3, 0.3, 0.4), (0.1, 0.2, 0.2, 0.1), (0, 45, 60, 30))]
+    vr = VaryingResolutionSpectralCube(d, header=hdr, beams=beams)
+    target = Beam(1.802775637731995 / 3600, 1.802775637731995 / 3600, 0.0)
+    conv = vr.convolve_to(target)._device_data().get()
+    for ii, bm in enumerate(beams):
+        k = target.deconvolve(bm).as_kernel(pix)
+        h = k.shape[0] // 2
+        k5 = k[h - 2:h + 3, h - 2:h + 3] if h >= 2 else np.pad(k, 2 - h)
+        np.testing.assert_allclose(conv[ii], k5 / k.sum(), atol=1e-6)
