@@ -91,8 +91,16 @@ typedef struct {
 } spc_device_info;
 int spc_get_device_info(int device, spc_device_info* info);
 
+/* Device buffers.  spc_free keeps the block in a per-device pool (after draining the device, as
+ * hipFree does) and spc_malloc hands idle blocks of nearly the requested size out again: cube-sized
+ * hipMalloc calls intermittently take seconds on this stack.  The pool is bounded
+ * (SPC_POOL_MAX_BYTES, default half of the device memory; SPC_POOL=0 disables it), is emptied when
+ * a real allocation runs out of memory, and by spc_pool_trim.  spc_free also accepts pointers that
+ * came from a plain hipMalloc. */
 int spc_malloc(int device, size_t bytes, void** d_ptr);
 int spc_free(int device, void* d_ptr);
+int spc_pool_trim(int device);
+int spc_pool_stats(int device, int64_t* live_bytes, int64_t* idle_bytes);
 int spc_host_alloc(size_t bytes, void** h_ptr);       /* pinned */
 int spc_host_free(void* h_ptr);
 int spc_memcpy_h2d(int device, void* d_dst, const void* h_src, size_t bytes, void* stream);

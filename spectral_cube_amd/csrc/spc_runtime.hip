@@ -1,7 +1,51 @@
 // Device management, staging copies, streams and events behind the C ABI.
 #include "spc_common.h"
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 static thread_local char g_err[512] = "";
+
+// ---- device buffer pool behind spc_malloc / spc_free ------------------------------------------
+// Cube-sized hipMalloc calls are the slowest thing a pipeline of operators meets on this stack:
+// usually ~0.2 ms, but every few calls of >= 4 GiB one takes 0.7 - 3.8 s (measured, MI355X /
+// ROCm 7.2: tests/bench_alloc.py), two orders of magnitude more than the kernel that fills the
+// buffer.  Freed blocks are therefore kept per device and handed out again for requests of
+// (nearly) the same size - operator pipelines allocate the same few cube / map sizes over and
+// over.  Semantics stay those of hipMalloc / hipFree: spc_free drains the device before the
+// block becomes reusable (hipFree does the same), so no stream ordering is assumed.  The cache
+// is bounded (SPC_POOL_MAX_BYTES, default half of the device memory; SPC_POOL=0 turns it off),
+// gives everything back when a real hipMalloc runs out of memory, and on spc_pool_trim().
+namespace {
+constexpr int kMaxDevices = 16;
+struct DevicePool {
+    std::mutex mu;
+    std::multimap<size_t, void*> idle;              // size -> block, ready for reuse
+    std::unordered_map<void*, size_t> size_of;      // every block this pool handed out or holds
+    size_t idle_bytes = 0, live_bytes = 0, cap = 0;
+    bool cap_known = false;
+};
+DevicePool g_pool[kMaxDevices];
+
+bool pool_enabled() {
+    static const bool on = [] { const char* e = getenv("SPC_POOL"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+size_t pool_round(size_t bytes) {
+    const size_t q = bytes >= (1u << 20) ? (size_t)2 << 20 : 512;     // 2 MiB pages for anything large
+    return (bytes + q - 1) / q * q;
+}
+// callers hold the lock and have the device set
+void pool_release_idle(DevicePool& P, size_t keep_bytes) {
+    while (P.idle_bytes > keep_bytes && !P.idle.empty()) {
+        auto it = std::prev(P.idle.end());                            // largest first
+        (void)hipFree(it->second);
+        P.size_of.erase(it->second);
+        P.idle_bytes -= it->first;
+        P.idle.erase(it);
+    }
+}
+}  // namespace
 
 void spc_set_error(const char* fmt, ...) {
     va_list ap;
@@ -39,6 +83,10 @@ int spc_get_device_info(int device, spc_device_info* info) {
     SPC_HIP(hipMemGetInfo(&fr, &tot));
     info->total_mem = (int64_t)tot;
     info->free_mem = (int64_t)fr;
+    if (device >= 0 && device < kMaxDevices) {      // idle pool blocks are available to spc_malloc
+        std::lock_guard<std::mutex> lk(g_pool[device].mu);
+        info->free_mem += (int64_t)g_pool[device].idle_bytes;
+    }
     return SPC_OK;
 }
 
@@ -47,20 +95,96 @@ int spc_malloc(int device, size_t bytes, void** d_ptr) {
     SPC_DEVICE(device);
     *d_ptr = nullptr;
     if (bytes == 0) return SPC_OK;
-    hipError_t e = hipMalloc(d_ptr, bytes);
+    const bool pooled = pool_enabled() && device >= 0 && device < kMaxDevices;
+    if (!pooled) {
+        hipError_t e = hipMalloc(d_ptr, bytes);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            spc_set_error("hipMalloc(%zu bytes) out of memory on device %d", bytes, device);
+            return SPC_ERR_NOMEM;
+        }
+        SPC_HIP(e);
+        return SPC_OK;
+    }
+    DevicePool& P = g_pool[device];
+    const size_t want = pool_round(bytes);
+    std::lock_guard<std::mutex> lk(P.mu);
+    auto it = P.idle.lower_bound(want);
+    if (it != P.idle.end() && it->first <= want + want / 8) {          // at most 12.5 % larger than asked
+        *d_ptr = it->second;
+        P.idle_bytes -= it->first;
+        P.live_bytes += it->first;
+        P.idle.erase(it);
+        return SPC_OK;
+    }
+    hipError_t e = hipMalloc(d_ptr, want);
+    if (e == hipErrorOutOfMemory && !P.idle.empty()) {                // give the cache back and try again
+        (void)hipGetLastError();
+        pool_release_idle(P, 0);
+        e = hipMalloc(d_ptr, want);
+    }
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
+        *d_ptr = nullptr;
         spc_set_error("hipMalloc(%zu bytes) out of memory on device %d", bytes, device);
         return SPC_ERR_NOMEM;
     }
     SPC_HIP(e);
+    P.size_of[*d_ptr] = want;
+    P.live_bytes += want;
     return SPC_OK;
 }
 
 int spc_free(int device, void* d_ptr) {
     if (!d_ptr) return SPC_OK;
     SPC_DEVICE(device);
-    SPC_HIP(hipFree(d_ptr));
+    if (pool_enabled() && device >= 0 && device < kMaxDevices) {
+        DevicePool& P = g_pool[device];
+        std::unique_lock<std::mutex> lk(P.mu);
+        auto it = P.size_of.find(d_ptr);
+        if (it != P.size_of.end()) {
+            const size_t sz = it->second;
+            if (!P.cap_known) {
+                size_t fr = 0, tot = 0;
+                const char* e = getenv("SPC_POOL_MAX_BYTES");
+                if (e) P.cap = (size_t)strtoull(e, nullptr, 10);
+                else if (hipMemGetInfo(&fr, &tot) == hipSuccess) P.cap = tot / 2;
+                P.cap_known = true;
+            }
+            lk.unlock();
+            SPC_HIP(hipDeviceSynchronize());        // what hipFree guarantees: nothing queued still uses the block
+            lk.lock();
+            P.live_bytes -= sz;
+            if (sz > P.cap) {
+                P.size_of.erase(d_ptr);
+                SPC_HIP(hipFree(d_ptr));
+                return SPC_OK;
+            }
+            P.idle.emplace(sz, d_ptr);
+            P.idle_bytes += sz;
+            pool_release_idle(P, P.cap);            // over the bound: the largest idle blocks go back to the driver
+            return SPC_OK;
+        }
+    }
+    SPC_HIP(hipFree(d_ptr));                        // not one of ours (any hipMalloc'd pointer is accepted)
+    return SPC_OK;
+}
+
+int spc_pool_trim(int device) {
+    SPC_REQUIRE(device >= 0 && device < kMaxDevices, "device index out of range");
+    SPC_DEVICE(device);
+    DevicePool& P = g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    pool_release_idle(P, 0);
+    return SPC_OK;
+}
+
+int spc_pool_stats(int device, int64_t* live_bytes, int64_t* idle_bytes) {
+    SPC_REQUIRE(device >= 0 && device < kMaxDevices, "device index out of range");
+    DevicePool& P = g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (live_bytes) *live_bytes = (int64_t)P.live_bytes;
+    if (idle_bytes) *idle_bytes = (int64_t)P.idle_bytes;
     return SPC_OK;
 }
 

@@ -65,6 +65,18 @@ def synchronize(device=0):
     _lib.call("spc_device_sync", device)
 
 
+def pool_stats(device=0):
+    """(live_bytes, idle_bytes) of the library's device buffer pool (spc_pool_stats)."""
+    live, idle = C.c_int64(0), C.c_int64(0)
+    _lib.call("spc_pool_stats", device, C.byref(live), C.byref(idle))
+    return live.value, idle.value
+
+
+def pool_trim(device=0):
+    """hand every idle pooled block back to the driver (spc_pool_trim)"""
+    _lib.call("spc_pool_trim", device)
+
+
 class DeviceArray:
     """C-contiguous n-d array resident in HBM."""
 

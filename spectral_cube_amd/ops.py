@@ -269,7 +269,7 @@ def spectral_lerp(cube, lo, t, inv_dx, fill=np.nan, mask=None, out=None, stream=
     return out
 
 
-def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_footprint=True):
+def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_footprint=True, out=None):
     """bilinear spatial resample of every channel at (xs, ys) source pixel
     coordinates (resampler of reproject_interp, spectral_cube.py:2726-2732)."""
     dev = cube.device
@@ -279,7 +279,10 @@ def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_fo
         raise ValueError("xs, ys must be 2-D maps of identical shape")
     ny_out, nx_out = xs.shape
     d_xs, d_ys = DeviceArray.from_numpy(xs, dev), DeviceArray.from_numpy(ys, dev)
-    out = DeviceArray((cube.shape[0], ny_out, nx_out), np.float32, dev)
+    if out is None:
+        out = DeviceArray((cube.shape[0], ny_out, nx_out), np.float32, dev)
+    elif out.shape != (cube.shape[0], ny_out, nx_out) or out.dtype != np.float32 or getattr(out, "_is_view", False):
+        raise ValueError("out must be a contiguous float32 (nz, ny_out, nx_out) DeviceArray")
     foot = DeviceArray((ny_out, nx_out), np.uint8, dev) if want_footprint else None
     c, m = _cube_c(cube), _mask_c(mask, cube)
     _lib.call("spc_resample_bilinear_f32", dev, _sh(stream), C.byref(c), C.byref(m), float(fill),

@@ -564,3 +564,63 @@ def test_spatial_conv_very_wide_separable(gpu, nk):
         fin = np.isfinite(exp)
         assert np.array_equal(np.isnan(got), np.isnan(exp))
         assert np.max(np.abs(got[fin] - exp[fin])) <= 2e-5 * np.max(np.abs(exp[fin]))
+
+
+def test_device_buffer_pool(gpu):
+    """spc_malloc / spc_free pool (include/spcube_hip.h): a freed block is handed out again for a
+    request of the same size, its content is whatever the new owner writes (no stale reads through
+    the ops), idle bytes are reported and count as free memory, trim gives them back, and a
+    subprocess with SPC_POOL=0 / a tiny SPC_POOL_MAX_BYTES still computes the same moments."""
+    import subprocess, sys, os
+    from spectral_cube_amd import ops
+    from spectral_cube_amd.device import DeviceArray, pool_stats, pool_trim, device_info
+    pool_trim(0)
+    live0, idle0 = pool_stats(0)
+    assert idle0 == 0
+    a = DeviceArray((3 << 20,), np.uint8)
+    p = a.ptr
+    live1, _ = pool_stats(0)
+    assert live1 - live0 >= 3 << 20
+    a.free()
+    assert pool_stats(0) == (live0, live1 - live0)
+    free_with_idle = device_info(0)["free_mem"]
+    b = DeviceArray((3 << 20,), np.uint8)           # same size: the same block comes back
+    assert b.ptr == p and pool_stats(0)[1] == 0
+    c = DeviceArray((3 << 20,), np.uint8)           # pool empty: a new block
+    assert c.ptr != p
+    b.free(); c.free()
+    assert pool_stats(0)[1] == 2 * (live1 - live0)
+    big = DeviceArray((64 << 20,), np.uint8)        # no idle block is within 12.5 %: fresh allocation
+    assert big.ptr not in (p, c.ptr)
+    big.free()
+    pool_trim(0)
+    assert pool_stats(0) == (live0, 0)
+    assert device_info(0)["free_mem"] >= free_with_idle - (8 << 20)
+    # reuse through the ops: results do not depend on what the recycled buffers held before
+    rng = np.random.default_rng(5)
+    d = rng.standard_normal((40, 24, 32)).astype(np.float32)
+    cen = (np.arange(40) - 20) * 1.0
+    ref = None
+    for it in range(4):
+        junk = DeviceArray.from_numpy(np.full((24, 32), np.nan))           # float64 map-sized junk, then freed
+        junk.free()
+        cube = DeviceArray.from_numpy(d)
+        r = ops.moments(cube, DeviceArray.from_numpy(cen), want=("m0", "m1", "m2"))
+        got = {k: r[k].get() for k in ("m0", "m1", "m2")}
+        if ref is None:
+            ref = got
+        for k in got:
+            np.testing.assert_array_equal(got[k], ref[k])
+    code = ("import numpy as np, sys; sys.path.insert(0, %r);"
+            "from spectral_cube_amd import ops; from spectral_cube_amd.device import DeviceArray, pool_stats;"
+            "d = np.random.default_rng(5).standard_normal((40, 24, 32)).astype(np.float32);"
+            "r = [ops.moments(DeviceArray.from_numpy(d), DeviceArray.from_numpy((np.arange(40) - 20) * 1.0), want=('m0',))['m0'].get() for _ in range(3)];"
+            "assert all(np.array_equal(r[0], x) for x in r); print(repr(float(r[0].sum())), pool_stats(0)[1])"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for env in ({"SPC_POOL": "0"}, {"SPC_POOL_MAX_BYTES": "4096"}, {}):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(res.stdout.split())
+    assert outs[0][0] == outs[1][0] == outs[2][0] == repr(float(ref["m0"].sum()))
+    assert outs[0][1] == "0" and int(outs[1][1]) <= 4096
