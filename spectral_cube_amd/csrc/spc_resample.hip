@@ -63,7 +63,13 @@ __device__ __forceinline__ typename LV<VEC>::F load_filled_v(const float* p, con
     return v;
 }
 
-template <int VEC>
+// Each lane owns VEC adjacent spaxels and marches along the output channels in groups of U: the
+// bracketing input planes of a whole group are requested first (lo[] is wave-uniform, so which planes
+// those are is scalar control flow), then the group is interpolated and stored.  U = 1 is what is
+// launched: at C5 (2048 -> 4096 channels, two thirds of the traffic are stores) it runs at 5.07 TB/s,
+// U = 4 at 4.84 and U = 8 at 3.80 - eight waves per SIMD already cover the load latency, and deeper
+// groups only make the store stream burstier and cost occupancy.
+template <int VEC, int U>
 __global__ __launch_bounds__(256) void spectral_lerp_kernel(const LerpArgs A) {
     using F = typename LV<VEC>::F;
     const int64_t gpr = A.nx / VEC;
@@ -77,28 +83,40 @@ __global__ __launch_bounds__(256) void spectral_lerp_kernel(const LerpArgs A) {
     const int64_t je = min(A.nz_out, jb + A.jchunk);
     int cur = -2;
     F ylo{}, yhi{};
-    for (int64_t j = jb; j < je; ++j) {
-        const int lo = A.lo[j];          // wave-uniform
-        F res;
-        if (lo < 0) {
+    for (int64_t j0 = jb; j0 < je; j0 += U) {
+        int los[U];
+        F a[U], b[U];
 #pragma unroll
-            for (int i = 0; i < VEC; ++i) lset(res, i, A.fill);
-        } else {
-            if (lo != cur) {
+        for (int u = 0; u < U; ++u) {
+            const int lo = A.lo[min(j0 + u, je - 1)];          // wave-uniform
+            los[u] = lo;
+            if (lo >= 0 && lo != cur) {
                 if (lo == cur + 1) ylo = yhi;
                 else ylo = load_filled_v<VEC>(p, pm, A.mask, (int64_t)lo * A.plane_stride, (int64_t)lo * A.mask.plane_stride);
                 yhi = load_filled_v<VEC>(p, pm, A.mask, (int64_t)(lo + 1) * A.plane_stride, (int64_t)(lo + 1) * A.mask.plane_stride);
                 cur = lo;
             }
-            // scipy: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x_new - x_lo) + y_lo
-            const double wj = A.inv_dx[j] * A.t[j];
-#pragma unroll
-            for (int i = 0; i < VEC; ++i) {
-                const float diff = lget(yhi, i) - lget(ylo, i);       // float32 like numpy's f32 - f32
-                lset(res, i, (float)((double)diff * wj + (double)lget(ylo, i)));
-            }
+            a[u] = ylo; b[u] = yhi;
         }
-        __builtin_nontemporal_store(res, reinterpret_cast<F*>(po + j * A.out_plane_stride));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + u;
+            if (j >= je) break;
+            F res;
+            if (los[u] < 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) lset(res, i, A.fill);
+            } else {
+                // scipy: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x_new - x_lo) + y_lo
+                const double wj = A.inv_dx[j] * A.t[j];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float diff = lget(b[u], i) - lget(a[u], i);       // float32 like numpy's f32 - f32
+                    lset(res, i, (float)((double)diff * wj + (double)lget(a[u], i)));
+                }
+            }
+            __builtin_nontemporal_store(res, reinterpret_cast<F*>(po + j * A.out_plane_stride));
+        }
     }
 }
 
@@ -402,8 +420,8 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube, co
     A.jchunk = (nz_out + nsplit - 1) / nsplit;
     nsplit = (int)((nz_out + A.jchunk - 1) / A.jchunk);
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
-    if (v4) hipLaunchKernelGGL(spectral_lerp_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, A);
-    else hipLaunchKernelGGL(spectral_lerp_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    if (v4) hipLaunchKernelGGL((spectral_lerp_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL((spectral_lerp_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
