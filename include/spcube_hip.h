@@ -209,7 +209,9 @@ int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube,
  * (ny,nx) float32 map) the statistic is taken of |x - center|, and the result is
  * multiplied by scale: median absolute deviation -> mad_std (:711-731, astropy
  * stats.mad_std: scale = 1.482602218505602).  Rays without a valid sample give
- * NaN.  d_out: (ny,nx) float32, C-contiguous. */
+ * NaN.  d_out: (ny,nx) float32, C-contiguous.  * The rays run along the FIRST axis of the view that is passed in: for a selection along y
+ * of a (nz, ny, nx) cube hand over the same buffer as {nz' = ny, ny' = nz, row_stride' =
+ * plane_stride, plane_stride' = row_stride} (mask strides likewise); the result is (nz, nx). */
 int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,
                              const spc_mask* mask, double q, const float* d_center,
                              float scale, float* d_out);

@@ -110,6 +110,18 @@ static inline int spc_check_cube(const spc_cube_f32* c) {
     return SPC_OK;
 }
 
+// for kernels that only ever form z * plane_stride + y * row_stride + x: also accepts a view whose
+// first two axes are exchanged (row_stride > plane_stride), e.g. selection along y instead of z
+static inline int spc_check_cube_any_order(const spc_cube_f32* c) {
+    SPC_REQUIRE(c != nullptr && c->d_data != nullptr, "cube pointer is NULL");
+    SPC_REQUIRE(c->nz > 0 && c->ny > 0 && c->nx > 0, "cube shape must be positive (got %lld,%lld,%lld)",
+                (long long)c->nz, (long long)c->ny, (long long)c->nx);
+    SPC_REQUIRE(c->row_stride >= c->nx && c->plane_stride >= c->nx, "row / plane stride smaller than nx");
+    SPC_REQUIRE(c->plane_stride >= c->row_stride * (c->ny - 1) + c->nx ||
+                c->row_stride >= c->plane_stride * (c->nz - 1) + c->nx, "overlapping rows and planes");
+    return SPC_OK;
+}
+
 // predicate part of the mask (array part is handled by the caller's loads)
 __device__ __forceinline__ bool spc_pred(uint32_t flags, float thr_lo, float thr_hi, float v) {
     bool inc = true;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
 
 extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                                         double q, const float* d_center, float scale, float* d_out) {
-    int rc = spc_check_cube(cube);
+    int rc = spc_check_cube_any_order(cube);
     if (rc) return rc;
     SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
     SPC_REQUIRE(q >= 0.0 && q <= 100.0, "Percentiles must be in the range [0, 100]");

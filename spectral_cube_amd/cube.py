@@ -543,32 +543,34 @@ class SpectralCube:
         return self._reduce("min", axis)
 
     def _order_stat(self, q, axis, what, center=None, scale=1.0):
+        if axis == 1:            # rays along y: the same kernels on a view with the first two axes exchanged
+            return ops.percentile_axis0(self._device_data().swap01(), q, mask=self._mask_spec().swap01(),
+                                        center=center, scale=scale)
         if axis != 0:
-            raise NotImplementedError("%s is built along the spectral axis (axis=0) only; the reference itself "
-                                      "falls back to loading the whole cube for axis=None" % what)
-        out = ops.percentile_axis0(self._device_data(), q, mask=self._mask_spec(), center=center, scale=scale)
-        if center is not None:
-            return out
-        return out
+            raise NotImplementedError("%s is built along the spectral axis (axis=0) and along y (axis=1); the "
+                                      "reference itself falls back to loading the whole cube for axis=None" % what)
+        return ops.percentile_axis0(self._device_data(), q, mask=self._mask_spec(), center=center, scale=scale)
+
+    def _order_wcs(self, axis):
+        return self._wcs.drop_spectral() if (axis == 0 and self._wcs is not None) else None
 
     def median(self, axis=None, **kwargs):
         """nanmedian along the spectral axis (dask_spectral_cube.py:657-671): bit descent on
         order-preserving keys, no sort (csrc/spc_select.hip)."""
         return Projection(self._order_stat(50.0, axis, "median").get(), unit=self._unit,
-                          wcs=self._wcs.drop_spectral() if self._wcs is not None else None, meta=dict(self._meta))
+                          wcs=self._order_wcs(axis), meta=dict(self._meta))
 
     def percentile(self, q, axis=None, **kwargs):
         """np.nanpercentile along the spectral axis (dask_spectral_cube.py:673-693)."""
         return Projection(self._order_stat(float(q), axis, "percentile").get(), unit=self._unit,
-                          wcs=self._wcs.drop_spectral() if self._wcs is not None else None, meta=dict(self._meta))
+                          wcs=self._order_wcs(axis), meta=dict(self._meta))
 
     def mad_std(self, axis=None, ignore_nan=True, **kwargs):
         """astropy mad_std along the spectral axis (dask_spectral_cube.py:711-731): two selections
         (median, then median of |x - median|) without leaving the device."""
         med = self._order_stat(50.0, axis, "mad_std")
         out = self._order_stat(50.0, axis, "mad_std", center=med, scale=ops.MAD_TO_STD)
-        return Projection(out.get(), unit=self._unit,
-                          wcs=self._wcs.drop_spectral() if self._wcs is not None else None, meta=dict(self._meta))
+        return Projection(out.get(), unit=self._unit, wcs=self._order_wcs(axis), meta=dict(self._meta))
 
     def sigma_clip_spectrally(self, threshold, **kwargs):
         """astropy's sigma clipper along the spectral axis, clipped (and excluded) values -> NaN

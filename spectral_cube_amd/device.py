@@ -160,6 +160,20 @@ class DeviceArray:
             v._is_view = True
         return v
 
+    def swap01(self):
+        """(ny, nz, nx) view of a (nz, ny, nx) array with the first two axes exchanged (no copy):
+        row_stride and plane_stride trade places.  For the kernels that accept such a view
+        (spc_percentile_axis0_f32: selection along y)."""
+        if len(self.shape) != 3:
+            raise ValueError("swap01() needs a (nz, ny, nx) array")
+        nz, ny, nx = self.shape
+        v = DeviceArray((ny, nz, nx), self.dtype, self.device, ptr=self.ptr, owner=self)
+        v.row_stride = getattr(self, "plane_stride", ny * nx)
+        v.plane_stride = getattr(self, "row_stride", nx)
+        v.nbytes = 0
+        v._is_view = True
+        return v
+
     def reshape(self, shape):
         shape = tuple(int(s) for s in shape)
         if int(np.prod(shape, dtype=np.int64)) * self.dtype.itemsize != self.nbytes:

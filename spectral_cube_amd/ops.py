@@ -43,6 +43,10 @@ class MaskSpec:
         return MaskSpec(self.flags, self.thr_lo, self.thr_hi,
                         self.array.rows(y0, y1) if self.array is not None else None)
 
+    def swap01(self):
+        """the same mask for DeviceArray.swap01() views"""
+        return MaskSpec(self.flags, self.thr_lo, self.thr_hi, self.array.swap01() if self.array is not None else None)
+
     def planes(self, z0, z1):
         """the same mask restricted to channels [z0, z1)"""
         return MaskSpec(self.flags, self.thr_lo, self.thr_hi,
@@ -351,7 +355,8 @@ MAD_TO_STD = 1.482602218505602          # 1 / Phi^-1(3/4), astropy.stats.mad_std
 def percentile_axis0(cube, q, mask=None, center=None, scale=1.0, stream=None, out=None):
     """q-th percentile along the spectral axis per spaxel (median: q = 50), numpy 'linear'
     interpolation, NaN / masked samples ignored (dask_spectral_cube.py:657-693); with *center*
-    (a (ny, nx) float32 DeviceArray) of |x - center| times *scale* (mad_std, :711-731)."""
+    (a (ny, nx) float32 DeviceArray) of |x - center| times *scale* (mad_std, :711-731).
+    Selection along y: pass ``cube.swap01()`` (and ``mask.swap01()``); the result is (nz, nx)."""
     if out is None:
         out = DeviceArray(cube.shape[1:], np.float32, cube.device)
     c, m = _cube_c(cube), _mask_c(mask, cube)

@@ -471,7 +471,31 @@ def test_median_percentile_mad_std(gpu):
         assert_close(got, g["p%g" % q], atol=2e-6 * np.nanmax(np.abs(g["p%g" % q])), what="percentile %g" % q)
     assert_close(np.asarray(cube.mad_std(axis=0)), g["mad_std"], atol=2e-6 * np.nanmax(np.abs(g["mad_std"])), what="mad_std")
     with pytest.raises(NotImplementedError):
-        cube.median(axis=1)
+        cube.median(axis=2)
+    # along y (axis=1): the same kernels on a view with the first two axes exchanged - must equal the
+    # axis-0 result of the transposed cube bit for bit, and numpy's nanmedian / nanpercentile
+    filled = np.where(inc, d, np.nan).astype(np.float32)
+    swapped = SpectralCube.read(np.ascontiguousarray(d.swapaxes(0, 1)), hdr).with_mask(np.ascontiguousarray(inc.swapaxes(0, 1)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        e1 = np.nanmedian(filled, axis=1)
+        e1p = np.nanpercentile(filled.astype(np.float64), 37.5, axis=1)
+    for fn in (lambda c, ax: c.median(axis=ax), lambda c, ax: c.percentile(37.5, axis=ax), lambda c, ax: c.mad_std(axis=ax)):
+        a1, a0 = np.asarray(fn(cube, 1)), np.asarray(fn(swapped, 0))
+        assert a1.shape == (d.shape[0], d.shape[2])
+        assert np.array_equal(np.isnan(a1), np.isnan(a0)) and np.array_equal(a1[~np.isnan(a0)], a0[~np.isnan(a0)])
+    m1 = np.asarray(cube.median(axis=1))
+    assert np.array_equal(np.isnan(m1), np.isnan(e1)) and np.array_equal(m1[~np.isnan(e1)], e1[~np.isnan(e1)])
+    p1 = np.asarray(cube.percentile(37.5, axis=1))
+    fin = np.isfinite(e1p)
+    assert np.array_equal(np.isnan(p1), np.isnan(e1p)) and np.allclose(p1[fin], e1p[fin], rtol=2e-6, atol=2e-6 * np.nanmax(np.abs(e1p)))
+    odd = np.random.default_rng(8).standard_normal((9, 57, 13)).astype(np.float32)       # odd nx -> scalar kernel
+    odd[np.random.default_rng(9).random(odd.shape) < 0.2] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        eo = np.nanmedian(odd, axis=1)
+    go = np.asarray(SpectralCube.read(odd, hdr).median(axis=1))
+    assert np.array_equal(np.isnan(go), np.isnan(eo)) and np.array_equal(go[~np.isnan(eo)], eo[~np.isnan(eo)])
     rng = np.random.default_rng(4)
     big = rng.standard_normal((301, 7, 13)).astype(np.float32)          # odd nx -> scalar kernel
     big[rng.random(big.shape) < 0.1] = np.nan
