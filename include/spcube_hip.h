@@ -96,7 +96,8 @@ int spc_get_device_info(int device, spc_device_info* info);
  * hipMalloc calls intermittently take seconds on this stack.  The pool is bounded
  * (SPC_POOL_MAX_BYTES, default half of the device memory; SPC_POOL=0 disables it), is emptied when
  * a real allocation runs out of memory, and by spc_pool_trim.  spc_free also accepts pointers that
- * came from a plain hipMalloc. */
+ * came from a plain hipMalloc.  Buffers are NOT zeroed (hipMalloc does not promise it either);
+ * SPC_POOL_POISON=1 fills every returned block with 0xFF bytes to catch code that assumes so. */
 int spc_malloc(int device, size_t bytes, void** d_ptr);
 int spc_free(int device, void* d_ptr);
 int spc_pool_trim(int device);

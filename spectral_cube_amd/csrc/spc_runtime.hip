@@ -31,6 +31,12 @@ bool pool_enabled() {
     static const bool on = [] { const char* e = getenv("SPC_POOL"); return !(e && atoi(e) == 0); }();
     return on;
 }
+// SPC_POOL_POISON=1 (debugging): every block spc_malloc returns is filled with 0xFF bytes (NaN as float /
+// double, -1 as integer), so that an operator relying on zeroed fresh memory fails the test-suite at once
+bool pool_poison() {
+    static const bool on = [] { const char* e = getenv("SPC_POOL_POISON"); return e && atoi(e) != 0; }();
+    return on;
+}
 size_t pool_round(size_t bytes) {
     const size_t q = bytes >= (1u << 20) ? (size_t)2 << 20 : 512;     // 2 MiB pages for anything large
     return (bytes + q - 1) / q * q;
@@ -115,6 +121,7 @@ int spc_malloc(int device, size_t bytes, void** d_ptr) {
         P.idle_bytes -= it->first;
         P.live_bytes += it->first;
         P.idle.erase(it);
+        if (pool_poison()) { SPC_HIP(hipMemset(*d_ptr, 0xFF, bytes)); SPC_HIP(hipDeviceSynchronize()); }
         return SPC_OK;
     }
     hipError_t e = hipMalloc(d_ptr, want);
@@ -132,6 +139,7 @@ int spc_malloc(int device, size_t bytes, void** d_ptr) {
     SPC_HIP(e);
     P.size_of[*d_ptr] = want;
     P.live_bytes += want;
+    if (pool_poison()) { SPC_HIP(hipMemset(*d_ptr, 0xFF, bytes)); SPC_HIP(hipDeviceSynchronize()); }
     return SPC_OK;
 }
 
