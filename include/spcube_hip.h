@@ -203,6 +203,14 @@ typedef struct spc_stats_outputs {
 int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube,
                        const spc_mask* mask, int axis, const spc_stats_outputs* out);
 
+/* argmax / argmin along a SPATIAL axis (BaseSpectralCube.argmax / argmin with axis = 1 or 2,
+ * spectral_cube/spectral_cube.py:793-819; axis 0 is an output of spc_moments_f32): nanargmax of
+ * the data filled with -inf (argmin: +inf) - excluded and NaN samples take the fill, the first
+ * index wins ties, rays without an included sample give 0.  int64 maps (nz,nx) / (nz,ny),
+ * C-contiguous; a NULL output is skipped. */
+int spc_argextrema_axis_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                            int axis, int64_t* d_argmin, int64_t* d_argmax);
+
 /* ---- order statistics along the spectral axis ---
  * q-th percentile (numpy 'linear' interpolation; q = 50: the median) of the
  * included, non-NaN samples of every ray: DaskSpectralCubeMixin.median /
@@ -210,7 +218,8 @@ int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube,
  * (ny,nx) float32 map) the statistic is taken of |x - center|, and the result is
  * multiplied by scale: median absolute deviation -> mad_std (:711-731, astropy
  * stats.mad_std: scale = 1.482602218505602).  Rays without a valid sample give
- * NaN.  d_out: (ny,nx) float32, C-contiguous.  * The rays run along the FIRST axis of the view that is passed in: for a selection along y
+ * NaN.  d_out: (ny,nx) float32, C-contiguous.
+ * The rays run along the FIRST axis of the view that is passed in: for a selection along y
  * of a (nz, ny, nx) cube hand over the same buffer as {nz' = ny, ny' = nz, row_stride' =
  * plane_stride, plane_stride' = row_stride} (mask strides likewise); the result is (nz, nx). */
 int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,

@@ -218,6 +218,122 @@ __global__ __launch_bounds__(256) void stats_rows_kernel(const StatArgs A) {
     if (lane == 0) write_outputs(A, r, a);
 }
 
+// ---- argmax / argmin along a spatial axis (a8: spectral_cube.py:793-819) -------------------
+// nanargmax of the data filled with -inf (argmin: +inf): excluded and NaN samples take the fill,
+// the FIRST index wins ties, a ray without included samples gives 0.  Axis 0 comes out of the
+// fused moment kernel (spc_moments_f32); these serve axis 1 (march over y) and axis 2 (along the
+// row), with the same loops as the statistics kernels above.
+struct ArgAcc { float mn, mx; int imn, imx; };
+__device__ __forceinline__ ArgAcc arg_zero() { return ArgAcc{INFINITY, -INFINITY, 0, 0}; }
+__device__ __forceinline__ void arg_add(ArgAcc& a, float v, bool ok, int k) {   // k ascending per caller
+    const bool up = ok && (v > a.mx), dn = ok && (v < a.mn);
+    a.mx = up ? v : a.mx; a.imx = up ? k : a.imx;
+    a.mn = dn ? v : a.mn; a.imn = dn ? k : a.imn;
+}
+__device__ __forceinline__ void arg_merge(ArgAcc& a, const ArgAcc& b) {
+    const bool up = (b.mx > a.mx) || (b.mx == a.mx && b.imx < a.imx);
+    const bool dn = (b.mn < a.mn) || (b.mn == a.mn && b.imn < a.imn);
+    a.mx = up ? b.mx : a.mx; a.imx = up ? b.imx : a.imx;
+    a.mn = dn ? b.mn : a.mn; a.imn = dn ? b.imn : a.imn;
+}
+struct ArgArgs {
+    StatArgs s;
+    int64_t* o_argmin;
+    int64_t* o_argmax;
+};
+
+template <int VEC, bool ARR>
+__global__ __launch_bounds__(256) void arg_march_kernel(const ArgArgs B) {
+    const StatArgs& A = B.s;
+    constexpr int ZW = 4, U = 4;
+    __shared__ ArgAcc s_acc[ZW - 1][64][VEC];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t x = ((int64_t)blockIdx.x * 64 + lane) * VEC;
+    const int64_t o = blockIdx.y;
+    const bool live = x < A.nx;
+    const int64_t xc = live ? x : 0;
+    const float* p = A.cube + o * A.outer_stride + xc;
+    const uint8_t* pm = ARR ? A.mask.arr + o * A.m_outer_stride + xc : nullptr;
+    ArgAcc a[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) a[c] = arg_zero();
+    for (int64_t k0 = w; k0 < A.n_march; k0 += ZW * U) {
+        float v[U][VEC];
+        unsigned mk[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = min(k0 + (int64_t)u * ZW, A.n_march - 1);
+            if (VEC == 4) {
+                const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + k * A.march_stride));
+                const uint32_t m = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm + k * A.m_march_stride)) : 0x01010101u;
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) { v[u][c] = q[c]; mk[u][c] = (m >> (8 * c)) & 0xffu; }
+            } else {
+                v[u][0] = p[k * A.march_stride];
+                mk[u][0] = ARR ? pm[k * A.m_march_stride] : 1u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = k0 + (int64_t)u * ZW;
+            const bool in = k < A.n_march;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) arg_add(a[c], v[u][c], in && included(A.mask, v[u][c], mk[u][c]), (int)k);
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) s_acc[w - 1][lane][c] = a[c];
+    }
+    __syncthreads();
+    if (w == 0 && live) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+#pragma unroll
+            for (int k = 0; k < ZW - 1; ++k) arg_merge(a[c], s_acc[k][lane][c]);
+            if (x + c < A.nx) {
+                if (B.o_argmin) B.o_argmin[o * A.nx + x + c] = a[c].imn;
+                if (B.o_argmax) B.o_argmax[o * A.nx + x + c] = a[c].imx;
+            }
+        }
+    }
+}
+
+template <bool ARR>
+__global__ __launch_bounds__(256) void arg_rows_kernel(const ArgArgs B) {
+    const StatArgs& A = B.s;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= A.nz * A.ny) return;
+    const int64_t z = r / A.ny, y = r - z * A.ny;
+    const float* p = A.cube + z * A.plane_stride + y * A.row_stride;
+    const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + y * A.mask.row_stride : nullptr;
+    ArgAcc a = arg_zero();
+    const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
+    const int64_t n4 = al ? A.nx / 4 : 0;
+    for (int64_t i = lane; i < n4; i += 64) {
+        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+        const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[i] : 0x01010101u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) arg_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu), (int)(4 * i + c));
+    }
+    for (int64_t j = n4 * 4 + lane; j < A.nx; j += 64) {
+        const float v = p[j];
+        arg_add(a, v, included(A.mask, v, ARR ? pm[j] : 1u), (int)j);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        ArgAcc b;
+        b.mn = __shfl_xor(a.mn, d, 64); b.mx = __shfl_xor(a.mx, d, 64);
+        b.imn = __shfl_xor(a.imn, d, 64); b.imx = __shfl_xor(a.imx, d, 64);
+        arg_merge(a, b);
+    }
+    if (lane == 0) {
+        if (B.o_argmin) B.o_argmin[r] = a.imn;
+        if (B.o_argmax) B.o_argmax[r] = a.imx;
+    }
+}
+
 // ---- 2-D convolution of ONE float64 map --------------------------------------------------
 // For the algebraic spatial_smooth -> moment path (spectral_cube_amd/cube.py): with every voxel
 // valid, spatial smoothing (astropy's NaN-free branch: zero fill outside, division by the kernel
@@ -408,6 +524,47 @@ int spc_stats_axis_f32(int device, void* stream, const spc_cube_f32* cube, const
         dim3 grid((unsigned)((A.nx + 63) / 64), (unsigned)A.n_outer);
         if (arr) hipLaunchKernelGGL((stats_march_kernel<1, true>), grid, dim3(256), 0, st, A);
         else hipLaunchKernelGGL((stats_march_kernel<1, false>), grid, dim3(256), 0, st, A);
+    }
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_argextrema_axis_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, int axis,
+                            int64_t* d_argmin, int64_t* d_argmax) {
+    SPC_REQUIRE(axis == 1 || axis == 2, "axis must be 1 or 2 (axis 0 is an output of spc_moments_f32)");
+    SPC_REQUIRE(d_argmin || d_argmax, "no output requested");
+    ArgArgs B{};
+    StatArgs& A = B.s;
+    int rc = fill_common(A, cube, mask);
+    if (rc) return rc;
+    SPC_REQUIRE(A.nx < (1ll << 31) && A.ny < (1ll << 31), "axis longer than 2^31 samples");
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    B.o_argmin = d_argmin; B.o_argmax = d_argmax;
+    if (axis == 2) {
+        const int64_t rows = A.nz * A.ny;
+        SPC_REQUIRE((rows + 3) / 4 <= 0x7fffffffLL, "too many rows for one launch");
+        dim3 grid((unsigned)((rows + 3) / 4));
+        if (arr) hipLaunchKernelGGL(arg_rows_kernel<true>, grid, dim3(256), 0, st, B);
+        else hipLaunchKernelGGL(arg_rows_kernel<false>, grid, dim3(256), 0, st, B);
+        SPC_LAUNCH_CHECK();
+        return SPC_OK;
+    }
+    A.n_outer = A.nz; A.outer_stride = A.plane_stride; A.n_march = A.ny; A.march_stride = A.row_stride;
+    A.m_outer_stride = A.mask.plane_stride; A.m_march_stride = A.mask.row_stride;
+    SPC_REQUIRE(A.n_outer <= 65535, "more than 65535 output rows per call not supported (split the call)");
+    const bool v4 = (A.nx % 4 == 0) && (A.row_stride % 4 == 0) && (A.plane_stride % 4 == 0) &&
+                    ((((uintptr_t)A.cube) & 15) == 0) &&
+                    (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
+    if (v4) {
+        dim3 grid((unsigned)((A.nx + 255) / 256), (unsigned)A.n_outer);
+        if (arr) hipLaunchKernelGGL((arg_march_kernel<4, true>), grid, dim3(256), 0, st, B);
+        else hipLaunchKernelGGL((arg_march_kernel<4, false>), grid, dim3(256), 0, st, B);
+    } else {
+        dim3 grid((unsigned)((A.nx + 63) / 64), (unsigned)A.n_outer);
+        if (arr) hipLaunchKernelGGL((arg_march_kernel<1, true>), grid, dim3(256), 0, st, B);
+        else hipLaunchKernelGGL((arg_march_kernel<1, false>), grid, dim3(256), 0, st, B);
     }
     SPC_LAUNCH_CHECK();
     return SPC_OK;

@@ -477,16 +477,34 @@ class SpectralCube:
         return Projection(np.asarray(s) * SIGMA2FWHM, unit=s.unit, wcs=s.wcs, meta=s.meta)
 
     def _extremum(self, key, axis, how):
-        if axis != 0:
-            raise NotImplementedError("only the spectral axis is built on the GPU path")
-        return self._moment_device((key,))[key].get()
+        if axis == 0:
+            return self._moment_device((key,))[key].get()
+        if axis in (1, 2):
+            return ops.argextrema_axis(self._device_data(), axis, mask=self._mask_spec(), want=(key,))[key].get()
+        if axis is not None:
+            raise ValueError("axis must be None, 0, 1 or 2")
+        # whole cube: flat C-order index of the first extreme voxel, from the per-spaxel extreme and
+        # its first channel (one pass of the fused kernel)
+        vkey = "vmax" if key == "argmax" else "vmin"
+        r = self._moment_device((key, vkey))
+        val, idx = r[vkey].get().astype(np.float64), r[key].get()
+        fill = -np.inf if key == "argmax" else np.inf
+        val = np.where(np.isnan(val), fill, val)               # rays without an included sample
+        best = val.max() if key == "argmax" else val.min()
+        if best == fill:
+            return np.int64(0)
+        nz, ny, nx = self._shape
+        yy, xx = np.nonzero(val == best)
+        return np.int64(np.min(idx[yy, xx] * (ny * nx) + yy * nx + xx))
 
-    def argmax(self, axis=0, how="auto", **kwargs):
-        """index of the maximum along the spectral axis (spectral_cube.py:793-804);
-        first index on ties, 0 for fully masked rays; int64."""
+    def argmax(self, axis=None, how="auto", **kwargs):
+        """index of the maximum along *axis* (spectral_cube.py:793-804: nanargmax of the data filled
+        with -inf); first index on ties, 0 for fully masked rays; int64.  ``axis=None``: flat index
+        into the cube."""
         return self._extremum("argmax", axis, how)
 
-    def argmin(self, axis=0, how="auto", **kwargs):
+    def argmin(self, axis=None, how="auto", **kwargs):
+        """spectral_cube.py:806-819 (fill +inf)"""
         return self._extremum("argmin", axis, how)
 
     # ---- statistics / nan-reductions (SURVEY.md section 8f rank 1) -----------------------------

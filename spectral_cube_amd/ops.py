@@ -129,6 +129,21 @@ def moments(cube, cen, dv=1.0, m1_add=0.0, mask=None, want=_WANT_ALL, stream=Non
     return bufs
 
 
+def argextrema_axis(cube, axis, mask=None, want=("argmax", "argmin"), stream=None):
+    """argmax / argmin along a spatial axis (spectral_cube.py:793-819 with axis = 1 or 2): int64
+    maps (nz, nx) / (nz, ny); first index on ties, 0 for rays without an included sample."""
+    nz, ny, nx = cube.shape
+    if axis not in (1, 2):
+        raise ValueError("axis must be 1 or 2 (axis 0 comes out of ops.moments)")
+    shape = (nz, nx) if axis == 1 else (nz, ny)
+    bufs = {n: DeviceArray(shape, np.int64, cube.device) for n in want if n in ("argmax", "argmin")}
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    ptr = lambda n: C.c_void_p(bufs[n].ptr) if n in bufs else None  # noqa: E731
+    _lib.call("spc_argextrema_axis_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis),
+              ptr("argmin"), ptr("argmax"))
+    return bufs
+
+
 def moment_order(cube, cen, order, mu, s0, mask=None, stream=None):
     """sum v*(c-mu)^order / S0 - second pass for order > 2
     (dask_spectral_cube.py:1094-1099)."""

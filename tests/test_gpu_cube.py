@@ -98,8 +98,8 @@ def test_c1_config_against_reference_output(gpu):
     # the kernel carries fp64 sums: agreement is in fact ~1e-12, not just 1e-5
     ok = np.isfinite(g["mom1"])
     assert np.abs(moms[1][ok] - g["mom1"][ok]).max() < 1e-9 * span
-    assert np.array_equal(sc.argmax(), g["argmax"]) and sc.argmax().dtype == np.int64
-    assert np.array_equal(sc.argmin(), g["argmin"])
+    assert np.array_equal(sc.argmax(axis=0), g["argmax"]) and sc.argmax(axis=0).dtype == np.int64
+    assert np.array_equal(sc.argmin(axis=0), g["argmin"])
     assert_close(sc.linewidth_sigma(), g["linewidth_sigma"], atol=1e-6 * np.nanmax(g["linewidth_sigma"]))
     assert_close(sc.linewidth_fwhm(), g["linewidth_fwhm"], atol=1e-6 * np.nanmax(g["linewidth_fwhm"]))
     # the same mask as a device predicate (cube > median) gives the same maps
@@ -664,3 +664,42 @@ def test_varying_resolution_convolve_to(gpu, tmp_path):
         h = k.shape[0] // 2
         k5 = k[h - 2:h + 3, h - 2:h + 3] if h >= 2 else np.pad(k, 2 - h)
         np.testing.assert_allclose(conv[ii], k5 / k.sum(), atol=1e-6)
+
+
+def test_argmax_argmin_every_axis(gpu):
+    """argmax / argmin for axis None, 0, 1, 2 (spectral_cube/tests/test_spectral_cube.py:616-650:
+    `_check_numpy` loops over exactly these): the reference's own data_adv case (golden
+    adv_argmax.npz, written by both of its classes), then larger cubes with ties, NaNs, fully
+    masked rays and both the 16-byte and the scalar kernels against the oracle / numpy - bit-exact
+    int64."""
+    g = golden("adv_argmax.npz")
+    d = g["data"]
+    hdr = str(golden("c1_moments.npz")["header"])
+    sc = SpectralCube.read(d.astype(np.float32), hdr)
+    sc = sc.with_mask(BooleanArrayMask(d > 0.5, sc.wcs))
+    for axis in (0, 1, 2):
+        am, an = sc.argmax(axis=axis), sc.argmin(axis=axis)
+        assert am.dtype == np.int64 and an.dtype == np.int64
+        np.testing.assert_array_equal(am, g["argmax_a%d" % axis])
+        np.testing.assert_array_equal(an, g["argmin_a%d" % axis])
+    assert sc.argmax() == np.nanargmax(np.where(d > 0.5, d, -10)) and sc.argmin() == np.nanargmin(np.where(d > 0.5, d, 10))
+    rng = np.random.default_rng(31)
+    for shape in ((37, 45, 64), (12, 70, 33), (5, 9, 260)):
+        big = np.round(rng.standard_normal(shape) * 3).astype(np.float32)          # many ties
+        big[rng.random(shape) < 0.05] = np.nan
+        inc = rng.random(shape) < 0.7
+        inc[:, 3, :] = False                 # rays along z and x without a sample
+        inc[2, :, 5] = False                 # a ray along y without a sample
+        cube = SpectralCube.read(big, hdr).with_mask(BooleanArrayMask(inc, None))
+        for axis in (0, 1, 2):
+            np.testing.assert_array_equal(cube.argmax(axis=axis), O.argmax(big, inc, axis=axis))
+            np.testing.assert_array_equal(cube.argmin(axis=axis), O.argmin(big, inc, axis=axis))
+        fmax = np.where(inc & ~np.isnan(big), big, -np.inf)
+        fmin = np.where(inc & ~np.isnan(big), big, np.inf)
+        assert cube.argmax() == np.argmax(fmax) and cube.argmin() == np.argmin(fmin)
+        assert isinstance(cube.argmax(), np.int64)
+    empty = SpectralCube.read(big, hdr).with_mask(BooleanArrayMask(np.zeros(shape, bool), None))
+    assert empty.argmax() == 0 and empty.argmin() == 0
+    assert not empty.argmax(axis=1).any() and not empty.argmin(axis=2).any()
+    with pytest.raises(ValueError):
+        cube.argmax(axis=3)
