@@ -237,6 +237,11 @@ int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,
  *                      *h_nchanged (HOST) = number of samples clipped by this call. */
 int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                         float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);
+/* out[z][x][y] = included ? data[z][y][x] : fill, d_out a C-contiguous (nz, nx, ny) buffer: the
+ * filled copy with the spatial axes exchanged, which turns an order statistic along x
+ * (median(axis=2)) into one along y for spc_percentile_axis0_f32's exchanged-stride form. */
+int spc_fill_masked_transpose_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                  float fill, float* d_out);
 int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, int64_t ny, int64_t nx,
                          const float* d_lo, const float* d_hi, uint64_t* h_nchanged);
 

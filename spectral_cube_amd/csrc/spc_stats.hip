@@ -398,6 +398,38 @@ __global__ __launch_bounds__(256) void fill_masked_kernel(const ClipArgs A) {
     }
 }
 
+// filled copy with the two spatial axes exchanged: out[z][x][y] = included ? in[z][y][x] : fill.
+// Puts the rays of an order statistic along x (median(axis=2)) along y, where the selection
+// kernels stream them coalesced.  64 x 64 tile through LDS (pitch 65: conflict-free both ways),
+// rows of the tile are read and written as 256-byte segments.
+template <bool ARR>
+__global__ __launch_bounds__(256) void fill_masked_transpose_kernel(const ClipArgs A) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t x0 = (int64_t)blockIdx.x * 64, y0 = (int64_t)blockIdx.y * 64;
+    for (int64_t z = blockIdx.z; z < A.nz; z += gridDim.z) {
+#pragma unroll 4
+        for (int r = w; r < 64; r += 4) {
+            const int64_t y = y0 + r, x = x0 + lane;
+            float v = A.fill;
+            if (y < A.ny && x < A.nx) {
+                const float q = A.in[z * A.plane_stride + y * A.row_stride + x];
+                bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, q);
+                if (ARR) ok = ok && A.mask.arr[z * A.mask.plane_stride + y * A.mask.row_stride + x] != 0;
+                v = ok ? q : A.fill;
+            }
+            tile[r][lane] = v;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int r = w; r < 64; r += 4) {
+            const int64_t x = x0 + r, y = y0 + lane;
+            if (x < A.nx && y < A.ny) A.out[z * A.out_plane_stride + x * A.out_row_stride + y] = tile[lane][r];
+        }
+        __syncthreads();
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void clip_outside_kernel(const ClipArgs A) {
     // lane = VEC adjacent x of one row, marching over its share of the planes (16-byte accesses when VEC == 4)
@@ -614,6 +646,28 @@ int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, cons
     dim3 grid((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)std::min<int64_t>(cube->nz, 64));
     if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(fill_masked_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(fill_masked_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_fill_masked_transpose_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                  float fill, float* d_out) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    ClipArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_REQUIRE((cube->ny + 63) / 64 <= 65535, "too many rows for one launch");
+    SPC_DEVICE(device);
+    A.in = cube->d_data; A.out = d_out; A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.out_row_stride = cube->ny;                      // out is (nz, nx, ny), C-contiguous
+    A.out_plane_stride = cube->nx * cube->ny;
+    A.fill = fill;
+    dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + 63) / 64), (unsigned)std::min<int64_t>(cube->nz, 1024));
+    if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(fill_masked_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(fill_masked_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }

@@ -564,9 +564,12 @@ class SpectralCube:
         if axis == 1:            # rays along y: the same kernels on a view with the first two axes exchanged
             return ops.percentile_axis0(self._device_data().swap01(), q, mask=self._mask_spec().swap01(),
                                         center=center, scale=scale)
+        if axis == 2:            # rays along x: NaN-filled copy with the spatial axes exchanged, then as along y
+            flipped = ops.fill_masked_transposed(self._device_data(), self._mask_spec(), np.nan)
+            return ops.percentile_axis0(flipped.swap01(), q, center=center, scale=scale)
         if axis != 0:
-            raise NotImplementedError("%s is built along the spectral axis (axis=0) and along y (axis=1); the "
-                                      "reference itself falls back to loading the whole cube for axis=None" % what)
+            raise NotImplementedError("%s is built along one axis (0, 1 or 2); the reference itself falls back "
+                                      "to loading the whole cube into memory for axis=None" % what)
         return ops.percentile_axis0(self._device_data(), q, mask=self._mask_spec(), center=center, scale=scale)
 
     def _order_wcs(self, axis):

@@ -391,6 +391,16 @@ def fill_masked(cube, mask=None, fill=np.nan, stream=None, out=None):
     return out
 
 
+def fill_masked_transposed(cube, mask=None, fill=np.nan, stream=None):
+    """(nz, nx, ny) device copy: excluded voxels replaced by *fill*, spatial axes exchanged
+    (spc_fill_masked_transpose_f32) - rays along x become rays along y."""
+    nz, ny, nx = cube.shape
+    out = DeviceArray((nz, nx, ny), np.float32, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_fill_masked_transpose_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(fill), C.c_void_p(out.ptr))
+    return out
+
+
 def sigma_clip_axis0(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc="median",
                      stdfunc="std", mask=None, stream=None):
     """astropy.stats.sigma_clip(axis=0, masked=False, copy=True) on the device

@@ -471,7 +471,31 @@ def test_median_percentile_mad_std(gpu):
         assert_close(got, g["p%g" % q], atol=2e-6 * np.nanmax(np.abs(g["p%g" % q])), what="percentile %g" % q)
     assert_close(np.asarray(cube.mad_std(axis=0)), g["mad_std"], atol=2e-6 * np.nanmax(np.abs(g["mad_std"])), what="mad_std")
     with pytest.raises(NotImplementedError):
-        cube.median(axis=2)
+        cube.median(axis=None)
+    # along x (axis=2): NaN-filled copy with the spatial axes exchanged, then the same selection
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        filled2 = np.where(inc, d, np.nan).astype(np.float32)
+        e2 = np.nanmedian(filled2, axis=2)
+        e2p = np.nanpercentile(filled2.astype(np.float64), 90.0, axis=2)
+        dev2 = np.abs(filled2 - e2[:, :, None])
+        e2m = np.nanmedian(dev2, axis=2) * 1.482602218505602
+    m2 = np.asarray(cube.median(axis=2))
+    assert m2.shape == d.shape[:2]
+    assert np.array_equal(np.isnan(m2), np.isnan(e2)) and np.array_equal(m2[~np.isnan(e2)], e2[~np.isnan(e2)])
+    p2 = np.asarray(cube.percentile(90.0, axis=2))
+    fin2 = np.isfinite(e2p)
+    assert np.array_equal(np.isnan(p2), np.isnan(e2p)) and np.allclose(p2[fin2], e2p[fin2], rtol=2e-6, atol=2e-6 * np.nanmax(np.abs(e2p)))
+    s2 = np.asarray(cube.mad_std(axis=2))
+    fin2 = np.isfinite(e2m)
+    assert np.array_equal(np.isnan(s2), np.isnan(e2m)) and np.allclose(s2[fin2], e2m[fin2], rtol=3e-6, atol=3e-6 * np.nanmax(e2m))
+    ragged = np.random.default_rng(10).standard_normal((3, 70, 131)).astype(np.float32)   # partial 64 x 64 tiles
+    ragged[np.random.default_rng(11).random(ragged.shape) < 0.3] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        er = np.nanmedian(ragged, axis=2)
+    gr = np.asarray(SpectralCube.read(ragged, hdr).median(axis=2))
+    assert np.array_equal(np.isnan(gr), np.isnan(er)) and np.array_equal(gr[~np.isnan(er)], er[~np.isnan(er)])
     # along y (axis=1): the same kernels on a view with the first two axes exchanged - must equal the
     # axis-0 result of the transposed cube bit for bit, and numpy's nanmedian / nanpercentile
     filled = np.where(inc, d, np.nan).astype(np.float32)
