@@ -237,6 +237,13 @@ int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,
  *                      *h_nchanged (HOST) = number of samples clipped by this call. */
 int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                         float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);
+/* The same statistic over the WHOLE cube (median / percentile / mad_std with axis=None): four
+ * histogram passes over the key bytes.  With has_center the statistic is taken of
+ * |x - center| (float32 arithmetic, as numpy does for a float32 cube).  *h_out (HOST) gets the
+ * value in double; NaN when nothing is included. */
+int spc_percentile_global_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                              double q, int has_center, float center, double* h_out);
+
 /* out[z][x][y] = included ? data[z][y][x] : fill, d_out a C-contiguous (nz, nx, ny) buffer: the
  * filled copy with the spatial axes exchanged, which turns an order statistic along x
  * (median(axis=2)) into one along y for spc_percentile_axis0_f32's exchanged-stride form. */

@@ -260,6 +260,81 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
     }
 }
 
+
+// ---- whole-cube order statistic (median / percentile / mad_std with axis=None) ----------------
+// The cube is one long ray here, so the digits of the key are found with shared histograms: one
+// streaming pass per key BYTE (4 passes) counts, among the samples whose key matches the prefix
+// found so far, the next byte; the host walks the 256 counters.  Histograms are built in LDS -
+// 16 interleaved copies ([bin][lane & 15]: same-bin updates of different copies fall on different
+// banks; real data put most samples in a handful of top-byte bins) - and flushed with one 64-bit
+// atomic per bin and block.  A fifth pass (minimum key above the selected one) is only needed
+// when the two order statistics of an interpolated percentile are different values.
+struct GSelArgs {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    MaskDev mask;
+    int64_t nrows, rowlen, row_a, row_b;   // as in the statistics kernel: 1 row when contiguous
+    uint32_t prefix, pmask;
+    int shift;
+    int has_center;
+    float center;
+    unsigned long long* hist;              // [256]
+    uint32_t* next;                        // MODE 1: minimum key > prefix
+};
+
+template <bool ARR, int MODE>
+__global__ __launch_bounds__(256) void gselect_kernel(const GSelArgs A) {
+    __shared__ uint32_t lh[256 * 16];
+    __shared__ uint32_t s_min;
+    const int t = threadIdx.x;
+    if (MODE == 0) {
+        for (int i = t; i < 256 * 16; i += 256) lh[i] = 0;
+    } else if (t == 0) {
+        s_min = 0xffffffffu;
+    }
+    __syncthreads();
+    const int copy = t & 15;
+    uint32_t mymin = 0xffffffffu;
+    auto take = [&](float v, unsigned mk) {
+        const bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v) && (mk != 0);
+        if (!ok) return;
+        if (A.has_center) v = __builtin_fabsf(v - A.center);
+        const uint32_t k = fkey(v);
+        if (MODE == 0) {
+            if ((k & A.pmask) == A.prefix) atomicAdd(&lh[((k >> A.shift) & 0xffu) * 16 + copy], 1u);
+        } else {
+            if (k > A.prefix) mymin = min(mymin, k);
+        }
+    };
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = 0; r < A.nrows; ++r) {
+        const int64_t off = (A.nrows == 1) ? 0 : (r / A.ny) * A.row_a + (r % A.ny) * A.row_b;
+        const int64_t moff = (A.nrows == 1) ? 0 : (r / A.ny) * A.mask.plane_stride + (r % A.ny) * A.mask.row_stride;
+        const float* p = A.cube + off;
+        const uint8_t* pm = ARR ? A.mask.arr + moff : nullptr;
+        const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
+        const int64_t n4 = al ? A.rowlen / 4 : 0;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n4; i += stride) {
+            const f32x4s v = __builtin_nontemporal_load(reinterpret_cast<const f32x4s*>(p) + i);
+            const uint32_t m = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm) + i) : 0x01010101u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) take(v[c], (m >> (8 * c)) & 0xffu);
+        }
+        for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * 256 + t; j < A.rowlen; j += stride) take(p[j], ARR ? pm[j] : 1u);
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) tot += lh[t * 16 + c];
+        if (tot) atomicAdd(&A.hist[t], tot);
+    } else {
+        atomicMin(&s_min, mymin);
+        __syncthreads();
+        if (t == 0 && s_min != 0xffffffffu) atomicMin(A.next, s_min);
+    }
+}
+
 }  // namespace
 
 extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
@@ -299,5 +374,82 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
         else hipLaunchKernelGGL((select_axis0_kernel<1, false>), grid, dim3(256), 0, st, A);
     }
     SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                         double q, int has_center, float center, double* h_out) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(h_out != nullptr, "h_out is NULL");
+    SPC_REQUIRE(q >= 0.0 && q <= 100.0, "Percentiles must be in the range [0, 100]");
+    GSelArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.has_center = has_center; A.center = center;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    const bool contig = (A.row_stride == A.nx) && (A.plane_stride == A.ny * A.nx) &&
+                        (!arr || (A.mask.row_stride == A.nx && A.mask.plane_stride == A.ny * A.nx));
+    if (contig) { A.nrows = 1; A.rowlen = A.nz * A.ny * A.nx; A.row_a = 0; A.row_b = 0; }
+    else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
+    const int64_t per_block = 256 * 4 * 8;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (A.rowlen + per_block - 1) / per_block));
+    unsigned long long* d_hist = nullptr;              // 256 counters + (as uint32) the "next key" cell
+    SPC_HIP(spc_scratch_alloc((void**)&d_hist, sizeof(unsigned long long) * 257, st));
+    A.hist = d_hist;
+    A.next = reinterpret_cast<uint32_t*>(d_hist + 256);
+    unsigned long long h[256];
+    hipError_t e = hipSuccess;
+    unsigned long long n = 0, below = 0, eq = 0;
+    long long klo = 0, khi = 0, k = 0;
+    double frac = 0.0;
+    for (int pass = 0; pass < 4 && e == hipSuccess; ++pass) {
+        A.shift = 24 - 8 * pass;
+        e = hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 256, st);
+        if (e != hipSuccess) break;
+        if (arr) hipLaunchKernelGGL((gselect_kernel<true, 0>), dim3(nblocks), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((gselect_kernel<false, 0>), dim3(nblocks), dim3(256), 0, st, A);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d_hist, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) break;
+        if (pass == 0) {
+            for (int d = 0; d < 256; ++d) n += h[d];
+            if (n == 0) break;
+            const double pos = q / 100.0 * (double)(n - 1);
+            klo = (long long)floor(pos);
+            khi = std::min<long long>((long long)ceil(pos), (long long)n - 1);
+            frac = pos - floor(pos);
+            k = klo;
+        }
+        int d = 0;
+        while (d < 255 && (unsigned long long)k >= h[d]) { k -= (long long)h[d]; below += h[d]; ++d; }
+        eq = h[d];
+        A.prefix |= (uint32_t)d << A.shift;
+        A.pmask |= 0xffu << A.shift;
+    }
+    uint32_t key_lo = A.prefix, key_hi = A.prefix;
+    if (e == hipSuccess && n > 0 && (unsigned long long)khi >= below + eq) {     // the upper statistic is the next larger value
+        uint32_t init = 0xffffffffu;
+        e = hipMemcpyAsync(A.next, &init, sizeof(init), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            if (arr) hipLaunchKernelGGL((gselect_kernel<true, 1>), dim3(nblocks), dim3(256), 0, st, A);
+            else hipLaunchKernelGGL((gselect_kernel<false, 1>), dim3(nblocks), dim3(256), 0, st, A);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&key_hi, A.next, sizeof(key_hi), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)spc_scratch_free(d_hist, st);
+    SPC_HIP(e);
+    if (n == 0) { *h_out = NAN; return SPC_OK; }
+    auto unkey = [](uint32_t kk) { uint32_t u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk; float f; memcpy(&f, &u, 4); return (double)f; };
+    const double a = unkey(key_lo), b = unkey(key_hi);
+    *h_out = (frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac;
     return SPC_OK;
 }

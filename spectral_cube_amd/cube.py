@@ -568,27 +568,37 @@ class SpectralCube:
             flipped = ops.fill_masked_transposed(self._device_data(), self._mask_spec(), np.nan)
             return ops.percentile_axis0(flipped.swap01(), q, center=center, scale=scale)
         if axis != 0:
-            raise NotImplementedError("%s is built along one axis (0, 1 or 2); the reference itself falls back "
-                                      "to loading the whole cube into memory for axis=None" % what)
+            raise ValueError("axis must be None, 0, 1 or 2")
         return ops.percentile_axis0(self._device_data(), q, mask=self._mask_spec(), center=center, scale=scale)
 
     def _order_wcs(self, axis):
         return self._wcs.drop_spectral() if (axis == 0 and self._wcs is not None) else None
 
+    def _order_stat_global(self, q, center=None):
+        """whole-cube statistic (axis=None): float32 like numpy's result for a float32 cube"""
+        return np.float32(ops.percentile_global(self._device_data(), q, mask=self._mask_spec(), center=center))
+
     def median(self, axis=None, **kwargs):
-        """nanmedian along the spectral axis (dask_spectral_cube.py:657-671): bit descent on
-        order-preserving keys, no sort (csrc/spc_select.hip)."""
+        """nanmedian along an axis or of the whole cube (dask_spectral_cube.py:657-671): digit
+        descent on order-preserving keys, no sort (csrc/spc_select.hip)."""
+        if axis is None:
+            return float(self._order_stat_global(50.0))
         return Projection(self._order_stat(50.0, axis, "median").get(), unit=self._unit,
                           wcs=self._order_wcs(axis), meta=dict(self._meta))
 
     def percentile(self, q, axis=None, **kwargs):
-        """np.nanpercentile along the spectral axis (dask_spectral_cube.py:673-693)."""
+        """np.nanpercentile along an axis or of the whole cube (dask_spectral_cube.py:673-693)."""
+        if axis is None:
+            return float(self._order_stat_global(float(q)))
         return Projection(self._order_stat(float(q), axis, "percentile").get(), unit=self._unit,
                           wcs=self._order_wcs(axis), meta=dict(self._meta))
 
     def mad_std(self, axis=None, ignore_nan=True, **kwargs):
         """astropy mad_std along the spectral axis (dask_spectral_cube.py:711-731): two selections
         (median, then median of |x - median|) without leaving the device."""
+        if axis is None:
+            med = self._order_stat_global(50.0)
+            return float(np.float32(self._order_stat_global(50.0, center=med) * np.float32(ops.MAD_TO_STD)))
         med = self._order_stat(50.0, axis, "mad_std")
         out = self._order_stat(50.0, axis, "mad_std", center=med, scale=ops.MAD_TO_STD)
         return Projection(out.get(), unit=self._unit, wcs=self._order_wcs(axis), meta=dict(self._meta))

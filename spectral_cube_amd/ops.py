@@ -391,6 +391,16 @@ def fill_masked(cube, mask=None, fill=np.nan, stream=None, out=None):
     return out
 
 
+def percentile_global(cube, q, mask=None, center=None, stream=None):
+    """q-th percentile of all included samples of the cube (np.nanpercentile(..., axis=None));
+    with *center* of |x - center|.  Returns a python float (NaN when nothing is included)."""
+    out = C.c_double(0.0)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_percentile_global_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(q),
+              0 if center is None else 1, 0.0 if center is None else float(center), C.byref(out))
+    return out.value
+
+
 def fill_masked_transposed(cube, mask=None, fill=np.nan, stream=None):
     """(nz, nx, ny) device copy: excluded voxels replaced by *fill*, spatial axes exchanged
     (spc_fill_masked_transpose_f32) - rays along x become rays along y."""

@@ -470,8 +470,37 @@ def test_median_percentile_mad_std(gpu):
         got = np.asarray(cube.percentile(q, axis=0))
         assert_close(got, g["p%g" % q], atol=2e-6 * np.nanmax(np.abs(g["p%g" % q])), what="percentile %g" % q)
     assert_close(np.asarray(cube.mad_std(axis=0)), g["mad_std"], atol=2e-6 * np.nanmax(np.abs(g["mad_std"])), what="mad_std")
-    with pytest.raises(NotImplementedError):
-        cube.median(axis=None)
+    with pytest.raises(ValueError):
+        cube.median(axis=3)
+    # the whole cube (axis=None): four histogram passes over the key bytes
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fz = np.where(inc, d, np.nan).astype(np.float32)
+        assert cube.median() == float(np.nanmedian(fz))
+        for q in (0.0, 3.0, 37.5, 50.0, 99.9, 100.0):
+            e = float(np.nanpercentile(fz.astype(np.float64), q))
+            assert abs(cube.percentile(q) - e) <= 2e-6 * max(1.0, abs(e)), q
+        em = float(np.nanmedian(np.abs(fz - np.nanmedian(fz)))) * 1.482602218505602
+        assert abs(cube.mad_std() - em) <= 3e-6 * em
+    ties = np.round(np.random.default_rng(12).standard_normal((20, 33, 47)) * 2).astype(np.float32)   # heavy ties, even count
+    ties[0, 0, 0] = np.inf
+    ties[0, 0, 1] = -np.inf
+    ties[1, 2, 3] = np.nan
+    ct = SpectralCube.read(ties, hdr)
+    ct._mask = None                                                                 # +-inf stay in, as for nanmedian
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert ct.median() == float(np.nanmedian(ties))
+        for q in (0.0, 100.0):        # numpy's lerp gives NaN between two equal infinities; so does the kernel
+            np.testing.assert_equal(ct.percentile(q), float(np.nanpercentile(ties.astype(np.float64), q)))
+        assert ct.percentile(25.0) == float(np.nanpercentile(ties.astype(np.float64), 25.0))
+    strip = cube._device_data().rows(3, 9)                                          # strided view: row addressing
+    from spectral_cube_amd import ops as _ops
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.float32(_ops.percentile_global(strip, 50.0)) == np.nanmedian(d[:, 3:9, :].astype(np.float32))
+    nothing = SpectralCube.read(d, hdr).with_mask(np.zeros(d.shape, bool))
+    assert np.isnan(nothing.median()) and np.isnan(nothing.mad_std())
     # along x (axis=2): NaN-filled copy with the spatial axes exchanged, then the same selection
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
