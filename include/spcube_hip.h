@@ -226,17 +226,6 @@ int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,
                              const spc_mask* mask, double q, const float* d_center,
                              float scale, float* d_out);
 
-/* ---- sigma clipping along the spectral axis (dask_spectral_cube.py:851-878) ----
- * astropy.stats.sigma_clip(axis=0, masked=False) iterates: per-ray centre and std
- * (spc_percentile_axis0_f32 / spc_stats_axis_f32), then everything outside
- * [centre - sigma_lower*std, centre + sigma_upper*std] becomes NaN, until nothing
- * changes.  These are the two elementwise ends of that loop:
- * spc_fill_masked_f32: out = included ? data : fill   (the NaN-filled working copy,
- *                      MaskBase._filled, masks.py:197-237);
- * spc_clip_outside_f32: in place, contiguous (nz,ny,nx): v < lo[y,x] || v > hi[y,x] -> NaN;
- *                      *h_nchanged (HOST) = number of samples clipped by this call. */
-int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
-                        float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);
 /* The same statistic over the WHOLE cube (median / percentile / mad_std with axis=None): four
  * histogram passes over the key bytes.  With has_center the statistic is taken of
  * |x - center| (float32 arithmetic, as numpy does for a float32 cube).  *h_out (HOST) gets the
@@ -249,6 +238,18 @@ int spc_percentile_global_f32(int device, void* stream, const spc_cube_f32* cube
  * (median(axis=2)) into one along y for spc_percentile_axis0_f32's exchanged-stride form. */
 int spc_fill_masked_transpose_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                                   float fill, float* d_out);
+
+/* ---- sigma clipping along the spectral axis (dask_spectral_cube.py:851-878) ----
+ * astropy.stats.sigma_clip(axis=0, masked=False) iterates: per-ray centre and std
+ * (spc_percentile_axis0_f32 / spc_stats_axis_f32), then everything outside
+ * [centre - sigma_lower*std, centre + sigma_upper*std] becomes NaN, until nothing
+ * changes.  These are the two elementwise ends of that loop:
+ * spc_fill_masked_f32: out = included ? data : fill   (the NaN-filled working copy,
+ *                      MaskBase._filled, masks.py:197-237);
+ * spc_clip_outside_f32: in place, contiguous (nz,ny,nx): v < lo[y,x] || v > hi[y,x] -> NaN;
+ *                      *h_nchanged (HOST) = number of samples clipped by this call. */
+int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                        float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);
 int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, int64_t ny, int64_t nx,
                          const float* d_lo, const float* d_hi, uint64_t* h_nchanged);
 
