@@ -519,6 +519,30 @@ class SpectralCube:
             n = st["npts"]
             vals = {"count": np.float64(n), "sum": np.float64(st["sum"]), "sumsq": np.float64(st["sumsq"]),
                     "max": np.float64(st["max"]), "min": np.float64(st["min"])}
+        elif isinstance(axis, (tuple, list)):
+            # two axes at once (e.g. the mean spectrum, axis=(1, 2)): one device pass removes the first
+            # of them, the small (5 statistics x one map) remainder is finished on the host
+            axes = sorted(set(int(a) for a in axis))
+            if len(axes) == 3:
+                return self._reduce(op, None, ddof)
+            if len(axes) == 1:
+                return self._reduce(op, axes[0], ddof)
+            if len(axes) != 2 or any(a not in (0, 1, 2) for a in axes):
+                raise ValueError("axis must be None, 0, 1, 2 or a tuple of these")
+            first, second = axes[1], axes[0]            # drop the higher axis on the device, the lower one here
+            r = ops.stats_axis(self._device_data(), first, mask=self._mask_spec(), want=need)
+            part = {k: r[k].get().astype(np.float64) for k in need}
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                vals = {"count": part["count"].sum(axis=second)}
+                for k in need:
+                    if k in ("sum", "sumsq"):
+                        vals[k] = np.nansum(part[k], axis=second)
+                    elif k == "max":
+                        vals[k] = np.nanmax(np.where(part["count"] > 0, part[k], -np.inf), axis=second)
+                    elif k == "min":
+                        vals[k] = np.nanmin(np.where(part["count"] > 0, part[k], np.inf), axis=second)
+            axis = tuple(axes)
         else:
             if axis not in (0, 1, 2):
                 raise ValueError("axis must be None, 0, 1 or 2")

@@ -282,6 +282,18 @@ def test_statistics_and_reductions(gpu):
             exp = g["%s_%s" % (op, "all" if axis is None else axis)]
             scale = np.nanmax(np.abs(exp))
             assert_close(got, exp, atol=1e-9 * scale, what="%s axis=%s" % (op, axis))
+    # two axes at once (the mean spectrum is cube.mean(axis=(1, 2))): numpy nan-reductions of the filled data
+    filled = np.where(inc, d, np.nan).astype(np.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for axes in ((1, 2), (0, 1), (0, 2), (2, 1), (0, 1, 2)):
+            cnt = np.sum(~np.isnan(filled), axis=axes)
+            exp = {"sum": np.where(cnt > 0, np.nansum(filled, axis=axes), np.nan), "mean": np.nanmean(filled, axis=axes),
+                   "std": np.nanstd(filled, axis=axes), "max": np.nanmax(filled, axis=axes), "min": np.nanmin(filled, axis=axes)}
+            for op in exp:
+                got = np.asarray(getattr(cube, op)(axis=axes), dtype=np.float64)
+                assert got.shape == np.shape(exp[op])
+                assert_close(got, exp[op], atol=1e-6 * np.nanmax(np.abs(exp[op])), what="%s axis=%s" % (op, axes))
     # reference known-answer table (float64 fixture cast to this path's fp32: rtol 1e-6)
     table = {"npts": 24, "mean": 0.4941651776136591, "sigma": 0.3021908870982011,
              "sum": 11.85996426272782, "sumsq": 7.961125988022091, "min": 0.0363300285196364,
