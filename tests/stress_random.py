@@ -61,6 +61,20 @@ for it in range(nround):
     close(ops.percentile_axis0(dd, 50.0, mask=spec).get(), O.median(d, inc), 0.0, tag + " median")
     q = float(rng.uniform(0, 100))
     close(ops.percentile_axis0(dd, q, mask=spec).get(), O.percentile(d.astype(np.float64), inc, q), 3e-6, tag + " pct")
+    # order statistics along y / x / the whole cube; argmax / argmin along the spatial axes
+    fz = O.filled(d, inc, np.nan).astype(np.float32)
+    mspec = spec if spec is not None else ops.MaskSpec()
+    with np.errstate(all="ignore"):
+        close(ops.percentile_axis0(dd.swap01(), 50.0, mask=mspec.swap01()).get(), np.nanmedian(fz, axis=1), 0.0, tag + " median ax1")
+        close(ops.percentile_axis0(ops.fill_masked_transposed(dd, spec).swap01(), 50.0).get(), np.nanmedian(fz, axis=2), 0.0, tag + " median ax2")
+        gm = np.float32(ops.percentile_global(dd, 50.0, mask=spec)); em = np.nanmedian(fz)
+        if not ((np.isnan(gm) and np.isnan(em)) or gm == em): fails += 1; print("FAIL", tag, "global median", gm, em, flush=True)
+        gq = ops.percentile_global(dd, q, mask=spec); eq_ = np.nanpercentile(fz.astype(np.float64), q) if np.isfinite(fz).any() else np.nan
+        if not ((np.isnan(gq) and np.isnan(eq_)) or abs(gq - eq_) <= 3e-6 * max(1.0, abs(eq_))): fails += 1; print("FAIL", tag, "global pct", q, gq, eq_, flush=True)
+    for ax in (1, 2):
+        ra = ops.argextrema_axis(dd, ax, mask=spec)
+        if not np.array_equal(ra["argmax"].get(), O.argmax(d, inc, axis=ax)): fails += 1; print("FAIL", tag, "argmax ax%d" % ax, flush=True)
+        if not np.array_equal(ra["argmin"].get(), O.argmin(d, inc, axis=ax)): fails += 1; print("FAIL", tag, "argmin ax%d" % ax, flush=True)
     # spectral smoothing (ring sizes + generic), fused moments
     nt = int(rng.choice([1, 3, 7, 9, 15, 33, 41]))
     k = np.abs(rng.standard_normal(nt)) + 0.05
