@@ -466,9 +466,10 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
         A.ntiles32 = ntiles;
         int ns = 1;
         if (ntiles < 4096) ns = (int)std::max<int64_t>(1, std::min<int64_t>((4096 + ntiles - 1) / ntiles, cube->nz / 64));
-        // at most 256 channels per block: neighbouring tiles (same XCD, see the kernel) then stay within a few
-        // stages of each other and find the source sectors they share in L2 (C5: 9.4 ms with 1024-channel
-        // chunks, 8.5 ms with 128 - 256, 9.4 with 64 where the per-block footprint set-up starts to show)
+        // at most 256 channels per block (C5: 9.4 ms with 1024-channel chunks, 8.5 ms with 128 - 256, 9.4 with 64
+        // where the per-block footprint set-up starts to show).  The gain is scheduling - four times more, shorter
+        // blocks even out the tail - not cache reuse: FETCH_SIZE stays at x1.70 of the algorithmic read
+        // (profiles/r01_pmc_traffic.txt), and walking each XCD's band in compact 8 x 4 tile patches changes nothing.
         A.zchunk_lds = std::min<int64_t>((cube->nz + ns - 1) / ns, 256);
         if (const char* zc = getenv("SPC_BILINEAR_ZCHUNK")) A.zchunk_lds = std::max(8, atoi(zc));
         A.zchunk_lds = ((A.zchunk_lds + kStageU - 1) / kStageU) * kStageU;
