@@ -768,3 +768,12 @@ def test_argmax_argmin_every_axis(gpu):
     assert not empty.argmax(axis=1).any() and not empty.argmin(axis=2).any()
     with pytest.raises(ValueError):
         cube.argmax(axis=3)
+
+
+def test_graft_entry_smoke(gpu):
+    """the driver's round-end smoke() (one small pass of the hot path on cuda:0 against the oracle)
+    stays runnable: interface changes must not break it unnoticed"""
+    import importlib, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
