@@ -151,6 +151,15 @@ class SpectralCube:
             if "BUNIT" in hdr:
                 meta["BUNIT"] = hdr["BUNIT"]
             table = io_fits.read_beams_table(os.fspath(data)) if "beams" not in kw else None
+            if table is not None and len(table["BMAJ"]) != dev.shape[0] and "POL" in table:
+                # full-polarisation tables list every channel once per Stokes plane (cube_utils._split_stokes
+                # hands each component its rows); this path reads one plane: keep the first polarisation's rows
+                keep = table["POL"] == table["POL"][0]
+                table = {k: v[keep] for k, v in table.items()}
+            if table is not None and len(table["BMAJ"]) != dev.shape[0]:
+                warnings.warn("BEAMS table with %d rows does not match the %d channels of the cube: ignored"
+                              % (len(table["BMAJ"]), dev.shape[0]), BeamWarning)
+                table = None
             if table is not None:            # a BEAMS extension makes it a varying-resolution cube (io/fits.py:216-228)
                 cls, kw = VaryingResolutionSpectralCube, dict(kw, beam_table=table)
             cube = cls(None, header=hdr, device=device, _dev=dev, meta=meta, **kw)

@@ -426,7 +426,7 @@ def read_beams_table(path):
     return None
 
 
-def append_beams_table(path, bmaj_deg, bmin_deg, bpa_deg):
+def append_beams_table(path, bmaj_deg, bmin_deg, bpa_deg, chan=None, pol=None):
     """Append a ``BEAMS`` BINTABLE HDU (arcsec / arcsec / deg, float32, + CHAN, POL int32) to an
     existing FITS file: what beams_to_bintable / VaryingResolutionSpectralCube.hdulist produce
     (dask_spectral_cube.py:1493-1509)."""
@@ -435,7 +435,9 @@ def append_beams_table(path, bmaj_deg, bmin_deg, bpa_deg):
     rec["BMAJ"] = np.asarray(bmaj_deg, dtype=np.float64) * 3600.0
     rec["BMIN"] = np.asarray(bmin_deg, dtype=np.float64) * 3600.0
     rec["BPA"] = bpa_deg
-    rec["CHAN"] = np.arange(n)
+    rec["CHAN"] = np.arange(n) if chan is None else chan
+    if pol is not None:
+        rec["POL"] = pol
     cards = [_card("XTENSION", "BINTABLE"), _card("BITPIX", 8), _card("NAXIS", 2), _card("NAXIS1", rec.dtype.itemsize),
              _card("NAXIS2", n), _card("PCOUNT", 0), _card("GCOUNT", 1), _card("TFIELDS", 5)]
     for i, (name, form, unit) in enumerate((("BMAJ", "1E", "arcsec"), ("BMIN", "1E", "arcsec"), ("BPA", "1E", "deg"),

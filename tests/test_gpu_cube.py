@@ -713,6 +713,22 @@ def test_varying_resolution_convolve_to(gpu, tmp_path):
     assert isinstance(again, VaryingResolutionSpectralCube)
     np.testing.assert_allclose([b.major for b in again.unmasked_beams], [b.major for b in cube.unmasked_beams],
                                rtol=1e-6, equal_nan=True)
+    # full-polarisation table (conftest prepare_4_beams_withfullpol: every channel once per Stokes plane):
+    # the first polarisation's rows are used; a table that cannot be matched is ignored with a warning
+    fp = tmp_path / "fullpol.fits"
+    io_fits.write_fits(str(fp), np.zeros((4, 5, 5), np.float32), str(golden("c1_moments.npz")["header"]))
+    io_fits.append_beams_table(str(fp), np.tile([0.4, 0.3, 0.3, 0.4], 4) / 3600, np.tile([0.1, 0.2, 0.2, 0.1], 4) / 3600,
+                               np.tile([0.0, 45.0, 60.0, 30.0], 4), chan=np.tile(np.arange(4), 4), pol=np.repeat(np.arange(4), 4))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fpc = SpectralCube.read(str(fp))
+    assert isinstance(fpc, VaryingResolutionSpectralCube) and [round(b.pa) for b in fpc.beams] == [0, 45, 60, 30]
+    bad = tmp_path / "badtable.fits"
+    io_fits.write_fits(str(bad), np.zeros((4, 5, 5), np.float32), str(golden("c1_moments.npz")["header"]))
+    io_fits.append_beams_table(str(bad), [1e-3] * 3, [1e-3] * 3, [0.0] * 3)
+    with pytest.warns(UserWarning, match="does not match"):
+        plain = SpectralCube.read(str(bad))
+    assert type(plain) is SpectralCube
     # the reference's own delta-cube case (test_regrid.py:59-79): every plane is the normalised kernel
     d = np.zeros((4, 5, 5), np.float32)
     d[:, 2, 2] = 1.0
