@@ -214,3 +214,55 @@ def test_c2_statistics_1024cubed_periodic_rows(gpu):
         r = ops.stats_axis(cube, ax, mask=mspec, want=("count", "sum"))
         assert int(r["count"].get().astype(np.int64).sum()) == int(st["npts"])
         assert float(np.nansum(r["sum"].get())) == pytest.approx(st["sum"], rel=1e-10)
+
+
+def test_c2_order_statistics_and_argextrema_1024cubed(gpu):
+    """SURVEY.md section 8f rank 4 and row a8 at configs[1] size (1024^3 + uint8 mask, a tile replicated
+    along y): the median of the whole cube equals the tile's (replication keeps every quantile) and splits
+    the counts (#{x < m} <= n/2 >= #{x > m}, counted by the statistics kernel with threshold predicates);
+    medians along z and x are periodic in y and equal the tile's, bit for bit; argmax / argmin along x are
+    the tile's, along y they point into the first period (first index wins ties)."""
+    shape, ty = (1024, 1024, 1024), 8
+    _need(shape[0] * shape[1] * shape[2] * 5 * 2)
+    tile = synth.gaussian_line_cube((shape[0], ty, shape[2]), synth.SEEDS["C2"], chunk_rows=ty)
+    tile[:, 2, 16:24] = np.nan
+    tmask = synth.boolean_mask(tile, synth.SEEDS["C2"]).astype(bool)
+    cube, mask = DeviceArray(shape, np.float32), DeviceArray(shape, np.uint8)
+    _replicate_rows(cube, tile, 4)
+    _replicate_rows(mask, tmask.astype(np.uint8), 1)
+    mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=mask)
+    filled = np.where(tmask, tile, np.nan).astype(np.float32)
+    rep = shape[1] // ty
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # whole cube
+        med = np.float32(ops.percentile_global(cube, 50.0, mask=mspec))
+        assert med == np.nanmedian(filled)
+        n = ops.stats_global(cube, mask=mspec)["npts"]
+        below = ops.stats_global(cube, mask=ops.MaskSpec(_lib.MASK_ARRAY | _lib.MASK_LT, 0.0, float(med), mask))["npts"]
+        above = ops.stats_global(cube, mask=ops.MaskSpec(_lib.MASK_ARRAY | _lib.MASK_GT, float(med), 0.0, mask))["npts"]
+        assert below <= n / 2 and above <= n / 2 and n == np.count_nonzero(~np.isnan(filled)) * rep
+        q90 = ops.percentile_global(cube, 90.0, mask=mspec)
+        e90 = np.nanpercentile(np.tile(filled.astype(np.float64), (1, 4, 1)), 90.0)       # 4 periods: the quantile converges fast
+        assert abs(q90 - e90) <= 1e-3 * abs(e90)
+        # along z: periodic in y, equal to the tile's
+        m0 = ops.percentile_axis0(cube, 50.0, mask=mspec).get().reshape(rep, ty, shape[2])
+        e0 = np.nanmedian(filled, axis=0)
+        assert np.array_equal(np.isnan(m0[0]), np.isnan(e0)) and np.array_equal(m0[0][~np.isnan(e0)], e0[~np.isnan(e0)])
+        assert np.array_equal(m0[rep // 2], m0[0], equal_nan=True) and np.array_equal(m0[-1], m0[0], equal_nan=True)
+        # along x (fill + transpose + selection): (nz, ny) periodic in y
+        m2 = ops.percentile_axis0(ops.fill_masked_transposed(cube, mspec).swap01(), 50.0).get().reshape(shape[0], rep, ty)
+        e2 = np.nanmedian(filled, axis=2)
+        assert np.array_equal(m2[:, 0], e2, equal_nan=True) and np.array_equal(m2[:, -1], e2, equal_nan=True)
+        # along y: the replicated ray has the tile ray's median
+        m1 = ops.percentile_axis0(cube.swap01(), 50.0, mask=mspec.swap01()).get()
+        e1 = np.nanmedian(filled, axis=1)
+        assert np.array_equal(m1, e1, equal_nan=True)
+    a2 = ops.argextrema_axis(cube, 2, mask=mspec)
+    for key, fn in (("argmax", O.argmax), ("argmin", O.argmin)):
+        got = a2[key].get().reshape(shape[0], rep, ty)
+        exp = fn(tile, tmask, axis=2)
+        assert np.array_equal(got[:, 0], exp) and np.array_equal(got[:, rep - 1], exp)
+    a1 = ops.argextrema_axis(cube, 1, mask=mspec)
+    assert np.array_equal(a1["argmax"].get(), O.argmax(tile, tmask, axis=1))          # first period wins the ties
+    assert np.array_equal(a1["argmin"].get(), O.argmin(tile, tmask, axis=1))
