@@ -75,11 +75,13 @@ class Projection(np.ndarray):
     """2-D result map (stands in for lower_dimensional_structures.Projection
     :246-292): an ndarray carrying unit, wcs and meta."""
 
-    def __new__(cls, value, unit="", wcs=None, meta=None):
+    def __new__(cls, value, unit="", wcs=None, meta=None, beam=None, device=0):
         obj = np.asarray(value).view(cls)
         obj.unit = unit
         obj.wcs = wcs
         obj.meta = dict(meta or {})
+        obj.beam = beam if beam is not None else obj.meta.get("beam")
+        obj._spc_device = device
         return obj
 
     def __array_finalize__(self, obj):
@@ -88,6 +90,51 @@ class Projection(np.ndarray):
         self.unit = getattr(obj, "unit", "")
         self.wcs = getattr(obj, "wcs", None)
         self.meta = getattr(obj, "meta", {})
+        self.beam = getattr(obj, "beam", None)
+        self._spc_device = getattr(obj, "_spc_device", 0)
+
+    def _celestial(self):
+        if self.ndim != 2 or self.wcs is None or getattr(self.wcs, "naxis", 0) < 2:
+            raise ValueError("WCS does not contain two spatial axes.")      # _raise_wcs_no_celestial
+        return self.wcs
+
+    def convolve_to(self, beam, convolve=None, **kwargs):
+        """Convolve the image to *beam* (lower_dimensional_structures.py:450-494): the kernel
+        ``beam.deconvolve(self.beam).as_kernel(pixscale)`` through the same NaN-aware 2-D stencils as
+        the cube (one channel), astropy's normalised 'interpolate' treatment."""
+        if convolve is not None or kwargs.get("nan_treatment", "interpolate") != "interpolate":
+            raise NotImplementedError("only astropy's default convolution (nan_treatment='interpolate') runs on the device")
+        w = self._celestial()
+        if self.beam is None:
+            raise ValueError("No beam is contained in Projection.meta.")
+        if beam == self.beam:
+            warnings.warn("The given beam is identical to the current beam. Skipping convolution.")
+            return self
+        psm = w.pixel_scale_matrix
+        pixscale = math.sqrt(abs(psm[0, 0] * psm[1, 1] - psm[0, 1] * psm[1, 0]))
+        karr = beam.deconvolve(self.beam).as_kernel(pixscale)
+        _lib.require_gpu()
+        img = DeviceArray.from_numpy(np.asarray(self, dtype=np.float32)[None], self._spc_device)
+        out = ops.spatial_conv(img, karr).get()[0].astype(self.dtype if self.dtype.kind == "f" else np.float32)
+        return Projection(out, unit=self.unit, wcs=self.wcs, meta=dict(self.meta, beam=beam), beam=beam, device=self._spc_device)
+
+    def reproject(self, header, order="bilinear"):
+        """Reproject the image onto the celestial WCS of *header* (lower_dimensional_structures.py:496-538):
+        bilinear, NaN outside the footprint - the cube's resampling kernel on one channel."""
+        if order not in ("bilinear", 1):
+            raise NotImplementedError("only order='bilinear' is built on the GPU path")
+        w = self._celestial()
+        newwcs = header if isinstance(header, SimpleWCS) else SimpleWCS(header, naxis=2)
+        hdr = newwcs.header
+        ny_out, nx_out = (int(hdr["NAXIS2"]), int(hdr["NAXIS1"])) if ("NAXIS1" in hdr and "NAXIS2" in hdr) else self.shape
+        xs, ys = reproject_pixel_map(w, newwcs, (ny_out, nx_out))
+        xs = np.where(np.isfinite(xs), xs, -1e30)
+        ys = np.where(np.isfinite(ys), ys, -1e30)
+        _lib.require_gpu()
+        img = DeviceArray.from_numpy(np.asarray(self, dtype=np.float32)[None], self._spc_device)
+        dev, _ = ops.resample_bilinear(img, xs, ys, fill=np.nan, want_footprint=False)
+        out = dev.get()[0].astype(self.dtype if self.dtype.kind == "f" else np.float32)
+        return Projection(out, unit=self.unit, wcs=newwcs, meta=dict(self.meta), beam=self.beam, device=self._spc_device)
 
     @property
     def value(self):
@@ -445,7 +492,8 @@ class SpectralCube:
         meta = {"moment_order": order, "moment_axis": axis}
         meta.update(self._meta)
         new_wcs = self._wcs.drop_spectral() if (self._wcs is not None and axis == 0) else None
-        return Projection(out, unit=unit, wcs=new_wcs, meta=meta)
+        beam = None if isinstance(self, VaryingResolutionSpectralCube) else self.beam
+        return Projection(out, unit=unit, wcs=new_wcs, meta=meta, beam=beam, device=self.device)
 
     def moment0(self, axis=0, how="auto"):
         return self.moment(axis=axis, order=0, how=how)
@@ -469,8 +517,9 @@ class SpectralCube:
         unit = _unit_mul(self._unit, self.spectral_unit) if order == 0 else _unit_pow(self.spectral_unit, max(order, 1))
         meta = {"moment_order": order, "moment_axis": 0}
         meta.update(self._meta)
+        beam = None if isinstance(self, VaryingResolutionSpectralCube) else self.beam
         return Projection(arr, unit=unit, wcs=self._wcs.drop_spectral() if self._wcs is not None else None,
-                          meta=meta)
+                          meta=meta, beam=beam, device=self.device)
 
     def linewidth_sigma(self, how="auto"):
         """sqrt(moment 2), no VarianceWarning (spectral_cube.py:1746-1753)."""

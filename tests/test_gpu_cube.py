@@ -793,3 +793,56 @@ def test_graft_entry_smoke(gpu):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     g = importlib.import_module("__graft_entry__")
     g.smoke()
+
+
+def test_projection_convolve_to_and_reproject(gpu):
+    """Projection.convolve_to / Projection.reproject (lower_dimensional_structures.py:450-538), written like
+    spectral_cube/tests/test_regrid.py:364-429: a 5 x 5 delta image with a 1" beam convolved to 1.8028" is
+    the normalised 1.5" Gaussian; moment maps carry the cube's beam; images without two celestial axes are
+    refused; reprojection of a moment map equals the cube's reprojection of the same plane."""
+    from spectral_cube_amd import Beam, Projection
+    pix = 5.555555555555e-4
+    hdr = {"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "CTYPE3": "VRAD", "CDELT1": -pix, "CDELT2": pix, "CDELT3": 1.0,
+           "CRPIX1": 3.0, "CRPIX2": 3.0, "CRPIX3": 1.0, "CRVAL1": 30.0, "CRVAL2": 20.0, "CRVAL3": 0.0, "CUNIT3": "km/s",
+           "BUNIT": "K", "BMAJ": 1.0 / 3600, "BMIN": 1.0 / 3600, "BPA": 0.0}
+    d = np.zeros((2, 5, 5), np.float32)
+    d[0, 2, 2] = 1.0
+    cube = SpectralCube.read(d, hdr)
+    proj = cube.moment0()
+    assert proj.beam == Beam(1.0 / 3600)
+    target = Beam(1.802775637731995 / 3600)
+    conv = proj.convolve_to(target)
+    sig = 1.5 / 2.3548200450309493 / (pix * 3600)
+    yy, xx = np.mgrid[-2:3, -2:3]
+    expected = np.exp(-0.5 * (xx * xx + yy * yy) / sig ** 2)
+    expected /= expected.sum()
+    np.testing.assert_almost_equal(np.asarray(conv) / cube._pix_size_slice(0), expected, decimal=6)
+    assert conv.beam == target and isinstance(conv, Projection) and conv.dtype == proj.dtype
+    with pytest.warns(UserWarning, match="identical"):
+        assert proj.convolve_to(Beam(1.0 / 3600)) is proj
+    with pytest.raises(NotImplementedError):
+        proj.convolve_to(target, nan_treatment="fill")
+    with pytest.raises(ValueError, match="two spatial axes"):
+        cube.moment0(axis=1).convolve_to(target)
+    nobeam = Projection(np.asarray(proj), wcs=proj.wcs)
+    with pytest.raises(ValueError, match="No beam"):
+        nobeam.convolve_to(target)
+    # reproject: the image path equals the cube path on the same plane
+    rng = np.random.default_rng(2)
+    big = rng.standard_normal((3, 40, 48)).astype(np.float32)
+    hb = dict(hdr, CRPIX1=24.5, CRPIX2=20.5)
+    cb = SpectralCube.read(big, hb)
+    c, s_ = np.cos(np.radians(20)), np.sin(np.radians(20))
+    target_hdr = dict(hb, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c, NAXIS=2, NAXIS1=44, NAXIS2=36)
+    for k in ("CTYPE3", "CDELT3", "CRPIX3", "CRVAL3", "CUNIT3"):
+        target_hdr.pop(k)
+    m0 = cb.moment0()
+    rp = m0.reproject(target_hdr)
+    assert rp.shape == (36, 44) and rp.beam == m0.beam
+    plane = SpectralCube.read(np.asarray(m0, dtype=np.float32)[None], hb).reproject(dict(target_hdr, **{"NAXIS": 2}))
+    exp = plane._device_data().get()[0]
+    got = np.asarray(rp)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.isnan(exp).any() and np.isfinite(exp).any()
+    np.testing.assert_array_equal(got[~np.isnan(exp)].astype(np.float32), exp[~np.isnan(exp)])
+    with pytest.raises(ValueError, match="two spatial axes"):
+        cb.moment0(axis=2).reproject(target_hdr)
