@@ -250,6 +250,13 @@ int spc_fill_masked_transpose_f32(int device, void* stream, const spc_cube_f32* 
  *                      *h_nchanged (HOST) = number of samples clipped by this call. */
 int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                         float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);
+/* per-ray clipping bounds of one iteration, all on the device: lo = centre - sigma_lower * std,
+ * hi = centre + sigma_upper * std over n rays.  centre = d_center (e.g. the median map) or, when
+ * NULL, the mean from d_count / d_sum / d_sumsq; std = d_spread (e.g. the mad_std map) or, when
+ * NULL, sqrt(max(sumsq / n - mean^2, 0)) - float64 arithmetic, float32 bounds like astropy's. */
+int spc_clip_bounds_f32(int device, void* stream, int64_t n, const int32_t* d_count, const double* d_sum,
+                        const double* d_sumsq, const float* d_center, const float* d_spread,
+                        double sigma_lower, double sigma_upper, float* d_lo, float* d_hi);
 int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, int64_t ny, int64_t nx,
                          const float* d_lo, const float* d_hi, uint64_t* h_nchanged);
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "spc_argextrema_axis_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _vp]),
     "spc_fill_masked_transpose_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp]),
     "spc_percentile_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), C.c_double, _i, _f, _P(C.c_double)]),
+    "spc_clip_bounds_f32": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
     "spc_pool_trim": (_i, [_i]),
     "spc_pool_stats": (_i, [_i, _P(C.c_int64), _P(C.c_int64)]),
     "spc_host_alloc": (_i, [_sz, _P(_vp)]),

@@ -430,6 +430,36 @@ __global__ __launch_bounds__(256) void fill_masked_transpose_kernel(const ClipAr
     }
 }
 
+// bounds of one sigma-clipping iteration, per ray: [centre - sigma_lower * std, centre + sigma_upper * std]
+// from the maps the other kernels left on the device (count / sum / sum of squares -> mean and std in
+// float64 exactly as numpy would from the same sums; or a median map as centre and a mad_std map as
+// spread), so that an iteration makes no host round trip besides the change counter.
+struct BoundsArgs {
+    const int32_t* cnt; const double* sum; const double* ssq;
+    const float* center; const float* spread;
+    double lo_s, hi_s;
+    float* lo; float* hi;
+    int64_t n;
+};
+__global__ __launch_bounds__(256) void clip_bounds_kernel(const BoundsArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    double mean = nan, sd = nan;
+    if (A.cnt) {
+        const int c = A.cnt[i];
+        if (c > 0) {
+            mean = A.sum[i] / (double)c;
+            const double var = __dsub_rn(A.ssq[i] / (double)c, __dmul_rn(mean, mean));    // no FMA contraction: numpy rounds twice
+            sd = (var != var) ? nan : sqrt(var > 0.0 ? var : 0.0);
+        }
+    }
+    const double cen = A.center ? (double)A.center[i] : mean;
+    if (A.spread) sd = (double)A.spread[i];
+    A.lo[i] = (float)__dsub_rn(cen, __dmul_rn(A.lo_s, sd));
+    A.hi[i] = (float)__dadd_rn(cen, __dmul_rn(A.hi_s, sd));
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void clip_outside_kernel(const ClipArgs A) {
     // lane = VEC adjacent x of one row, marching over its share of the planes (16-byte accesses when VEC == 4)
@@ -668,6 +698,19 @@ int spc_fill_masked_transpose_f32(int device, void* stream, const spc_cube_f32* 
     dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + 63) / 64), (unsigned)std::min<int64_t>(cube->nz, 1024));
     if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(fill_masked_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(fill_masked_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_clip_bounds_f32(int device, void* stream, int64_t n, const int32_t* d_count, const double* d_sum,
+                        const double* d_sumsq, const float* d_center, const float* d_spread,
+                        double sigma_lower, double sigma_upper, float* d_lo, float* d_hi) {
+    SPC_REQUIRE(n > 0 && d_lo && d_hi, "bad arguments");
+    SPC_REQUIRE((d_count && d_sum && d_sumsq) || (d_center && d_spread), "need the statistics maps or centre + spread maps");
+    SPC_REQUIRE(!d_count || (d_sum && d_sumsq), "count without sum / sumsq");
+    SPC_DEVICE(device);
+    BoundsArgs A{d_count, d_sum, d_sumsq, d_center, d_spread, sigma_lower, sigma_upper, d_lo, d_hi, n};
+    hipLaunchKernelGGL(clip_bounds_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }

@@ -424,30 +424,30 @@ def sigma_clip_axis0(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxite
         raise NotImplementedError("cenfunc must be 'median' or 'mean', stdfunc 'std' or 'mad_std' on the device path")
     work = fill_masked(cube, mask, np.nan, stream)
     nz, ny, nx = work.shape
+    dev = work.device
+    d_lo, d_hi = DeviceArray((ny, nx), np.float32, dev), DeviceArray((ny, nx), np.float32, dev)
+    need_stats = cenfunc == "mean" or stdfunc == "std"
+    st = None
     it = 0
     while maxiters is None or it < maxiters:
         it += 1
-        st = stats_axis(work, 0, want=("count", "sum", "sumsq"), stream=stream)
-        n = st["count"].get().astype(np.float64)
-        ssum, ssq = st["sum"].get(), st["sumsq"].get()
-        with np.errstate(invalid="ignore", divide="ignore"):
-            mean = np.where(n > 0, ssum / n, np.nan)
-            if cenfunc == "median":
-                med_dev = percentile_axis0(work, 50.0, stream=stream)
-                cen = med_dev.get().astype(np.float64)
-            else:
-                med_dev, cen = None, mean
-            if stdfunc == "std":
-                std = np.sqrt(np.maximum(np.where(n > 0, ssq / n - mean * mean, np.nan), 0.0))
-            else:
-                if med_dev is None:
-                    med_dev = percentile_axis0(work, 50.0, stream=stream)
-                std = percentile_axis0(work, 50.0, center=med_dev, scale=MAD_TO_STD, stream=stream).get().astype(np.float64)
-            lo = (cen - lo_s * std).astype(np.float32)
-            hi = (cen + hi_s * std).astype(np.float32)
-        d_lo, d_hi = DeviceArray.from_numpy(lo, work.device), DeviceArray.from_numpy(hi, work.device)
+        if need_stats:
+            st = stats_axis(work, 0, want=("count", "sum", "sumsq"), stream=stream, out=st)
+        med = percentile_axis0(work, 50.0, stream=stream) if (cenfunc == "median" or stdfunc == "mad_std") else None
+        spread = percentile_axis0(work, 50.0, center=med, scale=MAD_TO_STD, stream=stream) if stdfunc == "mad_std" else None
+        center = med if cenfunc == "median" else None
+        if center is None and spread is not None:          # mean centre with a mad_std spread: the mean map itself
+            n = st["count"].get().astype(np.float64)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                center = DeviceArray.from_numpy(np.where(n > 0, st["sum"].get() / n, np.nan).astype(np.float32), dev)
+        ptr = lambda a: C.c_void_p(a.ptr) if a is not None else None  # noqa: E731
+        use_stats = need_stats and (center is None or spread is None)
+        _lib.call("spc_clip_bounds_f32", dev, _sh(stream), ny * nx,
+                  ptr(st["count"]) if use_stats else None, ptr(st["sum"]) if use_stats else None,
+                  ptr(st["sumsq"]) if use_stats else None, ptr(center), ptr(spread), float(lo_s), float(hi_s),
+                  C.c_void_p(d_lo.ptr), C.c_void_p(d_hi.ptr))
         nch = C.c_uint64(0)
-        _lib.call("spc_clip_outside_f32", work.device, _sh(stream), C.c_void_p(work.ptr), nz, ny, nx,
+        _lib.call("spc_clip_outside_f32", dev, _sh(stream), C.c_void_p(work.ptr), nz, ny, nx,
                   C.c_void_p(d_lo.ptr), C.c_void_p(d_hi.ptr), C.byref(nch))
         if nch.value == 0:
             break
