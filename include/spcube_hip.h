@@ -329,6 +329,25 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube,
                           float* d_out, int64_t out_row_stride,
                           int64_t out_plane_stride);
 
+/* Pixel map of a reprojection, on the device: for every pixel of the target grid (wcs_out) the
+ * 0-based pixel coordinates in the source grid (wcs_in) - what reproject_interp obtains from
+ * astropy.wcs (pixel_to_world on the target, world_to_pixel on the source; spectral_cube.py:2700-2732).
+ * FITS paper II arithmetic in float64 for the zenithal projections TAN / SIN / ARC / STG / ZEA and
+ * CAR; pixels that cannot be projected get -1e30 (outside every footprint).  The host fills the
+ * struct from the header (spectral_cube_amd/wcs.py). */
+typedef struct spc_celestial_wcs {
+    int32_t proj;              /* 0 TAN, 1 SIN, 2 ARC, 3 STG, 4 ZEA, 5 CAR */
+    int32_t reserved;
+    double crpix[2];           /* FITS 1-based reference pixel (x, y) */
+    double lin[4];             /* CDELT_i * PC_ij, 2 x 2 row-major: degrees per pixel */
+    double lin_inv[4];         /* its inverse */
+    double alpha_p, delta_p;   /* celestial coordinates of the native pole (radians) */
+    double phi_p;              /* LONPOLE (radians) */
+} spc_celestial_wcs;
+int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs_out,
+                          const spc_celestial_wcs* wcs_in, int64_t ny_out, int64_t nx_out,
+                          double* d_xs, double* d_ys);
+
 /* bilinear spatial resample: replaces the inner resampler of
  * reproject.reproject_interp(order='bilinear') called from
  * BaseSpectralCube.reproject (spectral_cube.py:2700-2732).  d_xs, d_ys:

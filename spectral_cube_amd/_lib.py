@@ -56,6 +56,11 @@ class SpcMomentOutputs(C.Structure):
                 ("d_nvalid", C.c_void_p), ("out_row_stride", C.c_int64)]
 
 
+class SpcCelestialWcs(C.Structure):
+    _fields_ = [("proj", C.c_int32), ("reserved", C.c_int32), ("crpix", C.c_double * 2), ("lin", C.c_double * 4),
+                ("lin_inv", C.c_double * 4), ("alpha_p", C.c_double), ("delta_p", C.c_double), ("phi_p", C.c_double)]
+
+
 class SpcStatsOutputs(C.Structure):
     _fields_ = [("d_count", C.c_void_p), ("d_min", C.c_void_p), ("d_max", C.c_void_p),
                 ("d_sum", C.c_void_p), ("d_sumsq", C.c_void_p)]
@@ -83,6 +88,7 @@ SIGNATURES = {
     "spc_fill_masked_transpose_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp]),
     "spc_percentile_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), C.c_double, _i, _f, _P(C.c_double)]),
     "spc_clip_bounds_f32": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
+    "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _i64, _i64, _vp, _vp]),
     "spc_pool_trim": (_i, [_i]),
     "spc_pool_stats": (_i, [_i, _P(C.c_int64), _P(C.c_int64)]),
     "spc_host_alloc": (_i, [_sz, _P(_vp)]),

@@ -387,6 +387,79 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
     }
 }
 
+
+// ---- reprojection pixel map (FITS paper II, float64) ----------------------------------------------
+// Same sequence of operations as spectral_cube_amd/wcs.py (celestial_pix2world of the target followed
+// by celestial_world2pix of the source), which is validated against astropy.wcs; on the host this map
+// costs 0.8 s for 1024^2 pixels - a hundred times the resampling kernel it feeds.
+struct WcsPair { spc_celestial_wcs o, i; int64_t ny, nx; double* xs; double* ys; };
+
+__global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
+    const int64_t x = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int64_t y = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= A.nx || y >= A.ny) return;
+    const double D2R = 0.017453292519943295, R2D = 57.29577951308232, PI = 3.141592653589793;
+    // target pixel -> native spherical -> celestial
+    const double dx = (double)x + 1.0 - A.o.crpix[0], dy = (double)y + 1.0 - A.o.crpix[1];
+    const double px = A.o.lin[0] * dx + A.o.lin[1] * dy;
+    const double py = A.o.lin[2] * dx + A.o.lin[3] * dy;
+    double phi, theta;
+    if (A.o.proj == 5) {
+        phi = px * D2R; theta = py * D2R;
+    } else {
+        const double rr = hypot(px, py) * D2R;
+        phi = atan2(px, -py);
+        switch (A.o.proj) {
+            case 0: theta = atan2(1.0, rr); break;
+            case 1: theta = acos(fmin(fmax(rr, -1.0), 1.0)); break;
+            case 2: theta = PI / 2 - rr; break;
+            case 3: theta = PI / 2 - 2.0 * atan(rr / 2.0); break;
+            default: theta = PI / 2 - 2.0 * asin(fmin(fmax(rr / 2.0, -1.0), 1.0)); break;
+        }
+    }
+    double st = sin(theta), ct = cos(theta);
+    double dphi = phi - A.o.phi_p;
+    double sdp = sin(A.o.delta_p), cdp = cos(A.o.delta_p);
+    double lon = A.o.alpha_p + atan2(-ct * sin(dphi), st * cdp - ct * sdp * cos(dphi));
+    double lat = asin(fmin(fmax(st * sdp + ct * cdp * cos(dphi), -1.0), 1.0));
+    double lon_deg = fmod(lon * R2D, 360.0);
+    if (lon_deg < 0.0) lon_deg += 360.0;
+    lon = lon_deg * D2R;
+    lat = (lat * R2D) * D2R;
+    // celestial -> native unit vector of the source -> source pixel
+    const double da = lon - A.i.alpha_p;
+    const double sl = sin(lat), cl = cos(lat);
+    sdp = sin(A.i.delta_p); cdp = cos(A.i.delta_p);
+    const double xn = -cl * sin(da);
+    const double yn = sl * cdp - cl * sdp * cos(da);
+    const double zn = sl * sdp + cl * cdp * cos(da);
+    const double rho = hypot(xn, yn);
+    double ph = A.i.phi_p + atan2(xn, yn);
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    double ix, iy;
+    if (A.i.proj == 5) {
+        ph = fmod(ph + PI, 2 * PI);
+        if (ph < 0.0) ph += 2 * PI;
+        ph -= PI;
+        ix = ph * R2D; iy = atan2(zn, rho) * R2D;
+    } else {
+        double r;
+        switch (A.i.proj) {
+            case 0: r = zn > 0 ? R2D * rho / zn : nan; break;
+            case 1: r = zn >= 0 ? R2D * rho : nan; break;
+            case 2: r = R2D * atan2(rho, zn); break;
+            case 3: r = 2.0 * R2D * rho / (1.0 + zn); break;
+            default: r = 2.0 * R2D * rho / sqrt(2.0 * (1.0 + zn)); break;
+        }
+        ix = r * sin(ph); iy = -r * cos(ph);
+    }
+    double sx = A.i.lin_inv[0] * ix + A.i.lin_inv[1] * iy + A.i.crpix[0] - 1.0;
+    double sy = A.i.lin_inv[2] * ix + A.i.lin_inv[3] * iy + A.i.crpix[1] - 1.0;
+    const bool fin = (fabs(sx) <= 1.79e308) && (fabs(sy) <= 1.79e308);      // false for NaN / Inf
+    A.xs[y * A.nx + x] = fin ? sx : -1e30;
+    A.ys[y * A.nx + x] = fin ? sy : -1e30;
+}
+
 }  // namespace
 
 extern "C" {
@@ -422,6 +495,20 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube, co
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
     if (v4) hipLaunchKernelGGL((spectral_lerp_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL((spectral_lerp_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs_out, const spc_celestial_wcs* wcs_in,
+                          int64_t ny_out, int64_t nx_out, double* d_xs, double* d_ys) {
+    SPC_REQUIRE(wcs_out && wcs_in && d_xs && d_ys, "NULL pointer argument");
+    SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
+    SPC_REQUIRE(wcs_out->proj >= 0 && wcs_out->proj <= 5 && wcs_in->proj >= 0 && wcs_in->proj <= 5, "unknown projection code");
+    SPC_REQUIRE((ny_out + 3) / 4 <= 65535, "too many rows for one launch");
+    SPC_DEVICE(device);
+    WcsPair A{*wcs_out, *wcs_in, ny_out, nx_out, d_xs, d_ys};
+    hipLaunchKernelGGL(wcs_pixel_map_kernel, dim3((unsigned)((nx_out + 63) / 64), (unsigned)((ny_out + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }

@@ -288,16 +288,46 @@ def spectral_lerp(cube, lo, t, inv_dx, fill=np.nan, mask=None, out=None, stream=
     return out
 
 
+def _wcs_struct(w):
+    code, crpix, lin, inv, ap, dp, php = w.celestial_params()
+    s = _lib.SpcCelestialWcs()
+    s.proj = code
+    s.crpix[0], s.crpix[1] = crpix
+    for i in range(4):
+        s.lin[i], s.lin_inv[i] = lin[i], inv[i]
+    s.alpha_p, s.delta_p, s.phi_p = ap, dp, php
+    return s
+
+
+def wcs_pixel_map(wcs_in, wcs_out, shape_out, device=0, stream=None):
+    """(xs, ys) float64 DeviceArrays: source-grid pixel coordinates of every pixel of the target grid,
+    computed on the device (spc_wcs_pixel_map_f64; the host version is wcs.reproject_pixel_map).
+    Pixels that cannot be projected hold -1e30."""
+    ny, nx = (int(n) for n in shape_out)
+    d_xs, d_ys = DeviceArray((ny, nx), np.float64, device), DeviceArray((ny, nx), np.float64, device)
+    so, si = _wcs_struct(wcs_out), _wcs_struct(wcs_in)
+    _lib.call("spc_wcs_pixel_map_f64", device, _sh(stream), C.byref(so), C.byref(si), ny, nx,
+              C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr))
+    return d_xs, d_ys
+
+
 def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_footprint=True, out=None):
     """bilinear spatial resample of every channel at (xs, ys) source pixel
-    coordinates (resampler of reproject_interp, spectral_cube.py:2726-2732)."""
+    coordinates (resampler of reproject_interp, spectral_cube.py:2726-2732).  xs, ys: host arrays or
+    float64 DeviceArrays (wcs_pixel_map)."""
     dev = cube.device
-    xs = np.ascontiguousarray(xs, dtype=np.float64)
-    ys = np.ascontiguousarray(ys, dtype=np.float64)
-    if xs.shape != ys.shape or xs.ndim != 2:
-        raise ValueError("xs, ys must be 2-D maps of identical shape")
-    ny_out, nx_out = xs.shape
-    d_xs, d_ys = DeviceArray.from_numpy(xs, dev), DeviceArray.from_numpy(ys, dev)
+    if isinstance(xs, DeviceArray) and isinstance(ys, DeviceArray):
+        if xs.dtype != np.float64 or ys.dtype != np.float64 or xs.shape != ys.shape or len(xs.shape) != 2:
+            raise ValueError("xs, ys must be 2-D float64 maps of identical shape")
+        d_xs, d_ys = xs, ys
+        ny_out, nx_out = xs.shape
+    else:
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        if xs.shape != ys.shape or xs.ndim != 2:
+            raise ValueError("xs, ys must be 2-D maps of identical shape")
+        ny_out, nx_out = xs.shape
+        d_xs, d_ys = DeviceArray.from_numpy(xs, dev), DeviceArray.from_numpy(ys, dev)
     if out is None:
         out = DeviceArray((cube.shape[0], ny_out, nx_out), np.float32, dev)
     elif out.shape != (cube.shape[0], ny_out, nx_out) or out.dtype != np.float32 or getattr(out, "_is_view", False):

@@ -147,6 +147,16 @@ class SimpleWCS:
     def _lin2(self):
         return (self.cdelt[:, None] * self.pc)[:2, :2]
 
+    def celestial_params(self):
+        """the numbers spc_wcs_pixel_map_f64 needs (include/spcube_hip.h: spc_celestial_wcs):
+        (proj code, crpix (x, y), lin 2x2, lin^-1 2x2, alpha_p, delta_p, phi_p)"""
+        if self.naxis < 2 or not self.proj:
+            raise ValueError("WCS does not contain two spatial axes.")
+        code = {"TAN": 0, "SIN": 1, "ARC": 2, "STG": 3, "ZEA": 4, "CAR": 5}[self.proj]
+        m = self._lin2()
+        return (code, (float(self.crpix[0]), float(self.crpix[1])), tuple(m.ravel()), tuple(np.linalg.inv(m).ravel()),
+                float(self._ap), float(self._dp), float(self._php))
+
     def celestial_pix2world(self, px, py):
         """0-based pixel -> (lon, lat) degrees."""
         px = np.asarray(px, dtype=np.float64)

@@ -624,3 +624,43 @@ def test_device_buffer_pool(gpu):
         outs.append(res.stdout.split())
     assert outs[0][0] == outs[1][0] == outs[2][0] == repr(float(ref["m0"].sum()))
     assert outs[0][1] == "0" and int(outs[1][1]) <= 4096
+
+
+@pytest.mark.parametrize("proj", ["TAN", "SIN", "ARC", "STG", "ZEA", "CAR"])
+def test_wcs_pixel_map_device_vs_host(gpu, proj):
+    """spc_wcs_pixel_map_f64 against spectral_cube_amd.wcs.reproject_pixel_map (numpy, validated against
+    astropy.wcs in tests/test_oracle_golden.py): rotated + shifted + rescaled target grids, every supported
+    projection on either side, a high-latitude field, non-projectable pixels -> -1e30.  Tolerance 1e-9 pixel
+    (libm vs device trigonometry)."""
+    from spectral_cube_amd import ops
+    from spectral_cube_amd.wcs import SimpleWCS, reproject_pixel_map
+    base = {"CTYPE1": "RA---" + proj, "CTYPE2": "DEC--" + proj, "CRVAL1": 150.0, "CRVAL2": 2.0 if proj != "CAR" else 0.0,
+            "CRPIX1": 40.5, "CRPIX2": 33.0, "CDELT1": -2.0 / 3600, "CDELT2": 2.0 / 3600, "NAXIS": 2}
+    c, s_ = np.cos(np.radians(33)), np.sin(np.radians(33))
+    cases = [
+        (base, dict(base, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c, CRPIX1=31.0), (57, 70)),
+        (base, dict(base, CTYPE1="RA---TAN", CTYPE2="DEC--TAN", CDELT1=-3.1 / 3600, CDELT2=3.1 / 3600, CRVAL1=150.01), (64, 48)),
+        (dict(base, CTYPE1="RA---SIN", CTYPE2="DEC--SIN", CRVAL2=2.0), dict(base, CRVAL1=149.98, CRVAL2=base["CRVAL2"] + 0.01), (33, 129)),
+    ]
+    if proj != "CAR":
+        hi = dict(base, CRVAL2=88.5, CDELT1=-60.0 / 3600, CDELT2=60.0 / 3600)
+        cases.append((hi, dict(hi, CRVAL1=200.0, CRVAL2=87.9), (50, 50)))
+    for h_in, h_out, shape in cases:
+        w_in, w_out = SimpleWCS(h_in, naxis=2), SimpleWCS(h_out, naxis=2)
+        ex, ey = reproject_pixel_map(w_in, w_out, shape)
+        d_xs, d_ys = ops.wcs_pixel_map(w_in, w_out, shape)
+        gx, gy = d_xs.get(), d_ys.get()
+        bad = ~(np.isfinite(ex) & np.isfinite(ey))
+        assert np.array_equal(gx == -1e30, bad) and np.array_equal(gy == -1e30, bad)
+        assert np.abs(gx[~bad] - ex[~bad]).max() < 1e-9 and np.abs(gy[~bad] - ey[~bad]).max() < 1e-9
+    # pixels beyond the horizon of a wide SIN / TAN field are not projectable
+    wide = {"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "CRVAL1": 10.0, "CRVAL2": 0.0, "CRPIX1": 16.0, "CRPIX2": 16.0,
+            "CDELT1": -8.0, "CDELT2": 8.0, "NAXIS": 2}
+    car = {"CTYPE1": "RA---CAR", "CTYPE2": "DEC--CAR", "CRVAL1": 10.0, "CRVAL2": 0.0, "CRPIX1": 16.0, "CRPIX2": 16.0,
+           "CDELT1": -11.0, "CDELT2": 5.5, "NAXIS": 2}
+    w_in, w_out = SimpleWCS(wide, naxis=2), SimpleWCS(car, naxis=2)
+    ex, ey = reproject_pixel_map(w_in, w_out, (32, 32))
+    gx, gy = (a.get() for a in ops.wcs_pixel_map(w_in, w_out, (32, 32)))
+    bad = ~(np.isfinite(ex) & np.isfinite(ey))
+    assert bad.any() and (~bad).any() and np.array_equal(gx == -1e30, bad)
+    assert np.abs(gx[~bad] - ex[~bad]).max() < 1e-9 and np.abs(gy[~bad] - ey[~bad]).max() < 1e-9
