@@ -188,6 +188,31 @@ def sharded_moments(strip_cube, ny_total, comm, orders=(0, 1, 2)):
     return out
 
 
+def combine_statistics(parts):
+    """statistics() of a cube from the per-strip records {npts, min, max, sum, sumsq} (the aggregation step
+    of DaskSpectralCubeMixin.statistics, dask_spectral_cube.py:795-814, across ranks instead of chunks)."""
+    npts = sum(int(p["npts"]) for p in parts)
+    live = [p for p in parts if int(p["npts"]) > 0]
+    out = {"npts": npts,
+           "min": min((float(p["min"]) for p in live), default=float("nan")),
+           "max": max((float(p["max"]) for p in live), default=float("nan")),
+           "sum": float(sum(float(p["sum"]) for p in live)), "sumsq": float(sum(float(p["sumsq"]) for p in live))}
+    with np.errstate(invalid="ignore", divide="ignore"):      # same formulae as SpectralCube.statistics
+        out["mean"] = out["sum"] / npts if npts else float("nan")
+        out["sigma"] = float(np.sqrt((out["sumsq"] - out["sum"] ** 2 / npts) / (npts - 1))) if npts > 1 else float("nan")
+        out["rms"] = float(np.sqrt(out["sumsq"] / npts)) if npts else float("nan")
+    return out
+
+
+def sharded_statistics(strip_stats, group=None):
+    """statistics() of a row-sharded cube: every rank passes the record of ITS strip (ops.stats_global on
+    the device, one pass), five numbers per rank travel through torch.distributed.all_gather_object."""
+    import torch.distributed as dist
+    parts = [None] * dist.get_world_size(group)
+    dist.all_gather_object(parts, {k: float(strip_stats[k]) for k in ("npts", "min", "max", "sum", "sumsq")}, group=group)
+    return combine_statistics(parts)
+
+
 def sharded_smooth_moment0(strip_cube, kernel, ny_total, comm):
     """config C4 (spatial_smooth -> moment0) on row strips WITHOUT halo exchange: when every voxel
     is valid, smoothing commutes with the sum along the spectral axis, so each rank reduces its

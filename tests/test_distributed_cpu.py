@@ -18,7 +18,7 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "o
 import torch.distributed as dist
 import oracle_np as O
 from spectral_cube_amd import synth
-from spectral_cube_amd.distributed import HostGatherComm, strip_bounds
+from spectral_cube_amd.distributed import HostGatherComm, strip_bounds, sharded_statistics
 dist.init_process_group("gloo", init_method="env://")
 rank, ws = dist.get_rank(), dist.get_world_size()
 shape = (24, 9, 5)                     # 9 rows over 2 ranks: strips of 5 and 4 rows
@@ -29,7 +29,12 @@ y0, y1 = strip_bounds(shape[1], ws, rank)
 comm = HostGatherComm()
 full = [comm.allgather_rows(O.moment(d[:, y0:y1], inc[:, y0:y1], o, cen, 2.0), shape[1]) for o in range(3)]
 ids = comm.allgather_rows(O.argmax(d[:, y0:y1], inc[:, y0:y1]), shape[1])
+st = sharded_statistics(O.statistics(d[:, y0:y1], inc[:, y0:y1]))
 comm.barrier()
+es = O.statistics(d, inc)
+assert st["npts"] == es["npts"] and st["min"] == es["min"] and st["max"] == es["max"]
+for k in ("sum", "sumsq", "mean", "sigma", "rms"):
+    assert abs(st[k] - es[k]) <= 1e-12 * abs(es[k]), k
 if rank == 0:
     for o in range(3):
         exp = O.moment(d, inc, o, cen, 2.0)
