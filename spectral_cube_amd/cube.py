@@ -102,8 +102,10 @@ class Projection(np.ndarray):
         """Convolve the image to *beam* (lower_dimensional_structures.py:450-494): the kernel
         ``beam.deconvolve(self.beam).as_kernel(pixscale)`` through the same NaN-aware 2-D stencils as
         the cube (one channel), astropy's normalised 'interpolate' treatment."""
-        if convolve is not None or kwargs.get("nan_treatment", "interpolate") != "interpolate":
-            raise NotImplementedError("only astropy's default convolution (nan_treatment='interpolate') runs on the device")
+        treat = kwargs.pop("nan_treatment", "interpolate")
+        if convolve is not None or treat not in ("interpolate", "fill") or kwargs.pop("fill_value", 0.0) != 0.0 or kwargs:
+            raise NotImplementedError("the device stencil is astropy.convolution.convolve with boundary='fill', "
+                                      "fill_value=0, normalize_kernel=True and nan_treatment 'interpolate' or 'fill'")
         w = self._celestial()
         if self.beam is None:
             raise ValueError("No beam is contained in Projection.meta.")
@@ -114,7 +116,10 @@ class Projection(np.ndarray):
         pixscale = math.sqrt(abs(psm[0, 0] * psm[1, 1] - psm[0, 1] * psm[1, 0]))
         karr = beam.deconvolve(self.beam).as_kernel(pixscale)
         _lib.require_gpu()
-        img = DeviceArray.from_numpy(np.asarray(self, dtype=np.float32)[None], self._spc_device)
+        pix = np.asarray(self, dtype=np.float32)
+        if treat == "fill":                  # astropy: NaN -> fill_value (0), plain normalised convolution
+            pix = np.where(np.isnan(pix), np.float32(0.0), pix)
+        img = DeviceArray.from_numpy(pix[None], self._spc_device)
         out = ops.spatial_conv(img, karr).get()[0].astype(self.dtype if self.dtype.kind == "f" else np.float32)
         return Projection(out, unit=self.unit, wcs=self.wcs, meta=dict(self.meta, beam=beam), beam=beam, device=self._spc_device)
 
@@ -729,7 +734,9 @@ class SpectralCube:
         return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
 
     def spatial_smooth(self, kernel, convolve=None, raise_error_jybm=True, **kwargs):
-        """Smooth every channel with a 2-D kernel (dask_spectral_cube.py:962-993)."""
+        """Smooth every channel with a 2-D kernel (dask_spectral_cube.py:962-993).  Extra keyword
+        arguments are accepted and not used - exactly what the Dask class does with them (its
+        convolve_wrapper only receives ``kernel``, :990-993; spectral_smooth likewise, :912-917)."""
         self.check_jybeam_smoothing(raise_error_jybm=raise_error_jybm)
         karr = kernel_array(kernel, 2)
         if convolve is not None:

@@ -820,8 +820,12 @@ def test_projection_convolve_to_and_reproject(gpu):
     assert conv.beam == target and isinstance(conv, Projection) and conv.dtype == proj.dtype
     with pytest.warns(UserWarning, match="identical"):
         assert proj.convolve_to(Beam(1.0 / 3600)) is proj
+    holed = Projection(np.where(np.arange(25).reshape(5, 5) == 7, np.nan, np.asarray(proj)), wcs=proj.wcs, beam=proj.beam)
+    filled = holed.convolve_to(target, nan_treatment="fill")                       # test_regrid.py:386 passes this kwarg
+    np.testing.assert_almost_equal(np.asarray(filled), np.asarray(conv), decimal=6)     # the hole counts as a zero
+    assert np.isnan(np.asarray(holed.convolve_to(target))).sum() == 0                   # 'interpolate' fills it too
     with pytest.raises(NotImplementedError):
-        proj.convolve_to(target, nan_treatment="fill")
+        proj.convolve_to(target, boundary="wrap")
     with pytest.raises(ValueError, match="two spatial axes"):
         cube.moment0(axis=1).convolve_to(target)
     nobeam = Projection(np.asarray(proj), wcs=proj.wcs)
