@@ -566,14 +566,7 @@ def test_spatial_conv_very_wide_separable(gpu, nk):
         assert np.max(np.abs(got[fin] - exp[fin])) <= 2e-5 * np.max(np.abs(exp[fin]))
 
 
-def test_device_buffer_pool(gpu):
-    """spc_malloc / spc_free pool (include/spcube_hip.h): a freed block is handed out again for a
-    request of the same size, its content is whatever the new owner writes (no stale reads through
-    the ops), idle bytes are reported and count as free memory, trim gives them back, and a
-    subprocess with SPC_POOL=0 / a tiny SPC_POOL_MAX_BYTES still computes the same moments."""
-    import subprocess, sys, os
-    from spectral_cube_amd import ops
-    from spectral_cube_amd.device import DeviceArray, pool_stats, pool_trim, device_info
+def _pool_accounting(DeviceArray, pool_stats, pool_trim, device_info):
     pool_trim(0)
     live0, idle0 = pool_stats(0)
     assert idle0 == 0
@@ -596,6 +589,23 @@ def test_device_buffer_pool(gpu):
     pool_trim(0)
     assert pool_stats(0) == (live0, 0)
     assert device_info(0)["free_mem"] >= free_with_idle - (8 << 20)
+
+
+def test_device_buffer_pool(gpu):
+    """spc_malloc / spc_free pool (include/spcube_hip.h): a freed block is handed out again for a
+    request of the same size, its content is whatever the new owner writes (no stale reads through
+    the ops), idle bytes are reported and count as free memory, trim gives them back, and a
+    subprocess with SPC_POOL=0 / a tiny SPC_POOL_MAX_BYTES still computes the same moments."""
+    import subprocess, sys, os
+    from spectral_cube_amd import ops
+    from spectral_cube_amd.device import DeviceArray, pool_stats, pool_trim, device_info
+    import gc
+    gc.collect()                # cubes of earlier tests sit in reference cycles (cube <-> LazyMask): release their
+    gc.disable()                # buffers now, and keep the collector from doing it in the middle of the accounting
+    try:
+        _pool_accounting(DeviceArray, pool_stats, pool_trim, device_info)
+    finally:
+        gc.enable()
     # reuse through the ops: results do not depend on what the recycled buffers held before
     rng = np.random.default_rng(5)
     d = rng.standard_normal((40, 24, 32)).astype(np.float32)
