@@ -20,6 +20,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _need(nbytes):
+    import gc
+    gc.collect()            # cubes of earlier tests live in reference cycles (cube <-> LazyMask) until collected
     free = device_info(0)["free_mem"]
     if free < nbytes * 1.05:
         pytest.skip("needs %.0f GiB of HBM, %.0f GiB free" % (nbytes / 2**30, free / 2**30))
