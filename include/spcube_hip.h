@@ -193,6 +193,11 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube,
  * maps are C-contiguous with the reduced axis removed: (ny,nx), (nz,nx), (nz,ny).
  * NULL outputs are skipped.  A ray without included samples gives count 0 and
  * NaN in the four floating maps (nansum_allbadtonan, nanmin / nanmax of all-NaN). */
+/* The same five numbers for every channel: h_stats (HOST) = nz records {npts, min, max, sum, sumsq}
+ * of the (ny,nx) planes - the nan-reductions with axis=(1, 2), e.g. the mean spectrum cube.mean(axis=(1, 2)). */
+int spc_stats_planes_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                         double* h_stats);
+
 typedef struct spc_stats_outputs {
     int32_t* d_count;
     float* d_min;

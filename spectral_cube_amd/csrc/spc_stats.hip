@@ -131,6 +131,66 @@ __global__ __launch_bounds__(256) void stats_global_kernel(const StatArgs A) {
     }
 }
 
+// ---- per channel: statistics of every (ny, nx) plane (sum / mean / ... with axis=(1, 2): spectra) -------
+// grid = (segments, nz): a block streams its share of one plane, one partial record per block; the host adds
+// the few segments of a plane.  Contiguous planes are read as one run of 16-byte loads, strided ones row by row.
+template <bool ARR>
+__global__ __launch_bounds__(256) void stats_planes_kernel(const StatArgs A) {
+    __shared__ double s_red[4][5];
+    Acc a = acc_zero();
+    const int t = threadIdx.x;
+    const int64_t z = blockIdx.y;
+    const bool flat = (A.row_stride == A.nx) && (!ARR || A.mask.row_stride == A.nx);
+    const int64_t nrows = flat ? 1 : A.ny, rowlen = flat ? A.ny * A.nx : A.nx;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = 0; r < nrows; ++r) {
+        const float* p = A.cube + z * A.plane_stride + r * A.row_stride;
+        const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + r * A.mask.row_stride : nullptr;
+        const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
+        const int64_t n4 = al ? rowlen / 4 : 0;
+        constexpr int U = 4;
+        int64_t i = (int64_t)blockIdx.x * 256 + t;
+        for (; i + (U - 1) * stride < n4; i += U * stride) {
+            f32x4 v[U];
+            uint32_t m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i + u * stride);
+                m[u] = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm) + i + u * stride) : 0x01010101u;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc_add(a, v[u][c], included(A.mask, v[u][c], (m[u] >> (8 * c)) & 0xffu));
+        }
+        for (; i < n4; i += stride) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
+            const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[i] : 0x01010101u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu));
+        }
+        for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * 256 + t; j < rowlen; j += stride) {
+            const float v = p[j];
+            acc_add(a, v, included(A.mask, v, ARR ? pm[j] : 1u));
+        }
+    }
+    a = acc_wave_reduce(a);
+    const int w = t >> 6;
+    if ((t & 63) == 0) {
+        s_red[w][0] = (double)a.cnt; s_red[w][1] = (double)a.mn; s_red[w][2] = (double)a.mx;
+        s_red[w][3] = a.sum; s_red[w][4] = a.ssq;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double* o = A.partial + (z * gridDim.x + blockIdx.x) * 5;
+        o[0] = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+        o[1] = fmin(fmin(s_red[0][1], s_red[1][1]), fmin(s_red[2][1], s_red[3][1]));
+        o[2] = fmax(fmax(s_red[0][2], s_red[1][2]), fmax(s_red[2][2], s_red[3][2]));
+        o[3] = (s_red[0][3] + s_red[1][3]) + (s_red[2][3] + s_red[3][3]);
+        o[4] = (s_red[0][4] + s_red[1][4]) + (s_red[2][4] + s_red[3][4]);
+    }
+}
+
 __device__ __forceinline__ void write_outputs(const StatArgs& A, int64_t o, const Acc& a) {
     if (A.o_cnt) A.o_cnt[o] = a.cnt;
     if (A.o_min) A.o_min[o] = a.cnt ? a.mn : NAN;        // nanmin / nanmax of an all-NaN ray is NaN
@@ -543,6 +603,45 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, con
     h_stats[2] = cnt > 0 ? mx : NAN;
     h_stats[3] = (double)sum;
     h_stats[4] = (double)ssq;
+    return SPC_OK;
+}
+
+int spc_stats_planes_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, double* h_stats) {
+    SPC_REQUIRE(h_stats != nullptr, "h_stats is NULL");
+    StatArgs A{};
+    int rc = fill_common(A, cube, mask);
+    if (rc) return rc;
+    SPC_REQUIRE(A.nz <= 65535, "more than 65535 channels per call not supported (split the call)");
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    // enough blocks for the chip even with few channels; a segment should still have a few thousand samples
+    const int64_t plane = A.ny * A.nx;
+    int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + A.nz - 1) / A.nz, (plane + 16383) / 16384));
+    nseg = std::min(nseg, 64);
+    const size_t nrec = (size_t)A.nz * nseg;
+    double* d_partial = nullptr;
+    SPC_HIP(spc_scratch_alloc((void**)&d_partial, sizeof(double) * 5 * nrec, st));
+    A.partial = d_partial;
+    dim3 grid((unsigned)nseg, (unsigned)A.nz);
+    if (arr) hipLaunchKernelGGL(stats_planes_kernel<true>, grid, dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(stats_planes_kernel<false>, grid, dim3(256), 0, st, A);
+    hipError_t e = hipGetLastError();
+    std::vector<double> h(5 * nrec);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_partial, sizeof(double) * 5 * nrec, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)spc_scratch_free(d_partial, st);
+    SPC_HIP(e);
+    for (int64_t z = 0; z < A.nz; ++z) {
+        double cnt = 0.0, mn = INFINITY, mx = -INFINITY;
+        long double sum = 0.0L, ssq = 0.0L;
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            const double* r = &h[((size_t)z * nseg + sgm) * 5];
+            cnt += r[0]; mn = std::min(mn, r[1]); mx = std::max(mx, r[2]); sum += r[3]; ssq += r[4];
+        }
+        double* o = h_stats + z * 5;
+        o[0] = cnt; o[1] = cnt > 0 ? mn : NAN; o[2] = cnt > 0 ? mx : NAN; o[3] = (double)sum; o[4] = (double)ssq;
+    }
     return SPC_OK;
 }
 

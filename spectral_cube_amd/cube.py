@@ -590,6 +590,10 @@ class SpectralCube:
                 return self._reduce(op, axes[0], ddof)
             if len(axes) != 2 or any(a not in (0, 1, 2) for a in axes):
                 raise ValueError("axis must be None, 0, 1, 2 or a tuple of these")
+            if axes == [1, 2]:                           # per channel (spectra): one dedicated pass, nz records
+                vals = ops.stats_planes(self._device_data(), mask=self._mask_spec())
+                axis = (1, 2)
+                return self._finish_reduce(op, vals, axis, ddof)
             first, second = axes[1], axes[0]            # drop the higher axis on the device, the lower one here
             r = ops.stats_axis(self._device_data(), first, mask=self._mask_spec(), want=need)
             part = {k: r[k].get().astype(np.float64) for k in need}
@@ -609,6 +613,9 @@ class SpectralCube:
                 raise ValueError("axis must be None, 0, 1 or 2")
             r = ops.stats_axis(self._device_data(), axis, mask=self._mask_spec(), want=need)
             vals = {k: r[k].get().astype(np.float64) for k in need}
+        return self._finish_reduce(op, vals, axis, ddof)
+
+    def _finish_reduce(self, op, vals, axis, ddof=0):
         n = vals["count"]
         with np.errstate(invalid="ignore", divide="ignore"):
             if op == "sum":

@@ -356,6 +356,17 @@ def stats_global(cube, mask=None, stream=None):
     return {"npts": h[0], "min": h[1], "max": h[2], "sum": h[3], "sumsq": h[4]}
 
 
+def stats_planes(cube, mask=None, stream=None):
+    """{count, min, max, sum, sumsq} -> float64 arrays of length nz: the statistics of every channel's
+    plane in ONE pass (nan-reductions with axis=(1, 2): spectra).  Synchronises."""
+    nz = cube.shape[0]
+    buf = (C.c_double * (5 * nz))()
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_stats_planes_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), buf)
+    a = np.frombuffer(buf, dtype=np.float64).reshape(nz, 5)
+    return {"count": a[:, 0].copy(), "min": a[:, 1].copy(), "max": a[:, 2].copy(), "sum": a[:, 3].copy(), "sumsq": a[:, 4].copy()}
+
+
 def stats_axis(cube, axis, mask=None, want=STAT_KEYS, stream=None, out=None):
     """count / min / max / sum / sumsq maps along *axis* in ONE pass (the nan-reductions behind
     sum / mean / std / max / min, dask_spectral_cube.py:641-767).  Returns DeviceArrays

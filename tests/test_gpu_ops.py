@@ -3,6 +3,8 @@
 Tolerances: outputs within 1e-5 * scale of the float64
 oracle, NaN patterns identical, integer maps bit-exact.
 """
+import warnings
+
 import numpy as np
 import pytest
 
@@ -674,3 +676,34 @@ def test_wcs_pixel_map_device_vs_host(gpu, proj):
     bad = ~(np.isfinite(ex) & np.isfinite(ey))
     assert bad.any() and (~bad).any() and np.array_equal(gx == -1e30, bad)
     assert np.abs(gx[~bad] - ex[~bad]).max() < 1e-9 and np.abs(gy[~bad] - ey[~bad]).max() < 1e-9
+
+
+@pytest.mark.parametrize("shape", [(7, 33, 64), (70, 5, 13), (3, 130, 257)])
+def test_stats_planes(gpu, shape):
+    """spc_stats_planes_f32 (nan-reductions with axis=(1, 2): one record per channel) against numpy on the
+    filled data: contiguous planes, odd shapes (scalar tail), a uint8 mask + threshold predicate, and a strided
+    row view (planes read row by row); an empty channel gives count 0 and NaN extrema."""
+    from spectral_cube_amd import ops, _lib
+    rng = np.random.default_rng(sum(shape))
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[rng.random(shape) < 0.1] = np.nan
+    inc = rng.random(shape) < 0.7
+    inc[1] = False
+    dd = _dev(d)
+    for include, spec in ((None, None), (inc, _mspec(inc)), ((d > -0.2) & inc, _mspec(inc, _lib.MASK_GT, -0.2))):
+        f = np.where(np.isnan(d) | (False if include is None else ~include), np.nan, d).astype(np.float64)
+        got = ops.stats_planes(dd, mask=spec)
+        cnt = np.sum(~np.isnan(f), axis=(1, 2))
+        np.testing.assert_array_equal(got["count"], cnt)
+        with np.errstate(all="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            np.testing.assert_array_equal(got["min"], np.nanmin(f, axis=(1, 2)))
+            np.testing.assert_array_equal(got["max"], np.nanmax(f, axis=(1, 2)))
+            np.testing.assert_allclose(got["sum"], np.nansum(f, axis=(1, 2)), rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(got["sumsq"], np.nansum(f * f, axis=(1, 2)), rtol=1e-12)
+    if shape[1] > 8:
+        view = dd.rows(2, shape[1] - 3)
+        got = ops.stats_planes(view, mask=_mspec(inc).rows(2, shape[1] - 3))
+        f = np.where(np.isnan(d) | ~inc, np.nan, d).astype(np.float64)[:, 2:shape[1] - 3]
+        np.testing.assert_array_equal(got["count"], np.sum(~np.isnan(f), axis=(1, 2)))
+        np.testing.assert_allclose(got["sum"], np.nansum(f, axis=(1, 2)), rtol=1e-12, atol=1e-12)
