@@ -10,10 +10,10 @@
 //
 // Streaming ring: one lane owns one spaxel and marches over z.  The R = 2H+1
 // outputs currently "in flight" (those the newest input still contributes to)
-// live in R packed (num, den) fp32 accumulators; each new input is loaded ONCE,
-// turned into (v*ok, ok) and FMA-ed into all R accumulators with the R kernel
-// weights (v_pk_fma_f32: numerator and NaN-renormalising denominator ride in
-// one instruction); the oldest output then completes and is emitted.  The
+// live in R (num, den) float64 accumulators (astropy accumulates in float64 and
+// rounds once to float32; so does every kernel here); each new input is loaded
+// ONCE, turned into (v*ok, ok) and FMA-ed into all R accumulators with the R kernel
+// weights; the oldest output then completes and is emitted.  The
 // loop is unrolled by R so every ring slot and weight index is static.  No
 // halo re-reads, no LDS: the cube is read exactly once (4 B/voxel) and, when
 // materialised, written once.
@@ -37,7 +37,7 @@ namespace {
 
 // generic fallback for kernels wider than kMaxTaps taps (runtime tap loop,
 // re-reads served by L1/L2)
-__global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvArgs A, const float* kern, int ntaps) {
+__global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvArgs A, const double* kern, int ntaps) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ny * A.nx) return;
     const int64_t y = col / A.nx, x = col - y * A.nx;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvAr
     const int64_t zb = (int64_t)blockIdx.y * A.zchunk;
     const int64_t ze = min(A.nz, zb + A.zchunk);
     for (int64_t o = zb; o < ze; ++o) {
-        float num = 0.f, den = 0.f;
+        double num = 0.0, den = 0.0;
         for (int j = 0; j < ntaps; ++j) {
             const int64_t i = o + H - j;  // weight kern[o - i + H] = kern[j]
             float v = 0.f; bool ok = true;
@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvAr
                 ok = inc && (v == v);
                 if (!ok) v = 0.f;
             }
-            num = fmaf(kern[j], v, num);
-            den = fmaf(kern[j], ok ? 1.f : 0.f, den);
+            num = fma(kern[j], (double)v, num);
+            den = fma(kern[j], ok ? 1.0 : 0.0, den);
         }
         float res;
-        if (den != 0.f) {
-            res = num / den;
+        if (den != 0.0) {
+            res = (float)(num / den);
         } else {  // empty window -> (filled) centre sample
             const float c = p[o * A.plane_stride];
             bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
@@ -78,16 +78,16 @@ __global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvAr
 // ---- wide kernels (more taps than the largest ring): runs of 16 outputs along z -------------------
 // A lane owns one spaxel (lanes along x: coalesced) and produces 16 consecutive output channels at a
 // time: it walks the ntaps + 15 input planes of the run once (one load + classification each) and
-// feeds every sample into up to 16 packed (num, den) accumulators, the weights coming in as
+// feeds every sample into up to 16 float64 (num, den) accumulator pairs, the weights coming in as
 // wave-uniform scalars - 23 per chunk of 8 planes: kpad[15 + j] = k[j] with 15 zeros of padding on
 // both sides that are never multiplied (which (plane, output) pairs exist is static in the two head
 // and the two tail chunks).  Consecutive runs re-read their (ntaps - 1)-plane halo from L2.  Replaces
 // the per-output tap loop (81 taps at 1024^3: 130 ms) for every kernel of 17 taps or more that has
 // no ring; same astropy semantics (zero fill, NaN renormalisation, empty window -> centre sample).
-typedef float float2w __attribute__((ext_vector_type(2)));
+struct double2w { double x, y; };
 
 template <bool ARR>
-__global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs A, const float* kpad, int ntaps) {
+__global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs A, const double* kpad, int ntaps) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ny * A.nx) return;
     const int64_t y = col / A.nx, x = col - y * A.nx;
@@ -97,33 +97,33 @@ __global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs 
     const int64_t zb = (int64_t)blockIdx.y * A.zchunk;
     const int64_t ze = min(A.nz, zb + A.zchunk);
     for (int64_t o0 = zb; o0 < ze; o0 += 16) {
-        float2w acc[16];
+        double2w acc[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = float2w{0.f, 0.f};
+        for (int q = 0; q < 16; ++q) acc[q] = double2w{0.0, 0.0};
         // output o0 + q, tap j reads plane o0 + q + H - j = (o0 - H) + r with r = q + ntaps - 1 - j
-        auto sample = [&](int r) -> float2w {
+        auto sample = [&](int r) -> double2w {
             const int64_t i = o0 - H + r;
-            if (i < 0 || i >= A.nz) return float2w{0.f, 1.f};        // outside the cube: a valid zero
+            if (i < 0 || i >= A.nz) return double2w{0.0, 1.0};       // outside the cube: a valid zero
             const float v = p[i * A.plane_stride];
             bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v);
             if (ARR) ok = ok && pm[i * A.mask.plane_stride] != 0;
-            return ok ? float2w{v, 1.f} : float2w{0.f, 0.f};
+            return ok ? double2w{(double)v, 1.0} : double2w{0.0, 0.0};
         };
         // chunk of 8 planes r0 .. r0+7; weight of (plane r0 + i, output q) = k[ntaps-1-(r0+i)+q] = wp[7 - i + q],
         // wp = kpad + 15 + (ntaps - 1 - r0) - 7.  mode 0: q <= i (+ off), mode 2: q >= i (+ off), mode 1: all.
         auto chunk = [&](int r0, int mode, int off, int nrows) {
-            const float* wp = kpad + 15 + (ntaps - 1 - r0) - 7;
-            float w[23];
+            const double* wp = kpad + 15 + (ntaps - 1 - r0) - 7;
+            double w[23];
 #pragma unroll
             for (int t = 0; t < 23; ++t) w[t] = wp[t];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (mode == 1 && i >= nrows) break;                   // wave-uniform
-                const float2w in = sample(r0 + i);
+                const double2w in = sample(r0 + i);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const bool on = (mode == 0) ? (q <= i + off) : (mode == 2) ? (q >= i + off) : true;
-                    if (on) acc[q] = __builtin_elementwise_fma(float2w{w[7 - i + q], w[7 - i + q]}, in, acc[q]);
+                    if (on) { acc[q].x = fma(w[7 - i + q], in.x, acc[q].x); acc[q].y = fma(w[7 - i + q], in.y, acc[q].y); }
                 }
             }
         };
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs 
             const int64_t o = o0 + q;
             if (o >= ze) break;
             float res;
-            if (acc[q].y != 0.f) res = acc[q].x / acc[q].y;
+            if (acc[q].y != 0.0) res = (float)(acc[q].x / acc[q].y);
             else {                                          // empty window -> (filled) centre sample
                 const float c = p[o * A.plane_stride];
                 bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
@@ -153,6 +153,20 @@ __global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs 
 
 // ring kernels need a non-zero centre tap (see the empty-window note in
 // spc_spectral_conv_impl.h); anything else goes to the generic kernel
+// The ring kernels address the R + 1 planes of a revolution through ONE buffer descriptor (4 GiB
+// range) plus 32-bit offsets: lane offset inside a plane + plane delta.  Larger planes (beyond
+// ~5600^2 for 33 taps) take the kernels without a ring.
+bool ring_fits(int R, const spc_cube_f32* c, const spc_mask* m, int64_t out_row_stride, int64_t out_plane_stride) {
+    const int64_t lim = 1LL << 32;
+    bool ok = (R + 1) * c->plane_stride * 4 + c->ny * c->row_stride * 4 < lim && c->ny * c->row_stride < (1LL << 29);
+    if (out_plane_stride) ok = ok && (R + 1) * out_plane_stride * 4 + c->ny * out_row_stride * 4 < lim && c->ny * out_row_stride < (1LL << 29);
+    if (m && (m->flags & SPC_MASK_ARRAY)) {
+        const int64_t mr = m->row_stride ? m->row_stride : c->row_stride, mp = m->plane_stride ? m->plane_stride : c->plane_stride;
+        ok = ok && (R + 1) * mp + c->ny * mr < lim;
+    }
+    return ok;
+}
+
 int pick_ring(const double* k, int ntaps) {
     if (k[ntaps / 2] == 0.0) return 0;
     // (a 63-tap ring compiles for > 10 minutes; wider kernels use the generic kernel)
@@ -282,7 +296,7 @@ int try_weighted_moments(ConvArgs& A, const spc_cube_f32* cube, const double* h_
         }
         w[3 * i] = (double)(a0 / ksum); w[3 * i + 1] = (double)(a1 / ksum); w[3 * i + 2] = (double)(a2 / ksum);
     }
-    const size_t ntiles = (size_t)((A.ny * A.nx / 2 + 63) / 64);
+    const size_t ntiles = (size_t)((A.ny * A.nx + 127) / 128);
     if (spc_scratch_alloc((void**)d_status, ntiles, st) != hipSuccess) return 0;
     if (spc_scratch_alloc((void**)d_w, sizeof(double) * w.size(), st) != hipSuccess) { (void)spc_scratch_free(*d_status, st); *d_status = nullptr; return 0; }
     (void)spc_flags_clear(*d_status, ntiles, st);
@@ -307,27 +321,25 @@ int launch_ring_raw(int R, const ConvArgs& A, hipStream_t st, int fast, bool fus
     return SPC_ERR_UNSUPPORTED;
 }
 
-// vec == 2 (8-byte aligned rows), no mask array and a single z slice: speculate that the
-// data has no invalid samples (all-valid fast kernel), then redo only the dirty tiles
+// no mask array and a single z slice: speculate that the data has no invalid samples
+// (all-valid fast kernel, vec spaxels per lane), then redo only the dirty tiles
 int launch_ring(int R, ConvArgs& A, hipStream_t st, int vec, bool fuse) {
     const char* env = getenv("SPC_CONV_FAST");
     const bool want = env ? atoi(env) != 0 : true;
-    // (the fast kernel addresses R+1 planes through one descriptor + 32-bit scalar offsets)
-    const bool fits = (A.plane_stride * 4 * (R + 1) < (1LL << 31)) && (A.out_plane_stride * 4 * (R + 1) < (1LL << 31));
-    const bool fast = want && fits && vec == 2 && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && A.zchunk >= A.nz;
+    const bool fast = want && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && A.zchunk >= A.nz;
     A.status = nullptr;
     if (!fast) return launch_ring_raw(R, A, st, 0, fuse);
-    const size_t ntiles = (size_t)((A.ny * A.nx / 2 + 63) / 64);
+    const size_t ntiles = (size_t)((A.ny * A.nx + 127) / 128);
     unsigned char* d_status = nullptr;
     SPC_HIP(spc_scratch_alloc((void**)&d_status, ntiles, st));
     SPC_HIP(spc_flags_clear(d_status, ntiles, st));
     A.status = d_status;
-    const int rc = launch_ring_raw(R, A, st, 1, fuse);
+    const int rc = launch_ring_raw(R, A, st, vec, fuse);
     SPC_HIP(spc_scratch_free(d_status, st));
     return rc;
 }
 
-// two spaxels per lane need 8-byte aligned rows everywhere
+// two spaxels per lane need 8-byte aligned rows everywhere (SPC_CONV_VEC=1 forces one)
 int pick_vec(const spc_cube_f32* c, const MaskDev& m, const float* out, int64_t out_row, int64_t out_plane) {
     const char* env = getenv("SPC_CONV_VEC");
     if (env && atoi(env) == 1) return 1;
@@ -346,16 +358,16 @@ int fill_common(ConvArgs& A, const spc_cube_f32* cube, const spc_mask* mask, con
     A.cube = cube->d_data;
     A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
-    for (int i = 0; i < 64; ++i) A.k[i] = 0.f;
-    for (int i = 0; i < 130; ++i) A.kPS[i] = 0.f;
+    for (int i = 0; i < 64; ++i) A.k[i] = 0.0;
+    for (int i = 0; i < 130; ++i) A.kPS[i] = 0.0;
     if (R) {
         const int pad = (R - ntaps) / 2;
-        for (int i = 0; i < ntaps; ++i) A.k[pad + i] = (float)h_kernel[i];
-        { double ks = 0.0; for (int i = 0; i < R; ++i) ks += (double)A.k[i]; A.inv_ksum = (float)(1.0 / ks); }
-        double acc = 0.0;                      // prefix / suffix sums of the float32 taps
-        for (int i = 0; i < R; ++i) { acc += (double)A.k[i]; A.kPS[2 * i] = (float)acc; }
+        for (int i = 0; i < ntaps; ++i) A.k[pad + i] = h_kernel[i];
+        { double ks = 0.0; for (int i = 0; i < R; ++i) ks += A.k[i]; A.ksum = ks; A.inv_ksum = 1.0 / ks; }
+        double acc = 0.0;                      // prefix / suffix sums of the taps
+        for (int i = 0; i < R; ++i) { acc += A.k[i]; A.kPS[2 * i] = acc; }
         acc = 0.0;
-        for (int i = R - 1; i >= 0; --i) { A.kPS[2 * i + 1] = (float)acc; acc += (double)A.k[i]; }
+        for (int i = R - 1; i >= 0; --i) { A.kPS[2 * i + 1] = acc; acc += A.k[i]; }
     }
     return SPC_OK;
 }
@@ -383,7 +395,11 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     rc = check_kernel(h_kernel, ntaps);
     if (rc) return rc;
     SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
-    const int R = pick_ring(h_kernel, ntaps);
+    int R = pick_ring(h_kernel, ntaps);
+    {
+        const int64_t ors = out_row_stride ? out_row_stride : cube->nx;
+        if (R && !ring_fits(R, cube, mask, ors, out_plane_stride ? out_plane_stride : cube->ny * ors)) R = 0;
+    }
     ConvArgs A{};
     rc = fill_common(A, cube, mask, h_kernel, ntaps, R);
     if (rc) return rc;
@@ -404,8 +420,6 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
     hipStream_t st = (hipStream_t)stream;
     if (R) {
-        SPC_REQUIRE(cube->ny * cube->row_stride < (1LL << 29) && cube->ny * A.out_row_stride < (1LL << 29),
-                    "image plane too large for 32-bit buffer offsets");
         const int vec = pick_vec(cube, A.mask, d_out, A.out_row_stride, A.out_plane_stride);
         return launch_ring(R, A, st, vec, false);
     }
@@ -414,11 +428,11 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     const char* wenv = getenv("SPC_CONV_WIDE");
     const bool wide = (wenv ? atoi(wenv) != 0 : true) && ntaps >= 17;
     const int npad = wide ? ntaps + 30 : ntaps;
-    std::vector<float> hk((size_t)npad, 0.f);
-    for (int i = 0; i < ntaps; ++i) hk[(wide ? 15 : 0) + i] = (float)h_kernel[i];
-    float* d_k = nullptr;
-    SPC_HIP(hipMalloc((void**)&d_k, sizeof(float) * npad));
-    hipError_t e = hipMemcpy(d_k, hk.data(), sizeof(float) * npad, hipMemcpyHostToDevice);
+    std::vector<double> hk((size_t)npad, 0.0);
+    for (int i = 0; i < ntaps; ++i) hk[(wide ? 15 : 0) + i] = h_kernel[i];
+    double* d_k = nullptr;
+    SPC_HIP(hipMalloc((void**)&d_k, sizeof(double) * npad));
+    hipError_t e = hipMemcpy(d_k, hk.data(), sizeof(double) * npad, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         if (wide) {
             // whole runs of 16 per z slice
@@ -446,7 +460,8 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
     rc = check_kernel(h_kernel, ntaps);
     if (rc) return rc;
     SPC_REQUIRE(out != nullptr && d_cen != nullptr, "NULL pointer argument");
-    const int R = pick_ring(h_kernel, ntaps);
+    int R = pick_ring(h_kernel, ntaps);
+    if (R && !ring_fits(R, cube, mask, 0, 0)) R = 0;
     ConvArgs A{};
     rc = fill_common(A, cube, mask, h_kernel, ntaps, R);
     if (rc) return rc;
@@ -460,7 +475,7 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
         double* d_w = nullptr;
         bool ok = false;
         if (try_weighted_moments(A, cube, h_kernel, ntaps, h_cen, (hipStream_t)stream, &d_status, &d_w)) {
-            const size_t ntiles = (size_t)((A.ny * A.nx / 2 + 63) / 64);
+            const size_t ntiles = (size_t)((A.ny * A.nx + 127) / 128);
             std::vector<unsigned char> hs(ntiles);
             ok = hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
                  hipMemcpy(hs.data(), d_status, ntiles, hipMemcpyDeviceToHost) == hipSuccess;
@@ -486,7 +501,6 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
     A.mo = *out;
     A.mo_row_stride = out->out_row_stride ? out->out_row_stride : cube->nx;
     A.zchunk = cube->nz;
-    SPC_REQUIRE(cube->ny * cube->row_stride < (1LL << 29), "image plane too large for 32-bit buffer offsets");
     const int vec = pick_vec(cube, A.mask, nullptr, 0, 0);
     unsigned char* d_status = nullptr;
     double* d_w = nullptr;

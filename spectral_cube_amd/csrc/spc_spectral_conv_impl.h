@@ -10,10 +10,22 @@
 // completes and is emitted.  The loop is unrolled by R ("one revolution") so
 // slots and weights are static registers.
 //
+// Arithmetic = astropy's: astropy.convolution.convolve promotes the array and the
+// kernel to float64, accumulates top += val * ker / bot += ker in float64, divides
+// and rounds ONCE to the input dtype (float32).  The rings therefore hold float64
+// accumulators fed by v_fma_f64 with the float64 taps in SGPR pairs, the division
+// is a correctly rounded float64 division (a reciprocal multiply + one Newton
+// residual step when the denominator is the full kernel sum), and the result is
+// rounded to float32 once.  What differs from astropy is only the ORDER of the
+// float64 additions (1e-16 relative), so the float32 outputs are bit-identical
+// except where the float64 value sits within ~1e-16 of a float32 rounding
+// boundary - which is what makes the argmax of a smoothed cube an exact integer
+// map and keeps ill-conditioned moments of the smoothed cube inside 1e-5.
+//
 // What bounds it: VALU issue, not HBM.  Measured on MI355X
 // (tests/micro/valu_rate.hip): a wave64 VALU instruction occupies its SIMD for
 // ~4 cycles whether it is v_fmac_f32, v_pk_fma_f32 or v_fma_f64.  Hence:
-//   * the FMAs are in-place `v_fmac_f32` inline asm with the weight in an SGPR:
+//   * the FMAs are in-place `v_fma_f64` inline asm with the weight in an SGPR pair:
 //     left alone, LLVM sinks each slot's FMA chain to its emission point (R-long
 //     dependent chains, twice the registers);
 //   * the NaN-renormalising denominator den = sum of the weights of the VALID
@@ -26,9 +38,6 @@
 //     copy the whole ring (measured: 2x VGPRs or 2R v_mov per step);
 //   * loads/stores go through buffer descriptors built from readfirstlane'd
 //     plane bases (no per-load 64-bit VGPR address, no waterfall loops).
-// Experiments that did NOT pay (kept out of the tree, numbers in DESIGN.md):
-// two spaxels per lane with v_pk_fma_f32 (register file -> occupancy 1),
-// per-step prefetch ring + per-step validity vote (phi copies of the ring).
 #pragma once
 #include "spc_common.h"
 #include <algorithm>
@@ -54,11 +63,11 @@ struct ConvArgs {
     int64_t mo_row_stride;
     // all-valid fast pass: one byte per 128-column tile, 0 = done by the fast kernel
     unsigned char* status;
-    float inv_ksum;            // 1 / sum(k)
-    alignas(8) float k[64];    // taps padded to R, centred
+    double ksum, inv_ksum;     // sum(k) in tap order, 1 / sum(k)
+    alignas(16) double k[64];  // taps padded to R, centred
     // kPS[2s]   = k[0] + ... + k[s]      (what a slot completing at step s collected this revolution)
     // kPS[2s+1] = k[s+1] + ... + k[R-1]  (what a slot restarted at step s+1 will still collect)
-    float kPS[130];
+    double kPS[130];
 };
 
 // fused-moment running state of one spaxel
@@ -69,25 +78,22 @@ struct MomState {
     int imax = 0, imin = 0;
 };
 
-// ---- in-place FMA / MUL with a scalar (SGPR) weight -------------------------------------
-// VEC = 1: v_fmac_f32 acc, s_w, x
-// VEC = 2: v_pk_fma_f32 acc, s[w_pair], x, acc with op_sel picking ONE half of the pair for
-//          both packed lanes (so R weights need only R SGPRs, not 2R)
-__device__ __forceinline__ void fma_w(float& acc, const ConvArgs& A, int j, float x) {
-    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(A.k[j]), "v"(x));
+// ---- in-place FMA / MUL with a scalar (SGPR pair) float64 weight ------------------------
+__device__ __forceinline__ void fma_w(double& acc, const ConvArgs& A, int j, double x) {
+    asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(acc) : "s"(A.k[j]), "v"(x));
 }
-__device__ __forceinline__ void mul_w(float& acc, const ConvArgs& A, int j, float x) {
-    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(acc) : "s"(A.k[j]), "v"(x));
+__device__ __forceinline__ void mul_w(double& acc, const ConvArgs& A, int j, double x) {
+    asm volatile("v_mul_f64 %0, %1, %2" : "=v"(acc) : "s"(A.k[j]), "v"(x));
 }
-__device__ __forceinline__ void fma_w(float2v& acc, const ConvArgs& A, int j, float2v x) {
-    const float2v wp = *reinterpret_cast<const float2v*>(&A.k[j & ~1]);
-    if (j & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wp), "v"(x));
-    else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wp), "v"(x));
-}
-__device__ __forceinline__ void mul_w(float2v& acc, const ConvArgs& A, int j, float2v x) {
-    const float2v wp = *reinterpret_cast<const float2v*>(&A.k[j & ~1]);
-    if (j & 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(acc) : "s"(wp), "v"(x));
-    else asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(acc) : "s"(wp), "v"(x));
+
+// num / sum(k), correctly rounded: q = num * (1/ksum) is within an ulp; one residual step
+// r = num - q * ksum (exact in the FMA), q += r / ksum brings it to the rounded quotient
+// (the step every software division ends with) - 3 VALU slots instead of ~14.
+__device__ __forceinline__ double div_ksum(double num, const ConvArgs& A) {
+    const double q = num * A.inv_ksum;
+    // (an infinite quotient has a NaN residual: max() drops the NaN, the infinity survives the FMA)
+    const double r = fmax(fma(-q, A.ksum, num), -1.7976931348623157e308);
+    return fma(r, A.inv_ksum, q);
 }
 
 // Buffer descriptor over one plane.  The base must be wave-uniform AND provably
@@ -97,63 +103,64 @@ __device__ __forceinline__ auto plane_srd(const void* base) {
     const unsigned long long a = (unsigned long long)base;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff,
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)0xffffffffu,
                                              0x00020000);
 }
 
 // loads / stores relative to a per-revolution descriptor: soffset (SGPR) = plane delta in bytes
-__device__ __forceinline__ float2v ld2_soff(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
-    return __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, /*nt*/ 2));
-}
-__device__ __forceinline__ void st2_soff(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float2v v) {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, /*nt*/ 2);
-}
-
-template <int VEC> struct Ld;
-template <> struct Ld<1> {
+template <int VEC> struct Io;
+template <> struct Io<1> {
     using T = float;
-    static __device__ __forceinline__ T data(const float* plane, int voff) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_srd(plane), voff, 0, /*nt*/ 2));
+    static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, /*nt*/ 2));
     }
-    static __device__ __forceinline__ unsigned mask(const uint8_t* plane, int moff) {
-        return __builtin_amdgcn_raw_buffer_load_b8(plane_srd(plane), moff, 0, 2);
+    static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t rs, int voff, int soff, const float (&v)[1]) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[0]), rs, voff, soff, /*nt*/ 2);
     }
-    static __device__ __forceinline__ void store(float* plane, int voff, T v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), plane_srd(plane), voff, 0, 0);
-    }
+    static __device__ __forceinline__ float get(T v, int) { return v; }
 };
-template <> struct Ld<2> {
+template <> struct Io<2> {
     using T = float2v;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ T data(const float* plane, int voff) {
-        return __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(plane_srd(plane), voff, 0, 2));
+    static __device__ __forceinline__ T ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+        return __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, /*nt*/ 2));
     }
-    static __device__ __forceinline__ unsigned mask(const uint8_t* plane, int moff) {
-        return __builtin_amdgcn_raw_buffer_load_b16(plane_srd(plane), moff, 0, 2);
+    static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t rs, int voff, int soff, const float (&v)[2]) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, float2v{v[0], v[1]}), rs, voff, soff, /*nt*/ 2);
     }
-    static __device__ __forceinline__ void store(float* plane, int voff, T v) {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), plane_srd(plane), voff, 0, 0);
-    }
+    static __device__ __forceinline__ float get(T v, int c) { return v[c]; }
 };
+
+__device__ __forceinline__ float ld1(const float* plane, int voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane_srd(plane), voff, 0, /*nt*/ 2));
+}
+__device__ __forceinline__ unsigned ldm1(const uint8_t* plane, int moff) {
+    return __builtin_amdgcn_raw_buffer_load_b8(plane_srd(plane), moff, 0, 2);
+}
 
 // The R x R update + emission part of one revolution.
 //   v[s]  : classified input: the value when valid, NaN when invalid, 0 when out of range
 //   incb  : (FUSE only) bit s = sample s is in range and included by the mask
 // ALLV (wave-uniform, run-time): the wavefront's R samples are all valid ->
-// numerator FMAs only.
+// numerator FMAs only.  FULL (wave-uniform): this and the previous revolution were all
+// valid, so every output completing now has the whole kernel as its denominator
+// (out-of-range samples are valid zeros, boundary='fill').
 template <int R, bool ARR, bool FUSE, bool EXT, bool SYM>
-__device__ __forceinline__ void ring_body(const ConvArgs& A, float (&num)[R], float (&den)[R],
+__device__ __forceinline__ void ring_body(const ConvArgs& A, double (&num)[R], double (&den)[R],
                                           const float (&v)[R], unsigned long long incb,
                                           unsigned long long& inc_hist, MomState& ms, int voff_out, int i0,
-                                          int zb, int ze, const bool ALLV) {
+                                          int zb, int ze, const bool ALLV, const bool FULL) {
     constexpr int H = R / 2;
+    // outputs of this revolution: planes i0 - H .. i0 + H, addressed from the first one that exists
+    const int ob = max(i0 - H, 0);
+    const int obytes = FUSE ? 0 : (int)(A.out_plane_stride * 4);
+    const auto ro = plane_srd(FUSE ? (const void*)A.cube : (const void*)(A.out + (int64_t)ob * A.out_plane_stride));
     // slot 0 always restarts at step 0; after a GENERAL revolution its den is stale
-    if (ALLV) den[0] = 0.f;
+    if (ALLV) den[0] = 0.0;
     // prefix/suffix sums are fetched one step ahead through an opaque index so that the
     // 2R scalar loads are not all hoisted to the top (they would not fit the SGPR file)
     int zo = 0;
-    float kp = 0.f, ks = 0.f, kp_n = 0.f, ks_n = 0.f;
+    double kp = 0.0, ks = 0.0, kp_n = 0.0, ks_n = 0.0;
     if (ALLV) { asm volatile("" : "+s"(zo)); kp_n = A.kPS[zo]; ks_n = A.kPS[1 + zo]; }
 #pragma unroll
     for (int s = 0; s < R; ++s) {
@@ -162,7 +169,7 @@ __device__ __forceinline__ void ring_body(const ConvArgs& A, float (&num)[R], fl
             if (s + 1 < R) { asm volatile("" : "+s"(zo)); kp_n = A.kPS[2 * (s + 1) + zo]; ks_n = A.kPS[2 * (s + 1) + 1 + zo]; }
         }
         const bool ok = v[s] == v[s];
-        const float x = ok ? v[s] : 0.f;
+        const double x = ok ? (double)v[s] : 0.0;
 #pragma unroll
         for (int m = 0; m < R; ++m) {
             const int a = (s - m + R) % R;          // age of the output living in slot m
@@ -172,13 +179,13 @@ __device__ __forceinline__ void ring_body(const ConvArgs& A, float (&num)[R], fl
             else fma_w(num[m], A, j, x);
         }
         if (!ALLV) {
-            const float okf = ok ? 1.f : 0.f;
+            const double okd = ok ? 1.0 : 0.0;
 #pragma unroll
             for (int m = 0; m < R; ++m) {
                 const int a = (s - m + R) % R;
                 const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
-                if (a == 0) mul_w(den[m], A, j, okf);
-                else fma_w(den[m], A, j, okf);
+                if (a == 0) mul_w(den[m], A, j, okd);
+                else fma_w(den[m], A, j, okd);
             }
         }
         if (FUSE && A.mask.flags) inc_hist = (inc_hist << 1) | ((incb >> s) & 1ull);
@@ -186,14 +193,18 @@ __device__ __forceinline__ void ring_body(const ConvArgs& A, float (&num)[R], fl
         const int e = (s + 1) % R;
         const int o = i0 + s - H;
         if (o >= zb && o < ze) {
-            const float dtot = ALLV ? den[e] + kp : den[e];
-            // astropy returns the (filled) centre sample for an empty window; the host
-            // only dispatches kernels with a non-zero centre tap here, for which an empty
-            // window implies an invalid centre, i.e. NaN.  rcp: 1 ulp, tolerance is 1e-5
-            const float res = (ALLV || dtot != 0.f) ? num[e] * __builtin_amdgcn_rcpf(dtot) : NAN;
+            float res;
+            if (FULL) {
+                res = (float)div_ksum(num[e], A);
+            } else {
+                const double dtot = ALLV ? den[e] + kp : den[e];
+                // astropy returns the (filled) centre sample for an empty window; the host
+                // only dispatches kernels with a non-zero centre tap here, for which an empty
+                // window implies an invalid centre, i.e. NaN
+                res = (dtot != 0.0) ? (float)(num[e] / dtot) : NAN;
+            }
             if (!FUSE) {
-                const auto ro = plane_srd(A.out + (int64_t)o * A.out_plane_stride);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res), ro, voff_out, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res), ro, voff_out, (int)((unsigned)(o - ob) * (unsigned)obytes), 0);
             } else {
                 // no mask at all: every in-range channel is included
                 const bool inc_o = A.mask.flags ? (((inc_hist >> H) & 1ull) != 0ull) : true;
@@ -214,7 +225,7 @@ __device__ __forceinline__ void ring_body(const ConvArgs& A, float (&num)[R], fl
         }
         // all-valid revolution: the slot restarts at step s+1 and will collect the
         // weights k[R-1] .. k[s+1] (ages 0 .. R-2-s) before this revolution ends
-        if (ALLV) den[e] = (s < R - 1) ? ks : 0.f;
+        if (ALLV) den[e] = (s < R - 1) ? ks : 0.0;
     }
 }
 
@@ -235,22 +246,28 @@ __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
     const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
     const int voff = (int)((y * A.row_stride + x) * 4);              // < 2 GiB per plane (checked on the host)
     const int moff = ARR ? (int)(y * A.mask.row_stride + x) : 0;
-    float num[R], den[R];
+    double num[R], den[R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) { num[m] = 0.f; den[m] = 0.f; }
+    for (int m = 0; m < R; ++m) { num[m] = 0.0; den[m] = 0.0; }
     unsigned long long inc_hist = 0ull;  // include bit of the last 64 inputs (bit 0 = newest)
     MomState ms;
+    bool prev_allv = false;
+    const int pbytes = (int)(A.plane_stride * 4), mbytes = ARR ? (int)A.mask.plane_stride : 0;
 
     const int T = (ze - zb) + 2 * H;      // number of input steps
     for (int t0 = 0; t0 < T; t0 += R) {
         const int i0 = __builtin_amdgcn_readfirstlane(zb - H + t0);   // first input channel of this revolution
         float v[R];
         unsigned mk[R];
+        // ONE descriptor per revolution (base = first plane read) + a scalar byte offset per load
+        const int pb = min(max(i0, 0), nz - 1);
+        const auto rs = plane_srd(A.cube + (int64_t)pb * A.plane_stride);
+        const auto rm = plane_srd(ARR ? (const void*)(A.mask.arr + (int64_t)pb * A.mask.plane_stride) : (const void*)A.cube);
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-            const int64_t ic = min(max(i0 + s, 0), nz - 1);                  // clamped, uniform
-            v[s] = Ld<1>::data(A.cube + ic * A.plane_stride, voff);
-            if (ARR) mk[s] = Ld<1>::mask(A.mask.arr + ic * A.mask.plane_stride, moff);
+            const int dz = min(max(i0 + s, 0), nz - 1) - pb;                 // clamped, uniform
+            v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)dz * (unsigned)pbytes), /*nt*/ 2));
+            if (ARR) mk[s] = __builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)dz * (unsigned)mbytes), 2);
         }
         // ---- classify: value | NaN (invalid) | 0 (out of range = valid zero, boundary='fill')
         unsigned long long incb = 0ull;
@@ -266,7 +283,11 @@ __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
             if (FUSE && flags) incb |= ((in && inc) ? 1ull : 0ull) << s;
         }
         const bool allv = !__any(bad);
-        ring_body<R, ARR, FUSE, EXT, SYM>(A, num, den, v, incb, inc_hist, ms, voff_out, i0, zb, ze, allv);
+        // (the first revolution of a z slice starts from zeroed rings whose first H outputs lie
+        // before zb and are never emitted, so "previous revolution all valid" holds vacuously)
+        const bool full = allv && (prev_allv || t0 == 0);
+        ring_body<R, ARR, FUSE, EXT, SYM>(A, num, den, v, incb, inc_hist, ms, voff_out, i0, zb, ze, allv, full);
+        prev_allv = allv;
     }
 
     if (FUSE) {
@@ -288,34 +309,34 @@ __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
 
 // ---- all-valid fast kernel ------------------------------------------------------------
 // Speculative first pass for data WITHOUT invalid samples (the common case: cubes whose
-// only NaNs are blanked edges): two spaxels per lane, numerators only, one
-// v_pk_fma_f32 per tap and pair (16.5 VALU instructions per voxel instead of 33-66);
-// out = num / sum(k) exactly like astropy's NaN-free branch.  A wavefront that meets
-// an invalid sample marks its 128-column tile dirty and quits; the general kernel then
-// redoes only the dirty tiles.
-template <int R, bool FUSE>
+// only NaNs are blanked edges): numerators only, out = num / sum(k) exactly like
+// astropy's NaN-free branch (float64 accumulation, correctly rounded division, one
+// rounding to float32).  A wavefront that meets an invalid sample marks its tile dirty
+// and quits; the general kernel then redoes only the dirty tiles.  VEC = spaxels per lane.
+template <int R, bool FUSE, int VEC, bool SYM>
 __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs A) {
     constexpr int H = R / 2;
-    const int64_t gpr = A.nx / 2;
+    using IO = Io<VEC>;
+    const int64_t gpr = A.nx / VEC;
     const int64_t ngroups = A.ny * gpr;
     const int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t tile = __builtin_amdgcn_readfirstlane((int)(g0 >> 6));       // 64 lanes x 2 columns
+    // status bytes are per 128 columns of the linear spaxel index
     const bool live = g0 < ngroups;
     const int64_t g = live ? g0 : ngroups - 1;
-    const int64_t y = g / gpr, x = (g - y * gpr) * 2;
+    const int64_t y = g / gpr, x = (g - y * gpr) * VEC;
     const int nz = (int)A.nz;
     const int voff = (int)((y * A.row_stride + x) * 4);
     const int voff_out = FUSE ? 0 : (int)((y * A.out_row_stride + x) * 4);
     const bool EXT = FUSE && (A.mo.d_argmax || A.mo.d_argmin || A.mo.d_vmax || A.mo.d_vmin);
 
-    float2v num[R];
+    double num[VEC][R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) num[m] = float2v{0.f, 0.f};
-    MomState ms[2];
+    for (int c = 0; c < VEC; ++c)
+#pragma unroll
+        for (int m = 0; m < R; ++m) num[c][m] = 0.0;
+    MomState ms[VEC];
 
-    // One revolution's inputs are loaded up front (measured: the in-place
-    // "refill after use" prefetch variant was not faster - the kernel runs at ~85 % of what
-    // the read+write z-march pattern itself reaches, tests/micro/zmarch_copy.hip).
+    // One revolution's inputs are loaded up front.
     // Addressing: ONE buffer descriptor per revolution + a scalar byte offset per access.
     const int pbytes = (int)(A.plane_stride * 4), obytes = FUSE ? 0 : (int)(A.out_plane_stride * 4);
     const int T = nz + 2 * H;
@@ -325,40 +346,46 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
         const auto rs = plane_srd(A.cube + (int64_t)pb * A.plane_stride);
         const int ob = max(i0 - H, 0);                                     // base plane of the outputs
         const auto ro = plane_srd(FUSE ? (const float*)A.cube : A.out + (int64_t)ob * A.out_plane_stride);
-        float2v v[R];
+        typename IO::T v[R];
 #pragma unroll
-        for (int s = 0; s < R; ++s) v[s] = ld2_soff(rs, voff, (min(max(i0 + s, 0), nz - 1) - pb) * pbytes);
+        for (int s = 0; s < R; ++s) v[s] = IO::ld(rs, voff, (int)((unsigned)(min(max(i0 + s, 0), nz - 1) - pb) * (unsigned)pbytes));
         // The fast pass only runs for masks that reject exactly the non-finite samples (none /
         // isfinite), and those propagate through the FMAs: chk += 0 * (finished output) is NaN
-        // iff a NaN or Inf went into it - one packed FMA per output instead of compares on
-        // every sample.  Planes outside the cube (clamped duplicate loads) become valid zeros
-        // under a wave-uniform branch that only the first / last revolution takes.
+        // iff a NaN or Inf went into it - one FMA per output instead of compares on every
+        // sample.  Planes outside the cube (clamped duplicate loads) become valid zeros under
+        // a wave-uniform branch that only the first / last revolution takes.
         if ((i0 < 0) || (i0 + R > nz)) {
 #pragma unroll
             for (int s = 0; s < R; ++s)
-                if (!((i0 + s >= 0) && (i0 + s < nz))) v[s] = float2v{0.f, 0.f};
+                if (!((i0 + s >= 0) && (i0 + s < nz))) v[s] = typename IO::T{};
         }
-        float2v chk = float2v{0.f, 0.f};
+        float chk = 0.f;
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-#pragma unroll
-            for (int m = 0; m < R; ++m) {
-                const int a = (s - m + R) % R;
-                if (a == 0) mul_w(num[m], A, 2 * H - a, v[s]);
-                else fma_w(num[m], A, 2 * H - a, v[s]);
-            }
             const int e = (s + 1) % R;
             const int o = i0 + s - H;
-            chk = __builtin_elementwise_fma(num[e], float2v{0.f, 0.f}, chk);
+            float res[VEC];
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+                const double x64 = (double)IO::get(v[s], c);
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                    const int a = (s - m + R) % R;
+                    const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
+                    if (a == 0) mul_w(num[c][m], A, j, x64);
+                    else fma_w(num[c][m], A, j, x64);
+                }
+                res[c] = (float)div_ksum(num[c][e], A);
+                chk = fmaf(res[c], 0.f, chk);
+            }
             if (o >= 0 && o < nz) {
-                const float2v res = num[e] * A.inv_ksum;
                 if (!FUSE) {
-                    if (live) st2_soff(ro, voff_out, (o - ob) * obytes, res);
+                    if (live) IO::st(ro, voff_out, (int)((unsigned)(o - ob) * (unsigned)obytes), res);
                 } else {
                     const double cz = A.cen_linear ? fma((double)o, A.cen_dc, A.cen_c0) : A.cen[o];
                     const double czz = cz * cz;
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < VEC; ++c) {
                         const double wd = (double)res[c];
                         MomState& w = ms[c];
                         w.s0 += wd;
@@ -373,15 +400,17 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
             }
         }
         // wave-uniform: a non-finite sample went into this revolution's outputs -> the general
-        // kernel redoes the tile (whatever this wave already stored is overwritten)
-        if (__any((!(chk.x == chk.x) || !(chk.y == chk.y)) && live)) {
-            if ((threadIdx.x & 63) == 0) spc_flag_set(A.status + tile);
+        // kernel redoes the tile (whatever this wave already stored is overwritten).  A wave of
+        // VEC = 1 covers 64 columns = half a 128-column status tile; flagging the whole tile is
+        // harmless (the general kernel recomputes it from the inputs).
+        if (__any(!(chk == chk) && live)) {
+            if ((threadIdx.x & 63) == 0) spc_flag_set(A.status + ((y * A.nx + x) >> 7));
             return;
         }
     }
     if (FUSE && live) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < VEC; ++c) {
             const int64_t o = y * A.mo_row_stride + x + c;
             MomState w = ms[c];
             w.nvalid = nz;                                 // every sample of a clean tile is valid
@@ -415,8 +444,8 @@ int launch_rs(const ConvArgs& A, hipStream_t st, dim3 grid, bool arr, bool ext) 
 }
 
 // entry point instantiated once per ring size in spc_spectral_conv_r<R>.hip
-// fast: run the all-valid two-spaxel kernel first (A.status must point at
-// ceil(ny*nx/128) zeroed bytes), then the general kernel on the dirty tiles.
+// fast: run the all-valid kernel first (A.status must point at ceil(ny*nx/128) zeroed
+// bytes; fast = spaxels per lane, 1 or 2), then the general kernel on the dirty tiles.
 template <int R>
 int launch(const ConvArgs& A, hipStream_t st, int fast, bool fuse) {
     bool sym = true;
@@ -424,10 +453,19 @@ int launch(const ConvArgs& A, hipStream_t st, int fast, bool fuse) {
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     const bool ext = fuse && (A.mo.d_argmax || A.mo.d_argmin || A.mo.d_vmax || A.mo.d_vmin);
     if (fast) {
-        const int64_t ngroups = A.ny * (A.nx / 2);
+        const int64_t ngroups = A.ny * (A.nx / fast);
         dim3 fgrid((unsigned)((ngroups + 255) / 256), 1), block(256);
-        if (fuse) hipLaunchKernelGGL((spectral_conv_fast_kernel<R, true>), fgrid, block, 0, st, A);
-        else hipLaunchKernelGGL((spectral_conv_fast_kernel<R, false>), fgrid, block, 0, st, A);
+        if (fast == 2) {
+            if (fuse) { if (sym) hipLaunchKernelGGL((spectral_conv_fast_kernel<R, true, 2, true>), fgrid, block, 0, st, A);
+                        else hipLaunchKernelGGL((spectral_conv_fast_kernel<R, true, 2, false>), fgrid, block, 0, st, A); }
+            else { if (sym) hipLaunchKernelGGL((spectral_conv_fast_kernel<R, false, 2, true>), fgrid, block, 0, st, A);
+                   else hipLaunchKernelGGL((spectral_conv_fast_kernel<R, false, 2, false>), fgrid, block, 0, st, A); }
+        } else {
+            if (fuse) { if (sym) hipLaunchKernelGGL((spectral_conv_fast_kernel<R, true, 1, true>), fgrid, block, 0, st, A);
+                        else hipLaunchKernelGGL((spectral_conv_fast_kernel<R, true, 1, false>), fgrid, block, 0, st, A); }
+            else { if (sym) hipLaunchKernelGGL((spectral_conv_fast_kernel<R, false, 1, true>), fgrid, block, 0, st, A);
+                   else hipLaunchKernelGGL((spectral_conv_fast_kernel<R, false, 1, false>), fgrid, block, 0, st, A); }
+        }
         SPC_LAUNCH_CHECK();
     }
     const int64_t ncols = A.ny * A.nx;

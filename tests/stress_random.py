@@ -78,23 +78,23 @@ for it in range(nround):
     # spectral smoothing (ring sizes + generic), fused moments
     nt = int(rng.choice([1, 3, 7, 9, 15, 33, 41]))
     k = np.abs(rng.standard_normal(nt)) + 0.05
-    close(ops.spectral_conv(dd, k, mask=spec).get(), O.spectral_smooth(d, inc, k), 2e-5, tag + " sconv%d" % nt)
+    close(ops.spectral_conv(dd, k, mask=spec).get(), O.spectral_smooth(d, inc, k), 1e-5, tag + " sconv%d" % nt)
     if nt <= 33:
         sm = O.spectral_smooth(d, inc, k)
         f0 = O.moment(sm, inc, 0, cen, 1.3)
         rf = ops.spectral_conv_moments(dd, k, dev(cen - cref), dv=1.3, m1_add=cref + 10.0, mask=spec, want=("m0",), cen_host=cen - cref)
-        close(rf["m0"].get(), f0, 2e-5, tag + " fused m0 taps%d" % nt)
+        close(rf["m0"].get(), f0, 1e-5, tag + " fused m0 taps%d" % nt)
     # spatial smoothing: separable and not
     ky = int(rng.choice([3, 9, 17, 29])); g = np.exp(-0.5 * (np.arange(-(ky // 2), ky // 2 + 1) / (ky / 6.0)) ** 2)
     k2 = np.outer(g, g)
     small = d[:min(nz, 3)]
     sinc = None if inc is None else inc[:min(nz, 3)]
     sspec = None if spec is None else (ops.MaskSpec(_lib.MASK_ARRAY, array=dev(sinc.astype(np.uint8))) if kind == 1 else spec)
-    close(ops.spatial_conv(dev(small), k2, mask=sspec).get(), O.spatial_smooth(small, sinc, k2), 2e-5, tag + " spconv%d" % ky)
+    close(ops.spatial_conv(dev(small), k2, mask=sspec).get(), O.spatial_smooth(small, sinc, k2), 1e-5, tag + " spconv%d" % ky)
     kk = int(rng.choice([5, 9, 13]))
     yy, xx = np.mgrid[-(kk // 2):kk // 2 + 1, -(kk // 2):kk // 2 + 1]
     kn = np.exp(-0.5 * (((xx + 0.5 * yy) / 2.0) ** 2 + (yy / 1.2) ** 2))
-    close(ops.spatial_conv(dev(small), kn, mask=sspec).get(), O.spatial_smooth(small, sinc, kn), 2e-5, tag + " nonsep%d" % kk)
+    close(ops.spatial_conv(dev(small), kn, mask=sspec).get(), O.spatial_smooth(small, sinc, kn), 1e-5, tag + " nonsep%d" % kk)
     # lerp + bilinear
     if nz >= 2:
         xin = np.arange(nz) * 2.0; xout = np.linspace(rng.uniform(-3, nz), rng.uniform(nz, 2 * nz + 3), int(rng.integers(2, 120)))

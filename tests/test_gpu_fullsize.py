@@ -158,7 +158,7 @@ def test_c4_spatial_smooth_moment0_4096x2048x2048(gpu):
                   C.c_void_p(sm.ptr + ((shape[0] - tz + z) * shape[1] * shape[2]) * 4), row.nbytes, None)
         got_planes[z] = row[:, :160]
     assert_close(got_planes, exp_sm, atol=1e-5 * np.nanmax(np.abs(exp_sm)), what="C4 smoothed planes")
-    assert_close(m0[:96, :160], exp_m0, atol=2e-5 * np.nanmax(np.abs(exp_m0)), what="C4 moment0")
+    assert_close(m0[:96, :160], exp_m0, atol=1e-5 * np.nanmax(np.abs(exp_m0)), what="C4 moment0")
 
 
 def test_c5_spectral_interpolate_2048_to_4096(gpu):

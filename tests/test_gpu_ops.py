@@ -205,11 +205,11 @@ def test_spectral_conv_moments_fused(gpu, kname):
             m2 = r["m2"].get()
             assert np.array_equal(np.isnan(m2), np.isnan(e2))
             wc = np.isfinite(e2) & (np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0)))
-            assert np.all(np.abs(m2[wc] - e2[wc]) <= 1e-4 * np.nanmax(np.abs(e2[wc])))
+            assert np.all(np.abs(m2[wc] - e2[wc]) <= 1e-5 * np.nanmax(np.abs(e2[wc])))
         am = r["argmax"].get()
         ea = O.argmax(sm, m)
-        # fp32 rounding can flip near-ties between neighbouring channels
-        assert (am != ea).mean() < 0.02
+        # integer map: bit-exact (the stencil accumulates in float64 and rounds once, like astropy)
+        assert np.array_equal(am, ea), (am != ea).sum()
 
 
 @pytest.mark.parametrize("sig", ["3.397287", "1.500000", "0.700000"])
@@ -478,7 +478,7 @@ def test_fused_smooth_moments_algebraic_path(gpu, monkeypatch, kname):
                 assert_close(res[alg]["m0"], e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="m0 alg=" + alg)
                 assert_close(res[alg]["m1"], e1, atol=1e-5 * (cen[-1] - cen[0]), what="m1 alg=" + alg)
                 wc = np.isfinite(e2) & (np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0)))
-                assert np.all(np.abs(res[alg]["m2"][wc] - e2[wc]) <= 1e-4 * np.nanmax(np.abs(e2[wc])))
+                assert np.all(np.abs(res[alg]["m2"][wc] - e2[wc]) <= 1e-5 * np.nanmax(np.abs(e2[wc])))
         assert np.array_equal(res["1"]["nvalid"], res["0"]["nvalid"])
         assert_close(res["1"]["m0"], res["0"]["m0"], atol=2e-6 * np.nanmax(np.abs(e0)), what="algebraic vs stencil m0")
 
