@@ -111,6 +111,10 @@ int spc_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes, voi
 int spc_memcpy3d_h2d(int device, void* d_dst, size_t d_row_pitch, size_t d_plane_pitch,
                      const void* h_src, size_t h_row_pitch, size_t h_plane_pitch,
                      size_t row_bytes, size_t ny, size_t nz, void* stream);
+/* the same between two device buffers (row strips of a cube, tiling a cube from a smaller one) */
+int spc_memcpy3d_d2d(int device, void* d_dst, size_t dst_row_pitch, size_t dst_plane_pitch,
+                     const void* d_src, size_t src_row_pitch, size_t src_plane_pitch,
+                     size_t row_bytes, size_t ny, size_t nz, void* stream);
 int spc_memset(int device, void* d_ptr, int value, size_t bytes, void* stream);
 int spc_stream_create(int device, void** stream);
 int spc_stream_destroy(int device, void* stream);

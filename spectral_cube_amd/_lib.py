@@ -98,6 +98,7 @@ SIGNATURES = {
     "spc_memcpy_d2h": (_i, [_i, _vp, _vp, _sz, _vp]),
     "spc_memcpy_d2d": (_i, [_i, _vp, _vp, _sz, _vp]),
     "spc_memcpy3d_h2d": (_i, [_i, _vp, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "spc_memcpy3d_d2d": (_i, [_i, _vp, _sz, _sz, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "spc_memset": (_i, [_i, _vp, _i, _sz, _vp]),
     "spc_stream_create": (_i, [_i, _P(_vp)]),
     "spc_stream_destroy": (_i, [_i, _vp]),

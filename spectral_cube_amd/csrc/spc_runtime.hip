@@ -257,6 +257,28 @@ int spc_memcpy3d_h2d(int device, void* d_dst, size_t d_row_pitch, size_t d_plane
     return SPC_OK;
 }
 
+int spc_memcpy3d_d2d(int device, void* d_dst, size_t dst_row_pitch, size_t dst_plane_pitch,
+                     const void* d_src, size_t src_row_pitch, size_t src_plane_pitch,
+                     size_t row_bytes, size_t ny, size_t nz, void* stream) {
+    if (row_bytes == 0 || ny == 0 || nz == 0) return SPC_OK;
+    SPC_REQUIRE(d_dst && d_src, "memcpy3d with NULL pointer");
+    SPC_REQUIRE(dst_row_pitch >= row_bytes && src_row_pitch >= row_bytes, "row pitch smaller than row");
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    if (dst_row_pitch == row_bytes && src_row_pitch == row_bytes) {
+        // whole (ny x row) blocks are contiguous on both sides: ONE 2-D copy with the planes as rows
+        SPC_HIP(hipMemcpy2DAsync(d_dst, dst_plane_pitch, d_src, src_plane_pitch, row_bytes * ny, nz,
+                                 hipMemcpyDeviceToDevice, st));
+    } else {
+        for (size_t z = 0; z < nz; ++z)
+            SPC_HIP(hipMemcpy2DAsync((char*)d_dst + z * dst_plane_pitch, dst_row_pitch,
+                                     (const char*)d_src + z * src_plane_pitch, src_row_pitch, row_bytes, ny,
+                                     hipMemcpyDeviceToDevice, st));
+    }
+    if (!stream) SPC_HIP(hipStreamSynchronize(st));
+    return SPC_OK;
+}
+
 int spc_memset(int device, void* d_ptr, int value, size_t bytes, void* stream) {
     if (bytes == 0) return SPC_OK;
     SPC_DEVICE(device);

@@ -3,13 +3,23 @@
 Every row of SURVEY.md section 8(a) is independent per spaxel, so a cube
 shards over contiguous row strips ``(nz, ny/G, nx)`` - one process per GPU, no
 collective on the data path.  The only exchange is the stitch of the final
-2-D map strips: ONE all-gather (RCCL over xGMI on GPUs; a gloo all-gather of
-host arrays in the CPU tests).  The reference has no counterpart (its
-parallelism is dask chunking, dask_spectral_cube.py:259-312).
+2-D map strips: ONE all-gather (RCCL over xGMI on GPUs; an all-gather of host
+arrays through the rendezvous transport in the CPU tests).  The reference has no
+counterpart (its parallelism is dask chunking, dask_spectral_cube.py:259-312).
 
-torch.distributed is used here only as the rendezvous / bootstrap plumbing the
-launcher (`python -m torch.distributed.run`) already provides; the RCCL calls
-themselves go through the C ABI (spc_comm_init / spc_allgather_rows).
+No torch here: the 128-byte RCCL id and the few host-side records travel through a
+*transport* object (``rendezvous.FileRendezvous`` in production: files in a shared
+directory; the CPU tests also run the drivers over a gloo transport of their own).
+The RCCL calls go through the C ABI (spc_comm_init / spc_allgather_rows).
+
+Drivers, by BASELINE config:
+  C2 / C4 maps      sharded_moments                 strip moments + one all-gather
+  C3                sharded_spectral_smooth_moment  fused smooth->moment per strip + one all-gather
+  C4                sharded_smooth_moment0 (no halo, all-valid) / smooth_moment0_strip (halo rows)
+  C5                sharded_spectral_interpolate    per-spaxel, no exchange
+                    reproject_source_rows + sharded_reproject   output-row strips; every rank loads
+                                                    only the source rows its strip's pixel map touches
+  statistics        sharded_statistics              five numbers per rank
 """
 import ctypes as C
 
@@ -77,33 +87,27 @@ def read_strip(path, rank, world_size, halo=0, device=None, **kw):
 
 
 class HostGatherComm:
-    """all-gather of host strips through torch.distributed (gloo).  Used by the
-    world_size-2 CPU tests and as the loud, explicitly reported stitch fallback
-    of bench.py when RCCL cannot initialise."""
+    """all-gather of host strips through a rendezvous transport (rendezvous.FileRendezvous, or the
+    gloo transport of the world_size-2 CPU tests).  Also the loud, explicitly reported stitch
+    fallback of bench.py when RCCL cannot initialise."""
 
-    kind = "gloo-host"
+    kind = "host"
 
-    def __init__(self, group=None):
-        import torch.distributed as dist
-        self._dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world_size = dist.get_world_size(group)
+    def __init__(self, transport):
+        self.transport = transport
+        self.rank, self.world_size = transport.rank, transport.world_size
 
     def allgather_rows(self, strip, ny_total):
-        import torch
         strip = np.ascontiguousarray(strip)
         rows = strip_rows(ny_total, self.world_size)
         pad = np.full((rows,) + strip.shape[1:], np.nan if strip.dtype.kind == "f" else 0, dtype=strip.dtype)
         pad[:strip.shape[0]] = strip
-        t = torch.from_numpy(pad)
-        outs = [torch.empty_like(t) for _ in range(self.world_size)]
-        self._dist.all_gather(outs, t, group=self.group)
-        full = np.concatenate([o.numpy() for o in outs], axis=0)
+        parts = self.transport.allgather_bytes(pad.tobytes())
+        full = np.concatenate([np.frombuffer(b, dtype=strip.dtype).reshape(pad.shape) for b in parts], axis=0)
         return full[:ny_total]
 
     def barrier(self):
-        self._dist.barrier(group=self.group)
+        self.transport.barrier()
 
 
 class RcclComm:
@@ -111,19 +115,18 @@ class RcclComm:
 
     kind = "rccl"
 
-    def __init__(self, device, rank, world_size, bcast_bytes):
-        """bcast_bytes(payload_or_None) -> bytes: broadcast rank 0's payload to
-        all ranks (any host mechanism: torch.distributed, a shared file...)."""
-        self.device, self.rank, self.world_size = device, rank, world_size
+    def __init__(self, device, transport):
+        """transport: rendezvous object (rank, world_size, bcast_bytes): carries rank 0's unique id."""
+        self.device, self.rank, self.world_size = device, transport.rank, transport.world_size
         ident = None
-        if rank == 0:
+        if self.rank == 0:
             buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
             _lib.call("spc_comm_unique_id", buf)
             ident = bytes(buf)
-        ident = bcast_bytes(ident)
+        ident = transport.bcast_bytes(ident)
         buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(ident)
         h = C.c_void_p()
-        _lib.call("spc_comm_init", device, buf, world_size, rank, C.byref(h))
+        _lib.call("spc_comm_init", device, buf, self.world_size, self.rank, C.byref(h))
         self._h = h
 
     def allgather_rows_device(self, strip_dev, recv_dev, stream=None):
@@ -155,37 +158,98 @@ class RcclComm:
             pass
 
 
-def torch_bcast_bytes(group=None):
-    """bootstrap helper: broadcast bytes from rank 0 over torch.distributed."""
-    import torch.distributed as dist
+def _stitch(strip, ny_total, comm, pad_value=np.nan):
+    """(ny_total, nx) ndarray on every rank from the ranks' (rows, nx) map strips: ONE all-gather."""
+    if isinstance(comm, RcclComm):
+        rows = strip_rows(ny_total, comm.world_size)
+        if strip.shape[0] != rows:       # pad a short last strip on the host
+            padded = np.full((rows, strip.shape[1]), pad_value, dtype=strip.dtype)
+            padded[:strip.shape[0]] = strip.get()
+            strip = DeviceArray.from_numpy(padded, strip.device)
+        return comm.allgather_rows(strip, ny_total).get()[:ny_total]
+    return comm.allgather_rows(strip.get() if isinstance(strip, DeviceArray) else strip, ny_total)
 
-    def bcast(payload):
-        obj = [payload]
-        dist.broadcast_object_list(obj, src=0, group=group)
-        return obj[0]
-    return bcast
+
+_KEYS = {0: "m0", 1: "m1", 2: "m2"}
 
 
 def sharded_moments(strip_cube, ny_total, comm, orders=(0, 1, 2)):
     """moment maps of a cube sharded by row strips: every rank computes the
     maps of ITS strip with the fused HIP kernel, then one all-gather stitches
     them.  Returns {order: (ny_total, nx) float64 ndarray} on every rank."""
-    keys = {0: "m0", 1: "m1", 2: "m2"}
-    want = tuple(keys[o] for o in orders)
+    want = tuple(_KEYS[o] for o in orders)
     r = strip_cube._moment_device(want)
-    out = {}
-    for o in orders:
-        strip = r[keys[o]]
-        if isinstance(comm, RcclComm):
-            rows = strip_rows(ny_total, comm.world_size)
-            if strip.shape[0] != rows:       # pad a short last strip on the host
-                padded = np.full((rows, strip.shape[1]), np.nan)
-                padded[:strip.shape[0]] = strip.get()
-                strip = DeviceArray.from_numpy(padded, strip.device)
-            out[o] = comm.allgather_rows(strip, ny_total).get()[:ny_total]
-        else:
-            out[o] = comm.allgather_rows(strip.get() if isinstance(strip, DeviceArray) else strip, ny_total)
-    return out
+    return {o: _stitch(r[_KEYS[o]], ny_total, comm) for o in orders}
+
+
+def sharded_spectral_smooth_moment(strip_cube, kernel, ny_total, comm, orders=(1,)):
+    """config C3 (spectral_smooth -> moment) on row strips: the stencil runs along z, so strips need
+    no halo and no exchange; every rank runs the FUSED smooth->moment kernels on its strip (the
+    smoothed strip is never written, dask_spectral_cube.py:880-917 is lazy and keeps the mask) and
+    one all-gather stitches the maps.  Returns {order: (ny_total, nx) float64 ndarray}."""
+    sm = strip_cube.spectral_smooth(kernel)
+    want = tuple(_KEYS[o] for o in orders)
+    r = sm._moment_device(want, sm._fusable())
+    return {o: _stitch(r[_KEYS[o]], ny_total, comm) for o in orders}
+
+
+def sharded_spectral_interpolate(strip_cube, spectral_grid, **kw):
+    """config C5, first half: spectral_interpolate is per spaxel (dask_spectral_cube.py:1250-1373), so
+    the rank's strip is resampled in place - no halo, no exchange.  Returns the rank's new strip cube."""
+    return strip_cube.spectral_interpolate(spectral_grid, **kw)
+
+
+def _strip_pixel_map(wcs_in, header_out, rank, world_size, device):
+    """the rank's rows [y0, y1) of the full target pixel map (device, float64) + their row range"""
+    from . import ops
+    from .wcs import SimpleWCS
+    newwcs = header_out if isinstance(header_out, SimpleWCS) else SimpleWCS(header_out)
+    hdr = newwcs.header
+    ny_out, nx_out = int(hdr["NAXIS2"]), int(hdr["NAXIS1"])
+    y0, y1 = strip_bounds(ny_out, world_size, rank)
+    xs, ys = ops.wcs_pixel_map(wcs_in, newwcs, (ny_out, nx_out), device)   # 0.3 ms per 1024^2: every rank forms the whole map
+    cut = lambda a: DeviceArray((y1 - y0, nx_out), np.float64, device, ptr=a.ptr + y0 * nx_out * 8, owner=a)  # noqa: E731
+    return cut(xs), cut(ys), (y0, y1), (ny_out, nx_out), newwcs
+
+
+def reproject_source_rows(wcs_in, shape_in, header_out, rank, world_size, device=0):
+    """config C5, second half: rows [r0, r1) of the SOURCE image that the rank's strip of output rows
+    reads (bilinear: the two rows around every in-image source coordinate, one row of margin so that a
+    strip edge is never mistaken for the image border).  (0, 0) when the strip sees nothing.  The rank
+    then loads only those rows (io_fits.load_cube(rows=...) / DeviceArray.rows)."""
+    ny_in, nx_in = int(shape_in[-2]), int(shape_in[-1])
+    xs, ys, _, _, _ = _strip_pixel_map(wcs_in, header_out, rank, world_size, device)
+    if ys.shape[0] == 0:
+        return 0, 0
+    hx, hy = xs.get(), ys.get()
+    inside = (hx >= -0.5) & (hx <= nx_in - 0.5) & (hy >= -0.5) & (hy <= ny_in - 0.5)
+    if not inside.any():
+        return 0, 0
+    lo, hi = float(hy[inside].min()), float(hy[inside].max())
+    return max(0, int(np.floor(lo)) - 1), min(ny_in, int(np.ceil(hi)) + 2)
+
+
+def sharded_reproject(src_rows, r0, wcs_in, shape_in, header_out, rank, world_size, mask=None, fill=np.nan):
+    """Reproject the rank's strip of OUTPUT rows (spectral_cube.py:2649-2746 sharded by output rows).
+
+    src_rows: (nz, r1 - r0, nx_in) float32 DeviceArray = rows [r0, r1) of the source cube as given by
+    reproject_source_rows (mask: MaskSpec over the same rows).  The strip's pixel map is the rank's
+    rows of the full map with r0 subtracted from the row coordinate (exact in float64), so the result
+    is bit-identical to the same rows of the unsharded reprojection.  Returns (out, footprint,
+    (y0, y1)): (nz, y1 - y0, nx_out) float32 + (y1 - y0, nx_out) uint8 DeviceArrays; ranks whose
+    strip sees no source pixel get NaN rows and a zero footprint."""
+    from . import ops
+    device = src_rows.device
+    xs, ys, (y0, y1), (ny_out, nx_out), _ = _strip_pixel_map(wcs_in, header_out, rank, world_size, device)
+    nz = src_rows.shape[0]
+    if y1 == y0:
+        return DeviceArray((nz, 0, nx_out), np.float32, device), DeviceArray((0, nx_out), np.uint8, device), (y0, y1)
+    ys_local = DeviceArray.from_numpy(ys.get() - float(r0), device)        # a few MB; exact subtraction
+    if src_rows.shape[1] == 0:
+        out = DeviceArray.from_numpy(np.full((nz, y1 - y0, nx_out), np.nan, np.float32), device)
+        return out, DeviceArray.zeros((y1 - y0, nx_out), np.uint8, device), (y0, y1)
+    out, foot = ops.resample_bilinear(src_rows, xs, ys_local, fill=fill, mask=mask)
+    return out, foot, (y0, y1)
 
 
 def combine_statistics(parts):
@@ -204,13 +268,11 @@ def combine_statistics(parts):
     return out
 
 
-def sharded_statistics(strip_stats, group=None):
+def sharded_statistics(strip_stats, transport):
     """statistics() of a row-sharded cube: every rank passes the record of ITS strip (ops.stats_global on
-    the device, one pass), five numbers per rank travel through torch.distributed.all_gather_object."""
-    import torch.distributed as dist
-    parts = [None] * dist.get_world_size(group)
-    dist.all_gather_object(parts, {k: float(strip_stats[k]) for k in ("npts", "min", "max", "sum", "sumsq")}, group=group)
-    return combine_statistics(parts)
+    the device, one pass), five numbers per rank travel through the rendezvous transport."""
+    rec = {k: float(strip_stats[k]) for k in ("npts", "min", "max", "sum", "sumsq")}
+    return combine_statistics(transport.allgather_object(rec))
 
 
 def sharded_smooth_moment0(strip_cube, kernel, ny_total, comm):
@@ -228,15 +290,7 @@ def sharded_smooth_moment0(strip_cube, kernel, ny_total, comm):
     s0 = r["s0"]
     if int(r["nvalid"].get().min()) != nz:
         s0 = DeviceArray.from_numpy(np.full(s0.shape, np.nan), s0.device)
-    if isinstance(comm, RcclComm):
-        rows = strip_rows(ny_total, comm.world_size)
-        if s0.shape[0] != rows:
-            padded = np.zeros((rows, s0.shape[1]))
-            padded[:s0.shape[0]] = s0.get()
-            s0 = DeviceArray.from_numpy(padded, s0.device)
-        full = comm.allgather_rows(s0, ny_total).get()[:ny_total]
-    else:
-        full = comm.allgather_rows(s0.get(), ny_total)
+    full = _stitch(s0, ny_total, comm, pad_value=0.0)
     if not np.all(np.isfinite(full)):
         return None
     karr = kernel_array(kernel, 2)

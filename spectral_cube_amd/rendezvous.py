@@ -1,0 +1,143 @@
+"""Host-side rendezvous for the one-process-per-GPU driver, without torch.
+
+The only things the ranks of one node have to tell each other on the host are
+tiny: the 128-byte RCCL unique id (rank 0 -> everyone), a few statistics records,
+and "I am here" for barriers.  A shared directory does that: every collective is
+one small file per rank, written atomically (temp file + rename) and polled by
+the others.  No sockets, no third-party package; works for any launcher that gives
+every rank RANK / WORLD_SIZE (``python -m torch.distributed.run`` does - its
+environment is read, torch itself is not imported).
+
+The transport protocol (what ``distributed.py`` asks of a rendezvous object):
+
+    rank, world_size
+    bcast_bytes(payload_or_None) -> bytes        rank 0's payload on every rank
+    allgather_bytes(payload) -> [bytes] * world  in rank order
+    barrier()
+
+``tests/test_distributed_cpu.py`` runs the same drivers over a torch.distributed
+(gloo) transport with this protocol, and over this class, with world_size 2.
+"""
+import os
+import pickle
+import shutil
+import tempfile
+import time
+
+
+class RendezvousTimeout(RuntimeError):
+    pass
+
+
+class FileRendezvous:
+    """Collectives of small host payloads through files in *path* (single node)."""
+
+    def __init__(self, path, rank, world_size, timeout=300.0):
+        if world_size < 1 or not (0 <= rank < world_size):
+            raise ValueError("bad rank %d / world %d" % (rank, world_size))
+        self.path, self.rank, self.world_size, self.timeout = os.fspath(path), int(rank), int(world_size), timeout
+        self._seq = 0
+        os.makedirs(self.path, exist_ok=True)
+
+    # ---- construction from the launcher's environment ----------------------------------------
+    @classmethod
+    def from_env(cls, env=None, timeout=300.0):
+        """RANK / WORLD_SIZE from the environment; the directory is SPC_RDV_DIR, or one that
+        every rank of THIS launch derives alike: the launcher's pid (all ranks are its children)
+        and MASTER_PORT keep two launches on one box apart."""
+        env = os.environ if env is None else env
+        rank, world = int(env.get("RANK", 0)), int(env.get("WORLD_SIZE", 1))
+        path = env.get("SPC_RDV_DIR")
+        if not path:
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            path = os.path.join(base, "spc_rdv_%s_%d" % (env.get("MASTER_PORT", "0"), os.getppid()))
+        return cls(path, rank, world, timeout)
+
+    # ---- files -------------------------------------------------------------------------------
+    def _name(self, seq, rank):
+        return os.path.join(self.path, "%08d.%d" % (seq, rank))
+
+    def _write(self, seq, payload):
+        tmp = self._name(seq, self.rank) + ".tmp%d" % os.getpid()
+        with open(tmp, "wb") as fh:
+            fh.write(payload)
+        os.replace(tmp, self._name(seq, self.rank))          # atomic: readers never see a partial file
+
+    def _read(self, seq, rank):
+        name = self._name(seq, rank)
+        t0, delay = time.monotonic(), 0.0002
+        while True:
+            try:
+                with open(name, "rb") as fh:
+                    return fh.read()
+            except FileNotFoundError:
+                if time.monotonic() - t0 > self.timeout:
+                    raise RendezvousTimeout("rank %d waited %.0f s for rank %d (step %d) in %s"
+                                            % (self.rank, self.timeout, rank, seq, self.path))
+                time.sleep(delay)
+                delay = min(delay * 1.5, 0.005)
+
+    def _retire(self, seq):
+        # every rank has written step `seq`, so every rank has finished READING step seq - 1
+        if seq >= 1:
+            try:
+                os.unlink(self._name(seq - 1, self.rank))
+            except FileNotFoundError:
+                pass
+
+    # ---- collectives -------------------------------------------------------------------------
+    def allgather_bytes(self, payload):
+        seq = self._seq
+        self._seq += 1
+        self._write(seq, bytes(payload))
+        out = [self._read(seq, r) if r != self.rank else bytes(payload) for r in range(self.world_size)]
+        self._retire(seq)
+        return out
+
+    def bcast_bytes(self, payload=None):
+        """rank 0's payload (others pass None)"""
+        if self.rank == 0 and payload is None:
+            raise ValueError("rank 0 must provide the payload")
+        return self.allgather_bytes(payload if self.rank == 0 else b"")[0]
+
+    def allgather_object(self, obj):
+        return [pickle.loads(b) for b in self.allgather_bytes(pickle.dumps(obj))]
+
+    def barrier(self):
+        self.allgather_bytes(b"")
+
+    def close(self):
+        """last collective: every rank leaves a marker once it needs nothing from the directory any
+        more; rank 0 waits for all of them and removes it"""
+        try:
+            self.barrier()
+            self._seq += 1
+            self._write(self._seq, b"bye")
+            if self.rank == 0:
+                for r in range(1, self.world_size):
+                    self._read(self._seq, r)
+        except (RendezvousTimeout, OSError):
+            pass
+        if self.rank == 0:
+            shutil.rmtree(self.path, ignore_errors=True)
+
+
+class SingleProcess:
+    """world_size 1: the same protocol without any exchange"""
+
+    rank, world_size = 0, 1
+
+    def allgather_bytes(self, payload):
+        return [bytes(payload)]
+
+    def bcast_bytes(self, payload=None):
+        return payload
+
+    def allgather_object(self, obj):
+        return [obj]
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass

@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     if (!lib) { fprintf(stderr, "dlopen failed: %s\n", dlerror()); return 2; }
     SYM(spc_abi_version); SYM(spc_last_error); SYM(spc_device_count); SYM(spc_get_device_info);
     SYM(spc_malloc); SYM(spc_free); SYM(spc_host_alloc); SYM(spc_host_free);
-    SYM(spc_memcpy_h2d); SYM(spc_memcpy_d2h); SYM(spc_memcpy_d2d); SYM(spc_memcpy3d_h2d); SYM(spc_memset);
+    SYM(spc_memcpy_h2d); SYM(spc_memcpy_d2h); SYM(spc_memcpy_d2d); SYM(spc_memcpy3d_h2d); SYM(spc_memcpy3d_d2d); SYM(spc_memset);
     SYM(spc_stream_create); SYM(spc_stream_destroy); SYM(spc_stream_sync); SYM(spc_device_sync);
     SYM(spc_event_create); SYM(spc_event_destroy); SYM(spc_event_record); SYM(spc_event_sync);
     SYM(spc_stream_wait_event); SYM(spc_event_elapsed_ms);

@@ -1,53 +1,84 @@
-"""CPU, world_size 2 over gloo: the N>1 path (row-strip sharding + the single
-all-gather stitch).  No HIP compute can run here, so each rank's strip maps
-come from the oracle - what is under test is strip_bounds, padding of a short
-last strip and the gather order."""
+"""CPU, world_size 2: the N>1 path (row-strip sharding + the single all-gather stitch) over
+both host transports - torch.distributed / gloo (a transport class local to this test: the
+product package imports no torch) and the package's own file rendezvous.  No HIP compute can run
+here, so each rank's strip maps come from the oracle - what is under test is strip_bounds,
+padding of a short last strip, the gather order, the statistics combine and the rendezvous."""
 import os
 import socket
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from conftest import REPO
 
 WORKER = r'''
-import os, sys
+import os, sys, pickle
 import numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
-import torch.distributed as dist
 import oracle_np as O
 from spectral_cube_amd import synth
 from spectral_cube_amd.distributed import HostGatherComm, strip_bounds, sharded_statistics
-dist.init_process_group("gloo", init_method="env://")
-rank, ws = dist.get_rank(), dist.get_world_size()
+from spectral_cube_amd.rendezvous import FileRendezvous
+
+kind = sys.argv[2]
+if kind == "gloo":
+    import torch, torch.distributed as dist
+    dist.init_process_group("gloo", init_method="env://")
+
+    class GlooTransport:                      # the rendezvous protocol over torch.distributed (test only)
+        rank, world_size = dist.get_rank(), dist.get_world_size()
+        def allgather_bytes(self, payload):
+            out = [None] * self.world_size
+            dist.all_gather_object(out, bytes(payload))
+            return out
+        def bcast_bytes(self, payload=None):
+            obj = [payload]
+            dist.broadcast_object_list(obj, src=0)
+            return obj[0]
+        def allgather_object(self, obj):
+            return [pickle.loads(b) for b in self.allgather_bytes(pickle.dumps(obj))]
+        def barrier(self):
+            dist.barrier()
+        def close(self):
+            dist.destroy_process_group()
+    tr = GlooTransport()
+else:
+    tr = FileRendezvous.from_env(timeout=120)
+rank, ws = tr.rank, tr.world_size
+assert tr.bcast_bytes(b"id-from-rank-0" if rank == 0 else None) == b"id-from-rank-0"
 shape = (24, 9, 5)                     # 9 rows over 2 ranks: strips of 5 and 4 rows
 d = synth.gaussian_line_cube(shape, 77)
 inc = synth.boolean_mask(d, 3).astype(bool)
 cen = np.arange(24.0) * 2.0
 y0, y1 = strip_bounds(shape[1], ws, rank)
-comm = HostGatherComm()
+comm = HostGatherComm(tr)
 full = [comm.allgather_rows(O.moment(d[:, y0:y1], inc[:, y0:y1], o, cen, 2.0), shape[1]) for o in range(3)]
 ids = comm.allgather_rows(O.argmax(d[:, y0:y1], inc[:, y0:y1]), shape[1])
-st = sharded_statistics(O.statistics(d[:, y0:y1], inc[:, y0:y1]))
+st = sharded_statistics(O.statistics(d[:, y0:y1], inc[:, y0:y1]), tr)
 comm.barrier()
 es = O.statistics(d, inc)
 assert st["npts"] == es["npts"] and st["min"] == es["min"] and st["max"] == es["max"]
 for k in ("sum", "sumsq", "mean", "sigma", "rms"):
     assert abs(st[k] - es[k]) <= 1e-12 * abs(es[k]), k
+for o in range(3):
+    exp = O.moment(d, inc, o, cen, 2.0)
+    assert full[o].shape == exp.shape
+    assert np.array_equal(np.isnan(full[o]), np.isnan(exp))
+    assert np.array_equal(full[o][~np.isnan(exp)], exp[~np.isnan(exp)])
+assert np.array_equal(ids, O.argmax(d, inc))
+for i in range(20):                    # many small collectives back to back (file retirement)
+    got = tr.allgather_object((rank, i))
+    assert got == [(r, i) for r in range(ws)]
+tr.close()
 if rank == 0:
-    for o in range(3):
-        exp = O.moment(d, inc, o, cen, 2.0)
-        assert full[o].shape == exp.shape
-        assert np.array_equal(np.isnan(full[o]), np.isnan(exp))
-        assert np.array_equal(full[o][~np.isnan(exp)], exp[~np.isnan(exp)])
-    assert np.array_equal(ids, O.argmax(d, inc))
     print("DIST_OK")
-dist.destroy_process_group()
 '''
 
 
-def test_two_rank_gloo_stitch(tmp_path):
+@pytest.mark.parametrize("kind", ["gloo", "file"])
+def test_two_rank_stitch(tmp_path, kind):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     s = socket.socket()
@@ -57,9 +88,23 @@ def test_two_rank_gloo_stitch(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen([sys.executable, str(script), REPO], env=env,
+                   MASTER_PORT=str(port), LOCAL_RANK=str(rank), SPC_RDV_DIR=str(tmp_path / "rdv"))
+        procs.append(subprocess.Popen([sys.executable, str(script), REPO, kind], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "DIST_OK" in outs[0]
+    if kind == "file":
+        assert not (tmp_path / "rdv").exists(), "rank 0 removes the rendezvous directory"
+
+
+def test_file_rendezvous_default_directory_is_per_launch():
+    from spectral_cube_amd.rendezvous import FileRendezvous
+    a = FileRendezvous.from_env({"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "29512"})
+    b = FileRendezvous.from_env({"RANK": "0", "WORLD_SIZE": "1", "MASTER_PORT": "29513"})
+    try:
+        assert a.path != b.path and str(os.getppid()) in a.path
+        assert a.allgather_object({"x": 1}) == [{"x": 1}]
+    finally:
+        a.close(); b.close()
+    assert not os.path.exists(a.path)

@@ -169,6 +169,49 @@ def test_spectral_conv_vs_oracle(gpu, kname, shape):
         assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="spectral conv %s" % kname)
 
 
+@pytest.mark.parametrize("kname", ["g4", "g1", "asym", "r33", "wide", "box5"])
+def test_spectral_conv_float64_accumulation_bit_level(gpu, kname):
+    """astropy accumulates in float64 and rounds once to float32; so do the stencil kernels (same order
+    of the taps, v_fma_f64 where astropy's C loop has `top += val * ker`).  With generic (Gaussian, Hann)
+    weights the float32 outputs must be bit-identical to the float64 oracle's rounding, and the argmax of
+    the smoothed cube an exact integer map, ties included.  Kernels with small-rational weights (box 1/5,
+    hand-written decimals) put many exact sums ON float32 rounding midpoints; which neighbour such a tie
+    takes depends on whether the multiply-add is fused (x86-64 baseline builds of astropy: no; aarch64
+    builds: yes; here: yes), so for those the test allows one unit in the last place on < 2 % of the voxels."""
+    from spectral_cube_amd import ops
+    k = _kernels()[kname]
+    rational = kname in ("asym", "box5")
+    shape = (300, 24, 128)
+    rng = np.random.default_rng(5)
+    d = (rng.standard_normal(shape) * 3 + 1).astype(np.float32)
+    d[:, 3, 5] = np.float32(1.25)                 # constant ray: every smoothed interior value ties
+    d[40:60, 7, 9] = np.nan
+    inc = rng.random(shape) > 0.25
+    for m in (None, inc):
+        out = ops.spectral_conv(_dev(d), k, mask=_mspec(m)).get()
+        exp = O.spectral_smooth(d, m, k)
+        assert exp.dtype == np.float32 and out.dtype == np.float32
+        assert np.array_equal(np.isnan(out), np.isnan(exp))
+        ok = np.isfinite(exp)
+        differ = out[ok] != exp[ok]
+        # (generic weights: a handful of cancelling sums per million land within the fused / unfused difference of a boundary)
+        assert differ.mean() <= (2e-2 if rational else 1e-4), (kname, differ.sum())
+        if differ.any():                          # never by more than one unit in the last place
+            assert np.all(np.abs(out[ok][differ] - exp[ok][differ]) <= np.spacing(np.abs(exp[ok][differ])))
+        if len(k) <= 33:
+            cen = np.arange(shape[0], dtype=np.float64)
+            r = ops.spectral_conv_moments(_dev(d), k, _dev(cen), mask=_mspec(m), want=("argmax", "argmin"), cen_host=cen)
+            for name, ref in (("argmax", O.argmax(exp, m)), ("argmin", O.argmin(exp, m))):
+                got = r[name].get()
+                if not rational:
+                    assert np.array_equal(got, ref), (kname, name, (got != ref).sum())
+                else:           # a tie-broken midpoint may move the extremum to a channel whose value is one ulp away
+                    yy, xx = np.nonzero(got != ref)
+                    assert len(yy) <= 0.02 * got.size
+                    a, b = exp[got[yy, xx], yy, xx], exp[ref[yy, xx], yy, xx]
+                    assert np.all(np.abs(a - b) <= np.spacing(np.abs(b)))
+
+
 def test_spectral_conv_golden(gpu):
     from spectral_cube_amd import ops
     g = golden("spectral_smooth.npz")
