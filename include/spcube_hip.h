@@ -10,8 +10,13 @@
  * Conventions
  *   - every function returns 0 on success, a negative spc_status otherwise;
  *     spc_last_error() gives a thread-local message; nothing throws;
- *   - the caller owns every buffer; "d_" pointers are device (HBM) addresses
- *     obtained from spc_malloc (or any hipMalloc), "h_" pointers are host;
+ *   - the caller owns every buffer, scratch included; "d_" pointers are device (HBM)
+ *     addresses obtained from spc_malloc (or any hipMalloc), "h_" pointers are host.
+ *     No compute entry point allocates, frees or drains the device: a call that needs
+ *     scratch takes (d_workspace, workspace_bytes) - spc_workspace_bytes() gives the
+ *     size - and queues everything on the caller's stream.  The host is only made to
+ *     wait (for THAT stream) where a result comes back to it: the entry points with
+ *     an "h_" output say so;
  *   - cubes are C-contiguous (nz, ny, nx) float32, spectral axis first, x
  *     fastest; row/plane strides are given in ELEMENTS so that a (y) row strip
  *     of a larger cube can be processed in place;
@@ -30,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 1
+#define SPC_ABI_VERSION 2
 
 typedef enum {
     SPC_OK = 0,
@@ -127,6 +132,28 @@ int spc_event_sync(int device, void* event);
 int spc_stream_wait_event(int device, void* stream, void* event);   /* hipStreamWaitEvent */
 int spc_event_elapsed_ms(int device, void* start, void* stop, float* ms);
 
+/* ---- device scratch -----------------------------------------------------
+ * Bytes of d_workspace an entry point needs for a (nz,ny,nx) cube; p0 / p1 are the
+ * kernel extents or the output shape it is called with.  An upper bound that only
+ * depends on these numbers (not on the data, the mask kind or environment switches),
+ * so one buffer sized once serves a whole pipeline of equal-sized calls.  Contents
+ * need not be preserved between calls; two calls in flight at the same time (two
+ * streams) need two workspaces. */
+typedef enum {
+    SPC_WS_MOMENTS = 0,               /* spc_moments_f32 (== spc_moments_workspace_bytes) */
+    SPC_WS_SPECTRAL_CONV = 1,         /* spc_spectral_conv_f32, p0 = ntaps */
+    SPC_WS_SPECTRAL_CONV_MOMENTS = 2, /* spc_spectral_conv_moments_f32, p0 = ntaps */
+    SPC_WS_SPATIAL_CONV_SEP = 3,      /* spc_spatial_conv_sep_f32, p0 = nky, p1 = nkx */
+    SPC_WS_SPATIAL_CONV2D = 4,        /* spc_spatial_conv2d_f32, p0 = nky, p1 = nkx */
+    SPC_WS_RESAMPLE_BILINEAR = 5,     /* spc_resample_bilinear_f32, p0 = ny_out, p1 = nx_out */
+    SPC_WS_STATS_GLOBAL = 6,          /* spc_stats_global_f32 */
+    SPC_WS_STATS_PLANES = 7,          /* spc_stats_planes_f32 */
+    SPC_WS_MAP_CONV2D = 8,            /* spc_map_conv2d_f64, (ny,nx) = map, p0 = nky, p1 = nkx */
+    SPC_WS_CLIP_OUTSIDE = 9,          /* spc_clip_outside_f32 */
+    SPC_WS_PERCENTILE_GLOBAL = 10     /* spc_percentile_global_f32 */
+} spc_ws_kind;
+size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
+
 /* ---- moments ------------------------------------------------------------
  * Replaces DaskSpectralCubeMixin.moment (spectral_cube/dask_spectral_cube.py
  * :1031-1132, arithmetic :1083-1104 and nansum_allbadtonan :54-59),
@@ -190,7 +217,7 @@ int spc_scale_f32(int device, void* stream, float* d_data, int64_t n, double fac
  * h_stats (HOST, 5 doubles) = {npts, min, max, sum, sumsq}; min / max are NaN
  * when nothing is included.  Synchronises the stream. */
 int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube,
-                         const spc_mask* mask, double* h_stats);
+                         const spc_mask* mask, double* h_stats, void* d_workspace, size_t workspace_bytes);
 
 /* Reductions along one axis (0, 1 or 2) behind sum / mean / std / max / min with
  * axis given (dask_spectral_cube.py:641-767; spectral_cube.py:578-791).  Output
@@ -200,7 +227,7 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube,
 /* The same five numbers for every channel: h_stats (HOST) = nz records {npts, min, max, sum, sumsq}
  * of the (ny,nx) planes - the nan-reductions with axis=(1, 2), e.g. the mean spectrum cube.mean(axis=(1, 2)). */
 int spc_stats_planes_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
-                         double* h_stats);
+                         double* h_stats, void* d_workspace, size_t workspace_bytes);
 
 typedef struct spc_stats_outputs {
     int32_t* d_count;
@@ -240,7 +267,8 @@ int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,
  * |x - center| (float32 arithmetic, as numpy does for a float32 cube).  *h_out (HOST) gets the
  * value in double; NaN when nothing is included. */
 int spc_percentile_global_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
-                              double q, int has_center, float center, double* h_out);
+                              double q, int has_center, float center, double* h_out,
+                              void* d_workspace, size_t workspace_bytes);
 
 /* out[z][x][y] = included ? data[z][y][x] : fill, d_out a C-contiguous (nz, nx, ny) buffer: the
  * filled copy with the spatial axes exchanged, which turns an order statistic along x
@@ -259,6 +287,13 @@ int spc_fill_masked_transpose_f32(int device, void* stream, const spc_cube_f32* 
  *                      *h_nchanged (HOST) = number of samples clipped by this call. */
 int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                         float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);
+/* The include map of a mask evaluated on the cube it is bound to, as a uint8 (nz,ny,nx) array in
+ * HBM: d_out = included ? 1 : 0 (MaskBase.include, masks.py:105-116).  For masks that belong to
+ * ANOTHER cube's data - a smoothed cube keeps its parent's mask object (dask_spectral_cube.py:836-840):
+ * the predicate terms run on the parent's device data instead of a host copy of it.  nan_excluded != 0
+ * additionally drops NaN samples (~isnan style masks). */
+int spc_mask_include_u8(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                        int nan_excluded, uint8_t* d_out);
 /* per-ray clipping bounds of one iteration, all on the device: lo = centre - sigma_lower * std,
  * hi = centre + sigma_upper * std over n rays.  centre = d_center (e.g. the median map) or, when
  * NULL, the mean from d_count / d_sum / d_sumsq; std = d_spread (e.g. the mad_std map) or, when
@@ -267,7 +302,8 @@ int spc_clip_bounds_f32(int device, void* stream, int64_t n, const int32_t* d_co
                         const double* d_sumsq, const float* d_center, const float* d_spread,
                         double sigma_lower, double sigma_upper, float* d_lo, float* d_hi);
 int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, int64_t ny, int64_t nx,
-                         const float* d_lo, const float* d_hi, uint64_t* h_nchanged);
+                         const float* d_lo, const float* d_hi, uint64_t* h_nchanged,
+                         void* d_workspace, size_t workspace_bytes);
 
 /* 2-D convolution of one (ny, nx) float64 map with an odd-sized kernel (zero fill outside,
  * kernel normalised by its sum, true convolution, NaN propagates).  Serves the algebraic
@@ -275,7 +311,8 @@ int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, in
  * (dask_spectral_cube.py:962-993) commutes with the sums along the spectral axis
  * (:1083-1104), so the moment sums of the smoothed cube are the smoothed moment sums. */
 int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny, int64_t nx,
-                       const double* h_kernel, int nky, int nkx, double* d_out);
+                       const double* h_kernel, int nky, int nkx, double* d_out,
+                       void* d_workspace, size_t workspace_bytes);
 
 /* moments along a spatial axis (axis = 1 or 2), reference golden tables
  * spectral_cube/tests/test_moments.py:19-49.  d_cen is a (ny,nx) float64 map
@@ -286,6 +323,13 @@ int spc_moments_spatial_f32(int device, void* stream, const spc_cube_f32* cube,
                             const spc_mask* mask, int axis, const double* d_cen,
                             double pix_size, double* d_m0, double* d_m1,
                             double* d_m2);
+
+/* order N >= 2 along a spatial axis, second pass: out = sum v (c - mu)^N / sum v with d_mu = the
+ * moment-1 map of spc_moments_spatial_f32 (offsets, no world coordinate added), same output shapes
+ * (dask_spectral_cube.py:1094-1099; _moments.py:185-193 with axis != 0). */
+int spc_moment_order_spatial_f32(int device, void* stream, const spc_cube_f32* cube,
+                                 const spc_mask* mask, int axis, const double* d_cen, int order,
+                                 const double* d_mu, double* d_out);
 
 /* ---- NaN-aware convolution (astropy.convolution.convolve semantics:
  * boundary='fill', fill_value=0, nan_treatment='interpolate',
@@ -298,7 +342,7 @@ int spc_moments_spatial_f32(int device, void* stream, const spc_cube_f32* cube,
 int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube,
                           const spc_mask* mask, const double* h_kernel, int ntaps,
                           float* d_out, int64_t out_row_stride,
-                          int64_t out_plane_stride);
+                          int64_t out_plane_stride, void* d_workspace, size_t workspace_bytes);
 
 /* fused spectral_smooth -> moments (legal because the Dask smooth is lazy and
  * keeps the ORIGINAL mask, dask_spectral_cube.py:836-840): the smoothed cube
@@ -310,7 +354,8 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube,
 int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* cube,
                                   const spc_mask* mask, const double* h_kernel,
                                   int ntaps, const double* d_cen, const double* h_cen,
-                                  double dv, double m1_add, const spc_moment_outputs* out);
+                                  double dv, double m1_add, const spc_moment_outputs* out,
+                                  void* d_workspace, size_t workspace_bytes);
 
 /* spatial: replaces the per-channel 2-D convolution of spatial_smooth
  * (dask_spectral_cube.py:962-993 + :540-547; NumPy twin spectral_cube.py
@@ -319,11 +364,12 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
 int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
                              const spc_mask* mask, const double* h_ky, int nky,
                              const double* h_kx, int nkx, float* d_out,
-                             int64_t out_row_stride, int64_t out_plane_stride);
+                             int64_t out_row_stride, int64_t out_plane_stride,
+                             void* d_workspace, size_t workspace_bytes);
 int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube,
                            const spc_mask* mask, const double* h_kernel, int nky,
                            int nkx, float* d_out, int64_t out_row_stride,
-                           int64_t out_plane_stride);
+                           int64_t out_plane_stride, void* d_workspace, size_t workspace_bytes);
 
 /* ---- resampling -----------------------------------------------------------
  * spectral lerp: replaces interp_wrapper / scipy interp1d(kind='linear') of
@@ -357,17 +403,24 @@ int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs
                           const spc_celestial_wcs* wcs_in, int64_t ny_out, int64_t nx_out,
                           double* d_xs, double* d_ys);
 
-/* bilinear spatial resample: replaces the inner resampler of
- * reproject.reproject_interp(order='bilinear') called from
+/* spatial resample: replaces the inner resampler of
+ * reproject.reproject_interp(order='bilinear' | 'nearest-neighbor') called from
  * BaseSpectralCube.reproject (spectral_cube.py:2700-2732).  d_xs, d_ys:
  * (ny_out,nx_out) float64 source pixel coordinates (0-based).  Output pixels
  * whose source falls outside [-0.5, n-0.5] are NaN and get footprint 0.
- * d_footprint (uint8, (ny_out,nx_out)) may be NULL. */
+ * order: 1 = bilinear (a NaN neighbour propagates even with weight 0, as in
+ * scipy.ndimage.map_coordinates), 0 = nearest neighbour (floor(x + 0.5)).
+ * d_footprint (uint8, (ny_out,nx_out)) may be NULL.  d_any_valid (one uint32 in
+ * HBM, may be NULL) is set to 1 iff some output value is not NaN: the reference's
+ * "All values in reprojected cube are nan" check (spectral_cube.py:2733-2739)
+ * without another pass over the output. */
 int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube,
                               const spc_mask* mask, float fill, int64_t ny_out,
                               int64_t nx_out, const double* d_xs, const double* d_ys,
                               float* d_out, int64_t out_row_stride,
-                              int64_t out_plane_stride, uint8_t* d_footprint);
+                              int64_t out_plane_stride, uint8_t* d_footprint,
+                              int order, uint32_t* d_any_valid,
+                              void* d_workspace, size_t workspace_bytes);
 
 /* ---- multi-GPU stitch (RCCL over xGMI) -----------------------------------
  * One process per GPU; each rank owns a row strip of the 2-D map.  The id is

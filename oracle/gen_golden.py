@@ -526,6 +526,59 @@ def case_bilinear_scipy():
     print("bilinear vs scipy.ndimage.map_coordinates ok")
 
 
+def case_reproject_glue_scipy():
+    """Pins the two other argument sets reproject hands to map_coordinates (reproject itself is not
+    installed; the steps are its published ones, as in case_bilinear_scipy):
+      * order='nearest-neighbor': map_coordinates(padded, coords + 1, order=0, mode='constant', cval=nan)
+        + the [-0.5, n - 0.5] reset  ->  oracle_np.resample_nearest;
+      * a 3-D target header: ONE call on the cube padded by an edge-replicated voxel on all three axes,
+        coords = (z + 1, y + 1, x + 1), order=1  ->  oracle_np.reproject_separable (the coordinate
+        map of a cube header is separable: z depends on the channel only, (y, x) on the pixel only)."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(78)
+    nz, ny, nx = 6, 19, 23
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[0, 5, 7] = np.nan
+    d[3, 0, :3] = np.nan
+    d[5, -1, -1] = np.nan
+    nyo, nxo = 21, 27
+    yy, xx = np.mgrid[0:nyo, 0:nxo].astype(np.float64)
+    a = np.deg2rad(-31.0)
+    xs = 1.1 * (np.cos(a) * (xx - 13) - np.sin(a) * (yy - 10)) + 11.6
+    ys = 1.1 * (np.sin(a) * (xx - 13) + np.cos(a) * (yy - 10)) + 9.2
+    xs[0, :10] = [7, 6.5, 7.5, 7.49, 0, 22, -0.5, 22.5, 6.499999, 2.5]      # half-way points round up
+    ys[0, :10] = [5, 5, 5, 4.5, 0, 18, -0.25, 18.5, 5.5, 0.5]
+    # ---- nearest neighbour
+    exp0 = np.empty((nz, nyo, nxo))
+    reset = (xs < -0.5) | (xs > nx - 0.5) | (ys < -0.5) | (ys > ny - 0.5)
+    for k in range(nz):
+        padded = np.pad(d[k].astype(np.float64), 1, mode="edge")
+        v = map_coordinates(padded, np.array([ys + 1, xs + 1]), order=0, mode="constant", cval=np.nan)
+        v[reset] = np.nan
+        exp0[k] = v
+    got0, foot0 = O.resample_nearest(d, xs, ys)
+    assert np.array_equal(np.isnan(got0), np.isnan(exp0)), "nearest NaN pattern differs from scipy"
+    ok = ~np.isnan(exp0)
+    assert np.array_equal(got0[ok], exp0[ok])
+    # ---- 3-D: spectral axis resampled in the same call
+    zs = np.array([0.0, 0.25, 1.0, 2.5, 2.999, 4.0, 5.0, 5.4, -0.3, -0.6, 5.6, 3.0])
+    nzo = len(zs)
+    padded3 = np.pad(d.astype(np.float64), 1, mode="edge")
+    zz = np.broadcast_to(zs[:, None, None], (nzo, nyo, nxo))
+    coords = np.array([zz + 1, np.broadcast_to(ys, zz.shape) + 1, np.broadcast_to(xs, zz.shape) + 1])
+    exp3 = map_coordinates(padded3, coords, order=1, mode="constant", cval=np.nan)
+    reset3 = np.broadcast_to(reset, zz.shape) | (zz < -0.5) | (zz > nz - 0.5)
+    exp3[reset3] = np.nan
+    got3, foot3 = O.reproject_separable(d, xs, ys, zs)
+    assert np.array_equal(np.isnan(got3), np.isnan(exp3)), "3-D NaN pattern differs from scipy"
+    ok = ~np.isnan(exp3)
+    assert np.max(np.abs(got3[ok] - exp3[ok])) < 1e-12, np.max(np.abs(got3[ok] - exp3[ok]))
+    assert np.array_equal(foot3, ~reset3)
+    np.savez(os.path.join(OUT, "reproject_glue_scipy.npz"), data=d, xs=xs, ys=ys, zs=zs, nearest=exp0,
+             footprint2d=foot0[0], trilinear=exp3, footprint3d=foot3)
+    print("nearest-neighbour and 3-D map_coordinates argument sets ok")
+
+
 def case_statistics():
     """statistics() and sum / mean / std / max / min (axis None, 0, 1, 2) of the Dask class
     on a masked fp32 cube with NaNs and a fully masked column; plus the reference's own
@@ -755,17 +808,10 @@ def case_beams_cube():
 
 
 if __name__ == "__main__":
-    case_beams_cube()
-    case_moment_cube()
-    case_c1()
-    case_adv_argmax()
-    case_smooth()
-    case_interp()
-    case_kernels()
-    case_wcs()
-    case_bilinear_scipy()
-    case_statistics()
-    case_fits_files()
-    case_order_statistics()
-    case_sigma_clip()
-    print("ALL GOLDEN VECTORS WRITTEN to", OUT)
+    cases = [case_beams_cube, case_moment_cube, case_c1, case_adv_argmax, case_smooth, case_interp, case_kernels,
+             case_wcs, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
+             case_order_statistics, case_sigma_clip]
+    only = set(sys.argv[1:])                 # e.g. `gen_golden.py case_reproject_glue_scipy` regenerates one fixture
+    for fn in cases:
+        if not only or fn.__name__ in only:
+            fn()

@@ -327,6 +327,29 @@ def resample_bilinear(plane_or_cube, xs, ys):
     return out, foot
 
 
+def resample_nearest(plane_or_cube, xs, ys):
+    """``reproject_interp(order='nearest-neighbor')``: the same published steps as resample_bilinear
+    with ``scipy.ndimage.map_coordinates(..., order=0)`` - the sample whose centre is nearest
+    (``floor(x + 0.5)``; inside the half-pixel border zone that is the border pixel), no neighbour
+    takes part, so a NaN only shows where it is picked.  Pinned against scipy in
+    oracle/gen_golden.py (tests/golden/reproject_glue_scipy.npz).  Returns (data, footprint)."""
+    a = np.asarray(plane_or_cube)
+    cube = a if a.ndim == 3 else a[None]
+    nz, ny, nx = cube.shape
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        inside = ((xs >= -0.5) & (xs <= nx - 0.5) & (ys >= -0.5) & (ys <= ny - 0.5))
+    inside &= np.isfinite(xs) & np.isfinite(ys)
+    xi = np.clip(np.floor(np.where(inside, xs, 0.0) + 0.5).astype(np.int64), 0, nx - 1)
+    yi = np.clip(np.floor(np.where(inside, ys, 0.0) + 0.5).astype(np.int64), 0, ny - 1)
+    out = np.where(inside[None], cube[:, yi, xi].astype(np.float64), np.nan)
+    foot = np.broadcast_to(inside, out.shape).copy()
+    if a.ndim == 2:
+        return out[0], foot[0]
+    return out, foot
+
+
 def reproject_separable(cube, xs, ys, zs=None):
     """Spatial bilinear resample, optionally composed with a linear resample
     along z at fractional channel positions *zs* (trilinear with a separable

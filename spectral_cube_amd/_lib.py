@@ -22,6 +22,10 @@ SPC_ERR_COMM = -5
 MASK_NONE, MASK_ARRAY, MASK_FINITE = 0, 1, 2
 MASK_GT, MASK_GE, MASK_LT, MASK_LE = 4, 8, 16, 32
 COMM_ID_BYTES = 128
+ABI_VERSION = 2
+# spc_ws_kind
+(WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
+ WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL) = range(11)
 
 
 class HipLibraryError(RuntimeError):
@@ -86,10 +90,10 @@ SIGNATURES = {
     "spc_free": (_i, [_i, _vp]),
     "spc_argextrema_axis_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _vp]),
     "spc_fill_masked_transpose_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp]),
-    "spc_percentile_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), C.c_double, _i, _f, _P(C.c_double)]),
+    "spc_percentile_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), C.c_double, _i, _f, _P(C.c_double), _vp, _sz]),
     "spc_clip_bounds_f32": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
     "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _i64, _i64, _vp, _vp]),
-    "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double)]),
+    "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _vp, _sz]),
     "spc_pool_trim": (_i, [_i]),
     "spc_pool_stats": (_i, [_i, _P(C.c_int64), _P(C.c_int64)]),
     "spc_host_alloc": (_i, [_sz, _P(_vp)]),
@@ -111,27 +115,30 @@ SIGNATURES = {
     "spc_stream_wait_event": (_i, [_i, _vp, _vp]),
     "spc_event_elapsed_ms": (_i, [_i, _vp, _vp, _P(_f)]),
     "spc_moments_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "spc_workspace_bytes": (_sz, [_i, _i64, _i64, _i64, _i64, _i64]),
     "spc_moments_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _vp, _d, _d,
                              _P(SpcMomentOutputs), _vp, _sz]),
     "spc_moment_order_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _vp, _i, _vp, _vp, _vp, _i64]),
     "spc_moments_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _d, _vp, _vp, _vp]),
-    "spc_spectral_conv_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _i64, _i64]),
+    "spc_moment_order_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _i, _vp, _vp]),
+    "spc_spectral_conv_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _i64, _i64, _vp, _sz]),
     "spc_spectral_conv_moments_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _P(_d), _d, _d,
-                                           _P(SpcMomentOutputs)]),
+                                           _P(SpcMomentOutputs), _vp, _sz]),
     "spc_spatial_conv_sep_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _P(_d), _i,
-                                      _vp, _i64, _i64]),
-    "spc_spatial_conv2d_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _i, _vp, _i64, _i64]),
+                                      _vp, _i64, _i64, _vp, _sz]),
+    "spc_spatial_conv2d_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _i, _vp, _i64, _i64, _vp, _sz]),
     "spc_spectral_lerp_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i64, _vp, _vp, _vp, _f,
                                    _vp, _i64, _i64]),
     "spc_resample_bilinear_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _i64, _i64, _vp, _vp,
-                                       _vp, _i64, _i64, _vp]),
+                                       _vp, _i64, _i64, _vp, _i, _vp, _vp, _sz]),
     "spc_percentile_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
+    "spc_mask_include_u8": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp]),
     "spc_fill_masked_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp, _i64, _i64]),
-    "spc_clip_outside_f32": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _P(C.c_uint64)]),
-    "spc_map_conv2d_f64": (_i, [_i, _vp, _vp, _i64, _i64, _P(_d), _i, _i, _vp]),
+    "spc_clip_outside_f32": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _P(C.c_uint64), _vp, _sz]),
+    "spc_map_conv2d_f64": (_i, [_i, _vp, _vp, _i64, _i64, _P(_d), _i, _i, _vp, _vp, _sz]),
     "spc_scale_f32": (_i, [_i, _vp, _vp, _i64, _d]),
     "spc_fits_to_f32": (_i, [_i, _vp, _vp, _i, _d, _d, _i, _i64, _i64, _vp]),
-    "spc_stats_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d)]),
+    "spc_stats_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _vp, _sz]),
     "spc_stats_axis_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _P(SpcStatsOutputs)]),
     "spc_comm_unique_id": (_i, [_P(C.c_uint8)]),
     "spc_comm_init": (_i, [_i, _P(C.c_uint8), _i, _i, _P(_vp)]),
@@ -165,7 +172,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError = ABI mismatch, keep it loud
             fn.restype = res
             fn.argtypes = args
-        if lib.spc_abi_version() != 1:
+        if lib.spc_abi_version() != ABI_VERSION:
             raise HipLibraryError("ABI version mismatch: %d" % lib.spc_abi_version())
         _lib = lib
         return _lib

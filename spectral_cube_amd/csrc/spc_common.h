@@ -60,13 +60,46 @@ struct SpcDeviceGuard {
         return SPC_ERR_HIP;                                                   \
     }
 
-// ---- scratch allocations ------------------------------------------------------------------
-// Synchronous hipMalloc / hipFree on purpose: with the stream-ordered allocator (hipMallocAsync /
-// hipFreeAsync) of this ROCm build, calls that alternate between kernel families intermittently
-// computed on wrong data; hipFree also drains the device, which is
-// what lets a scratch buffer be released right after the last kernel using it was queued.
-static inline hipError_t spc_scratch_alloc(void** p, size_t bytes, hipStream_t) { return hipMalloc(p, bytes ? bytes : 1); }
-static inline hipError_t spc_scratch_free(void* p, hipStream_t) { return p ? hipFree(p) : hipSuccess; }
+// ---- caller-owned device scratch -------------------------------------------------------------
+// No entry point allocates, frees or drains: whatever scratch a call needs (tile flags, partial
+// records, weight tables, intermediate (num, den) planes) is carved out of the d_workspace the
+// caller passes in - spc_workspace_bytes() says how much - and everything is queued on the
+// caller's stream, so calls on different streams overlap and a stream of calls never blocks the
+// host except where a result has to come back to it (documented per entry point).
+struct SpcWorkspace {
+    char* base;
+    size_t size, used;
+    SpcWorkspace(void* p, size_t n) : base((char*)p), size(p ? n : 0), used(0) {}
+    // 256-byte aligned slices; nullptr when the workspace is too small
+    void* take(size_t bytes) {
+        const size_t at = (used + 255) & ~(size_t)255;
+        if (!base || at + bytes > size) { used = at + bytes; return nullptr; }
+        used = at + bytes;
+        return base + at;
+    }
+};
+static inline size_t spc_ws_round(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+#define SPC_WS_TAKE(var, ws, type, count)                                                          \
+    type* var = (type*)(ws).take(sizeof(type) * (size_t)(count));                                   \
+    if (!var) {                                                                                    \
+        spc_set_error("d_workspace too small: this call needs at least %zu bytes (spc_workspace_bytes)", \
+                      (ws).used);                                                                  \
+        return SPC_ERR_INVALID;                                                                    \
+    }
+
+// A small host table (kernel taps, per-channel weights) -> device memory by kernel launches only:
+// the bytes travel as kernel arguments, so the host buffer may die when the call returns and nothing
+// synchronises (a hipMemcpyAsync from pageable memory would need the buffer kept alive or a wait).
+hipError_t spc_table_upload(void* d_dst, const void* h_src, size_t bytes, hipStream_t st);
+
+// per-entry-point scratch sizes (defined next to the entry points, dispatched by spc_workspace_bytes)
+size_t spc_ws_spectral_conv(int64_t nz, int64_t ny, int64_t nx, int64_t ntaps, bool fused);
+size_t spc_ws_spatial_conv_sep(int64_t nz, int64_t ny, int64_t nx, int64_t nky, int64_t nkx);
+size_t spc_ws_spatial_conv2d(int64_t nz, int64_t ny, int64_t nx, int64_t nky, int64_t nkx);
+size_t spc_ws_resample_bilinear(int64_t ny_out, int64_t nx_out);
+size_t spc_ws_stats(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
+size_t spc_ws_percentile_global(void);
 
 // ---- tile flags handed from a speculative kernel to the kernel that redoes flagged tiles -----
 // Producer and consumer are queued back to back on one stream; the kernel boundary orders them.

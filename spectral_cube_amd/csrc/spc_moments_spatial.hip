@@ -18,10 +18,22 @@ struct SpMomArgs {
     const double* cen;     // (ny,nx)
     double size;
     double *m0, *m1, *m2;
+    // second pass for order N >= 3 (ORD kernels): out = sum v (c - mu)^N / sum v with mu = the
+    // first-pass moment 1 of the same ray (dask_spectral_cube.py:1094-1099; _moments.py:185-193)
+    int order;
+    const double* mu;
+    double* mN;
 };
+
+__device__ __forceinline__ double ipow(double b, int n) {      // b^n by squaring, n >= 0
+    double r = 1.0;
+    while (n) { if (n & 1) r *= b; b *= b; n >>= 1; }
+    return r;
+}
 
 __device__ __forceinline__ void emit(const SpMomArgs& A, int64_t o, double s0, double s1, double s2, int n) {
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (A.order) { A.mN[o] = s1 / s0; return; }
     const double mu = s1 / s0;
     if (A.m0) A.m0[o] = n > 0 ? A.size * s0 : nan;
     if (A.m1) A.m1[o] = mu;
@@ -33,17 +45,22 @@ typedef double f64x2m __attribute__((ext_vector_type(2)));
 
 struct Acc3 { double s0, s1, s2; int n; };
 
-__device__ __forceinline__ void acc3_add(Acc3& a, float v, bool ok, double c) {
+template <bool ORD>
+__device__ __forceinline__ void acc3_add(Acc3& a, float v, bool ok, double c, int order, double mu) {
     const double d = ok ? (double)v : 0.0;
     a.s0 += d;
-    a.s1 = fma(d, c, a.s1);
-    a.s2 = fma(d, c * c, a.s2);
+    if (ORD) {
+        a.s1 = fma(d, ipow(c - mu, order), a.s1);
+    } else {
+        a.s1 = fma(d, c, a.s1);
+        a.s2 = fma(d, c * c, a.s2);
+    }
     a.n += ok ? 1 : 0;
 }
 
 // axis 1: a lane owns VEC adjacent x of one channel, the 4 waves of a block split y (U rows in flight),
 // LDS combine - the access pattern of the spectral moment kernel with y in the role of z
-template <int VEC, bool ARR>
+template <int VEC, bool ARR, bool ORD>
 __global__ __launch_bounds__(256) void moments_axis1_kernel(const SpMomArgs A) {
     constexpr int YW = 4, U = 4;
     __shared__ double sh[YW - 1][4][VEC][64];
@@ -56,8 +73,12 @@ __global__ __launch_bounds__(256) void moments_axis1_kernel(const SpMomArgs A) {
     const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + xc : nullptr;
     const double* pc = A.cen + xc;
     Acc3 a[VEC];
+    double muv[VEC];
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) a[c] = Acc3{0.0, 0.0, 0.0, 0};
+    for (int c = 0; c < VEC; ++c) {
+        a[c] = Acc3{0.0, 0.0, 0.0, 0};
+        muv[c] = (ORD && x + c < A.nx) ? A.mu[z * A.nx + x + c] : 0.0;
+    }
     for (int64_t y0 = w; y0 < A.ny; y0 += YW * U) {
         float v[U][VEC];
         unsigned mk[U][VEC];
@@ -86,7 +107,7 @@ __global__ __launch_bounds__(256) void moments_axis1_kernel(const SpMomArgs A) {
             for (int c = 0; c < VEC; ++c) {
                 const float val = v[u][c];
                 const bool ok = in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, val) && (val == val) && (mk[u][c] != 0);
-                acc3_add(a[c], val, ok, cc[u][c]);
+                acc3_add<ORD>(a[c], val, ok, cc[u][c], A.order, muv[c]);
             }
         }
     }
@@ -117,7 +138,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // axis 2: one wavefront per (z, y) row, 16-byte loads when the row is aligned, wave reduction
-template <bool ARR>
+template <bool ARR, bool ORD>
 __global__ __launch_bounds__(256) void moments_axis2_kernel(const SpMomArgs A) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (z,y) row index
@@ -127,6 +148,7 @@ __global__ __launch_bounds__(256) void moments_axis2_kernel(const SpMomArgs A) {
     const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride + y * A.mask.row_stride : nullptr;
     const double* cen = A.cen + y * A.nx;
     Acc3 a{0.0, 0.0, 0.0, 0};
+    const double muv = ORD ? A.mu[row] : 0.0;
     const bool al = ((((uintptr_t)p) & 15) == 0) && ((((uintptr_t)cen) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
     const int64_t n4 = al ? A.nx / 4 : 0;
     for (int64_t i = lane; i < n4; i += 64) {
@@ -138,13 +160,13 @@ __global__ __launch_bounds__(256) void moments_axis2_kernel(const SpMomArgs A) {
         for (int c = 0; c < 4; ++c) {
             const float val = q[c];
             const bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, val) && (val == val) && (((m >> (8 * c)) & 0xffu) != 0);
-            acc3_add(a, val, ok, cc[c]);
+            acc3_add<ORD>(a, val, ok, cc[c], A.order, muv);
         }
     }
     for (int64_t x = n4 * 4 + lane; x < A.nx; x += 64) {
         const float val = p[x];
         const bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, val) && (val == val) && (!ARR || pm[x] != 0);
-        acc3_add(a, val, ok, cen[x]);
+        acc3_add<ORD>(a, val, ok, cen[x], A.order, muv);
     }
     a.s0 = wave_sum(a.s0); a.s1 = wave_sum(a.s1); a.s2 = wave_sum(a.s2);
 #pragma unroll
@@ -154,22 +176,8 @@ __global__ __launch_bounds__(256) void moments_axis2_kernel(const SpMomArgs A) {
 
 }  // namespace
 
-extern "C" int spc_moments_spatial_f32(int device, void* stream, const spc_cube_f32* cube,
-                                       const spc_mask* mask, int axis, const double* d_cen,
-                                       double pix_size, double* d_m0, double* d_m1, double* d_m2) {
-    int rc = spc_check_cube(cube);
-    if (rc) return rc;
-    SPC_REQUIRE(axis == 1 || axis == 2, "axis must be 1 or 2 (got %d)", axis);
-    SPC_REQUIRE(d_cen != nullptr, "d_cen is NULL");
-    SpMomArgs A{};
-    rc = spc_mask_to_dev(mask, cube, &A.mask);
-    if (rc) return rc;
-    SPC_DEVICE(device);
-    A.cube = cube->d_data;
-    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
-    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
-    A.cen = d_cen; A.size = pix_size; A.m0 = d_m0; A.m1 = d_m1; A.m2 = d_m2;
-    hipStream_t st = (hipStream_t)stream;
+template <bool ORD>
+static int launch_spatial(const SpMomArgs& A, const spc_cube_f32* cube, int axis, const double* d_cen, hipStream_t st) {
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     if (axis == 1) {
         SPC_REQUIRE(cube->nz <= 65535, "nz > 65535 not supported for axis-1 moments");
@@ -178,18 +186,56 @@ extern "C" int spc_moments_spatial_f32(int device, void* stream, const spc_cube_
                         (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
         if (v4) {
             dim3 grid((unsigned)((cube->nx + 255) / 256), (unsigned)cube->nz);
-            if (arr) hipLaunchKernelGGL((moments_axis1_kernel<4, true>), grid, dim3(256), 0, st, A);
-            else hipLaunchKernelGGL((moments_axis1_kernel<4, false>), grid, dim3(256), 0, st, A);
+            if (arr) hipLaunchKernelGGL((moments_axis1_kernel<4, true, ORD>), grid, dim3(256), 0, st, A);
+            else hipLaunchKernelGGL((moments_axis1_kernel<4, false, ORD>), grid, dim3(256), 0, st, A);
         } else {
             dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)cube->nz);
-            if (arr) hipLaunchKernelGGL((moments_axis1_kernel<1, true>), grid, dim3(256), 0, st, A);
-            else hipLaunchKernelGGL((moments_axis1_kernel<1, false>), grid, dim3(256), 0, st, A);
+            if (arr) hipLaunchKernelGGL((moments_axis1_kernel<1, true, ORD>), grid, dim3(256), 0, st, A);
+            else hipLaunchKernelGGL((moments_axis1_kernel<1, false, ORD>), grid, dim3(256), 0, st, A);
         }
     } else {
         const int64_t rows = cube->nz * cube->ny;
-        if (arr) hipLaunchKernelGGL(moments_axis2_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A);
-        else hipLaunchKernelGGL(moments_axis2_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A);
+        if (arr) hipLaunchKernelGGL((moments_axis2_kernel<true, ORD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((moments_axis2_kernel<false, ORD>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A);
     }
     SPC_LAUNCH_CHECK();
     return SPC_OK;
+}
+
+static int fill_spatial(SpMomArgs& A, const spc_cube_f32* cube, const spc_mask* mask, int axis, const double* d_cen) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(axis == 1 || axis == 2, "axis must be 1 or 2 (got %d)", axis);
+    SPC_REQUIRE(d_cen != nullptr, "d_cen is NULL");
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.cen = d_cen;
+    return SPC_OK;
+}
+
+extern "C" int spc_moments_spatial_f32(int device, void* stream, const spc_cube_f32* cube,
+                                       const spc_mask* mask, int axis, const double* d_cen,
+                                       double pix_size, double* d_m0, double* d_m1, double* d_m2) {
+    SpMomArgs A{};
+    int rc = fill_spatial(A, cube, mask, axis, d_cen);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    A.size = pix_size; A.m0 = d_m0; A.m1 = d_m1; A.m2 = d_m2;
+    return launch_spatial<false>(A, cube, axis, d_cen, (hipStream_t)stream);
+}
+
+extern "C" int spc_moment_order_spatial_f32(int device, void* stream, const spc_cube_f32* cube,
+                                            const spc_mask* mask, int axis, const double* d_cen, int order,
+                                            const double* d_mu, double* d_out) {
+    SpMomArgs A{};
+    int rc = fill_spatial(A, cube, mask, axis, d_cen);
+    if (rc) return rc;
+    SPC_REQUIRE(order >= 2 && order <= 64, "order must be in 2..64 (got %d)", order);
+    SPC_REQUIRE(d_mu != nullptr && d_out != nullptr, "NULL pointer argument");
+    SPC_DEVICE(device);
+    A.order = order; A.mu = d_mu; A.mN = d_out;
+    return launch_spatial<true>(A, cube, axis, d_cen, (hipStream_t)stream);
 }

@@ -136,6 +136,8 @@ struct BilArgs {
     unsigned char* status;
     int64_t tiles32_x, ntiles32;
     int64_t zchunk_lds;
+    int nearest;               // order 0: the nearest sample alone (scipy map_coordinates order=0)
+    unsigned int* any_valid;   // optional device word: set to 1 by a block that wrote a non-NaN value
 };
 
 // Lane <-> output pixel of a 16 x 4 tile per wavefront (a 64 x 16 tile per block): the
@@ -163,9 +165,10 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     // reproject's resampler: scipy map_coordinates(order=1) on the image padded by one
     // edge-replicated pixel.  floor(xs) in [-1, nx-1]; neighbours -1 / nx are the border pixel
     // itself, so within half a pixel of the border both neighbours coincide.
-    const double xf = floor(xs), yf = floor(ys);
-    const int64_t x0 = max((int64_t)xf, (int64_t)0), y0 = max((int64_t)yf, (int64_t)0);
-    const int64_t x1 = min((int64_t)xf + 1, A.nx - 1), y1 = min((int64_t)yf + 1, A.ny - 1);
+    // order 0: the sample at floor(x + 0.5) (border zone: the border pixel), both "neighbours" coincide
+    const double xf = A.nearest ? floor(xs + 0.5) : floor(xs), yf = A.nearest ? floor(ys + 0.5) : floor(ys);
+    const int64_t x0 = min(max((int64_t)xf, (int64_t)0), A.nx - 1), y0 = min(max((int64_t)yf, (int64_t)0), A.ny - 1);
+    const int64_t x1 = A.nearest ? x0 : min((int64_t)xf + 1, A.nx - 1), y1 = A.nearest ? y0 : min((int64_t)yf + 1, A.ny - 1);
     const float fx = (float)(xs - xf), fy = (float)(ys - yf);
     const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
     const int64_t o00 = y0 * A.row_stride + x0, o01 = y0 * A.row_stride + x1;
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const int64_t m10 = y1 * A.mask.row_stride + x0, m11 = y1 * A.mask.row_stride + x1;
     const bool anymask = A.mask.flags != 0;
     constexpr int U = 4;                      // channels in flight per lane (8 measured slower)
+    bool anyv = false;
     for (int64_t zq = zb; zq < ze; zq += U) {
         float a[U], b[U], c[U], d[U];
 #pragma unroll
@@ -199,10 +203,12 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
                 aa = i0 ? aa : A.fill; bb = i1 ? bb : A.fill; cc = i2 ? cc : A.fill; dd = i3 ? dd : A.fill;
             }
             // plain weighted sum like scipy: a NaN neighbour propagates even with weight 0
-            const float r = fmaf(w11, dd, fmaf(w10, cc, fmaf(w01, bb, w00 * aa)));
+            const float r = A.nearest ? aa : fmaf(w11, dd, fmaf(w10, cc, fmaf(w01, bb, w00 * aa)));
+            anyv = anyv || (r == r);
             __builtin_nontemporal_store(r, po + z * A.out_plane_stride);
         }
     }
+    if (A.any_valid && __any(anyv) && lane == 0) atomicOr(A.any_valid, 1u);
 }
 
 // ---- LDS-staged bilinear resampling ------------------------------------------------------
@@ -257,10 +263,10 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
             inside[q] = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
             if (blockIdx.y == 0 && A.footprint) A.footprint[pix] = inside[q] ? 1 : 0;
             if (inside[q]) {
-                const double xf = floor(xs), yf = floor(ys);      // see bilinear_kernel
-                x0[q] = max((int)xf, 0); y0[q] = max((int)yf, 0);
-                dx[q] = min((int)xf + 1, (int)A.nx - 1) - x0[q];   // 0 inside the replicated border, else 1
-                dy[q] = min((int)yf + 1, (int)A.ny - 1) - y0[q];
+                const double xf = A.nearest ? floor(xs + 0.5) : floor(xs), yf = A.nearest ? floor(ys + 0.5) : floor(ys);      // see bilinear_kernel
+                x0[q] = min(max((int)xf, 0), (int)A.nx - 1); y0[q] = min(max((int)yf, 0), (int)A.ny - 1);
+                dx[q] = A.nearest ? 0 : min((int)xf + 1, (int)A.nx - 1) - x0[q];   // 0 inside the replicated border, else 1
+                dy[q] = A.nearest ? 0 : min((int)yf + 1, (int)A.ny - 1) - y0[q];
                 const float fx = (float)(xs - xf), fy = (float)(ys - yf);
                 w00[q] = (1.f - fy) * (1.f - fx); w01[q] = (1.f - fy) * fx; w10[q] = fy * (1.f - fx); w11[q] = fy * fx;
                 atomicMin(&s_ymin, y0[q]);
@@ -354,6 +360,7 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
         }
     };
     fetch(zb);
+    bool anyv = false;
     for (int64_t zq = zb; zq < ze; zq += kStageU) {
 #pragma unroll
         for (int u = 0; u < kStageU; ++u)
@@ -371,8 +378,9 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float aa = sp[l0[q]], bb = sp[l0[q] + dx[q]], cc = sp[l1[q]], dd = sp[l1[q] + dx[q]];
-                const float r = fmaf(w11[q], dd, fmaf(w10[q], cc, fmaf(w01[q], bb, w00[q] * aa)));
+                const float r = A.nearest ? aa : fmaf(w11[q], dd, fmaf(w10[q], cc, fmaf(w01[q], bb, w00[q] * aa)));
                 r4[q] = inside[q] ? r : NAN;
+                anyv = anyv || (r4[q] == r4[q]);
             }
             float* po = A.out + z * A.out_plane_stride + yo * A.out_row_stride + xo;
             if (yo < A.ny_out) {
@@ -385,6 +393,7 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
         }
         lds_only_barrier();
     }
+    if (A.any_valid && __any(anyv) && (t & 63) == 0) atomicOr(A.any_valid, 1u);
 }
 
 
@@ -516,11 +525,13 @@ int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs
 int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                               float fill, int64_t ny_out, int64_t nx_out, const double* d_xs,
                               const double* d_ys, float* d_out, int64_t out_row_stride,
-                              int64_t out_plane_stride, uint8_t* d_footprint) {
+                              int64_t out_plane_stride, uint8_t* d_footprint, int order, uint32_t* d_any_valid,
+                              void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
     SPC_REQUIRE(d_xs && d_ys && d_out, "NULL pointer argument");
+    SPC_REQUIRE(order == 0 || order == 1, "order must be 1 (bilinear) or 0 (nearest neighbour), got %d", order);
     BilArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
     if (rc) return rc;
@@ -533,6 +544,8 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     A.out_row_stride = out_row_stride ? out_row_stride : nx_out;
     A.out_plane_stride = out_plane_stride ? out_plane_stride : ny_out * A.out_row_stride;
     A.footprint = d_footprint;
+    A.nearest = order == 0; A.any_valid = d_any_valid;
+    if (d_any_valid) SPC_HIP(hipMemsetAsync(d_any_valid, 0, sizeof(uint32_t), (hipStream_t)stream));
     const int64_t nblocks = ((nx_out + 63) / 64) * ((ny_out + 3) / 4);      // 64 x 4 pixel tiles
     int nsplit = 1;
     if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, cube->nz / 8));
@@ -545,7 +558,6 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     const bool fits = cube->ny * cube->row_stride < (1ll << 31) &&
                       (!arr || cube->ny * A.mask.row_stride < (1ll << 31));
-    unsigned char* d_status = nullptr;
     A.status = nullptr;
     if (want && fits) {
         A.tiles32_x = (nx_out + kTile - 1) / kTile;
@@ -561,7 +573,8 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
         if (const char* zc = getenv("SPC_BILINEAR_ZCHUNK")) A.zchunk_lds = std::max(8, atoi(zc));
         A.zchunk_lds = ((A.zchunk_lds + kStageU - 1) / kStageU) * kStageU;
         ns = (int)((cube->nz + A.zchunk_lds - 1) / A.zchunk_lds);
-        SPC_HIP(spc_scratch_alloc((void**)&d_status, (size_t)ntiles, st));
+        SpcWorkspace ws(d_workspace, workspace_bytes);
+        SPC_WS_TAKE(d_status, ws, unsigned char, ntiles);
         SPC_HIP(spc_flags_clear(d_status, (size_t)ntiles, st));
         A.status = d_status;
         dim3 g((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)ns);
@@ -572,8 +585,11 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     }
     hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
     SPC_LAUNCH_CHECK();
-    if (d_status) SPC_HIP(spc_scratch_free(d_status, st));
     return SPC_OK;
 }
 
 }  // extern "C"
+
+size_t spc_ws_resample_bilinear(int64_t ny_out, int64_t nx_out) {
+    return spc_ws_round((size_t)(((nx_out + kTile - 1) / kTile) * ((ny_out + kTile - 1) / kTile))) + 256;
+}

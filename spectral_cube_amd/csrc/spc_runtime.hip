@@ -53,6 +53,37 @@ void pool_release_idle(DevicePool& P, size_t keep_bytes) {
 }
 }  // namespace
 
+// ---- small host tables as kernel arguments (see spc_common.h) ---------------------------------
+namespace {
+constexpr int kTableWords = 896;                            // 3584 bytes of the 4 KiB kernarg segment
+struct TableChunk { uint32_t w[kTableWords]; };
+__global__ __launch_bounds__(256) void table_write_kernel(uint32_t* dst, const TableChunk c, int nwords) {
+    for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = c.w[i];
+}
+__global__ __launch_bounds__(64) void table_write_bytes_kernel(unsigned char* dst, const TableChunk c, int nbytes) {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(c.w);
+    for (int i = threadIdx.x; i < nbytes; i += 64) dst[i] = src[i];
+}
+}  // namespace
+
+hipError_t spc_table_upload(void* d_dst, const void* h_src, size_t bytes, hipStream_t st) {
+    const char* src = (const char*)h_src;
+    char* dst = (char*)d_dst;
+    while (bytes) {
+        const size_t n = bytes < sizeof(TableChunk) ? bytes : sizeof(TableChunk);
+        TableChunk c;
+        memcpy(c.w, src, n);
+        if ((n & 3) == 0 && (((uintptr_t)dst) & 3) == 0)
+            hipLaunchKernelGGL(table_write_kernel, dim3(1), dim3(256), 0, st, (uint32_t*)dst, c, (int)(n / 4));
+        else
+            hipLaunchKernelGGL(table_write_bytes_kernel, dim3(1), dim3(64), 0, st, (unsigned char*)dst, c, (int)n);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        src += n; dst += n; bytes -= n;
+    }
+    return hipSuccess;
+}
+
 void spc_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -64,6 +95,24 @@ extern "C" {
 
 int spc_abi_version(void) { return SPC_ABI_VERSION; }
 const char* spc_last_error(void) { return g_err; }
+
+size_t spc_moments_workspace_bytes(int64_t nz, int64_t ny, int64_t nx);
+
+size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1) {
+    if (nz <= 0 || ny <= 0 || nx <= 0) return 0;
+    switch (kind) {
+        case SPC_WS_MOMENTS: return spc_moments_workspace_bytes(nz, ny, nx);
+        case SPC_WS_SPECTRAL_CONV: return spc_ws_spectral_conv(nz, ny, nx, p0, false);
+        case SPC_WS_SPECTRAL_CONV_MOMENTS: return spc_ws_spectral_conv(nz, ny, nx, p0, true);
+        case SPC_WS_SPATIAL_CONV_SEP: return spc_ws_spatial_conv_sep(nz, ny, nx, p0, p1);
+        case SPC_WS_SPATIAL_CONV2D: return spc_ws_spatial_conv2d(nz, ny, nx, p0, p1);
+        case SPC_WS_RESAMPLE_BILINEAR: return spc_ws_resample_bilinear(p0, p1);
+        case SPC_WS_STATS_GLOBAL: case SPC_WS_STATS_PLANES: case SPC_WS_MAP_CONV2D: case SPC_WS_CLIP_OUTSIDE:
+            return spc_ws_stats(kind, nz, ny, nx, p0, p1);
+        case SPC_WS_PERCENTILE_GLOBAL: return spc_ws_percentile_global();
+    }
+    return 0;
+}
 
 int spc_device_count(int* count) {
     SPC_REQUIRE(count, "count is NULL");

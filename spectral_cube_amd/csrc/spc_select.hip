@@ -378,7 +378,8 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
 }
 
 extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
-                                         double q, int has_center, float center, double* h_out) {
+                                         double q, int has_center, float center, double* h_out,
+                                         void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     SPC_REQUIRE(h_out != nullptr, "h_out is NULL");
@@ -399,8 +400,8 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
     const int64_t per_block = 256 * 4 * 8;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (A.rowlen + per_block - 1) / per_block));
-    unsigned long long* d_hist = nullptr;              // 256 counters + (as uint32) the "next key" cell
-    SPC_HIP(spc_scratch_alloc((void**)&d_hist, sizeof(unsigned long long) * 257, st));
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_hist, ws, unsigned long long, 257);  // 256 counters + (as uint32) the "next key" cell
     A.hist = d_hist;
     A.next = reinterpret_cast<uint32_t*>(d_hist + 256);
     unsigned long long h[256];
@@ -435,8 +436,7 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     }
     uint32_t key_lo = A.prefix, key_hi = A.prefix;
     if (e == hipSuccess && n > 0 && (unsigned long long)khi >= below + eq) {     // the upper statistic is the next larger value
-        uint32_t init = 0xffffffffu;
-        e = hipMemcpyAsync(A.next, &init, sizeof(init), hipMemcpyHostToDevice, st);
+        e = hipMemsetAsync(A.next, 0xff, sizeof(uint32_t), st);
         if (e == hipSuccess) {
             if (arr) hipLaunchKernelGGL((gselect_kernel<true, 1>), dim3(nblocks), dim3(256), 0, st, A);
             else hipLaunchKernelGGL((gselect_kernel<false, 1>), dim3(nblocks), dim3(256), 0, st, A);
@@ -445,7 +445,6 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
         if (e == hipSuccess) e = hipMemcpyAsync(&key_hi, A.next, sizeof(key_hi), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    (void)spc_scratch_free(d_hist, st);
     SPC_HIP(e);
     if (n == 0) { *h_out = NAN; return SPC_OK; }
     auto unkey = [](uint32_t kk) { uint32_t u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk; float f; memcpy(&f, &u, 4); return (double)f; };
@@ -453,3 +452,5 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     *h_out = (frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac;
     return SPC_OK;
 }
+
+size_t spc_ws_percentile_global(void) { return spc_ws_round(sizeof(unsigned long long) * 257) + 256; }

@@ -303,13 +303,33 @@ int fill_args(SpArgs& A, const spc_cube_f32* cube, const spc_mask* mask, float* 
     return SPC_OK;
 }
 
+// planes per chunk of the two-pass wide path: <= 256 MiB of (num, den) per chunk
+int64_t wide_chunk_planes(int64_t nz, int64_t plane) {
+    return std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(nz, 65535), (int64_t)(1ll << 28) / (plane * 8)));
+}
+
 }  // namespace
+
+size_t spc_ws_spatial_conv_sep(int64_t nz, int64_t ny, int64_t nx, int64_t nky, int64_t nkx) {
+    const int R = pick_ring((int)std::max(nky, nkx));
+    if (R) {                                                    // tile flags of the speculative pass: strips x channels
+        const int64_t nstrips = (nx + fast_txo(33) - 1) / fast_txo(33);      // the narrowest strips of any ring
+        return spc_ws_round((size_t)(nstrips * nz)) + 256;
+    }
+    const int64_t nyp = std::max<int64_t>(nky, 17);
+    return spc_ws_round(sizeof(float) * (size_t)(nyp + 30 + nkx)) +
+           spc_ws_round(sizeof(float2v) * (size_t)(wide_chunk_planes(nz, ny * nx) * ny * nx)) + 512;
+}
+
+size_t spc_ws_spatial_conv2d(int64_t, int64_t, int64_t, int64_t nky, int64_t nkx) {
+    return spc_ws_round(sizeof(float) * (size_t)(nkx * (nky + 14))) + 256;
+}
 
 extern "C" {
 
 int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                            const double* h_kernel, int nky, int nkx, float* d_out,
-                           int64_t out_row_stride, int64_t out_plane_stride) {
+                           int64_t out_row_stride, int64_t out_plane_stride, void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     if ((rc = check_kernel(h_kernel, nky, "y")) || (rc = check_kernel(h_kernel, nkx, "x"))) return rc;
@@ -336,10 +356,10 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, c
     } else {
         for (int i = 0; i < n; ++i) hk[i] = (float)h_kernel[i];
     }
-    float* d_k = nullptr;
-    SPC_HIP(hipMalloc((void**)&d_k, sizeof(float) * n));
-    hipError_t e = hipMemcpy(d_k, hk.data(), sizeof(float) * n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_k, ws, float, (size_t)nkx * (nky + 14));
+    SPC_HIP(spc_table_upload(d_k, hk.data(), sizeof(float) * n, st));
+    {
         if (tiled) {
             const int pitch = (kT2X + nkx - 1) | 1;
             const size_t lds = (size_t)(kT2Y + nky - 1) * pitch * sizeof(float2v);
@@ -354,17 +374,14 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, c
             dim3 grid((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + 3) / 4), (unsigned)cube->nz);
             hipLaunchKernelGGL(spatial_conv2d_kernel, grid, dim3(256), 0, st, A, d_k, nky, nkx);
         }
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
-    (void)hipFree(d_k);
-    SPC_HIP(e);
+    SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
 
 int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                              const double* h_ky, int nky, const double* h_kx, int nkx, float* d_out,
-                             int64_t out_row_stride, int64_t out_plane_stride) {
+                             int64_t out_row_stride, int64_t out_plane_stride, void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     if ((rc = check_kernel(h_ky, nky, "y")) || (rc = check_kernel(h_kx, nkx, "x"))) return rc;
@@ -392,17 +409,14 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
         for (int j = 0; j < nky; ++j) hk[15 + (nyp - nky) / 2 + j] = (float)h_ky[j];
         for (int j = 0; j < nkx; ++j) hk[(size_t)(nyp + 30) + j] = (float)h_kx[j];
         const int64_t plane = cube->ny * cube->nx;
-        const int64_t nzc_max = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cube->nz, 65535), (int64_t)(1ll << 31) / (plane * 8)));   // <= 2 GiB of (num, den)
-        float* d_k = nullptr;
-        float2v* d_inter = nullptr;
-        SPC_HIP(spc_scratch_alloc((void**)&d_k, sizeof(float) * hk.size(), st));
-        hipError_t e = hipMalloc((void**)&d_inter, sizeof(float2v) * (size_t)(nzc_max * plane));
-        if (e != hipSuccess) { (void)spc_scratch_free(d_k, st); (void)hipGetLastError(); spc_set_error("hipMalloc of the (num, den) buffer failed"); return SPC_ERR_NOMEM; }
-        e = hipMemcpyAsync(d_k, hk.data(), sizeof(float) * hk.size(), hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        const int64_t nzc_max = wide_chunk_planes(cube->nz, plane);
+        SpcWorkspace ws(d_workspace, workspace_bytes);
+        SPC_WS_TAKE(d_k, ws, float, hk.size());
+        SPC_WS_TAKE(d_inter, ws, float2v, (size_t)(nzc_max * plane));
+        SPC_HIP(spc_table_upload(d_k, hk.data(), sizeof(float) * hk.size(), st));
         A.ychunk = ((std::max<int64_t>(16, (cube->ny + 3) / 4) + 15) / 16) * 16;      // a few y slices of whole runs
         const unsigned nys = (unsigned)((cube->ny + A.ychunk - 1) / A.ychunk);
-        for (int64_t z0 = 0; e == hipSuccess && z0 < cube->nz; z0 += nzc_max) {
+        for (int64_t z0 = 0; z0 < cube->nz; z0 += nzc_max) {
             const int64_t nzc = std::min<int64_t>(nzc_max, cube->nz - z0);
             dim3 gy((unsigned)((nzc * cube->nx + 255) / 256), nys);
             dim3 gx((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)nzc);
@@ -414,12 +428,8 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
                 hipLaunchKernelGGL(spatial_wide_ypass_kernel<false>, gy, dim3(256), 0, st, A, d_k, nyp, d_inter, z0, nzc);
                 hipLaunchKernelGGL(spatial_wide_xpass_kernel<false>, gx, dim3(256), lds, st, A, d_k + (nyp + 30), nkx, d_inter, z0, (float)sy);
             }
-            e = hipGetLastError();
+            SPC_LAUNCH_CHECK();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        (void)hipFree(d_inter);
-        (void)spc_scratch_free(d_k, st);
-        SPC_HIP(e);
         return SPC_OK;
     }
     SpArgs A{};
@@ -454,11 +464,11 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
     A.status = nullptr;
     A.inv_ksum = (float)(1.0 / sum);
     canonical_pred(A);
-    unsigned char* d_status = nullptr;
     if (want && al && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && nysplit == 1 && R <= 33 && cube->nx >= 64) {
         A.fast_nstrips = (int)((cube->nx + fast_txo(R) - 1) / fast_txo(R));
         const size_t nt = (size_t)A.fast_nstrips * (size_t)cube->nz;
-        SPC_HIP(spc_scratch_alloc((void**)&d_status, nt, st));
+        SpcWorkspace ws(d_workspace, workspace_bytes);
+        SPC_WS_TAKE(d_status, ws, unsigned char, nt);
         SPC_HIP(spc_flags_clear(d_status, nt, st));
         A.status = d_status;
     }
@@ -470,7 +480,6 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
         case 65: rc = launch_sep<65>(A, st, grid, arr); break;
         default: spc_set_error("no ring kernel for R=%d", R); rc = SPC_ERR_UNSUPPORTED;
     }
-    if (d_status) SPC_HIP(spc_scratch_free(d_status, st));
     return rc;
 }
 

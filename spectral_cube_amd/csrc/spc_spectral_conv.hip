@@ -186,6 +186,8 @@ int pick_ring(const double* k, int ntaps) {
 // that holds a NaN / Inf is not linear (NaN renormalisation): its 128-column tile is flagged
 // and redone by the general fused kernel.  (The reference rounds the smoothed cube to float32
 // before summing; this path does not - a 1e-7-level difference, inside the 1e-5 tolerance.)
+constexpr int kMaxAlgebraicTaps = 255;            // taps of the algebraic path travel as kernel arguments
+
 struct WmArgs {
     const float* cube;
     int64_t nz, ny, nx, row_stride, plane_stride;
@@ -269,45 +271,47 @@ __global__ __launch_bounds__(256) void weighted_moments_kernel(const WmArgs A) {
     }
 }
 
-// returns 1 when the algebraic pass ran (A.status then marks the tiles left to the general kernel)
+// per-channel weights of the algebraic path, on the device: W_n(i) = sum_o k[o + H - i] c_o^n / sum(k)
+// over the outputs o = i - H + j that exist.  One thread per channel; the taps ride in as kernel arguments.
+struct WeightTaps { double k[kMaxAlgebraicTaps]; };
+
+__global__ __launch_bounds__(256) void moment_weights_kernel(const double* cen, int64_t nz, const WeightTaps T, int ntaps,
+                                                             double ksum, double* w) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nz) return;
+    const int H = ntaps / 2;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int j = 0; j < ntaps; ++j) {
+        const int64_t o = i - H + j;                   // the output that reads input i through tap j
+        if (o < 0 || o >= nz) continue;
+        const double kj = T.k[j], c = cen[o];
+        a0 += kj; a1 = fma(kj, c, a1); a2 = fma(kj * c, c, a2);
+    }
+    w[3 * i] = a0 / ksum; w[3 * i + 1] = a1 / ksum; w[3 * i + 2] = a2 / ksum;
+}
+
+// returns 1 when the algebraic pass ran (A.status then marks the tiles left to the general kernel);
+// d_status (one byte per 128 columns) and d_w (3 nz doubles) come out of the caller's workspace
 int try_weighted_moments(ConvArgs& A, const spc_cube_f32* cube, const double* h_kernel, int ntaps,
-                         const double* h_cen, hipStream_t st, unsigned char** d_status, double** d_w) {
+                         hipStream_t st, unsigned char* d_status, double* d_w) {
     const char* env = getenv("SPC_FUSE_ALGEBRAIC");
     if (env && atoi(env) == 0) return 0;
     const bool ext = A.mo.d_argmax || A.mo.d_argmin || A.mo.d_vmax || A.mo.d_vmin;
     const bool al = (cube->nx % 4 == 0) && (cube->row_stride % 4 == 0) && (cube->plane_stride % 4 == 0) &&
                     ((((uintptr_t)cube->d_data) & 15) == 0);
-    if (ext || !al || (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) != 0 || cube->ny > 65535) return 0;
+    if (ext || !al || (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) != 0 || cube->ny > 65535 || ntaps > kMaxAlgebraicTaps) return 0;
     const int64_t nz = cube->nz;
-    std::vector<double> cen((size_t)nz);
-    if (h_cen) std::copy(h_cen, h_cen + nz, cen.begin());
-    else if (hipMemcpy(cen.data(), A.cen, sizeof(double) * nz, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    WeightTaps T{};
     double ksum = 0.0;
-    for (int j = 0; j < ntaps; ++j) ksum += h_kernel[j];
-    const int H = ntaps / 2;
-    std::vector<double> w((size_t)nz * 3);
-    for (int64_t i = 0; i < nz; ++i) {
-        long double a0 = 0, a1 = 0, a2 = 0;
-        for (int j = 0; j < ntaps; ++j) {
-            const int64_t o = i - H + j;                   // the output that reads input i through tap j
-            if (o < 0 || o >= nz) continue;
-            const long double kj = h_kernel[j], c = cen[(size_t)o];
-            a0 += kj; a1 += kj * c; a2 += kj * c * c;
-        }
-        w[3 * i] = (double)(a0 / ksum); w[3 * i + 1] = (double)(a1 / ksum); w[3 * i + 2] = (double)(a2 / ksum);
-    }
+    for (int j = 0; j < ntaps; ++j) { T.k[j] = h_kernel[j]; ksum += h_kernel[j]; }
     const size_t ntiles = (size_t)((A.ny * A.nx + 127) / 128);
-    if (spc_scratch_alloc((void**)d_status, ntiles, st) != hipSuccess) return 0;
-    if (spc_scratch_alloc((void**)d_w, sizeof(double) * w.size(), st) != hipSuccess) { (void)spc_scratch_free(*d_status, st); *d_status = nullptr; return 0; }
-    (void)spc_flags_clear(*d_status, ntiles, st);
-    // pageable source: the copy is staged before the call returns, so the vector may die afterwards
-    (void)hipMemcpyAsync(*d_w, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, st);
-    (void)hipStreamSynchronize(st);
+    (void)spc_flags_clear(d_status, ntiles, st);
+    hipLaunchKernelGGL(moment_weights_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, A.cen, nz, T, ntaps, ksum, d_w);
     WmArgs W{};
     W.cube = A.cube; W.nz = A.nz; W.ny = A.ny; W.nx = A.nx; W.row_stride = A.row_stride; W.plane_stride = A.plane_stride;
-    W.w = *d_w; W.dv = A.dv; W.m1_add = A.m1_add; W.mo = A.mo; W.mo_row_stride = A.mo_row_stride; W.status = *d_status;
+    W.w = d_w; W.dv = A.dv; W.m1_add = A.m1_add; W.mo = A.mo; W.mo_row_stride = A.mo_row_stride; W.status = d_status;
     hipLaunchKernelGGL(weighted_moments_kernel, dim3((unsigned)((A.nx + 255) / 256), (unsigned)A.ny), dim3(256), 0, st, W);
-    A.status = *d_status;
+    A.status = d_status;
     return 1;
 }
 
@@ -322,21 +326,18 @@ int launch_ring_raw(int R, const ConvArgs& A, hipStream_t st, int fast, bool fus
 }
 
 // no mask array and a single z slice: speculate that the data has no invalid samples
-// (all-valid fast kernel, vec spaxels per lane), then redo only the dirty tiles
-int launch_ring(int R, ConvArgs& A, hipStream_t st, int vec, bool fuse) {
+// (all-valid fast kernel, vec spaxels per lane), then redo only the dirty tiles.  d_status: one byte
+// per 128 columns from the caller's workspace.
+int launch_ring(int R, ConvArgs& A, hipStream_t st, int vec, bool fuse, unsigned char* d_status) {
     const char* env = getenv("SPC_CONV_FAST");
     const bool want = env ? atoi(env) != 0 : true;
     const bool fast = want && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && A.zchunk >= A.nz;
     A.status = nullptr;
     if (!fast) return launch_ring_raw(R, A, st, 0, fuse);
     const size_t ntiles = (size_t)((A.ny * A.nx + 127) / 128);
-    unsigned char* d_status = nullptr;
-    SPC_HIP(spc_scratch_alloc((void**)&d_status, ntiles, st));
     SPC_HIP(spc_flags_clear(d_status, ntiles, st));
     A.status = d_status;
-    const int rc = launch_ring_raw(R, A, st, vec, fuse);
-    SPC_HIP(spc_scratch_free(d_status, st));
-    return rc;
+    return launch_ring_raw(R, A, st, vec, fuse);
 }
 
 // two spaxels per lane need 8-byte aligned rows everywhere (SPC_CONV_VEC=1 forces one)
@@ -389,7 +390,7 @@ extern "C" {
 
 int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                           const double* h_kernel, int ntaps, float* d_out, int64_t out_row_stride,
-                          int64_t out_plane_stride) {
+                          int64_t out_plane_stride, void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     rc = check_kernel(h_kernel, ntaps);
@@ -404,6 +405,7 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     rc = fill_common(A, cube, mask, h_kernel, ntaps, R);
     if (rc) return rc;
     SPC_DEVICE(device);
+    SpcWorkspace ws(d_workspace, workspace_bytes);
     A.out = d_out;
     A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
     A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
@@ -420,41 +422,36 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
     hipStream_t st = (hipStream_t)stream;
     if (R) {
+        SPC_WS_TAKE(d_status, ws, unsigned char, (ncols + 127) / 128);
         const int vec = pick_vec(cube, A.mask, d_out, A.out_row_stride, A.out_plane_stride);
-        return launch_ring(R, A, st, vec, false);
+        return launch_ring(R, A, st, vec, false, d_status);
     }
     // no ring for this kernel: runs-of-16 kernel for 17 taps or more, per-output tap loop below that
-    // (taps in device memory; plain synchronous allocation / copy, released after the kernel has drained)
+    // (taps in the workspace, written there by kernel-argument uploads: nothing waits)
     const char* wenv = getenv("SPC_CONV_WIDE");
     const bool wide = (wenv ? atoi(wenv) != 0 : true) && ntaps >= 17;
     const int npad = wide ? ntaps + 30 : ntaps;
     std::vector<double> hk((size_t)npad, 0.0);
     for (int i = 0; i < ntaps; ++i) hk[(wide ? 15 : 0) + i] = h_kernel[i];
-    double* d_k = nullptr;
-    SPC_HIP(hipMalloc((void**)&d_k, sizeof(double) * npad));
-    hipError_t e = hipMemcpy(d_k, hk.data(), sizeof(double) * npad, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        if (wide) {
-            // whole runs of 16 per z slice
-            A.zchunk = ((A.zchunk + 15) / 16) * 16;
-            dim3 wgrid((unsigned)nblocks, (unsigned)((cube->nz + A.zchunk - 1) / A.zchunk));
-            if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(spectral_conv_wide_kernel<true>, wgrid, dim3(256), 0, st, A, d_k, ntaps);
-            else hipLaunchKernelGGL(spectral_conv_wide_kernel<false>, wgrid, dim3(256), 0, st, A, d_k, ntaps);
-        } else {
-            hipLaunchKernelGGL(spectral_conv_generic_kernel, grid, dim3(256), 0, st, A, d_k, ntaps);
-        }
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    SPC_WS_TAKE(d_k, ws, double, ntaps + 30);
+    SPC_HIP(spc_table_upload(d_k, hk.data(), sizeof(double) * npad, st));
+    if (wide) {
+        // whole runs of 16 per z slice
+        A.zchunk = ((A.zchunk + 15) / 16) * 16;
+        dim3 wgrid((unsigned)nblocks, (unsigned)((cube->nz + A.zchunk - 1) / A.zchunk));
+        if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(spectral_conv_wide_kernel<true>, wgrid, dim3(256), 0, st, A, d_k, ntaps);
+        else hipLaunchKernelGGL(spectral_conv_wide_kernel<false>, wgrid, dim3(256), 0, st, A, d_k, ntaps);
+    } else {
+        hipLaunchKernelGGL(spectral_conv_generic_kernel, grid, dim3(256), 0, st, A, d_k, ntaps);
     }
-    (void)hipFree(d_k);
-    SPC_HIP(e);
+    SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
 
 int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* cube,
                                   const spc_mask* mask, const double* h_kernel, int ntaps,
                                   const double* d_cen, const double* h_cen, double dv, double m1_add,
-                                  const spc_moment_outputs* out) {
+                                  const spc_moment_outputs* out, void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     rc = check_kernel(h_kernel, ntaps);
@@ -465,31 +462,30 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
     ConvArgs A{};
     rc = fill_common(A, cube, mask, h_kernel, ntaps, R);
     if (rc) return rc;
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    const size_t ntiles = (size_t)((cube->ny * cube->nx + 127) / 128);
+    SPC_WS_TAKE(d_status, ws, unsigned char, ntiles);
+    SPC_WS_TAKE(d_w, ws, double, 3 * cube->nz);
+    A.cen = d_cen; A.dv = dv; A.m1_add = m1_add; A.mo = *out;
+    A.mo_row_stride = out->out_row_stride ? out->out_row_stride : cube->nx;
     if (!R) {
         // no ring (wide kernel): only the algebraic all-valid path can fuse; a flagged tile or an
-        // extremum request sends the caller to the materialised route
-        SPC_DEVICE(device);
-        A.cen = d_cen; A.dv = dv; A.m1_add = m1_add; A.mo = *out;
-        A.mo_row_stride = out->out_row_stride ? out->out_row_stride : cube->nx;
-        unsigned char* d_status = nullptr;
-        double* d_w = nullptr;
+        // extremum request sends the caller to the materialised route.  Whether a tile was flagged is a
+        // result the HOST needs before it can answer: this branch waits for the stream.
         bool ok = false;
-        if (try_weighted_moments(A, cube, h_kernel, ntaps, h_cen, (hipStream_t)stream, &d_status, &d_w)) {
-            const size_t ntiles = (size_t)((A.ny * A.nx + 127) / 128);
+        if (try_weighted_moments(A, cube, h_kernel, ntaps, st, d_status, d_w)) {
             std::vector<unsigned char> hs(ntiles);
-            ok = hipStreamSynchronize((hipStream_t)stream) == hipSuccess &&
-                 hipMemcpy(hs.data(), d_status, ntiles, hipMemcpyDeviceToHost) == hipSuccess;
+            ok = hipMemcpyAsync(hs.data(), d_status, ntiles, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipStreamSynchronize(st) == hipSuccess;
             for (size_t i = 0; ok && i < ntiles; ++i) ok = hs[i] == 0;
-            (void)spc_scratch_free(d_status, (hipStream_t)stream);
-            (void)spc_scratch_free(d_w, (hipStream_t)stream);
         }
         if (ok) return SPC_OK;
         spc_set_error("fused smooth->moments with %d taps needs an all-valid cube and no extremum outputs "
                       "(ring kernels go up to %d taps); materialise with spc_spectral_conv_f32 instead", ntaps, 33);
         return SPC_ERR_UNSUPPORTED;
     }
-    SPC_DEVICE(device);
-    A.cen = d_cen; A.dv = dv; A.m1_add = m1_add;
     // linear spectral axis (every FITS axis is): c[z] = c0 + z*dc -> no per-channel loads
     A.cen_linear = 0;
     if (h_cen && cube->nz >= 2) {
@@ -498,20 +494,20 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
         for (int64_t z = 0; z < cube->nz; ++z) worst = std::max(worst, std::abs(h_cen[z] - (c0 + dc * (double)z)));
         if (worst <= 1e-13 * std::max(span, 1e-300)) { A.cen_linear = 1; A.cen_c0 = c0; A.cen_dc = dc; }
     }
-    A.mo = *out;
-    A.mo_row_stride = out->out_row_stride ? out->out_row_stride : cube->nx;
     A.zchunk = cube->nz;
     const int vec = pick_vec(cube, A.mask, nullptr, 0, 0);
-    unsigned char* d_status = nullptr;
-    double* d_w = nullptr;
-    if (try_weighted_moments(A, cube, h_kernel, ntaps, h_cen, (hipStream_t)stream, &d_status, &d_w)) {
+    if (try_weighted_moments(A, cube, h_kernel, ntaps, st, d_status, d_w)) {
         SPC_LAUNCH_CHECK();
-        rc = launch_ring_raw(R, A, (hipStream_t)stream, 0, true);      // general kernel: flagged tiles only
-        (void)spc_scratch_free(d_status, (hipStream_t)stream);
-        (void)spc_scratch_free(d_w, (hipStream_t)stream);
-        return rc;
+        return launch_ring_raw(R, A, st, 0, true);      // general kernel: flagged tiles only
     }
-    return launch_ring(R, A, (hipStream_t)stream, vec, true);
+    return launch_ring(R, A, st, vec, true, d_status);
 }
 
 }  // extern "C"
+
+size_t spc_ws_spectral_conv(int64_t nz, int64_t ny, int64_t nx, int64_t ntaps, bool fused) {
+    size_t n = spc_ws_round((size_t)((ny * nx + 127) / 128));              // tile flags
+    n += fused ? spc_ws_round(sizeof(double) * 3 * (size_t)nz)            // per-channel weights of the algebraic path
+               : spc_ws_round(sizeof(double) * (size_t)(ntaps + 30));     // taps of the kernels without a ring
+    return n + 256;
+}

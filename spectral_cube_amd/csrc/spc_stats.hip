@@ -458,6 +458,22 @@ __global__ __launch_bounds__(256) void fill_masked_kernel(const ClipArgs A) {
     }
 }
 
+// include map of a mask evaluated on the cube it is bound to: out[z][y][x] = included ? 1 : 0 (uint8,
+// C-contiguous).  `nan_excluded`: a NaN sample counts as excluded as well (what ~isnan-style masks say).
+template <bool ARR>
+__global__ __launch_bounds__(256) void mask_include_kernel(const ClipArgs A, uint8_t* out, int nan_excluded) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= A.nx) return;
+    for (int64_t z = blockIdx.z; z < A.nz; z += gridDim.z) {
+        const float v = A.in[z * A.plane_stride + y * A.row_stride + x];
+        bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v);
+        if (ARR) ok = ok && A.mask.arr[z * A.mask.plane_stride + y * A.mask.row_stride + x] != 0;
+        if (nan_excluded) ok = ok && (v == v);
+        out[(z * A.ny + y) * A.nx + x] = ok ? 1 : 0;
+    }
+}
+
 // filled copy with the two spatial axes exchanged: out[z][x][y] = included ? in[z][y][x] : fill.
 // Puts the rays of an order statistic along x (median(axis=2)) along y, where the selection
 // kernels stream them coalesced.  64 x 64 tile through LDS (pitch 65: conflict-free both ways),
@@ -566,7 +582,7 @@ int fill_common(StatArgs& A, const spc_cube_f32* cube, const spc_mask* mask) {
 extern "C" {
 
 int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
-                         double* h_stats) {
+                         double* h_stats, void* d_workspace, size_t workspace_bytes) {
     SPC_REQUIRE(h_stats != nullptr, "h_stats is NULL");
     StatArgs A{};
     int rc = fill_common(A, cube, mask);
@@ -581,16 +597,15 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, con
     // enough blocks to fill the chip, few enough that the host-side finish is trivial
     const int64_t per_block = 256 * 4 * 4;
     const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (A.rowlen + per_block - 1) / per_block));
-    double* d_partial = nullptr;
-    SPC_HIP(spc_scratch_alloc((void**)&d_partial, sizeof(double) * 5 * nblocks, st));
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_partial, ws, double, 5 * (size_t)nblocks);
     A.partial = d_partial;
     if (arr) hipLaunchKernelGGL(stats_global_kernel<true>, dim3(nblocks), dim3(256), 0, st, A);
     else hipLaunchKernelGGL(stats_global_kernel<false>, dim3(nblocks), dim3(256), 0, st, A);
     hipError_t e = hipGetLastError();
     std::vector<double> h((size_t)5 * nblocks);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_partial, sizeof(double) * 5 * nblocks, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)spc_scratch_free(d_partial, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);         // the record goes back to the host: wait for THIS stream
     SPC_HIP(e);
     double cnt = 0.0, mn = INFINITY, mx = -INFINITY;
     long double sum = 0.0L, ssq = 0.0L;
@@ -606,7 +621,8 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, con
     return SPC_OK;
 }
 
-int spc_stats_planes_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, double* h_stats) {
+int spc_stats_planes_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, double* h_stats,
+                         void* d_workspace, size_t workspace_bytes) {
     SPC_REQUIRE(h_stats != nullptr, "h_stats is NULL");
     StatArgs A{};
     int rc = fill_common(A, cube, mask);
@@ -620,8 +636,8 @@ int spc_stats_planes_f32(int device, void* stream, const spc_cube_f32* cube, con
     int nseg = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + A.nz - 1) / A.nz, (plane + 16383) / 16384));
     nseg = std::min(nseg, 64);
     const size_t nrec = (size_t)A.nz * nseg;
-    double* d_partial = nullptr;
-    SPC_HIP(spc_scratch_alloc((void**)&d_partial, sizeof(double) * 5 * nrec, st));
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_partial, ws, double, 5 * nrec);
     A.partial = d_partial;
     dim3 grid((unsigned)nseg, (unsigned)A.nz);
     if (arr) hipLaunchKernelGGL(stats_planes_kernel<true>, grid, dim3(256), 0, st, A);
@@ -630,7 +646,6 @@ int spc_stats_planes_f32(int device, void* stream, const spc_cube_f32* cube, con
     std::vector<double> h(5 * nrec);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_partial, sizeof(double) * 5 * nrec, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)spc_scratch_free(d_partial, st);
     SPC_HIP(e);
     for (int64_t z = 0; z < A.nz; ++z) {
         double cnt = 0.0, mn = INFINITY, mx = -INFINITY;
@@ -732,7 +747,7 @@ int spc_argextrema_axis_f32(int device, void* stream, const spc_cube_f32* cube, 
 }
 
 int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny, int64_t nx,
-                       const double* h_kernel, int nky, int nkx, double* d_out) {
+                       const double* h_kernel, int nky, int nkx, double* d_out, void* d_workspace, size_t workspace_bytes) {
     SPC_REQUIRE(d_in && d_out && h_kernel, "NULL pointer argument");
     SPC_REQUIRE(ny > 0 && nx > 0 && nky > 0 && nkx > 0 && (nky & 1) && (nkx & 1), "bad map / kernel shape");
     double sum = 0.0;
@@ -743,17 +758,12 @@ int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny,
     hipStream_t st = (hipStream_t)stream;
     std::vector<double> k((size_t)nky * nkx);
     for (size_t i = 0; i < k.size(); ++i) k[i] = h_kernel[i] / sum;
-    double* d_k = nullptr;
-    SPC_HIP(spc_scratch_alloc((void**)&d_k, sizeof(double) * k.size(), st));
-    hipError_t e = hipMemcpyAsync(d_k, k.data(), sizeof(double) * k.size(), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);         // (k is a local vector)
-    if (e == hipSuccess) {
-        MapConvArgs A{d_in, d_out, d_k, ny, nx, nky, nkx};
-        hipLaunchKernelGGL(map_conv2d_f64_kernel, dim3((unsigned)((nx + 63) / 64), (unsigned)((ny + 3) / 4)), dim3(256), 0, st, A);
-        e = hipGetLastError();
-    }
-    (void)spc_scratch_free(d_k, st);
-    SPC_HIP(e);
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_k, ws, double, k.size());
+    SPC_HIP(spc_table_upload(d_k, k.data(), sizeof(double) * k.size(), st));
+    MapConvArgs A{d_in, d_out, d_k, ny, nx, nky, nkx};
+    hipLaunchKernelGGL(map_conv2d_f64_kernel, dim3((unsigned)((nx + 63) / 64), (unsigned)((ny + 3) / 4)), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
 
@@ -775,6 +785,25 @@ int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, cons
     dim3 grid((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)std::min<int64_t>(cube->nz, 64));
     if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(fill_masked_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL(fill_masked_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_mask_include_u8(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                        int nan_excluded, uint8_t* d_out) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    ClipArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_REQUIRE(cube->ny <= 65535, "too many rows for one launch");
+    SPC_DEVICE(device);
+    A.in = cube->d_data; A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    dim3 grid((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)std::min<int64_t>(cube->nz, 64));
+    if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(mask_include_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, A, d_out, nan_excluded);
+    else hipLaunchKernelGGL(mask_include_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, A, d_out, nan_excluded);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
@@ -815,13 +844,13 @@ int spc_clip_bounds_f32(int device, void* stream, int64_t n, const int32_t* d_co
 }
 
 int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, int64_t ny, int64_t nx,
-                         const float* d_lo, const float* d_hi, uint64_t* h_nchanged) {
+                         const float* d_lo, const float* d_hi, uint64_t* h_nchanged, void* d_workspace, size_t workspace_bytes) {
     SPC_REQUIRE(d_cube && d_lo && d_hi && h_nchanged, "NULL pointer argument");
     SPC_REQUIRE(nz > 0 && ny > 0 && nx > 0 && ny <= 65535, "bad shape");
     SPC_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long* d_n = nullptr;
-    SPC_HIP(spc_scratch_alloc((void**)&d_n, sizeof(unsigned long long), st));
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_n, ws, unsigned long long, 1);
     hipError_t e = hipMemsetAsync(d_n, 0, sizeof(unsigned long long), st);
     if (e == hipSuccess) {
         ClipArgs A{};
@@ -838,11 +867,20 @@ int spc_clip_outside_f32(int device, void* stream, float* d_cube, int64_t nz, in
     }
     unsigned long long h = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&h, d_n, sizeof h, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)spc_scratch_free(d_n, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);         // the count goes back to the host
     SPC_HIP(e);
     *h_nchanged = (uint64_t)h;
     return SPC_OK;
 }
 
 }  // extern "C"
+
+size_t spc_ws_stats(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1) {
+    switch (kind) {
+        case SPC_WS_STATS_GLOBAL: return spc_ws_round(sizeof(double) * 5 * 4096) + 256;          // <= 4096 partial records
+        case SPC_WS_STATS_PLANES: return spc_ws_round(sizeof(double) * 5 * 64 * (size_t)nz) + 256; // <= 64 segments per channel
+        case SPC_WS_MAP_CONV2D: return spc_ws_round(sizeof(double) * (size_t)(p0 * p1)) + 256;     // normalised taps
+        case SPC_WS_CLIP_OUTSIDE: return 512;                                                   // one counter
+    }
+    return 0;
+}

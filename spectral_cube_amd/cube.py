@@ -17,10 +17,12 @@ GPU the compute methods raise ``HipLibraryError``.
 Differences by design: results of cube->cube operations are
 float32 device-resident cubes (the Dask class keeps float32 too; only
 spectral_interpolate returns float64 there); 2-D maps are float64 like the
-reference; units are plain strings unless astropy is importable; the 1e8-voxel
-``warn_slow`` guard (utils.py:41-75) is not enforced because nothing is
-materialised on the host.
+reference; units are plain strings unless astropy is importable.  The 1e8-voxel
+``warn_slow`` guard (utils.py:41-75) is kept where BOTH reference classes have it
+(``reproject``, ``convolve_to``): set ``cube.allow_huge_operations = True`` for
+cubes above the threshold, exactly as with the reference.
 """
+import functools
 import math
 import operator
 import os
@@ -32,7 +34,8 @@ from . import _lib, masks as M, ops
 from .beam import Beam, BeamError
 from .device import DeviceArray
 from .kernels import kernel_array
-from .wcs import SimpleWCS, pix_cen_spatial, pix_size, reproject_pixel_map
+from .wcs import (SimpleWCS, join_celestial_spectral, pix_cen_spatial, pix_size, reproject_pixel_map,
+                  spectral_unit_scale)
 
 SIGMA2FWHM = 2. * np.sqrt(2. * np.log(2.))      # spectral_cube.py:66
 
@@ -57,6 +60,42 @@ _VARIANCE_MSG = ("Note that the second moment returned will be a "
                  "variance map. To get a linewidth map, use the "
                  "SpectralCube.linewidth_fwhm() or "
                  "SpectralCube.linewidth_sigma() methods instead.")
+
+
+MEMORY_THRESHOLD = 1e8        # voxels: cube_utils.py:266-274
+
+
+def warn_slow(function):
+    """utils.py:41-75: operations the reference refuses on huge cubes unless
+    ``allow_huge_operations`` is set (they load the whole cube there; here they need the whole cube
+    resident in HBM, plus an output of the same size).  Same switch, same ValueError."""
+    @functools.wraps(function)
+    def wrapper(self, *args, **kwargs):
+        if self._is_huge and not self.allow_huge_operations:
+            raise ValueError("This function ({0}) requires loading the entire "
+                             "cube into memory, and the cube is large ({1} "
+                             "pixels), so by default we disable this operation. "
+                             "To enable the operation, set "
+                             "`cube.allow_huge_operations=True` and try again.  "
+                             "See {2} for details.".format(str(function), self.size,
+                                                           "https://spectral-cube.readthedocs.io/en/latest/big_data.html"))
+        return function(self, *args, **kwargs)
+    return wrapper
+
+
+def _check_convolve(convolve):
+    """The ``convolve=`` seam of spectral_smooth / spatial_smooth / convolve_to
+    (dask_spectral_cube.py:883, 963; spectral_cube.py:2810, 3188, 3335).  The device stencils ARE
+    astropy's normalised, NaN-interpolating convolution, so astropy's own ``convolve`` (the default of
+    the smoothing methods) and ``convolve_fft`` (the default of convolve_to; same mathematics through
+    an FFT) are accepted as naming it; any other callable cannot run on the device."""
+    if convolve is None:
+        return
+    mod, name = getattr(convolve, "__module__", "") or "", getattr(convolve, "__name__", "")
+    if mod.startswith("astropy.convolution") and name in ("convolve", "convolve_fft"):
+        return
+    raise NotImplementedError("custom `convolve` callables cannot run on the device; the HIP stencils "
+                              "implement astropy.convolution.convolve (pass that, convolve_fft, or nothing)")
 
 
 def _unit_mul(a, b):
@@ -103,7 +142,8 @@ class Projection(np.ndarray):
         ``beam.deconvolve(self.beam).as_kernel(pixscale)`` through the same NaN-aware 2-D stencils as
         the cube (one channel), astropy's normalised 'interpolate' treatment."""
         treat = kwargs.pop("nan_treatment", "interpolate")
-        if convolve is not None or treat not in ("interpolate", "fill") or kwargs.pop("fill_value", 0.0) != 0.0 or kwargs:
+        _check_convolve(convolve)
+        if treat not in ("interpolate", "fill") or kwargs.pop("fill_value", 0.0) != 0.0 or kwargs:
             raise NotImplementedError("the device stencil is astropy.convolution.convolve with boundary='fill', "
                                       "fill_value=0, normalize_kernel=True and nan_treatment 'interpolate' or 'fill'")
         w = self._celestial()
@@ -220,11 +260,16 @@ class SpectralCube:
         cube._mask = finite if beam_mask is None else (finite & beam_mask)
         return cube
 
-    def write(self, filename, overwrite=False, format=None):
-        """Write the (unmasked) data as a FITS cube (io/fits.py:262-294): device byte swap,
-        pinned read-back, no host arithmetic."""
+    def write(self, filename, overwrite=False, format=None, filled=True):
+        """Write the cube as FITS (io/fits.py:262-294; device byte swap, pinned read-back, no host
+        arithmetic).  Like the reference's ``hdu`` (dask_spectral_cube.py:1405,1502:
+        ``_get_filled_data(fill=self._fill_value)``) what goes to disk is the FILLED data: excluded
+        voxels carry the fill value (NaN by default).  ``filled=False`` writes the raw voxels."""
         from . import io_fits
-        io_fits.save_cube(os.fspath(filename), self._device_data(), header=self._header, overwrite=overwrite)
+        dev = self._device_data()
+        if filled and self._mask is not None:
+            dev = ops.fill_masked(dev, self._mask_spec(), self._fill_value)
+        io_fits.save_cube(os.fspath(filename), dev, header=self._header, overwrite=overwrite)
 
     @classmethod
     def from_device(cls, dev, wcs=None, header=None, mask=None, **kw):
@@ -263,6 +308,10 @@ class SpectralCube:
     @property
     def size(self):
         return int(np.prod(self._shape, dtype=np.int64))
+
+    @property
+    def _is_huge(self):
+        return self.size > MEMORY_THRESHOLD                  # cube_utils.is_huge
 
     @property
     def unit(self):
@@ -345,9 +394,20 @@ class SpectralCube:
     def _mask_spec(self):
         """lower the mask tree once and keep the uint8 array resident in HBM."""
         if self._mask_cache is None:
-            flags, lo, hi, arr = M.lower_mask(self._mask, self, self._shape)
-            darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
-            self._mask_cache = ops.MaskSpec(flags, lo, hi, darr)
+            owner = M.foreign_owner(self._mask) if self._mask is not None else None
+            if (owner is not None and not owner._is_same_data(self) and tuple(owner._shape) == tuple(self._shape)
+                    and self._mask._device_terms(owner) is not None):
+                # every lazy term belongs to ANOTHER cube's data (a smoothed cube keeps its parent's mask):
+                # evaluate it there, on the device - no host copy of either cube
+                flags, lo, hi, arr = M.lower_mask(self._mask, owner, self._shape)
+                darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
+                inc = ops.mask_include(owner._device_data(), ops.MaskSpec(flags, lo, hi, darr),
+                                       nan_excluded=M.contains(self._mask, M.NotNaNMask))
+                self._mask_cache = ops.MaskSpec(_lib.MASK_ARRAY, 0.0, 0.0, inc)
+            else:
+                flags, lo, hi, arr = M.lower_mask(self._mask, self, self._shape)
+                darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
+                self._mask_cache = ops.MaskSpec(flags, lo, hi, darr)
         return self._mask_cache
 
     @property
@@ -483,10 +543,14 @@ class SpectralCube:
             d_cen = DeviceArray.from_numpy(cen, self.device)
             size = self._pix_size_slice(axis)
             key = {0: "m0", 1: "m1", 2: "m2"}.get(order)
-            if key is None:
-                raise NotImplementedError("moments of order > 2 along spatial axes are not built yet")
-            out = ops.moments_spatial(self._device_data(), d_cen, axis, size, mask=self._mask_spec(),
-                                      want=(key,))[key].get()
+            if key is None:          # order > 2: second pass about the first moment (_moments.py:185-193)
+                mu = ops.moments_spatial(self._device_data(), d_cen, axis, size, mask=self._mask_spec(),
+                                         want=("m1",))["m1"]
+                out = ops.moment_order_spatial(self._device_data(), d_cen, axis, order, mu,
+                                               mask=self._mask_spec()).get()
+            else:
+                out = ops.moments_spatial(self._device_data(), d_cen, axis, size, mask=self._mask_spec(),
+                                          want=(key,))[key].get()
             axunit = self._wcs.cunit[2 - axis] if self._wcs is not None else ""
         if order == 0:
             unit = _unit_mul(self._unit, axunit)
@@ -723,9 +787,7 @@ class SpectralCube:
         (dask_spectral_cube.py:880-917).  Lazy like the Dask class: a following
         ``moment`` runs fused with the stencil, any other access materialises."""
         karr = kernel_array(kernel, 1)
-        if convolve is not None:
-            raise NotImplementedError("custom `convolve` callables cannot run on the device; "
-                                      "the HIP stencil implements astropy.convolution.convolve")
+        _check_convolve(convolve)
         parent = self
 
         class _Lazy:
@@ -746,8 +808,7 @@ class SpectralCube:
         convolve_wrapper only receives ``kernel``, :990-993; spectral_smooth likewise, :912-917)."""
         self.check_jybeam_smoothing(raise_error_jybm=raise_error_jybm)
         karr = kernel_array(kernel, 2)
-        if convolve is not None:
-            raise NotImplementedError("custom `convolve` callables cannot run on the device")
+        _check_convolve(convolve)
         parent = self
 
         class _Lazy:
@@ -776,12 +837,12 @@ class SpectralCube:
         new._header = dict(self._header, BMAJ=beam.major, BMIN=beam.minor, BPA=beam.pa)
         return new
 
+    @warn_slow
     def convolve_to(self, beam, convolve=None, **kwargs):
         """Convolve every channel to *beam* (dask_spectral_cube.py:1412-1464): kernel = beam.deconvolve(
         self.beam).as_kernel(pixscale) through the 2-D stencils (separable when the kernel is, else the
         LDS-tiled direct kernel), Jy/beam data scaled by the ratio of the beam areas."""
-        if convolve is not None:
-            raise NotImplementedError("custom `convolve` callables cannot run on the device")
+        _check_convolve(convolve)
         if self.beam is None:
             raise ValueError("cube has no beam (BMAJ / BMIN / BPA) to convolve from")
         if beam == self.beam:
@@ -850,18 +911,40 @@ class SpectralCube:
         out._mask = M.NotNaNMask(out)
         return out
 
+    @warn_slow
     def reproject(self, header, order="bilinear", use_memmap=False, filled=True, **kwargs):
-        """Spatially reproject onto the celestial WCS of *header*
-        (spectral_cube.py:2649-2746).  Bilinear only; the pixel map comes from
-        this package's WCS (validated against astropy.wcs)."""
-        if order not in ("bilinear", 1):
-            raise NotImplementedError("only order='bilinear' is built on the GPU path")
+        """Reproject onto the WCS of *header* (spectral_cube.py:2649-2746 -> reproject_interp).
+
+        The celestial plane of every channel is resampled at the source positions of the target pixels
+        (``order`` 'bilinear' / 1 or 'nearest-neighbor' / 0; the pixel map is formed on the device by
+        this package's WCS, validated against astropy.wcs).  Like the reference, a cube header also
+        carries the output's spectral axis: ``NAXIS3`` channels at the target's spectral coordinates,
+        linearly interpolated between the source channels (reproject_interp's one trilinear call for a
+        separable cube WCS, restated as oracle_np.reproject_separable and pinned against scipy).  A
+        2-axis header keeps this cube's spectral axis.  Masked voxels enter as ``fill_value`` when
+        ``filled``; the new mask is the footprint; an output without a single non-NaN value raises the
+        reference's ValueError."""
+        order = {"nearest-neighbor": 0, "bilinear": 1}.get(order, order)
+        if order not in (0, 1):
+            raise NotImplementedError("order %r: the device resampler does 'bilinear' and 'nearest-neighbor'" % (order,))
         newwcs = header if isinstance(header, SimpleWCS) else SimpleWCS(header)
         hdr = newwcs.header
         if "NAXIS1" in hdr and "NAXIS2" in hdr:
             ny_out, nx_out = int(hdr["NAXIS2"]), int(hdr["NAXIS1"])
         else:
             ny_out, nx_out = self._shape[1:]
+        nz = self._shape[0]
+        zs = None
+        if newwcs.naxis >= 3 and self._wcs is not None and self._wcs.naxis >= 3:
+            nz_out = int(hdr.get("NAXIS3", nz))
+            scale = spectral_unit_scale(newwcs.spectral_unit or self.spectral_unit, self.spectral_unit)
+            zs = self._wcs.spectral_world2pix(newwcs.spectral_pix2world(np.arange(nz_out)) * scale)
+            if nz_out == nz and np.all(np.abs(zs - np.arange(nz)) <= 1e-9 * max(nz, 1)):
+                zs = None                         # the same channels: a purely spatial reprojection
+        elif self._wcs is not None and self._wcs.naxis >= 3:
+            newwcs = join_celestial_spectral(newwcs, self._wcs)
+        if zs is not None and (order == 0 or nz < 2):
+            raise NotImplementedError("resampling the spectral axis as well needs order='bilinear' and at least two channels")
         if os.environ.get("SPC_WCS_HOST_MAP", "0") == "1":         # cross-check: the numpy map (0.8 s per 1024^2 pixels)
             xs, ys = reproject_pixel_map(self._wcs, newwcs, (ny_out, nx_out))
             xs = np.where(np.isfinite(xs), xs, -1e30)
@@ -870,17 +953,32 @@ class SpectralCube:
             _lib.require_gpu()
             xs, ys = ops.wcs_pixel_map(self._wcs, newwcs, (ny_out, nx_out), self.device)
         mask = self._mask_spec() if filled else None
+        flag = DeviceArray((1,), np.uint32, self.device)
         dev, foot = ops.resample_bilinear(self._device_data(), xs, ys, fill=float(self._fill_value),
-                                          mask=mask)
+                                          mask=mask, order=order, any_valid=flag)
         footprint = foot.get().astype(bool)
-        if not footprint.any():
+        valid3d = footprint[None]
+        if zs is not None:
+            # reproject_separable: channel positions inside [-0.5, nz - 0.5] are clipped to the cube,
+            # each output channel is the linear blend of the two resampled planes around it
+            inside = (zs >= -0.5) & (zs <= nz - 0.5)
+            zc = np.clip(np.where(inside, zs, 0.0), 0.0, nz - 1.0)
+            z0 = np.minimum(np.floor(zc).astype(np.int64), nz - 2)
+            lo = np.where(inside, z0, -1).astype(np.int32)
+            dev = ops.spectral_lerp(dev, lo, zc - z0, np.ones(len(zs)), np.nan)
+            if not inside.all():
+                valid3d = footprint[None] & inside[:, None, None]
+            nothing = (not inside.any()) or ops.stats_global(dev)["npts"] == 0
+        else:
+            nothing = int(flag.get()[0]) == 0
+        if nothing:
             raise ValueError("All values in reprojected cube are nan.  This can be caused"
                              " by an error in which coordinates do not 'round-trip'.  Try "
                              "setting ``roundtrip_coords=False``.  You might also check "
                              "whether the WCS transformation produces valid pixel->world "
                              "and world->pixel coordinates in each axis.")
         out = self._new_cube_with(dev=dev, wcs=newwcs, mask=False, shape=dev.shape)
-        out._mask = M.BooleanArrayMask(footprint[None], newwcs, shape=dev.shape)
+        out._mask = M.BooleanArrayMask(valid3d, newwcs, shape=dev.shape)
         out._footprint = footprint
         return out
 
@@ -970,14 +1068,14 @@ class VaryingResolutionSpectralCube(SpectralCube):
         io_fits.append_beams_table(os.fspath(filename), [b.major for b in self._beams],
                                    [b.minor for b in self._beams], [b.pa for b in self._beams])
 
+    @warn_slow
     def convolve_to(self, beam, allow_smaller=False, convolve=None, **kwargs):
         """Convolve each channel to *beam* (dask_spectral_cube.py:1511-1630): channel k gets the kernel
         ``beam.deconvolve(beams[k]).as_kernel(pixscale)`` and, for Jy/beam data, the factor
         ``beam.sr / beams[k].sr``; channels whose beam is masked, equals the target, or (with
         ``allow_smaller``) cannot be deconvolved are passed through as filled data.  Returns a
         single-beam SpectralCube."""
-        if convolve is not None:
-            raise NotImplementedError("custom `convolve` callables cannot run on the device")
+        _check_convolve(convolve)
         if self._wcs is None:
             raise ValueError("convolve_to needs the celestial pixel scale of a WCS")
         psm = self._wcs.pixel_scale_matrix

@@ -183,8 +183,10 @@ class LazyComparisonMask(LazyMask):
             # the same for "weak" python scalars (NEP 50); typed float64 scalars are
             # compared in float64, so only lower those when exactly representable.
             weak = type(self._value) in (float, int)
+            if v != v:
+                return None          # a NaN threshold includes nothing: left to the host form (all False)
             if weak or float(np.float32(v)) == v or not np.isfinite(v):
-                v = float(np.float32(v))
+                v = float(np.float32(v))          # +-inf stay +-inf: `cube > -inf` is a real comparison
                 flag = _CMP[self._cmp]
                 if flag in (_lib.MASK_GT, _lib.MASK_GE):
                     return (flag, v, np.inf, None)
@@ -251,13 +253,50 @@ def lower_mask(mask, data, shape):
         return (0, 0.0, 0.0, None)
     terms = mask._device_terms(data)
     if terms is None:
-        inc = np.asarray(mask.include(data=data))
+        # host form: FunctionMask and friends index the voxel ARRAY (masks.py:760-803), not the cube object
+        host = data._host_data() if hasattr(data, "_host_data") else data
+        inc = np.asarray(mask.include(data=host))
         terms = (0, -np.inf, np.inf, np.broadcast_to(inc, shape))
     flags, lo, hi, m = terms
     arr = None
     if m is not None:
         flags |= _lib.MASK_ARRAY
         arr = np.ascontiguousarray(np.broadcast_to(m, shape)).view(np.uint8)
-    lo = float(lo) if np.isfinite(lo) else 0.0
-    hi = float(hi) if np.isfinite(hi) else 0.0
+    # a bound that is not in force is passed as 0; one that is keeps its value, infinities included
+    lo = float(lo) if flags & (_lib.MASK_GT | _lib.MASK_GE) else 0.0
+    hi = float(hi) if flags & (_lib.MASK_LT | _lib.MASK_LE) else 0.0
     return (flags, lo, hi, arr)
+
+
+def contains(mask, cls):
+    """True when a term of the mask tree is an instance of *cls*"""
+    if isinstance(mask, cls):
+        return True
+    if isinstance(mask, CompositeMask):
+        return contains(mask._mask1, cls) or contains(mask._mask2, cls)
+    if isinstance(mask, InvertedMask):
+        return contains(mask._mask, cls)
+    return False
+
+
+def foreign_owner(mask):
+    """The ONE other cube whose data every lazy term of *mask* is bound to (e.g. the parent of a
+    smoothed cube, which keeps the parent's mask object: dask_spectral_cube.py:836-840), or None
+    when there is no such single cube.  cube._mask_spec() then evaluates the mask on that cube's
+    device data instead of copying it to the host."""
+    owners = []
+
+    def walk(m):
+        if isinstance(m, CompositeMask):
+            walk(m._mask1); walk(m._mask2)
+        elif isinstance(m, InvertedMask):
+            walk(m._mask)
+        elif isinstance(m, LazyMask):
+            owners.append(m._data_ref)
+        elif isinstance(m, FunctionMask):
+            owners.append(None)
+    walk(mask)
+    first = owners[0] if owners else None
+    if first is None or isinstance(first, _Holder) or any(o is not first for o in owners):
+        return None
+    return first

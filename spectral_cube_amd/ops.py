@@ -5,6 +5,7 @@ Each function names the reference code it stands in for (paths relative to the
 reference tree).  There is no CPU fallback here.
 """
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -76,6 +77,39 @@ def _mask_c(mask, cube):
 def _kern(k):
     k = np.ascontiguousarray(k, dtype=np.float64).ravel()
     return k, k.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ---- device scratch: one reusable buffer per (device, stream, host thread) ---------------------------
+# The C ABI never allocates (include/spcube_hip.h): every call gets its scratch from the caller.  Calls
+# queued on one stream run one after the other, so they can share ONE buffer that only ever grows; two
+# streams, or two host threads (dask `threads` workers), get their own.  Growing replaces the buffer -
+# the old one goes back through spc_free, which waits for the work still using it.
+_ws_lock = threading.Lock()
+_ws_cache = {}
+
+
+def workspace(device, stream, kind, nz, ny, nx, p0=0, p1=0, explicit=None):
+    """(c_void_p, nbytes) of a device scratch buffer large enough for entry point *kind* (a
+    _lib.WS_* constant) - *explicit* (a DeviceArray) when the caller manages its own."""
+    need = int(_lib.load().spc_workspace_bytes(int(kind), int(nz), int(ny), int(nx), int(p0), int(p1)))
+    if explicit is not None:
+        if explicit.nbytes < need:
+            raise ValueError("workspace of %d bytes given, %d needed" % (explicit.nbytes, need))
+        return C.c_void_p(explicit.ptr), explicit.nbytes
+    h = _sh(stream)
+    key = (device, getattr(h, "value", h) or 0, threading.get_ident())
+    with _ws_lock:
+        buf = _ws_cache.get(key)
+        if buf is None or buf.nbytes < need:
+            buf = DeviceArray((max(need, 1 << 16),), np.uint8, device)
+            _ws_cache[key] = buf
+    return C.c_void_p(buf.ptr), buf.nbytes
+
+
+def release_workspaces():
+    """drop every cached scratch buffer (they return to the pool of spc_malloc)"""
+    with _ws_lock:
+        _ws_cache.clear()
 
 
 _WANT_ALL = ("m0", "m1", "m2")
@@ -171,6 +205,19 @@ def moments_spatial(cube, cen2d, axis, pix_size, mask=None, want=_WANT_ALL, stre
     return bufs
 
 
+def moment_order_spatial(cube, cen2d, axis, order, mu, mask=None, stream=None):
+    """sum v (c - mu)^order / sum v along a spatial axis: the second pass for order > 2
+    (dask_spectral_cube.py:1094-1099 with axis != 0); *mu* = the m1 map of moments_spatial."""
+    nz, ny, nx = cube.shape
+    if axis not in (1, 2):
+        raise ValueError("axis must be 1 or 2")
+    out = DeviceArray((nz, nx) if axis == 1 else (nz, ny), np.float64, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_moment_order_spatial_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis),
+              C.c_void_p(cen2d.ptr), int(order), C.c_void_p(mu.ptr), C.c_void_p(out.ptr))
+    return out
+
+
 def spectral_conv(cube, kernel1d, mask=None, out=None, stream=None):
     """NaN-aware convolution along the spectral axis = chunk function of
     spectral_smooth (dask_spectral_cube.py:880-917)."""
@@ -178,8 +225,9 @@ def spectral_conv(cube, kernel1d, mask=None, out=None, stream=None):
         out = DeviceArray(cube.shape, np.float32, cube.device)
     k, kp = _kern(kernel1d)
     c, m = _cube_c(cube), _mask_c(mask, cube)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_SPECTRAL_CONV, *cube.shape, len(k))
     _lib.call("spc_spectral_conv_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), kp, len(k),
-              C.c_void_p(out.ptr), 0, 0)
+              C.c_void_p(out.ptr), 0, 0, ws, wsn)
     return out
 
 
@@ -195,8 +243,9 @@ def spectral_conv_moments(cube, kernel1d, cen, dv=1.0, m1_add=0.0, mask=None, wa
     if cen_host is not None:
         cen_host = np.ascontiguousarray(cen_host, dtype=np.float64)
         hc = cen_host.ctypes.data_as(C.POINTER(C.c_double))
+    ws, wsn = workspace(cube.device, stream, _lib.WS_SPECTRAL_CONV_MOMENTS, *cube.shape, len(k))
     _lib.call("spc_spectral_conv_moments_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), kp,
-              len(k), C.c_void_p(cen.ptr), hc, float(dv), float(m1_add), C.byref(o))
+              len(k), C.c_void_p(cen.ptr), hc, float(dv), float(m1_add), C.byref(o), ws, wsn)
     return bufs
 
 
@@ -234,12 +283,14 @@ def spatial_conv(cube, kernel2d, mask=None, out=None, stream=None):
     sep = separable_factors(k2)
     if sep is not None:
         (ky, kyp), (kx, kxp) = _kern(sep[0]), _kern(sep[1])
+        ws, wsn = workspace(cube.device, stream, _lib.WS_SPATIAL_CONV_SEP, *cube.shape, len(ky), len(kx))
         _lib.call("spc_spatial_conv_sep_f32", cube.device, _sh(stream), C.byref(c), C.byref(m),
-                  kyp, len(ky), kxp, len(kx), C.c_void_p(out.ptr), 0, 0)
+                  kyp, len(ky), kxp, len(kx), C.c_void_p(out.ptr), 0, 0, ws, wsn)
     else:
         k, kp = _kern(k2)
+        ws, wsn = workspace(cube.device, stream, _lib.WS_SPATIAL_CONV2D, *cube.shape, k2.shape[0], k2.shape[1])
         _lib.call("spc_spatial_conv2d_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), kp,
-                  k2.shape[0], k2.shape[1], C.c_void_p(out.ptr), 0, 0)
+                  k2.shape[0], k2.shape[1], C.c_void_p(out.ptr), 0, 0, ws, wsn)
     return out
 
 
@@ -311,10 +362,12 @@ def wcs_pixel_map(wcs_in, wcs_out, shape_out, device=0, stream=None):
     return d_xs, d_ys
 
 
-def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_footprint=True, out=None):
+def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_footprint=True, out=None,
+                      order=1, any_valid=None):
     """bilinear spatial resample of every channel at (xs, ys) source pixel
     coordinates (resampler of reproject_interp, spectral_cube.py:2726-2732).  xs, ys: host arrays or
-    float64 DeviceArrays (wcs_pixel_map)."""
+    float64 DeviceArrays (wcs_pixel_map).  order: 1 bilinear, 0 nearest neighbour.  any_valid: optional
+    1-element uint32 DeviceArray, set to 1 iff some output value is not NaN."""
     dev = cube.device
     if isinstance(xs, DeviceArray) and isinstance(ys, DeviceArray):
         if xs.dtype != np.float64 or ys.dtype != np.float64 or xs.shape != ys.shape or len(xs.shape) != 2:
@@ -334,9 +387,11 @@ def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_fo
         raise ValueError("out must be a contiguous float32 (nz, ny_out, nx_out) DeviceArray")
     foot = DeviceArray((ny_out, nx_out), np.uint8, dev) if want_footprint else None
     c, m = _cube_c(cube), _mask_c(mask, cube)
+    ws, wsn = workspace(dev, stream, _lib.WS_RESAMPLE_BILINEAR, *cube.shape, ny_out, nx_out)
     _lib.call("spc_resample_bilinear_f32", dev, _sh(stream), C.byref(c), C.byref(m), float(fill),
               ny_out, nx_out, C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr), C.c_void_p(out.ptr), 0, 0,
-              C.c_void_p(foot.ptr) if foot is not None else None)
+              C.c_void_p(foot.ptr) if foot is not None else None, int(order),
+              C.c_void_p(any_valid.ptr) if any_valid is not None else None, ws, wsn)
     out._plan = (d_xs, d_ys)
     return out, foot
 
@@ -352,7 +407,8 @@ def stats_global(cube, mask=None, stream=None):
     Returns python floats; synchronises."""
     c, m = _cube_c(cube), _mask_c(mask, cube)
     h = (C.c_double * 5)()
-    _lib.call("spc_stats_global_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), h)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_STATS_GLOBAL, *cube.shape)
+    _lib.call("spc_stats_global_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), h, ws, wsn)
     return {"npts": h[0], "min": h[1], "max": h[2], "sum": h[3], "sumsq": h[4]}
 
 
@@ -362,7 +418,8 @@ def stats_planes(cube, mask=None, stream=None):
     nz = cube.shape[0]
     buf = (C.c_double * (5 * nz))()
     c, m = _cube_c(cube), _mask_c(mask, cube)
-    _lib.call("spc_stats_planes_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), buf)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_STATS_PLANES, *cube.shape)
+    _lib.call("spc_stats_planes_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), buf, ws, wsn)
     a = np.frombuffer(buf, dtype=np.float64).reshape(nz, 5)
     return {"count": a[:, 0].copy(), "min": a[:, 1].copy(), "max": a[:, 2].copy(), "sum": a[:, 3].copy(), "sumsq": a[:, 4].copy()}
 
@@ -400,8 +457,9 @@ def map_conv2d(dmap, kernel2d, stream=None, out=None):
         raise ValueError("kernel must be 2-D")
     if out is None:
         out = DeviceArray(dmap.shape, np.float64, dmap.device)
+    ws, wsn = workspace(dmap.device, stream, _lib.WS_MAP_CONV2D, 1, dmap.shape[0], dmap.shape[1], k.shape[0], k.shape[1])
     _lib.call("spc_map_conv2d_f64", dmap.device, _sh(stream), C.c_void_p(dmap.ptr), dmap.shape[0], dmap.shape[1],
-              k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], C.c_void_p(out.ptr))
+              k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], C.c_void_p(out.ptr), ws, wsn)
     return out
 
 
@@ -432,13 +490,25 @@ def fill_masked(cube, mask=None, fill=np.nan, stream=None, out=None):
     return out
 
 
+def mask_include(cube, mask=None, nan_excluded=False, stream=None):
+    """uint8 (nz, ny, nx) DeviceArray: 1 where *mask* (a MaskSpec evaluated on *cube*'s values) includes
+    the voxel (spc_mask_include_u8) - a lazy mask bound to another device-resident cube is lowered
+    like this instead of through a host copy of that cube."""
+    out = DeviceArray(cube.shape, np.uint8, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    _lib.call("spc_mask_include_u8", cube.device, _sh(stream), C.byref(c), C.byref(m), 1 if nan_excluded else 0,
+              C.c_void_p(out.ptr))
+    return out
+
+
 def percentile_global(cube, q, mask=None, center=None, stream=None):
     """q-th percentile of all included samples of the cube (np.nanpercentile(..., axis=None));
     with *center* of |x - center|.  Returns a python float (NaN when nothing is included)."""
     out = C.c_double(0.0)
     c, m = _cube_c(cube), _mask_c(mask, cube)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_PERCENTILE_GLOBAL, *cube.shape)
     _lib.call("spc_percentile_global_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(q),
-              0 if center is None else 1, 0.0 if center is None else float(center), C.byref(out))
+              0 if center is None else 1, 0.0 if center is None else float(center), C.byref(out), ws, wsn)
     return out.value
 
 
@@ -488,8 +558,9 @@ def sigma_clip_axis0(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxite
                   ptr(st["sumsq"]) if use_stats else None, ptr(center), ptr(spread), float(lo_s), float(hi_s),
                   C.c_void_p(d_lo.ptr), C.c_void_p(d_hi.ptr))
         nch = C.c_uint64(0)
+        ws, wsn = workspace(dev, stream, _lib.WS_CLIP_OUTSIDE, nz, ny, nx)
         _lib.call("spc_clip_outside_f32", dev, _sh(stream), C.c_void_p(work.ptr), nz, ny, nx,
-                  C.c_void_p(d_lo.ptr), C.c_void_p(d_hi.ptr), C.byref(nch))
+                  C.c_void_p(d_lo.ptr), C.c_void_p(d_hi.ptr), C.byref(nch), ws, wsn)
         if nch.value == 0:
             break
     return work

@@ -232,6 +232,13 @@ class SimpleWCS:
             raise NotImplementedError("spectral and celestial axes must be separable")
         return self.crval[2] + self.cdelt[2] * self.pc[2, 2] * (pz + 1.0 - self.crpix[2])
 
+    def spectral_world2pix(self, w):
+        """world coordinate (in this axis' CUNIT3) -> 0-based channel (fractional); linear axis"""
+        if self.naxis < 3:
+            raise ValueError("no spectral axis")
+        w = np.asarray(w, dtype=np.float64)
+        return (w - self.crval[2]) / (self.cdelt[2] * self.pc[2, 2]) + self.crpix[2] - 1.0
+
     @property
     def spectral_unit(self):
         return self.cunit[2] if self.naxis >= 3 else ""
@@ -269,6 +276,35 @@ class SimpleWCS:
                 if self.pc[i, j] != (1.0 if i == j else 0.0):
                     h["PC%d_%d" % (i + 1, j + 1)] = float(self.pc[i, j])
         return h
+
+
+_SPECTRAL_SI = {"m/s": ("speed", 1.0), "km/s": ("speed", 1e3), "cm/s": ("speed", 1e-2),
+                "Hz": ("freq", 1.0), "kHz": ("freq", 1e3), "MHz": ("freq", 1e6), "GHz": ("freq", 1e9),
+                "m": ("length", 1.0), "cm": ("length", 1e-2), "mm": ("length", 1e-3), "um": ("length", 1e-6),
+                "nm": ("length", 1e-9), "Angstrom": ("length", 1e-10), "angstrom": ("length", 1e-10)}
+
+
+def spectral_unit_scale(unit_from, unit_to):
+    """factor that takes a spectral coordinate in *unit_from* to *unit_to* (what wcslib's SI normalisation
+    does for two headers of one spectral type, spectral_cube.py:218-228); ValueError when the two are not
+    the same kind of quantity - that is a change of spectral representation, not a regrid."""
+    a, b = (unit_from or "").strip(), (unit_to or "").strip()
+    if a == b:
+        return 1.0
+    if a not in _SPECTRAL_SI or b not in _SPECTRAL_SI or _SPECTRAL_SI[a][0] != _SPECTRAL_SI[b][0]:
+        raise ValueError("cannot relate spectral units %r and %r: convert the cube's spectral axis first" % (a, b))
+    return _SPECTRAL_SI[a][1] / _SPECTRAL_SI[b][1]
+
+
+def join_celestial_spectral(celestial, spectral):
+    """3-axis WCS with the celestial axes of *celestial* and the spectral axis of *spectral*"""
+    h = {k: v for k, v in celestial.header.items() if not (k.endswith("3") or "3_" in k or "_3" in k)}
+    for k, v in spectral.header.items():
+        if k.endswith("3") and not k.startswith("NAXIS"):
+            h[k] = v
+    h["NAXIS"] = 3
+    h["WCSAXES"] = 3
+    return SimpleWCS(h)
 
 
 def angular_separation(lon1, lat1, lon2, lat2):

@@ -33,10 +33,10 @@ int main(int argc, char** argv) {
     SYM(spc_stream_create); SYM(spc_stream_destroy); SYM(spc_stream_sync); SYM(spc_device_sync);
     SYM(spc_event_create); SYM(spc_event_destroy); SYM(spc_event_record); SYM(spc_event_sync);
     SYM(spc_stream_wait_event); SYM(spc_event_elapsed_ms);
-    SYM(spc_moments_workspace_bytes); SYM(spc_moments_f32); SYM(spc_moment_order_f32); SYM(spc_moments_spatial_f32);
+    SYM(spc_moments_workspace_bytes); SYM(spc_workspace_bytes); SYM(spc_moments_f32); SYM(spc_moment_order_f32); SYM(spc_moments_spatial_f32);
     SYM(spc_spectral_conv_f32); SYM(spc_spectral_conv_moments_f32); SYM(spc_spatial_conv_sep_f32);
     SYM(spc_spatial_conv2d_f32); SYM(spc_spectral_lerp_f32); SYM(spc_resample_bilinear_f32);
-    SYM(spc_stats_global_f32); SYM(spc_stats_axis_f32); SYM(spc_fits_to_f32); SYM(spc_map_conv2d_f64); SYM(spc_percentile_axis0_f32); SYM(spc_fill_masked_f32); SYM(spc_clip_outside_f32); SYM(spc_scale_f32);
+    SYM(spc_stats_global_f32); SYM(spc_stats_axis_f32); SYM(spc_fits_to_f32); SYM(spc_map_conv2d_f64); SYM(spc_percentile_axis0_f32); SYM(spc_fill_masked_f32); SYM(spc_moment_order_spatial_f32); SYM(spc_mask_include_u8); SYM(spc_clip_outside_f32); SYM(spc_scale_f32);
     SYM(spc_argextrema_axis_f32); SYM(spc_percentile_global_f32); SYM(spc_fill_masked_transpose_f32); SYM(spc_pool_trim); SYM(spc_pool_stats); SYM(spc_clip_bounds_f32); SYM(spc_wcs_pixel_map_f64); SYM(spc_stats_planes_f32);
     SYM(spc_comm_unique_id); SYM(spc_comm_init); SYM(spc_comm_destroy); SYM(spc_allgather_rows);
 
@@ -88,6 +88,37 @@ int main(int argc, char** argv) {
         }
     }
     dfree(0, d_data); dfree(0, d_cen); dfree(0, d_m0); dfree(0, d_m1); dfree(0, d_m2);
-    printf("gpu ok: 3x3x3 reference moment cube reproduced through the C ABI\n");
+    /* caller-owned scratch: spectral_smooth of the reference's 5x2x2 delta cube (test_regrid.py:138-172: the
+     * smoothed spike equals the kernel samples) with a workspace sized by spc_workspace_bytes; a call with a
+     * workspace that is too small is rejected before any device work */
+    typedef size_t (*wsbytes_fn)(int, int64_t, int64_t, int64_t, int64_t, int64_t);
+    typedef int (*sconv_fn)(int, void*, const spc_cube_f32*, const spc_mask*, const double*, int, float*, int64_t, int64_t,
+                            void*, size_t);
+    wsbytes_fn wsbytes = (wsbytes_fn)dlsym(lib, "spc_workspace_bytes");
+    sconv_fn sconv = (sconv_fn)dlsym(lib, "spc_spectral_conv_f32");
+    float delta[20]; memset(delta, 0, sizeof delta);
+    for (int p = 0; p < 4; ++p) delta[2 * 4 + p] = 1.0f;                     /* channel 2 of (5,2,2) */
+    double g[9], gs = 0.0;
+    for (int j = 0; j < 9; ++j) { g[j] = exp(-0.5 * (j - 4) * (j - 4)); gs += g[j]; }
+    void *d_delta, *d_sm, *d_ws;
+    const size_t need = wsbytes(SPC_WS_SPECTRAL_CONV, 5, 2, 2, 9, 0);
+    if (need == 0 || dmalloc(0, sizeof delta, &d_delta) || dmalloc(0, sizeof delta, &d_sm) || dmalloc(0, need, &d_ws)) {
+        fprintf(stderr, "workspace query / allocation failed: %s\n", last_error()); return 9;
+    }
+    h2d(0, d_delta, delta, sizeof delta, NULL);
+    spc_cube_f32 dc = {(const float*)d_delta, 5, 2, 2, 2, 4};
+    if (sconv(0, NULL, &dc, NULL, g, 9, (float*)d_sm, 0, 0, d_ws, 0) != SPC_ERR_INVALID || !strstr(last_error(), "d_workspace")) {
+        fprintf(stderr, "a too small workspace was not rejected\n"); return 10;
+    }
+    if (sconv(0, NULL, &dc, NULL, g, 9, (float*)d_sm, 0, 0, d_ws, need) != SPC_OK) {
+        fprintf(stderr, "spc_spectral_conv_f32 failed: %s\n", last_error()); return 11;
+    }
+    float sm[20];
+    d2h(0, sm, d_sm, sizeof sm, NULL);
+    for (int z = 0; z < 5; ++z)
+        for (int p = 0; p < 4; ++p)
+            if (fabs(sm[z * 4 + p] - g[z + 2] / gs) > 1e-7) { fprintf(stderr, "smoothed delta: channel %d got %.9g\n", z, sm[z * 4 + p]); return 12; }
+    dfree(0, d_delta); dfree(0, d_sm); dfree(0, d_ws);
+    printf("gpu ok: 3x3x3 reference moment cube and the smoothed delta cube reproduced through the C ABI\n");
     return 0;
 }

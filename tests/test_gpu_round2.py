@@ -1,0 +1,225 @@
+"""GPU: what round 2 added to the contract - reproject with a cube header (spectral axis resampled too),
+nearest neighbour, the all-NaN error on VALUES; moments of order > 2 along spatial axes; filled data on
+write; masks that belong to another device-resident cube; the convolve= seam; and the boundary rule that
+no entry point allocates or drains: two different stencils in flight on two streams."""
+import os
+import threading
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close, golden
+from spectral_cube_amd import (SpectralCube, SimpleWCS, Gaussian1DKernel, Gaussian2DKernel, BooleanArrayMask,
+                               _lib, ops, synth)
+from spectral_cube_amd import masks as M
+from spectral_cube_amd.device import DeviceArray, Stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _hdr(nz, ny, nx, **kw):
+    h = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3,
+         "CDELT3": 0.5, "CUNIT3": "km/s", "CRPIX1": nx / 2, "CRPIX2": ny / 2, "CRPIX3": 1, "CRVAL1": 10.0,
+         "CRVAL2": 20.0, "CRVAL3": -16.0, "BUNIT": "K", "NAXIS": 3, "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nz}
+    h.update(kw)
+    return h
+
+
+def _rot(h, deg):
+    a = np.deg2rad(deg)
+    return dict(h, PC1_1=np.cos(a), PC1_2=-np.sin(a), PC2_1=np.sin(a), PC2_2=np.cos(a))
+
+
+def test_reproject_cube_header_resamples_the_spectral_axis(gpu):
+    """spectral_cube.py:2705-2732: shape_out comes from NAXIS1..3 of the header and reproject_interp
+    resamples all three axes; oracle = reproject_separable (pinned against scipy's trilinear call)."""
+    rng = np.random.default_rng(3)
+    nz, ny, nx = 9, 40, 36
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[4, 10:13, 8:11] = np.nan
+    cube = SpectralCube.read(d, _hdr(nz, ny, nx))
+    # target: rotated 25 degrees, 14 channels of 0.3 km/s starting half a channel before the cube's first
+    tgt = _rot(_hdr(14, 44, 38, CDELT3=0.3, CRVAL3=-16.2, CRPIX1=19.0, CRPIX2=22.0), 25.0)
+    out = cube.reproject(tgt)
+    assert out.shape == (14, 44, 38)
+    np.testing.assert_allclose(out.spectral_axis, -16.2 + 0.3 * np.arange(14))
+    xs, ys = ops.wcs_pixel_map(cube.wcs, SimpleWCS(tgt), (44, 38))
+    zs = ((-16.2 + 0.3 * np.arange(14)) - (-16.0)) / 0.5
+    exp, foot = O.reproject_separable(np.where(np.isfinite(d), d, np.nan), xs.get(), ys.get(), zs)
+    got = out._device_data().get()
+    assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="3-D reproject")
+    assert np.array_equal(out.mask.include(), np.broadcast_to(foot, got.shape))
+    assert not foot[0].any() or zs[0] >= -0.5              # the first target channel lies -0.4 channels out: still inside
+    # a header in m/s describing the same axis, same pixels: purely spatial, bit-identical to the 2-D form
+    same = _rot(_hdr(nz, 44, 38, CUNIT3="m/s", CDELT3=500.0, CRVAL3=-16000.0, CRPIX1=19.0, CRPIX2=22.0), 25.0)
+    a = cube.reproject(same)._device_data().get()
+    two = {k: v for k, v in same.items() if not (k.endswith("3") or k == "NAXIS")}
+    two["NAXIS"] = 2
+    o2 = cube.reproject(two)
+    assert np.array_equal(a, o2._device_data().get(), equal_nan=True)
+    np.testing.assert_allclose(o2.spectral_axis, cube.spectral_axis)          # a 2-axis header keeps the cube's channels
+    with pytest.raises(ValueError, match="cannot relate spectral units"):
+        cube.reproject(dict(same, CUNIT3="Hz"))
+
+
+def test_reproject_nearest_neighbour_and_value_check(gpu):
+    g = golden("reproject_glue_scipy.npz")
+    d = g["data"]
+    out, foot = ops.resample_bilinear(DeviceArray.from_numpy(d), g["xs"], g["ys"], order=0)
+    assert np.array_equal(out.get(), g["nearest"].astype(np.float32), equal_nan=True)
+    assert np.array_equal(foot.get().astype(bool), g["footprint2d"])
+    for env in ("0", "1"):                                  # gather kernel alone and LDS kernel give the same bits
+        os.environ["SPC_BILINEAR_LDS"] = env
+        o2, _ = ops.resample_bilinear(DeviceArray.from_numpy(d), g["xs"], g["ys"], order=0)
+        assert np.array_equal(o2.get(), out.get(), equal_nan=True)
+    os.environ.pop("SPC_BILINEAR_LDS")
+    # through the cube API, against the oracle
+    rng = np.random.default_rng(4)
+    c = rng.standard_normal((3, 30, 28)).astype(np.float32)
+    cube = SpectralCube.read(c, _hdr(3, 30, 28))
+    tgt = _rot(_hdr(3, 33, 31, CRPIX1=15.0, CRPIX2=17.0), -40.0)
+    r = cube.reproject(tgt, order="nearest-neighbor")
+    xs, ys = ops.wcs_pixel_map(cube.wcs, SimpleWCS(tgt), (33, 31))
+    exp, _ = O.resample_nearest(c, xs.get(), ys.get())
+    assert np.array_equal(r._device_data().get(), exp.astype(np.float32), equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        cube.reproject(tgt, order="bicubic")
+    # spectral_cube.py:2733-2739 looks at the VALUES: a non-empty footprint over all-NaN data raises too
+    nan_cube = SpectralCube.read(np.full((3, 30, 28), np.nan, np.float32), _hdr(3, 30, 28))
+    with pytest.raises(ValueError, match="All values in reprojected cube are nan"):
+        nan_cube.reproject(tgt)
+    masked = cube.with_mask(np.zeros(c.shape, bool))        # everything masked -> filled with NaN -> all NaN
+    with pytest.raises(ValueError, match="All values in reprojected cube are nan"):
+        masked.reproject(tgt)
+
+
+@pytest.mark.parametrize("axis", [1, 2])
+@pytest.mark.parametrize("order", [3, 4])
+def test_moment_orders_above_two_along_spatial_axes(gpu, axis, order):
+    """_moments.py:170-193 / dask_spectral_cube.py:1094-1099 for any axis."""
+    shape = (7, 33, 52)
+    d = synth.gaussian_line_cube(shape, 21) + 1.0
+    d[2, 5:9, 7] = np.nan
+    inc = np.random.default_rng(2).random(shape) > 0.2
+    inc[3, :, 10] = False
+    inc[4, 11, :] = False
+    cube = SpectralCube.read(d.astype(np.float32), _hdr(*shape)).with_mask(inc)
+    got = np.asarray(cube.moment(order=order, axis=axis))
+    cen = cube._pix_cen_axis(axis)
+    exp = O.moment(d.astype(np.float32), inc, order, cen[None], cube._pix_size_slice(axis), axis=axis)
+    with np.errstate(all="ignore"):
+        assert_close(got, exp, rtol=1e-9, atol=1e-9 * np.nanmax(np.abs(exp)), what="order %d axis %d" % (order, axis))
+    assert np.isnan(got).any()                               # the fully masked rays
+
+
+def test_write_stores_filled_data(gpu, tmp_path):
+    """dask_spectral_cube.py:1405,1502: the HDU holds _get_filled_data(fill=self._fill_value)."""
+    from spectral_cube_amd import io_fits
+    rng = np.random.default_rng(6)
+    d = rng.standard_normal((4, 6, 8)).astype(np.float32) + 3.0
+    cube = SpectralCube.read(d, _hdr(4, 6, 8))
+    m = cube.with_mask(cube > 3.0)
+    m.write(tmp_path / "filled.fits")
+    back, _ = io_fits.load_cube(str(tmp_path / "filled.fits"))
+    assert np.array_equal(back.get(), np.where(d > 3.0, d, np.nan), equal_nan=True)
+    m.with_fill_value(-1.0).write(tmp_path / "fill.fits")
+    back, _ = io_fits.load_cube(str(tmp_path / "fill.fits"))
+    assert np.array_equal(back.get(), np.where(d > 3.0, d, np.float32(-1.0)))
+    m.write(tmp_path / "raw.fits", filled=False)
+    back, _ = io_fits.load_cube(str(tmp_path / "raw.fits"))
+    assert np.array_equal(back.get(), d)
+
+
+def test_parent_mask_of_a_smoothed_cube_is_lowered_on_the_device(gpu, monkeypatch):
+    """A smoothed cube keeps its parent's mask (dask_spectral_cube.py:836-840).  Once materialised, lowering
+    that mask must not copy the parent cube to the host: the predicate runs on the parent's
+    device data (spc_mask_include_u8)."""
+    shape = (40, 12, 64)
+    d = synth.gaussian_line_cube(shape, 14)
+    d[5, 3, 3] = np.nan
+    k = Gaussian1DKernel(1.5)
+    parent = SpectralCube.read(d, _hdr(*shape))
+    parent = parent.with_mask(parent > 0.4)
+    sm = parent.spectral_smooth(k)
+    sm._device_data()                                        # materialise: the fused route is off the table
+    monkeypatch.setattr(SpectralCube, "_host_data", lambda self: (_ for _ in ()).throw(AssertionError("host copy")))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = [np.asarray(sm.moment(order=o)) for o in (0, 1, 2)]
+    spec = sm._mask_spec()
+    assert spec.flags == _lib.MASK_ARRAY and spec.array is not None
+    inc = (d > np.float32(0.4)) & np.isfinite(d)
+    assert np.array_equal(spec.array.get().astype(bool), inc)
+    smo = O.spectral_smooth(d, inc, k.array)
+    exp = O.moments012(smo, inc, parent._pix_cen_axis(0), parent._pix_size_slice(0), parent.spectral_axis[0])
+    with np.errstate(all="ignore"):
+        assert_close(got[0], exp[0], atol=1e-5 * np.nanmax(np.abs(exp[0])), what="m0")
+        assert_close(got[1], exp[1], atol=1e-5 * 0.5 * shape[0], what="m1")
+
+
+def test_nonfinite_thresholds_on_the_device(gpu):
+    d = np.random.default_rng(9).standard_normal((6, 5, 8)).astype(np.float32)
+    d[1, 1, 1] = -np.inf; d[2, 2, 2] = np.inf; d[3, 3, 3] = np.nan
+    cube = SpectralCube(d, header=_hdr(6, 5, 8))
+    with np.errstate(invalid="ignore"):
+        for m, inc in ((cube > -np.inf, d > -np.inf), (cube < np.inf, d < np.inf), (cube > np.nan, np.zeros(d.shape, bool))):
+            c = cube.with_mask(m)
+            got = ops.mask_include(c._device_data(), c._mask_spec()).get().astype(bool)
+            assert np.array_equal(got, inc)
+
+
+def test_two_stencils_in_flight_on_two_streams(gpu):
+    """No entry point allocates, frees or drains the device (include/spcube_hip.h): a spectral and a spatial
+    stencil queued from two host threads on two streams, each with its own workspace, several rounds with
+    changing data - both match the oracle every time."""
+    shape = (48, 40, 128)
+    k1, k2 = Gaussian1DKernel(2.0).array, Gaussian2DKernel(1.5).array
+    rng = np.random.default_rng(31)
+    datas = []
+    for r in range(4):
+        d = rng.standard_normal(shape).astype(np.float32)
+        if r % 2:
+            d[7, 5, 9] = np.nan                              # alternate clean / dirty tiles (speculative passes)
+        datas.append(d)
+    exp1 = [O.spectral_smooth(d, np.isfinite(d), k1) for d in datas]
+    exp2 = [O.spatial_smooth(d, np.isfinite(d), k2) for d in datas]
+    spec = ops.MaskSpec(_lib.MASK_FINITE)
+    errors = []
+
+    def worker(which):
+        try:
+            st = Stream(0)
+            for r, d in enumerate(datas * 3):
+                dev = DeviceArray.from_numpy(d)
+                if which == 0:
+                    out = ops.spectral_conv(dev, k1, mask=spec, stream=st)
+                    exp = exp1[r % 4]
+                else:
+                    out = ops.spatial_conv(dev, k2, mask=spec, stream=st)
+                    exp = exp2[r % 4]
+                got = out.get(stream=st)
+                assert np.array_equal(np.isnan(got), np.isnan(exp))
+                ok = np.isfinite(exp)
+                assert np.abs(got[ok] - exp[ok]).max() <= 1e-5 * np.abs(exp[ok]).max()
+        except Exception as exc:                             # noqa: BLE001
+            errors.append((which, repr(exc)))
+
+    ts = [threading.Thread(target=worker, args=(w,)) for w in (0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+
+
+def test_chunk_functions_under_dask_map_blocks(gpu):
+    """_map_blocks_to_cube (dask_spectral_cube.py:816-844) hands the chunk functions numpy blocks through
+    dask.array.map_blocks; runs only where dask is importable."""
+    da = pytest.importorskip("dask.array")
+    from spectral_cube_amd.dask_adapter import SpectralSmoothChunk
+    d = np.random.default_rng(5).standard_normal((32, 16, 24)).astype(np.float32)
+    k = Gaussian1DKernel(1.5).array
+    arr = da.from_array(d, chunks=(-1, 8, 12))
+    out = da.map_blocks(SpectralSmoothChunk(k), arr, dtype=arr.dtype).compute(scheduler="synchronous")
+    exp = O.spectral_smooth(d, None, k)
+    assert_close(out, exp, atol=1e-5 * np.abs(exp).max(), what="map_blocks")

@@ -1,0 +1,134 @@
+"""GPU: the sharded drivers of spectral_cube_amd.distributed with the ranks run ONE AFTER THE OTHER on
+this GPU (8-GPU runs belong to the driver).  What is checked: the strips stitched in rank order equal
+the unsharded result - bit for bit, since every strip runs the same kernels on the same numbers - and
+that a rank only touches the rows it needs."""
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close, golden
+from spectral_cube_amd import SpectralCube, SimpleWCS, Gaussian1DKernel, synth
+from spectral_cube_amd import distributed as D
+from spectral_cube_amd.device import DeviceArray
+
+pytestmark = pytest.mark.gpu
+
+
+class ReplayComm:
+    """stands in for the all-gather when the ranks run serially: pass 1 records every rank's strips,
+    pass 2 hands the stitched maps back (the drivers are deterministic, so each runs twice)"""
+
+    def __init__(self, world_size):
+        self.world_size, self.rank = world_size, 0
+        self.record, self.strips, self.calls = True, {}, 0
+
+    def start(self, rank, record):
+        self.rank, self.record, self.calls = rank, record, 0
+
+    def allgather_rows(self, strip, ny_total):
+        key, self.calls = self.calls, self.calls + 1
+        if self.record:
+            self.strips.setdefault(key, {})[self.rank] = np.array(strip)
+            return np.full((ny_total,) + strip.shape[1:], np.nan)
+        return np.concatenate([self.strips[key][r] for r in range(self.world_size)], axis=0)[:ny_total]
+
+
+def _hdr(nz, ny, nx):
+    return {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3,
+            "CDELT3": 0.5, "CUNIT3": "km/s", "CRPIX1": nx / 2, "CRPIX2": ny / 2, "CRPIX3": 1, "CRVAL1": 10.0,
+            "CRVAL2": 20.0, "CRVAL3": -16.0, "BUNIT": "K", "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nz}
+
+
+def _strip_cube(d, inc, hdr, y0, y1):
+    h = dict(hdr, CRPIX2=hdr["CRPIX2"] - y0, NAXIS2=y1 - y0)
+    c = SpectralCube.read(np.ascontiguousarray(d[:, y0:y1]), h)
+    return c.with_mask(np.ascontiguousarray(inc[:, y0:y1])) if inc is not None else c
+
+
+@pytest.mark.parametrize("masked", [False, True])
+@pytest.mark.parametrize("ws", [1, 2, 3])
+def test_sharded_spectral_smooth_moment_c3(gpu, ws, masked):
+    """configs[2] on row strips: fused spectral_smooth -> moment per strip + one stitch."""
+    shape = (96, 22, 64)
+    d = synth.gaussian_line_cube(shape, 41)
+    d[10:14, 5, 7] = np.nan
+    inc = synth.boolean_mask(d, 41).astype(bool) if masked else None
+    hdr = _hdr(*shape)
+    k = Gaussian1DKernel(2.0)
+    whole = _strip_cube(d, inc, hdr, 0, shape[1]).spectral_smooth(k)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = {o: np.asarray(whole.moment(order=o)) for o in (0, 1, 2)}
+    comm = ReplayComm(ws)
+    got = None
+    for record in (True, False):
+        for r in range(ws):
+            y0, y1 = D.strip_bounds(shape[1], ws, r)
+            comm.start(r, record)
+            res = D.sharded_spectral_smooth_moment(_strip_cube(d, inc, hdr, y0, y1), k, shape[1], comm, orders=(0, 1, 2))
+            if not record:
+                if got is None:
+                    got = res
+                for o in (0, 1, 2):                     # every rank holds the same stitched maps
+                    assert np.array_equal(res[o], got[o], equal_nan=True)
+    for o in (0, 1, 2):
+        assert np.array_equal(got[o], exp[o], equal_nan=True), "order %d" % o
+    # and against the oracle at the contract tolerance
+    einc = inc if masked else np.isfinite(d)       # (the smoothed cube keeps the parent's isfinite mask)
+    sm = O.spectral_smooth(d, einc, k.array)
+    ref = whole
+    e1 = O.moment(sm, einc, 1, ref._pix_cen_axis(0), ref._pix_size_slice(0), world0=ref.spectral_axis[0])
+    with np.errstate(all="ignore"):
+        assert_close(got[1], e1, atol=1e-5 * 0.5 * shape[0], what="C3 sharded moment1")
+
+
+@pytest.mark.parametrize("ws", [1, 3, 4])
+def test_sharded_interpolate_then_reproject_c5(gpu, ws):
+    """configs[4] on output-row strips: every rank loads only the source rows its strip of the rotated
+    grid touches, interpolates them spectrally (per spaxel, no exchange) and resamples; the stitched
+    strips equal the unsharded spectral_interpolate -> reproject bit for bit."""
+    g = golden("wcs.npz")
+    rng = np.random.default_rng(12)
+    nz, ny, nx = 12, 96, 80
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[3, 40:44, 30:33] = np.nan
+    hin = SimpleWCS(str(g["rp_hdr_in"])).header
+    hin = dict(hin, NAXIS1=nx, NAXIS2=ny, NAXIS3=nz, CRPIX1=nx / 2, CRPIX2=ny / 2)
+    cube = SpectralCube.read(d, hin)
+    hout = {k: v for k, v in SimpleWCS(str(g["rp_hdr_out"])).header.items() if not (k.endswith("3") or k == "NAXIS")}
+    hout = dict(hout, NAXIS=2, NAXIS1=70, NAXIS2=90, CRPIX1=35.0, CRPIX2=45.0)       # celestial target: channels kept
+    grid = np.linspace(cube.spectral_axis[0], cube.spectral_axis[-1], 2 * nz)
+    whole = cube.spectral_interpolate(grid, suppress_smooth_warning=True).reproject(hout)
+    exp, efoot = whole._device_data().get(), whole._footprint
+    assert np.isfinite(exp).any() and not efoot.all()
+    outs, foots, loaded = [], [], []
+    for r in range(ws):
+        r0, r1 = D.reproject_source_rows(cube.wcs, cube.shape, hout, r, ws)
+        loaded.append(r1 - r0)
+        src = _strip_cube(d, None, hin, r0, r1)                        # "load" rows [r0, r1) only
+        up = D.sharded_spectral_interpolate(src, grid, suppress_smooth_warning=True)
+        out, foot, (y0, y1) = D.sharded_reproject(up._device_data(), r0, cube.wcs, cube.shape, hout, r, ws,
+                                                  mask=up._mask_spec(), fill=np.nan)
+        assert out.shape == (2 * nz, y1 - y0, 70)
+        outs.append(out.get()); foots.append(foot.get())
+    got, gfoot = np.concatenate(outs, axis=1), np.concatenate(foots, axis=0).astype(bool)
+    assert np.array_equal(gfoot, efoot)
+    assert np.array_equal(got, exp, equal_nan=True)
+    if ws > 1:
+        assert max(loaded) < ny, "a strip of a 30-degree rotated grid does not need every source row"
+
+
+def test_reproject_source_rows_margins(gpu):
+    """identity mapping: the strip of output rows [y0, y1) needs source rows [y0 - 1, y1 + 1) (one row of
+    margin for the +1 neighbour and so that a strip edge is not taken for the image border)"""
+    hdr = _hdr(4, 60, 50)
+    w = SimpleWCS(hdr)
+    for r in range(3):
+        y0, y1 = D.strip_bounds(60, 3, r)
+        r0, r1 = D.reproject_source_rows(w, (4, 60, 50), hdr, r, 3)
+        assert r0 <= max(0, y0 - 1) and r1 >= min(60, y1 + 1) and (r1 - r0) <= (y1 - y0) + 4
+    far = dict(hdr, CRVAL1=200.0)
+    assert D.reproject_source_rows(w, (4, 60, 50), far, 0, 2) == (0, 0)
+    out, foot, _ = D.sharded_reproject(DeviceArray((4, 0, 50), np.float32), 0, w, (4, 60, 50), far, 0, 2)
+    assert np.isnan(out.get()).all() and not foot.get().any()

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libspcube_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.spc_abi_version() == 1
+    assert lib.spc_abi_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -153,6 +153,82 @@ def test_mask_lowering_to_device_terms():
     c8 = cube.with_mask(cube > np.float64(0.1))           # typed float64: not exactly representable
     flags, lo, hi, arr = M.lower_mask(c8.mask, c8, c8.shape)
     assert flags & _lib.MASK_ARRAY
+
+def test_mask_lowering_nonfinite_thresholds_and_function_masks():
+    """`cube > -inf` must stay a real comparison (not `> 0`), a NaN threshold includes nothing,
+    and masks the device cannot express (FunctionMask, or / xor composites) are evaluated on the voxel
+    ARRAY, not on the cube object."""
+    cube, d = _cube()
+    d2 = d.copy(); d2[1, 1, 1] = -np.inf; d2[2, 2, 2] = np.inf
+    c = SpectralCube.read(d2, cube.header)
+    with np.errstate(invalid="ignore"):
+        for m, exp in ((c > -np.inf, d2 > -np.inf), (c < np.inf, d2 < np.inf), (c >= np.inf, d2 >= np.inf),
+                       (c > np.nan, d2 > np.nan), (c <= float("nan"), np.zeros(d2.shape, bool))):
+            flags, lo, hi, arr = M.lower_mask(m, c, c.shape)
+            if arr is not None:
+                got = arr.astype(bool)
+            else:                                   # predicate form: evaluate it the way the kernels do
+                got = np.ones(d2.shape, bool)
+                v = d2
+                if flags & _lib.MASK_GT: got &= v > np.float32(lo)
+                if flags & _lib.MASK_GE: got &= v >= np.float32(lo)
+                if flags & _lib.MASK_LT: got &= v < np.float32(hi)
+                if flags & _lib.MASK_LE: got &= v <= np.float32(hi)
+            np.testing.assert_array_equal(got, exp)
+    fm = M.FunctionMask(lambda a: a > 0.3)
+    flags, lo, hi, arr = M.lower_mask(fm, cube, cube.shape)
+    with np.errstate(invalid="ignore"):
+        assert flags == _lib.MASK_ARRAY and np.array_equal(arr.astype(bool), d > 0.3)
+        for comp, exp in (((cube > 0.1) | fm, (d > np.float32(0.1)) | (d > 0.3)),
+                          ((cube > 0.1) ^ (cube < 0.5), (d > np.float32(0.1)) ^ (d < np.float32(0.5)))):
+            flags, lo, hi, arr = M.lower_mask(comp, cube, cube.shape)
+            assert flags == _lib.MASK_ARRAY and np.array_equal(arr.astype(bool), exp)
+    # a smoothed cube keeps its parent's mask object: every lazy term belongs to the parent
+    sm = cube.with_mask(cube > 0.2).spectral_smooth(K.Gaussian1DKernel(1.0))
+    assert M.foreign_owner(sm.mask)._is_same_data(cube) and M.foreign_owner(cube.mask) is cube
+    assert M.foreign_owner(M.BooleanArrayMask(np.ones(cube.shape, bool))) is None
+    assert M.foreign_owner(cube.mask & fm) is None
+
+
+def test_huge_cube_guard_and_convolve_seam():
+    """utils.py:41-75: reproject / convolve_to refuse cubes above 1e8 voxels unless allow_huge_operations
+    (raised before any device work); the `convolve=` seam accepts astropy's own convolve / convolve_fft."""
+    from spectral_cube_amd.cube import _check_convolve
+    cube, d = _cube()
+    big = SpectralCube(None, wcs=cube.wcs, _lazy=lambda: None, _shape=(1000, 400, 400))
+    assert big._is_huge and not cube._is_huge
+    with pytest.raises(ValueError, match="allow_huge_operations=True"):
+        big.reproject(cube.header)
+    with pytest.raises(ValueError, match="requires loading the entire cube into memory"):
+        big.convolve_to(None)
+    big.allow_huge_operations = True
+    with pytest.raises((HipLibraryError, AttributeError, ValueError, TypeError)):
+        big.convolve_to(None)                     # past the guard now (fails later: no beam / no GPU)
+
+    def convolve(array, kernel, **kw):
+        raise AssertionError("never called")
+    convolve.__module__ = "astropy.convolution.convolve"
+    _check_convolve(convolve); _check_convolve(None)
+    cube.spectral_smooth(K.Gaussian1DKernel(1.0), convolve=convolve)        # lazy: accepted, no GPU touched
+    cube.spatial_smooth(K.Gaussian2DKernel(1.0), convolve=convolve)
+    with pytest.raises(NotImplementedError, match="custom `convolve`"):
+        cube.spectral_smooth(K.Gaussian1DKernel(1.0), convolve=lambda a, k, **kw: a)
+
+
+def test_workspace_sizes_are_declared_for_every_scratch_user():
+    """spc_workspace_bytes: non-zero for every entry point that takes (d_workspace, workspace_bytes), and
+    depending only on shapes (an upper bound the caller can size once)."""
+    lib = _lib.load()
+    kinds = [(_lib.WS_SPECTRAL_CONV, 33, 0), (_lib.WS_SPECTRAL_CONV, 81, 0), (_lib.WS_SPECTRAL_CONV_MOMENTS, 33, 0),
+             (_lib.WS_SPATIAL_CONV_SEP, 29, 29), (_lib.WS_SPATIAL_CONV_SEP, 81, 81), (_lib.WS_SPATIAL_CONV2D, 15, 15),
+             (_lib.WS_RESAMPLE_BILINEAR, 300, 200), (_lib.WS_STATS_GLOBAL, 0, 0), (_lib.WS_STATS_PLANES, 0, 0),
+             (_lib.WS_MAP_CONV2D, 29, 29), (_lib.WS_CLIP_OUTSIDE, 0, 0), (_lib.WS_PERCENTILE_GLOBAL, 0, 0)]
+    for kind, p0, p1 in kinds:
+        n = lib.spc_workspace_bytes(kind, 64, 128, 256, p0, p1)
+        assert 0 < n < (1 << 31), (kind, n)
+    assert lib.spc_workspace_bytes(_lib.WS_MOMENTS, 64, 128, 256, 0, 0) == lib.spc_moments_workspace_bytes(64, 128, 256)
+    assert lib.spc_workspace_bytes(_lib.WS_SPATIAL_CONV_SEP, 512, 2048, 2048, 81, 81) <= (1 << 28) + (1 << 20)   # bounded chunks
+    assert lib.spc_workspace_bytes(99, 4, 4, 4, 0, 0) == 0
 
 
 def test_lerp_plan_matches_oracle_indexing():
