@@ -4,20 +4,6 @@
 #include "spc_common.h"
 #include <algorithm>
 
-// build-time experiment switches of the all-valid kernel (defaults = what ships; the measured
-// alternatives are recorded next to fast_phases() below)
-#ifndef SPC_FAST_PHASES_29
-#define SPC_FAST_PHASES_29 1     // x-pass phases per revolution for rings >= 29 taps
-#endif
-#ifndef SPC_FAST_PREFETCH
-#define SPC_FAST_PREFETCH 1      // issue the next revolution's row loads before the x pass
-#endif
-#ifndef SPC_XPASS_FENCE
-#define SPC_XPASS_FENCE 0        // scheduling fence every N x-pass taps (0 = none)
-#endif
-#ifndef SPC_NO_EDGE
-#define SPC_NO_EDGE 0
-#endif
 
 namespace spc_spconv {
 
@@ -64,6 +50,14 @@ __device__ __forceinline__ void pk_mul_w(float2v& acc, const float* karr, int j,
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Output stores.  Measured on MI355X, 512 x 2048^2 (all-valid kernel, same box): the short rings (<= 17 taps)
+// are store-bound and like non-temporal stores with the sector-pairing below (9 taps: 4.08 vs 4.31 ms); the
+// long rings are bound by the FMA / LDS pipeline and run 2 - 3 % faster with plain stores.
+template <bool NT>
+__device__ __forceinline__ void st4(f32x4 val, f32x4* ptr) {
+    if (NT) __builtin_nontemporal_store(val, ptr);
+    else *ptr = val;
+}
 
 // A lane of the x pass owns a run of 8 outputs = two 16-byte stores; issued as they are, each
 // store instruction writes the first (second) HALF of every 32-byte sector.  For the short,
@@ -80,46 +74,54 @@ __device__ __forceinline__ void store_run8_paired(float* p, int odd, f32x4 lo, f
     const f32x4 got = f32x4{dpp_swap_pair(give.x), dpp_swap_pair(give.y), dpp_swap_pair(give.z), dpp_swap_pair(give.w)};
     const f32x4 s1 = odd ? got : lo;                      // even: own [0,4) ; odd: partner's [4,8) just below
     const f32x4 s2 = odd ? hi : got;                      // even: partner's [0,4) just above ; odd: own [4,8)
-    __builtin_nontemporal_store(s1, reinterpret_cast<f32x4*>(p + (odd ? -4 : 0)));
-    __builtin_nontemporal_store(s2, reinterpret_cast<f32x4*>(p + (odd ? 4 : 8)));
+    st4<true>(s1, reinterpret_cast<f32x4*>(p + (odd ? -4 : 0)));
+    st4<true>(s2, reinterpret_cast<f32x4*>(p + (odd ? 4 : 8)));
 }
 
 constexpr int kFastCols = 512;                // input columns per block of the fast kernel (2 per lane)
 constexpr int fast_txo(int R) { return ((kFastCols - 2 * (R / 2)) / 16) * 16; }
-// rows per x-pass phase of the fast kernel: ceil(R / nph) rounded up to an even count (row pairs)
-constexpr int fast_phase_rows(int R, int nph) { return (((R + nph - 1) / nph) + 1) / 2 * 2; }
-// Measured (29 taps, C4): 2 phases halve the LDS footprint (38 KB) but the kernel then needs 208
-// VGPRs; forcing 3 waves/SIMD spills 40 of them into the y pass (45.5 ms vs 37.9 ms), so one phase.
-// Also tried and dropped: a wave-specialised variant (8 waves per block, waves 0-3 run the y pass
-// of revolution n into one LDS buffer while waves 4-7 run the x pass of revolution n-1 out of the
-// other; 142 KB LDS, one block per CU, 163 VGPRs, one barrier per revolution): correct, but
-// 47.6 ms at C4 against 38.2 ms for two independent 4-wave blocks per CU.
-constexpr int fast_phases(int R) { return SPC_FAST_PHASES_29 > 1 && R >= 29 ? SPC_FAST_PHASES_29 : 1; }
-constexpr bool kFastPrefetch = SPC_FAST_PREFETCH != 0;
+// A revolution (R input rows -> R finished y-pass rows) is cut into groups of at most kGroupRows rows;
+// only one group's rows (x 2 for the double buffer) ever sit in LDS.
+constexpr int kGroupRows = 8;
+constexpr int fast_ngroups(int R) { return (R + kGroupRows - 1) / kGroupRows; }
 
 // ---- all-valid fast kernel -----------------------------------------------------------
 // Speculative first pass for planes without invalid samples: out = (Gy * Gx * d) / (sum ky *
 // sum kx), astropy's NaN-free branch.  One block = one channel x a strip of 480 output
 // columns, streaming down the rows.
 //   y pass: lane <-> 2 adjacent input columns, register ring of R packed numerators, one
-//           v_pk_fma_f32 per tap and column pair; finished rows go to LDS (float rows,
-//           9-per-8 padded, pitch chosen so that a wave's tasks never share a bank);
-//   x pass: after every revolution (R rows), a task = (row pair, run of 8 columns): the two
-//           rows are packed into one v_pk_fma_f32 per tap (same scalar weight for both), i.e.
+//           v_pk_fma_f32 per tap and column pair; finished rows go to LDS two at a time as
+//           float2 (row a, row b) per column - exactly the operand the x pass multiplies;
+//   x pass: a task = (row pair, run of 8 columns): the two rows ride in one v_pk_fma_f32 per tap
+//           (same scalar weight for both), fed by ONE ds_read_b64 per input column (9-per-8 padded
+//           float2 rows: a wave's 32-lane groups touch 32 distinct even banks).
 //           14.5 FMA instructions per voxel in each direction instead of 29 + 29.
+// Pipeline: the R rows of a revolution are produced in groups of 8 (round 1: 70 KB of LDS for all
+// R rows, two barriers per revolution, 2 blocks per CU, VALU 57 % busy).  Group g goes to LDS buffer
+// g & 1; ONE barrier later every lane runs its x-pass task over that group while the loads of the next
+// group are in flight, then produces the next group into the other buffer: y(g) | barrier | x(g), y(g+1) |
+// barrier | ...  A lane that passes barrier g+1 has finished x(g), so buffer g & 1 is free for y(g+2).
+// LDS per block: 2 x 4 pair rows x 576 float2 = 36 KB -> 4 blocks (16 waves) per CU, in different
+// phases: while one block waits at its barrier or for its loads the others issue FMAs.
 // A block that meets an invalid sample marks its tile dirty and quits; the general kernel then
 // redoes the dirty tiles.
 // ISO: kx == ky (every Gaussian2DKernel with one stddev): both passes read the SAME scalar
 // weights - with two weight sets the 2 x 30 SGPRs spill and every spill reload is a VALU
 // v_readlane (measured: 755 per revolution next to 1044 FMAs).
-template <int R, bool ISO, int NPH>
-__global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs A) {
+// waves per SIMD the register budget is cut for: 4 (128 VGPRs) up to 29 taps, 3 beyond (a 33-slot ring of
+// pairs alone is 66 registers)
+constexpr int fast_waves(int R) { return R <= 29 ? 4 : 3; }
+template <int R, bool ISO>
+__global__ __launch_bounds__(kThreads, fast_waves(R)) void spatial_sep_fast_kernel(const SpArgs A) {
     constexpr int H = R / 2;
     constexpr int kTxoF = fast_txo(R);
-    constexpr int kPitchF = 590;                          // floats per LDS row; 2*pitch = 28 (mod 32)
-    constexpr int kRows = fast_phase_rows(R, NPH);        // LDS rows: one phase of the revolution (even)
-    static_assert(kPitchF >= kFastCols + kFastCols / 8, "LDS row too short");
-    __shared__ float yrow[kRows * kPitchF];
+    constexpr int NG = fast_ngroups(R);
+    // groups requested ahead of the one being consumed.  Two (needs an even group count) was measured too:
+    // no gain at 3 waves per SIMD, spills at 4 - the kernel is not waiting for its loads.
+    constexpr int PF = 1;
+    constexpr int kPairRows = kGroupRows / 2;
+    constexpr int kPitch2 = kFastCols + kFastCols / 8;    // float2 per LDS pair row, 9-per-8 padded
+    __shared__ float2v ybuf[2][kPairRows][kPitch2];
     __shared__ int dirty;             // set by any lane that meets a non-finite sample (plain LDS word: the
                                       // barrier asm is a compiler memory barrier; `volatile` made it a FLAT sc0 sc1 access)
 
@@ -140,7 +142,6 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     const int ncols = nrun_eff * kRun + 2 * H;
     if (2 * (t & ~63) >= ncols) return;
     if (t == 0) dirty = 0;
-    lds_barrier();
     const int nthr = min(kThreads, ((ncols + 127) / 128) * 64);
     const float inv_nrun = 1.0f / (float)nrun_eff;
     // lanes t, t^1 hold adjacent runs of one row pair iff the run count is even; whole runs only
@@ -153,98 +154,122 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
     for (int m = 0; m < R; ++m) num[m] = float2v{0.f, 0.f};
 
     const int T = ny + 2 * H;
-    // software pipeline: the loads of revolution n+1 are issued right after the y pass of
-    // revolution n has consumed v[], so they are in flight during the LDS x pass
-    float2v v[R];
+    // the inputs of ONE group live in registers; those of the next group are requested right after the
+    // barrier that ends the current group's y pass, i.e. they are in flight during its x pass
+    float2v v[PF][kGroupRows];
+    auto fetch = [&](int slot, int first_row, int n) {
 #pragma unroll
-    for (int s = 0; s < R; ++s) {
-        const int64_t ic = min(max(-H + s, 0), ny - 1);
-        v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
-    }
+        for (int s = 0; s < kGroupRows; ++s) {
+            if (s < n) {
+                const int64_t ic = min(max(first_row + s, 0), ny - 1);
+                v[slot][s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
+            }
+        }
+    };
+    // rows of group gi counted from the first group of the first revolution
+    auto group_first = [&](int gi) { return -H + (gi / NG) * R + (gi % NG) * kGroupRows; };
+    auto group_rows = [&](int gi) { const int g = gi % NG; return ((g + 1) * kGroupRows < R ? (g + 1) * kGroupRows : R) - g * kGroupRows; };
+#pragma unroll
+    for (int q = 0; q < PF; ++q) fetch(q, group_first(q), group_rows(q));
+    lds_barrier();                                        // dirty = 0 is visible
+    float2v chk = float2v{0.f, 0.f};
     for (int t0 = 0; t0 < T; t0 += R) {
         const int i0 = t0 - H;                            // first input row of this revolution
-        if (!kFastPrefetch && t0 > 0) {
 #pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const int64_t ic = min(max(i0 + s, 0), ny - 1);
-                v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
+        for (int g = 0; g < NG; ++g) {
+            constexpr int kG = kGroupRows;
+            const int s0 = g * kG, s1 = (g + 1) * kG < R ? (g + 1) * kG : R;     // static after unrolling
+            // consecutive groups alternate between the two buffers - across revolutions too, so with an odd
+            // group count the choice depends on the revolution (a block-uniform run-time offset)
+            float2v (*buf)[kPitch2] = ybuf[(NG % 2 == 0) ? (g & 1) : (((t0 / R) * NG + g) & 1)];
+            // Interior groups of interior strips (the common case) carry NO per-sample bookkeeping;
+            // rows / columns outside the plane (clamped duplicate loads) become valid zeros only where
+            // they can occur, under block-uniform branches.
+            if (edge_cols || (i0 + s0 < 0) || (i0 + s1 > ny)) {
+#pragma unroll
+                for (int s = s0; s < s1; ++s) {
+                    const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
+                    if (!in) v[g % PF][s - s0] = float2v{0.f, 0.f};       // out of bounds = valid zero
+                }
             }
-        }
-        // Interior revolutions of interior strips (the common case) carry NO per-sample
-        // bookkeeping at all; rows / columns outside the plane (clamped duplicate loads) are
-        // turned into valid zeros only where they can occur, under block-uniform branches.
-        const bool edge = edge_cols || (i0 < 0) || (i0 + R > ny);
-        if (edge && !SPC_NO_EDGE) {
-#pragma unroll
-            for (int s = 0; s < R; ++s) {
-                const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
-                if (!in) v[s] = float2v{0.f, 0.f};       // out of bounds = valid zero
-            }
-        }
-        // ---- y pass in NPH phases, each followed by the x pass over the rows it finished (LDS only
-        // holds one phase's rows: 29 taps, 2 phases: 38 KB instead of 71 KB per block -> the
-        // register file, not LDS, sets the occupancy).  The fast pass only runs for masks where
-        // exactly the non-finite samples are invalid (none, or isfinite), and those propagate:
-        // chk += 0 * (finished row) is NaN iff a NaN or Inf went into that row - one packed FMA per
-        // row instead of compares on every sample (an Inf under "no mask" is merely handed to the
-        // general kernel).
-        float2v chk = float2v{0.f, 0.f};
-#pragma unroll
-        for (int phs = 0; phs < NPH; ++phs) {
-            constexpr int kPh = fast_phase_rows(R, NPH);
-            const int s0 = phs * kPh, s1 = (phs + 1) * kPh < R ? (phs + 1) * kPh : R;
+            // ---- y pass of the group.  The fast pass only runs for masks where exactly the non-finite
+            // samples are invalid (none, or isfinite), and those propagate: chk += 0 * (finished row) is
+            // NaN iff a NaN or Inf went into that row - one packed FMA per row instead of compares on
+            // every sample (an Inf under "no mask" is merely handed to the general kernel).
+            float2v held = float2v{0.f, 0.f};
 #pragma unroll
             for (int s = s0; s < s1; ++s) {
 #pragma unroll
                 for (int m = 0; m < R; ++m) {
                     const int a = (s - m + R) % R;
-                    if (a == 0) pk_mul_w(num[m], A.ky, 2 * H - a, v[s]);
-                    else pk_fma_w(num[m], A.ky, 2 * H - a, v[s]);
+                    if (a == 0) pk_mul_w(num[m], A.ky, 2 * H - a, v[g % PF][s - s0]);
+                    else pk_fma_w(num[m], A.ky, 2 * H - a, v[g % PF][s - s0]);
                 }
                 const float2v done = num[(s + 1) % R];   // row o = i0 + s - H
                 chk = __builtin_elementwise_fma(done, float2v{0.f, 0.f}, chk);
-                yrow[(s - s0) * kPitchF + ph0] = done.x;
-                yrow[(s - s0) * kPitchF + ph1] = done.y;
+                if (((s - s0) & 1) == 0 && s + 1 < s1) {
+                    held = done;                          // first row of a pair: wait for its partner
+                } else {
+                    const bool single = ((s - s0) & 1) == 0;       // odd group: the last row has no partner
+                    const int pr = (s - s0) >> 1;
+                    buf[pr][ph0] = single ? float2v{done.x, 0.f} : float2v{held.x, done.x};
+                    buf[pr][ph1] = single ? float2v{done.y, 0.f} : float2v{held.y, done.y};
+                }
             }
-            if (phs == NPH - 1 && (!(chk.x == chk.x) || !(chk.y == chk.y))) dirty = 1;
+            if (!(chk.x == chk.x) || !(chk.y == chk.y)) dirty = 1;
             lds_barrier();
-            if (phs == NPH - 1 && dirty) {                // block-uniform: hand the tile to the general kernel
+            if (dirty) {                                  // block-uniform: hand the tile to the general kernel
                 if (t == 0) spc_flag_set(A.status + z * A.fast_nstrips + strip);   // (rows already written are redone)
                 return;
             }
-            if (kFastPrefetch && t0 + R < T) {            // this phase's inputs of the NEXT revolution
-#pragma unroll
-                for (int s = s0; s < s1; ++s) {
-                    const int64_t ic = min(max(i0 + R + s, 0), ny - 1);
-                    v[s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
-                }
+            // ---- inputs of the group PF ahead, into the registers this group has just freed
+            {
+                const int gi = (t0 / R) * NG + g + PF;          // (t0 / R: revolutions done; a shift-free division by a constant)
+                if (group_first(gi) < ny + H) fetch(g % PF, group_first(gi), group_rows(gi));
             }
-            // ---- x pass of this phase: task = (row pair, run of kRun output columns)
-            for (int task = t; task < ((s1 - s0 + 1) / 2) * nrun_eff; task += nthr) {
+            // ---- x pass over the group: task = (row pair, run of kRun output columns)
+            const int npairs = (s1 - s0 + 1) / 2;
+            for (int task = t; task < npairs * nrun_eff; task += nthr) {
                 const int pr = (int)(((float)task + 0.5f) * inv_nrun);   // exact: task < 2^12, nrun <= 62
                 const int j = task - pr * nrun_eff;
-                const int sa = 2 * pr, sb = 2 * pr + 1;
-                const int oa = i0 + s0 + sa - H, ob = oa + 1;
-                const bool wa = (oa >= 0) && (oa < ny), wb = (s0 + sb < s1) && (ob >= 0) && (ob < ny);
+                const int oa = i0 + s0 + 2 * pr - H, ob = oa + 1;
+                const bool wa = (oa >= 0) && (oa < ny), wb = (s0 + 2 * pr + 1 < s1) && (ob >= 0) && (ob < ny);
                 if (!wa && !wb) continue;
-                const float* ra = yrow + sa * kPitchF;
-                const float* rb = yrow + (s0 + sb < s1 ? sb : sa) * kPitchF;
+                const float2v* row = buf[pr];
                 float2v r[kRun];
 #pragma unroll
                 for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
+                // The kRun + 2H input columns come in batches of kXB: batch b + 1 is requested before the
+                // FMAs of batch b issue, and scheduling fences keep it that way - left alone the compiler
+                // hoists all 36 reads of a task to its top and pays for them with 72 VGPRs (spills at the
+                // 128-register budget of four blocks per CU).
+                constexpr int kXB = 4, kNB = (kRun + 2 * H + kXB - 1) / kXB;
+                const float2v* src = row + kRun * j + j;              // column c = 8 j + i sits at c + (c >> 3)
+                float2v in[2][kXB];
 #pragma unroll
-                for (int i = 0; i < kRun + 2 * H; ++i) {
-                    // (scheduling fence: left alone the compiler hoists all 2 x 36 LDS reads of a task
-                    // to its top and pays for them with 70 VGPRs - one wave per SIMD less)
-                    if (SPC_XPASS_FENCE > 0 && (i % (SPC_XPASS_FENCE > 0 ? SPC_XPASS_FENCE : 1)) == 0) __builtin_amdgcn_sched_barrier(0);
-                    const int c = kRun * j + i;
-                    const int ph = c + (c >> 3);
-                    const float2v in = float2v{ra[ph], rb[ph]};
+                for (int q = 0; q < kXB; ++q) in[0][q] = src[q + (q >> 3)];
 #pragma unroll
-                    for (int k = 0; k < kRun; ++k) {
-                        const int widx = k + 2 * H - i;
-                        if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
+                for (int b = 0; b < kNB; ++b) {
+                    if (b + 1 < kNB) {
+#pragma unroll
+                        for (int q = 0; q < kXB; ++q) {
+                            const int i = (b + 1) * kXB + q;
+                            if (i < kRun + 2 * H) in[(b + 1) & 1][q] = src[i + (i >> 3)];
+                        }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < kXB; ++q) {
+                        const int i = b * kXB + q;
+                        if (i < kRun + 2 * H) {
+#pragma unroll
+                            for (int k = 0; k < kRun; ++k) {
+                                const int widx = k + 2 * H - i;
+                                if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in[b & 1][q]);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 const int64_t xo = x0 + kRun * j;
                 float* da = A.out + z * A.out_plane_stride + (int64_t)oa * A.out_row_stride + xo;
@@ -256,12 +281,12 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
                                               f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum);
                 } else if (xo + kRun <= A.nx) {
                     if (wa) {
-                        __builtin_nontemporal_store(f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da));
-                        __builtin_nontemporal_store(f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da + 4));
+                        st4<(R <= kPairedStoreMaxR)>(f32x4{r[0].x, r[1].x, r[2].x, r[3].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da));
+                        st4<(R <= kPairedStoreMaxR)>(f32x4{r[4].x, r[5].x, r[6].x, r[7].x} * A.inv_ksum, reinterpret_cast<f32x4*>(da + 4));
                     }
                     if (wb) {
-                        __builtin_nontemporal_store(f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db));
-                        __builtin_nontemporal_store(f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db + 4));
+                        st4<(R <= kPairedStoreMaxR)>(f32x4{r[0].y, r[1].y, r[2].y, r[3].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db));
+                        st4<(R <= kPairedStoreMaxR)>(f32x4{r[4].y, r[5].y, r[6].y, r[7].y} * A.inv_ksum, reinterpret_cast<f32x4*>(db + 4));
                     }
                 } else {
 #pragma unroll
@@ -273,7 +298,6 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_fast_kernel(const SpArgs
                     }
                 }
             }
-            lds_barrier();
         }
     }
 }
@@ -466,8 +490,8 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
     if constexpr (R <= 33) {
         if (A.status) {      // speculative all-valid pass (the general kernel below redoes dirty tiles)
             dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1);
-            if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true, fast_phases(R)>), fgrid, block, 0, st, A);
-            else hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false, fast_phases(R)>), fgrid, block, 0, st, A);
+            if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true>), fgrid, block, 0, st, A);
+            else hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
             SPC_LAUNCH_CHECK();
         }
     }
