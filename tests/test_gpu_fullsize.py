@@ -184,6 +184,117 @@ def test_c5_spectral_interpolate_2048_to_4096(gpu):
     assert rc == 0
     assert_close(full, exp[:, ty - 1, :], atol=1e-5 * np.nanmax(np.abs(exp)), what="C5 lerp last row")
 
+def _rotated_map(ny, nx, deg):
+    yy, xx = np.mgrid[0:ny, 0:nx].astype(np.float64)
+    a = np.deg2rad(deg)
+    xs = np.cos(a) * (xx - nx / 2) - np.sin(a) * (yy - ny / 2) + nx / 2
+    ys = np.sin(a) * (xx - nx / 2) + np.cos(a) * (yy - ny / 2) + ny / 2
+    return xs, ys
+
+
+def _periodic_expected(small, xs, ys, ny, nx, rows, chans):
+    """bilinear samples of a source that repeats *small* (tz, P, P) in z, y and x: inside the image and away
+    from its border an output pixel only sees values of the tile, at the coordinates taken modulo P (the
+    fractions are untouched: P is an integer) - the oracle runs on a 3 x 3 arrangement of the tile."""
+    tz, P, _ = small.shape
+    big = np.tile(small, (1, 3, 3))
+    x, y = xs[rows], ys[rows]
+    inner = (x >= 1) & (x <= nx - 2) & (y >= 1) & (y <= ny - 2)
+    exp, _ = O.resample_bilinear(big[[c % tz for c in chans]], np.mod(x, P) + P, np.mod(y, P) + P)
+    return exp, inner
+
+
+def test_c5_reproject_4096x1024x1024_rotated_30deg(gpu):
+    """configs[4] (second half) at full size: a 4096 x 1024 x 1024 cube resampled onto the same grid rotated
+    by 30 degrees.  The source repeats a 64 x 64 x 4 tile in all three directions, so every output pixel
+    whose footprint lies inside the image follows from the oracle on the tile (64-bit addressing of the
+    resampler: 16 GiB in, 16 GiB out; the round-1 test set stopped at 150 x 170 images)."""
+    shape, P, tz = (4096, 1024, 1024), 64, 4
+    _need(shape[0] * shape[1] * shape[2] * 4 * 2.1)
+    rng = np.random.default_rng(synth.SEEDS["C5"])
+    small = rng.standard_normal((tz, P, P)).astype(np.float32)
+    small[1, 10, 20] = np.nan
+    tile = np.tile(small, (1, 1, shape[2] // P))                       # (tz, P, nx): periodic along x already
+    cube = DeviceArray(shape, np.float32)
+    plane = DeviceArray((tz, shape[1], shape[2]), np.float32)
+    _replicate_rows(plane, tile, 4)
+    _replicate_planes(cube, plane.get(), 4)
+    del plane
+    xs, ys = _rotated_map(shape[1], shape[2], 30.0)
+    out, foot = ops.resample_bilinear(cube, xs, ys)
+    f = foot.get().astype(bool)
+    inside = (xs >= -0.5) & (xs <= shape[2] - 0.5) & (ys >= -0.5) & (ys <= shape[1] - 0.5)
+    assert np.array_equal(f, inside)
+    rows = [0, 1, 200, 511, 512, 777, 1023]
+    chans = [0, 1, 2, 3, 2049, 4094, 4095]
+    exp, inner = _periodic_expected(small, xs, ys, shape[1], shape[2], rows, chans)
+    rowb = shape[2] * 4
+    for ci, c in enumerate(chans):
+        for ri, r in enumerate(rows):
+            got = np.empty(shape[2], np.float32)
+            _lib.call("spc_memcpy_d2h", 0, got.ctypes.data_as(C.c_void_p),
+                      C.c_void_p(out.ptr + (c * shape[1] + r) * rowb), rowb, None)
+            assert np.all(np.isnan(got[~inside[r]]))
+            ok = inner[ri]
+            e = exp[ci, ri]
+            assert np.array_equal(np.isnan(got[ok]), np.isnan(e[ok])), (c, r)
+            fin = ok & ~np.isnan(e)
+            assert np.abs(got[fin] - e[fin]).max() <= 1e-5 * np.nanmax(np.abs(small)), (c, r)
+
+
+def test_c5_interpolate_then_reproject_chain_fullsize(gpu):
+    """configs[4] end to end at full size through the operator interface: 2048 x 1024 x 1024 ->
+    spectral_interpolate to 4096 channels -> reproject onto the grid rotated by 30 degrees (celestial header:
+    the channels are kept).  The cube repeats a 64 x 64 spatial tile and is LINEAR along the spectral axis
+    (value = a(y, x) + b(y, x) * channel), so interpolation is exact and every interior output pixel is the
+    oracle's bilinear sample of a(.) + b(.) * (its fractional source channel)."""
+    from spectral_cube_amd import SpectralCube
+    shape, P = (2048, 1024, 1024), 64
+    _need(shape[0] * shape[1] * shape[2] * 4 * 5.2)
+    rng = np.random.default_rng(synth.SEEDS["C5"] + 1)
+    a0 = rng.standard_normal((P, P)).astype(np.float32)
+    b0 = (rng.standard_normal((P, P)) * 1e-3).astype(np.float32)
+    A, B = np.tile(a0, (shape[1] // P, shape[2] // P)), np.tile(b0, (shape[1] // P, shape[2] // P))
+    cube = DeviceArray(shape, np.float32)
+    for z0 in range(0, shape[0], 64):                                   # staged 64 planes at a time
+        blk = (A[None] + B[None] * np.arange(z0, z0 + 64, dtype=np.float32)[:, None, None]).astype(np.float32)
+        _lib.call("spc_memcpy_h2d", 0, C.c_void_p(cube.ptr + z0 * shape[1] * shape[2] * 4),
+                  blk.ctypes.data_as(C.c_void_p), blk.nbytes, None)
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-4, "CDELT2": 1e-4,
+           "CDELT3": 500.0, "CUNIT3": "m/s", "CRPIX1": 512.5, "CRPIX2": 512.5, "CRPIX3": 1, "CRVAL1": 40.0,
+           "CRVAL2": 0.0, "CRVAL3": 0.0, "NAXIS": 3, "NAXIS1": 1024, "NAXIS2": 1024, "NAXIS3": 2048}
+    sc = SpectralCube.from_device(cube, header=hdr)
+    sc.allow_huge_operations = True
+    v = sc.spectral_axis
+    grid = np.linspace(v[0], v[-1], 4096)
+    up = sc.spectral_interpolate(grid, suppress_smooth_warning=True)
+    up.allow_huge_operations = True
+    a = np.deg2rad(30.0)
+    tgt = {k: hdr[k] for k in ("CTYPE1", "CTYPE2", "CDELT1", "CDELT2", "CRPIX1", "CRPIX2", "CRVAL1", "CRVAL2")}
+    tgt.update(NAXIS=2, NAXIS1=1024, NAXIS2=1024, PC1_1=np.cos(a), PC1_2=-np.sin(a), PC2_1=np.sin(a), PC2_2=np.cos(a))
+    with pytest.raises(ValueError, match="allow_huge_operations"):
+        SpectralCube.from_device(cube, header=hdr).reproject(tgt)       # the guard of utils.py:41-75 (no work is queued)
+    res = up.reproject(tgt)
+    assert res.shape == (4096, 1024, 1024)
+    np.testing.assert_allclose(res.spectral_axis, grid, rtol=1e-12, atol=1e-6)
+    xs, ys = ops.wcs_pixel_map(sc.wcs, res.wcs, (1024, 1024))
+    xs, ys = xs.get(), ys.get()
+    assert np.array_equal(res._footprint, (xs >= -0.5) & (xs <= 1023.5) & (ys >= -0.5) & (ys <= 1023.5))
+    dev = res._device_data()
+    rows, chans = [3, 400, 512, 1020], [0, 1, 2047, 2048, 4095]
+    zfrac = (grid - v[0]) / (v[1] - v[0])                              # fractional source channel of every output channel
+    big = np.stack([np.tile(a0, (3, 3)), np.tile(b0, (3, 3))])
+    rowb = 1024 * 4
+    for r in rows:
+        x, y = xs[r], ys[r]
+        inner = (x >= 1) & (x <= 1022) & (y >= 1) & (y <= 1022)
+        ab, _ = O.resample_bilinear(big, np.mod(x, P)[None] + P, np.mod(y, P)[None] + P)
+        for c in chans:
+            got = np.empty(1024, np.float32)
+            _lib.call("spc_memcpy_d2h", 0, got.ctypes.data_as(C.c_void_p), C.c_void_p(dev.ptr + (c * 1024 + r) * rowb), rowb, None)
+            e = ab[0, 0] + ab[1, 0] * zfrac[c]
+            assert np.abs(got[inner] - e[inner]).max() <= 2e-5 * (np.abs(a0).max() + 2.1), (r, c)
+
 
 def test_c2_statistics_1024cubed_periodic_rows(gpu):
     """SURVEY.md section 8f rank 1 at configs[1] size: statistics() and the per-axis reductions
