@@ -134,7 +134,8 @@ struct BilArgs {
     int64_t zchunk;
     // LDS-staged pass: one byte per 32 x 32 output tile, 0 = done by bilinear_lds_kernel
     unsigned char* status;
-    int64_t tiles32_x, ntiles32;
+    int64_t tiles32_x, ntiles32;    // tile grid of the LDS pass (tiles of 1 << tile_shift pixels)
+    int tile_shift;
     int64_t zchunk_lds;
     int nearest;               // order 0: the nearest sample alone (scipy map_coordinates order=0)
     unsigned int* any_valid;   // optional device word: set to 1 by a block that wrote a non-NaN value
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const int64_t xo = bx * 64 + (wave * 16) + (lane & 15);
     const int64_t yo = by * 4 + (lane >> 4);
     if (xo >= A.nx_out || yo >= A.ny_out) return;
-    if (A.status && spc_flag_get(A.status + (yo >> 5) * A.tiles32_x + (xo >> 5)) == 0) return;   // wave-uniform: tile done via LDS
+    if (A.status && spc_flag_get(A.status + (yo >> A.tile_shift) * A.tiles32_x + (xo >> A.tile_shift)) == 0) return;   // wave-uniform: tile done via LDS
     const int64_t pix = yo * A.nx_out + xo;
     const double xs = A.xs[pix], ys = A.ys[pix];
     const bool inside = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
@@ -222,18 +223,27 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
 // 4 adjacent pixels with one 16-byte store.  The per-pixel arithmetic is the gather
 // kernel's, so both give identical bits; a tile whose footprint does not fit (strong
 // down-sampling) is flagged and left to the gather kernel.
-constexpr int kTile = 32;
-constexpr int kRowsMax = 64;                 // source rows a tile may touch
-constexpr int kElemsMax = 2048;              // staged source samples per channel
-constexpr int kFill = kElemsMax / 256;       // samples per thread and channel
-constexpr int kStageU = 8;                   // channels staged per iteration
+// Tile geometry.  Row spans of a 32 x 32 tile average 23 floats for a 30 degree rotation, so the 64-byte
+// sector granularity alone amplifies the reads x1.7 (PMC, round 1); a 64 x 64 tile has spans of ~55 floats
+// (x1.3) at the price of one 1024-thread block per CU and 4 instead of 8 staged channels.
+template <int TILE> struct BilTile;
+template <> struct BilTile<32> {
+    static constexpr int kThreads = 256, kRowsMax = 64, kElemsMax = 2048, kStageU = 8, kShift = 5;
+};
+template <> struct BilTile<64> {
+    static constexpr int kThreads = 1024, kRowsMax = 128, kElemsMax = 6144, kStageU = 4, kShift = 6;
+};
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool ARR, bool ANYMASK>
-__global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
+template <int TILE, bool ARR, bool ANYMASK>
+__global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(const BilArgs A) {
+    using G = BilTile<TILE>;
+    constexpr int kTile = TILE, kRowsMax = G::kRowsMax, kElemsMax = G::kElemsMax, kStageU = G::kStageU;
+    constexpr int kThreads = G::kThreads, kFill = kElemsMax / kThreads;       // samples per thread and channel
+    constexpr int kLanesX = TILE / 4;                                        // threads along x (4 adjacent pixels each)
     __shared__ float stage[kStageU * kElemsMax];
-    __shared__ int s_xmin[kRowsMax], s_xmax[kRowsMax], s_off[kRowsMax + 1];
+    __shared__ int s_xmin[kRowsMax], s_xmax[kRowsMax], s_off[kRowsMax + 1], s_tot[kRowsMax / 64];
     __shared__ int s_ymin, s_ymax;
     const int t = threadIdx.x;
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
@@ -244,8 +254,8 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
     const int64_t tile_id = (int64_t)(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (tile_id >= A.ntiles32) return;
     const int64_t bx = tile_id % A.tiles32_x, by = tile_id / A.tiles32_x;
-    const int64_t xo = bx * kTile + (t & 7) * 4;           // first of this lane's 4 adjacent pixels
-    const int64_t yo = by * kTile + (t >> 3);
+    const int64_t xo = bx * kTile + (t % kLanesX) * 4;     // first of this lane's 4 adjacent pixels
+    const int64_t yo = by * kTile + (t / kLanesX);
 
     bool inside[4];
     int x0[4], y0[4], dx[4], dy[4];
@@ -288,18 +298,27 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
         }
     }
     __syncthreads();
-    if (t < 64) {                              // one wave packs the row spans (inclusive scan)
+    if (t < kRowsMax) {                        // kRowsMax / 64 waves pack the row spans (inclusive scan per wave ...)
         int len = (t < nrows && s_xmax[t] >= 0) ? s_xmax[t] - s_xmin[t] + 1 : 0;
         int acc = len;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int up = __shfl_up(acc, d, 64);
-            if (t >= d) acc += up;
+            if ((t & 63) >= d) acc += up;
         }
         s_off[t + 1] = acc;
+        if ((t & 63) == 63) s_tot[t >> 6] = acc;
         if (t == 0) s_off[0] = 0;
     }
     __syncthreads();
+    if (kRowsMax > 64) {                       // ... then the totals of the waves before are added)
+        if (t >= 64 && t < kRowsMax) {
+            int base = 0;
+            for (int w = 0; w < (t >> 6); ++w) base += s_tot[w];
+            s_off[t + 1] += base;
+        }
+        __syncthreads();
+    }
     const int E = s_off[nrows];
     if (E > kElemsMax) { if (t == 0) spc_flag_set(A.status + tile); return; }
 
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
     int foff[kFill], moff[kFill];
 #pragma unroll
     for (int k = 0; k < kFill; ++k) {
-        const int e = t + 256 * k;
+        const int e = t + kThreads * k;
         foff[k] = -1; moff[k] = 0;
         if (e < E) {
             int lo = 0, hi = nrows;            // largest r with s_off[r] <= e
@@ -343,7 +362,7 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
             const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride : nullptr;
 #pragma unroll
             for (int k = 0; k < kFill; ++k) {
-                if (256 * k < E) {             // block-uniform
+                if (kThreads * k < E) {        // block-uniform
                     float v = 0.f;
                     if (foff[k] >= 0) {
                         v = p[foff[k]];
@@ -366,7 +385,7 @@ __global__ __launch_bounds__(256) void bilinear_lds_kernel(const BilArgs A) {
         for (int u = 0; u < kStageU; ++u)
 #pragma unroll
             for (int k = 0; k < kFill; ++k)
-                if (256 * k < E && foff[k] >= 0) stage[u * kElemsMax + t + 256 * k] = pre[u][k];
+                if (kThreads * k < E && foff[k] >= 0) stage[u * kElemsMax + t + kThreads * k] = pre[u][k];
         lds_only_barrier();
         if (zq + kStageU < ze) fetch(zq + kStageU);        // in flight while this group is resampled
 #pragma unroll
@@ -560,15 +579,19 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
                       (!arr || cube->ny * A.mask.row_stride < (1ll << 31));
     A.status = nullptr;
     if (want && fits) {
-        A.tiles32_x = (nx_out + kTile - 1) / kTile;
-        const int64_t ntiles = A.tiles32_x * ((ny_out + kTile - 1) / kTile);
+        const char* tenv = getenv("SPC_BILINEAR_TILE");
+        const int tile = tenv ? (atoi(tenv) == 32 ? 32 : 64) : ((nx_out >= 128 && ny_out >= 128) ? 64 : 32);
+        const int kStageU = tile == 64 ? BilTile<64>::kStageU : BilTile<32>::kStageU;
+        A.tile_shift = tile == 64 ? 6 : 5;
+        A.tiles32_x = (nx_out + tile - 1) / tile;
+        const int64_t ntiles = A.tiles32_x * ((ny_out + tile - 1) / tile);
         A.ntiles32 = ntiles;
         int ns = 1;
-        if (ntiles < 4096) ns = (int)std::max<int64_t>(1, std::min<int64_t>((4096 + ntiles - 1) / ntiles, cube->nz / 64));
-        // at most 256 channels per block (C5: 9.4 ms with 1024-channel chunks, 8.5 ms with 128 - 256, 9.4 with 64
-        // where the per-block footprint set-up starts to show).  The gain is scheduling - four times more, shorter
-        // blocks even out the tail - not cache reuse: FETCH_SIZE stays at x1.70 of the algorithmic read
-        // (profiles/r01_pmc_traffic.txt), and walking each XCD's band in compact 8 x 4 tile patches changes nothing.
+        const int64_t want_blocks = tile == 64 ? 1024 : 4096;
+        if (ntiles < want_blocks) ns = (int)std::max<int64_t>(1, std::min<int64_t>((want_blocks + ntiles - 1) / ntiles, cube->nz / 64));
+        // at most 256 channels per block (C5, 32 x 32 tiles: 9.4 ms with 1024-channel chunks, 8.5 ms with 128 - 256, 9.4 with 64
+        // where the per-block footprint set-up starts to show).  The gain is scheduling - more, shorter blocks even out the
+        // tail - not cache reuse: FETCH_SIZE did not move (profiles/r01_pmc_traffic.txt).
         A.zchunk_lds = std::min<int64_t>((cube->nz + ns - 1) / ns, 256);
         if (const char* zc = getenv("SPC_BILINEAR_ZCHUNK")) A.zchunk_lds = std::max(8, atoi(zc));
         A.zchunk_lds = ((A.zchunk_lds + kStageU - 1) / kStageU) * kStageU;
@@ -578,9 +601,17 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
         SPC_HIP(spc_flags_clear(d_status, (size_t)ntiles, st));
         A.status = d_status;
         dim3 g((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)ns);
-        if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<true, true>), g, dim3(256), 0, st, A);
-        else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<false, true>), g, dim3(256), 0, st, A);
-        else hipLaunchKernelGGL((bilinear_lds_kernel<false, false>), g, dim3(256), 0, st, A);
+        if (tile == 64) {
+            dim3 b(BilTile<64>::kThreads);
+            if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<64, true, true>), g, b, 0, st, A);
+            else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<64, false, true>), g, b, 0, st, A);
+            else hipLaunchKernelGGL((bilinear_lds_kernel<64, false, false>), g, b, 0, st, A);
+        } else {
+            dim3 b(BilTile<32>::kThreads);
+            if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<32, true, true>), g, b, 0, st, A);
+            else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<32, false, true>), g, b, 0, st, A);
+            else hipLaunchKernelGGL((bilinear_lds_kernel<32, false, false>), g, b, 0, st, A);
+        }
         SPC_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
@@ -591,5 +622,5 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
 }  // extern "C"
 
 size_t spc_ws_resample_bilinear(int64_t ny_out, int64_t nx_out) {
-    return spc_ws_round((size_t)(((nx_out + kTile - 1) / kTile) * ((ny_out + kTile - 1) / kTile))) + 256;
+    return spc_ws_round((size_t)(((nx_out + 31) / 32) * ((ny_out + 31) / 32))) + 256;     // tile flags (32 x 32: the finer grid)
 }

@@ -15,17 +15,21 @@ tile = synth.gaussian_line_cube((shape[0], 2, shape[2]), 2004, chunk_rows=2)
 cube = DeviceArray(shape, np.float32); _replicate_rows(cube, tile, 4)
 hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CRVAL1": 150.0, "CRVAL2": 2.0, "CRPIX1": 512.5, "CRPIX2": 512.5,
        "CDELT1": -1 / 3600, "CDELT2": 1 / 3600, "NAXIS": 2}
-c, s_ = np.cos(np.radians(30)), np.sin(np.radians(30))
-w_in, w_out = SimpleWCS(hdr, naxis=2), SimpleWCS(dict(hdr, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c), naxis=2)
-xs, ys = reproject_pixel_map(w_in, w_out, (1024, 1024))
 out = DeviceArray(shape, np.float32)
-for label, env in [("default", {})] + [("zchunk=%d" % z, {"SPC_BILINEAR_ZCHUNK": str(z)}) for z in (512, 256, 128, 64, 32)]:
-    os.environ.pop("SPC_BILINEAR_ZCHUNK", None)
-    os.environ.update(env)
-    ts = []
-    for i in range(5):
-        e0, e1 = Event(), Event()
-        e0.record(); ops.resample_bilinear(cube, xs, ys, out=out); e1.record(); e1.synchronize()
-        ts.append(e0.elapsed_ms(e1))
-    vox = np.prod(shape, dtype=np.int64)
-    print("%-14s %s  median %.3f ms  %.0f GB/s" % (label, ["%.2f" % t for t in ts], np.median(ts[1:]), vox * 8 / np.median(ts[1:]) / 1e6), flush=True)
+ref = None
+for deg in (30.0, 7.0, 45.0):
+    c, s_ = np.cos(np.radians(deg)), np.sin(np.radians(deg))
+    w_in, w_out = SimpleWCS(hdr, naxis=2), SimpleWCS(dict(hdr, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c), naxis=2)
+    xs, ys = reproject_pixel_map(w_in, w_out, (1024, 1024))
+    for label, env in [("tile 64", {"SPC_BILINEAR_TILE": "64"}), ("tile 32", {"SPC_BILINEAR_TILE": "32"}),
+                       ("tile 64 z128", {"SPC_BILINEAR_TILE": "64", "SPC_BILINEAR_ZCHUNK": "128"}),
+                       ("tile 64 z512", {"SPC_BILINEAR_TILE": "64", "SPC_BILINEAR_ZCHUNK": "512"})]:
+        for k in ("SPC_BILINEAR_ZCHUNK", "SPC_BILINEAR_TILE"): os.environ.pop(k, None)
+        os.environ.update(env)
+        ts = []
+        for i in range(5):
+            e0, e1 = Event(), Event()
+            e0.record(); ops.resample_bilinear(cube, xs, ys, out=out); e1.record(); e1.synchronize()
+            ts.append(e0.elapsed_ms(e1))
+        vox = np.prod(shape, dtype=np.int64)
+        print("%4.0f deg %-14s median %.3f ms  %.0f GB/s  %.1f%%" % (deg, label, np.median(ts[1:]), vox * 8 / np.median(ts[1:]) / 1e6, vox * 8 / np.median(ts[1:]) / 1e6 / 80), flush=True)
