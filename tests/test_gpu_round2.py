@@ -212,14 +212,68 @@ def test_two_stencils_in_flight_on_two_streams(gpu):
     assert not errors, errors
 
 
-def test_chunk_functions_under_dask_map_blocks(gpu):
-    """_map_blocks_to_cube (dask_spectral_cube.py:816-844) hands the chunk functions numpy blocks through
-    dask.array.map_blocks; runs only where dask is importable."""
-    da = pytest.importorskip("dask.array")
-    from spectral_cube_amd.dask_adapter import SpectralSmoothChunk
-    d = np.random.default_rng(5).standard_normal((32, 16, 24)).astype(np.float32)
-    k = Gaussian1DKernel(1.5).array
-    arr = da.from_array(d, chunks=(-1, 8, 12))
-    out = da.map_blocks(SpectralSmoothChunk(k), arr, dtype=arr.dtype).compute(scheduler="synchronous")
-    exp = O.spectral_smooth(d, None, k)
-    assert_close(out, exp, atol=1e-5 * np.abs(exp).max(), what="map_blocks")
+DASK_WORKER = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import numpy as np
+import dask, dask.array as da
+import oracle_np as O
+from spectral_cube_amd.dask_adapter import SpectralSmoothChunk, SpatialSmoothChunk, MomentChunk, SpectralInterpolateChunk
+from spectral_cube_amd.kernels import Gaussian1DKernel, Gaussian2DKernel
+rng = np.random.default_rng(5)
+d = rng.standard_normal((48, 40, 56)).astype(np.float32)
+d[5:9, 3, 7] = np.nan                                     # masked voxels arrive NaN-filled (FilledArrayHandler)
+k1, k2 = Gaussian1DKernel(1.5).array, Gaussian2DKernel(1.2).array
+def close(a, b, what):
+    assert a.shape == b.shape and a.dtype == b.dtype, (what, a.shape, b.shape, a.dtype, b.dtype)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what
+    ok = np.isfinite(b)
+    assert np.abs(a[ok] - b[ok]).max() <= 1e-5 * np.abs(b[ok]).max(), what
+for sched in ("synchronous", "threads"):                  # dask_spectral_cube.py:259, 278-312
+    with dask.config.set(scheduler=sched):
+        # apply_function_parallel_spectral -> _map_blocks_to_cube: rechunk (-1, auto, auto), map_blocks(dtype=data.dtype)
+        arr = da.from_array(d, chunks=(-1, 16, 24))
+        out = da.map_blocks(SpectralSmoothChunk(k1), arr, dtype=arr.dtype).compute()
+        close(out, O.spectral_smooth(d, None, k1), "spectral " + sched)
+        # apply_function_parallel_spatial: rechunk (auto, -1, -1)
+        arr = da.from_array(d, chunks=(10, -1, -1))
+        out = da.map_blocks(SpatialSmoothChunk(k2), arr, dtype=arr.dtype).compute()
+        close(out, O.spatial_smooth(d, None, k2), "spatial " + sched)
+        # a reduced chunk function (tests/test_dask.py:144-169 pattern): drop_axis=[0]
+        cen = np.arange(48.0) * 0.5
+        arr = da.from_array(d, chunks=(-1, 20, 28))
+        m1 = da.map_blocks(MomentChunk(1, cen, 0.5, world0=-3.0), arr, dtype=np.float64, drop_axis=[0],
+                           chunks=(arr.chunks[1], arr.chunks[2])).compute()
+        e1 = O.moment(d, None, 1, cen, 0.5, world0=-3.0)
+        assert np.array_equal(np.isnan(m1), np.isnan(e1)) and np.nanmax(np.abs(m1 - e1)) <= 1e-5 * 24.0
+        # interp_wrapper: the chunk grows along the spectral axis
+        x = np.arange(48.0); grid = np.linspace(0.0, 47.0, 95)
+        out = da.map_blocks(SpectralInterpolateChunk(x, grid), arr, dtype=arr.dtype,
+                            chunks=((95,), arr.chunks[1], arr.chunks[2])).compute()
+        exp, _ = O.spectral_interpolate(d, None, x, grid)
+        close(out, exp.astype(np.float32), "interp " + sched)
+print("DASK_OK", dask.__version__)
+'''
+
+
+def test_chunk_functions_under_dask_map_blocks(gpu, tmp_path):
+    """The chunk functions under a REAL dask.array.map_blocks, the way _map_blocks_to_cube
+    (dask_spectral_cube.py:816-844) calls them: spectral / spatial chunking, a reduced function with
+    drop_axis, a chunk that grows along z, under the `synchronous` and the `threads` scheduler (re-entrancy:
+    every worker thread gets its own device scratch).  dask lives in the image's conda interpreter only, so the
+    test runs there as a subprocess; skipped where that interpreter or dask is missing."""
+    import shutil
+    import subprocess
+    from conftest import REPO
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import dask.array"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with dask on this box")
+    script = tmp_path / "dask_worker.py"
+    script.write_text(DASK_WORKER)
+    # conda ships an older libstdc++ that scipy would load first: the system one must win for libspcube_hip.so
+    env = dict(os.environ)
+    sys_cxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_cxx):
+        env["LD_PRELOAD"] = sys_cxx
+    r = subprocess.run([py, "-B", str(script), REPO], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DASK_OK" in r.stdout, r.stdout + r.stderr
