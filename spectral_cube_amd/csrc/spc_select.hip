@@ -261,6 +261,163 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
 }
 
 
+// N samples of one lane (256 words apart in the tile), counted into sixteen 4-bit fields by the digit at bit b
+// among those that agree with `prefix` above it (N <= 15: a field cannot overflow).  All loads are issued first.
+template <int N>
+__device__ __forceinline__ unsigned long long count_digits(const uint32_t* keys, uint32_t prefix, int b) {
+    uint32_t key[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) key[u] = keys[u * 256];
+    unsigned long long a = 0ull;
+    if (b == 28) {                                               // no prefix yet
+#pragma unroll
+        for (int u = 0; u < N; ++u) a += 1ull << ((key[u] >> 28) * 4u);
+    } else {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const uint32_t x = key[u] ^ prefix;                  // the digits above b vanish for a sample inside the prefix
+            const unsigned long long one = ((x >> (b + 4)) == 0u) ? 1ull : 0ull;
+            a += one << (((x >> b) & 15u) * 4u);
+        }
+    }
+    return a;
+}
+
+// ---- rays resident in LDS: ONE read of the cube (round 2) ----------------------------------------------
+// The descents above stream the cube once per digit (8 or 17 reads): 18.7 ms for a median at 1024^3, 3.6 % of
+// the roofline of a single read.  Here a block owns TS adjacent spaxels (TS x 4 bytes contiguous per plane: 64-
+// or 128-byte segments), reads their rays ONCE, turns every sample into its order-preserving key (excluded / NaN
+// samples become the largest key, which no valid float maps to) and keeps the TS x nz keys in LDS (<= 64 KB: two
+// blocks per CU).  The radix-16 descent then runs over LDS: 256 / TS lanes share a ray, each counts its slice of
+// the ray into sixteen 8-bit fields of two 64-bit registers (no atomics, no dynamic indexing), the per-ray totals
+// meet in a small LDS histogram (three rotating buffers: one barrier per digit), every lane of the ray walks the
+// sixteen totals to the digit.  The second order statistic of an interpolated percentile is either the same
+// value (ties) or the smallest key above the first: one more sweep over LDS.
+template <int TS, bool ARR>
+__global__ __launch_bounds__(256) void select_tile_kernel(const SelArgs A) {
+    extern __shared__ uint32_t tile_keys[];                    // [nzp][TS], nzp = nz rounded up to the lanes of a ray
+    __shared__ uint32_t hist[3][TS][16];
+    __shared__ uint32_t nvalid[TS], nextkey[TS];
+    constexpr int kLanesPerRay = 256 / TS;
+    const int t = threadIdx.x;
+    const int r = t % TS, j = t / TS;                           // ray of the tile, slice of the ray
+    const int64_t tiles_x = (A.nx + TS - 1) / TS;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
+    const int nz = (int)A.nz;
+    const int iters = (nz + kLanesPerRay - 1) / kLanesPerRay;   // samples per lane (<= 64), the same for every lane:
+    const bool col_in = x0 + r < A.nx;                          // the tail of the last round holds the largest key
+    const int64_t xc = col_in ? x0 + r : A.nx - 1;
+    const float* p = A.cube + y * A.row_stride + xc;
+    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc : nullptr;
+    const bool use_cen = A.center != nullptr;
+    const float cen = (use_cen && col_in) ? A.center[y * A.nx + x0 + r] : 0.f;
+    if (t < TS) { nvalid[t] = 0u; nextkey[t] = 0xffffffffu; }
+    for (int i = t; i < 3 * TS * 16; i += 256) (&hist[0][0][0])[i] = 0u;
+    __syncthreads();
+    // ---- the one read of the cube: keys into LDS
+    int mine = 0;
+    constexpr int U = 4;
+    for (int z0 = j; z0 < iters * kLanesPerRay; z0 += kLanesPerRay * U) {
+        float raw[U];
+        unsigned mk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = min(z0 + u * kLanesPerRay, nz - 1);
+            raw[u] = __builtin_nontemporal_load(p + (int64_t)z * A.plane_stride);
+            mk[u] = ARR ? pm[(int64_t)z * A.mask.plane_stride] : 1u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = z0 + u * kLanesPerRay;
+            if (z < iters * kLanesPerRay) {
+                bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
+                const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
+                ok = ok && (v == v);
+                tile_keys[z * TS + r] = ok ? fkey(v) : 0xffffffffu;
+                mine += ok ? 1 : 0;
+            }
+        }
+    }
+    if (mine) atomicAdd(&nvalid[r], (uint32_t)mine);
+    __syncthreads();
+    const int n = (int)nvalid[r];
+    const double pos = A.q / 100.0 * (double)(n > 0 ? n - 1 : 0);
+    const double fl = floor(pos);
+    int k = (int)fl;                                             // rank still to be found inside the current prefix
+    const int khi = min((int)ceil(pos), max(n - 1, 0));
+    const double frac = pos - fl;
+    int below = 0;                                               // keys smaller than everything matching the prefix
+    uint32_t prefix = 0u;
+    int eq = 0;
+    const uint32_t* mykeys = tile_keys + j * TS + r;             // sample i of this lane: mykeys[i * 256]
+    constexpr unsigned long long kNib = 0x0f0f0f0f0f0f0f0full;
+#pragma unroll 1
+    for (int pass = 0; pass < 8; ++pass) {
+        const int b = 28 - 4 * pass;
+        // sixteen 4-bit counters in one 64-bit register (one shift + one add per sample), emptied every 15 samples into
+        // 8-bit counters: even digits in accE, odd digits in accO
+        unsigned long long accE = 0ull, accO = 0ull;
+        int i = 0;
+        for (; i + 15 <= iters; i += 15) {
+            const unsigned long long a = count_digits<15>(mykeys + i * 256, prefix, b);
+            accE += a & kNib;
+            accO += (a >> 4) & kNib;
+        }
+        {
+            unsigned long long a = 0ull;                         // < 15 samples left
+            for (; i + 4 <= iters; i += 4) a += count_digits<4>(mykeys + i * 256, prefix, b);
+            for (; i < iters; ++i) a += count_digits<1>(mykeys + i * 256, prefix, b);
+            accE += a & kNib;
+            accO += (a >> 4) & kNib;
+        }
+        uint32_t* h = hist[pass % 3][r];
+        uint32_t* hz = hist[(pass + 1) % 3][r];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const uint32_t c0 = (uint32_t)(accE >> (8 * d)) & 0xffu, c1 = (uint32_t)(accO >> (8 * d)) & 0xffu;
+            if (c0) atomicAdd(&h[2 * d], c0);
+            if (c1) atomicAdd(&h[2 * d + 1], c1);
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) hz[d] = 0u;              // next pass's buffer (last read two passes ago)
+        }
+        __syncthreads();
+        uint32_t dsel = 15u;
+        bool found = false;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            const int c = (int)h[d];
+            if (!found) {
+                if (k < c) { dsel = d; found = true; eq = c; }
+                else { k -= c; below += c; }
+            }
+        }
+        prefix |= dsel << b;
+    }
+    // prefix = the key of rank floor(pos); `eq` samples carry it, `below` are smaller
+    uint32_t key_hi = prefix;
+    const bool need_next = (n > 0) && (khi >= below + eq);       // ray-uniform
+    if (need_next) {
+        uint32_t mn = 0xffffffffu;
+        for (int i = 0; i < iters; ++i) {
+            const uint32_t key = mykeys[i * 256];
+            if (key > prefix) mn = min(mn, key);
+        }
+        atomicMin(&nextkey[r], mn);
+    }
+    __syncthreads();
+    if (need_next) key_hi = nextkey[r];
+    if (j == 0 && col_in) {
+        float res = NAN;
+        if (n > 0) {
+            const double a = (double)funkey(prefix), bb = (double)funkey(key_hi);
+            res = (float)((frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac) * (double)A.scale);
+        }
+        A.out[y * A.nx + x0 + r] = res;
+    }
+}
+
 // ---- whole-cube order statistic (median / percentile / mad_std with axis=None) ----------------
 // The cube is one long ray here, so the digits of the key are found with shared histograms: one
 // streaming pass per key BYTE (4 passes) counts, among the samples whose key matches the prefix
@@ -356,6 +513,33 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
                     ((((uintptr_t)cube->d_data) & 15) == 0) &&
                     (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
     hipStream_t st = (hipStream_t)stream;
+    // rays resident in LDS (one read of the cube) when TS x nz keys fit 64 KB: nz <= 512 / 1024 / 2048 for 32 / 16 / 8
+    // spaxels per block; any strides (a y-ray view included)
+    const char* tenv = getenv("SPC_SELECT_TILE");
+    if ((tenv ? atoi(tenv) != 0 : true) && cube->nz <= 2048 && cube->ny * ((cube->nx + 7) / 8) < (1LL << 31)) {
+        const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
+        const int lanes = 256 / ts;
+        const size_t lds = (size_t)ts * (size_t)((cube->nz + lanes - 1) / lanes * lanes) * sizeof(uint32_t);
+        const int64_t nblk = cube->ny * ((cube->nx + ts - 1) / ts);
+        dim3 grid((unsigned)nblk);
+#define SPC_LAUNCH_TILE(TS_)                                                                                          \
+        do {                                                                                                          \
+            if (arr) hipLaunchKernelGGL((select_tile_kernel<TS_, true>), grid, dim3(256), lds, st, A);                \
+            else hipLaunchKernelGGL((select_tile_kernel<TS_, false>), grid, dim3(256), lds, st, A);                   \
+        } while (0)
+        if (lds > 48 * 1024) {      // dynamic LDS beyond the default limit has to be requested
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        }
+        if (ts == 32) SPC_LAUNCH_TILE(32); else if (ts == 16) SPC_LAUNCH_TILE(16); else SPC_LAUNCH_TILE(8);
+#undef SPC_LAUNCH_TILE
+        SPC_LAUNCH_CHECK();
+        return SPC_OK;
+    }
     const char* env = getenv("SPC_SELECT_RADIX16");
     if (v4 && cube->nz <= 65535 && (env ? atoi(env) != 0 : true)) {
         const int64_t n = cube->ny * (cube->nx / 4);

@@ -277,3 +277,42 @@ def test_chunk_functions_under_dask_map_blocks(gpu, tmp_path):
         env["LD_PRELOAD"] = sys_cxx
     r = subprocess.run([py, "-B", str(script), REPO], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "DASK_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (515, 2, 37), (1030, 2, 21), (2050, 1, 12)])
+def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
+    """np.nanmedian / np.nanpercentile of masked rays through every selection kernel: the LDS-resident tiles
+    (32 / 16 / 8 spaxels per block by ray length, lengths that are no multiple of the lanes per ray, tiles
+    hanging over the row end), and - by switch - the streaming radix-16 and bisection descents that longer rays
+    fall back to.  Medians are bit-exact; MAD (centre per spaxel) goes through the same kernels."""
+    import warnings
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    rng = np.random.default_rng(shape[0])
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[rng.random(shape) < 0.05] = np.nan
+    d[:, 0, 0] = np.nan                                             # an empty ray
+    d[: shape[0] // 2, 0, 1] = 2.5                                  # ties
+    inc = rng.random(shape) < 0.8
+    fz = np.where(inc, d, np.nan).astype(np.float32)
+    dd = DeviceArray.from_numpy(d)
+    spec = ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        emed = np.nanmedian(fz, axis=0)
+        e30 = np.nanpercentile(fz.astype(np.float64), 30.0, axis=0)
+        emad = np.nanmedian(np.abs(fz - emed[None]), axis=0)
+        emed_nomask = np.nanmedian(d, axis=0)
+    for env in ({}, {"SPC_SELECT_TILE": "0"}, {"SPC_SELECT_TILE": "0", "SPC_SELECT_RADIX16": "0"}):
+        for k in ("SPC_SELECT_TILE", "SPC_SELECT_RADIX16"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        med = ops.percentile_axis0(dd, 50.0, mask=spec)
+        assert np.array_equal(med.get(), emed, equal_nan=True), env
+        assert np.array_equal(ops.percentile_axis0(dd, 50.0).get(), emed_nomask, equal_nan=True), env
+        got30 = ops.percentile_axis0(dd, 30.0, mask=spec).get()
+        assert np.array_equal(np.isnan(got30), np.isnan(e30))
+        np.testing.assert_allclose(got30, e30, rtol=3e-6, atol=1e-7, equal_nan=True)
+        mad = ops.percentile_axis0(dd, 50.0, mask=spec, center=med).get()
+        assert np.array_equal(mad, emad, equal_nan=True), env
