@@ -360,15 +360,10 @@ int fill_common(ConvArgs& A, const spc_cube_f32* cube, const spc_mask* mask, con
     A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
     for (int i = 0; i < 64; ++i) A.k[i] = 0.0;
-    for (int i = 0; i < 130; ++i) A.kPS[i] = 0.0;
     if (R) {
         const int pad = (R - ntaps) / 2;
         for (int i = 0; i < ntaps; ++i) A.k[pad + i] = h_kernel[i];
         { double ks = 0.0; for (int i = 0; i < R; ++i) ks += A.k[i]; A.ksum = ks; A.inv_ksum = 1.0 / ks; }
-        double acc = 0.0;                      // prefix / suffix sums of the taps
-        for (int i = 0; i < R; ++i) { acc += A.k[i]; A.kPS[2 * i] = acc; }
-        acc = 0.0;
-        for (int i = R - 1; i >= 0; --i) { A.kPS[2 * i + 1] = acc; acc += A.k[i]; }
     }
     return SPC_OK;
 }

@@ -28,11 +28,14 @@
 //   * the FMAs are in-place `v_fma_f64` inline asm with the weight in an SGPR pair:
 //     left alone, LLVM sinks each slot's FMA chain to its emission point (R-long
 //     dependent chains, twice the registers);
-//   * the NaN-renormalising denominator den = sum of the weights of the VALID
-//     samples is only FMA-ed in revolutions where some lane of the wavefront saw
-//     an invalid sample.  In an all-valid revolution each slot receives a known run
-//     of weights, i.e. a prefix / suffix sum of the kernel (kPS), added once per
-//     output instead of R FMAs;
+//   * the NaN-renormalising denominator den = sum of the weights of the VALID samples of
+//     a window is a function of the window's R validity bits only.  It is not accumulated:
+//     every lane keeps the validity of its last 64 samples in one 64-bit register and the
+//     block keeps, in LDS, the partial sums of the taps for every pattern of 11 adjacent
+//     bits (ceil(R / 11) tables of 2048 float64 sums, built by the block when it starts).
+//     A denominator is then <= 3 LDS reads + 2 additions instead of R FMAs and R live
+//     registers; a revolution whose windows are all valid (wave-uniform) divides by the
+//     kernel sum without looking anything up;
 //   * ONE unrolled body with wave-uniform run-time flags: two specialised bodies
 //     (or a per-step validity branch) make the register allocator duplicate /
 //     copy the whole ring (measured: 2x VGPRs or 2R v_mov per step);
@@ -44,7 +47,7 @@
 
 namespace spc_sconv {
 
-constexpr int kMaxTaps = 63;                   // ring <= 63: the uniform-den vector has 64 lanes
+constexpr int kMaxTaps = 33;                   // three denominator tables of 11 validity bits
 typedef float float2v __attribute__((ext_vector_type(2)));
 
 struct ConvArgs {
@@ -65,10 +68,46 @@ struct ConvArgs {
     unsigned char* status;
     double ksum, inv_ksum;     // sum(k) in tap order, 1 / sum(k)
     alignas(16) double k[64];  // taps padded to R, centred
-    // kPS[2s]   = k[0] + ... + k[s]      (what a slot completing at step s collected this revolution)
-    // kPS[2s+1] = k[s+1] + ... + k[R-1]  (what a slot restarted at step s+1 will still collect)
-    double kPS[130];
 };
+
+// ---- denominators from validity bits ------------------------------------------------------
+// Bit b of a lane's validity history = the sample that arrived b steps ago; when an output
+// completes, that sample carried tap k[b] (the newest sample takes k[0], see ring_body).
+constexpr int kLutBits = 11, kLutSize = 1 << kLutBits;
+constexpr int lut_tables(int R) { return (R + kLutBits - 1) / kLutBits; }
+// threads per block of the general kernel: the tables are per block (48 KB for 33 taps), so the block size sets
+// how many waves share a CU: 2 x 512 threads (4 waves per SIMD) where the registers allow it (no mask array, not
+// fused: 120 VGPRs), 3 x 256 threads otherwise (139 VGPRs with a mask array; measured 3.7 ms against 4.1 ms)
+constexpr int general_block(bool arr, bool fuse) { return (arr || fuse) ? 256 : 512; }
+
+template <int R>
+__device__ __forceinline__ void lut_build(const ConvArgs& A, double* lut) {
+#pragma unroll
+    for (int t = 0; t < lut_tables(R); ++t) {
+        for (int w = threadIdx.x; w < kLutSize; w += blockDim.x) {
+            double acc = 0.0;
+#pragma unroll
+            for (int b = 0; b < kLutBits; ++b)
+                if (kLutBits * t + b < R) acc += ((w >> b) & 1) ? A.k[kLutBits * t + b] : 0.0;
+            lut[t * kLutSize + w] = acc;
+        }
+    }
+}
+
+// byte-offset mask of a table of which `bits` (<= 11) index bits are in use
+constexpr unsigned lut_mask(int bits) { return (((bits >= kLutBits) ? (unsigned)kLutSize : (bits > 0 ? (1u << (bits > 0 ? bits : 0)) : 1u)) - 1u) * 8u; }
+
+template <int R>
+__device__ __forceinline__ double lut_den(const double* lut, unsigned long long hist) {
+    const unsigned lo = (unsigned)hist, hi = (unsigned)(hist >> 32);
+    const char* base = reinterpret_cast<const char*>(lut);
+    double den = *reinterpret_cast<const double*>(base + ((lo << 3) & lut_mask(R)));
+    if (R > kLutBits)
+        den += *reinterpret_cast<const double*>(base + kLutSize * 8 + ((lo >> (kLutBits - 3)) & lut_mask(R - kLutBits)));
+    if (R > 2 * kLutBits)
+        den += *reinterpret_cast<const double*>(base + 2 * kLutSize * 8 + (__builtin_amdgcn_alignbit(hi, lo, 2 * kLutBits - 3) & lut_mask(R - 2 * kLutBits)));
+    return den;
+}
 
 // fused-moment running state of one spaxel
 struct MomState {
@@ -141,33 +180,22 @@ __device__ __forceinline__ unsigned ldm1(const uint8_t* plane, int moff) {
 // The R x R update + emission part of one revolution.
 //   v[s]  : classified input: the value when valid, NaN when invalid, 0 when out of range
 //   incb  : (FUSE only) bit s = sample s is in range and included by the mask
-// ALLV (wave-uniform, run-time): the wavefront's R samples are all valid ->
-// numerator FMAs only.  FULL (wave-uniform): this and the previous revolution were all
-// valid, so every output completing now has the whole kernel as its denominator
-// (out-of-range samples are valid zeros, boundary='fill').
+//   okhist: validity of the lane's last 64 samples, bit 0 = newest (out-of-range samples are
+//           valid zeros, boundary='fill')
+// FULL (wave-uniform, run-time): this and the previous revolution were all valid, so every
+// output completing now has the whole kernel as its denominator.
 template <int R, bool ARR, bool FUSE, bool EXT, bool SYM>
-__device__ __forceinline__ void ring_body(const ConvArgs& A, double (&num)[R], double (&den)[R],
-                                          const float (&v)[R], unsigned long long incb,
+__device__ __forceinline__ void ring_body(const ConvArgs& A, double (&num)[R], const double* lut,
+                                          const float (&v)[R], unsigned long long incb, unsigned long long& okhist,
                                           unsigned long long& inc_hist, MomState& ms, int voff_out, int i0,
-                                          int zb, int ze, const bool ALLV, const bool FULL) {
+                                          int zb, int ze, const bool FULL) {
     constexpr int H = R / 2;
     // outputs of this revolution: planes i0 - H .. i0 + H, addressed from the first one that exists
     const int ob = max(i0 - H, 0);
     const int obytes = FUSE ? 0 : (int)(A.out_plane_stride * 4);
     const auto ro = plane_srd(FUSE ? (const void*)A.cube : (const void*)(A.out + (int64_t)ob * A.out_plane_stride));
-    // slot 0 always restarts at step 0; after a GENERAL revolution its den is stale
-    if (ALLV) den[0] = 0.0;
-    // prefix/suffix sums are fetched one step ahead through an opaque index so that the
-    // 2R scalar loads are not all hoisted to the top (they would not fit the SGPR file)
-    int zo = 0;
-    double kp = 0.0, ks = 0.0, kp_n = 0.0, ks_n = 0.0;
-    if (ALLV) { asm volatile("" : "+s"(zo)); kp_n = A.kPS[zo]; ks_n = A.kPS[1 + zo]; }
 #pragma unroll
     for (int s = 0; s < R; ++s) {
-        if (ALLV) {
-            kp = kp_n; ks = ks_n;
-            if (s + 1 < R) { asm volatile("" : "+s"(zo)); kp_n = A.kPS[2 * (s + 1) + zo]; ks_n = A.kPS[2 * (s + 1) + 1 + zo]; }
-        }
         const bool ok = v[s] == v[s];
         const double x = ok ? (double)v[s] : 0.0;
 #pragma unroll
@@ -178,16 +206,7 @@ __device__ __forceinline__ void ring_body(const ConvArgs& A, double (&num)[R], d
             if (a == 0) mul_w(num[m], A, j, x);
             else fma_w(num[m], A, j, x);
         }
-        if (!ALLV) {
-            const double okd = ok ? 1.0 : 0.0;
-#pragma unroll
-            for (int m = 0; m < R; ++m) {
-                const int a = (s - m + R) % R;
-                const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
-                if (a == 0) mul_w(den[m], A, j, okd);
-                else fma_w(den[m], A, j, okd);
-            }
-        }
+        if (!FULL) okhist = (okhist << 1) | (ok ? 1ull : 0ull);
         if (FUSE && A.mask.flags) inc_hist = (inc_hist << 1) | ((incb >> s) & 1ull);
         // ---- the output that just received its last contribution
         const int e = (s + 1) % R;
@@ -197,7 +216,7 @@ __device__ __forceinline__ void ring_body(const ConvArgs& A, double (&num)[R], d
             if (FULL) {
                 res = (float)div_ksum(num[e], A);
             } else {
-                const double dtot = ALLV ? den[e] + kp : den[e];
+                const double dtot = lut_den<R>(lut, okhist);
                 // astropy returns the (filled) centre sample for an empty window; the host
                 // only dispatches kernels with a non-zero centre tap here, for which an empty
                 // window implies an invalid centre, i.e. NaN
@@ -223,20 +242,23 @@ __device__ __forceinline__ void ring_body(const ConvArgs& A, double (&num)[R], d
                 }
             }
         }
-        // all-valid revolution: the slot restarts at step s+1 and will collect the
-        // weights k[R-1] .. k[s+1] (ages 0 .. R-2-s) before this revolution ends
-        if (ALLV) den[e] = (s < R - 1) ? ks : 0.0;
     }
+    if (FULL) okhist = ~0ull;                        // R valid samples went by
 }
 
 template <int R, bool ARR, bool FUSE, bool EXT, bool SYM>
-__global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
+__global__ __launch_bounds__(general_block(ARR, FUSE)) void spectral_conv_kernel(const ConvArgs A) {
     constexpr int H = R / 2;
-    static_assert(R <= kMaxTaps, "ring too large for the 64-bit include word");
+    static_assert(R <= 3 * kLutBits, "three denominator tables cover 33 taps");
+    __shared__ double lut[lut_tables(R) * kLutSize];
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= A.ny * A.nx) return;
     // tiles (128 columns) already finished by the all-valid fast kernel
-    if (A.status && spc_flag_get(A.status + __builtin_amdgcn_readfirstlane((int)(col >> 7))) == 0) return;
+    const bool live = (col < A.ny * A.nx) &&
+                      !(A.status && spc_flag_get(A.status + __builtin_amdgcn_readfirstlane((int)(min(col, A.ny * A.nx - 1) >> 7))) == 0);
+    if (!__syncthreads_or(live ? 1 : 0)) return;
+    lut_build<R>(A, lut);
+    __syncthreads();
+    if (!live) return;
     const int64_t y = col / A.nx, x = col - y * A.nx;
     const int nz = (int)A.nz;
     const int zb = (int)(blockIdx.y * A.zchunk);
@@ -246,10 +268,11 @@ __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
     const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
     const int voff = (int)((y * A.row_stride + x) * 4);              // < 2 GiB per plane (checked on the host)
     const int moff = ARR ? (int)(y * A.mask.row_stride + x) : 0;
-    double num[R], den[R];
+    double num[R];
 #pragma unroll
-    for (int m = 0; m < R; ++m) { num[m] = 0.0; den[m] = 0.0; }
+    for (int m = 0; m < R; ++m) num[m] = 0.0;
     unsigned long long inc_hist = 0ull;  // include bit of the last 64 inputs (bit 0 = newest)
+    unsigned long long okhist = ~0ull;   // validity of the last 64 inputs (what lies before the slice start is never emitted)
     MomState ms;
     bool prev_allv = false;
     const int pbytes = (int)(A.plane_stride * 4), mbytes = ARR ? (int)A.mask.plane_stride : 0;
@@ -286,7 +309,7 @@ __global__ __launch_bounds__(256) void spectral_conv_kernel(const ConvArgs A) {
         // (the first revolution of a z slice starts from zeroed rings whose first H outputs lie
         // before zb and are never emitted, so "previous revolution all valid" holds vacuously)
         const bool full = allv && (prev_allv || t0 == 0);
-        ring_body<R, ARR, FUSE, EXT, SYM>(A, num, den, v, incb, inc_hist, ms, voff_out, i0, zb, ze, allv, full);
+        ring_body<R, ARR, FUSE, EXT, SYM>(A, num, lut, v, incb, okhist, inc_hist, ms, voff_out, i0, zb, ze, full);
         prev_allv = allv;
     }
 
@@ -430,12 +453,15 @@ __global__ __launch_bounds__(256) void spectral_conv_fast_kernel(const ConvArgs 
 }
 
 template <int R, bool FUSE, bool SYM>
-int launch_rs(const ConvArgs& A, hipStream_t st, dim3 grid, bool arr, bool ext) {
-    dim3 block(256);
+int launch_rs(const ConvArgs& A, hipStream_t st, int64_t ncols, unsigned nsplit, bool arr, bool ext) {
     if (arr) {
+        constexpr int B = general_block(true, FUSE);
+        dim3 grid((unsigned)((ncols + B - 1) / B), nsplit), block(B);
         if (FUSE && ext) hipLaunchKernelGGL((spectral_conv_kernel<R, true, FUSE, FUSE, SYM>), grid, block, 0, st, A);
         else hipLaunchKernelGGL((spectral_conv_kernel<R, true, FUSE, false, SYM>), grid, block, 0, st, A);
     } else {
+        constexpr int B = general_block(false, FUSE);
+        dim3 grid((unsigned)((ncols + B - 1) / B), nsplit), block(B);
         if (FUSE && ext) hipLaunchKernelGGL((spectral_conv_kernel<R, false, FUSE, FUSE, SYM>), grid, block, 0, st, A);
         else hipLaunchKernelGGL((spectral_conv_kernel<R, false, FUSE, false, SYM>), grid, block, 0, st, A);
     }
@@ -470,9 +496,8 @@ int launch(const ConvArgs& A, hipStream_t st, int fast, bool fuse) {
     }
     const int64_t ncols = A.ny * A.nx;
     const int64_t nsplit = (A.nz + A.zchunk - 1) / A.zchunk;
-    dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)nsplit);
-    if (fuse) return sym ? launch_rs<R, true, true>(A, st, grid, arr, ext) : launch_rs<R, true, false>(A, st, grid, arr, ext);
-    return sym ? launch_rs<R, false, true>(A, st, grid, arr, ext) : launch_rs<R, false, false>(A, st, grid, arr, ext);
+    if (fuse) return sym ? launch_rs<R, true, true>(A, st, ncols, (unsigned)nsplit, arr, ext) : launch_rs<R, true, false>(A, st, ncols, (unsigned)nsplit, arr, ext);
+    return sym ? launch_rs<R, false, true>(A, st, ncols, (unsigned)nsplit, arr, ext) : launch_rs<R, false, false>(A, st, ncols, (unsigned)nsplit, arr, ext);
 }
 
 }  // namespace spc_sconv

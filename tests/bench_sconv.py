@@ -28,6 +28,12 @@ maskc = DeviceArray(shape, np.uint8)
 mp = (rng.random((ny, nx)) > 0.3).astype(np.uint8)
 for z in range(nz):
     _lib.call("spc_memcpy_h2d", 0, C.c_void_p(maskc.ptr + z * mp.nbytes), np.roll(mp, z).ctypes.data_as(C.c_void_p), mp.nbytes, None)
+# sparse NaNs (what blanked pixels of real cubes look like to the general kernel): density 1e-4 per voxel
+nanc = DeviceArray(shape, np.float32)
+npl = plane.copy()
+npl[rng.random((ny, nx)) < 1e-4] = np.nan
+for z in range(nz):
+    _lib.call("spc_memcpy_h2d", 0, C.c_void_p(nanc.ptr + z * plane.nbytes), (np.roll(npl, 37 * z) + np.float32(z % 7)).ctypes.data_as(C.c_void_p), plane.nbytes, None)
 vox = nz * ny * nx
 out = DeviceArray(shape, np.float32)
 cen_h = (np.arange(nz) - nz // 2) * 500.0
@@ -47,6 +53,7 @@ for taps, sig in ((33, 4.0), (17, 2.0), (9, 1.0)):
         report("sconv %d taps all-valid %s" % (taps, env), timeit(lambda: ops.spectral_conv(cube, g, out=out)), 8)
     for k in ("SPC_CONV_VEC", "SPC_CONV_FAST"): os.environ.pop(k, None)
     report("sconv %d taps u8 mask (general)" % taps, timeit(lambda: ops.spectral_conv(cube, g, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskc), out=out)), 9)
+    report("sconv %d taps NaNs at 1e-4 (fast pass + general)" % taps, timeit(lambda: ops.spectral_conv(nanc, g, out=out)), 8)
     report("sconv %d taps fused moments (algebraic)" % taps, timeit(lambda: ops.spectral_conv_moments(cube, g, cen, cen_host=cen_h, want=("m0", "m1", "m2"))), 4)
     os.environ["SPC_FUSE_ALGEBRAIC"] = "0"
     report("sconv %d taps fused moments (stencil)" % taps, timeit(lambda: ops.spectral_conv_moments(cube, g, cen, cen_host=cen_h, want=("m0", "m1", "m2"))), 4)
