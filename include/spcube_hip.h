@@ -270,6 +270,19 @@ int spc_percentile_global_f32(int device, void* stream, const spc_cube_f32* cube
                               double q, int has_center, float center, double* h_out,
                               void* d_workspace, size_t workspace_bytes);
 
+/* ONE pass of that selection, for a cube that is sharded over ranks (each rank calls this on its strip, the ranks add
+ * their counters - or take the minimum of their next keys - and walk them together; the reference's counterpart is
+ * the dask reduction tree under dask_spectral_cube.py:657-693).  Samples are compared through their order-preserving
+ * 32-bit keys (of |x - center| with has_center); spc_key_to_f32 maps a key back to its float.
+ *   h_hist != NULL (HOST, 256 counters): h_hist[d] = included samples whose key agrees with `prefix` on the bits of
+ *       `pmask` and carries byte d at bit `shift` (24, 16, 8 or 0);
+ *   h_next != NULL (HOST): the smallest key above `prefix`, 0xffffffff when there is none.
+ * Exactly one of the two must be given.  Workspace: SPC_WS_PERCENTILE_GLOBAL. */
+int spc_key_histogram_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                          uint32_t prefix, uint32_t pmask, int shift, int has_center, float center,
+                          uint64_t* h_hist, uint32_t* h_next, void* d_workspace, size_t workspace_bytes);
+float spc_key_to_f32(uint32_t key);
+
 /* out[z][x][y] = included ? data[z][y][x] : fill, d_out a C-contiguous (nz, nx, ny) buffer: the
  * filled copy with the spatial axes exchanged, which turns an order statistic along x
  * (median(axis=2)) into one along y for spc_percentile_axis0_f32's exchanged-stride form. */

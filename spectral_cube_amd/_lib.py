@@ -91,6 +91,9 @@ SIGNATURES = {
     "spc_argextrema_axis_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _vp]),
     "spc_fill_masked_transpose_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp]),
     "spc_percentile_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), C.c_double, _i, _f, _P(C.c_double), _vp, _sz]),
+    "spc_key_histogram_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), C.c_uint32, C.c_uint32, _i, _i, _f,
+                                    _P(C.c_uint64), _P(C.c_uint32), _vp, _sz]),
+    "spc_key_to_f32": (_f, [C.c_uint32]),
     "spc_clip_bounds_f32": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
     "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _i64, _i64, _vp, _vp]),
     "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _vp, _sz]),

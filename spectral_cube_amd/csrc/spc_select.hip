@@ -637,4 +637,68 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     return SPC_OK;
 }
 
+// One pass of the whole-cube selection as its own entry point, for cubes that are sharded over ranks: the ranks sum
+// their 256 counters (or take the minimum of their next keys) before the walk, see distributed.sharded_percentile.
+//   h_hist != NULL: h_hist[d] = number of included samples whose key agrees with `prefix` on the bits of `pmask` and
+//                   has byte value d at bit `shift` (24, 16, 8, 0);
+//   h_next != NULL: *h_next = the smallest key above `prefix` (0xffffffff when there is none).
+// Keys are the order-preserving integers of the samples (of |x - center| with has_center); spc_key_to_f32 maps back.
+extern "C" int spc_key_histogram_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                     uint32_t prefix, uint32_t pmask, int shift, int has_center, float center,
+                                     uint64_t* h_hist, uint32_t* h_next, void* d_workspace, size_t workspace_bytes) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE((h_hist != nullptr) != (h_next != nullptr), "exactly one of h_hist / h_next must be given");
+    SPC_REQUIRE(h_next || shift == 24 || shift == 16 || shift == 8 || shift == 0, "shift must be 24, 16, 8 or 0");
+    GSelArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.has_center = has_center; A.center = center;
+    A.prefix = prefix; A.pmask = pmask; A.shift = shift;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    const bool contig = (A.row_stride == A.nx) && (A.plane_stride == A.ny * A.nx) &&
+                        (!arr || (A.mask.row_stride == A.nx && A.mask.plane_stride == A.ny * A.nx));
+    if (contig) { A.nrows = 1; A.rowlen = A.nz * A.ny * A.nx; A.row_a = 0; A.row_b = 0; }
+    else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
+    const int64_t per_block = 256 * 4 * 8;
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (A.rowlen + per_block - 1) / per_block));
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_hist, ws, unsigned long long, 257);
+    A.hist = d_hist;
+    A.next = reinterpret_cast<uint32_t*>(d_hist + 256);
+    hipError_t e;
+    if (h_hist) {
+        e = hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 256, st);
+        if (e == hipSuccess) {
+            if (arr) hipLaunchKernelGGL((gselect_kernel<true, 0>), dim3(nblocks), dim3(256), 0, st, A);
+            else hipLaunchKernelGGL((gselect_kernel<false, 0>), dim3(nblocks), dim3(256), 0, st, A);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_hist, d_hist, sizeof(unsigned long long) * 256, hipMemcpyDeviceToHost, st);
+    } else {
+        e = hipMemsetAsync(A.next, 0xff, sizeof(uint32_t), st);
+        if (e == hipSuccess) {
+            if (arr) hipLaunchKernelGGL((gselect_kernel<true, 1>), dim3(nblocks), dim3(256), 0, st, A);
+            else hipLaunchKernelGGL((gselect_kernel<false, 1>), dim3(nblocks), dim3(256), 0, st, A);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_next, A.next, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    SPC_HIP(e);
+    return SPC_OK;
+}
+
+extern "C" float spc_key_to_f32(uint32_t key) {
+    const uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 size_t spc_ws_percentile_global(void) { return spc_ws_round(sizeof(unsigned long long) * 257) + 256; }

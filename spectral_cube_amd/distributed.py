@@ -275,6 +275,69 @@ def sharded_statistics(strip_stats, transport):
     return combine_statistics(transport.allgather_object(rec))
 
 
+def walk_key_histograms(q, count_pass, next_pass):
+    """The host side of a whole-cube order statistic (numpy 'linear' percentile) over 32-bit order-preserving keys:
+    four byte passes pin the key of rank floor(pos) down, a fifth gives the next larger key when the two order
+    statistics differ.  *count_pass(prefix, pmask, shift)* returns the 256 counters of one pass summed over ALL
+    ranks, *next_pass(prefix)* the smallest key above prefix over all ranks.  Returns (key_lo, key_hi, frac) or None
+    when no sample is included.  (The same walk as spc_percentile_global_f32 does for one GPU.)"""
+    prefix = pmask = 0
+    n = below = eq = 0
+    k = khi = 0
+    frac = 0.0
+    for p in range(4):
+        shift = 24 - 8 * p
+        h = [int(v) for v in count_pass(prefix, pmask, shift)]
+        if p == 0:
+            n = sum(h)
+            if n == 0:
+                return None
+            pos = q / 100.0 * (n - 1)
+            k = int(np.floor(pos))
+            khi = min(int(np.ceil(pos)), n - 1)
+            frac = pos - np.floor(pos)
+        d = 0
+        while d < 255 and k >= h[d]:
+            k -= h[d]
+            below += h[d]
+            d += 1
+        eq = h[d]
+        prefix |= d << shift
+        pmask |= 0xff << shift
+    key_hi = prefix
+    if khi >= below + eq:
+        key_hi = int(next_pass(prefix))
+    return prefix, key_hi, float(frac)
+
+
+def sharded_percentile(strip, q, transport, mask=None, center=None, passes=None):
+    """median / percentile / (with *center*) the MAD of a cube whose row strips live on different ranks
+    (np.nanpercentile(cube, q) over everything; dask_spectral_cube.py:657-693 with the chunks on GPUs): every rank
+    histograms ITS strip (ops.key_histogram, one streaming pass per key byte), the 256 counters of all ranks are added
+    through the rendezvous transport (2 KB per rank and pass) and every rank walks the same totals.  *strip* is this
+    rank's DeviceArray (nz, rows, nx) - rows may be 0.  Returns the same python float on every rank.
+    *passes* = (key_histogram, key_next, key_to_float) replaces the device passes (the CPU tests of the exchange)."""
+    from . import ops
+    hist_fn, next_fn, unkey = passes or (ops.key_histogram, ops.key_next, ops.key_to_float)
+    empty = strip.shape[0] == 0 or strip.shape[1] == 0 or strip.shape[2] == 0
+
+    def count_pass(prefix, pmask, shift):
+        mine = np.zeros(256, np.uint64) if empty else hist_fn(strip, prefix, pmask, shift, mask=mask, center=center)
+        parts = transport.allgather_bytes(mine.tobytes())
+        return np.sum([np.frombuffer(b, np.uint64) for b in parts], axis=0, dtype=np.uint64)
+
+    def next_pass(prefix):
+        mine = 0xffffffff if empty else next_fn(strip, prefix, mask=mask, center=center)
+        return min(int.from_bytes(b, "little") for b in transport.allgather_bytes(int(mine).to_bytes(4, "little")))
+
+    r = walk_key_histograms(float(q), count_pass, next_pass)
+    if r is None:
+        return float("nan")
+    a, b, frac = unkey(r[0]), unkey(r[1]), r[2]
+    with np.errstate(invalid="ignore"):
+        return float(0.5 * (a + b) if frac == 0.5 else a + (b - a) * frac)
+
+
 def sharded_smooth_moment0(strip_cube, kernel, ny_total, comm):
     """config C4 (spatial_smooth -> moment0) on row strips WITHOUT halo exchange: when every voxel
     is valid, smoothing commutes with the sum along the spectral axis, so each rank reduces its

@@ -512,6 +512,34 @@ def percentile_global(cube, q, mask=None, center=None, stream=None):
     return out.value
 
 
+def key_histogram(cube, prefix, pmask, shift, mask=None, center=None, stream=None):
+    """One pass of the whole-cube selection on THIS rank's part of a cube (spc_key_histogram_f32): the 256 counters
+    of the key byte at bit *shift* among the included samples whose key agrees with *prefix* on *pmask*.
+    Returns a uint64 ndarray of 256."""
+    h = np.zeros(256, np.uint64)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_PERCENTILE_GLOBAL, *cube.shape)
+    _lib.call("spc_key_histogram_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(prefix), int(pmask), int(shift),
+              0 if center is None else 1, 0.0 if center is None else float(center),
+              h.ctypes.data_as(C.POINTER(C.c_uint64)), None, ws, wsn)
+    return h
+
+
+def key_next(cube, prefix, mask=None, center=None, stream=None):
+    """smallest sample key above *prefix* on this rank's part (0xffffffff when there is none)."""
+    nxt = C.c_uint32(0)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_PERCENTILE_GLOBAL, *cube.shape)
+    _lib.call("spc_key_histogram_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(prefix), 0xffffffff, 0,
+              0 if center is None else 1, 0.0 if center is None else float(center), None, C.byref(nxt), ws, wsn)
+    return nxt.value
+
+
+def key_to_float(key):
+    """the float32 sample an order-preserving key stands for (spc_key_to_f32)."""
+    return float(_lib.load().spc_key_to_f32(C.c_uint32(int(key))))
+
+
 def fill_masked_transposed(cube, mask=None, fill=np.nan, stream=None):
     """(nz, nx, ny) device copy: excluded voxels replaced by *fill*, spatial axes exchanged
     (spc_fill_masked_transpose_f32) - rays along x become rays along y."""

@@ -19,7 +19,7 @@ import numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
 import oracle_np as O
 from spectral_cube_amd import synth
-from spectral_cube_amd.distributed import HostGatherComm, strip_bounds, sharded_statistics
+from spectral_cube_amd.distributed import HostGatherComm, strip_bounds, sharded_statistics, sharded_percentile
 from spectral_cube_amd.rendezvous import FileRendezvous
 
 kind = sys.argv[2]
@@ -68,6 +68,34 @@ for o in range(3):
     assert np.array_equal(np.isnan(full[o]), np.isnan(exp))
     assert np.array_equal(full[o][~np.isnan(exp)], exp[~np.isnan(exp)])
 assert np.array_equal(ids, O.argmax(d, inc))
+# whole-cube order statistics of the sharded cube: the per-rank passes restated in numpy (the device passes are
+# spc_key_histogram_f32), the exchange + walk are the product code
+def _keys(a, inc_, center):
+    v = a[inc_ & np.isfinite(a) | (inc_ & np.isinf(a))].astype(np.float32)
+    if center is not None:
+        v = np.abs(v - np.float32(center))
+    u = v.view(np.uint32)
+    return np.where(u & 0x80000000, ~u, u | np.uint32(0x80000000)).astype(np.uint32)
+def _hist(strip, prefix, pmask, shift, mask=None, center=None):
+    k = _keys(strip, mask, center)
+    k = k[(k & np.uint32(pmask)) == np.uint32(prefix)]
+    return np.bincount((k >> np.uint32(shift)) & 0xff, minlength=256).astype(np.uint64)
+def _next(strip, prefix, mask=None, center=None):
+    k = _keys(strip, mask, center)
+    k = k[k > np.uint32(prefix)]
+    return int(k.min()) if k.size else 0xffffffff
+def _unkey(key):
+    u = np.uint32(key)
+    return float(np.array([u & 0x7fffffff if u & 0x80000000 else ~u], np.uint32).view(np.float32)[0])
+fz = np.where(inc, d, np.nan).astype(np.float32)
+for q in (0.0, 12.5, 50.0, 99.0, 100.0):
+    got = sharded_percentile(d[:, y0:y1], q, tr, mask=inc[:, y0:y1], passes=(_hist, _next, _unkey))
+    exp = float(np.nanpercentile(fz.astype(np.float64), q))
+    assert abs(got - exp) <= 2e-7 * max(1.0, abs(exp)), (q, got, exp)
+med = float(np.nanmedian(fz))
+mad = sharded_percentile(d[:, y0:y1], 50.0, tr, mask=inc[:, y0:y1], center=med, passes=(_hist, _next, _unkey))
+assert mad == float(np.nanmedian(np.abs(fz - np.float32(med))))
+assert np.isnan(sharded_percentile(d[:, y0:y1], 50.0, tr, mask=np.zeros_like(inc[:, y0:y1]), passes=(_hist, _next, _unkey)))
 for i in range(20):                    # many small collectives back to back (file retirement)
     got = tr.allgather_object((rank, i))
     assert got == [(r, i) for r in range(ws)]

@@ -132,3 +132,80 @@ def test_reproject_source_rows_margins(gpu):
     assert D.reproject_source_rows(w, (4, 60, 50), far, 0, 2) == (0, 0)
     out, foot, _ = D.sharded_reproject(DeviceArray((4, 0, 50), np.float32), 0, w, (4, 60, 50), far, 0, 2)
     assert np.isnan(out.get()).all() and not foot.get().any()
+
+
+class ThreadTransport:
+    """the rendezvous protocol between threads of this process (every rank is a thread driving the same GPU)"""
+
+    def __init__(self, world_size):
+        import threading
+        self.world_size = world_size
+        self._slots = {}
+        self._cv = threading.Condition()
+
+    def view(self, rank):
+        outer = self
+
+        class _View:
+            world_size = outer.world_size
+
+            def __init__(self):
+                self.rank, self._seq = rank, 0
+
+            def allgather_bytes(self, payload):
+                seq, self._seq = self._seq, self._seq + 1
+                with outer._cv:
+                    outer._slots.setdefault(seq, {})[self.rank] = bytes(payload)
+                    outer._cv.notify_all()
+                    assert outer._cv.wait_for(lambda: len(outer._slots[seq]) == outer.world_size, timeout=60)
+                    return [outer._slots[seq][r] for r in range(outer.world_size)]
+        return _View()
+
+
+@pytest.mark.parametrize("ws", [1, 2, 3])
+def test_sharded_percentile_whole_cube(gpu, ws):
+    """median / percentile / MAD of a cube whose row strips belong to different ranks: every rank histograms its
+    strip on the device (spc_key_histogram_f32), the counters are added through the transport, all ranks return
+    the value np.nanpercentile gives for the whole cube (median and MAD bit-exact)."""
+    import threading
+    import warnings
+    from spectral_cube_amd import ops, _lib
+    rng = np.random.default_rng(5)
+    shape = (33, 41, 57)
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[rng.random(shape) < 0.02] = np.nan
+    d[3, 4, 5], d[6, 7, 8] = np.inf, -np.inf
+    inc = rng.random(shape) < 0.7
+    fz = np.where(inc, d, np.nan).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = {q: float(np.nanpercentile(fz.astype(np.float64), q)) for q in (0.0, 30.0, 50.0, 100.0)}
+        med = float(np.nanmedian(fz))
+        emad = float(np.nanmedian(np.abs(fz - np.float32(med))))
+    tt = ThreadTransport(ws)
+    results, errors = [None] * ws, []
+
+    def rank_main(r):
+        try:
+            tr = tt.view(r)
+            y0, y1 = D.strip_bounds(shape[1], ws, r)
+            strip = DeviceArray.from_numpy(np.ascontiguousarray(d[:, y0:y1]))
+            spec = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(np.ascontiguousarray(inc[:, y0:y1]).astype(np.uint8)))
+            out = {q: D.sharded_percentile(strip, q, tr, mask=spec) for q in exp}
+            out["mad"] = D.sharded_percentile(strip, 50.0, tr, mask=spec, center=out[50.0])
+            results[r] = out
+        except Exception as e:            # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(ws)]
+    for t in threads: t.start()
+    for t in threads: t.join(120)
+    assert not errors, errors
+    for r in range(ws):
+        np.testing.assert_equal(results[r], results[0])          # (NaN == NaN: the lerp between two infinities)
+    assert results[0][50.0] == med and results[0]["mad"] == emad
+    for q, e in exp.items():
+        np.testing.assert_allclose(results[0][q], e, rtol=2e-7, atol=0)
+    # against the one-GPU entry point
+    whole = DeviceArray.from_numpy(d)
+    wspec = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
+    assert ops.percentile_global(whole, 30.0, mask=wspec) == results[0][30.0]
