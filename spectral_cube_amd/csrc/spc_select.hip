@@ -261,82 +261,93 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
 }
 
 
-// N samples of one lane (256 words apart in the tile), counted into sixteen 4-bit fields by the digit at bit b
-// among those that agree with `prefix` above it (N <= 15: a field cannot overflow).  All loads are issued first.
-template <int N>
-__device__ __forceinline__ unsigned long long count_digits(const uint32_t* keys, uint32_t prefix, int b) {
-    uint32_t key[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) key[u] = keys[u * 256];
+// ---- rays resident in REGISTERS: ONE read of the cube (round 2) ------------------------------------------
+// The descents above stream the cube once per digit (8 or 17 reads): 18.7 ms for a median at 1024^3, 3.6 % of the
+// roofline of a single read.  Here a block owns TS adjacent spaxels (TS x 4 bytes contiguous per plane: 32- to
+// 128-byte segments) and reads their rays ONCE: 256 / TS lanes share a ray, a lane turns its KPL = ceil(nz / lanes)
+// <= 64 samples (z = j + lanes * i) into order-preserving keys (excluded / NaN samples become the largest key,
+// which no valid float maps to) and keeps them in registers.  A digit pass of the radix-16 descent is then 7 VALU
+// instructions per key: sixteen 4-bit counters in ONE 64-bit register (the digit picks the field: one shift, one
+// add, no dynamic indexing, no atomics), emptied into 8-bit counters every 15 keys; the per-ray totals meet in a
+// 16-counter LDS histogram (three rotating buffers: one barrier per digit) and every lane of the ray walks the
+// sixteen totals to the digit.  LDS only carries the histograms (a few KB): the ~105 VGPRs set the occupancy
+// (4 waves per SIMD).  The descent stops early: once four digits (16 bits) are known, the samples that still match
+// are few (their number is the count of the selected bin); if no ray of the block has more than kCandMax of them,
+// they are gathered into LDS and ranked directly (each lane of the ray ranks its share against all candidates)
+// instead of four more passes over all keys.  Rays with many equal or near-equal samples (quantised data) take all
+// eight passes.  The upper order statistic of an interpolated percentile is either the same value (ties) or the
+// smallest key above the first: one more sweep over the registers.
+// (A first version kept the keys in LDS - 64 KB per block, 2 waves per SIMD, an LDS read per key and pass: 6.25 ms
+// where this one takes 2.5 - 3.2 ms.)
+constexpr int kCandMax = 32;
+
+template <int KPL, bool FIRST>
+__device__ __forceinline__ void count_keys(const uint32_t (&key)[KPL], uint32_t prefix, int b,
+                                           unsigned long long& accE, unsigned long long& accO) {
+    constexpr unsigned long long kNib = 0x0f0f0f0f0f0f0f0full;
     unsigned long long a = 0ull;
-    if (b == 28) {                                               // no prefix yet
 #pragma unroll
-        for (int u = 0; u < N; ++u) a += 1ull << ((key[u] >> 28) * 4u);
-    } else {
-#pragma unroll
-        for (int u = 0; u < N; ++u) {
-            const uint32_t x = key[u] ^ prefix;                  // the digits above b vanish for a sample inside the prefix
-            const unsigned long long one = ((x >> (b + 4)) == 0u) ? 1ull : 0ull;
-            a += one << (((x >> b) & 15u) * 4u);
+    for (int i = 0; i < KPL; ++i) {
+        if (FIRST) {
+            a += 1ull << ((key[i] >> 28) * 4u);
+        } else {
+            const uint32_t tt = (key[i] ^ prefix) >> b;          // < 16 exactly for the samples inside the prefix
+            const unsigned long long one = (tt < 16u) ? 1ull : 0ull;
+            a += one << ((tt * 4u) & 63u);
+        }
+        if (i % 15 == 14 || i == KPL - 1) {                      // a 4-bit field holds 15
+            accE += a & kNib;
+            accO += (a >> 4) & kNib;
+            a = 0ull;
+            __builtin_amdgcn_sched_barrier(0);                   // (keeps the scheduler from expanding all keys at once)
         }
     }
-    return a;
 }
 
-// ---- rays resident in LDS: ONE read of the cube (round 2) ----------------------------------------------
-// The descents above stream the cube once per digit (8 or 17 reads): 18.7 ms for a median at 1024^3, 3.6 % of
-// the roofline of a single read.  Here a block owns TS adjacent spaxels (TS x 4 bytes contiguous per plane: 64-
-// or 128-byte segments), reads their rays ONCE, turns every sample into its order-preserving key (excluded / NaN
-// samples become the largest key, which no valid float maps to) and keeps the TS x nz keys in LDS (<= 64 KB: two
-// blocks per CU).  The radix-16 descent then runs over LDS: 256 / TS lanes share a ray, each counts its slice of
-// the ray into sixteen 8-bit fields of two 64-bit registers (no atomics, no dynamic indexing), the per-ray totals
-// meet in a small LDS histogram (three rotating buffers: one barrier per digit), every lane of the ray walks the
-// sixteen totals to the digit.  The second order statistic of an interpolated percentile is either the same
-// value (ties) or the smallest key above the first: one more sweep over LDS.
-template <int TS, bool ARR>
-__global__ __launch_bounds__(256) void select_tile_kernel(const SelArgs A) {
-    extern __shared__ uint32_t tile_keys[];                    // [nzp][TS], nzp = nz rounded up to the lanes of a ray
+template <int TS, int KPL, bool ARR>
+__global__ __launch_bounds__(256) void select_reg_kernel(const SelArgs A) {
     __shared__ uint32_t hist[3][TS][16];
-    __shared__ uint32_t nvalid[TS], nextkey[TS];
+    __shared__ uint32_t nvalid[TS], nextkey[TS], ncand[TS], sel_key[TS], sel_below[TS], sel_eq[TS];
+    __shared__ uint32_t cand[TS][kCandMax];
     constexpr int kLanesPerRay = 256 / TS;
     const int t = threadIdx.x;
     const int r = t % TS, j = t / TS;                           // ray of the tile, slice of the ray
     const int64_t tiles_x = (A.nx + TS - 1) / TS;
     const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
     const int nz = (int)A.nz;
-    const int iters = (nz + kLanesPerRay - 1) / kLanesPerRay;   // samples per lane (<= 64), the same for every lane:
-    const bool col_in = x0 + r < A.nx;                          // the tail of the last round holds the largest key
+    const bool col_in = x0 + r < A.nx;
     const int64_t xc = col_in ? x0 + r : A.nx - 1;
     const float* p = A.cube + y * A.row_stride + xc;
     const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc : nullptr;
     const bool use_cen = A.center != nullptr;
     const float cen = (use_cen && col_in) ? A.center[y * A.nx + x0 + r] : 0.f;
-    if (t < TS) { nvalid[t] = 0u; nextkey[t] = 0xffffffffu; }
+    if (t < TS) { nvalid[t] = 0u; nextkey[t] = 0xffffffffu; ncand[t] = 0u; }
     for (int i = t; i < 3 * TS * 16; i += 256) (&hist[0][0][0])[i] = 0u;
     __syncthreads();
-    // ---- the one read of the cube: keys into LDS
+    // ---- the one read of the cube: keys into registers (excluded / NaN / beyond nz: the largest key)
+    uint32_t key[KPL];
     int mine = 0;
-    constexpr int U = 4;
-    for (int z0 = j; z0 < iters * kLanesPerRay; z0 += kLanesPerRay * U) {
+    constexpr int U = KPL < 8 ? KPL : 8;
+#pragma unroll
+    for (int i0 = 0; i0 < KPL; i0 += U) {
         float raw[U];
         unsigned mk[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int z = min(z0 + u * kLanesPerRay, nz - 1);
+            const int z = min(j + kLanesPerRay * (i0 + u), nz - 1);
             raw[u] = __builtin_nontemporal_load(p + (int64_t)z * A.plane_stride);
             mk[u] = ARR ? pm[(int64_t)z * A.mask.plane_stride] : 1u;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int z = z0 + u * kLanesPerRay;
-            if (z < iters * kLanesPerRay) {
-                bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
-                const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
-                ok = ok && (v == v);
-                tile_keys[z * TS + r] = ok ? fkey(v) : 0xffffffffu;
-                mine += ok ? 1 : 0;
-            }
+            const int z = j + kLanesPerRay * (i0 + u);
+            bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
+            const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
+            ok = ok && (v == v);
+            key[i0 + u] = ok ? fkey(v) : 0xffffffffu;
+            mine += ok ? 1 : 0;
         }
+        __builtin_amdgcn_sched_barrier(0);                       // U loads in flight, not KPL
     }
     if (mine) atomicAdd(&nvalid[r], (uint32_t)mine);
     __syncthreads();
@@ -349,27 +360,17 @@ __global__ __launch_bounds__(256) void select_tile_kernel(const SelArgs A) {
     int below = 0;                                               // keys smaller than everything matching the prefix
     uint32_t prefix = 0u;
     int eq = 0;
-    const uint32_t* mykeys = tile_keys + j * TS + r;             // sample i of this lane: mykeys[i * 256]
-    constexpr unsigned long long kNib = 0x0f0f0f0f0f0f0f0full;
+    bool done = false;                                           // block-uniform
 #pragma unroll 1
-    for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < 8 && !done; ++pass) {
         const int b = 28 - 4 * pass;
-        // sixteen 4-bit counters in one 64-bit register (one shift + one add per sample), emptied every 15 samples into
-        // 8-bit counters: even digits in accE, odd digits in accO
-        unsigned long long accE = 0ull, accO = 0ull;
-        int i = 0;
-        for (; i + 15 <= iters; i += 15) {
-            const unsigned long long a = count_digits<15>(mykeys + i * 256, prefix, b);
-            accE += a & kNib;
-            accO += (a >> 4) & kNib;
-        }
-        {
-            unsigned long long a = 0ull;                         // < 15 samples left
-            for (; i + 4 <= iters; i += 4) a += count_digits<4>(mykeys + i * 256, prefix, b);
-            for (; i < iters; ++i) a += count_digits<1>(mykeys + i * 256, prefix, b);
-            accE += a & kNib;
-            accO += (a >> 4) & kNib;
-        }
+        unsigned long long accE = 0ull, accO = 0ull;             // even / odd digits, 8 bits each (<= 64 keys per lane)
+        // (the first pass has no prefix; `pass` is made opaque so that its digit extraction - which does not depend on
+        // anything the loop changes - is not hoisted out of the loop and kept in 64 more registers)
+        int popaque = pass;
+        asm volatile("" : "+s"(popaque));
+        if (popaque == 0) count_keys<KPL, true>(key, prefix, b, accE, accO);
+        else count_keys<KPL, false>(key, prefix, b, accE, accO);
         uint32_t* h = hist[pass % 3][r];
         uint32_t* hz = hist[(pass + 1) % 3][r];
 #pragma unroll
@@ -394,20 +395,52 @@ __global__ __launch_bounds__(256) void select_tile_kernel(const SelArgs A) {
             }
         }
         prefix |= dsel << b;
+        if (pass == 3) {
+            // 16 bits known: few samples are left in the bin.  All rays of the block small enough -> rank them directly
+            const bool big = (n > 0) && (eq > kCandMax);
+            if (!__syncthreads_or(big ? 1 : 0)) {
+                if (n > 0) {
+#pragma unroll
+                    for (int i = 0; i < KPL; ++i) {
+                        if (((key[i] ^ prefix) >> 16) == 0u) {
+                            const uint32_t slot = atomicAdd(&ncand[r], 1u);
+                            cand[r][slot] = key[i];
+                        }
+                    }
+                }
+                __syncthreads();
+                if (n > 0) {
+                    for (int idx = j; idx < eq; idx += kLanesPerRay) {
+                        const uint32_t c = cand[r][idx];
+                        int less = 0, same_before = 0, same = 0;
+                        for (int m = 0; m < eq; ++m) {
+                            const uint32_t o = cand[r][m];
+                            less += (o < c) ? 1 : 0;
+                            same += (o == c) ? 1 : 0;
+                            same_before += (o == c && m < idx) ? 1 : 0;
+                        }
+                        if (less + same_before == k) { sel_key[r] = c; sel_below[r] = (uint32_t)(below + less); sel_eq[r] = (uint32_t)same; }
+                    }
+                }
+                __syncthreads();
+                if (n > 0) { prefix = sel_key[r]; below = (int)sel_below[r]; eq = (int)sel_eq[r]; }
+                done = true;
+            }
+        }
     }
     // prefix = the key of rank floor(pos); `eq` samples carry it, `below` are smaller
     uint32_t key_hi = prefix;
     const bool need_next = (n > 0) && (khi >= below + eq);       // ray-uniform
-    if (need_next) {
-        uint32_t mn = 0xffffffffu;
-        for (int i = 0; i < iters; ++i) {
-            const uint32_t key = mykeys[i * 256];
-            if (key > prefix) mn = min(mn, key);
+    if (__syncthreads_or(need_next ? 1 : 0)) {
+        if (need_next) {
+            uint32_t mn = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) mn = (key[i] > prefix) ? min(mn, key[i]) : mn;
+            atomicMin(&nextkey[r], mn);
         }
-        atomicMin(&nextkey[r], mn);
+        __syncthreads();
+        if (need_next) key_hi = nextkey[r];
     }
-    __syncthreads();
-    if (need_next) key_hi = nextkey[r];
     if (j == 0 && col_in) {
         float res = NAN;
         if (n > 0) {
@@ -513,30 +546,28 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
                     ((((uintptr_t)cube->d_data) & 15) == 0) &&
                     (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
     hipStream_t st = (hipStream_t)stream;
-    // rays resident in LDS (one read of the cube) when TS x nz keys fit 64 KB: nz <= 512 / 1024 / 2048 for 32 / 16 / 8
-    // spaxels per block; any strides (a y-ray view included)
-    const char* tenv = getenv("SPC_SELECT_TILE");
-    if ((tenv ? atoi(tenv) != 0 : true) && cube->nz <= 2048 && cube->ny * ((cube->nx + 7) / 8) < (1LL << 31)) {
+    // rays in registers (one read of the cube): up to 64 keys per lane, nz <= 512 / 1024 / 2048 for 32 / 16 / 8 spaxels
+    // per block; any strides (a y-ray view included)
+    const char* renv = getenv("SPC_SELECT_REG");
+    if ((renv ? atoi(renv) != 0 : true) && cube->nz <= 2048 && cube->ny * ((cube->nx + 7) / 8) < (1LL << 31)) {
         const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
         const int lanes = 256 / ts;
-        const size_t lds = (size_t)ts * (size_t)((cube->nz + lanes - 1) / lanes * lanes) * sizeof(uint32_t);
+        const int need = (int)((cube->nz + lanes - 1) / lanes);
+        const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
         const int64_t nblk = cube->ny * ((cube->nx + ts - 1) / ts);
         dim3 grid((unsigned)nblk);
-#define SPC_LAUNCH_TILE(TS_)                                                                                          \
-        do {                                                                                                          \
-            if (arr) hipLaunchKernelGGL((select_tile_kernel<TS_, true>), grid, dim3(256), lds, st, A);                \
-            else hipLaunchKernelGGL((select_tile_kernel<TS_, false>), grid, dim3(256), lds, st, A);                   \
+#define SPC_LAUNCH_REG(TS_, K_)                                                                                     \
+        do {                                                                                                        \
+            if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true>), grid, dim3(256), 0, st, A);             \
+            else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false>), grid, dim3(256), 0, st, A);                \
         } while (0)
-        if (lds > 48 * 1024) {      // dynamic LDS beyond the default limit has to be requested
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&select_tile_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-        }
-        if (ts == 32) SPC_LAUNCH_TILE(32); else if (ts == 16) SPC_LAUNCH_TILE(16); else SPC_LAUNCH_TILE(8);
-#undef SPC_LAUNCH_TILE
+#define SPC_LAUNCH_REG_K(TS_)                                                                                       \
+        do {                                                                                                        \
+            if (kpl == 16) SPC_LAUNCH_REG(TS_, 16); else if (kpl == 32) SPC_LAUNCH_REG(TS_, 32); else SPC_LAUNCH_REG(TS_, 64); \
+        } while (0)
+        if (ts == 32) SPC_LAUNCH_REG_K(32); else if (ts == 16) SPC_LAUNCH_REG_K(16); else SPC_LAUNCH_REG_K(8);
+#undef SPC_LAUNCH_REG_K
+#undef SPC_LAUNCH_REG
         SPC_LAUNCH_CHECK();
         return SPC_OK;
     }

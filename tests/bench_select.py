@@ -16,13 +16,18 @@ def timeit(fn, n=3):
     fn(); synchronize(); e0, e1 = Event(), Event(); e0.record()
     for _ in range(n): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_ms(e1) / n
-for env in ({"SPC_SELECT_TILE": "1"}, {"SPC_SELECT_TILE": "0"}):
+qcube = DeviceArray(shape, np.float32)                  # quantised data (heavy ties: the candidates never get few)
+_replicate_rows(qcube, np.round(tile * 4).astype(np.float32), 4)
+for env in ({}, {"SPC_SELECT_REG": "0"}):
+    for k in ("SPC_SELECT_REG",): os.environ.pop(k, None)
     os.environ.update(env)
-    print(env, "median u8 mask %.3f ms | no mask %.3f ms | p90 %.3f ms | median along y (swap01) %.3f ms" % (
+    print(env or "default (rays in registers)", "median u8 mask %.3f ms | no mask %.3f ms | p90 %.3f ms | median along y (swap01) %.3f ms | quantised, no mask %.3f ms" % (
         timeit(lambda: ops.percentile_axis0(cube, 50.0, mask=mspec)), timeit(lambda: ops.percentile_axis0(cube, 50.0)),
         timeit(lambda: ops.percentile_axis0(cube, 90.0, mask=mspec)),
-        timeit(lambda: ops.percentile_axis0(cube.swap01(), 50.0, mask=mspec.swap01()))), flush=True)
-os.environ["SPC_SELECT_TILE"] = "1"
+        timeit(lambda: ops.percentile_axis0(cube.swap01(), 50.0, mask=mspec.swap01())),
+        timeit(lambda: ops.percentile_axis0(qcube, 50.0))), flush=True)
+os.environ.pop("SPC_SELECT_REG", None)
 import time
 t0 = time.perf_counter(); out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec); synchronize(); print("sigma_clip wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 t0 = time.perf_counter(); out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec); synchronize(); print("sigma_clip wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+t0 = time.perf_counter(); out = ops.sigma_clip_axis0(cube, sigma=3.0); synchronize(); print("sigma_clip (no mask) wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))

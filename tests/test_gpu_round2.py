@@ -281,10 +281,11 @@ def test_chunk_functions_under_dask_map_blocks(gpu, tmp_path):
 
 @pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (515, 2, 37), (1030, 2, 21), (2050, 1, 12)])
 def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
-    """np.nanmedian / np.nanpercentile of masked rays through every selection kernel: the LDS-resident tiles
-    (32 / 16 / 8 spaxels per block by ray length, lengths that are no multiple of the lanes per ray, tiles
-    hanging over the row end), and - by switch - the streaming radix-16 and bisection descents that longer rays
-    fall back to.  Medians are bit-exact; MAD (centre per spaxel) goes through the same kernels."""
+    """np.nanmedian / np.nanpercentile of masked rays through every selection kernel: the register-resident rays
+    (32 / 16 / 8 spaxels per block by ray length, lengths that are no multiple of the lanes per ray, tiles hanging
+    over the row end; with the early ranking of the surviving candidates and - on the tie-heavy column - without),
+    and - by switch - the streaming radix-16 and bisection descents that longer rays fall back to.  Medians are
+    bit-exact; MAD (centre per spaxel) goes through the same kernels."""
     import warnings
     from spectral_cube_amd import ops, _lib
     from spectral_cube_amd.device import DeviceArray
@@ -303,8 +304,8 @@ def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
         e30 = np.nanpercentile(fz.astype(np.float64), 30.0, axis=0)
         emad = np.nanmedian(np.abs(fz - emed[None]), axis=0)
         emed_nomask = np.nanmedian(d, axis=0)
-    for env in ({}, {"SPC_SELECT_TILE": "0"}, {"SPC_SELECT_TILE": "0", "SPC_SELECT_RADIX16": "0"}):
-        for k in ("SPC_SELECT_TILE", "SPC_SELECT_RADIX16"):
+    for env in ({}, {"SPC_SELECT_REG": "0"}, {"SPC_SELECT_REG": "0", "SPC_SELECT_RADIX16": "0"}):
+        for k in ("SPC_SELECT_REG", "SPC_SELECT_RADIX16"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
