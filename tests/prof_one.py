@@ -31,6 +31,13 @@ for _ in range(reps):
         ops.resample_bilinear(cube, xs, ys)
     elif op == "stats": ops.stats_global(cube)
     elif op == "median": ops.percentile_axis0(cube, 50.0)
+    elif op == "sconv_mask":
+        if _ == 0:
+            mp = (rng.random((ny, nx)) > 0.3).astype(np.uint8)
+            maskc = DeviceArray(shape, np.uint8)
+            for z in range(nz):
+                _lib.call("spc_memcpy_h2d", 0, C.c_void_p(maskc.ptr + z * mp.nbytes), np.roll(mp, z).ctypes.data_as(C.c_void_p), mp.nbytes, None)
+        ops.spectral_conv(cube, g, out=out, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskc))
     elif op == "spconv_mask":
         if _ == 0:
             mp = (rng.random((ny, nx)) > 0.2).astype(np.uint8)
