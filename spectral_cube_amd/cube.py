@@ -486,15 +486,18 @@ class SpectralCube:
             return None
         nz = self._shape[0]
         higher = ("m1" in want) or ("m2" in want)
-        r = parent._moment_device(("s0", "nvalid") + (("mu", "m2") if higher else ()))
+        # moment 0 alone: the kernel scales by the channel width (m0 = dv * S0), the convolved map is the result
+        r = parent._moment_device((("s0", "mu", "m2") if higher else ("m0",)) + ("nvalid",))
         if int(r["nvalid"].get().min()) != nz:
             return None
-        c0 = ops.map_conv2d(r["s0"], lz.kernel).get()        # S0 never leaves the device
-        if not (np.all(np.isfinite(c0)) and np.all(c0 != 0.0)):   # a NaN / Inf / zero sum anywhere: not this path
+        c0 = ops.map_conv2d(r["s0" if higher else "m0"], lz.kernel).get()        # the sums never leave the device
+        # a NaN / Inf sum anywhere (one reduction: the total is non-finite iff a term is; cannot happen when the mask
+        # keeps finite samples only), or - where the moments divide by it - a zero: not this path
+        if (not (spec.flags & _lib.MASK_FINITE) and not np.isfinite(c0.sum())) or (higher and not np.all(c0 != 0.0)):
             return None
         out = {}
         if "m0" in want:
-            out["m0"] = self._pix_size_slice(0) * c0
+            out["m0"] = self._pix_size_slice(0) * c0 if higher else c0
         if higher:
             s0, mu, m2 = r["s0"].get(), r["mu"].get(), r["m2"].get()
             if not (np.all(s0 != 0.0) and np.all(np.isfinite(mu)) and np.all(np.isfinite(m2))):

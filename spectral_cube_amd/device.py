@@ -34,6 +34,62 @@ def _sh(stream):
     return stream.handle if isinstance(stream, Stream) else stream
 
 
+class _PinnedPool:
+    """Page-locked host buffers for results that come back from the device (DeviceArray.get()).  A device-to-host
+    copy into fresh pageable numpy memory runs at ~3 GB/s (page faults + the runtime's staging) - 10 ms for a
+    2048 x 2048 float64 moment map, more than the kernel that produced it; into pinned memory it runs at the link
+    rate.  get() therefore hands out numpy arrays that live IN pinned buffers; a buffer returns to this pool when the
+    last array viewing it is collected, and is unpinned once the pool holds more than *max_bytes* idle."""
+
+    MIN_BYTES = 1 << 20          # smaller results use plain numpy memory
+
+    def __init__(self, max_bytes=1 << 30):
+        import threading
+        self.max_bytes = max_bytes
+        self.idle = {}           # size class -> [ptr]
+        self.idle_bytes = 0
+        self.lock = threading.Lock()
+
+    @staticmethod
+    def size_class(nbytes):
+        return 1 << max(int(nbytes) - 1, 1).bit_length()
+
+    def take(self, nbytes):
+        cls = self.size_class(nbytes)
+        with self.lock:
+            lst = self.idle.get(cls)
+            if lst:
+                self.idle_bytes -= cls
+                return lst.pop(), cls
+        p = C.c_void_p()
+        _lib.call("spc_host_alloc", C.c_size_t(cls), C.byref(p))
+        return p.value, cls
+
+    def give(self, ptr, cls):
+        try:
+            with self.lock:
+                if self.idle_bytes + cls <= self.max_bytes:
+                    self.idle.setdefault(cls, []).append(ptr)
+                    self.idle_bytes += cls
+                    return
+            _lib.call("spc_host_free", C.c_void_p(ptr))
+        except Exception:        # interpreter shutdown
+            pass
+
+    def array(self, shape, dtype):
+        """uninitialised numpy array of *shape* / *dtype* in a pinned buffer of the pool"""
+        import weakref
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        ptr, cls = self.take(nbytes)
+        raw = (C.c_byte * nbytes).from_address(ptr)
+        weakref.finalize(raw, self.give, ptr, cls)       # numpy keeps `raw` alive as the base of every view
+        return np.frombuffer(raw, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+
+
+pinned_pool = _PinnedPool()
+
+
 class Event:
     def __init__(self, device=0):
         self.device = device
@@ -120,7 +176,10 @@ class DeviceArray:
     def get(self, stream=None):
         if getattr(self, "_is_view", False):
             raise ValueError("strided row view: copy through the parent array")
-        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes >= _PinnedPool.MIN_BYTES:
+            out = pinned_pool.array(self.shape, self.dtype)
+        else:
+            out = np.empty(self.shape, dtype=self.dtype)
         if stream is not None:
             _lib.call("spc_stream_sync", self.device, _sh(stream))
         _lib.call("spc_memcpy_d2h", self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),

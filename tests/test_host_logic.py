@@ -446,3 +446,43 @@ def test_beams_table_and_varying_resolution_host_side(tmp_path):
     with pytest.raises(AttributeError, match="spectrally interpolated"):
         c.spectral_interpolate(None)
     assert isinstance(c.with_mask(np.ones(d.shape, bool)), VaryingResolutionSpectralCube)
+
+
+def test_pinned_result_pool(monkeypatch):
+    """DeviceArray.get() hands out numpy arrays that live in pooled page-locked buffers: a buffer stays out while
+    any view of the result is alive, returns to the pool afterwards, is reused by the next result of its size class,
+    and is released when the pool is full (the allocator is replaced by ctypes memory here: no GPU)."""
+    import ctypes as C
+    import gc
+    import spectral_cube_amd.device as D
+    from spectral_cube_amd import _lib
+    log, keep = [], {}
+
+    def fake_call(name, *a):
+        if name == "spc_host_alloc":
+            buf = (C.c_byte * a[0].value)()
+            keep[C.addressof(buf)] = buf
+            a[1]._obj.value = C.addressof(buf)
+            log.append(("alloc", a[0].value))
+        elif name == "spc_host_free":
+            keep.pop(a[0].value)
+            log.append(("free", a[0].value))
+        else:
+            raise AssertionError(name)
+    monkeypatch.setattr(_lib, "call", fake_call)
+    pool = D._PinnedPool(max_bytes=1 << 22)
+    a = pool.array((512, 512), np.float64)
+    a[:] = 1.5
+    v = a[10:20]
+    del a
+    gc.collect()
+    assert pool.idle_bytes == 0 and v.sum() == 1.5 * 10 * 512      # a view keeps the buffer out of the pool
+    del v
+    gc.collect()
+    assert pool.idle_bytes == 1 << 21
+    b = pool.array((300, 600), np.float64)                           # same size class: reused, not allocated
+    assert pool.idle_bytes == 0 and [x[0] for x in log] == ["alloc"]
+    c = pool.array((1024, 1024), np.float64)                         # 8 MiB: more than the pool may keep idle
+    del b, c
+    gc.collect()
+    assert pool.idle_bytes == 1 << 21 and log[-1][0] == "free" and len(keep) == 1
