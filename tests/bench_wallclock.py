@@ -15,6 +15,7 @@ dev = DeviceArray(shape, np.float32); _replicate_rows(dev, tile, 4)
 hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1 / 3600, "CDELT2": 1 / 3600, "CDELT3": 0.5,
        "CUNIT3": "km/s", "CRPIX1": 512.5, "CRPIX2": 512.5, "CRPIX3": 1, "CRVAL1": 150.0, "CRVAL2": 2.0, "CRVAL3": -256.0, "BUNIT": "K"}
 cube = SpectralCube.from_device(dev, header=hdr)
+cube.allow_huge_operations = True          # (the reference's guard for reproject / convolve_to above 1e8 voxels)
 
 
 def wall(label, fn, n=4):
@@ -42,3 +43,8 @@ v = cube.spectral_axis
 wall("cube.spectral_interpolate(2048 channels)", lambda: cube.spectral_interpolate(np.linspace(v[0], v[-1], 2048))._device_data(), n=3)
 masked = cube.with_mask(cube > 0.5)
 wall("(cube > 0.5 mask).moment0()", lambda: masked.moment0())
+if os.environ.get("SPC_WALL_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    r = cube.spectral_interpolate(np.linspace(v[0], v[-1], 2048))._device_data(); synchronize()
+    pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(8)

@@ -317,3 +317,42 @@ def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
         np.testing.assert_allclose(got30, e30, rtol=3e-6, atol=1e-7, equal_nan=True)
         mad = ops.percentile_axis0(dd, 50.0, mask=spec, center=med).get()
         assert np.array_equal(mad, emad, equal_nan=True), env
+
+
+@pytest.mark.parametrize("ntaps,sym", [(9, True), (17, True), (33, True), (33, False), (13, False)])
+@pytest.mark.parametrize("shape", [(300, 5, 7), (70, 3, 130)])
+def test_spectral_smooth_masked_table_denominators(gpu, shape, ntaps, sym):
+    """The general spectral stencil (mask array + NaNs) takes its denominators from validity-bit tables: every ring
+    size, symmetric and not, kernels narrower than their ring (13 taps in the 17 ring), tall cubes that are split
+    along z (a slice starts mid-cube with an empty history), runs of invalid samples longer than the kernel (empty
+    windows -> NaN) and windows hanging over both ends - against the oracle at the contract tolerance, materialised
+    and fused with the moments."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    rng = np.random.default_rng(ntaps * 7 + shape[0])
+    d = rng.standard_normal(shape).astype(np.float32) + 3.0
+    d[rng.random(shape) < 0.03] = np.nan
+    inc = rng.random(shape) < 0.6
+    inc[40:40 + 2 * ntaps, 1, 2] = False                              # an empty window in the middle
+    inc[:ntaps, 0, 0] = False                                        # ... and at the start of the ray
+    inc[:, 2, 3] = True
+    k = np.exp(-0.5 * (np.arange(ntaps) - ntaps // 2) ** 2 / (ntaps / 6.0) ** 2)
+    if not sym:
+        k = k * np.linspace(0.5, 1.5, ntaps)
+    exp = O.spectral_smooth(d, inc, k)
+    dd = DeviceArray.from_numpy(d)
+    spec = ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
+    got = ops.spectral_conv(dd, k, mask=spec).get()
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    np.testing.assert_allclose(got[ok], exp[ok], rtol=1e-6, atol=1e-6)
+    # fused with the moments of the smoothed cube (same mask on the smoothed samples)
+    cen = (np.arange(shape[0]) - shape[0] // 2) * 0.5
+    r = ops.spectral_conv_moments(dd, k, DeviceArray.from_numpy(cen), mask=spec, cen_host=cen, want=("m0", "m1"))
+    einc = inc & np.isfinite(d)             # the smoothed cube keeps the parent's mask: array AND isfinite(parent data)
+    e0 = O.moment(exp.astype(np.float32), einc, 0, cen, 1.0)
+    e1 = O.moment(exp.astype(np.float32), einc, 1, cen, 1.0)
+    assert_close(r["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="fused m0")
+    with np.errstate(all="ignore"):
+        wc = np.abs(e0) > 1e-3 * np.nanmax(np.abs(e0))
+    assert_close(np.where(wc, r["m1"].get(), 0.0), np.where(wc, e1, 0.0), atol=1e-5 * np.abs(cen).max(), what="fused m1")
