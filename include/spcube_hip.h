@@ -327,6 +327,17 @@ int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny,
                        const double* h_kernel, int nky, int nkx, double* d_out,
                        void* d_workspace, size_t workspace_bytes);
 
+/* Elementwise arithmetic on float64 maps of n elements, so that the algebra around spc_map_conv2d_f64 (moment
+ * sums from moments, moments from smoothed sums) stays on the device:
+ *   SPC_MAP_MUL                out = a * b
+ *   SPC_MAP_SECOND_MOMENT_SUM  out = (a + b*b) * c        S2 = (m2 + mu^2) * S0
+ *   SPC_MAP_DIV_ADD            out = a / b + s            mu' = S1' / S0' (+ axis offset)
+ *   SPC_MAP_DIV_SUB_SQ         out = a / b - c*c          m2' = S2' / S0' - mu'^2
+ * d_out may alias an input. */
+typedef enum { SPC_MAP_MUL = 0, SPC_MAP_SECOND_MOMENT_SUM = 1, SPC_MAP_DIV_ADD = 2, SPC_MAP_DIV_SUB_SQ = 3 } spc_map_op;
+int spc_map_arith_f64(int device, void* stream, int op, const double* d_a, const double* d_b, const double* d_c,
+                      double s, double* d_out, int64_t n);
+
 /* moments along a spatial axis (axis = 1 or 2), reference golden tables
  * spectral_cube/tests/test_moments.py:19-49.  d_cen is a (ny,nx) float64 map
  * of offsets along that axis (spectral_cube.py:1476-1503), pix_size the pixel

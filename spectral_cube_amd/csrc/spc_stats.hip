@@ -767,6 +767,38 @@ int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny,
     return SPC_OK;
 }
 
+// ---- elementwise arithmetic on float64 maps (the algebra around spc_map_conv2d_f64 without a trip to the host)
+namespace {
+__global__ __launch_bounds__(256) void map_arith_kernel(int op, const double* a, const double* b, const double* c, double s,
+                                                        double* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b ? b[i] : 0.0, z = c ? c[i] : 0.0;
+    double r;
+    switch (op) {
+        case SPC_MAP_MUL: r = x * y; break;
+        case SPC_MAP_SECOND_MOMENT_SUM: r = (x + y * y) * z; break;       // (m2 + mu^2) * S0 = S2
+        case SPC_MAP_DIV_ADD: r = x / y + s; break;                      // S1' / S0' + offset
+        case SPC_MAP_DIV_SUB_SQ: r = x / y - z * z; break;               // S2' / S0' - mu'^2
+        default: r = x; break;
+    }
+    out[i] = r;
+}
+}  // namespace
+
+int spc_map_arith_f64(int device, void* stream, int op, const double* d_a, const double* d_b, const double* d_c, double s,
+                      double* d_out, int64_t n) {
+    SPC_REQUIRE(d_a && d_out && n >= 0, "NULL pointer argument");
+    SPC_REQUIRE(op >= SPC_MAP_MUL && op <= SPC_MAP_DIV_SUB_SQ, "unknown map operation");
+    SPC_REQUIRE(d_b != nullptr, "d_b is NULL");
+    SPC_REQUIRE(d_c != nullptr || (op != SPC_MAP_SECOND_MOMENT_SUM && op != SPC_MAP_DIV_SUB_SQ), "d_c is NULL");
+    if (n == 0) return SPC_OK;
+    SPC_DEVICE(device);
+    hipLaunchKernelGGL(map_arith_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, d_a, d_b, d_c, s, d_out, n);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
 int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, float fill,
                         float* d_out, int64_t out_row_stride, int64_t out_plane_stride) {
     int rc = spc_check_cube(cube);

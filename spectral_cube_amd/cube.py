@@ -490,26 +490,33 @@ class SpectralCube:
         r = parent._moment_device((("s0", "mu", "m2") if higher else ("m0",)) + ("nvalid",))
         if int(r["nvalid"].get().min()) != nz:
             return None
-        c0 = ops.map_conv2d(r["s0" if higher else "m0"], lz.kernel).get()        # the sums never leave the device
-        # a NaN / Inf sum anywhere (one reduction: the total is non-finite iff a term is; cannot happen when the mask
-        # keeps finite samples only), or - where the moments divide by it - a zero: not this path
-        if (not (spec.flags & _lib.MASK_FINITE) and not np.isfinite(c0.sum())) or (higher and not np.all(c0 != 0.0)):
-            return None
-        out = {}
-        if "m0" in want:
-            out["m0"] = self._pix_size_slice(0) * c0 if higher else c0
-        if higher:
-            s0, mu, m2 = r["s0"].get(), r["mu"].get(), r["m2"].get()
-            if not (np.all(s0 != 0.0) and np.all(np.isfinite(mu)) and np.all(np.isfinite(m2))):
+        if not higher:
+            c0 = ops.map_conv2d(r["m0"], lz.kernel).get()        # the sums never leave the device
+            # a NaN / Inf sum anywhere (one reduction: the total is non-finite iff a term is; cannot happen when the
+            # mask keeps finite samples only): not this path
+            if not (spec.flags & _lib.MASK_FINITE) and not np.isfinite(c0.sum()):
                 return None
-            conv = lambda m: ops.map_conv2d(DeviceArray.from_numpy(m, self.device), lz.kernel).get()   # noqa: E731
-            cen = self._pix_cen_axis(0)
-            cref = cen[nz // 2]
-            mup = conv(mu * s0) / c0
-            if "m1" in want:
-                out["m1"] = mup + cref + self.spectral_axis[0]
-            if "m2" in want:
-                out["m2"] = conv((m2 + mu * mu) * s0) / c0 - mup * mup
+            return {"m0": c0}
+        # S1 = mu * S0 and S2 = (m2 + mu^2) * S0 about the reference channel are smoothed like S0; the moments of the
+        # smoothed cube are their ratios.  All of it on the device: only the requested maps come back.  A spaxel whose
+        # spectrum sums to zero (0/0 in mu), a zero smoothed sum or a non-finite sample shows up as a non-finite value
+        # in the result: not this path.
+        s0, mu, m2 = r["s0"], r["mu"], r["m2"]
+        c0d = ops.map_conv2d(s0, lz.kernel)
+        c1d = ops.map_conv2d(ops.map_arith(_lib.MAP_MUL, mu, s0), lz.kernel)
+        cen = self._pix_cen_axis(0)
+        cref = cen[nz // 2]
+        out = {}
+        if "m1" in want:
+            out["m1"] = ops.map_arith(_lib.MAP_DIV_ADD, c1d, c0d, s=cref + self.spectral_axis[0]).get()
+        if "m2" in want:
+            c2d = ops.map_conv2d(ops.map_arith(_lib.MAP_SECOND_MOMENT_SUM, m2, mu, s0), lz.kernel)
+            mupd = ops.map_arith(_lib.MAP_DIV_ADD, c1d, c0d, s=0.0)
+            out["m2"] = ops.map_arith(_lib.MAP_DIV_SUB_SQ, c2d, c0d, mupd).get()
+        if "m0" in want:
+            out["m0"] = self._pix_size_slice(0) * c0d.get()
+        if not all(np.isfinite(m.sum()) for m in out.values()):
+            return None
         return out
 
     def moment(self, order=0, axis=0, how="auto", **kwargs):

@@ -463,6 +463,19 @@ def map_conv2d(dmap, kernel2d, stream=None, out=None):
     return out
 
 
+def map_arith(op, a, b, c=None, s=0.0, out=None, stream=None):
+    """elementwise arithmetic on float64 maps (spc_map_arith_f64; op one of _lib.MAP_*): the algebra around
+    map_conv2d without a trip to the host."""
+    for m in (a, b, c):
+        if m is not None and (m.dtype != np.float64 or tuple(m.shape) != tuple(a.shape)):
+            raise TypeError("maps must be float64 DeviceArrays of one shape")
+    if out is None:
+        out = DeviceArray(a.shape, np.float64, a.device)
+    _lib.call("spc_map_arith_f64", a.device, _sh(stream), int(op), C.c_void_p(a.ptr), C.c_void_p(b.ptr),
+              C.c_void_p(c.ptr) if c is not None else None, float(s), C.c_void_p(out.ptr), int(np.prod(a.shape, dtype=np.int64)))
+    return out
+
+
 MAD_TO_STD = 1.482602218505602          # 1 / Phi^-1(3/4), astropy.stats.mad_std
 
 

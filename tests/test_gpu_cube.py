@@ -388,11 +388,14 @@ def test_spatial_smooth_then_moment_algebraic(gpu, monkeypatch):
     calls = []
     real = ops.spatial_conv
     monkeypatch.setattr(ops, "spatial_conv", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
-    for variant in ("clean", "nan", "masked"):
+    for variant in ("clean", "nan", "masked", "zerosum"):
         dd = d.copy()
         inc = None
         if variant == "nan":
             dd[7, 9, 11] = np.nan
+        if variant == "zerosum":                 # a spectrum that sums to exactly zero: its mu is 0/0, the shortcut
+            dd[:, 5, 6] = 0.0                    # for the higher moments must step aside (moment 0 may keep it)
+            dd[3, 5, 6], dd[9, 5, 6] = 1.5, -1.5
         cube = SpectralCube.read(dd, hdr)
         if variant == "masked":
             inc = rng.random(shape) > 0.2
@@ -410,6 +413,10 @@ def test_spatial_smooth_then_moment_algebraic(gpu, monkeypatch):
             warnings.simplefilter("ignore")
             m0, m1, m2 = np.asarray(smc.moment0()), np.asarray(smc.moment1()), np.asarray(smc.moment2())
         assert (len(calls) == 0) == (variant == "clean"), (variant, len(calls))    # shortcut only when clean
+        if variant == "zerosum":
+            del calls[:]
+            np.asarray(cube.spatial_smooth(k2).moment0())
+            assert len(calls) == 0                               # moment 0 alone does not divide: still the shortcut
         with np.errstate(all="ignore"):
             assert_close(m0, e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="m0 " + variant)
             assert_close(m1, e1, atol=1e-5 * abs(cen[-1] - cen[0]), what="m1 " + variant)
