@@ -30,6 +30,8 @@ namespace spc_sconv {
 extern template int launch<9>(const ConvArgs&, hipStream_t, int, bool);
 extern template int launch<17>(const ConvArgs&, hipStream_t, int, bool);
 extern template int launch<33>(const ConvArgs&, hipStream_t, int, bool);
+extern template int launch_fast_only<49>(const ConvArgs&, hipStream_t);
+extern template int launch_fast_only<65>(const ConvArgs&, hipStream_t);
 }
 using namespace spc_sconv;
 
@@ -90,6 +92,8 @@ template <bool ARR>
 __global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs A, const double* kpad, int ntaps) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ny * A.nx) return;
+    // tiles (128 columns) already finished by an all-valid ring pass
+    if (A.status && spc_flag_get(A.status + __builtin_amdgcn_readfirstlane((int)(col >> 7))) == 0) return;
     const int64_t y = col / A.nx, x = col - y * A.nx;
     const int H = ntaps / 2;
     const float* p = A.cube + y * A.row_stride + x;
@@ -359,7 +363,7 @@ int fill_common(ConvArgs& A, const spc_cube_f32* cube, const spc_mask* mask, con
     A.cube = cube->d_data;
     A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
-    for (int i = 0; i < 64; ++i) A.k[i] = 0.0;
+    for (int i = 0; i < 72; ++i) A.k[i] = 0.0;
     if (R) {
         const int pad = (R - ntaps) / 2;
         for (int i = 0; i < ntaps; ++i) A.k[pad + i] = h_kernel[i];
@@ -430,6 +434,28 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
     for (int i = 0; i < ntaps; ++i) hk[(wide ? 15 : 0) + i] = h_kernel[i];
     SPC_WS_TAKE(d_k, ws, double, ntaps + 30);
     SPC_HIP(spc_table_upload(d_k, hk.data(), sizeof(double) * npad, st));
+    A.status = nullptr;
+    // 35 - 65 symmetric taps on data the mask of which only rejects non-finite samples: the all-valid ring pass first
+    // (spc_spectral_conv_r49/65), then the kernels below redo the tiles that hold an invalid sample
+    {
+        const int Rf = ntaps <= 49 ? 49 : 65;
+        bool sym = (ntaps & 1) && ntaps <= 65 && h_kernel[ntaps / 2] != 0.0;
+        for (int i = 0; sym && i < ntaps / 2; ++i) sym = h_kernel[i] == h_kernel[ntaps - 1 - i];
+        const char* fenv = getenv("SPC_CONV_FAST");
+        if (wide && sym && (fenv ? atoi(fenv) != 0 : true) && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 &&
+            ring_fits(Rf, cube, mask, A.out_row_stride, A.out_plane_stride)) {
+            rc = fill_common(A, cube, mask, h_kernel, ntaps, Rf);            // taps centred in the ring, kernel sum
+            if (rc) return rc;
+            SPC_WS_TAKE(d_status, ws, unsigned char, (ncols + 127) / 128);
+            SPC_HIP(spc_flags_clear(d_status, (size_t)((ncols + 127) / 128), st));
+            A.status = d_status;
+            const int64_t keep = A.zchunk;
+            A.zchunk = cube->nz;                                             // the ring pass marches over the whole ray
+            rc = Rf == 49 ? spc_sconv::launch_fast_only<49>(A, st) : spc_sconv::launch_fast_only<65>(A, st);
+            if (rc) return rc;
+            A.zchunk = keep;
+        }
+    }
     if (wide) {
         // whole runs of 16 per z slice
         A.zchunk = ((A.zchunk + 15) / 16) * 16;

@@ -67,7 +67,7 @@ struct ConvArgs {
     // all-valid fast pass: one byte per 128-column tile, 0 = done by the fast kernel
     unsigned char* status;
     double ksum, inv_ksum;     // sum(k) in tap order, 1 / sum(k)
-    alignas(16) double k[64];  // taps padded to R, centred
+    alignas(16) double k[72];  // taps padded to R, centred (R <= 65)
 };
 
 // ---- denominators from validity bits ------------------------------------------------------
@@ -500,6 +500,17 @@ int launch(const ConvArgs& A, hipStream_t st, int fast, bool fuse) {
     const int64_t nsplit = (A.nz + A.zchunk - 1) / A.zchunk;
     if (fuse) return sym ? launch_rs<R, true, true>(A, st, ncols, (unsigned)nsplit, arr, ext) : launch_rs<R, true, false>(A, st, ncols, (unsigned)nsplit, arr, ext);
     return sym ? launch_rs<R, false, true>(A, st, ncols, (unsigned)nsplit, arr, ext) : launch_rs<R, false, false>(A, st, ncols, (unsigned)nsplit, arr, ext);
+}
+
+// Rings wider than 33 taps exist for the all-valid pass only (symmetric kernels: the distinct taps have to fit the
+// SGPR file; one spaxel per lane: R float64 accumulators + R staged inputs per lane): dirty tiles go to the
+// runs-of-16 kernel of spc_spectral_conv.hip.  A.status must point at zeroed tile flags.
+template <int R>
+int launch_fast_only(const ConvArgs& A, hipStream_t st) {
+    const int64_t ngroups = A.ny * A.nx;
+    hipLaunchKernelGGL((spectral_conv_fast_kernel<R, false, 1, true>), dim3((unsigned)((ngroups + 255) / 256), 1), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
 }
 
 }  // namespace spc_sconv

@@ -1,0 +1,3 @@
+// 65-tap ring of the spectral stencil: all-valid pass only (see launch_fast_only in spc_spectral_conv_impl.h)
+#include "spc_spectral_conv_impl.h"
+namespace spc_sconv { template int launch_fast_only<65>(const ConvArgs&, hipStream_t); }

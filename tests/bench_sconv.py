@@ -60,5 +60,13 @@ for taps, sig in ((33, 4.0), (17, 2.0), (9, 1.0)):
     os.environ.pop("SPC_FUSE_ALGEBRAIC")
     report("sconv %d taps fused moments+argmax" % taps, timeit(lambda: ops.spectral_conv_moments(cube, g, cen, cen_host=cen_h, want=("m0", "m1", "m2", "argmax"))), 4)
     report("sconv %d taps fused moments u8 mask" % taps, timeit(lambda: ops.spectral_conv_moments(cube, g, cen, cen_host=cen_h, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskc), want=("m0", "m1", "m2"))), 5)
+for taps in (41, 49, 65):
+    h = taps // 2
+    g = np.exp(-0.5 * (np.arange(-h, h + 1) / (taps / 8.0)) ** 2)
+    report("sconv %d taps all-valid (ring pass)" % taps, timeit(lambda: ops.spectral_conv(cube, g, out=out), n=3), 8)
+    os.environ["SPC_CONV_FAST"] = "0"
+    report("sconv %d taps all-valid (runs-of-16 kernel)" % taps, timeit(lambda: ops.spectral_conv(cube, g, out=out), n=2), 8)
+    os.environ.pop("SPC_CONV_FAST")
+    report("sconv %d taps NaNs at 1e-4 (ring pass + runs of 16)" % taps, timeit(lambda: ops.spectral_conv(nanc, g, out=out), n=2), 8)
 g = np.exp(-0.5 * (np.arange(-40, 41) / 10.0) ** 2)
-report("sconv 81 taps (wide kernel)", timeit(lambda: ops.spectral_conv(cube, g, out=out), n=2), 8)
+report("sconv 81 taps (runs-of-16 kernel)", timeit(lambda: ops.spectral_conv(cube, g, out=out), n=2), 8)

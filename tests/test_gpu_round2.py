@@ -356,3 +356,31 @@ def test_spectral_smooth_masked_table_denominators(gpu, shape, ntaps, sym):
     with np.errstate(all="ignore"):
         wc = np.abs(e0) > 1e-3 * np.nanmax(np.abs(e0))
     assert_close(np.where(wc, r["m1"].get(), 0.0), np.where(wc, e1, 0.0), atol=1e-5 * np.abs(cen).max(), what="fused m1")
+
+
+@pytest.mark.parametrize("ntaps", [35, 41, 49, 51, 65])
+def test_spectral_smooth_wide_symmetric_rings(gpu, ntaps, monkeypatch):
+    """35 - 65 symmetric taps (Gaussian1DKernel(4.25 ... 8)): the all-valid pass runs on the 49- / 65-tap rings, tiles
+    holding a NaN are redone by the runs-of-16 kernel; both against the oracle at the contract tolerance and against
+    each other (SPC_CONV_FAST=0: the runs-of-16 kernel alone) to an ulp of float32."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    shape = (3 * ntaps + 5, 6, 300)
+    rng = np.random.default_rng(ntaps)
+    d = rng.standard_normal(shape).astype(np.float32) + 1.0
+    d[ntaps, 2, 17] = np.nan                 # one dirty 128-column tile, the others stay on the ring
+    d[0, 5, 299] = np.nan
+    k = np.exp(-0.5 * ((np.arange(ntaps) - ntaps // 2) / (ntaps / 8.0)) ** 2)
+    exp = O.spectral_smooth(d, np.isfinite(d), k)
+    dd = DeviceArray.from_numpy(d)
+    spec = ops.MaskSpec(_lib.MASK_FINITE)
+    got = ops.spectral_conv(dd, k, mask=spec).get()
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-6, equal_nan=True)
+    monkeypatch.setenv("SPC_CONV_FAST", "0")
+    ref = ops.spectral_conv(dd, k, mask=spec).get()
+    monkeypatch.delenv("SPC_CONV_FAST")
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.all(np.abs(got[ok] - ref[ok]) <= np.spacing(np.abs(ref[ok]).astype(np.float32)))
+    assert np.mean(got[ok] != ref[ok]) < 0.01          # different float64 summation order: rare float32 flips only
