@@ -304,59 +304,34 @@ __device__ __forceinline__ void count_keys(const uint32_t (&key)[KPL], uint32_t 
     }
 }
 
-template <int TS, int KPL, bool ARR>
-__global__ __launch_bounds__(256) void select_reg_kernel(const SelArgs A) {
-    __shared__ uint32_t hist[3][TS][16];
-    __shared__ uint32_t nvalid[TS], nextkey[TS], ncand[TS], sel_key[TS], sel_below[TS], sel_eq[TS];
-    __shared__ uint32_t cand[TS][kCandMax];
-    constexpr int kLanesPerRay = 256 / TS;
+// LDS scratch of one block of TS rays
+template <int TS>
+struct SelShared {
+    uint32_t hist[3][TS][16];
+    uint32_t nvalid[TS], nextkey[TS], ncand[TS], sel_key[TS], sel_below[TS], sel_eq[TS];
+    uint32_t cand[TS][kCandMax];
+};
+
+// every thread of the block: zero what a descent needs (followed by a barrier at the caller)
+template <int TS>
+__device__ __forceinline__ void sel_reset(SelShared<TS>& S) {
     const int t = threadIdx.x;
-    const int r = t % TS, j = t / TS;                           // ray of the tile, slice of the ray
-    const int64_t tiles_x = (A.nx + TS - 1) / TS;
-    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
-    const int nz = (int)A.nz;
-    const bool col_in = x0 + r < A.nx;
-    const int64_t xc = col_in ? x0 + r : A.nx - 1;
-    const float* p = A.cube + y * A.row_stride + xc;
-    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc : nullptr;
-    const bool use_cen = A.center != nullptr;
-    const float cen = (use_cen && col_in) ? A.center[y * A.nx + x0 + r] : 0.f;
-    if (t < TS) { nvalid[t] = 0u; nextkey[t] = 0xffffffffu; ncand[t] = 0u; }
-    for (int i = t; i < 3 * TS * 16; i += 256) (&hist[0][0][0])[i] = 0u;
-    __syncthreads();
-    // ---- the one read of the cube: keys into registers (excluded / NaN / beyond nz: the largest key)
-    uint32_t key[KPL];
-    int mine = 0;
-    constexpr int U = KPL < 8 ? KPL : 8;
-#pragma unroll
-    for (int i0 = 0; i0 < KPL; i0 += U) {
-        float raw[U];
-        unsigned mk[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int z = min(j + kLanesPerRay * (i0 + u), nz - 1);
-            raw[u] = __builtin_nontemporal_load(p + (int64_t)z * A.plane_stride);
-            mk[u] = ARR ? pm[(int64_t)z * A.mask.plane_stride] : 1u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int z = j + kLanesPerRay * (i0 + u);
-            bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
-            const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
-            ok = ok && (v == v);
-            key[i0 + u] = ok ? fkey(v) : 0xffffffffu;
-            mine += ok ? 1 : 0;
-        }
-        __builtin_amdgcn_sched_barrier(0);                       // U loads in flight, not KPL
-    }
-    if (mine) atomicAdd(&nvalid[r], (uint32_t)mine);
-    __syncthreads();
-    const int n = (int)nvalid[r];
-    const double pos = A.q / 100.0 * (double)(n > 0 ? n - 1 : 0);
+    if (t < TS) { S.nvalid[t] = 0u; S.nextkey[t] = 0xffffffffu; S.ncand[t] = 0u; }
+    for (int i = t; i < 3 * TS * 16; i += 256) (&S.hist[0][0][0])[i] = 0u;
+}
+
+// The descent over the registers of the block (all 256 threads call it; barriers inside).  r / j: ray and slice of this
+// lane, n: valid samples of the ray.  Returns the keys of the two order statistics numpy's 'linear' percentile q
+// interpolates between and the interpolation fraction.  S must have been reset (sel_reset + barrier).
+template <int TS, int KPL>
+__device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&key)[KPL], int r, int j, int n, double q,
+                                           uint32_t& key_lo, uint32_t& key_hi, double& frac) {
+    constexpr int kLanesPerRay = 256 / TS;
+    const double pos = q / 100.0 * (double)(n > 0 ? n - 1 : 0);
     const double fl = floor(pos);
     int k = (int)fl;                                             // rank still to be found inside the current prefix
     const int khi = min((int)ceil(pos), max(n - 1, 0));
-    const double frac = pos - fl;
+    frac = pos - fl;
     int below = 0;                                               // keys smaller than everything matching the prefix
     uint32_t prefix = 0u;
     int eq = 0;
@@ -371,8 +346,8 @@ __global__ __launch_bounds__(256) void select_reg_kernel(const SelArgs A) {
         asm volatile("" : "+s"(popaque));
         if (popaque == 0) count_keys<KPL, true>(key, prefix, b, accE, accO);
         else count_keys<KPL, false>(key, prefix, b, accE, accO);
-        uint32_t* h = hist[pass % 3][r];
-        uint32_t* hz = hist[(pass + 1) % 3][r];
+        uint32_t* h = S.hist[pass % 3][r];
+        uint32_t* hz = S.hist[(pass + 1) % 3][r];
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             const uint32_t c0 = (uint32_t)(accE >> (8 * d)) & 0xffu, c1 = (uint32_t)(accO >> (8 * d)) & 0xffu;
@@ -403,51 +378,222 @@ __global__ __launch_bounds__(256) void select_reg_kernel(const SelArgs A) {
 #pragma unroll
                     for (int i = 0; i < KPL; ++i) {
                         if (((key[i] ^ prefix) >> 16) == 0u) {
-                            const uint32_t slot = atomicAdd(&ncand[r], 1u);
-                            cand[r][slot] = key[i];
+                            const uint32_t slot = atomicAdd(&S.ncand[r], 1u);
+                            S.cand[r][slot] = key[i];
                         }
                     }
                 }
                 __syncthreads();
                 if (n > 0) {
                     for (int idx = j; idx < eq; idx += kLanesPerRay) {
-                        const uint32_t c = cand[r][idx];
+                        const uint32_t c = S.cand[r][idx];
                         int less = 0, same_before = 0, same = 0;
                         for (int m = 0; m < eq; ++m) {
-                            const uint32_t o = cand[r][m];
+                            const uint32_t o = S.cand[r][m];
                             less += (o < c) ? 1 : 0;
                             same += (o == c) ? 1 : 0;
                             same_before += (o == c && m < idx) ? 1 : 0;
                         }
-                        if (less + same_before == k) { sel_key[r] = c; sel_below[r] = (uint32_t)(below + less); sel_eq[r] = (uint32_t)same; }
+                        if (less + same_before == k) { S.sel_key[r] = c; S.sel_below[r] = (uint32_t)(below + less); S.sel_eq[r] = (uint32_t)same; }
                     }
                 }
                 __syncthreads();
-                if (n > 0) { prefix = sel_key[r]; below = (int)sel_below[r]; eq = (int)sel_eq[r]; }
+                if (n > 0) { prefix = S.sel_key[r]; below = (int)S.sel_below[r]; eq = (int)S.sel_eq[r]; }
                 done = true;
             }
         }
     }
     // prefix = the key of rank floor(pos); `eq` samples carry it, `below` are smaller
-    uint32_t key_hi = prefix;
+    key_lo = prefix;
+    key_hi = prefix;
     const bool need_next = (n > 0) && (khi >= below + eq);       // ray-uniform
     if (__syncthreads_or(need_next ? 1 : 0)) {
         if (need_next) {
             uint32_t mn = 0xffffffffu;
 #pragma unroll
             for (int i = 0; i < KPL; ++i) mn = (key[i] > prefix) ? min(mn, key[i]) : mn;
-            atomicMin(&nextkey[r], mn);
+            atomicMin(&S.nextkey[r], mn);
         }
         __syncthreads();
-        if (need_next) key_hi = nextkey[r];
+        if (need_next) key_hi = S.nextkey[r];
     }
-    if (j == 0 && col_in) {
-        float res = NAN;
-        if (n > 0) {
-            const double a = (double)funkey(prefix), bb = (double)funkey(key_hi);
-            res = (float)((frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac) * (double)A.scale);
+}
+
+// numpy's interpolation between the two order statistics (the mean of two for a median), in float64, rounded once
+__device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, double frac, double scale) {
+    const double a = (double)funkey(key_lo), bb = (double)funkey(key_hi);
+    return (float)((frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac) * scale);
+}
+
+template <int TS, int KPL, bool ARR>
+__global__ __launch_bounds__(256) void select_reg_kernel(const SelArgs A) {
+    __shared__ SelShared<TS> S;
+    constexpr int kLanesPerRay = 256 / TS;
+    const int t = threadIdx.x;
+    const int r = t % TS, j = t / TS;                           // ray of the tile, slice of the ray
+    const int64_t tiles_x = (A.nx + TS - 1) / TS;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
+    const int nz = (int)A.nz;
+    const bool col_in = x0 + r < A.nx;
+    const int64_t xc = col_in ? x0 + r : A.nx - 1;
+    const float* p = A.cube + y * A.row_stride + xc;
+    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc : nullptr;
+    const bool use_cen = A.center != nullptr;
+    const float cen = (use_cen && col_in) ? A.center[y * A.nx + x0 + r] : 0.f;
+    sel_reset<TS>(S);
+    __syncthreads();
+    // ---- the one read of the cube: keys into registers (excluded / NaN / beyond nz: the largest key)
+    uint32_t key[KPL];
+    int mine = 0;
+    constexpr int U = KPL < 8 ? KPL : 8;
+#pragma unroll
+    for (int i0 = 0; i0 < KPL; i0 += U) {
+        float raw[U];
+        unsigned mk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = min(j + kLanesPerRay * (i0 + u), nz - 1);
+            raw[u] = __builtin_nontemporal_load(p + (int64_t)z * A.plane_stride);
+            mk[u] = ARR ? pm[(int64_t)z * A.mask.plane_stride] : 1u;
         }
-        A.out[y * A.nx + x0 + r] = res;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = j + kLanesPerRay * (i0 + u);
+            bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
+            const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
+            ok = ok && (v == v);
+            key[i0 + u] = ok ? fkey(v) : 0xffffffffu;
+            mine += ok ? 1 : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // U loads in flight, not KPL
+    }
+    if (mine) atomicAdd(&S.nvalid[r], (uint32_t)mine);
+    __syncthreads();
+    const int n = (int)S.nvalid[r];
+    uint32_t key_lo, key_hi;
+    double frac;
+    ray_select<TS, KPL>(S, key, r, j, n, A.q, key_lo, key_hi, frac);
+    if (j == 0 && col_in) A.out[y * A.nx + x0 + r] = n > 0 ? sel_value(key_lo, key_hi, frac, (double)A.scale) : NAN;
+}
+
+// ---- sigma clipping with the rays resident in registers -------------------------------------------------
+// astropy.stats.sigma_clip(axis=0, masked=False) iterates centre / spread / clip over the cube; built from separate
+// kernels every iteration reads it three times and writes it once (ops.sigma_clip_axis0: ~20 passes for the 5
+// default iterations).  Here a block loads its TS rays once (the selection kernel's layout), iterates entirely in
+// registers - valid count, sum and sum of squares per ray (float64, lane partials added in a fixed order: the result
+// does not depend on scheduling), the median through ray_select, the bounds with spc_clip_bounds_f32's arithmetic,
+// clipped samples turned into the "excluded" key - until no ray of the block changes or maxiters is reached, and
+// writes the clipped rays once.  A ray that has converged recomputes the same bounds and clips nothing, so stopping per
+// block equals astropy's global "until nothing changes".
+struct ClipRegArgs {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    MaskDev mask;
+    float* out;                 // (nz, ny, nx) C-contiguous
+    double lo_s, hi_s;
+    int maxiters;               // < 0: until convergence
+    int cen_mean;               // centre: 0 median, 1 mean
+};
+
+template <int TS, int KPL, bool ARR>
+__global__ __launch_bounds__(256, 4) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+    __shared__ SelShared<TS> S;
+    constexpr int kLanesPerRay = 256 / TS;
+    __shared__ double part_s[TS][kLanesPerRay], part_q[TS][kLanesPerRay];
+    const int t = threadIdx.x;
+    const int r = t % TS, j = t / TS;
+    const int64_t tiles_x = (A.nx + TS - 1) / TS;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
+    const int nz = (int)A.nz;
+    const bool col_in = x0 + r < A.nx;
+    const int64_t xc = col_in ? x0 + r : A.nx - 1;
+    const float* p = A.cube + y * A.row_stride + xc;
+    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc : nullptr;
+    uint32_t key[KPL];
+    constexpr int U = KPL < 8 ? KPL : 8;
+#pragma unroll
+    for (int i0 = 0; i0 < KPL; i0 += U) {
+        float raw[U];
+        unsigned mk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = min(j + kLanesPerRay * (i0 + u), nz - 1);
+            raw[u] = __builtin_nontemporal_load(p + (int64_t)z * A.plane_stride);
+            mk[u] = ARR ? pm[(int64_t)z * A.mask.plane_stride] : 1u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int z = j + kLanesPerRay * (i0 + u);
+            const bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
+            key[i0 + u] = ok ? fkey(raw[u]) : 0xffffffffu;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll 1
+    for (int it = 0; A.maxiters < 0 || it < A.maxiters; ++it) {
+        // ---- valid count, sum, sum of squares of the ray (what spc_stats_axis_f32 gives the unfused path)
+        sel_reset<TS>(S);
+        int cnt = 0;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const bool ok = key[i] != 0xffffffffu;
+            const double v = ok ? (double)funkey(key[i]) : 0.0;
+            cnt += ok ? 1 : 0;
+            s += v;
+            ss = fma(v, v, ss);
+            if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        part_s[r][j] = s;
+        part_q[r][j] = ss;
+        __syncthreads();                                         // (also orders sel_reset before the counts)
+        if (cnt) atomicAdd(&S.nvalid[r], (uint32_t)cnt);
+        double sum = 0.0, ssq = 0.0;
+#pragma unroll 4
+        for (int l = 0; l < kLanesPerRay; ++l) { sum += part_s[r][l]; ssq += part_q[r][l]; }
+        __syncthreads();
+        const int n = (int)S.nvalid[r];
+        double mean = nan, sd = nan;
+        if (n > 0) {
+            mean = sum / (double)n;
+            const double var = __dsub_rn(ssq / (double)n, __dmul_rn(mean, mean));
+            sd = (var != var) ? nan : sqrt(var > 0.0 ? var : 0.0);
+        }
+        double cen = mean;
+        if (!A.cen_mean) {
+            uint32_t key_lo, key_hi;
+            double frac;
+            ray_select<TS, KPL>(S, key, r, j, n, 50.0, key_lo, key_hi, frac);
+            cen = n > 0 ? (double)sel_value(key_lo, key_hi, frac, 1.0) : (double)NAN;
+        }
+        const float lo = (float)__dsub_rn(cen, __dmul_rn(A.lo_s, sd));
+        const float hi = (float)__dadd_rn(cen, __dmul_rn(A.hi_s, sd));
+        int changed = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            // (opaque copy: otherwise the 64 floats of the statistics loop are kept alive across the selection)
+            uint32_t kk = key[i];
+            asm volatile("" : "+v"(kk));
+            const float v = funkey(kk);                           // (the excluded key is a NaN pattern: compares false)
+            const bool out_of = (key[i] != 0xffffffffu) && (v < lo || v > hi);
+            key[i] = out_of ? 0xffffffffu : key[i];
+            changed |= out_of ? 1 : 0;
+            if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    // ---- the clipped rays, written once
+    if (col_in) {
+        float* q = A.out + y * A.nx + x0 + r;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int z = j + kLanesPerRay * i;
+            uint32_t kk = key[i];
+            asm volatile("" : "+v"(kk));
+            if (z < nz) q[(int64_t)z * A.ny * A.nx] = funkey(kk);   // (the excluded key is a NaN)
+            if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
@@ -665,6 +811,52 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     auto unkey = [](uint32_t kk) { uint32_t u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk; float f; memcpy(&f, &u, 4); return (double)f; };
     const double a = unkey(key_lo), b = unkey(key_hi);
     *h_out = (frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac;
+    return SPC_OK;
+}
+
+// astropy.stats.sigma_clip(axis=0, masked=False, cenfunc = median | mean, stdfunc = std) with the rays resident in
+// registers (sigma_clip_reg_kernel): one read and one write of the cube for all iterations.  d_out: (nz, ny, nx)
+// C-contiguous float32, masked and clipped samples NaN.  Rays longer than 2048 channels: SPC_ERR_UNSUPPORTED (the
+// caller iterates spc_percentile_axis0_f32 / spc_stats_axis_f32 / spc_clip_outside_f32 instead).
+extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                        double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
+                                        float* d_out) {
+    int rc = spc_check_cube_any_order(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    if (cube->nz > 2048 || cube->ny * ((cube->nx + 7) / 8) >= (1LL << 31)) {
+        spc_set_error("rays of %lld channels do not fit the registers of a block", (long long)cube->nz);
+        return SPC_ERR_UNSUPPORTED;
+    }
+    ClipRegArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    A.cube = cube->d_data;
+    A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.out = d_out;
+    A.lo_s = sigma_lower; A.hi_s = sigma_upper; A.maxiters = maxiters; A.cen_mean = center_is_mean ? 1 : 0;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
+    const int lanes = 256 / ts;
+    const int need = (int)((cube->nz + lanes - 1) / lanes);
+    const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    dim3 grid((unsigned)(cube->ny * ((cube->nx + ts - 1) / ts)));
+#define SPC_LAUNCH_CLIP(TS_, K_)                                                                                    \
+    do {                                                                                                            \
+        if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true>), grid, dim3(256), 0, st, A);             \
+        else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false>), grid, dim3(256), 0, st, A);                \
+    } while (0)
+#define SPC_LAUNCH_CLIP_K(TS_)                                                                                      \
+    do {                                                                                                            \
+        if (kpl == 16) SPC_LAUNCH_CLIP(TS_, 16); else if (kpl == 32) SPC_LAUNCH_CLIP(TS_, 32); else SPC_LAUNCH_CLIP(TS_, 64); \
+    } while (0)
+    if (ts == 32) SPC_LAUNCH_CLIP_K(32); else if (ts == 16) SPC_LAUNCH_CLIP_K(16); else SPC_LAUNCH_CLIP_K(8);
+#undef SPC_LAUNCH_CLIP_K
+#undef SPC_LAUNCH_CLIP
+    SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
 

@@ -384,3 +384,34 @@ def test_spectral_smooth_wide_symmetric_rings(gpu, ntaps, monkeypatch):
     ok = ~np.isnan(ref)
     assert np.all(np.abs(got[ok] - ref[ok]) <= np.spacing(np.abs(ref[ok]).astype(np.float32)))
     assert np.mean(got[ok] != ref[ok]) < 0.01          # different float64 summation order: rare float32 flips only
+
+
+@pytest.mark.parametrize("shape", [(9, 4, 11), (60, 3, 70), (515, 2, 37), (1030, 2, 21)])
+def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
+    """sigma clipping with the rays resident in registers (one kernel for all iterations) against the oracle's
+    restatement of astropy.stats.sigma_clip(axis=0) and against the loop of separate kernels (the same clipped set:
+    both carry the sums in float64 and the bounds in float32): median and mean centres, asymmetric sigmas, iteration
+    caps, a mask array, rays that are empty, constant, or hold infinities."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    rng = np.random.default_rng(shape[0] + 1)
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[rng.random(shape) < 0.03] *= 12.0                              # outliers to clip
+    d[rng.random(shape) < 0.02] = np.nan
+    d[:, 0, 0] = np.nan                                              # empty ray
+    d[:, 0, 1] = 4.25                                                # constant ray: std 0, nothing outside [c, c]
+    d[0, 1, 2] = np.inf                                              # an infinity poisons the ray's std: nothing is clipped
+    inc = rng.random(shape) < 0.85
+    dd = DeviceArray.from_numpy(d)
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
+    for kw in (dict(), dict(maxiters=1), dict(maxiters=None), dict(sigma_lower=1.5, sigma_upper=4.0), dict(cenfunc="mean")):
+        sig = 2.5
+        monkeypatch.delenv("SPC_SIGMA_CLIP_FUSED", raising=False)
+        got = ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get()
+        monkeypatch.setenv("SPC_SIGMA_CLIP_FUSED", "0")
+        ref = ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get()
+        assert np.array_equal(got, ref, equal_nan=True), kw
+        exp = O.sigma_clip(d, inc & ~np.isnan(d), sig, **kw)
+        assert np.mean(np.isnan(got) != np.isnan(exp)) < 2e-4, kw    # float32-vs-float64 bounds: borderline samples only
+        ok = ~np.isnan(got) & ~np.isnan(exp)
+        assert np.array_equal(got[ok], exp[ok])
