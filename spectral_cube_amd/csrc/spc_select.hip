@@ -426,7 +426,7 @@ __device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, dou
 }
 
 template <int TS, int KPL, bool ARR>
-__global__ __launch_bounds__(256) void select_reg_kernel(const SelArgs A) {
+__global__ __launch_bounds__(256, 5) void select_reg_kernel(const SelArgs A) {
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = 256 / TS;
     const int t = threadIdx.x;

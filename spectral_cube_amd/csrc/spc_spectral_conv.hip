@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvAr
 struct double2w { double x, y; };
 
 template <bool ARR>
-__global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs A, const double* kpad, int ntaps) {
+__global__ __launch_bounds__(256, 3) void spectral_conv_wide_kernel(const ConvArgs A, const double* kpad, int ntaps) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ny * A.nx) return;
     // tiles (128 columns) already finished by an all-valid ring pass
@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void spectral_conv_wide_kernel(const ConvArgs 
         // chunk of 8 planes r0 .. r0+7; weight of (plane r0 + i, output q) = k[ntaps-1-(r0+i)+q] = wp[7 - i + q],
         // wp = kpad + 15 + (ntaps - 1 - r0) - 7.  mode 0: q <= i (+ off), mode 2: q >= i (+ off), mode 1: all.
         auto chunk = [&](int r0, int mode, int off, int nrows) {
-            const double* wp = kpad + 15 + (ntaps - 1 - r0) - 7;
+            // (read through the constant address space: wave-uniform scalar loads, the taps stay out of the VGPRs)
+            typedef const double __attribute__((address_space(4))) cdouble;
+            cdouble* wp = (cdouble*)(kpad + 15 + (ntaps - 1 - r0) - 7);
             double w[23];
 #pragma unroll
             for (int t = 0; t < 23; ++t) w[t] = wp[t];
