@@ -325,16 +325,24 @@ __device__ __forceinline__ float2v classify(float v, unsigned char mk, float lim
 }
 
 template <int R, bool ARR, bool PRED, bool ISO>
-__global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
+__global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(const SpArgs A) {
     constexpr int H = R / 2;
     // float2 per LDS row.  Pitch = 28 (mod 32): a 32-lane group of the x pass spans parts of
     // two rows (28 runs per row); with this pitch the second row's runs continue the first
     // row's 18-dword bank progression instead of landing on the same banks (the previous
     // pitch of 290 made every x-pass ds_read_b64 2-way conflicted - SQ_LDS_BANK_CONFLICT
     // was twice SQ_ACTIVE_INST_LDS)
+    // 29 taps: the revolution is cut into groups of kGen = 8 rows: y pass of a group (its finished rows parked in LDS),
+    // barrier, x pass of the group, barrier; the next revolution's rows are requested one by one as the y pass frees
+    // their registers.  20 KB of LDS instead of 73 KB (more than two blocks per CU), 3 waves per SIMD: 1024^3 with a uint8
+    // mask 4.73 -> 4.45 ms, with a threshold mask 4.58 -> 4.05 ms.  The other rings keep the whole revolution in one group:
+    // 9 / 17 taps fill the rounds of 256 lanes better that way (9 taps 2.36 ms against 2.94 ms grouped), 33 / 65 taps need
+    // more registers than 3 waves per SIMD leave (65 taps 12.3 ms against 18.6 ms grouped).
+    constexpr bool kGrouped = (R == 29);
+    constexpr int kGen = kGrouped ? 8 : R;
     constexpr int kPitch = (R <= 29) ? 316 : 290;       // 33 taps: two blocks per CU only with the short pitch; 65 taps: only fits with it
     static_assert(kPitch >= kThreads + kThreads / 8, "LDS row too short");
-    __shared__ float2v yres[R * kPitch];
+    __shared__ float2v yres[kGen * kPitch];
 
     const int t = threadIdx.x;
     const int64_t z = blockIdx.y;
@@ -388,12 +396,69 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
         }
     };
 
+    // row s of the revolution starting at i0 (the rolling prefetch of the next revolution: v[s] is free once step s has used it)
+    auto load_row = [&](int i0, int s) {
+        const int64_t ic = min(max(i0 + s, 0), ny - 1);
+        v[s] = p[ic * A.row_stride];
+        if (ARR) mk[s] = pm[ic * A.mask.row_stride];
+    };
     const int T = (ye - yb) + 2 * H;
     load_rows(yb - H);
     for (int t0 = 0; t0 < T; t0 += R) {
         const int i0 = yb - H + t0;                       // first input row of this revolution
         const bool edge = edge_cols || (i0 < 0) || (i0 + R > ny);
-        // ---- y pass
+        // ---- x pass over `grows` parked rows, the first of which is row slot gs of this revolution
+        auto xpass = [&](const int gs, const int grows) {
+            // ---- x pass over the rows of this group
+            for (int task = t; task < grows * nrun_eff; task += nthr) {
+                const int sl = (int)(((float)task + 0.5f) * inv_nrun);    // exact: task < 2^10, nrun <= 31
+                const int j = task - sl * nrun_eff;
+                const int o = i0 + gs + sl - H;       // output row
+                if (o < yb || o >= ye) continue;
+                float2v r[kRun];
+    #pragma unroll
+                for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
+                const float2v* src = yres + sl * kPitch;
+    #pragma unroll
+                for (int i = 0; i < kRun + 2 * H; ++i) {
+                    const float2v in = src[lds_phys(kRun * j + i)];
+    #pragma unroll
+                    for (int k = 0; k < kRun; ++k) {
+                        const int widx = k + 2 * H - i;       // kx index for output k, input i
+                        if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
+                    }
+                }
+                const int64_t xo = x0 + kRun * j;
+                float* dst = A.out + z * A.out_plane_stride + (int64_t)o * A.out_row_stride + xo;
+                float res[kRun];
+    #pragma unroll
+                for (int k = 0; k < kRun; ++k) {
+                    if (r[k].y != 0.f) {
+                        res[k] = r[k].x * __builtin_amdgcn_rcpf(r[k].y);
+                    } else {
+                        // empty window -> (filled) centre sample, like astropy
+                        res[k] = NAN;
+                        if (xo + k < A.nx) {
+                            const float c = A.cube[z * A.plane_stride + (int64_t)o * A.row_stride + xo + k];
+                            bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
+                            if (ARR) inc = inc && A.mask.arr[z * A.mask.plane_stride + (int64_t)o * A.mask.row_stride + xo + k] != 0;
+                            if (inc) res[k] = c;
+                        }
+                    }
+                }
+                if (R <= kPairedStoreMaxR && pairable) {
+                    store_run8_paired(dst, t & 1, f32x4{res[0], res[1], res[2], res[3]}, f32x4{res[4], res[5], res[6], res[7]});
+                } else if (xo + kRun <= A.nx && ((((uintptr_t)dst) & 15) == 0)) {
+                    *reinterpret_cast<f32x4*>(dst) = f32x4{res[0], res[1], res[2], res[3]};
+                    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{res[4], res[5], res[6], res[7]};
+                } else {
+    #pragma unroll
+                    for (int k = 0; k < kRun; ++k)
+                        if (xo + k < A.nx) dst[k] = res[k];
+                }
+            }
+        };
+        // ---- y pass (a group of rows at a time where the ring is grouped)
 #pragma unroll
         for (int s = 0; s < R; ++s) {
             float2v x2 = classify<R, ARR, PRED>(v[s], ARR ? mk[s] : (unsigned char)1, lim, lo, hi);
@@ -407,60 +472,22 @@ __global__ __launch_bounds__(kThreads) void spatial_sep_kernel(const SpArgs A) {
                 if (a == 0) pk_mul_w(acc[m], A.ky, 2 * H - a, x2);
                 else pk_fma_w(acc[m], A.ky, 2 * H - a, x2);
             }
-            // row o = i0 + s - H is complete: park it in LDS slot s
-            yres[s * kPitch + lds_phys(t)] = acc[(s + 1) % R];
-        }
-        lds_barrier();
-        if (t0 + R < T) load_rows(i0 + R);                // in flight during the x pass
-        // ---- x pass over the R rows of this revolution
-        for (int task = t; task < R * nrun_eff; task += nthr) {
-            const int s = (int)(((float)task + 0.5f) * inv_nrun);    // exact: task < 2^10, nrun <= 31
-            const int j = task - s * nrun_eff;
-            const int o = i0 + s - H;                     // output row
-            if (o < yb || o >= ye) continue;
-            float2v r[kRun];
-#pragma unroll
-            for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
-            const float2v* src = yres + s * kPitch;
-#pragma unroll
-            for (int i = 0; i < kRun + 2 * H; ++i) {
-                const float2v in = src[lds_phys(kRun * j + i)];
-#pragma unroll
-                for (int k = 0; k < kRun; ++k) {
-                    const int widx = k + 2 * H - i;       // kx index for output k, input i
-                    if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
-                }
-            }
-            const int64_t xo = x0 + kRun * j;
-            float* dst = A.out + z * A.out_plane_stride + (int64_t)o * A.out_row_stride + xo;
-            float res[kRun];
-#pragma unroll
-            for (int k = 0; k < kRun; ++k) {
-                if (r[k].y != 0.f) {
-                    res[k] = r[k].x * __builtin_amdgcn_rcpf(r[k].y);
-                } else {
-                    // empty window -> (filled) centre sample, like astropy
-                    res[k] = NAN;
-                    if (xo + k < A.nx) {
-                        const float c = A.cube[z * A.plane_stride + (int64_t)o * A.row_stride + xo + k];
-                        bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
-                        if (ARR) inc = inc && A.mask.arr[z * A.mask.plane_stride + (int64_t)o * A.mask.row_stride + xo + k] != 0;
-                        if (inc) res[k] = c;
-                    }
-                }
-            }
-            if (R <= kPairedStoreMaxR && pairable) {
-                store_run8_paired(dst, t & 1, f32x4{res[0], res[1], res[2], res[3]}, f32x4{res[4], res[5], res[6], res[7]});
-            } else if (xo + kRun <= A.nx && ((((uintptr_t)dst) & 15) == 0)) {
-                *reinterpret_cast<f32x4*>(dst) = f32x4{res[0], res[1], res[2], res[3]};
-                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{res[4], res[5], res[6], res[7]};
-            } else {
-#pragma unroll
-                for (int k = 0; k < kRun; ++k)
-                    if (xo + k < A.nx) dst[k] = res[k];
+            // row o = i0 + s - H is complete: park it in the group's LDS slot
+            yres[(s % kGen) * kPitch + lds_phys(t)] = acc[(s + 1) % R];
+            if (kGrouped && t0 + R < T) load_row(i0 + R, s);   // in flight during the rest of this revolution
+            if (kGrouped && (s % kGen == kGen - 1 || s == R - 1)) {
+                const int gs = (s / kGen) * kGen;         // first row slot of the group
+                lds_barrier();
+                xpass(gs, s - gs + 1);
+                lds_barrier();
             }
         }
-        lds_barrier();
+        if (!kGrouped) {                                  // one group: the whole revolution
+            lds_barrier();
+            if (t0 + R < T) load_rows(i0 + R);            // every row has been used: in flight during the x pass
+            xpass(0, R);
+            lds_barrier();
+        }
     }
 }
 

@@ -258,12 +258,14 @@ __global__ __launch_bounds__(256) void weighted_moments_kernel(const WmArgs A) {
         }
         bad = bad || !(chk[c] == chk[c]);
     }
-    // a 128-column tile = 32 lanes: if ANY of them is bad the whole tile is left to the general
-    // kernel (no output line is then written by both kernels)
+    // 32 lanes = 128 columns of this ROW: if ANY of them is bad, all of them leave their spaxels to the general kernel.
+    // The tile flags are indexed by the LINEAR spaxel number (128 spaxels per flag), so a half-wave of a row whose
+    // length is no multiple of 128 can lie in two flag tiles: every lane that quits flags the tile of ITS spaxels (only
+    // the bad lane did: the rest of a half-wave in the neighbouring, clean flag tile was then written by nobody).
     const unsigned long long bm = __ballot(bad && live);
     const bool tile_bad = ((lane < 32) ? (bm & 0xffffffffull) : (bm >> 32)) != 0;
     if (!live) return;
-    if (tile_bad) { if (bad) spc_flag_set(A.status + ((y * A.nx + x) >> 7)); return; }
+    if (tile_bad) { spc_flag_set(A.status + ((y * A.nx + x) >> 7)); return; }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int64_t o = y * A.mo_row_stride + x + c;

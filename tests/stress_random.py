@@ -84,6 +84,8 @@ for it in range(nround):
         f0 = O.moment(sm, inc, 0, cen, 1.3)
         rf = ops.spectral_conv_moments(dd, k, dev(cen - cref), dv=1.3, m1_add=cref + 10.0, mask=spec, want=("m0",), cen_host=cen - cref)
         close(rf["m0"].get(), f0, 1e-5, tag + " fused m0 taps%d" % nt)
+        if os.environ.get("SPC_STRESS_DUMP") == str(it):
+            np.savez("gpurun_out/stress_dump.npz", d=d, k=k, cen=cen, f0=f0, got=rf["m0"].get(), sm=sm)
     # spatial smoothing: separable and not
     ky = int(rng.choice([3, 9, 17, 29])); g = np.exp(-0.5 * (np.arange(-(ky // 2), ky // 2 + 1) / (ky / 6.0)) ** 2)
     k2 = np.outer(g, g)

@@ -415,3 +415,30 @@ def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
         assert np.mean(np.isnan(got) != np.isnan(exp)) < 2e-4, kw    # float32-vs-float64 bounds: borderline samples only
         ok = ~np.isnan(got) & ~np.isnan(exp)
         assert np.array_equal(got[ok], exp[ok])
+
+
+@pytest.mark.parametrize("shape", [(1, 68, 76), (7, 33, 100), (40, 9, 260)])
+def test_fused_smooth_moments_rows_across_flag_tiles(gpu, shape):
+    """smooth -> moments on a cube whose rows are no multiple of 128 spaxels, with a few NaNs: the algebraic pass works
+    in row segments, the tile flags that hand spaxels to the stencil kernel are per 128 LINEAR spaxels - a segment that
+    quits because of a NaN lies in up to two flag tiles and must flag both (a clean neighbouring tile used to keep
+    whatever the output buffer held).  The output buffers are poisoned first."""
+    from spectral_cube_amd import ops
+    from spectral_cube_amd.device import DeviceArray
+    rng = np.random.default_rng(shape[2])
+    nz = shape[0]
+    d = (rng.standard_normal(shape) * 3 + 1).astype(np.float32)
+    d[rng.random(shape) < 0.02 / max(nz // 4, 1)] = np.nan
+    k = np.abs(rng.standard_normal(15)) + 0.05
+    cen = np.cumsum(rng.uniform(0.5, 1.5, nz))
+    cref = cen[nz // 2]
+    sm = O.spectral_smooth(d, None, k)
+    e0 = O.moment(sm, None, 0, cen, 1.3)
+    e1 = O.moment(sm, None, 1, cen, 1.3, world0=10.0)
+    out = {"m0": DeviceArray.from_numpy(np.full(shape[1:], 1e30)), "m1": DeviceArray.from_numpy(np.full(shape[1:], 1e30))}
+    r = ops.spectral_conv_moments(DeviceArray.from_numpy(d), k, DeviceArray.from_numpy(cen - cref), dv=1.3, m1_add=cref + 10.0,
+                                  want=("m0", "m1"), cen_host=cen - cref, out=out)
+    assert_close(r["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="fused m0")
+    with np.errstate(all="ignore"):
+        wc = np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0))
+    assert_close(np.where(wc, r["m1"].get(), 0.0), np.where(wc, e1, 0.0), atol=1e-5 * max(cen[-1] - cen[0], 1.0), what="fused m1")
