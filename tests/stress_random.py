@@ -113,4 +113,33 @@ for it in range(nround):
     ob, of = ops.resample_bilinear(dd, xs, ys, mask=spec, fill=np.nan)
     close(ob.get(), eb, 1e-5, tag + " bilinear")
     if not np.array_equal(of.get().astype(bool), ef[0]): fails += 1; print("FAIL", tag, "footprint", flush=True)
+# tall, thin cubes: the register-resident selection / sigma-clip kernels at every (spaxels per block, keys per lane)
+# combination, the z-split of the masked spectral stencil
+for it in range(max(nround // 5, 2)):
+    nz, ny, nx = int(rng.integers(90, 2100)), int(rng.integers(1, 4)), int(rng.integers(1, 45))
+    d = (rng.standard_normal((nz, ny, nx)) * 2).astype(np.float32)
+    d[rng.random(d.shape) < 0.03] *= 9.0
+    d[rng.random(d.shape) < rng.choice([0.0, 0.02])] = np.nan
+    if rng.random() < 0.5: d = np.round(d * 2) / 2                    # ties
+    inc = rng.random(d.shape) > rng.choice([0.0, 0.3])
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=dev(inc.astype(np.uint8)))
+    tag = "tall%d %s" % (it, (nz, ny, nx))
+    dd = dev(d)
+    fz = np.where(inc, d, np.nan).astype(np.float32)
+    q = float(rng.choice([50.0, rng.uniform(0, 100)]))
+    exp = np.nanpercentile(fz.astype(np.float64), q, axis=0) if q != 50.0 else np.nanmedian(fz, axis=0)
+    close(ops.percentile_axis0(dd, q, mask=spec).get(), exp, 0.0 if q == 50.0 else 3e-6, tag + " pct%g" % q)
+    kw = dict(sigma=float(rng.uniform(1.5, 3.5)), maxiters=[1, 3, 5, None][int(rng.integers(0, 4))], cenfunc=str(rng.choice(["median", "mean"])))
+    os.environ.pop("SPC_SIGMA_CLIP_FUSED", None)
+    got = ops.sigma_clip_axis0(dd, mask=spec, **kw).get()
+    os.environ["SPC_SIGMA_CLIP_FUSED"] = "0"
+    ref = ops.sigma_clip_axis0(dd, mask=spec, **kw).get()
+    os.environ.pop("SPC_SIGMA_CLIP_FUSED")
+    if not np.array_equal(got, ref, equal_nan=True): fails += 1; print("FAIL", tag, "sigma_clip fused != loop", kw, int((np.isnan(got) != np.isnan(ref)).sum()), flush=True)
+    eo = O.sigma_clip(d, inc & ~np.isnan(d), **kw)
+    if np.mean(np.isnan(got) != np.isnan(eo)) > 5e-4: fails += 1; print("FAIL", tag, "sigma_clip vs oracle", kw, float(np.mean(np.isnan(got) != np.isnan(eo))), flush=True)
+    nt = int(rng.choice([9, 17, 33]))
+    k = np.abs(rng.standard_normal(nt)) + 0.05
+    if rng.random() < 0.5: k = k + k[::-1]
+    close(ops.spectral_conv(dd, k, mask=spec).get(), O.spectral_smooth(d, inc, k), 1e-5, tag + " sconv%d" % nt)
 print("rounds", nround, "failures", fails)
