@@ -398,6 +398,18 @@ def run_sharded(args, device, rdv):
         gather(0, wl.stream)
     elapsed = timed(step_serial)
 
+    # (1b) the same ONE call with the stitch hidden inside it (distributed.ChunkedMoments): the rank's rows in 4 blocks,
+    # the all-gather of a block's three maps on a second stream under the kernel of the next block.  Nothing is carried
+    # across calls: a call starts when the previous one has completed.  Needs the device all-gather.
+    chunked, elapsed_chunked = None, None
+    if stitch == "rccl" and rows % 64 == 0:
+        from spectral_cube_amd.distributed import ChunkedMoments
+        chunked = ChunkedMoments(cube, maskd, wl.d_cen, 500.0, wl.cref + wl.v[0], comm, chunks=4, workspace=wl.ws)
+
+        def step_chunked(i):
+            chunked(wl.stream, comm_stream)
+        elapsed_chunked = timed(step_chunked)
+
     # (2) pipelined: the stitch of step k on its own stream under the kernel of step k+1
     ev_kernel, ev_comm = [Event(device), Event(device)], [Event(device), Event(device)]
     count = [0]
@@ -438,6 +450,17 @@ def run_sharded(args, device, rdv):
     wl.stream.synchronize()
     full = recvs[0].get()                                   # (world, 3, rows, NX)
     verify = wl.verify([full[rank, k] for k in range(3)], tile, tmask, 4)
+    if chunked is not None:                                 # and the maps of the chunked call: every block of this rank
+        maps = chunked(wl.stream, comm_stream)
+        wl.stream.synchronize()
+        hm = [maps[k].get() for k in ("m0", "m1", "m2")]
+        for c in range(chunked.chunks):
+            g0, g1 = chunked.global_rows(rank, c)
+            wl.verify([m[g0:g1] for m in hm], tile, tmask, 4)
+            # block c of this rank = local rows [c * rc, (c + 1) * rc) = the strip's rows in the one-launch maps
+            for k in range(3):
+                assert np.array_equal(hm[k][g0:g1], full[rank, k][c * chunked.rc:(c + 1) * chunked.rc], equal_nan=True), \
+                    "chunked call disagrees with the one-launch call"
     # and that every rank holds the SAME stitched maps
     digest = [float(np.nansum(full[:, k])) for k in range(3)]
     digests = rdv.allgather_object(digest)
@@ -448,19 +471,29 @@ def run_sharded(args, device, rdv):
         comm.close()
 
     total = NZ * NY * NX
+    # the contract's value: ONE call at a time; with the device all-gather the call hides its stitch under its own
+    # kernel (chunked), otherwise kernel then stitch
+    best = elapsed if elapsed_chunked is None else min(elapsed, elapsed_chunked)
+    call_form = "rows in 4 blocks, all-gather of a block under the kernel of the next" if best != elapsed else "one launch, then one all-gather"
     line = {
-        "metric": METRIC, "value": total * args.steps / elapsed / 1e6, "unit": "Mvoxel/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "metric": METRIC, "value": total * args.steps / best / 1e6, "unit": "Mvoxel/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": best / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "north star: fixed %dx%dx%d fp32 cube + uint8 mask sharded by row strips over %d GPUs "
                                "(%d rows each), fused moment0+1+2 per strip + ONE all-gather stitching the three "
-                               "float64 maps on every rank; per call, nothing overlapped" % (NZ, NY, NX, world, rows),
+                               "float64 maps on every rank; ONE call at a time%s" % (
+                                   NZ, NY, NX, world, rows,
+                                   " - the rank's rows in 4 blocks (block-cyclic ownership), the all-gather of a block's maps "
+                                   "under the kernel of the next block, nothing carried across calls" if best != elapsed
+                                   else ", kernel then stitch, nothing overlapped"),
                    "input_dtype": "f32 cube + u8 mask, sums carried in f64, f64 maps out",
                    "mask_valid_fraction": float(np.mean(vfrac)), "stitch": stitch,
                    "sharding": "row strips (nz, %d, nx) of a %dx%dx%d cube" % (rows, NZ, NY, NX),
                    "allgather_bytes_per_rank": 3 * rows * NX * 8,
                    "device": device_info(device)["name"] or device_info(device)["arch"]},
-        "per_call": {"kernel_ms": k_ms_max, "allgather_ms": g_ms, "latency_ms": elapsed / args.steps * 1e3},
+        "per_call": {"kernel_ms": k_ms_max, "allgather_ms": g_ms, "latency_ms": best / args.steps * 1e3, "form": call_form,
+                     "latency_unoverlapped_ms": elapsed / args.steps * 1e3,
+                     "latency_chunked_ms": None if elapsed_chunked is None else elapsed_chunked / args.steps * 1e3},
         "pipelined": {"value": total * args.steps / elapsed_pipe / 1e6, "unit": "Mvoxel/s",
                       "ms_per_step": elapsed_pipe / args.steps * 1e3,
                       "note": "all-gather of step k on its own stream under the kernel of step k+1 (double buffered)"},
@@ -494,6 +527,13 @@ def main():
     else:
         line = run_single(args, device)
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(tuple(args.shape), args.cpu_seconds)
+    # whatever the native libraries still hold in the C stdio buffer (RCCL prints a version banner at init) goes out first:
+    # the JSON line is the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     if rank == 0:
         print(json.dumps(line), flush=True)
 

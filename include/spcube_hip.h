@@ -465,6 +465,10 @@ int spc_comm_init(int device, const uint8_t id[SPC_COMM_ID_BYTES], int nranks,
 int spc_comm_destroy(void* comm);
 int spc_allgather_rows(void* comm, void* stream, const void* d_send, void* d_recv,
                        size_t bytes_per_rank);
+/* n all-gathers in ONE grouped launch (ncclGroupStart / ncclGroupEnd): e.g. the three moment maps of a row chunk,
+ * each gathered into its own destination map. */
+int spc_allgather_rows_batch(void* comm, void* stream, int n, const void* const* d_send, void* const* d_recv,
+                             const size_t* bytes_per_rank);
 
 #ifdef __cplusplus
 }

@@ -150,6 +150,7 @@ SIGNATURES = {
     "spc_comm_init": (_i, [_i, _P(C.c_uint8), _i, _i, _P(_vp)]),
     "spc_comm_destroy": (_i, [_vp]),
     "spc_allgather_rows": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "spc_allgather_rows_batch": (_i, [_vp, _vp, _i, _P(_vp), _P(_vp), _P(_sz)]),
 }
 
 _lib = None

@@ -69,4 +69,24 @@ int spc_allgather_rows(void* comm, void* stream, const void* d_send, void* d_rec
     return SPC_OK;
 }
 
+// n all-gathers as ONE grouped RCCL launch (ncclGroupStart / End): the three moment maps of one row chunk, each into
+// its own destination map, without three launch latencies.
+int spc_allgather_rows_batch(void* comm, void* stream, int n, const void* const* d_send, void* const* d_recv,
+                             const size_t* bytes_per_rank) {
+    SPC_REQUIRE(comm && d_send && d_recv && bytes_per_rank && n >= 1 && n <= 64, "bad argument");
+    SpcComm* c = (SpcComm*)comm;
+    SPC_DEVICE(c->device);
+    SPC_NCCL(ncclGroupStart());
+    for (int i = 0; i < n; ++i) {
+        ncclResult_t r = ncclAllGather(d_send[i], d_recv[i], bytes_per_rank[i], ncclChar, c->comm, (hipStream_t)stream);
+        if (r != ncclSuccess) {
+            (void)ncclGroupEnd();
+            spc_set_error("ncclAllGather failed: %s", ncclGetErrorString(r));
+            return SPC_ERR_COMM;
+        }
+    }
+    SPC_NCCL(ncclGroupEnd());
+    return SPC_OK;
+}
+
 }  // extern "C"

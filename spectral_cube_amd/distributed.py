@@ -138,6 +138,18 @@ class RcclComm:
                   C.c_void_p(recv_dev.ptr), strip_dev.nbytes)
         return recv_dev
 
+    def allgather_batch(self, pairs, stream=None):
+        """several all-gathers in ONE grouped RCCL launch.  pairs: [(send DeviceArray, (destination pointer, bytes the
+        destination holds))] - every send has the same shape on every rank, its destination world_size times its size."""
+        n = len(pairs)
+        sends = (C.c_void_p * n)(*[p[0].ptr for p in pairs])
+        recvs = (C.c_void_p * n)(*[p[1][0] for p in pairs])
+        sizes = (C.c_size_t * n)(*[p[0].nbytes for p in pairs])
+        for send, (_, room) in pairs:
+            if room < send.nbytes * self.world_size:
+                raise ValueError("receive region must hold world_size strips")
+        _lib.call("spc_allgather_rows_batch", self._h, _sh(stream), n, sends, recvs, sizes)
+
     def allgather_rows(self, strip_dev, ny_total, stream=None):
         rows = strip_rows(ny_total, self.world_size)
         if strip_dev.shape[0] != rows:
@@ -156,6 +168,56 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+class ChunkedMoments:
+    """moment 0 / 1 / 2 of a row-sharded cube with the stitch hidden INSIDE the call: the rank's rows are taken in
+    `chunks` blocks; the kernel of block c+1 runs while the maps of block c are all-gathered on a second stream (one
+    grouped RCCL launch for the three maps of a block).  Row ownership is block-cyclic - with `rc` rows per block, block c
+    of rank r holds the rows c * (ny_total / chunks) + r * rc + [0, rc) of the cube - so that every all-gather lands its
+    world_size blocks in natural row order and the three (ny_total, nx) maps need no re-layout.  The latency of one call is
+    the kernel time plus the all-gather of the LAST block, instead of kernel + whole all-gather.
+    cube / mask_array: this rank's (nz, chunks * rc, nx) DeviceArrays (local row block c = cube rows [c * rc, (c+1) * rc))."""
+
+    def __init__(self, cube, mask_array, d_cen, dv, m1_add, comm, chunks=4, workspace=None):
+        from . import ops
+        self.ops, self.comm = ops, comm
+        nz, rows, nx = cube.shape
+        if rows % chunks:
+            raise ValueError("the rank's %d rows do not split into %d chunks" % (rows, chunks))
+        self.chunks, self.rc, self.nx = chunks, rows // chunks, nx
+        self.ny_total = rows * comm.world_size
+        dev = cube.device
+        self.args = dict(dv=dv, m1_add=m1_add, want=("m0", "m1", "m2"), workspace=workspace)
+        self.d_cen = d_cen
+        rc = self.rc
+        self.cubes = [cube.rows(c * rc, (c + 1) * rc) for c in range(chunks)]
+        self.masks = [None if mask_array is None else ops.MaskSpec(_lib.MASK_ARRAY, array=mask_array.rows(c * rc, (c + 1) * rc))
+                      for c in range(chunks)]
+        self.sends = [{k: DeviceArray((rc, nx), np.float64, dev) for k in ("m0", "m1", "m2")} for _ in range(chunks)]
+        self.maps = {k: DeviceArray((self.ny_total, nx), np.float64, dev) for k in ("m0", "m1", "m2")}
+        from .device import Event
+        self.ev = [Event(dev) for _ in range(chunks)]
+        self.ev_done = Event(dev)
+
+    def __call__(self, stream, comm_stream):
+        """enqueue one call; the maps are complete when `stream` has drained (it waits for the last all-gather)."""
+        block = self.rc * self.nx * 8
+        for c in range(self.chunks):
+            self.ops.moments(self.cubes[c], self.d_cen, mask=self.masks[c], stream=stream, out=self.sends[c], **self.args)
+            self.ev[c].record(stream)
+            comm_stream.wait_event(self.ev[c])
+            base = c * self.comm.world_size * block
+            self.comm.allgather_batch([(self.sends[c][k], (self.maps[k].ptr + base, self.comm.world_size * block))
+                                       for k in ("m0", "m1", "m2")], comm_stream)
+        self.ev_done.record(comm_stream)
+        stream.wait_event(self.ev_done)
+        return self.maps
+
+    def global_rows(self, rank, c):
+        """rows of the cube that block c of `rank` holds"""
+        y0 = c * (self.ny_total // self.chunks) + rank * self.rc
+        return y0, y0 + self.rc
 
 
 def _stitch(strip, ny_total, comm, pad_value=np.nan):

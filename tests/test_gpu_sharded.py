@@ -209,3 +209,37 @@ def test_sharded_percentile_whole_cube(gpu, ws):
     whole = DeviceArray.from_numpy(d)
     wspec = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
     assert ops.percentile_global(whole, 30.0, mask=wspec) == results[0][30.0]
+
+
+def test_chunked_moments_hide_the_stitch(gpu):
+    """distributed.ChunkedMoments: the rank's rows in blocks, the grouped RCCL all-gather of a block's three maps on a
+    second stream under the kernel of the next block.  With one rank (RCCL initialises on a 1-GPU box) the gathered
+    maps must equal the one-launch moments of the whole strip bit for bit; called twice (events are reused)."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import Stream
+    from spectral_cube_amd.rendezvous import SingleProcess
+    shape = (24, 64, 40)
+    d = synth.gaussian_line_cube(shape, 7)
+    m = synth.boolean_mask(d, 7)
+    dd, dm = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m)
+    cen = np.arange(shape[0]) * 500.0
+    cref = cen[shape[0] // 2]
+    d_cen = DeviceArray.from_numpy(cen - cref)
+    whole = ops.moments(dd, d_cen, dv=500.0, m1_add=cref - 3.0, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=dm), want=("m0", "m1", "m2"))
+    try:
+        comm = D.RcclComm(0, SingleProcess())
+    except Exception as exc:                       # pragma: no cover - RCCL missing on the box
+        pytest.skip("RCCL did not initialise: %s" % exc)
+    try:
+        cm = D.ChunkedMoments(dd, dm, d_cen, 500.0, cref - 3.0, comm, chunks=4)
+        s1, s2 = Stream(0), Stream(0)
+        for _ in range(2):
+            maps = cm(s1, s2)
+            s1.synchronize()
+            for k in ("m0", "m1", "m2"):
+                assert np.array_equal(maps[k].get(), whole[k].get(), equal_nan=True), k
+        assert cm.global_rows(0, 2) == (32, 48)
+        with pytest.raises(ValueError):
+            D.ChunkedMoments(dd, dm, d_cen, 500.0, 0.0, comm, chunks=5)
+    finally:
+        comm.close()
