@@ -303,7 +303,7 @@ int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, cons
 /* The whole loop in ONE kernel for centre = median (center_is_mean = 0) or mean and spread = std: the rays stay in
  * registers across the iterations, the cube is read once and the clipped copy written once (d_out: (nz,ny,nx)
  * C-contiguous float32; masked and clipped samples NaN).  maxiters < 0: until nothing changes.  Same arithmetic as
- * the pieces above (float64 sums, float32 centre and bounds).  Rays of more than 2048 channels: SPC_ERR_UNSUPPORTED. */
+ * the pieces above (float64 sums, float32 centre and bounds).  Rays of more than 4096 channels: SPC_ERR_UNSUPPORTED. */
 int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                              double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
                              float* d_out);

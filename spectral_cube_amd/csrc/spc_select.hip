@@ -426,7 +426,7 @@ __device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, dou
 }
 
 template <int TS, int KPL, bool ARR>
-__global__ __launch_bounds__(256, 5) void select_reg_kernel(const SelArgs A) {
+__global__ __launch_bounds__(256, KPL == 128 ? 2 : 5) void select_reg_kernel(const SelArgs A) {
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = 256 / TS;
     const int t = threadIdx.x;
@@ -496,7 +496,7 @@ struct ClipRegArgs {
 };
 
 template <int TS, int KPL, bool ARR>
-__global__ __launch_bounds__(256, 4) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+__global__ __launch_bounds__(256, KPL == 128 ? 1 : 4) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = 256 / TS;
     __shared__ double part_s[TS][kLanesPerRay], part_q[TS][kLanesPerRay];
@@ -692,14 +692,14 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
                     ((((uintptr_t)cube->d_data) & 15) == 0) &&
                     (!arr || ((A.mask.row_stride % 4 == 0) && (A.mask.plane_stride % 4 == 0) && ((((uintptr_t)A.mask.arr) & 3) == 0)));
     hipStream_t st = (hipStream_t)stream;
-    // rays in registers (one read of the cube): up to 64 keys per lane, nz <= 512 / 1024 / 2048 for 32 / 16 / 8 spaxels
+    // rays in registers (one read of the cube): up to 128 keys per lane, nz <= 512 / 1024 / 4096 for 32 / 16 / 8 spaxels
     // per block; any strides (a y-ray view included)
     const char* renv = getenv("SPC_SELECT_REG");
-    if ((renv ? atoi(renv) != 0 : true) && cube->nz <= 2048 && cube->ny * ((cube->nx + 7) / 8) < (1LL << 31)) {
+    if ((renv ? atoi(renv) != 0 : true) && cube->nz <= 4096 && cube->ny * ((cube->nx + 7) / 8) < (1LL << 31)) {
         const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
         const int lanes = 256 / ts;
         const int need = (int)((cube->nz + lanes - 1) / lanes);
-        const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+        const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : (need <= 64 ? 64 : 128));   // 128: 2049 - 4096 channels, 8 spaxels per block
         const int64_t nblk = cube->ny * ((cube->nx + ts - 1) / ts);
         dim3 grid((unsigned)nblk);
 #define SPC_LAUNCH_REG(TS_, K_)                                                                                     \
@@ -711,7 +711,7 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
         do {                                                                                                        \
             if (kpl == 16) SPC_LAUNCH_REG(TS_, 16); else if (kpl == 32) SPC_LAUNCH_REG(TS_, 32); else SPC_LAUNCH_REG(TS_, 64); \
         } while (0)
-        if (ts == 32) SPC_LAUNCH_REG_K(32); else if (ts == 16) SPC_LAUNCH_REG_K(16); else SPC_LAUNCH_REG_K(8);
+        if (kpl == 128) SPC_LAUNCH_REG(8, 128); else if (ts == 32) SPC_LAUNCH_REG_K(32); else if (ts == 16) SPC_LAUNCH_REG_K(16); else SPC_LAUNCH_REG_K(8);
 #undef SPC_LAUNCH_REG_K
 #undef SPC_LAUNCH_REG
         SPC_LAUNCH_CHECK();
@@ -816,7 +816,7 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
 
 // astropy.stats.sigma_clip(axis=0, masked=False, cenfunc = median | mean, stdfunc = std) with the rays resident in
 // registers (sigma_clip_reg_kernel): one read and one write of the cube for all iterations.  d_out: (nz, ny, nx)
-// C-contiguous float32, masked and clipped samples NaN.  Rays longer than 2048 channels: SPC_ERR_UNSUPPORTED (the
+// C-contiguous float32, masked and clipped samples NaN.  Rays longer than 4096 channels: SPC_ERR_UNSUPPORTED (the
 // caller iterates spc_percentile_axis0_f32 / spc_stats_axis_f32 / spc_clip_outside_f32 instead).
 extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                                         double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
@@ -824,8 +824,8 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     int rc = spc_check_cube_any_order(cube);
     if (rc) return rc;
     SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
-    if (cube->nz > 2048 || cube->ny * ((cube->nx + 7) / 8) >= (1LL << 31)) {
-        spc_set_error("rays of %lld channels do not fit the registers of a block", (long long)cube->nz);
+    if (cube->nz > 4096 || cube->ny * ((cube->nx + 7) / 8) >= (1LL << 31)) {
+        spc_set_error("rays of %lld channels do not fit the registers of a block (4096 at most)", (long long)cube->nz);
         return SPC_ERR_UNSUPPORTED;
     }
     ClipRegArgs A{};
@@ -842,7 +842,7 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
     const int lanes = 256 / ts;
     const int need = (int)((cube->nz + lanes - 1) / lanes);
-    const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : 64);
+    const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : (need <= 64 ? 64 : 128));
     dim3 grid((unsigned)(cube->ny * ((cube->nx + ts - 1) / ts)));
 #define SPC_LAUNCH_CLIP(TS_, K_)                                                                                    \
     do {                                                                                                            \
@@ -853,7 +853,7 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     do {                                                                                                            \
         if (kpl == 16) SPC_LAUNCH_CLIP(TS_, 16); else if (kpl == 32) SPC_LAUNCH_CLIP(TS_, 32); else SPC_LAUNCH_CLIP(TS_, 64); \
     } while (0)
-    if (ts == 32) SPC_LAUNCH_CLIP_K(32); else if (ts == 16) SPC_LAUNCH_CLIP_K(16); else SPC_LAUNCH_CLIP_K(8);
+    if (kpl == 128) SPC_LAUNCH_CLIP(8, 128); else if (ts == 32) SPC_LAUNCH_CLIP_K(32); else if (ts == 16) SPC_LAUNCH_CLIP_K(16); else SPC_LAUNCH_CLIP_K(8);
 #undef SPC_LAUNCH_CLIP_K
 #undef SPC_LAUNCH_CLIP
     SPC_LAUNCH_CHECK();

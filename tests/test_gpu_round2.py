@@ -279,10 +279,10 @@ def test_chunk_functions_under_dask_map_blocks(gpu, tmp_path):
     assert r.returncode == 0 and "DASK_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (515, 2, 37), (1030, 2, 21), (2050, 1, 12)])
+@pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (515, 2, 37), (1030, 2, 21), (2050, 1, 12), (4100, 1, 5)])
 def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
     """np.nanmedian / np.nanpercentile of masked rays through every selection kernel: the register-resident rays
-    (32 / 16 / 8 spaxels per block by ray length, lengths that are no multiple of the lanes per ray, tiles hanging
+    (32 / 16 / 8 spaxels per block and 16 - 128 keys per lane by ray length, lengths that are no multiple of the lanes per ray, tiles hanging
     over the row end; with the early ranking of the surviving candidates and - on the tie-heavy column - without),
     and - by switch - the streaming radix-16 and bisection descents that longer rays fall back to.  Medians are
     bit-exact; MAD (centre per spaxel) goes through the same kernels."""
@@ -386,7 +386,7 @@ def test_spectral_smooth_wide_symmetric_rings(gpu, ntaps, monkeypatch):
     assert np.mean(got[ok] != ref[ok]) < 0.01          # different float64 summation order: rare float32 flips only
 
 
-@pytest.mark.parametrize("shape", [(9, 4, 11), (60, 3, 70), (515, 2, 37), (1030, 2, 21)])
+@pytest.mark.parametrize("shape", [(9, 4, 11), (60, 3, 70), (515, 2, 37), (1030, 2, 21), (2100, 2, 9)])
 def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
     """sigma clipping with the rays resident in registers (one kernel for all iterations) against the oracle's
     restatement of astropy.stats.sigma_clip(axis=0) and against the loop of separate kernels (the same clipped set:
