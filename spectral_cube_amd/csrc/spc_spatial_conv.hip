@@ -464,7 +464,11 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
     A.status = nullptr;
     A.inv_ksum = (float)(1.0 / sum);
     canonical_pred(A);
-    if (want && al && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && nysplit == 1 && R <= 33 && cube->nx >= 64) {
+    // (the 65-tap ring - 35 to 65 taps - has an all-valid kernel for isotropic kernels only: two sets of 65 weights do
+    // not fit the SGPR file)
+    bool iso65 = R == 65;
+    for (int i = 0; iso65 && i < 65; ++i) iso65 = A.ky[i] == A.kx[i];
+    if (want && al && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && nysplit == 1 && (R <= 33 || iso65) && cube->nx >= 64) {
         A.fast_nstrips = (int)((cube->nx + fast_txo(R) - 1) / fast_txo(R));
         const size_t nt = (size_t)A.fast_nstrips * (size_t)cube->nz;
         SpcWorkspace ws(d_workspace, workspace_bytes);

@@ -110,7 +110,7 @@ constexpr int fast_ngroups(int R) { return (R + kGroupRows - 1) / kGroupRows; }
 // v_readlane (measured: 755 per revolution next to 1044 FMAs).
 // waves per SIMD the register budget is cut for: 4 (128 VGPRs) up to 29 taps, 3 beyond (a 33-slot ring of
 // pairs alone is 66 registers)
-constexpr int fast_waves(int R) { return R <= 29 ? 4 : 3; }
+constexpr int fast_waves(int R) { return R <= 29 ? 4 : (R <= 33 ? 3 : 2); }
 template <int R, bool ISO>
 __global__ __launch_bounds__(kThreads, fast_waves(R)) void spatial_sep_fast_kernel(const SpArgs A) {
     constexpr int H = R / 2;
@@ -514,11 +514,12 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
     dim3 block(kThreads);
     bool iso = true;
     for (int i = 0; i < R; ++i) iso = iso && (A.ky[i] == A.kx[i]);
-    if constexpr (R <= 33) {
+    if constexpr (R <= 33 || R == 65) {
         if (A.status) {      // speculative all-valid pass (the general kernel below redoes dirty tiles)
             dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1);
             if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true>), fgrid, block, 0, st, A);
-            else hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
+            else if constexpr (R <= 33) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
+            // (65 taps: the host only asks for this pass when kx == ky - two weight sets do not fit the SGPR file)
             SPC_LAUNCH_CHECK();
         }
     }
