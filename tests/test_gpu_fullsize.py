@@ -379,3 +379,30 @@ def test_c2_order_statistics_and_argextrema_1024cubed(gpu):
     a1 = ops.argextrema_axis(cube, 1, mask=mspec)
     assert np.array_equal(a1["argmax"].get(), O.argmax(tile, tmask, axis=1))          # first period wins the ties
     assert np.array_equal(a1["argmin"].get(), O.argmin(tile, tmask, axis=1))
+
+
+def test_c2_sigma_clip_1024cubed_periodic_rows(gpu):
+    """sigma_clip_spectrally at configs[1] size (1024^3 + uint8 mask, a tile replicated along y) through the one-kernel
+    form: clipping is per ray, so the result is periodic in y and every period equals the oracle's clipped tile (the
+    same samples survive, bit for bit; borderline samples at the float32-vs-float64 bounds allowed for: < 2e-5 of them);
+    64-bit addressing of the clipped copy (4 GiB written)."""
+    shape, ty = (1024, 1024, 1024), 8
+    _need(shape[0] * shape[1] * shape[2] * (4 + 4 + 1) * 1.2)
+    rng = np.random.default_rng(77)
+    tile = rng.standard_normal((shape[0], ty, shape[2])).astype(np.float32)
+    tile[rng.random(tile.shape) < 0.02] *= 15.0
+    tile[:, 2, 16:24] = np.nan
+    tmask = rng.random(tile.shape) < 0.9
+    cube, mask = DeviceArray(shape, np.float32), DeviceArray(shape, np.uint8)
+    _replicate_rows(cube, tile, 4)
+    _replicate_rows(mask, tmask.astype(np.uint8), 1)
+    out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mask))
+    exp = O.sigma_clip(tile, tmask & ~np.isnan(tile), 3.0)
+    rep = shape[1] // ty
+    whole = out.get()
+    for period in (0, rep // 3, rep - 1):
+        got = whole[:, period * ty:(period + 1) * ty]
+        assert np.mean(np.isnan(got) != np.isnan(exp)) < 2e-5
+        ok = ~np.isnan(got) & ~np.isnan(exp)
+        assert np.array_equal(got[ok], exp[ok])
+        assert np.array_equal(got, whole[:, :ty], equal_nan=True)
