@@ -42,6 +42,7 @@ class _PinnedPool:
     last array viewing it is collected, and is unpinned once the pool holds more than *max_bytes* idle."""
 
     MIN_BYTES = 1 << 20          # smaller results use plain numpy memory
+    MAX_BYTES = 1 << 30          # larger ones too (pinning tens of GiB of host memory is not this pool's business)
 
     def __init__(self, max_bytes=1 << 30):
         import threading
@@ -176,9 +177,13 @@ class DeviceArray:
     def get(self, stream=None):
         if getattr(self, "_is_view", False):
             raise ValueError("strided row view: copy through the parent array")
-        if self.nbytes >= _PinnedPool.MIN_BYTES:
-            out = pinned_pool.array(self.shape, self.dtype)
-        else:
+        out = None
+        if _PinnedPool.MIN_BYTES <= self.nbytes <= _PinnedPool.MAX_BYTES:   # maps and small cubes; whole cubes stay pageable
+            try:
+                out = pinned_pool.array(self.shape, self.dtype)
+            except (MemoryError, _lib.HipLibraryError):
+                out = None
+        if out is None:
             out = np.empty(self.shape, dtype=self.dtype)
         if stream is not None:
             _lib.call("spc_stream_sync", self.device, _sh(stream))
