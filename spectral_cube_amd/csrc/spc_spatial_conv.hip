@@ -29,6 +29,7 @@ extern template int launch_sep<9>(const SpArgs&, hipStream_t, dim3, bool);
 extern template int launch_sep<17>(const SpArgs&, hipStream_t, dim3, bool);
 extern template int launch_sep<29>(const SpArgs&, hipStream_t, dim3, bool);
 extern template int launch_sep<33>(const SpArgs&, hipStream_t, dim3, bool);
+extern template int launch_sep<49>(const SpArgs&, hipStream_t, dim3, bool);
 extern template int launch_sep<65>(const SpArgs&, hipStream_t, dim3, bool);
 }
 using namespace spc_spconv;
@@ -313,7 +314,7 @@ int64_t wide_chunk_planes(int64_t nz, int64_t plane) {
 size_t spc_ws_spatial_conv_sep(int64_t nz, int64_t ny, int64_t nx, int64_t nky, int64_t nkx) {
     const int R = pick_ring((int)std::max(nky, nkx));
     if (R) {                                                    // tile flags of the speculative pass: strips x channels
-        const int64_t nstrips = (nx + fast_txo(33) - 1) / fast_txo(33);      // the narrowest strips of any ring
+        const int64_t nstrips = (nx + fast_txo(65) - 1) / fast_txo(65);      // the narrowest strips of any ring
         return spc_ws_round((size_t)(nstrips * nz)) + 256;
     }
     const int64_t nyp = std::max<int64_t>(nky, 17);
@@ -464,10 +465,10 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
     A.status = nullptr;
     A.inv_ksum = (float)(1.0 / sum);
     canonical_pred(A);
-    // (the 65-tap ring - 35 to 65 taps - has an all-valid kernel for isotropic kernels only: two sets of 65 weights do
-    // not fit the SGPR file)
-    bool iso65 = R == 65;
-    for (int i = 0; iso65 && i < 65; ++i) iso65 = A.ky[i] == A.kx[i];
+    // (the 49- and 65-tap rings - 35 to 65 taps - have an all-valid kernel for isotropic kernels only: two sets of
+    // that many weights do not fit the SGPR file)
+    bool iso65 = R == 49 || R == 65;
+    for (int i = 0; iso65 && i < R; ++i) iso65 = A.ky[i] == A.kx[i];
     if (want && al && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 && nysplit == 1 && (R <= 33 || iso65) && cube->nx >= 64) {
         A.fast_nstrips = (int)((cube->nx + fast_txo(R) - 1) / fast_txo(R));
         const size_t nt = (size_t)A.fast_nstrips * (size_t)cube->nz;
@@ -481,6 +482,7 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
         case 17: rc = launch_sep<17>(A, st, grid, arr); break;
         case 29: rc = launch_sep<29>(A, st, grid, arr); break;
         case 33: rc = launch_sep<33>(A, st, grid, arr); break;
+        case 49: rc = launch_sep<49>(A, st, grid, arr); break;
         case 65: rc = launch_sep<65>(A, st, grid, arr); break;
         default: spc_set_error("no ring kernel for R=%d", R); rc = SPC_ERR_UNSUPPORTED;
     }

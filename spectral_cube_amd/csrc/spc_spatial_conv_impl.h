@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
 
 
 inline int pick_ring(int ntaps) {
-    const int rings[] = {9, 17, 29, 33, 65};
+    const int rings[] = {9, 17, 29, 33, 49, 65};
     for (int r : rings) if (ntaps <= r) return r;
     return 0;
 }
@@ -514,12 +514,12 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
     dim3 block(kThreads);
     bool iso = true;
     for (int i = 0; i < R; ++i) iso = iso && (A.ky[i] == A.kx[i]);
-    if constexpr (R <= 33 || R == 65) {
+    if constexpr (R <= 33 || R == 49 || R == 65) {
         if (A.status) {      // speculative all-valid pass (the general kernel below redoes dirty tiles)
             dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1);
             if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true>), fgrid, block, 0, st, A);
             else if constexpr (R <= 33) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
-            // (65 taps: the host only asks for this pass when kx == ky - two weight sets do not fit the SGPR file)
+            // (49 / 65 taps: the host only asks for this pass when kx == ky - two weight sets do not fit the SGPR file)
             SPC_LAUNCH_CHECK();
         }
     }

@@ -442,3 +442,28 @@ def test_fused_smooth_moments_rows_across_flag_tiles(gpu, shape):
     with np.errstate(all="ignore"):
         wc = np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0))
     assert_close(np.where(wc, r["m1"].get(), 0.0), np.where(wc, e1, 0.0), atol=1e-5 * max(cen[-1] - cen[0], 1.0), what="fused m1")
+
+
+@pytest.mark.parametrize("taps", [(41, 41), (57, 57), (41, 35), (65, 65)])
+def test_spatial_smooth_wide_rings(gpu, taps):
+    """separable spatial kernels of 35 - 65 taps (the 49- and 65-tap rings): the all-valid pass (isotropic kernels
+    only), a plane with a NaN (its strip is redone by the general kernel), a mask array, and an anisotropic pair of
+    kernels that has no all-valid kernel - all against the oracle at the contract tolerance."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    ny_t, nx_t = taps
+    rng = np.random.default_rng(ny_t + nx_t)
+    shape = (3, 90, 600)
+    d = rng.standard_normal(shape).astype(np.float32) + 2.0
+    d[1, 40, 300] = np.nan
+    gy = np.exp(-0.5 * ((np.arange(ny_t) - ny_t // 2) / (ny_t / 8.0)) ** 2)
+    gx = np.exp(-0.5 * ((np.arange(nx_t) - nx_t // 2) / (nx_t / 8.0)) ** 2)
+    k2 = np.outer(gy, gx)
+    dd = DeviceArray.from_numpy(d)
+    exp = O.spatial_smooth(d, np.isfinite(d), k2)
+    got = ops.spatial_conv(dd, k2, mask=ops.MaskSpec(_lib.MASK_FINITE)).get()
+    assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="finite mask %s" % (taps,))
+    inc = rng.random(shape) < 0.7
+    expm = O.spatial_smooth(d, inc & np.isfinite(d), k2)
+    gotm = ops.spatial_conv(dd, k2, mask=ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))).get()
+    assert_close(gotm, expm, atol=1e-5 * np.nanmax(np.abs(expm)), what="array mask %s" % (taps,))
