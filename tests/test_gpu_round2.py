@@ -453,7 +453,7 @@ def test_spatial_smooth_wide_rings(gpu, taps):
     from spectral_cube_amd.device import DeviceArray
     ny_t, nx_t = taps
     rng = np.random.default_rng(ny_t + nx_t)
-    shape = (3, 90, 600)
+    shape = (3, 90, 900)       # 900 columns: 3 strips of the 65-tap all-valid kernel, 2 of the 33-tap one (workspace bound)
     d = rng.standard_normal(shape).astype(np.float32) + 2.0
     d[1, 40, 300] = np.nan
     gy = np.exp(-0.5 * ((np.arange(ny_t) - ny_t // 2) / (ny_t / 8.0)) ** 2)
