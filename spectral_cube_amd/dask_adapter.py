@@ -57,6 +57,25 @@ class SpatialSmoothChunk:
         return out.astype(chunk.dtype, copy=False)
 
 
+class SigmaClipChunk:
+    """drop-in for the chunk function of ``sigma_clip_spectrally`` (dask_spectral_cube.py:851-878: astropy's
+    ``sigma_clip(chunk, sigma=threshold, axis=0, masked=False, **kwargs)`` under
+    ``apply_function_parallel_spectral(accepts_chunks=True)`` - the operation docs/dask.rst:176-275 times): the whole
+    clip loop of a chunk is one kernel with the rays resident in registers."""
+
+    def __init__(self, threshold, device=0, **kwargs):
+        unknown = set(kwargs) - {"sigma_lower", "sigma_upper", "maxiters", "cenfunc", "stdfunc"}
+        if unknown:
+            raise NotImplementedError("sigma_clip options not on the device path: %s" % sorted(unknown))
+        self.threshold, self.kwargs, self.device = float(threshold), kwargs, device
+
+    def __call__(self, chunk, **ignored):
+        if chunk.size == 0:
+            return chunk
+        out = ops.sigma_clip_axis0(_stage(chunk, self.device), sigma=self.threshold, **self.kwargs).get()
+        return out.astype(chunk.dtype, copy=False)
+
+
 class MomentChunk:
     """reduced chunk function (use with ``drop_axis=[0]``): moment map of a
     ``(nz, cy, cx)`` chunk.  ``pix_cen`` = offsets from channel 0, ``pix_size``

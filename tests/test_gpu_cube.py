@@ -261,6 +261,15 @@ def test_dask_chunk_functions(gpu):
         exp = O.moment(chunk, None, order, cen, 0.5, world0=-7.0)
         with np.errstate(all="ignore"):
             assert_close(out, exp, rtol=1e-7, atol=1e-9 * np.nanmax(np.abs(exp)), what="chunk moment")
+    # the chunk function of sigma_clip_spectrally (the operation docs/dask.rst times)
+    spiky = chunk.copy()
+    spiky[rng.random(chunk.shape) < 0.05] *= 20.0
+    out = A.SigmaClipChunk(2.5, maxiters=3)(spiky)
+    exp = O.sigma_clip(spiky, ~np.isnan(spiky), 2.5, maxiters=3)
+    assert out.shape == spiky.shape and out.dtype == spiky.dtype
+    assert np.array_equal(np.isnan(out), np.isnan(exp)) and np.array_equal(out[~np.isnan(exp)], exp[~np.isnan(exp)])
+    with pytest.raises(NotImplementedError):
+        A.SigmaClipChunk(3.0, grow=1)
 
 
 def test_statistics_and_reductions(gpu):
