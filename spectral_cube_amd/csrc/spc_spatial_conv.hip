@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256) void spatial_conv2d_tiled_kernel(const SpArgs 
     const int pitch = tcols | 1;                           // odd pitch in float2 units
     const int64_t z = blockIdx.z;
     const int64_t X0 = (int64_t)blockIdx.x * kT2X, Y0 = (int64_t)blockIdx.y * kT2Y;
+    // tiles already finished by the all-valid pass (its tiles are two of these wide)
+    if (A.status && spc_flag_get(A.status + (z * gridDim.y + blockIdx.y) * A.fast_nstrips + (blockIdx.x >> 1)) == 0) return;
     const float* p = A.cube + z * A.plane_stride;
     const uint8_t* pm = ARR ? A.mask.arr + z * A.mask.plane_stride : nullptr;
     // true convolution: out[y][x] = sum k[jy][jx] in[y + hy - jy][x + hx - jx]; tile row r holds input
@@ -188,6 +190,82 @@ __global__ __launch_bounds__(256) void spatial_conv2d_tiled_kernel(const SpArgs 
             res = inc ? c : NAN;
         }
         A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
+    }
+}
+
+// ---- all-valid pass of the tiled 2-D stencil ------------------------------------------------------------
+// The kernel above carries (value * valid, valid) pairs: with every sample valid half of each packed FMA is spent on a
+// denominator that is the kernel sum.  This pass owns a 128 x 32 output tile and packs TWO COLUMNS 64 apart into the
+// pair instead - (in[r][c], in[r][c + 64]) share every weight - so the same instruction stream produces twice the
+// outputs, out = num * (1 / sum k).  A block that meets an excluded sample in its tile or halo flags the tile and
+// quits; the kernel above then redoes the flagged tiles (speculation as in the separable stencils).
+__global__ __launch_bounds__(256) void spatial_conv2d_allvalid_kernel(const SpArgs A, const float* kern, int nky, int nkx) {
+    extern __shared__ float2v tile[];                     // (kT2Y + nky - 1) x pitch pairs (column c, column c + 64)
+    const int hy = nky / 2, hx = nkx / 2;
+    const int trows = kT2Y + nky - 1, tcols = kT2X + nkx - 1;
+    const int pitch = tcols | 1;
+    const int64_t z = blockIdx.z;
+    const int64_t X0 = (int64_t)blockIdx.x * (2 * kT2X), Y0 = (int64_t)blockIdx.y * kT2Y;
+    const float* p = A.cube + z * A.plane_stride;
+    bool bad = false;
+    for (int e = threadIdx.x; e < trows * tcols; e += 256) {
+        const int r = e / tcols, c = e - r * tcols;
+        const int64_t iy = Y0 - hy + r, ix = X0 - hx + c;
+        float2v val = float2v{0.f, 0.f};                   // outside the image: a valid zero
+        if (iy >= 0 && iy < A.ny) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t ixh = ix + h * kT2X;
+                if (ixh >= 0 && ixh < A.nx) {
+                    const float v = p[iy * A.row_stride + ixh];
+                    bad = bad || !(spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v));
+                    if (h == 0) val.x = v; else val.y = v;
+                }
+            }
+        }
+        tile[r * pitch + c] = val;
+    }
+    if (__syncthreads_or(bad ? 1 : 0)) {
+        if (threadIdx.x == 0) spc_flag_set(A.status + (z * gridDim.y + blockIdx.y) * A.fast_nstrips + blockIdx.x);
+        return;
+    }
+    const int tx = threadIdx.x & 63, ty = (threadIdx.x >> 6) * kT2Run;
+    float2v acc[kT2Run];
+#pragma unroll
+    for (int o = 0; o < kT2Run; ++o) acc[o] = float2v{0.f, 0.f};
+    const int wpitch = nky + 14;                            // (the weight table and the chunk walk of the kernel above)
+    auto chunk = [&](const float2v* col, const float* wp, int r0, int mode, int nrows) {
+        float w[15];
+#pragma unroll
+        for (int q = 0; q < 15; ++q) w[q] = wp[q];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (mode == 1 && i >= nrows) break;
+            const float2v in = col[(r0 + i) * pitch];
+#pragma unroll
+            for (int o = 0; o < kT2Run; ++o) {
+                const bool on = (mode == 0) ? (o <= i) : (mode == 2) ? (i <= o) : true;
+                if (on) acc[o] = __builtin_elementwise_fma(float2v{w[7 - i + o], w[7 - i + o]}, in, acc[o]);
+            }
+        }
+    };
+    for (int jx = 0; jx < nkx; ++jx) {
+        const float2v* col = tile + ty * pitch + tx + (nkx - 1 - jx);
+        const float* wcol = kern + (size_t)jx * wpitch;
+        chunk(col, wcol + (nky - 1), 0, 0, 8);
+        int r0 = 8;
+        for (; r0 + 8 <= nky - 1; r0 += 8) chunk(col, wcol + (nky - 1 - r0), r0, 1, 8);
+        if (r0 < nky - 1) chunk(col, wcol + (nky - 1 - r0), r0, 1, nky - 1 - r0);
+        chunk(col, wcol + 0, nky - 1, 2, 8);
+    }
+    const int64_t x = X0 + tx;
+#pragma unroll
+    for (int o = 0; o < kT2Run; ++o) {
+        const int64_t y = Y0 + ty + o;
+        if (y >= A.ny) break;
+        float* q = A.out + z * A.out_plane_stride + y * A.out_row_stride;
+        if (x < A.nx) q[x] = acc[o].x * A.inv_ksum;
+        if (x + kT2X < A.nx) q[x + kT2X] = acc[o].y * A.inv_ksum;
     }
 }
 
@@ -322,8 +400,9 @@ size_t spc_ws_spatial_conv_sep(int64_t nz, int64_t ny, int64_t nx, int64_t nky, 
            spc_ws_round(sizeof(float2v) * (size_t)(wide_chunk_planes(nz, ny * nx) * ny * nx)) + 512;
 }
 
-size_t spc_ws_spatial_conv2d(int64_t, int64_t, int64_t, int64_t nky, int64_t nkx) {
-    return spc_ws_round(sizeof(float) * (size_t)(nkx * (nky + 14))) + 256;
+size_t spc_ws_spatial_conv2d(int64_t nz, int64_t ny, int64_t nx, int64_t nky, int64_t nkx) {
+    const int64_t ntiles = nz * ((ny + kT2Y - 1) / kT2Y) * ((nx + 2 * kT2X - 1) / (2 * kT2X));   // flags of the all-valid pass
+    return spc_ws_round(sizeof(float) * (size_t)(nkx * (nky + 14))) + spc_ws_round((size_t)ntiles) + 256;
 }
 
 extern "C" {
@@ -368,6 +447,23 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, c
             if (lds > 48 * 1024) {      // dynamic LDS beyond the default limit has to be requested
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_tiled_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_tiled_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            }
+            // masks that only reject non-finite samples: the all-valid pass first, then the flagged tiles
+            const char* fenv = getenv("SPC_CONV_FAST");
+            A.status = nullptr;
+            if ((fenv ? atoi(fenv) != 0 : true) && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0) {
+                double sumf = 0.0;                      // the denominator the general kernel accumulates: float32 taps
+                for (int i = 0; i < nky * nkx; ++i) sumf += (double)(float)h_kernel[i];
+                A.inv_ksum = (float)(1.0 / sumf);
+                A.fast_nstrips = (int)((cube->nx + 2 * kT2X - 1) / (2 * kT2X));
+                const size_t nt = (size_t)cube->nz * grid.y * (size_t)A.fast_nstrips;
+                SPC_WS_TAKE(d_status, ws, unsigned char, nt);
+                SPC_HIP(spc_flags_clear(d_status, nt, st));
+                A.status = d_status;
+                if (lds > 48 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_allvalid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(spatial_conv2d_allvalid_kernel, dim3((unsigned)A.fast_nstrips, grid.y, grid.z), dim3(256), lds, st, A, d_k, nky, nkx);
+                SPC_LAUNCH_CHECK();
             }
             if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(spatial_conv2d_tiled_kernel<true>, grid, dim3(256), lds, st, A, d_k, nky, nkx);
             else hipLaunchKernelGGL(spatial_conv2d_tiled_kernel<false>, grid, dim3(256), lds, st, A, d_k, nky, nkx);

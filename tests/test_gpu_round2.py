@@ -467,3 +467,27 @@ def test_spatial_smooth_wide_rings(gpu, taps):
     expm = O.spatial_smooth(d, inc & np.isfinite(d), k2)
     gotm = ops.spatial_conv(dd, k2, mask=ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))).get()
     assert_close(gotm, expm, atol=1e-5 * np.nanmax(np.abs(expm)), what="array mask %s" % (taps,))
+
+
+def test_nonseparable_stencil_all_valid_pass(gpu, monkeypatch):
+    """rotated elliptical kernel (what convolve_to builds): the all-valid pass of the tiled 2-D stencil packs two columns
+    per FMA and hands flagged tiles to the (num, den) kernel - a plane with one NaN (one 128 x 32 tile and the tiles
+    whose halo reaches it are redone), a clean plane, image sizes that leave partial tiles; against the oracle and
+    against the (num, den) kernel alone (SPC_CONV_FAST=0) to float32 rounding."""
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    rng = np.random.default_rng(8)
+    shape = (2, 75, 330)
+    d = rng.standard_normal(shape).astype(np.float32) + 1.0
+    d[1, 40, 200] = np.nan
+    yy, xx = np.mgrid[-6:7, -6:7]
+    kn = np.exp(-0.5 * (((xx + 0.5 * yy) / 2.0) ** 2 + (yy / 1.2) ** 2))
+    dd = DeviceArray.from_numpy(d)
+    exp = O.spatial_smooth(d, np.isfinite(d), kn)
+    out = DeviceArray.from_numpy(np.full(shape, 1e30, np.float32))
+    got = ops.spatial_conv(dd, kn, mask=ops.MaskSpec(_lib.MASK_FINITE), out=out).get()
+    assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="two-pass 2-D stencil")
+    monkeypatch.setenv("SPC_CONV_FAST", "0")
+    ref = ops.spatial_conv(dd, kn, mask=ops.MaskSpec(_lib.MASK_FINITE)).get()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.nanmax(np.abs(got - ref)) <= 4e-7 * np.nanmax(np.abs(ref))
