@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void spatial_conv2d_tiled_kernel(const SpArgs 
 // pair instead - (in[r][c], in[r][c + 64]) share every weight - so the same instruction stream produces twice the
 // outputs, out = num * (1 / sum k).  A block that meets an excluded sample in its tile or halo flags the tile and
 // quits; the kernel above then redoes the flagged tiles (speculation as in the separable stencils).
+template <bool SCAL>
 __global__ __launch_bounds__(256) void spatial_conv2d_allvalid_kernel(const SpArgs A, const float* kern, int nky, int nkx) {
     extern __shared__ float2v tile[];                     // (kT2Y + nky - 1) x pitch pairs (column c, column c + 64)
     const int hy = nky / 2, hx = nkx / 2;
@@ -235,9 +236,12 @@ __global__ __launch_bounds__(256) void spatial_conv2d_allvalid_kernel(const SpAr
     for (int o = 0; o < kT2Run; ++o) acc[o] = float2v{0.f, 0.f};
     const int wpitch = nky + 14;                            // (the weight table and the chunk walk of the kernel above)
     auto chunk = [&](const float2v* col, const float* wp, int r0, int mode, int nrows) {
+        // SCAL (weight table <= 4 KB): read through the constant address space - scalar loads that stay in the scalar
+        // cache (13 x 13 taps: 9.1 -> 6.7 ms); larger tables thrash it (41 x 41: 49 -> 59 ms) and use plain loads
+        typedef const float __attribute__((address_space(4))) cfloat;
         float w[15];
 #pragma unroll
-        for (int q = 0; q < 15; ++q) w[q] = wp[q];
+        for (int q = 0; q < 15; ++q) w[q] = SCAL ? ((cfloat*)wp)[q] : wp[q];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             if (mode == 1 && i >= nrows) break;
@@ -460,9 +464,14 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube, c
                 SPC_WS_TAKE(d_status, ws, unsigned char, nt);
                 SPC_HIP(spc_flags_clear(d_status, nt, st));
                 A.status = d_status;
-                if (lds > 48 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_allvalid_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                hipLaunchKernelGGL(spatial_conv2d_allvalid_kernel, dim3((unsigned)A.fast_nstrips, grid.y, grid.z), dim3(256), lds, st, A, d_k, nky, nkx);
+                const bool scal = (size_t)nkx * (nky + 14) * sizeof(float) <= 4096;
+                if (lds > 48 * 1024) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_allvalid_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spatial_conv2d_allvalid_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                }
+                const dim3 fgrid((unsigned)A.fast_nstrips, grid.y, grid.z);
+                if (scal) hipLaunchKernelGGL(spatial_conv2d_allvalid_kernel<true>, fgrid, dim3(256), lds, st, A, d_k, nky, nkx);
+                else hipLaunchKernelGGL(spatial_conv2d_allvalid_kernel<false>, fgrid, dim3(256), lds, st, A, d_k, nky, nkx);
                 SPC_LAUNCH_CHECK();
             }
             if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(spatial_conv2d_tiled_kernel<true>, grid, dim3(256), lds, st, A, d_k, nky, nkx);
