@@ -88,12 +88,16 @@ __global__ __launch_bounds__(256) void spectral_conv_generic_kernel(const ConvAr
 // no ring; same astropy semantics (zero fill, NaN renormalisation, empty window -> centre sample).
 struct double2w { double x, y; };
 
-template <bool ARR>
+// ALLV: speculative all-valid form - numerators only (the denominator of an all-valid window is the kernel sum: samples
+// outside the cube are valid zeros), half the FMAs; a wavefront that meets an excluded sample flags its tile and quits,
+// the (num, den) form then redoes the flagged tiles.
+template <bool ARR, bool ALLV>
 __global__ __launch_bounds__(256, 3) void spectral_conv_wide_kernel(const ConvArgs A, const double* kpad, int ntaps) {
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= A.ny * A.nx) return;
-    // tiles (128 columns) already finished by an all-valid ring pass
-    if (A.status && spc_flag_get(A.status + __builtin_amdgcn_readfirstlane((int)(col >> 7))) == 0) return;
+    // tiles (128 columns) already finished by an all-valid pass
+    if (!ALLV && A.status && spc_flag_get(A.status + __builtin_amdgcn_readfirstlane((int)(col >> 7))) == 0) return;
+    bool bad = false;
     const int64_t y = col / A.nx, x = col - y * A.nx;
     const int H = ntaps / 2;
     const float* p = A.cube + y * A.row_stride + x;
@@ -111,6 +115,7 @@ __global__ __launch_bounds__(256, 3) void spectral_conv_wide_kernel(const ConvAr
             const float v = p[i * A.plane_stride];
             bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v);
             if (ARR) ok = ok && pm[i * A.mask.plane_stride] != 0;
+            if (ALLV) bad = bad || !ok;
             return ok ? double2w{(double)v, 1.0} : double2w{0.0, 0.0};
         };
         // chunk of 8 planes r0 .. r0+7; weight of (plane r0 + i, output q) = k[ntaps-1-(r0+i)+q] = wp[7 - i + q],
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, 3) void spectral_conv_wide_kernel(const ConvAr
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const bool on = (mode == 0) ? (q <= i + off) : (mode == 2) ? (q >= i + off) : true;
-                    if (on) { acc[q].x = fma(w[7 - i + q], in.x, acc[q].x); acc[q].y = fma(w[7 - i + q], in.y, acc[q].y); }
+                    if (on) { acc[q].x = fma(w[7 - i + q], in.x, acc[q].x); if (!ALLV) acc[q].y = fma(w[7 - i + q], in.y, acc[q].y); }
                 }
             }
         };
@@ -140,6 +145,19 @@ __global__ __launch_bounds__(256, 3) void spectral_conv_wide_kernel(const ConvAr
         if (r0 < ntaps - 1) chunk(r0, 1, 0, ntaps - 1 - r0);
         chunk(ntaps - 1, 2, 0, 8);                          // planes ntaps-1 .. ntaps+6: outputs q >= r - (ntaps-1)
         chunk(ntaps + 7, 2, 8, 8);                          // planes ntaps+7 .. ntaps+14
+        if (ALLV) {
+            if (__any(bad)) {                              // wave-uniform: the (num, den) kernel redoes this tile
+                if ((threadIdx.x & 63) == 0) spc_flag_set(A.status + (col >> 7));
+                return;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int64_t o = o0 + q;
+                if (o >= ze) break;
+                A.out[y * A.out_row_stride + x + o * A.out_plane_stride] = (float)(acc[q].x / A.ksum);
+            }
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int64_t o = o0 + q;
@@ -464,8 +482,23 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
         // whole runs of 16 per z slice
         A.zchunk = ((A.zchunk + 15) / 16) * 16;
         dim3 wgrid((unsigned)nblocks, (unsigned)((cube->nz + A.zchunk - 1) / A.zchunk));
-        if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL(spectral_conv_wide_kernel<true>, wgrid, dim3(256), 0, st, A, d_k, ntaps);
-        else hipLaunchKernelGGL(spectral_conv_wide_kernel<false>, wgrid, dim3(256), 0, st, A, d_k, ntaps);
+        // no ring pass ran (asymmetric kernel or more than 65 taps) and the mask only rejects non-finite samples: the
+        // numerator-only form first
+        {
+            const char* fenv = getenv("SPC_CONV_FAST");
+            if (!A.status && (fenv ? atoi(fenv) != 0 : true) && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0) {
+                SPC_WS_TAKE(d_status, ws, unsigned char, (ncols + 127) / 128);
+                SPC_HIP(spc_flags_clear(d_status, (size_t)((ncols + 127) / 128), st));
+                A.status = d_status;
+                double ks = 0.0;
+                for (int i = 0; i < ntaps; ++i) ks += h_kernel[i];
+                A.ksum = ks;
+                hipLaunchKernelGGL((spectral_conv_wide_kernel<false, true>), wgrid, dim3(256), 0, st, A, d_k, ntaps);
+                SPC_LAUNCH_CHECK();
+            }
+        }
+        if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL((spectral_conv_wide_kernel<true, false>), wgrid, dim3(256), 0, st, A, d_k, ntaps);
+        else hipLaunchKernelGGL((spectral_conv_wide_kernel<false, false>), wgrid, dim3(256), 0, st, A, d_k, ntaps);
     } else {
         hipLaunchKernelGGL(spectral_conv_generic_kernel, grid, dim3(256), 0, st, A, d_k, ntaps);
     }
