@@ -300,13 +300,14 @@ int spc_fill_masked_transpose_f32(int device, void* stream, const spc_cube_f32* 
  *                      *h_nchanged (HOST) = number of samples clipped by this call. */
 int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                         float fill, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);
-/* The whole loop in ONE kernel for centre = median (center_is_mean = 0) or mean and spread = std: the rays stay in
+/* The whole loop in ONE kernel for centre = median (center_is_mean = 0) or mean and spread = std (spread_is_mad = 0) or
+ * mad_std (1.4826 x the median of |x - median|, a second selection per iteration): the rays stay in
  * registers across the iterations, the cube is read once and the clipped copy written once (d_out: (nz,ny,nx)
  * C-contiguous float32; masked and clipped samples NaN).  maxiters < 0: until nothing changes.  Same arithmetic as
  * the pieces above (float64 sums, float32 centre and bounds).  Rays of more than 4096 channels: SPC_ERR_UNSUPPORTED. */
 int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                              double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
-                             float* d_out);
+                             int spread_is_mad, float* d_out);
 /* The include map of a mask evaluated on the cube it is bound to, as a uint8 (nz,ny,nx) array in
  * HBM: d_out = included ? 1 : 0 (MaskBase.include, masks.py:105-116).  For masks that belong to
  * ANOTHER cube's data - a smoothed cube keeps its parent's mask object (dask_spectral_cube.py:836-840):

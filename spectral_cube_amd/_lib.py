@@ -138,7 +138,7 @@ SIGNATURES = {
     "spc_percentile_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
     "spc_mask_include_u8": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp]),
     "spc_fill_masked_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp, _i64, _i64]),
-    "spc_sigma_clip_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _d, _i, _i, _vp]),
+    "spc_sigma_clip_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _d, _i, _i, _i, _vp]),
     "spc_clip_outside_f32": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _P(C.c_uint64), _vp, _sz]),
     "spc_map_conv2d_f64": (_i, [_i, _vp, _vp, _i64, _i64, _P(_d), _i, _i, _vp, _vp, _sz]),
     "spc_map_arith_f64": (_i, [_i, _vp, _i, _vp, _vp, _vp, _d, _vp, _i64]),

@@ -281,17 +281,31 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
 // where this one takes 2.5 - 3.2 ms.)
 constexpr int kCandMax = 32;
 
-template <int KPL, bool FIRST>
-__device__ __forceinline__ void count_keys(const uint32_t (&key)[KPL], uint32_t prefix, int b,
+// What a descent ranks: the resident keys themselves, or - for the MAD - the keys of |x - centre| formed on the fly
+// from the resident keys (float32 subtraction like numpy's; the excluded key stays the largest)
+struct KeyIdentity {
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const { return k; }
+};
+struct KeyAbsDev {
+    float center;
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const {
+        const float v = fabsf(funkey(k) - center);
+        return (k != 0xffffffffu && v == v) ? fkey(v) : 0xffffffffu;
+    }
+};
+
+template <int KPL, bool FIRST, class XF>
+__device__ __forceinline__ void count_keys(const uint32_t (&key)[KPL], uint32_t prefix, int b, const XF& xf,
                                            unsigned long long& accE, unsigned long long& accO) {
     constexpr unsigned long long kNib = 0x0f0f0f0f0f0f0f0full;
     unsigned long long a = 0ull;
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
+        const uint32_t ki = xf(key[i]);
         if (FIRST) {
-            a += 1ull << ((key[i] >> 28) * 4u);
+            a += 1ull << ((ki >> 28) * 4u);
         } else {
-            const uint32_t tt = (key[i] ^ prefix) >> b;          // < 16 exactly for the samples inside the prefix
+            const uint32_t tt = (ki ^ prefix) >> b;              // < 16 exactly for the samples inside the prefix
             const unsigned long long one = (tt < 16u) ? 1ull : 0ull;
             a += one << ((tt * 4u) & 63u);
         }
@@ -323,8 +337,8 @@ __device__ __forceinline__ void sel_reset(SelShared<TS>& S) {
 // The descent over the registers of the block (all 256 threads call it; barriers inside).  r / j: ray and slice of this
 // lane, n: valid samples of the ray.  Returns the keys of the two order statistics numpy's 'linear' percentile q
 // interpolates between and the interpolation fraction.  S must have been reset (sel_reset + barrier).
-template <int TS, int KPL>
-__device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&key)[KPL], int r, int j, int n, double q,
+template <int TS, int KPL, class XF>
+__device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&key)[KPL], const XF& xf, int r, int j, int n, double q,
                                            uint32_t& key_lo, uint32_t& key_hi, double& frac) {
     constexpr int kLanesPerRay = 256 / TS;
     const double pos = q / 100.0 * (double)(n > 0 ? n - 1 : 0);
@@ -344,8 +358,8 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
         // anything the loop changes - is not hoisted out of the loop and kept in 64 more registers)
         int popaque = pass;
         asm volatile("" : "+s"(popaque));
-        if (popaque == 0) count_keys<KPL, true>(key, prefix, b, accE, accO);
-        else count_keys<KPL, false>(key, prefix, b, accE, accO);
+        if (popaque == 0) count_keys<KPL, true>(key, prefix, b, xf, accE, accO);
+        else count_keys<KPL, false>(key, prefix, b, xf, accE, accO);
         uint32_t* h = S.hist[pass % 3][r];
         uint32_t* hz = S.hist[(pass + 1) % 3][r];
 #pragma unroll
@@ -377,9 +391,10 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
                 if (n > 0) {
 #pragma unroll
                     for (int i = 0; i < KPL; ++i) {
-                        if (((key[i] ^ prefix) >> 16) == 0u) {
+                        const uint32_t ki = xf(key[i]);
+                        if (((ki ^ prefix) >> 16) == 0u) {
                             const uint32_t slot = atomicAdd(&S.ncand[r], 1u);
-                            S.cand[r][slot] = key[i];
+                            S.cand[r][slot] = ki;
                         }
                     }
                 }
@@ -411,7 +426,7 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
         if (need_next) {
             uint32_t mn = 0xffffffffu;
 #pragma unroll
-            for (int i = 0; i < KPL; ++i) mn = (key[i] > prefix) ? min(mn, key[i]) : mn;
+            for (int i = 0; i < KPL; ++i) { const uint32_t ki = xf(key[i]); mn = (ki > prefix) ? min(mn, ki) : mn; }
             atomicMin(&S.nextkey[r], mn);
         }
         __syncthreads();
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(256, KPL == 128 ? 2 : 5) void select_reg_kernel(con
     const int n = (int)S.nvalid[r];
     uint32_t key_lo, key_hi;
     double frac;
-    ray_select<TS, KPL>(S, key, r, j, n, A.q, key_lo, key_hi, frac);
+    ray_select<TS, KPL>(S, key, KeyIdentity{}, r, j, n, A.q, key_lo, key_hi, frac);
     if (j == 0 && col_in) A.out[y * A.nx + x0 + r] = n > 0 ? sel_value(key_lo, key_hi, frac, (double)A.scale) : NAN;
 }
 
@@ -493,10 +508,11 @@ struct ClipRegArgs {
     double lo_s, hi_s;
     int maxiters;               // < 0: until convergence
     int cen_mean;               // centre: 0 median, 1 mean
+    int spread_mad;             // spread: 0 std, 1 mad_std
 };
 
-template <int TS, int KPL, bool ARR>
-__global__ __launch_bounds__(256, KPL == 128 ? 1 : 4) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+template <int TS, int KPL, bool ARR, bool MAD>
+__global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = 256 / TS;
     __shared__ double part_s[TS][kLanesPerRay], part_q[TS][kLanesPerRay];
@@ -561,11 +577,37 @@ __global__ __launch_bounds__(256, KPL == 128 ? 1 : 4) void sigma_clip_reg_kernel
             sd = (var != var) ? nan : sqrt(var > 0.0 ? var : 0.0);
         }
         double cen = mean;
-        if (!A.cen_mean) {
+        float med = NAN;
+        if (!A.cen_mean || MAD) {
             uint32_t key_lo, key_hi;
             double frac;
-            ray_select<TS, KPL>(S, key, r, j, n, 50.0, key_lo, key_hi, frac);
-            cen = n > 0 ? (double)sel_value(key_lo, key_hi, frac, 1.0) : (double)NAN;
+            ray_select<TS, KPL>(S, key, KeyIdentity{}, r, j, n, 50.0, key_lo, key_hi, frac);
+            med = n > 0 ? sel_value(key_lo, key_hi, frac, 1.0) : NAN;
+            if (!A.cen_mean) cen = (double)med;
+        }
+        if (MAD) {
+            // spread = 1.4826 x the median of |x - median| (astropy mad_std; float32 deviations like numpy's, the scale
+            // in float32 like spc_percentile_axis0_f32's argument): a second descent over the transformed keys
+            const KeyAbsDev xf{med};
+            __syncthreads();                                     // the first descent's last reads of S
+            sel_reset<TS>(S);
+            __syncthreads();
+            int nm = n;
+            if (__syncthreads_or((n > 0 && !(fabsf(med) <= 3.4028234664e38f)) ? 1 : 0)) {
+                // an infinite median: inf - inf deviations are NaN and drop out of the ray
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < KPL; ++i) c += (xf(key[i]) != 0xffffffffu) ? 1 : 0;
+                if (c) atomicAdd(&S.nvalid[r], (uint32_t)c);
+                __syncthreads();
+                nm = (int)S.nvalid[r];
+            }
+            uint32_t key_lo, key_hi;
+            double frac;
+            ray_select<TS, KPL>(S, key, xf, r, j, nm, 50.0, key_lo, key_hi, frac);
+            const float spread = nm > 0 ? sel_value(key_lo, key_hi, frac, (double)1.482602218505602f) : NAN;
+            sd = (double)spread;
+            if (A.cen_mean) cen = (double)(float)mean;           // (the loop of separate kernels hands a float32 mean map over)
         }
         const float lo = (float)__dsub_rn(cen, __dmul_rn(A.lo_s, sd));
         const float hi = (float)__dadd_rn(cen, __dmul_rn(A.hi_s, sd));
@@ -814,13 +856,13 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     return SPC_OK;
 }
 
-// astropy.stats.sigma_clip(axis=0, masked=False, cenfunc = median | mean, stdfunc = std) with the rays resident in
+// astropy.stats.sigma_clip(axis=0, masked=False, cenfunc = median | mean, stdfunc = std | mad_std) with the rays resident in
 // registers (sigma_clip_reg_kernel): one read and one write of the cube for all iterations.  d_out: (nz, ny, nx)
 // C-contiguous float32, masked and clipped samples NaN.  Rays longer than 4096 channels: SPC_ERR_UNSUPPORTED (the
 // caller iterates spc_percentile_axis0_f32 / spc_stats_axis_f32 / spc_clip_outside_f32 instead).
 extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                                         double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
-                                        float* d_out) {
+                                        int spread_is_mad, float* d_out) {
     int rc = spc_check_cube_any_order(cube);
     if (rc) return rc;
     SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
@@ -837,6 +879,7 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
     A.out = d_out;
     A.lo_s = sigma_lower; A.hi_s = sigma_upper; A.maxiters = maxiters; A.cen_mean = center_is_mean ? 1 : 0;
+    A.spread_mad = spread_is_mad ? 1 : 0;
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
     const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
@@ -846,8 +889,13 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     dim3 grid((unsigned)(cube->ny * ((cube->nx + ts - 1) / ts)));
 #define SPC_LAUNCH_CLIP(TS_, K_)                                                                                    \
     do {                                                                                                            \
-        if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true>), grid, dim3(256), 0, st, A);             \
-        else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false>), grid, dim3(256), 0, st, A);                \
+        if (A.spread_mad) {                                                                                         \
+            if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, true>), grid, dim3(256), 0, st, A);   \
+            else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, true>), grid, dim3(256), 0, st, A);      \
+        } else {                                                                                                    \
+            if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, false>), grid, dim3(256), 0, st, A);  \
+            else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, false>), grid, dim3(256), 0, st, A);     \
+        }                                                                                                           \
     } while (0)
 #define SPC_LAUNCH_CLIP_K(TS_)                                                                                      \
     do {                                                                                                            \

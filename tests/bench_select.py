@@ -31,3 +31,8 @@ import time
 t0 = time.perf_counter(); out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec); synchronize(); print("sigma_clip wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 t0 = time.perf_counter(); out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec); synchronize(); print("sigma_clip wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 t0 = time.perf_counter(); out = ops.sigma_clip_axis0(cube, sigma=3.0); synchronize(); print("sigma_clip (no mask) wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+t0 = time.perf_counter(); out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec, stdfunc="mad_std"); synchronize(); t0 = time.perf_counter()
+out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec, stdfunc="mad_std"); synchronize(); print("sigma_clip mad_std wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+os.environ["SPC_SIGMA_CLIP_FUSED"] = "0"
+out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec, stdfunc="mad_std"); synchronize(); t0 = time.perf_counter()
+out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=mspec, stdfunc="mad_std"); synchronize(); print("sigma_clip mad_std, loop of separate kernels, wall %.1f ms" % ((time.perf_counter() - t0) * 1e3))

@@ -129,7 +129,8 @@ for it in range(max(nround // 5, 2)):
     q = float(rng.choice([50.0, rng.uniform(0, 100)]))
     exp = np.nanpercentile(fz.astype(np.float64), q, axis=0) if q != 50.0 else np.nanmedian(fz, axis=0)
     close(ops.percentile_axis0(dd, q, mask=spec).get(), exp, 0.0 if q == 50.0 else 3e-6, tag + " pct%g" % q)
-    kw = dict(sigma=float(rng.uniform(1.5, 3.5)), maxiters=[1, 3, 5, None][int(rng.integers(0, 4))], cenfunc=str(rng.choice(["median", "mean"])))
+    kw = dict(sigma=float(rng.uniform(1.5, 3.5)), maxiters=[1, 3, 5, None][int(rng.integers(0, 4))], cenfunc=str(rng.choice(["median", "mean"])),
+              stdfunc=str(rng.choice(["std", "mad_std"])))
     os.environ.pop("SPC_SIGMA_CLIP_FUSED", None)
     got = ops.sigma_clip_axis0(dd, mask=spec, **kw).get()
     os.environ["SPC_SIGMA_CLIP_FUSED"] = "0"

@@ -390,7 +390,7 @@ def test_spectral_smooth_wide_symmetric_rings(gpu, ntaps, monkeypatch):
 def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
     """sigma clipping with the rays resident in registers (one kernel for all iterations) against the oracle's
     restatement of astropy.stats.sigma_clip(axis=0) and against the loop of separate kernels (the same clipped set:
-    both carry the sums in float64 and the bounds in float32): median and mean centres, asymmetric sigmas, iteration
+    both carry the sums in float64 and the bounds in float32): median and mean centres, std and mad_std spreads, asymmetric sigmas, iteration
     caps, a mask array, rays that are empty, constant, or hold infinities."""
     from spectral_cube_amd import ops, _lib
     from spectral_cube_amd.device import DeviceArray
@@ -404,7 +404,8 @@ def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
     inc = rng.random(shape) < 0.85
     dd = DeviceArray.from_numpy(d)
     spec = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
-    for kw in (dict(), dict(maxiters=1), dict(maxiters=None), dict(sigma_lower=1.5, sigma_upper=4.0), dict(cenfunc="mean")):
+    for kw in (dict(), dict(maxiters=1), dict(maxiters=None), dict(sigma_lower=1.5, sigma_upper=4.0), dict(cenfunc="mean"),
+               dict(stdfunc="mad_std"), dict(stdfunc="mad_std", cenfunc="mean", maxiters=3)):
         sig = 2.5
         monkeypatch.delenv("SPC_SIGMA_CLIP_FUSED", raising=False)
         got = ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get()
