@@ -371,11 +371,25 @@ __global__ __launch_bounds__(256) void arg_rows_kernel(const ArgArgs B) {
     ArgAcc a = arg_zero();
     const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
     const int64_t n4 = al ? A.nx / 4 : 0;
-    for (int64_t i = lane; i < n4; i += 64) {
-        const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
-        const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[i] : 0x01010101u;
+    // four 16-byte loads per lane in flight (a row is short: one wave per row lives on its load latency)
+    constexpr int U = 4;
+    for (int64_t i0 = lane; i0 < n4; i0 += 64 * U) {
+        f32x4 v[U];
+        uint32_t m[U];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) arg_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu), (int)(4 * i + c));
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = min(i0 + 64 * u, n4 - 1);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+            m[u] = ARR ? reinterpret_cast<const uint32_t*>(pm)[i] : 0x01010101u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + 64 * u;
+            if (i < n4) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) arg_add(a, v[u][c], included(A.mask, v[u][c], (m[u] >> (8 * c)) & 0xffu), (int)(4 * i + c));
+            }
+        }
     }
     for (int64_t j = n4 * 4 + lane; j < A.nx; j += 64) {
         const float v = p[j];
