@@ -261,6 +261,12 @@ int spc_argextrema_axis_f32(int device, void* stream, const spc_cube_f32* cube, 
 int spc_percentile_axis0_f32(int device, void* stream, const spc_cube_f32* cube,
                              const spc_mask* mask, double q, const float* d_center,
                              float scale, float* d_out);
+/* The same along x (axis 2) without a transposed copy: rays = the rows of the cube, which are contiguous; d_center and
+ * d_out are (nz, ny).  Rows of more than 4096 samples: SPC_ERR_UNSUPPORTED (transpose with
+ * spc_fill_masked_transpose_f32 and use the exchanged-stride form above). */
+int spc_percentile_axis2_f32(int device, void* stream, const spc_cube_f32* cube,
+                             const spc_mask* mask, double q, const float* d_center,
+                             float scale, float* d_out);
 
 /* The same statistic over the WHOLE cube (median / percentile / mad_std with axis=None): four
  * histogram passes over the key bytes.  With has_center the statistic is taken of

@@ -136,6 +136,7 @@ SIGNATURES = {
     "spc_resample_bilinear_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _i64, _i64, _vp, _vp,
                                        _vp, _i64, _i64, _vp, _i, _vp, _vp, _sz]),
     "spc_percentile_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
+    "spc_percentile_axis2_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
     "spc_mask_include_u8": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp]),
     "spc_fill_masked_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp, _i64, _i64]),
     "spc_sigma_clip_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _d, _i, _i, _i, _vp]),

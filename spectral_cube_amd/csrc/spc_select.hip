@@ -24,6 +24,11 @@ struct SelArgs {
     const float* center;      // NULL, or (ny, nx) map: select on |x - center|
     float scale;              // result multiplier (mad_std: 1.4826...)
     float* out;               // (ny, nx)
+    // register-resident kernel only: step between adjacent spaxels of a row (1 for rays along z or y; the row stride of
+    // the cube when the rays run along x) and whether consecutive LANES should walk along the ray (rays along x: the
+    // samples of a ray are the contiguous ones)
+    int64_t x_stride, m_x_stride;
+    int along_ray;
 };
 
 __device__ __forceinline__ uint32_t fkey(float v) {
@@ -445,14 +450,15 @@ __global__ __launch_bounds__(256, KPL == 128 ? 2 : 5) void select_reg_kernel(con
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = 256 / TS;
     const int t = threadIdx.x;
-    const int r = t % TS, j = t / TS;                           // ray of the tile, slice of the ray
+    // ray of the tile, slice of the ray: adjacent lanes hold adjacent spaxels - or, for rays along x, adjacent samples
+    const int r = A.along_ray ? t / kLanesPerRay : t % TS, j = A.along_ray ? t % kLanesPerRay : t / TS;
     const int64_t tiles_x = (A.nx + TS - 1) / TS;
     const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
     const int nz = (int)A.nz;
     const bool col_in = x0 + r < A.nx;
     const int64_t xc = col_in ? x0 + r : A.nx - 1;
-    const float* p = A.cube + y * A.row_stride + xc;
-    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc : nullptr;
+    const float* p = A.cube + y * A.row_stride + xc * A.x_stride;
+    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc * A.m_x_stride : nullptr;
     const bool use_cen = A.center != nullptr;
     const float cen = (use_cen && col_in) ? A.center[y * A.nx + x0 + r] : 0.f;
     sel_reset<TS>(S);
@@ -729,6 +735,7 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
     A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
     A.q = q; A.center = d_center; A.scale = scale; A.out = d_out;
+    A.x_stride = 1; A.m_x_stride = 1; A.along_ray = 0;
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     const bool v4 = (cube->nx % 4 == 0) && (cube->row_stride % 4 == 0) && (cube->plane_stride % 4 == 0) &&
                     ((((uintptr_t)cube->d_data) & 15) == 0) &&
@@ -853,6 +860,55 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     auto unkey = [](uint32_t kk) { uint32_t u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk; float f; memcpy(&f, &u, 4); return (double)f; };
     const double a = unkey(key_lo), b = unkey(key_hi);
     *h_out = (frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac;
+    return SPC_OK;
+}
+
+// The same statistic along x (median / percentile / mad_std with axis=2) without a transposed copy of the cube: the
+// register-resident kernel on the view whose "spaxels" are the (z, y) pairs and whose rays are the rows - consecutive
+// lanes take consecutive samples of a ray (contiguous in memory).  d_center / d_out: (nz, ny).  Rows of more than 4096
+// samples: SPC_ERR_UNSUPPORTED (the caller transposes, spc_fill_masked_transpose_f32, and selects along y).
+extern "C" int spc_percentile_axis2_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                        double q, const float* d_center, float scale, float* d_out) {
+    int rc = spc_check_cube_any_order(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    SPC_REQUIRE(q >= 0.0 && q <= 100.0, "Percentiles must be in the range [0, 100]");
+    if (cube->nx > 4096 || cube->nz * ((cube->ny + 7) / 8) >= (1LL << 31)) {
+        spc_set_error("rows of %lld samples do not fit the registers of a block (4096 at most)", (long long)cube->nx);
+        return SPC_ERR_UNSUPPORTED;
+    }
+    SelArgs A{};
+    rc = spc_mask_to_dev(mask, cube, &A.mask);
+    if (rc) return rc;
+    SPC_DEVICE(device);
+    // the view: samples along x (step 1), rows = channels (step plane_stride), adjacent spaxels = adjacent rows y
+    A.cube = cube->d_data;
+    A.nz = cube->nx; A.ny = cube->nz; A.nx = cube->ny;
+    A.plane_stride = 1; A.row_stride = cube->plane_stride; A.x_stride = cube->row_stride;
+    A.m_x_stride = A.mask.row_stride;
+    { const int64_t mrow = A.mask.plane_stride; A.mask.plane_stride = 1; A.mask.row_stride = mrow; }
+    A.along_ray = 1;
+    A.q = q; A.center = d_center; A.scale = scale; A.out = d_out;
+    const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int ts = A.nz <= 512 ? 32 : (A.nz <= 1024 ? 16 : 8);
+    const int lanes = 256 / ts;
+    const int need = (int)((A.nz + lanes - 1) / lanes);
+    const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : (need <= 64 ? 64 : 128));
+    dim3 grid((unsigned)(A.ny * ((A.nx + ts - 1) / ts)));
+#define SPC_LAUNCH_REG(TS_, K_)                                                                                     \
+    do {                                                                                                            \
+        if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true>), grid, dim3(256), 0, st, A);                 \
+        else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false>), grid, dim3(256), 0, st, A);                    \
+    } while (0)
+#define SPC_LAUNCH_REG_K(TS_)                                                                                       \
+    do {                                                                                                            \
+        if (kpl == 16) SPC_LAUNCH_REG(TS_, 16); else if (kpl == 32) SPC_LAUNCH_REG(TS_, 32); else SPC_LAUNCH_REG(TS_, 64); \
+    } while (0)
+    if (kpl == 128) SPC_LAUNCH_REG(8, 128); else if (ts == 32) SPC_LAUNCH_REG_K(32); else if (ts == 16) SPC_LAUNCH_REG_K(16); else SPC_LAUNCH_REG_K(8);
+#undef SPC_LAUNCH_REG_K
+#undef SPC_LAUNCH_REG
+    SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
 

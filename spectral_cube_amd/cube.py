@@ -730,7 +730,11 @@ class SpectralCube:
         if axis == 1:            # rays along y: the same kernels on a view with the first two axes exchanged
             return ops.percentile_axis0(self._device_data().swap01(), q, mask=self._mask_spec().swap01(),
                                         center=center, scale=scale)
-        if axis == 2:            # rays along x: NaN-filled copy with the spatial axes exchanged, then as along y
+        if axis == 2:            # rays along x: the rows themselves (contiguous samples, lanes walk along the ray) ...
+            try:
+                return ops.percentile_axis2(self._device_data(), q, mask=self._mask_spec(), center=center, scale=scale)
+            except _lib.HipUnsupported:
+                pass             # ... or, for rows of more than 4096 samples, a NaN-filled transposed copy, then as along y
             flipped = ops.fill_masked_transposed(self._device_data(), self._mask_spec(), np.nan)
             return ops.percentile_axis0(flipped.swap01(), q, center=center, scale=scale)
         if axis != 0:

@@ -515,6 +515,20 @@ def mask_include(cube, mask=None, nan_excluded=False, stream=None):
     return out
 
 
+def percentile_axis2(cube, q, mask=None, center=None, scale=1.0, stream=None, out=None):
+    """q-th percentile along x per (z, y) row, no transposed copy (spc_percentile_axis2_f32); *center*: a (nz, ny)
+    float32 DeviceArray.  Raises HipUnsupported for rows of more than 4096 samples."""
+    nz, ny, nx = cube.shape
+    if out is None:
+        out = DeviceArray((nz, ny), np.float32, cube.device)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    if center is not None and (center.dtype != np.float32 or tuple(center.shape) != (nz, ny)):
+        raise TypeError("center must be a float32 (nz, ny) DeviceArray")
+    _lib.call("spc_percentile_axis2_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(q),
+              C.c_void_p(center.ptr) if center is not None else None, float(scale), C.c_void_p(out.ptr))
+    return out
+
+
 def percentile_global(cube, q, mask=None, center=None, stream=None):
     """q-th percentile of all included samples of the cube (np.nanpercentile(..., axis=None));
     with *center* of |x - center|.  Returns a python float (NaN when nothing is included)."""

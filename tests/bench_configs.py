@@ -70,7 +70,7 @@ ms = med_ms(lambda: ops.percentile_axis0(cube, 50.0, out=om), n=3, warm=1)
 res.append(row("C2 1024^3 no mask: median along the spectral axis", vox, ms, 4))
 cubeobj_mask = mspec
 for ax, fn in ((1, lambda: ops.percentile_axis0(cube.swap01(), 50.0, mask=mspec.swap01())),
-               (2, lambda: ops.percentile_axis0(ops.fill_masked_transposed(cube, mspec).swap01(), 50.0))):
+               (2, lambda: ops.percentile_axis2(cube, 50.0, mask=mspec))):
     ms = med_ms(fn, n=3, warm=1)
     res.append(row("C2 1024^3 u8 mask: median along spatial axis %d" % ax, vox, ms, 5))
 ms = med_ms(lambda: ops.percentile_global(cube, 50.0, mask=mspec), n=3, warm=1)

@@ -21,10 +21,10 @@ _replicate_rows(qcube, np.round(tile * 4).astype(np.float32), 4)
 for env in ({}, {"SPC_SELECT_REG": "0"}):
     for k in ("SPC_SELECT_REG",): os.environ.pop(k, None)
     os.environ.update(env)
-    print(env or "default (rays in registers)", "median u8 mask %.3f ms | no mask %.3f ms | p90 %.3f ms | median along y (swap01) %.3f ms | quantised, no mask %.3f ms" % (
+    print(env or "default (rays in registers)", "median u8 mask %.3f ms | no mask %.3f ms | p90 %.3f ms | median along y (swap01; default row: along x, no transpose) %.3f ms | quantised, no mask %.3f ms" % (
         timeit(lambda: ops.percentile_axis0(cube, 50.0, mask=mspec)), timeit(lambda: ops.percentile_axis0(cube, 50.0)),
         timeit(lambda: ops.percentile_axis0(cube, 90.0, mask=mspec)),
-        timeit(lambda: ops.percentile_axis0(cube.swap01(), 50.0, mask=mspec.swap01())),
+        timeit(lambda: ops.percentile_axis0(cube.swap01(), 50.0, mask=mspec.swap01())) if env else timeit(lambda: ops.percentile_axis2(cube, 50.0, mask=mspec)),
         timeit(lambda: ops.percentile_axis0(qcube, 50.0))), flush=True)
 os.environ.pop("SPC_SELECT_REG", None)
 import time

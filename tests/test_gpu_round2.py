@@ -492,3 +492,29 @@ def test_nonseparable_stencil_all_valid_pass(gpu, monkeypatch):
     ref = ops.spatial_conv(dd, kn, mask=ops.MaskSpec(_lib.MASK_FINITE)).get()
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     assert np.nanmax(np.abs(got - ref)) <= 4e-7 * np.nanmax(np.abs(ref))
+
+
+@pytest.mark.parametrize("shape", [(5, 7, 9), (3, 40, 515), (2, 9, 2050), (2, 3, 4100)])
+def test_order_statistics_along_x_without_transpose(gpu, shape):
+    """median / percentile / mad_std with axis=2: the rows are the rays (lanes walk along the contiguous samples, no
+    transposed copy of the cube); rows of more than 4096 samples fall back to the transposed copy.  Against numpy on
+    the masked cube, medians and MADs bit for bit."""
+    import warnings
+    from spectral_cube_amd import SpectralCube
+    rng = np.random.default_rng(shape[2])
+    d = rng.standard_normal(shape).astype(np.float32)
+    d[rng.random(shape) < 0.05] = np.nan
+    d[0, 0, :] = np.nan
+    inc = rng.random(shape) < 0.8
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 1.0,
+           "CUNIT3": "km/s", "CRPIX1": 1, "CRPIX2": 1, "CRPIX3": 1, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": 0.0, "BUNIT": "K"}
+    cube = SpectralCube.read(d, hdr).with_mask(inc)
+    fz = np.where(inc, d, np.nan).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        emed = np.nanmedian(fz, axis=2)
+        e30 = np.nanpercentile(fz.astype(np.float64), 30.0, axis=2)
+        emad = np.nanmedian(np.abs(fz - emed[:, :, None]), axis=2) * np.float32(1.482602218505602)
+        assert np.array_equal(np.asarray(cube.median(axis=2)), emed, equal_nan=True)
+        np.testing.assert_allclose(np.asarray(cube.percentile(30.0, axis=2)), e30, rtol=3e-6, atol=1e-7, equal_nan=True)
+        np.testing.assert_allclose(np.asarray(cube.mad_std(axis=2)), emad, rtol=3e-7, equal_nan=True)
