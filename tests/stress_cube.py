@@ -84,6 +84,14 @@ for it in range(nround):
             got = getattr(cube, op)(axis=axis)
             exp = O.reduce(d, inc, op, axis=axis)
             close(np.asarray(got), np.asarray(exp), 1e-6 if op in ("max", "min") else 2e-6, tag + " %s ax%s" % (op, axis))
+    # spectral interpolation onto a random linear grid (finer / coarser, partly outside, sometimes reversed)
+    ax = cube.spectral_axis
+    lo_, hi_ = ax[0] - rng.uniform(0, 2) * abs(ax[1] - ax[0]), ax[-1] + rng.uniform(0, 2) * abs(ax[1] - ax[0])
+    grid = np.linspace(lo_, hi_, int(rng.integers(2, 3 * nz)))
+    if rng.random() < 0.3: grid = grid[::-1]
+    gi = cube.spectral_interpolate(grid, suppress_smooth_warning=True)._device_data().get()
+    ei = O.spectral_interpolate(d, inc, ax, grid)[0]
+    close(gi, ei, 1e-5, tag + " spectral_interpolate")
     # sigma clipping
     thr = float(rng.uniform(1.5, 3.0))
     got = cube.sigma_clip_spectrally(thr)._device_data().get()
