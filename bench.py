@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py - headline benchmark: fused moment0+moment1+moment2 of a masked fp32 cube.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: bench.py starts its own N ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (a launcher's ranks)
 
 One "step" = one pass of the hot path (ONE launch of the fused HIP moment kernel -> three float64
 maps) over the rank's device-resident cube.
@@ -18,17 +18,30 @@ N > 1   STRONG scaling of that fixed 4096x2048x2048 cube: rank r owns rows [r*20
         also reports the pipelined rate (all-gather of step k under the kernel of step k+1, what a
         stream of cubes gets) and the kernel / all-gather times alone.
 
+Every line carries `scale_basis`: the north-star cube's whole-job Mvoxel/s measured the SAME way at
+every N (K timed calls between barriers, wall clock) - the one key whose values at N = 1, 2, 4, 8 are
+the strong-scaling curve (`value` at N = 1 is configs[1], a different cube).
+N = 1 also carries `configs`: BASELINE.json configs[2], [3], [4] at full size (device-tiled data),
+every record with the kernel time by HIP events, its algorithmic bytes, the roofline fraction and an
+oracle check on the tile.
+
 Rank 0 prints ONE JSON line: metric, roofline of the dominant kernel measured live with HIP events
 on the kernel's stream, and (N = 1) a CPU baseline: the numpy restatement of the reference's
 arithmetic (oracle), threads over spaxel chunks like dask's `threads` scheduler, bounded sample.
-No torch: the launcher's RANK / WORLD_SIZE / LOCAL_RANK are read from the environment and the
-ranks meet through spectral_cube_amd.rendezvous (files in a per-launch directory).
+No torch: with WORLD_SIZE unset and --gpus N > 1 this script starts its N ranks itself (one process
+per GPU, RANK / LOCAL_RANK / WORLD_SIZE in their environment, rank 0's JSON relayed as the last line
+of stdout, non-zero exit status if any rank fails); under a launcher its RANK / WORLD_SIZE /
+LOCAL_RANK are read from the environment.  The ranks meet through spectral_cube_amd.rendezvous
+(files in a per-launch directory).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -39,7 +52,7 @@ NORTH_STAR = (4096, 2048, 2048)
 PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -50,7 +63,11 @@ def parse():
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
-    return ap.parse_args()
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[2..4] records")
+    ap.add_argument("--configs-only", default=None, metavar="C3,C4,C5",
+                    help="only the named config records (kernel work: before / after numbers)")
+    ap.add_argument("--configs-scale", type=int, default=1, help="divide the config cubes' longest axis (smoke runs)")
+    return ap.parse_args(argv)
 
 
 # ---- synthetic inputs (never timed) ------------------------------------------------------------
@@ -305,11 +322,20 @@ def run_single(args, device):
         if free < need:
             line["north_star"] = {"skipped": "needs %.0f GiB of HBM, %.0f GiB free" % (need / 2**30, free / 2**30)}
         else:
-            line["north_star"] = north_star_record(ns_shape, device)
+            line["north_star"] = north_star_record(ns_shape, device, args)
+            line["scale_basis"] = dict(line["north_star"]["scale_basis"], n_gpus=1)
+    if "scale_basis" not in line:
+        line["scale_basis"] = None
+    if not args.no_configs:
+        line["configs"] = config_records(args, device)
     return line
 
 
-def north_star_record(shape, device):
+SCALE_BASIS_NOTE = ("whole-job Mvoxel/s of moment0+1+2 over the FIXED north-star cube, K timed calls between barriers (wall "
+                    "clock, max over ranks): divide the values at N = 2, 4, 8 by the N = 1 value for the strong-scaling curve")
+
+
+def north_star_record(shape, device, args):
     import gc
     from spectral_cube_amd import synth
     from spectral_cube_amd.device import pool_trim
@@ -320,10 +346,25 @@ def north_star_record(shape, device):
     for _ in range(2):
         wl.launch(out)
     wl.stream.synchronize()
+    # the same measurement as `value` of the N > 1 lines: K calls between barriers, wall clock
+    from spectral_cube_amd.device import synchronize
+    for _ in range(args.warmup):
+        wl.launch(out)
+    wl.stream.synchronize()
+    synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.launch(out)
+    wl.stream.synchronize()
+    synchronize(device)
+    elapsed = time.perf_counter() - t0
     k_ms = wl.kernel_ms(out, 10)
     verify = wl.verify([out[k].get() for k in ("m0", "m1", "m2")], tile, tmask, 4)
     nz, ny, nx = shape
-    rec = {"workload": "north star: %dx%dx%d fp32 cube + uint8 mask resident on ONE GPU, fused moment0+1+2, "
+    rec = {"scale_basis": {"workload": "%dx%dx%d fp32 + uint8 mask, fused moment0+1+2" % shape,
+                           "value": nz * ny * nx * args.steps / elapsed / 1e6, "unit": "Mvoxel/s",
+                           "ms_per_call": elapsed / args.steps * 1e3, "note": SCALE_BASIS_NOTE},
+           "workload": "north star: %dx%dx%d fp32 cube + uint8 mask resident on ONE GPU, fused moment0+1+2, "
                        "device-tiled synthetic data (one seeded %d-row host tile repeated along y)" % (shape + (tile.shape[1],)),
            "kernel_ms": k_ms, "value": nz * ny * nx / (k_ms * 1e-3) / 1e6, "unit": "Mvoxel/s",
            "mask_valid_fraction": float(np.count_nonzero(tmask)) / tmask.size,
@@ -332,6 +373,315 @@ def north_star_record(shape, device):
     gc.collect()
     pool_trim(device)
     return rec
+
+
+# ---- BASELINE.json configs[2], [3], [4] at full size (N = 1) ------------------------------------------
+def replicate_rows(dev, tile):
+    """(nz, ny, nx) device array <- host tile (nz, ty, nx) repeated along y (one upload, D2D doubling)"""
+    from spectral_cube_amd import _lib
+    nz, ny, nx = dev.shape
+    ty, isz = tile.shape[1], dev.dtype.itemsize
+    row = nx * isz
+    _lib.call("spc_memcpy3d_h2d", dev.device, C.c_void_p(dev.ptr), row, ny * row, tile.ctypes.data_as(C.c_void_p),
+              row, ty * row, row, min(ty, ny), nz, None)
+    have = min(ty, ny)
+    while have < ny:
+        n = min(have, ny - have)
+        _lib.call("spc_memcpy3d_d2d", dev.device, C.c_void_p(dev.ptr + have * row), row, ny * row,
+                  C.c_void_p(dev.ptr), row, ny * row, row, n, nz, None)
+        have += n
+    _lib.call("spc_device_sync", dev.device)
+
+
+def replicate_planes(dev, tile):
+    """(nz, ny, nx) device array <- host tile (tz, ny, nx) repeated along z"""
+    from spectral_cube_amd import _lib
+    nz, ny, nx = dev.shape
+    tz = min(tile.shape[0], nz)
+    plane = ny * nx * dev.dtype.itemsize
+    _lib.call("spc_memcpy_h2d", dev.device, C.c_void_p(dev.ptr), tile.ctypes.data_as(C.c_void_p), tz * plane, None)
+    have = tz
+    while have < nz:
+        n = min(have, nz - have)
+        _lib.call("spc_memcpy_d2d", dev.device, C.c_void_p(dev.ptr + have * plane), C.c_void_p(dev.ptr), n * plane, None)
+        have += n
+    _lib.call("spc_device_sync", dev.device)
+
+
+def fetch_rows(dev, y0, y1):
+    """host copy of rows [y0, y1) of every plane of a (nz, ny, nx) device cube"""
+    from spectral_cube_amd import _lib
+    from spectral_cube_amd.device import DeviceArray
+    nz, ny, nx = dev.shape
+    row = nx * dev.dtype.itemsize
+    tmp = DeviceArray((nz, y1 - y0, nx), dev.dtype, dev.device)
+    _lib.call("spc_memcpy3d_d2d", dev.device, C.c_void_p(tmp.ptr), row, (y1 - y0) * row,
+              C.c_void_p(dev.ptr + y0 * row), row, ny * row, row, y1 - y0, nz, None)
+    return tmp.get()
+
+
+def event_ms(fn, device, n=5, warm=2):
+    """mean duration of fn() by HIP events on the stream its kernels are launched on (the null stream)"""
+    import numpy as np
+    from spectral_cube_amd.device import Event, synchronize
+    for _ in range(warm):
+        fn()
+    synchronize(device)
+    e0, e1 = Event(device), Event(device)
+    ts = []
+    for _ in range(n):
+        e0.record(None)
+        fn()
+        e1.record(None)
+        e1.synchronize()
+        ts.append(e0.elapsed_ms(e1))
+    return float(np.mean(ts))
+
+
+def cfg_record(name, kernel, ms, alg_bytes, voxels, verify, bytes_note, **extra):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    rec = {"name": name, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes": int(alg_bytes), "bytes_per_voxel": bytes_note,
+           "achieved_GBps": gbs, "frac": gbs / PEAK_GBS, "value": voxels / (ms * 1e-3) / 1e6, "unit": "Mvoxel/s",
+           "verify": verify}
+    rec.update(extra)
+    return rec
+
+
+def _close(got, exp, scale, what, tol=1e-5):
+    """NaN pattern identical, |got - exp| <= tol * scale; returns the scaled error"""
+    import numpy as np
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(exp)), what + ": NaN pattern mismatch vs oracle"
+    ok = ~np.isnan(exp)
+    err = float(np.abs(got[ok] - exp[ok]).max() / scale) if ok.any() else 0.0
+    assert err <= tol, (what, err)
+    return err
+
+
+def config_c3(device, scale):
+    """configs[2]: 2048^3 fp32, spectral_smooth(Gaussian sigma = 4 channels: 33 taps) then moment1.
+    Rows repeat a seeded 2-row tile.  All valid (the config as written) and with a uint8 mask."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_np as O
+    from spectral_cube_amd import _lib, ops, synth, Gaussian1DKernel
+    from spectral_cube_amd.device import DeviceArray
+    nz, ny, nx = 2048, 2048 // scale, 2048
+    vox = nz * ny * nx
+    tile = synth.gaussian_line_cube((nz, 2, nx), synth.SEEDS["C3"], chunk_rows=2)
+    tmask = synth.boolean_mask(tile, synth.SEEDS["C3"])
+    cube = DeviceArray((nz, ny, nx), np.float32, device)
+    replicate_rows(cube, tile)
+    k = Gaussian1DKernel(4).array
+    v = synth.spectral_axis(nz)
+    cen = v - v[0]
+    cref = cen[nz // 2]
+    d_cen = DeviceArray.from_numpy(cen - cref, device)
+    o1 = {"m1": DeviceArray((ny, nx), np.float64, device)}
+    W = 256                                                   # columns the oracle redoes
+    recs = []
+
+    def check_m1(inc, what):
+        got = o1["m1"].get()
+        sm = O.spectral_smooth(tile[:, :, :W], inc, k)
+        exp = O.moment(sm, inc, 1, cen, 500.0, world0=v[0])
+        s0 = O.moment(sm, inc, 0, cen, 1.0)
+        with np.errstate(invalid="ignore"):
+            wc = np.abs(s0) > 5.0                             # moment 1 = S1 / S0: well-conditioned spaxels (SURVEY 8d)
+        assert np.array_equal(np.isnan(got[:2, :W]), np.isnan(exp)), what + ": NaN pattern"
+        err = float(np.abs(got[:2, :W][wc] - exp[wc]).max() / (500.0 * nz))
+        assert err <= 1e-5, (what, err)
+        assert np.array_equal(got[-2:], got[:2], equal_nan=True), what + ": not periodic in y"
+        return {"max_scaled_err": err, "spaxels_checked": int(wc.sum()), "rows_periodic": True}
+
+    def check_cube(out, inc, what):
+        got = fetch_rows(out, ny - 2, ny)[:, :, :W]
+        exp = O.spectral_smooth(tile[:, :, :W], inc, k)
+        return {"max_scaled_err": _close(got, exp, float(np.nanmax(np.abs(exp))), what), "voxels_checked": int(exp.size)}
+
+    ms = event_ms(lambda: ops.spectral_conv_moments(cube, k, d_cen, dv=500.0, m1_add=cref + v[0], want=("m1",), out=o1,
+                                                    cen_host=cen - cref), device)
+    recs.append(cfg_record("C3 spectral_smooth(33 taps) -> moment1, fused, all valid", "weighted_moments_kernel (algebraic fusion)",
+                           ms, vox * 4 + ny * nx * 8, vox, check_m1(None, "C3 fused"), "4 read + 8 B/spaxel out"))
+    sm = DeviceArray((nz, ny, nx), np.float32, device)
+    ms = event_ms(lambda: ops.spectral_conv(cube, k, out=sm), device)
+    recs.append(cfg_record("C3 spectral_smooth(33 taps) materialised, all valid", "spectral_conv_fast_kernel<33>", ms, vox * 8, vox,
+                           check_cube(sm, None, "C3 smooth"), "4 read + 4 written"))
+    maskd = DeviceArray((nz, ny, nx), np.uint8, device)
+    replicate_rows(maskd, tmask)
+    mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=maskd)
+    inc = tmask[:, :, :W].astype(bool)
+    ms = event_ms(lambda: ops.spectral_conv_moments(cube, k, d_cen, dv=500.0, m1_add=cref + v[0], mask=mspec, want=("m1",),
+                                                    out=o1, cen_host=cen - cref), device)
+    recs.append(cfg_record("C3 spectral_smooth(33 taps) -> moment1, fused, uint8 mask", "spectral_conv_kernel<33,ARR,FUSE>", ms,
+                           vox * 5 + ny * nx * 8, vox, check_m1(inc, "C3 fused masked"), "4 + 1 read + 8 B/spaxel out",
+                           mask_valid_fraction=float(tmask.mean())))
+    ms = event_ms(lambda: ops.spectral_conv(cube, k, mask=mspec, out=sm), device)
+    recs.append(cfg_record("C3 spectral_smooth(33 taps) materialised, uint8 mask", "spectral_conv_kernel<33,ARR>", ms, vox * 9, vox,
+                           check_cube(sm, inc, "C3 smooth masked"), "4 + 1 read + 4 written",
+                           mask_valid_fraction=float(tmask.mean())))
+    return recs
+
+
+def config_c4(device, scale):
+    """configs[3]: 4096 x 2048 x 2048 fp32 (+ uint8 mask), spatial_smooth with a 2-D Gaussian of FWHM = 8 px
+    (29 x 29 taps) + moment0.  Planes repeat a seeded 2-plane tile."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_np as O
+    from spectral_cube_amd import _lib, ops, synth, Gaussian2DKernel
+    from spectral_cube_amd.device import DeviceArray
+    nz, ny, nx = 4096 // scale, 2048, 2048
+    vox = nz * ny * nx
+    rng = np.random.default_rng(synth.SEEDS["C4"])
+    tile = rng.standard_normal((2, ny, nx), dtype=np.float32) + 2.0
+    tmask = (rng.random((2, ny, nx), dtype=np.float32) > 0.2).view(np.uint8)
+    tmask[:, :8, :8] = 0
+    cube = DeviceArray((nz, ny, nx), np.float32, device)
+    replicate_planes(cube, tile)
+    k2 = Gaussian2DKernel(8 / 2.3548200450309493).array
+    assert k2.shape == (29, 29)
+    sm = DeviceArray((nz, ny, nx), np.float32, device)
+    WY, WX, PAD = 96, 160, 14
+    sub = (slice(None), slice(0, WY + PAD), slice(0, WX + PAD))
+    win = (slice(None), slice(0, WY), slice(0, WX))
+    recs = []
+
+    def smoothed_window(out):
+        got = np.empty((2, WY, WX), np.float32)
+        for z in range(2):                                   # the LAST two planes of the cube
+            rows = np.empty((WY, nx), np.float32)
+            _lib.call("spc_memcpy_d2h", device, rows.ctypes.data_as(C.c_void_p),
+                      C.c_void_p(out.ptr + (nz - 2 + z) * ny * nx * 4), rows.nbytes, None)
+            got[z] = rows[:, :WX]
+        return got
+
+    ms = event_ms(lambda: ops.spatial_conv(cube, k2, out=sm), device, n=3, warm=1)
+    exp = O.spatial_smooth(tile[sub], None, k2)[win]
+    ver = {"max_scaled_err": _close(smoothed_window(sm), exp, float(np.abs(exp).max()), "C4 smooth"), "voxels_checked": int(exp.size)}
+    recs.append(cfg_record("C4 spatial_smooth(29x29), all valid", "spatial_sep_fast_kernel<29>", ms, vox * 8, vox, ver, "4 read + 4 written"))
+
+    maskd = DeviceArray((nz, ny, nx), np.uint8, device)
+    replicate_planes(maskd, tmask)
+    mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=maskd)
+    inc = tmask[sub].astype(bool)
+    ms_s = event_ms(lambda: ops.spatial_conv(cube, k2, mask=mspec, out=sm), device, n=3, warm=1)
+    exp = O.spatial_smooth(tile[sub], inc, k2)[win]
+    ver = {"max_scaled_err": _close(smoothed_window(sm), exp, float(np.nanmax(np.abs(exp))), "C4 smooth masked"),
+           "voxels_checked": int(exp.size)}
+    recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 mask", "spatial_sep_kernel<29,ARR>", ms_s, vox * 9, vox, ver,
+                           "4 + 1 read + 4 written", mask_valid_fraction=float(tmask.mean())))
+
+    # the pipeline of the config: spatial_smooth -> moment0 (the smoothed cube keeps the ORIGINAL mask)
+    cen = DeviceArray.from_numpy(np.zeros(nz), device)
+    o0 = {"m0": DeviceArray((ny, nx), np.float64, device)}
+    need = _lib.load().spc_moments_workspace_bytes(nz, ny, nx)
+    ws = DeviceArray((max(need, 1),), np.uint8, device)
+
+    def pipeline_masked():
+        ops.spatial_conv(cube, k2, mask=mspec, out=sm)
+        ops.moments(sm, cen, dv=500.0, mask=mspec, want=("m0",), out=o0, workspace=ws)
+    ms = event_ms(pipeline_masked, device, n=3, warm=1)
+    incw = tmask[win].astype(bool)
+    exp_m0 = (nz // 2) * 500.0 * np.where(incw, exp, 0.0).sum(axis=0)
+    exp_m0[~incw.any(axis=0)] = np.nan
+    ver = {"max_scaled_err": _close(o0["m0"].get()[:WY, :WX], exp_m0, float(np.nanmax(np.abs(exp_m0))), "C4 moment0 masked"),
+           "spaxels_checked": int(exp_m0.size)}
+    recs.append(cfg_record("C4 pipeline spatial_smooth(29x29) -> moment0, uint8 mask (materialised)",
+                           "spatial_sep_kernel<29,ARR> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "fused ideal: 4 + 1 read + 8 B/spaxel out (the materialised form moves 9 + 5 B/voxel)",
+                           mask_valid_fraction=float(tmask.mean())))
+
+    # all valid: convolution commutes with the sums along z (algebraic path of SpectralCube.spatial_smooth -> moment0)
+    from spectral_cube_amd import SpectralCube
+    del sm, maskd, mspec
+    hdr = {"NAXIS": 3, "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nz, "CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD",
+           "CRVAL3": 0.0, "CDELT3": 500.0, "CRPIX3": 1.0, "CUNIT3": "m/s", "CDELT1": -1e-4, "CDELT2": 1e-4, "CRPIX1": 1.0,
+           "CRPIX2": 1.0, "CRVAL1": 10.0, "CRVAL2": 20.0, "BUNIT": "K"}
+    sc = SpectralCube.from_device(cube, header=hdr)
+    kobj = Gaussian2DKernel(8 / 2.3548200450309493)
+    from spectral_cube_amd.device import synchronize
+    for _ in range(2):
+        m0 = sc.spatial_smooth(kobj).moment0()
+    synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m0 = sc.spatial_smooth(kobj).moment0()
+    synchronize(device)
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    exp = O.spatial_smooth(tile[sub], None, k2)[win]
+    exp_m0 = (nz // 2) * 500.0 * exp.astype(np.float64).sum(axis=0)
+    ver = {"max_scaled_err": _close(np.asarray(m0)[:WY, :WX], exp_m0, float(np.abs(exp_m0).max()), "C4 moment0 all valid"),
+           "spaxels_checked": int(exp_m0.size)}
+    recs.append(cfg_record("C4 pipeline spatial_smooth(29x29) -> moment0, all valid (wall clock of the cube-level call)",
+                           "moments_kernel + map_conv2d (algebraic: conv commutes with the z sums)", ms, vox * 4 + ny * nx * 8, vox,
+                           ver, "4 read + 8 B/spaxel out", timing="wall clock incl. host map checks, not HIP events"))
+    return recs
+
+
+def config_c5(device, scale):
+    """configs[4]: 2048 x 1024 x 1024 cube, spectral_interpolate to 4096 channels, then reproject onto the same
+    TAN grid rotated by 30 degrees."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_np as O
+    from spectral_cube_amd import ops, synth
+    from spectral_cube_amd.device import DeviceArray
+    from spectral_cube_amd.wcs import SimpleWCS
+    nz, ny, nx = 2048, 1024 // scale, 1024
+    nzo = 4096
+    tile = synth.gaussian_line_cube((nz, 2, nx), synth.SEEDS["C5"], chunk_rows=2)
+    tile[700, 1, 9] = np.nan
+    cube = DeviceArray((nz, ny, nx), np.float32, device)
+    replicate_rows(cube, tile)
+    v = synth.spectral_axis(nz)
+    grid = np.linspace(v[0], v[-1], nzo)
+    lo, t, inv, _, _, fill = ops.lerp_plan(v, grid)
+    out = DeviceArray((nzo, ny, nx), np.float32, device)
+    recs = []
+    ms = event_ms(lambda: ops.spectral_lerp(cube, lo, t, inv, fill, out=out), device)
+    exp, _ = O.spectral_interpolate(tile, None, v, grid)
+    got = fetch_rows(out, ny - 2, ny)
+    ver = {"max_scaled_err": _close(got, exp, float(np.nanmax(np.abs(exp))), "C5 lerp"), "voxels_checked": int(exp.size)}
+    recs.append(cfg_record("C5 spectral_interpolate 2048 -> 4096 channels", "spectral_lerp_kernel<4>", ms, (nz + nzo) * ny * nx * 4,
+                           nzo * ny * nx, ver, "4 B x nz_in + 4 B x nz_out per spaxel"))
+    del cube
+    # reproject: rotated TAN header, device pixel map, bilinear
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CRVAL1": 150.0, "CRVAL2": 2.0, "CRPIX1": nx / 2 + 0.5, "CRPIX2": ny / 2 + 0.5,
+           "CDELT1": -1 / 3600, "CDELT2": 1 / 3600, "NAXIS": 2, "NAXIS1": nx, "NAXIS2": ny}
+    c, s_ = np.cos(np.radians(30)), np.sin(np.radians(30))
+    w_in, w_out = SimpleWCS(hdr, naxis=2), SimpleWCS(dict(hdr, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c), naxis=2)
+    xs, ys = ops.wcs_pixel_map(w_in, w_out, (ny, nx), device)
+    rep = DeviceArray((nzo, ny, nx), np.float32, device)
+    ms = event_ms(lambda: ops.resample_bilinear(out, xs, ys, out=rep, want_footprint=False), device, n=3, warm=1)
+    hx, hy = xs.get(), ys.get()
+    chans = [0, 1, nzo // 2 + 1, nzo - 1]
+    src = np.stack([out.planes(c_, c_ + 1).get()[0] for c_ in chans])
+    exp, _ = O.resample_bilinear(src, hx, hy)
+    got = np.stack([rep.planes(c_, c_ + 1).get()[0] for c_ in chans])
+    ver = {"max_scaled_err": _close(got, exp, float(np.nanmax(np.abs(src))), "C5 reproject"), "voxels_checked": int(exp.size),
+           "pixel_map": "spc_wcs_pixel_map_f64 on the device"}
+    recs.append(cfg_record("C5 reproject 4096 x 1024^2 onto the grid rotated by 30 deg (bilinear)", "bilinear_lds_kernel<64>", ms,
+                           nzo * ny * nx * 8, nzo * ny * nx, ver, "~4 read + 4 written per output voxel"))
+    return recs
+
+
+def config_records(args, device):
+    import gc
+    from spectral_cube_amd.device import pool_trim
+    which = ("C3", "C4", "C5") if not args.configs_only else tuple(w.strip().upper() for w in args.configs_only.split(","))
+    fns = {"C3": config_c3, "C4": config_c4, "C5": config_c5}
+    out = {}
+    for w in which:
+        t0 = time.perf_counter()
+        try:
+            out[w] = fns[w](device, max(1, args.configs_scale))
+        except AssertionError as exc:                       # a failed oracle check is reported, never hidden
+            out[w] = {"error": "oracle check failed: %r" % (exc,)}
+        gc.collect()
+        pool_trim(device)
+        print("[bench] %s records in %.1f s" % (w, time.perf_counter() - t0), file=sys.stderr, flush=True)
+    return out
 
 
 # ---- N > 1: strong scaling of the north-star cube -----------------------------------------------
@@ -349,6 +699,8 @@ def run_sharded(args, device, rdv):
     cube, maskd, tile, tmask = tiled_strip_on_device((NZ, rows, NX), synth.SEEDS["C4"] + 17 * rank, device)
     wl = Workload(cube, maskd, device)
 
+    # RcclComm completes the id broadcast on every rank whether or not rank 0 could make an id (the sequence of
+    # rendezvous collectives is the same on all ranks whatever fails); rccl or host-fallback is then decided TOGETHER
     try:
         comm, stitch = RcclComm(device, rdv), "rccl"
     except Exception as exc:          # loud, reported fallback for the STITCH only
@@ -499,21 +851,96 @@ def run_sharded(args, device, rdv):
                       "note": "all-gather of step k on its own stream under the kernel of step k+1 (double buffered)"},
         "roofline": roofline(wl, k_ms_max),
         "cpu_baseline": None,
+        "scale_basis": {"workload": "%dx%dx%d fp32 + uint8 mask, fused moment0+1+2" % (NZ, NY, NX), "n_gpus": world,
+                        "value": total * args.steps / best / 1e6, "unit": "Mvoxel/s", "ms_per_call": best / args.steps * 1e3,
+                        "note": SCALE_BASIS_NOTE},
         "verify": {"per_rank": verifies, "stitched_maps_identical_on_all_ranks": True},
     }
     return line
 
 
+# ---- self-launch: python bench.py --gpus N with no launcher -------------------------------------------
+def spawn_ranks(n, argv):
+    """Start the N ranks of this script (one process per GPU), wait for them, relay rank 0's stdout (its last
+    line is the JSON record).  Returns the exit status: 0 only if EVERY rank exited 0.  A rank that dies takes
+    the launch down at once - the others would wait for it in the rendezvous until its timeout."""
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    rdv_dir = tempfile.mkdtemp(prefix="spc_rdv_bench_", dir=base)
+    import socket
+    with socket.socket() as sk:                              # a free port, by convention only (nothing listens on it:
+        sk.bind(("127.0.0.1", 0))                            # the ranks meet through files, RCCL through its own id)
+        port = sk.getsockname()[1]
+    procs, out0 = [], []
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPC_RDV_DIR=rdv_dir)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+        reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout), daemon=True)
+        reader.start()
+        failed = None
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = (r, p.returncode)
+            time.sleep(0.05)
+        if failed is None:
+            failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+        if failed is not None:
+            for p in procs:                                  # exactly the processes started above
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        reader.join(timeout=10)
+    finally:
+        import shutil
+        shutil.rmtree(rdv_dir, ignore_errors=True)
+    sys.stdout.write("".join(out0))
+    sys.stdout.flush()
+    if failed is not None:
+        print("[bench] rank %d exited with status %s; launch of %d ranks aborted" % (failed[0], failed[1], n), file=sys.stderr)
+        return failed[1] if isinstance(failed[1], int) and failed[1] > 0 else 1
+    return 0
+
+
+def dry_run(args):
+    """SPC_BENCH_DRYRUN=1: everything of a multi-rank launch except the GPU work (the CPU test of the spawner):
+    rendezvous, a few collectives, rank 0's JSON line; SPC_BENCH_DRYRUN_FAIL_RANK=r makes rank r exit 3."""
+    from spectral_cube_amd.rendezvous import FileRendezvous, SingleProcess
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if os.environ.get("SPC_BENCH_DRYRUN_FAIL_RANK", "") == str(rank):
+        sys.exit(3)
+    rdv = FileRendezvous.from_env(timeout=60) if world > 1 else SingleProcess()
+    try:
+        token = rdv.bcast_bytes(b"id-from-rank-0" if rank == 0 else None)
+        ranks = rdv.allgather_object((rank, int(os.environ.get("LOCAL_RANK", -1)), os.getpid()))
+        rdv.barrier()
+    finally:
+        rdv.close()
+    if rank == 0:
+        print("noise before the record")
+        print(json.dumps({"dryrun": True, "n_gpus": world, "gpus_arg": args.gpus, "ranks": ranks, "bcast": token.decode(),
+                          "steps": args.steps}), flush=True)
+
+
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, argv))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                     "--master-addr 127.0.0.1 --master-port 29533 bench.py --gpus %d ..." % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world                                   # under a launcher its world size wins
+    if os.environ.get("SPC_BENCH_DRYRUN", "0") == "1":
+        return dry_run(args)
     from spectral_cube_amd import _lib
     from spectral_cube_amd.rendezvous import FileRendezvous, SingleProcess
     _lib.require_gpu()
@@ -522,8 +949,10 @@ def main():
     sharded = world > 1 or os.environ.get("SPC_BENCH_FORCE_DIST", "0") == "1"
     if sharded:
         rdv = FileRendezvous.from_env() if world > 1 else SingleProcess()
-        line = run_sharded(args, device, rdv)
-        rdv.close()
+        try:
+            line = run_sharded(args, device, rdv)
+        finally:
+            rdv.close()                                     # also after a failure: no stale files for a restarted launch
     else:
         line = run_single(args, device)
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(tuple(args.shape), args.cpu_seconds)

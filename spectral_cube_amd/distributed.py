@@ -118,12 +118,17 @@ class RcclComm:
     def __init__(self, device, transport):
         """transport: rendezvous object (rank, world_size, bcast_bytes): carries rank 0's unique id."""
         self.device, self.rank, self.world_size = device, transport.rank, transport.world_size
-        ident = None
+        ident, err = None, None
         if self.rank == 0:
-            buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
-            _lib.call("spc_comm_unique_id", buf)
-            ident = bytes(buf)
+            try:
+                buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+                _lib.call("spc_comm_unique_id", buf)
+                ident = bytes(buf)
+            except Exception as exc:          # the broadcast still happens (an empty id): every rank stays on the
+                ident, err = b"", exc         # same rendezvous sequence number and fails here TOGETHER
         ident = transport.bcast_bytes(ident)
+        if len(ident) != _lib.COMM_ID_BYTES:
+            raise _lib.HipLibraryError("rank 0 could not create an RCCL id%s" % (": %s" % err if err else ""))
         buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(ident)
         h = C.c_void_p()
         _lib.call("spc_comm_init", device, buf, self.world_size, self.rank, C.byref(h))

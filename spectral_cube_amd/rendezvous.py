@@ -8,6 +8,11 @@ the others.  No sockets, no third-party package; works for any launcher that giv
 every rank RANK / WORLD_SIZE (``python -m torch.distributed.run`` does - its
 environment is read, torch itself is not imported).
 
+A directory may outlive a launch (a fixed SPC_RDV_DIR, a torchrun restart after a crash that never
+reached close()): the ranks therefore open every launch with a HANDSHAKE that gives it a fresh
+session id, and every collective's file names carry that id - files of an earlier launch are never
+read, whatever they hold (see FileRendezvous._handshake).
+
 The transport protocol (what ``distributed.py`` asks of a rendezvous object):
 
     rank, world_size
@@ -20,6 +25,7 @@ The transport protocol (what ``distributed.py`` asks of a rendezvous object):
 """
 import os
 import pickle
+import secrets
 import shutil
 import tempfile
 import time
@@ -38,6 +44,7 @@ class FileRendezvous:
         self.path, self.rank, self.world_size, self.timeout = os.fspath(path), int(rank), int(world_size), timeout
         self._seq = 0
         os.makedirs(self.path, exist_ok=True)
+        self._sid = self._handshake()
 
     # ---- construction from the launcher's environment ----------------------------------------
     @classmethod
@@ -50,12 +57,94 @@ class FileRendezvous:
         path = env.get("SPC_RDV_DIR")
         if not path:
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-            path = os.path.join(base, "spc_rdv_%s_%d" % (env.get("MASTER_PORT", "0"), os.getppid()))
+            # the launcher's pid and port keep two launches apart, the elastic run id / restart count two
+            # ATTEMPTS of one launch (torchrun restarts its workers under the same agent pid)
+            attempt = "%s_%s" % (env.get("TORCHELASTIC_RUN_ID", "none"), env.get("TORCHELASTIC_RESTART_COUNT", "0"))
+            attempt = "".join(ch if ch.isalnum() or ch in "_-" else "_" for ch in attempt)
+            path = os.path.join(base, "spc_rdv_%s_%d_%s" % (env.get("MASTER_PORT", "0"), os.getppid(), attempt))
         return cls(path, rank, world, timeout)
+
+    # ---- handshake: a session id no earlier launch in this directory can have ----------------------
+    def _put(self, name, payload):
+        tmp = os.path.join(self.path, name + ".tmp%d" % os.getpid())
+        with open(tmp, "wb") as fh:
+            fh.write(payload)
+        os.replace(tmp, os.path.join(self.path, name))          # atomic: readers never see a partial file
+
+    def _get(self, name):
+        try:
+            with open(os.path.join(self.path, name), "rb") as fh:
+                return fh.read()
+        except FileNotFoundError:
+            return None
+
+    def _handshake(self):
+        """Every rank publishes a random nonce (hello.<rank>); rank 0 publishes `session` = its own fresh
+        session id + the nonces it has seen, and republishes whenever a hello changes; a rank accepts a session
+        only if it lists the rank's OWN nonce, and acknowledges it by id; rank 0 returns once every rank has
+        acknowledged the current id.  A stale hello / session / ack left by an earlier launch holds another
+        nonce or id, so it is ignored until its owner overwrites it - nothing depends on clocks or on the
+        directory being empty."""
+        nonce = secrets.token_hex(8)
+        self._put("hello.%d" % self.rank, nonce.encode())
+        t0, delay = time.monotonic(), 0.0002
+
+        def wait():
+            nonlocal delay
+            if time.monotonic() - t0 > self.timeout:
+                raise RendezvousTimeout("rank %d: no handshake within %.0f s in %s" % (self.rank, self.timeout, self.path))
+            time.sleep(delay)
+            delay = min(delay * 1.5, 0.005)
+
+        if self.rank == 0:
+            sid, seen = None, None
+            while True:
+                hellos = [nonce.encode()] + [self._get("hello.%d" % r) for r in range(1, self.world_size)]
+                if all(h is not None for h in hellos):
+                    if hellos != seen:
+                        seen, sid = hellos, secrets.token_hex(8)
+                        self._put("session", pickle.dumps((sid, hellos)))
+                    if all(self._get("ack.%d" % r) == sid.encode() for r in range(1, self.world_size)):
+                        self._put("go", sid.encode())
+                        return sid
+                wait()
+        while True:
+            raw = self._get("session")
+            if raw is not None:
+                try:
+                    sid, hellos = pickle.loads(raw)
+                except Exception:
+                    sid, hellos = None, ()
+                if len(hellos) == self.world_size and hellos[self.rank] == nonce.encode():
+                    self._put("ack.%d" % self.rank, sid.encode())
+                    # rank 0 may still re-issue the session if ANOTHER rank's hello was stale when it read it:
+                    # the first collective's file name carries the id, so wait until rank 0 has settled on it
+                    return self._settled(sid, nonce)
+            wait()
+
+    def _settled(self, sid, nonce):
+        """rank 0 writes `go.<sid>` once every acknowledgement matches; until then a newer session may appear"""
+        t0, delay = time.monotonic(), 0.0002
+        while True:
+            if self._get("go") == sid.encode():
+                return sid
+            raw = self._get("session")
+            if raw is not None:
+                try:
+                    cur, hellos = pickle.loads(raw)
+                except Exception:
+                    cur, hellos = sid, ()
+                if cur != sid and len(hellos) == self.world_size and hellos[self.rank] == nonce.encode():
+                    sid = cur
+                    self._put("ack.%d" % self.rank, sid.encode())
+            if time.monotonic() - t0 > self.timeout:
+                raise RendezvousTimeout("rank %d: session never settled in %s" % (self.rank, self.path))
+            time.sleep(delay)
+            delay = min(delay * 1.5, 0.005)
 
     # ---- files -------------------------------------------------------------------------------
     def _name(self, seq, rank):
-        return os.path.join(self.path, "%08d.%d" % (seq, rank))
+        return os.path.join(self.path, "%s.%08d.%d" % (self._sid, seq, rank))
 
     def _write(self, seq, payload):
         tmp = self._name(seq, self.rank) + ".tmp%d" % os.getpid()

@@ -136,3 +136,97 @@ def test_file_rendezvous_default_directory_is_per_launch():
     finally:
         a.close(); b.close()
     assert not os.path.exists(a.path)
+
+
+def test_file_rendezvous_ignores_what_an_earlier_launch_left_behind(tmp_path):
+    """a crashed launch leaves its files in a directory that the next launch reuses (fixed
+    SPC_RDV_DIR, torchrun restart).  The handshake gives every launch a fresh session id carried by every file
+    name, so neither stale collective payloads nor stale handshake files are ever read."""
+    import pickle
+    import threading
+    from spectral_cube_amd.rendezvous import FileRendezvous
+    d = tmp_path / "rdv"
+    d.mkdir()
+    # debris of an earlier launch: old-format payloads, handshake files of a dead session, same-format payloads
+    (d / "00000000.1").write_bytes(b"STALE-RCCL-ID")
+    (d / "hello.1").write_bytes(b"deadbeefdeadbeef")
+    (d / "hello.0").write_bytes(b"0123456701234567")
+    (d / "session").write_bytes(pickle.dumps(("oldsession000000", [b"0123456701234567", b"deadbeefdeadbeef"])))
+    (d / "ack.1").write_bytes(b"oldsession000000")
+    (d / "go").write_bytes(b"oldsession000000")
+    (d / "oldsession000000.00000000.1").write_bytes(b"STALE-RCCL-ID")
+    (d / "oldsession000000.00000000.0").write_bytes(b"STALE-RCCL-ID")
+    res, errs = {}, []
+
+    def rank(r, delay):
+        try:
+            import time
+            time.sleep(delay)                     # rank 1 arrives late: rank 0 first sees only the stale hello.1
+            tr = FileRendezvous(str(d), r, 2, timeout=30)
+            res[r] = (tr.bcast_bytes(b"fresh-id" if r == 0 else None), tr.allgather_object(("rank", r)))
+            tr.close()
+        except Exception as exc:                  # pragma: no cover
+            errs.append(exc)
+
+    ts = [threading.Thread(target=rank, args=(0, 0.0)), threading.Thread(target=rank, args=(1, 0.3))]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    assert not errs, errs
+    for r in (0, 1):
+        assert res[r] == (b"fresh-id", [("rank", 0), ("rank", 1)])
+    assert not d.exists()
+
+
+def test_rccl_comm_init_keeps_ranks_in_step_when_rank0_cannot_make_an_id(tmp_path, monkeypatch):
+    """a failure on rank 0 BEFORE the id broadcast must not desynchronise the rendezvous sequence:
+    the broadcast is completed with an empty id and every rank raises the same error."""
+    from spectral_cube_amd import _lib
+    from spectral_cube_amd.distributed import RcclComm
+
+    class Tr:
+        rank, world_size = 0, 2
+        sent = []
+
+        def bcast_bytes(self, payload=None):
+            Tr.sent.append(payload)
+            return payload
+
+    def boom(name, *a):
+        raise _lib.HipLibraryError("no RCCL here")
+    monkeypatch.setattr(_lib, "call", boom)
+    with pytest.raises(_lib.HipLibraryError, match="RCCL id"):
+        RcclComm(0, Tr())
+    assert Tr.sent == [b""], "the broadcast happened, with the sentinel"
+
+
+def _bench(args, **env):
+    e = dict(os.environ, **env)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=120)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher starts N ranks itself (RANK / LOCAL_RANK /
+    WORLD_SIZE in their environment), the ranks meet through the file rendezvous, rank 0's JSON record is the LAST
+    line of the parent's stdout, exit status 0.  (SPC_BENCH_DRYRUN=1: everything but the GPU work.)"""
+    import json
+    p = _bench(["--gpus", "4", "--steps", "3"], SPC_BENCH_DRYRUN="1")
+    assert p.returncode == 0, p.stderr
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["dryrun"] and rec["n_gpus"] == 4 and rec["steps"] == 3 and rec["bcast"] == "id-from-rank-0"
+    assert [r[:2] for r in rec["ranks"]] == [[i, i] for i in range(4)]
+    assert len({r[2] for r in rec["ranks"]}) == 4, "one process per rank"
+
+
+def test_bench_launch_fails_when_a_rank_fails():
+    import time
+    t0 = time.time()
+    p = _bench(["--gpus", "3"], SPC_BENCH_DRYRUN="1", SPC_BENCH_DRYRUN_FAIL_RANK="2")
+    assert p.returncode == 3 and "rank 2 exited" in p.stderr
+    assert time.time() - t0 < 30, "the surviving ranks are stopped, not left to the rendezvous timeout"
+
+
+def test_bench_without_gpu_fails_loudly_not_silently():
+    p = _bench(["--gpus", "1", "--steps", "1", "--no-north-star", "--no-cpu-baseline"])
+    assert p.returncode != 0 and "no HIP device" in p.stderr and not p.stdout.strip()
