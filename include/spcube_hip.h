@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 2
+#define SPC_ABI_VERSION 3
 
 typedef enum {
     SPC_OK = 0,
@@ -437,9 +437,14 @@ typedef struct spc_celestial_wcs {
     double alpha_p, delta_p;   /* celestial coordinates of the native pole (radians) */
     double phi_p;              /* LONPOLE (radians) */
 } spc_celestial_wcs;
+/* frame_rot (HOST pointer, 9 doubles row-major, may be NULL = same frame): rotation of the unit sphere that takes
+ * the TARGET's celestial frame to the SOURCE's (ICRS / FK5(equinox) / Galactic: spectral_cube_amd/wcs.py::
+ * frame_rotation) - reproject_interp transforms the target's sky coordinates to the source's frame before it
+ * asks the source WCS for pixels (the reference's own test goes RA/DEC -> GLON/GLAT, tests/test_regrid.py:99-135).
+ * (ABI 3: this argument is new.) */
 int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs_out,
-                          const spc_celestial_wcs* wcs_in, int64_t ny_out, int64_t nx_out,
-                          double* d_xs, double* d_ys);
+                          const spc_celestial_wcs* wcs_in, const double* frame_rot,
+                          int64_t ny_out, int64_t nx_out, double* d_xs, double* d_ys);
 
 /* spatial resample: replaces the inner resampler of
  * reproject.reproject_interp(order='bilinear' | 'nearest-neighbor') called from

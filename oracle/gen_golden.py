@@ -485,6 +485,100 @@ def case_wcs():
     print("wcs ok")
 
 
+def case_wcs_frames():
+    """Pixel maps ACROSS celestial frames, the way reproject_interp gets them (spectral_cube.py:2700-2732):
+    target pixels -> SkyCoord in the target's frame (astropy.wcs.utils.wcs_to_celestial_frame) -> transformed by
+    astropy.coordinates to the source's frame -> source pixels.  First pair = the reference's own reprojection test
+    (tests/test_regrid.py:99-135: the RA/DEC-SIN header of tests/data/header_jybeam.hdr, whose EPOCH = 2000 makes it
+    FK5, onto GLON/GLAT-SIN at 134.37608, -31.939241, 5 x 4 pixels)."""
+    from astropy.wcs.utils import wcs_to_celestial_frame
+    from astropy.coordinates import SkyCoord
+    store = {}
+    h_ref = fits.Header.fromtextfile(HDR_FILE)
+    src0 = {k: h_ref[k] for k in ("CTYPE1", "CTYPE2", "CRVAL1", "CRVAL2", "CRPIX1", "CRPIX2", "CDELT1", "CDELT2", "CUNIT1",
+                                  "CUNIT2", "EPOCH")}
+    dst0 = dict(src0, CTYPE1="GLON-SIN", CTYPE2="GLAT-SIN", CRVAL1=134.37608, CRVAL2=-31.939241, CRPIX1=2.0, CRPIX2=2.0)
+    base = {"CRVAL1": 83.6, "CRVAL2": -5.4, "CRPIX1": 20.5, "CRPIX2": 24.5, "CDELT1": -2.0 / 60, "CDELT2": 2.0 / 60,
+            "CUNIT1": "deg", "CUNIT2": "deg"}
+    c, s_ = np.cos(np.radians(20.0)), np.sin(np.radians(20.0))
+    pairs = [
+        (src0, dst0, (5, 4)),
+        (dict(base, CTYPE1="RA---TAN", CTYPE2="DEC--TAN"),                                   # no RADESYS, no EQUINOX: ICRS
+         dict(base, CTYPE1="GLON-TAN", CTYPE2="GLAT-TAN", CRVAL1=208.99, CRVAL2=-19.38, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c),
+         (48, 40)),
+        (dict(base, CTYPE1="GLON-ARC", CTYPE2="GLAT-ARC", CRVAL1=208.99, CRVAL2=-19.38),
+         dict(base, CTYPE1="RA---STG", CTYPE2="DEC--STG", RADESYS="FK5", EQUINOX=1975.0), (48, 40)),   # FK5, equinox != J2000
+        (dict(base, CTYPE1="RA---TAN", CTYPE2="DEC--TAN", RADESYS="FK5", EQUINOX=2000.0),
+         dict(base, CTYPE1="RA---TAN", CTYPE2="DEC--TAN", RADESYS="ICRS", CDELT1=-0.2 / 3600, CDELT2=0.2 / 3600), (48, 40)),
+        (dict(base, CTYPE1="RA---ZEA", CTYPE2="DEC--ZEA", RADESYS="FK5", EQUINOX=2000.0),
+         dict(base, CTYPE1="RA---ZEA", CTYPE2="DEC--ZEA", EQUINOX=2010.5), (48, 40)),         # FK5 -> FK5: precession only
+        (dict(base, CTYPE1="RA---SIN", CTYPE2="DEC--SIN"), dict(base, CTYPE1="RA---SIN", CTYPE2="DEC--SIN", CRPIX1=18.0),
+         (48, 40)),                                                                          # same frame: no rotation
+    ]
+    for i, (h_in, h_out, shape) in enumerate(pairs):
+        w_in, w_out = WCS(fits.Header(h_in)), WCS(fits.Header(h_out))
+        yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+        # = w_in.world_to_pixel(w_out.pixel_to_world(xx, yy)), spelled out (astropy 4.3's high-level WCS API stacks
+        # Quantities in a way numpy 1.26 rejects): wcslib for the pixels, astropy.coordinates between the frames
+        lon, lat = w_out.wcs_pix2world(xx, yy, 0)
+        sky = SkyCoord(lon.ravel() * u.deg, lat.ravel() * u.deg, frame=wcs_to_celestial_frame(w_out))
+        sky = sky.transform_to(wcs_to_celestial_frame(w_in))
+        xs, ys = w_in.wcs_world2pix(sky.spherical.lon.deg.reshape(shape), sky.spherical.lat.deg.reshape(shape), 0)
+        store["in%d" % i] = fits.Header(h_in).tostring(sep="\n")
+        store["out%d" % i] = fits.Header(h_out).tostring(sep="\n")
+        store["xs%d" % i], store["ys%d" % i] = np.asarray(xs, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+        fi, fo = wcs_to_celestial_frame(w_in), wcs_to_celestial_frame(w_out)
+        store["frames%d" % i] = np.array([fi.name, "%r" % getattr(getattr(fi, "equinox", None), "jyear", None),
+                                          fo.name, "%r" % getattr(getattr(fo, "equinox", None), "jyear", None)])
+    store["n"] = len(pairs)
+    # how astropy names the frame of headers this build refuses to relate to others
+    names = []
+    for extra in ({"EQUINOX": 1950.0}, {"RADESYS": "FK4"}, {"RADESYS": "FK4-NO-E", "EQUINOX": 1950.0}, {"RADECSYS": "FK5"},
+                  {"EPOCH": 1950.0}):
+        w = WCS(fits.Header(dict(base, CTYPE1="RA---TAN", CTYPE2="DEC--TAN", **extra)))
+        names.append("%s|%s" % (sorted(extra.items()), wcs_to_celestial_frame(w).name))
+    store["frame_names"] = np.array(names)
+    # ---- the reference's own test, set up with the reference's classes (tests/test_regrid.py:99-135); `reproject` is not
+    # installed, so the expected VALUES are its published steps on astropy's cross-frame pixel map: one trilinear
+    # map_coordinates call on the edge-padded cube (case_reproject_glue_scipy pins the oracle against exactly that)
+    from scipy.ndimage import map_coordinates
+    np.random.seed(96)
+    d = np.random.random((4, 3, 2))
+    cube = SpectralCube.read(hdu_from(d, hdr_255()), use_dask=False)
+    wcs_in = WCS(cube.header)
+    wcs_out = wcs_in.deepcopy()
+    wcs_out.wcs.ctype = ['GLON-SIN', 'GLAT-SIN', wcs_in.wcs.ctype[2]]
+    wcs_out.wcs.crval = [134.37608, -31.939241, wcs_in.wcs.crval[2]]
+    wcs_out.wcs.crpix = [2., 2., wcs_in.wcs.crpix[2]]
+    wcs_out.wcs.restwav = 0.21106114549833
+    header_out = cube.header
+    header_out['NAXIS1'] = 4
+    header_out['NAXIS2'] = 5
+    header_out['NAXIS3'] = cube.shape[0]
+    header_out.update(wcs_out.to_header())
+    yy, xx = np.mgrid[0:5, 0:4]
+    lon, lat = wcs_out.celestial.wcs_pix2world(xx, yy, 0)
+    sky = SkyCoord(lon.ravel() * u.deg, lat.ravel() * u.deg, frame=wcs_to_celestial_frame(wcs_out.celestial))
+    sky = sky.transform_to(wcs_to_celestial_frame(wcs_in.celestial))
+    xs, ys = wcs_in.celestial.wcs_world2pix(sky.spherical.lon.deg.reshape(5, 4), sky.spherical.lat.deg.reshape(5, 4), 0)
+    assert np.allclose(xs, store["xs0"], atol=1e-9) and np.allclose(ys, store["ys0"], atol=1e-9)
+    nz = d.shape[0]
+    padded = np.pad(d.astype(np.float64), 1, mode="edge")
+    zz = np.broadcast_to(np.arange(nz, dtype=np.float64)[:, None, None], (nz, 5, 4))
+    coords = np.array([zz + 1, np.broadcast_to(ys, zz.shape) + 1, np.broadcast_to(xs, zz.shape) + 1])
+    exp = map_coordinates(padded, coords, order=1, mode="constant", cval=np.nan)
+    reset = (xs < -0.5) | (xs > 2 - 0.5) | (ys < -0.5) | (ys > 3 - 0.5)
+    exp[np.broadcast_to(reset, exp.shape)] = np.nan
+    got, foot = O.reproject_separable(d, xs, ys, None)
+    close(got, exp, rtol=1e-12, atol=1e-12, what="reference reproject case through the oracle")
+    assert np.isfinite(exp).any()
+    store["adv_data"], store["adv_header"] = d, hdu_from(d, hdr_255()).header.tostring(sep="\n")
+    store["adv_header_out"] = header_out.tostring(sep="\n")
+    store["adv_expected"], store["adv_xs"], store["adv_ys"] = exp, xs, ys
+    np.savez_compressed(os.path.join(OUT, "wcs_frames.npz"), **store)
+    print("wcs_frames ok", names)
+
+
 def case_bilinear_scipy():
     """Pins oracle_np.resample_bilinear against the resampling primitive reproject calls.
 
@@ -809,7 +903,7 @@ def case_beams_cube():
 
 if __name__ == "__main__":
     cases = [case_beams_cube, case_moment_cube, case_c1, case_adv_argmax, case_smooth, case_interp, case_kernels,
-             case_wcs, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
+             case_wcs, case_wcs_frames, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
              case_order_statistics, case_sigma_clip]
     only = set(sys.argv[1:])                 # e.g. `gen_golden.py case_reproject_glue_scipy` regenerates one fixture
     for fn in cases:

@@ -22,7 +22,7 @@ SPC_ERR_COMM = -5
 MASK_NONE, MASK_ARRAY, MASK_FINITE = 0, 1, 2
 MASK_GT, MASK_GE, MASK_LT, MASK_LE = 4, 8, 16, 32
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
@@ -96,7 +96,7 @@ SIGNATURES = {
                                     _P(C.c_uint64), _P(C.c_uint32), _vp, _sz]),
     "spc_key_to_f32": (_f, [C.c_uint32]),
     "spc_clip_bounds_f32": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
-    "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _i64, _i64, _vp, _vp]),
+    "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _P(C.c_double), _i64, _i64, _vp, _vp]),
     "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _vp, _sz]),
     "spc_pool_trim": (_i, [_i]),
     "spc_pool_stats": (_i, [_i, _P(C.c_int64), _P(C.c_int64)]),

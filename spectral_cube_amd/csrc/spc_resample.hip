@@ -420,7 +420,7 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
 // Same sequence of operations as spectral_cube_amd/wcs.py (celestial_pix2world of the target followed
 // by celestial_world2pix of the source), which is validated against astropy.wcs; on the host this map
 // costs 0.8 s for 1024^2 pixels - a hundred times the resampling kernel it feeds.
-struct WcsPair { spc_celestial_wcs o, i; int64_t ny, nx; double* xs; double* ys; };
+struct WcsPair { spc_celestial_wcs o, i; int64_t ny, nx; double* xs; double* ys; int has_rot; double rot[9]; };
 
 __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     const int64_t x = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -454,6 +454,16 @@ __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     if (lon_deg < 0.0) lon_deg += 360.0;
     lon = lon_deg * D2R;
     lat = (lat * R2D) * D2R;
+    if (A.has_rot) {       // target frame -> source frame: a rotation of the unit vector (wcs.py::reproject_pixel_map)
+        const double cla = cos(lat), vx = cla * cos(lon), vy = cla * sin(lon), vz = sin(lat);
+        const double wx = A.rot[0] * vx + A.rot[1] * vy + A.rot[2] * vz;
+        const double wy = A.rot[3] * vx + A.rot[4] * vy + A.rot[5] * vz;
+        const double wz = A.rot[6] * vx + A.rot[7] * vy + A.rot[8] * vz;
+        double l2 = fmod(atan2(wy, wx) * R2D, 360.0);
+        if (l2 < 0.0) l2 += 360.0;
+        lon = l2 * D2R;
+        lat = (atan2(wz, hypot(wx, wy)) * R2D) * D2R;
+    }
     // celestial -> native unit vector of the source -> source pixel
     const double da = lon - A.i.alpha_p;
     const double sl = sin(lat), cl = cos(lat);
@@ -528,13 +538,17 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube, co
 }
 
 int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs_out, const spc_celestial_wcs* wcs_in,
-                          int64_t ny_out, int64_t nx_out, double* d_xs, double* d_ys) {
+                          const double* frame_rot, int64_t ny_out, int64_t nx_out, double* d_xs, double* d_ys) {
     SPC_REQUIRE(wcs_out && wcs_in && d_xs && d_ys, "NULL pointer argument");
     SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
     SPC_REQUIRE(wcs_out->proj >= 0 && wcs_out->proj <= 5 && wcs_in->proj >= 0 && wcs_in->proj <= 5, "unknown projection code");
     SPC_REQUIRE((ny_out + 3) / 4 <= 65535, "too many rows for one launch");
     SPC_DEVICE(device);
-    WcsPair A{*wcs_out, *wcs_in, ny_out, nx_out, d_xs, d_ys};
+    WcsPair A{*wcs_out, *wcs_in, ny_out, nx_out, d_xs, d_ys, 0, {1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    if (frame_rot) {
+        A.has_rot = 1;
+        for (int k = 0; k < 9; ++k) A.rot[k] = frame_rot[k];
+    }
     hipLaunchKernelGGL(wcs_pixel_map_kernel, dim3((unsigned)((nx_out + 63) / 64), (unsigned)((ny_out + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, A);
     SPC_LAUNCH_CHECK();

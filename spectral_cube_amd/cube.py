@@ -34,7 +34,7 @@ from . import _lib, masks as M, ops
 from .beam import Beam, BeamError
 from .device import DeviceArray
 from .kernels import kernel_array
-from .wcs import (SimpleWCS, join_celestial_spectral, pix_cen_spatial, pix_size, reproject_pixel_map,
+from .wcs import (SimpleWCS, check_same_spectral_kind, join_celestial_spectral, pix_cen_spatial, pix_size, reproject_pixel_map,
                   spectral_unit_scale)
 
 SIGMA2FWHM = 2. * np.sqrt(2. * np.log(2.))      # spectral_cube.py:66
@@ -951,12 +951,13 @@ class SpectralCube:
         zs = None
         if newwcs.naxis >= 3 and self._wcs is not None and self._wcs.naxis >= 3:
             nz_out = int(hdr.get("NAXIS3", nz))
+            check_same_spectral_kind(self._wcs, newwcs)
             scale = spectral_unit_scale(newwcs.spectral_unit or self.spectral_unit, self.spectral_unit)
             zs = self._wcs.spectral_world2pix(newwcs.spectral_pix2world(np.arange(nz_out)) * scale)
             if nz_out == nz and np.all(np.abs(zs - np.arange(nz)) <= 1e-9 * max(nz, 1)):
                 zs = None                         # the same channels: a purely spatial reprojection
         elif self._wcs is not None and self._wcs.naxis >= 3:
-            newwcs = join_celestial_spectral(newwcs, self._wcs)
+            newwcs = join_celestial_spectral(newwcs, self._wcs, nz)
         if zs is not None and (order == 0 or nz < 2):
             raise NotImplementedError("resampling the spectral axis as well needs order='bilinear' and at least two channels")
         if os.environ.get("SPC_WCS_HOST_MAP", "0") == "1":         # cross-check: the numpy map (0.8 s per 1024^2 pixels)

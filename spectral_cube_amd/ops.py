@@ -358,7 +358,11 @@ def wcs_pixel_map(wcs_in, wcs_out, shape_out, device=0, stream=None):
     ny, nx = (int(n) for n in shape_out)
     d_xs, d_ys = DeviceArray((ny, nx), np.float64, device), DeviceArray((ny, nx), np.float64, device)
     so, si = _wcs_struct(wcs_out), _wcs_struct(wcs_in)
-    _lib.call("spc_wcs_pixel_map_f64", device, _sh(stream), C.byref(so), C.byref(si), ny, nx,
+    # target frame -> source frame (ICRS / FK5 / Galactic; NotImplementedError for pairs that are not built; None = same)
+    from .wcs import frame_rotation
+    rot = frame_rotation(getattr(wcs_out, "frame", None), getattr(wcs_in, "frame", None))
+    rp = None if rot is None else (C.c_double * 9)(*np.ascontiguousarray(rot, dtype=np.float64).ravel())
+    _lib.call("spc_wcs_pixel_map_f64", device, _sh(stream), C.byref(so), C.byref(si), rp, ny, nx,
               C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr))
     return d_xs, d_ys
 

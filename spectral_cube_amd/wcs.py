@@ -12,12 +12,25 @@ It stands in for the astropy.wcs calls made by
 (_pix_cen, _pix_size_slice) and ``wcs_utils.py:28-45`` (drop_axis).
 """
 import copy
+import re
 
 import numpy as np
 
 _D2R = np.pi / 180.0
 _R2D = 180.0 / np.pi
 _ZENITHAL = ("TAN", "SIN", "ARC", "STG", "ZEA")
+
+
+_AXIS_KEY = re.compile(r"^(?:(?:CTYPE|CRVAL|CRPIX|CDELT|CUNIT|CROTA|NAXIS|CNAME|CRDER|CSYER)(\d)|(?:PC|CD)(\d)_(\d)|"
+                       r"PC00(\d)00(\d)|(?:PV|PS)(\d)_\d+)$")
+_SPECTRAL_KEYS = ("RESTFRQ", "RESTFREQ", "RESTWAV", "SPECSYS", "SSYSOBS", "VELREF", "VELOSYS", "ZSOURCE", "SSYSSRC")
+
+
+def key_axes(key):
+    """FITS axis numbers a WCS keyword refers to: CTYPE3 -> {3}, PC1_3 -> {1, 3}, PV2_3 -> {2} (the 3 is a parameter
+    index), A_3_0 / RESTFRQ -> {} (not an axis keyword)"""
+    m = _AXIS_KEY.match(str(key).upper())
+    return {int(g) for g in m.groups() if g is not None} if m else set()
 
 
 def parse_header(header):
@@ -101,6 +114,7 @@ class SimpleWCS:
             raise NotImplementedError("projection %r not supported by SimpleWCS" % self.proj)
         self.lonpole = g("LONPOLE", None)
         self.latpole = float(g("LATPOLE", 90.0))
+        self.frame = _celestial_frame(self.ctype[:2], h) if n >= 2 and self.proj else None
         for i in (0, 1):
             if i < n and self.cunit[i] not in ("", "deg"):
                 raise NotImplementedError("celestial CUNIT must be deg")
@@ -250,7 +264,7 @@ class SimpleWCS:
         out.ctype, out.cunit = out.ctype[:2], out.cunit[:2]
         out.crval, out.crpix, out.cdelt = out.crval[:2], out.crpix[:2], out.cdelt[:2]
         out.pc = out.pc[:2, :2]
-        out.header = {k: v for k, v in self.header.items() if not k.endswith("3") and "3_" not in k and "_3" not in k}
+        out.header = {k: v for k, v in self.header.items() if 3 not in key_axes(k)}
         return out
 
     def with_spectral(self, crval, cdelt, crpix=1.0, cunit=None):
@@ -278,6 +292,82 @@ class SimpleWCS:
         return h
 
 
+# ---- celestial reference frames ---------------------------------------------------------------------
+# reproject_interp hands full WCS objects to astropy (spectral_cube.py:2700-2732), which turns the target's
+# pixels into sky coordinates IN THE TARGET'S FRAME, transforms them to the source's frame and only then asks
+# the source WCS for pixels.  The frame of a header follows astropy.wcs.utils.wcs_to_celestial_frame; the
+# transformations between ICRS, FK5(equinox) and Galactic are constant rotations of the unit sphere (restated
+# from their published definitions below); FK4 (Besselian equinoxes: E-terms of aberration) is not built.
+def _celestial_frame(ctype, header):
+    """('icrs',) | ('fk5', equinox_jyear) | ('fk4', equinox_byear) | ('galactic',) | ('other', lon, lat)"""
+    x, y = str(ctype[0])[:4].upper(), str(ctype[1])[:4].upper()
+    g = header.get
+    if x == "RA--" and y == "DEC-":
+        radesys = str(g("RADESYS", g("RADECSYS", "")) or "").strip().upper()
+        eq = g("EQUINOX", g("EPOCH", None))                       # wcslib reads EPOCH as the old name of EQUINOX
+        eq = None if eq is None or eq == "" else float(eq)
+        if radesys == "":
+            radesys = "ICRS" if eq is None else ("FK4" if eq < 1984.0 else "FK5")
+        if radesys == "ICRS":
+            return ("icrs",)
+        if radesys == "FK5":
+            return ("fk5", 2000.0 if eq is None else eq)
+        if radesys in ("FK4", "FK4-NO-E"):
+            return (radesys.lower(), 1950.0 if eq is None else eq)
+        return ("other", "RA--:" + radesys, y)
+    if x == "GLON" and y == "GLAT":
+        return ("galactic",)
+    return ("other", x, y)
+
+
+def _rot(angle_deg, axis):
+    """passive rotation about a coordinate axis (the convention of astropy's rotation_matrix)"""
+    a = np.deg2rad(angle_deg)
+    c, s_ = np.cos(a), np.sin(a)
+    i = "xyz".index(axis)
+    a1, a2 = (i + 1) % 3, (i + 2) % 3
+    r = np.zeros((3, 3))
+    r[i, i] = 1.0
+    r[a1, a1], r[a1, a2], r[a2, a1], r[a2, a2] = c, s_, -s_, c
+    return r
+
+
+def _precess_from_j2000(jyear):
+    """precession J2000 -> Julian epoch *jyear*: Capitaine et al. 2003 as printed in USNO Circular 179 (the IAU
+    2006 angles zeta, z, theta in arcseconds) - what astropy's FK5 frame uses"""
+    t = (jyear - 2000.0) / 100.0
+    zeta = np.polyval((-0.0000003173, -0.000005971, 0.01801828, 0.2988499, 2306.083227, 2.650545), t) / 3600.0
+    z = np.polyval((-0.0000002904, -0.000028596, 0.01826837, 1.0927348, 2306.077181, -2.650545), t) / 3600.0
+    theta = np.polyval((-0.0000001274, -0.000007089, -0.04182264, -0.4294934, 2004.191903, 0.0), t) / 3600.0
+    return _rot(-z, "z") @ _rot(theta, "y") @ _rot(-zeta, "z")
+
+
+# ICRS -> FK5(J2000): the frame bias (eta0, xi0, dalpha0 in milliarcseconds; Hilton & Hohenkerk 2004)
+_ICRS_TO_FK5J2000 = _rot(19.9 / 3600000.0, "x") @ _rot(9.1 / 3600000.0, "y") @ _rot(-22.9 / 3600000.0, "z")
+# FK5(J2000) -> Galactic: north galactic pole and the longitude of the north celestial pole in FK5 J2000
+# (the IAU 1958 definition carried from B1950 to J2000)
+_FK5J2000_TO_GAL = (_rot(180.0 - 122.9319185680026, "z") @ _rot(90.0 - 27.12825118085622, "y")
+                    @ _rot(192.8594812065348, "z"))
+
+
+def _to_fk5j2000(frame):
+    if frame[0] == "icrs":
+        return _ICRS_TO_FK5J2000
+    if frame[0] == "galactic":
+        return _FK5J2000_TO_GAL.T
+    if frame[0] == "fk5":
+        return _precess_from_j2000(2000.0) @ _precess_from_j2000(float(frame[1])).T
+    raise NotImplementedError("celestial frame %r: only ICRS, FK5 and Galactic are related to each other here "
+                              "(FK4 / ecliptic / helioprojective headers reproject only onto their own frame)" % (frame,))
+
+
+def frame_rotation(frame_from, frame_to):
+    """3 x 3 matrix taking unit vectors of *frame_from* to *frame_to*, or None when the two are the same frame"""
+    if frame_from is None or frame_to is None or tuple(frame_from) == tuple(frame_to):
+        return None
+    return _to_fk5j2000(frame_to).T @ _to_fk5j2000(frame_from)
+
+
 _SPECTRAL_SI = {"m/s": ("speed", 1.0), "km/s": ("speed", 1e3), "cm/s": ("speed", 1e-2),
                 "Hz": ("freq", 1.0), "kHz": ("freq", 1e3), "MHz": ("freq", 1e6), "GHz": ("freq", 1e9),
                 "m": ("length", 1.0), "cm": ("length", 1e-2), "mm": ("length", 1e-3), "um": ("length", 1e-6),
@@ -296,15 +386,43 @@ def spectral_unit_scale(unit_from, unit_to):
     return _SPECTRAL_SI[a][1] / _SPECTRAL_SI[b][1]
 
 
-def join_celestial_spectral(celestial, spectral):
-    """3-axis WCS with the celestial axes of *celestial* and the spectral axis of *spectral*"""
-    h = {k: v for k, v in celestial.header.items() if not (k.endswith("3") or "3_" in k or "_3" in k)}
+def join_celestial_spectral(celestial, spectral, nz=None):
+    """3-axis WCS with the celestial axes of *celestial* and the spectral axis of *spectral* (keywords are chosen by
+    the axis they name, not by the digits they contain: PV2_3 and the SIP terms A_3_0 stay celestial, the PC1_3 /
+    PC3_1 cross terms of either header are dropped - the two parts are separable by construction)"""
+    h = {k: v for k, v in celestial.header.items() if 3 not in key_axes(k) and k not in _SPECTRAL_KEYS}
     for k, v in spectral.header.items():
-        if k.endswith("3") and not k.startswith("NAXIS"):
+        if key_axes(k) == {3} and not k.startswith("NAXIS"):
+            h[k] = v
+        elif k in _SPECTRAL_KEYS:
             h[k] = v
     h["NAXIS"] = 3
     h["WCSAXES"] = 3
+    if nz is None:
+        nz = spectral.header.get("NAXIS3")
+    if nz is not None:
+        h["NAXIS3"] = int(nz)
     return SimpleWCS(h)
+
+
+def check_same_spectral_kind(src, dst):
+    """reproject's spectral regrid is LINEAR in the axis both headers describe: it is only a regrid when they describe
+    the same axis.  The reference hands both full WCSs to reproject_interp, where wcslib converts between spectral
+    representations (spectral_cube.py:2700-2732); that conversion is not built, so a different CTYPE3 (VRAD vs VOPT,
+    both in m/s), rest frequency / wavelength or SPECSYS raises instead of resampling at the wrong channels."""
+    hs, hd = src.header, dst.header
+    a, b = str(hs.get("CTYPE3", "")).strip().upper()[:4], str(hd.get("CTYPE3", "")).strip().upper()[:4]
+    if a and b and a != b:
+        raise NotImplementedError("reproject onto another spectral representation (CTYPE3 %r -> %r) is not built: convert "
+                                  "the cube's spectral axis first" % (hs.get("CTYPE3"), hd.get("CTYPE3")))
+    for keys in (("RESTFRQ", "RESTFREQ"), ("RESTWAV",)):
+        va = next((float(hs[k]) for k in keys if k in hs and hs[k] not in ("", None)), None)
+        vb = next((float(hd[k]) for k in keys if k in hd and hd[k] not in ("", None)), None)
+        if va is not None and vb is not None and va != 0.0 and vb != 0.0 and abs(va - vb) > 1e-9 * abs(va):
+            raise NotImplementedError("reproject between rest %s %r and %r is not built" % (keys[0], va, vb))
+    sa, sb = str(hs.get("SPECSYS", "")).strip().upper(), str(hd.get("SPECSYS", "")).strip().upper()
+    if sa and sb and sa != sb:
+        raise NotImplementedError("reproject between spectral reference frames (SPECSYS %s -> %s) is not built" % (sa, sb))
 
 
 def angular_separation(lon1, lat1, lon2, lat2):
@@ -351,4 +469,11 @@ def reproject_pixel_map(wcs_in, wcs_out, shape_out):
     ny, nx = shape_out
     yy, xx = np.mgrid[0:ny, 0:nx]
     lon, lat = wcs_out.celestial_pix2world(xx, yy)
+    rot = frame_rotation(wcs_out.frame, wcs_in.frame)         # NotImplementedError for pairs that are not built
+    if rot is not None:
+        lo, la = lon * _D2R, lat * _D2R
+        v = np.stack([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)])
+        w = np.tensordot(rot, v, axes=1)
+        lon = np.mod(np.arctan2(w[1], w[0]) * _R2D, 360.0)
+        lat = np.arctan2(w[2], np.hypot(w[0], w[1])) * _R2D
     return wcs_in.celestial_world2pix(lon, lat)

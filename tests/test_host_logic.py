@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libspcube_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.spc_abi_version() == 2
+    assert lib.spc_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -486,3 +486,92 @@ def test_pinned_result_pool(monkeypatch):
     del b, c
     gc.collect()
     assert pool.idle_bytes == 1 << 21 and log[-1][0] == "free" and len(keep) == 1
+
+
+# ---- round 3: celestial frames (missing 2 / weak 1) -----------------------------------
+def test_pixel_map_across_celestial_frames_matches_astropy():
+    """reproject_interp transforms the target's sky coordinates to the SOURCE's frame before asking the source WCS
+    for pixels (spectral_cube.py:2700-2732).  Fixture: astropy.wcs + astropy.coordinates in the build container
+    (oracle/gen_golden.py::case_wcs_frames); pair 0 is the reference's own test (tests/test_regrid.py:99-135:
+    RA/DEC-SIN with EPOCH = 2000 -> FK5, onto GLON/GLAT-SIN at 134.37608, -31.939241, 5 x 4)."""
+    g = golden("wcs_frames.npz")
+    assert int(g["n"]) == 6
+    for i in range(int(g["n"])):
+        a, b = SimpleWCS(str(g["in%d" % i]), naxis=2), SimpleWCS(str(g["out%d" % i]), naxis=2)
+        names = [str(x) for x in g["frames%d" % i]]
+        for w, (name, eq) in ((a, names[:2]), (b, names[2:])):
+            assert w.frame[0] == name, (i, w.frame, name)
+            if name == "fk5":
+                assert w.frame[1] == float(eq)
+        xs, ys = reproject_pixel_map(a, b, g["xs%d" % i].shape)
+        assert np.nanmax(np.abs(xs - g["xs%d" % i])) <= 1e-9 and np.nanmax(np.abs(ys - g["ys%d" % i])) <= 1e-9, i
+    # the reference's case: the target pixels DO land on the source image (round 2: all NaN / off the image)
+    xs, ys = g["xs0"], g["ys0"]
+    assert xs.shape == (5, 4) and ((xs > -0.5) & (xs < 1.5) & (ys > -0.5) & (ys < 2.5)).sum() >= 6
+
+
+def test_celestial_frame_of_a_header_follows_astropy():
+    from spectral_cube_amd.wcs import frame_rotation
+    g = golden("wcs_frames.npz")
+    base = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CRVAL1": 83.6, "CRVAL2": -5.4, "CRPIX1": 20.5, "CRPIX2": 24.5,
+            "CDELT1": -2.0 / 60, "CDELT2": 2.0 / 60}
+    seen = {}
+    for rec in g["frame_names"]:
+        keys, name = str(rec).split("|")
+        extra = dict(eval(keys))                       # "[('EQUINOX', 1950.0)]": written by gen_golden, data only
+        seen[name] = SimpleWCS(dict(base, **extra), naxis=2).frame
+        assert seen[name][0].replace("-", "").replace("noe", "noeterms") == name or seen[name][0] == name, (rec, seen[name])
+    icrs = SimpleWCS(base, naxis=2)
+    assert icrs.frame == ("icrs",)
+    # FK4 needs the E-terms of aberration: not built, and it must say so instead of equating the frames
+    with pytest.raises(NotImplementedError, match="FK4|fk4"):
+        frame_rotation(seen["fk4"], icrs.frame)
+    with pytest.raises(NotImplementedError):
+        reproject_pixel_map(SimpleWCS(dict(base, EQUINOX=1950.0), naxis=2), icrs, (4, 4))
+    ecl = SimpleWCS(dict(base, CTYPE1="ELON-TAN", CTYPE2="ELAT-TAN"), naxis=2)
+    with pytest.raises(NotImplementedError):
+        reproject_pixel_map(icrs, ecl, (4, 4))
+    # the same frame on both sides needs no rotation, whatever the frame is
+    assert frame_rotation(ecl.frame, ecl.frame) is None and frame_rotation(seen["fk4"], seen["fk4"]) is None
+    r = frame_rotation(("icrs",), ("galactic",))
+    assert np.allclose(r @ r.T, np.eye(3), atol=1e-15) and abs(np.linalg.det(r) - 1) < 1e-15
+    # galactic centre, ICRS (17h45m37.224s, -28d56m10.23s) -> l = 0, b = 0 to ~0.1 arcsec (Reid & Brunthaler 2004)
+    ra, dec = np.deg2rad(266.40510), np.deg2rad(-28.936175)
+    v = r @ np.array([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)])
+    assert abs(np.degrees(np.arctan2(v[1], v[0]))) < 2e-3 and abs(np.degrees(np.arcsin(v[2]))) < 2e-3
+
+
+def test_header_keys_are_selected_by_axis_not_by_digit():
+    """PV2_3 / A_3_0 are celestial keywords that merely contain a 3; PC1_3 cross terms must not
+    travel with the spectral axis; NAXIS3 is defined."""
+    from spectral_cube_amd.wcs import join_celestial_spectral, key_axes
+    cel = SimpleWCS({"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CRVAL1": 1.0, "CRVAL2": 2.0, "CRPIX1": 3.0, "CRPIX2": 4.0,
+                     "CDELT1": -1e-3, "CDELT2": 1e-3, "PV2_3": 0.25, "A_3_0": 1e-9, "B_0_3": 2e-9, "NAXIS1": 5, "NAXIS2": 6}, naxis=2)
+    spec = SimpleWCS({"CTYPE1": "GLON-CAR", "CTYPE2": "GLAT-CAR", "CTYPE3": "VRAD", "CRVAL3": 5.0, "CDELT3": 2.0, "CRPIX3": 1.0,
+                      "CUNIT3": "km/s", "PC1_3": 0.0, "PC3_3": 1.0, "RESTFRQ": 1.4e9, "SPECSYS": "LSRK", "NAXIS3": 7})
+    j = join_celestial_spectral(cel, spec)
+    h = j.header
+    assert h["PV2_3"] == 0.25 and h["A_3_0"] == 1e-9 and h["B_0_3"] == 2e-9
+    assert "PC1_3" not in h and h["PC3_3"] == 1.0 and h["CTYPE3"] == "VRAD" and h["CTYPE1"] == "RA---TAN"
+    assert h["NAXIS3"] == 7 and h["RESTFRQ"] == 1.4e9 and h["SPECSYS"] == "LSRK"
+    assert join_celestial_spectral(cel, spec, nz=11).header["NAXIS3"] == 11
+    d = j.drop_spectral().header
+    assert "CTYPE3" not in d and "PC3_3" not in d and d["PV2_3"] == 0.25 and d["A_3_0"] == 1e-9
+    assert key_axes("PV2_3") == {2} and key_axes("PC1_3") == {1, 3} and key_axes("A_3_0") == set()
+
+
+def test_reproject_refuses_another_spectral_representation():
+    """a target header whose spectral axis is another KIND of axis (VRAD vs VOPT, both m/s; another
+    rest frequency; another SPECSYS) is not a regrid: raise instead of resampling at the wrong channels."""
+    from spectral_cube_amd.wcs import check_same_spectral_kind
+    h = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CUNIT3": "m/s", "CDELT3": 500.0, "CRVAL3": 0.0,
+         "CRPIX3": 1.0, "RESTFRQ": 1.420405752e9, "SPECSYS": "LSRK"}
+    a = SimpleWCS(h)
+    check_same_spectral_kind(a, SimpleWCS(dict(h, CDELT3=250.0, CUNIT3="km/s")))
+    check_same_spectral_kind(a, SimpleWCS({k: v for k, v in h.items() if k not in ("RESTFRQ", "SPECSYS")}))
+    for bad in (dict(h, CTYPE3="VOPT"), dict(h, RESTFRQ=1.6e9), dict(h, SPECSYS="BARYCENT")):
+        with pytest.raises(NotImplementedError):
+            check_same_spectral_kind(a, SimpleWCS(bad))
+    cube = SpectralCube(np.zeros((4, 3, 2), dtype=np.float32), header=dict(h, NAXIS1=2, NAXIS2=3, NAXIS3=4))
+    with pytest.raises(NotImplementedError, match="CTYPE3"):
+        cube.reproject(dict(h, CTYPE3="VOPT", NAXIS1=2, NAXIS2=3, NAXIS3=4))
