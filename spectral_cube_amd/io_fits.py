@@ -164,7 +164,25 @@ class _Pinned:
             self.ptr = 0
 
 
-def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, readers=8, stats=None, rows=None):
+class Staging:
+    """pinned staging buffers + their raw device twins + the copy stream of load_cube, kept across calls (the
+    out-of-core strip loop of streaming.py calls load_cube once per strip: pinning 1 GiB of host memory per call
+    would cost more than the strip's transfer)"""
+
+    def __init__(self, device=0, chunk_bytes=128 << 20, nbuffers=8):
+        self.device, self.chunk_bytes, self.nbuffers = device, int(chunk_bytes), int(nbuffers)
+        self.pinned = [_Pinned(self.chunk_bytes) for _ in range(self.nbuffers)]
+        self.d_raw = [DeviceArray((self.chunk_bytes,), np.uint8, device) for _ in range(self.nbuffers)]
+        self.stream = Stream(device)
+
+    def close(self):
+        for b in self.pinned:
+            b.close()
+        self.pinned, self.d_raw = [], []
+
+
+def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, readers=8, stats=None, rows=None,
+              staging=None):
     """Stream the image payload of *path* into a (nz, ny, nx) float32 DeviceArray.
 
     chunk_bytes / nbuffers: size and count of the pinned staging buffers; readers: threads
@@ -184,6 +202,8 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
         raise ValueError("rows must satisfy 0 <= y0 < y1 <= %d" % ny_file)
     ny = y1 - y0
     bps = _BYTES[img.bitpix]
+    if staging is not None:
+        chunk_bytes, nbuffers = staging.chunk_bytes, staging.nbuffers
     out = DeviceArray((nz, ny, nx), np.float32, device)
     seg = ny * nx * bps                                # one plane's strip: contiguous in the file
     total = nz * seg
@@ -196,9 +216,16 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
         chunk = ppc * seg
         nchunks = (nz + ppc - 1) // ppc
     nbuf = max(1, min(nbuffers, nchunks))
-    pinned = [_Pinned(chunk) for _ in range(nbuf)]
-    d_raw = [DeviceArray((chunk,), np.uint8, device) for _ in range(nbuf)]
-    stream = Stream(device)
+    if staging is not None:
+        if chunk > staging.chunk_bytes:
+            raise ValueError("one plane strip (%d bytes) does not fit the staging buffers (%d bytes)" % (chunk, staging.chunk_bytes))
+        pinned, d_raw, stream = staging.pinned[:nbuf], staging.d_raw[:nbuf], staging.stream
+        for b in pinned:
+            b.free_evt = None
+    else:
+        pinned = [_Pinned(chunk) for _ in range(nbuf)]
+        d_raw = [DeviceArray((chunk,), np.uint8, device) for _ in range(nbuf)]
+        stream = Stream(device)
     fd = os.open(path, os.O_RDONLY)
     has_blank = img.blank is not None and img.bitpix > 0
     t0 = time.perf_counter()
@@ -254,11 +281,13 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
         stream.synchronize()
     finally:
         os.close(fd)
-        for b in pinned:
-            b.close()
+        if staging is None:
+            for b in pinned:
+                b.close()
     if stats is not None:
         stats.update(bytes=total, seconds=time.perf_counter() - t0)
-    out._keep = d_raw
+    if staging is None:
+        out._keep = d_raw
     hdr = cube_header(img)
     if rows is not None:
         hdr["NAXIS2"] = ny

@@ -677,7 +677,7 @@ def test_convolve_to(gpu):
     assert out.beam == tgt and out.header["BMAJ"] == tgt.major
     karr = tgt.deconvolve(cur).as_kernel(pix)
     exp = O.spatial_smooth(d, None, karr) * (tgt.sr / cur.sr)
-    assert_close(res, exp, atol=2e-5 * np.max(np.abs(exp)), what="convolve_to vs oracle")
+    assert_close(res, exp, atol=1e-5 * np.max(np.abs(exp)), what="convolve_to vs oracle")
     w = res[0] / res[0].sum()
     cov = np.array([[np.sum(w * xx * xx), np.sum(w * xx * yy)], [np.sum(w * xx * yy), np.sum(w * yy * yy)]]) * pix * pix
     np.testing.assert_allclose(cov, tgt.covariance(), rtol=2e-2, atol=2e-2 * tgt.covariance().max())
@@ -710,7 +710,7 @@ def test_varying_resolution_convolve_to(gpu, tmp_path):
     assert type(out) is SpectralCube and out.beam == tgt
     res, exp = out._device_data().get(), g["expected"]
     assert np.array_equal(np.isnan(res), np.isnan(exp))
-    assert_close(res, exp, atol=2e-5 * np.nanmax(np.abs(exp)), what="per-channel convolve_to vs astropy")
+    assert_close(res, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="per-channel convolve_to vs astropy")
     np.testing.assert_array_equal(res[3], g["data"][3])                     # beam == target: untouched
     assert np.isnan(res[4]).all()                                           # masked-out layer
     # a target smaller than some channel's beam: error unless allow_smaller, then that channel passes through
@@ -757,7 +757,11 @@ def test_varying_resolution_convolve_to(gpu, tmp_path):
     target = Beam(1.802775637731995 / 3600, 1.802775637731995 / 3600, 0.0)
     conv = vr.convolve_to(target)._device_data().get()
     for ii, bm in enumerate(beams):
-        k = target.deconvolve(bm).as_kernel(pix)
+        # expectation from the oracle's INDEPENDENT beam algebra (second moments + eigen-decomposition), not from the
+        # product's beam.py (round 2 compared beam.py with itself here)
+        kb = O.deconvolve_beam((target.major, target.minor, target.pa), (bm.major, bm.minor, bm.pa))
+        k = O.elliptical_gaussian_kernel(kb[0], kb[1], kb[2], pix)
+        assert k.shape == target.deconvolve(bm).as_kernel(pix).shape
         h = k.shape[0] // 2
         k5 = k[h - 2:h + 3, h - 2:h + 3] if h >= 2 else np.pad(k, 2 - h)
         np.testing.assert_allclose(conv[ii], k5 / k.sum(), atol=1e-6)
