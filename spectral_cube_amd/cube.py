@@ -194,8 +194,8 @@ class SpectralCube:
 
     def __init__(self, data=None, wcs=None, mask=None, meta=None, fill_value=np.nan,
                  header=None, unit=None, device=0, allow_huge_operations=False, _dev=None,
-                 _lazy=None, _shape=None, _data_id=None):
-        if data is None and _dev is None and _lazy is None:
+                 _lazy=None, _shape=None, _data_id=None, _source=None):
+        if data is None and _dev is None and _lazy is None and _source is None:
             raise ValueError("data is required")
         if data is not None:
             data = np.asarray(data)
@@ -204,6 +204,7 @@ class SpectralCube:
         self._data = data                 # host ndarray or None
         self._dev = _dev                  # DeviceArray float32 or None
         self._lazy = _lazy                # pending (op, parent, args) - see spectral_smooth
+        self._source = _source            # streaming.FitsSource / NdarraySource of an out-of-core cube, or None
         self._shape = tuple(data.shape) if data is not None else (
             tuple(_dev.shape) if _dev is not None else tuple(_shape))
         if wcs is None and header is not None:
@@ -235,7 +236,21 @@ class SpectralCube:
         header.  Like the FITS reader (spectral_cube/io/fits.py:171-260) it attaches
         ``LazyMask(np.isfinite)`` and copies ``BUNIT`` into ``meta``."""
         if isinstance(data, (str, os.PathLike)):
-            from . import io_fits
+            from . import io_fits, streaming
+            img = io_fits.find_image(os.fspath(data), hdu)
+            fshape = tuple(io_fits.cube_shape(img))
+            _lib.require_gpu()
+            if 4 * int(np.prod(fshape, dtype=np.int64)) > streaming.hbm_budget(device):
+                # larger than the HBM budget: the cube stays in the file and goes through the device in row
+                # strips (streaming.py; the role of _moments.py:89-125 / cube_utils.py:277-301 in the reference)
+                src = streaming.FitsSource(os.fspath(data), hdu)
+                hdr = io_fits.cube_header(img)
+                meta = dict(kw.pop("meta", None) or {})
+                if "BUNIT" in hdr:
+                    meta["BUNIT"] = hdr["BUNIT"]
+                cube = cls(None, header=hdr, device=device, meta=meta, _source=src, _shape=fshape, **kw)
+                cube._mask = M.LazyMask(np.isfinite, cube=cube)
+                return cube
             dev, hdr = io_fits.load_cube(os.fspath(data), device=device, hdu=hdu)
             meta = dict(kw.pop("meta", None) or {})
             if "BUNIT" in hdr:
@@ -285,13 +300,28 @@ class SpectralCube:
                             fill_value=self._fill_value if fill_value is None else fill_value,
                             unit=self._unit if unit is None else unit, device=self.device,
                             allow_huge_operations=self.allow_huge_operations, _dev=dev,
-                            _lazy=lazy, _shape=shape, _data_id=self._data_id if same_data else None)
+                            _lazy=lazy, _shape=shape, _data_id=self._data_id if same_data else None,
+                            _source=self._source if same_data else None)
 
     # ---- identity used by lazy masks -------------------------------------------
     def _host_data(self):
         if self._data is None:
             self._data = self._device_data().get()
         return self._data
+
+    def _stream_source(self):
+        """streaming source of a cube that is NOT resident and larger than the HBM budget (a FITS file, a memory
+        map, a host array), else None.  Such a cube runs its spectral-axis reductions strip by strip
+        (streaming.py) and refuses the operators that need it whole."""
+        if self._dev is not None or self._lazy is not None:
+            return None
+        if self._source is not None:
+            return self._source
+        if self._data is not None:
+            from . import streaming
+            if 4 * self._data.size > streaming.hbm_budget(self.device):
+                self._source = streaming.NdarraySource(self._data)
+        return self._source
 
     def _is_same_data(self, data):
         return getattr(data, "_data_id", None) is self._data_id
@@ -388,6 +418,14 @@ class SpectralCube:
                 self._lazy = None
             else:
                 _lib.require_gpu()
+                if self._stream_source() is not None:
+                    from . import streaming
+                    nbytes = 4 * int(np.prod(self._shape, dtype=np.int64))
+                    raise streaming.HugeCubeError(
+                        "this operation needs the whole cube in HBM: %.2f GiB against a budget of %.2f GiB (SPC_HBM_BUDGET). "
+                        "Out-of-core cubes stream moment / moments012 / argmax / argmin / max / min along the spectral "
+                        "axis, spectral_smooth(...).moment, statistics() and the whole-cube reductions"
+                        % (nbytes / 2**30, streaming.hbm_budget(self.device) / 2**30))
                 self._dev = DeviceArray.from_numpy(self._data, self.device, dtype=np.float32)
         return self._dev
 
@@ -447,6 +485,12 @@ class SpectralCube:
         spec0 = self.spectral_axis[0]
         d_cen = DeviceArray.from_numpy(cen - cref, self.device)
         dv = self._pix_size_slice(0)
+        if fused_kernel is not None and fused_kernel[0]._stream_source() is not None:
+            from . import streaming                     # out-of-core parent: the fused kernels, strip by strip
+            return streaming.moments(fused_kernel[0], want, d_cen, dv, cref + spec0, kernel=fused_kernel[1], cen_host=cen - cref)
+        if fused_kernel is None and self._stream_source() is not None:
+            from . import streaming
+            return streaming.moments(self, want, d_cen, dv, cref + spec0)
         if fused_kernel is not None:
             parent, karr = fused_kernel
             try:
@@ -650,7 +694,11 @@ class SpectralCube:
         need = {"sum": ("count", "sum"), "mean": ("count", "sum"), "std": ("count", "sum", "sumsq"),
                 "max": ("count", "max"), "min": ("count", "min")}[op]
         if axis is None:
-            st = ops.stats_global(self._device_data(), mask=self._mask_spec())
+            if self._stream_source() is not None:
+                from . import streaming
+                st = streaming.statistics(self)
+            else:
+                st = ops.stats_global(self._device_data(), mask=self._mask_spec())
             n = st["npts"]
             vals = {"count": np.float64(n), "sum": np.float64(st["sum"]), "sumsq": np.float64(st["sumsq"]),
                     "max": np.float64(st["max"]), "min": np.float64(st["min"])}
@@ -787,6 +835,9 @@ class SpectralCube:
     def statistics(self):
         """global basic statistics in ONE pass (dask_spectral_cube.py:769-814): npts, min, max,
         sum, sumsq, mean, sigma (the reference's textbook formula), rms."""
+        if self._stream_source() is not None:
+            from . import streaming
+            return streaming.statistics(self)           # per-strip records, combined (same formulae)
         st = ops.stats_global(self._device_data(), mask=self._mask_spec())
         n = st["npts"]
         with np.errstate(invalid="ignore", divide="ignore"):

@@ -67,3 +67,101 @@ def test_reproject_raises_for_frames_it_cannot_relate(gpu):
     tgt = dict(SimpleWCS(str(g["adv_header_out"])).header, CTYPE1="ELON-SIN", CTYPE2="ELAT-SIN")
     with pytest.raises(NotImplementedError, match="frame"):
         cube.reproject(tgt)
+
+
+# ---- out-of-core streaming (missing 4) ---------------------------------------------------
+def _write_cube(tmp_path, d, hdr, name="big.fits", **kw):
+    from spectral_cube_amd import io_fits
+    p = tmp_path / name
+    io_fits.write_fits(str(p), d, hdr, **kw)
+    return str(p)
+
+
+def _c1_header():
+    return str(golden("c1_moments.npz")["header"])
+
+
+@pytest.mark.parametrize("source", ["fits", "ndarray", "memmap_f64"])
+def test_out_of_core_moments_and_argmax_equal_the_resident_result(gpu, tmp_path, monkeypatch, source):
+    """A cube 4x the HBM budget (SPC_HBM_BUDGET) - a FITS file, a host array, a float64 memory map - stays where it
+    is and streams through the device in (y, x) row strips, strip k + 1 staged while strip k computes: moment 0 / 1 / 2,
+    argmax / argmin (axis 0 and whole cube), max / min, statistics() are bit-identical to the resident result (the
+    z split of the moment kernel pinned: it otherwise follows the strip's size) - the role of _moments.py:89-125 /
+    cube_utils.py:277-301 in the reference."""
+    from spectral_cube_amd import streaming, synth
+    monkeypatch.setenv("SPC_MOMENTS_NSPLIT", "1")
+    nz, ny, nx = 96, 200, 64
+    d = synth.gaussian_line_cube((nz, ny, nx), 31)
+    d[:, 5:9, 3:7] = np.nan
+    d[40:, 77, 10] = np.nan
+    hdr = _c1_header()
+    res = SpectralCube.read(d, hdr)
+    budget = d.nbytes // 4
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(budget))
+    if source == "fits":
+        big = SpectralCube.read(_write_cube(tmp_path, d, hdr), device=0)
+        assert isinstance(big._source, streaming.FitsSource)
+    elif source == "ndarray":
+        big = SpectralCube.read(d.copy(), hdr)
+    else:
+        mm = np.lib.format.open_memmap(str(tmp_path / "c.npy"), mode="w+", dtype=np.float64, shape=d.shape)
+        mm[:] = d
+        mm.flush()
+        big = SpectralCube.read(np.load(str(tmp_path / "c.npy"), mmap_mode="r"), hdr)
+    assert big._stream_source() is not None and big._dev is None
+    thr = 1.0
+    for cube_s, cube_r in ((big, res), (big.with_mask(big > thr), res.with_mask(res > thr))):
+        monkeypatch.setenv("SPC_HBM_BUDGET", str(budget))
+        got = cube_s.moments012()
+        assert cube_s._dev is None, "the cube was never made resident"
+        am, an = cube_s.argmax(axis=0), cube_s.argmin(axis=0)
+        flat, st = cube_s.argmax(), cube_s.statistics()
+        mx = cube_s.max()
+        monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+        exp = cube_r.moments012()
+        for g_, e_ in zip(got, exp):
+            assert np.array_equal(np.asarray(g_), np.asarray(e_), equal_nan=True)
+        assert np.array_equal(am, cube_r.argmax(axis=0)) and np.array_equal(an, cube_r.argmin(axis=0))
+        assert flat == cube_r.argmax() and mx == cube_r.max()
+        est = cube_r.statistics()
+        assert st["npts"] == est["npts"] and st["min"] == est["min"] and st["max"] == est["max"]
+        assert st["sum"] == pytest.approx(est["sum"], rel=1e-12) and st["sigma"] == pytest.approx(est["sigma"], rel=1e-10)
+    # against the oracle too (not only against ourselves)
+    inc = np.isfinite(d)
+    cen = res.spectral_axis - res.spectral_axis[0]
+    e0, e1, e2 = O.moments012(d, inc, cen, res._pix_size_slice(0), res.spectral_axis[0])
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(budget))
+    m0 = big.moment0()
+    assert_close(np.asarray(m0), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="streamed m0 vs oracle")
+    # operators that need the whole cube say so, with the budget in the message
+    with pytest.raises(streaming.HugeCubeError, match="SPC_HBM_BUDGET"):
+        big.median(axis=0)
+
+
+def test_out_of_core_boolean_mask_and_fused_smooth(gpu, tmp_path, monkeypatch):
+    """streamed cube + a BooleanArrayMask (strips of the host array travel with the data) and
+    spectral_smooth(...).moment1 through the fused kernels, strip by strip."""
+    from spectral_cube_amd import Gaussian1DKernel, synth
+    monkeypatch.setenv("SPC_MOMENTS_NSPLIT", "1")
+    nz, ny, nx = 80, 120, 48
+    d = synth.gaussian_line_cube((nz, ny, nx), 32)
+    inc = synth.boolean_mask(d, 32).astype(bool)
+    hdr = _c1_header()
+    res = SpectralCube.read(d, hdr).with_mask(inc)
+    exp = res.moments012()
+    k = Gaussian1DKernel(2.0)
+    exp_s = res.spectral_smooth(k).moment1()
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 5))
+    big = SpectralCube.read(d.copy(), hdr).with_mask(inc)
+    got = big.moments012()
+    for g_, e_ in zip(got, exp):
+        assert np.array_equal(np.asarray(g_), np.asarray(e_), equal_nan=True)
+    got_s = big.spectral_smooth(k).moment1()
+    assert big._dev is None
+    assert_close(np.asarray(got_s), np.asarray(exp_s), atol=1e-9 * nz * 500.0, what="streamed fused smooth -> moment1")
+    sm = O.spectral_smooth(d, inc, k.array)
+    e1 = O.moment(sm, inc, 1, res.spectral_axis - res.spectral_axis[0], res._pix_size_slice(0), world0=res.spectral_axis[0])
+    s0 = O.moment(sm, inc, 0, res.spectral_axis - res.spectral_axis[0], 1.0)
+    with np.errstate(invalid="ignore"):
+        wc = np.abs(s0) > 5.0
+    assert np.abs(np.asarray(got_s)[wc] - e1[wc]).max() <= 1e-5 * nz * abs(res._pix_size_slice(0))
