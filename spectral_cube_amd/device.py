@@ -39,17 +39,24 @@ class _PinnedPool:
     copy into fresh pageable numpy memory runs at ~3 GB/s (page faults + the runtime's staging) - 10 ms for a
     2048 x 2048 float64 moment map, more than the kernel that produced it; into pinned memory it runs at the link
     rate.  get() therefore hands out numpy arrays that live IN pinned buffers; a buffer returns to this pool when the
-    last array viewing it is collected, and is unpinned once the pool holds more than *max_bytes* idle."""
+    last array viewing it is collected, and is unpinned once the pool holds more than *max_bytes* idle.
+    Page-locked memory cannot be swapped: the bytes OUTSTANDING (handed out and still referenced - a caller may keep
+    lists of maps or dask chunk outputs) are capped as well (*max_outstanding*, SPC_PINNED_MAX_BYTES, default 4 GiB);
+    beyond the cap array() raises MemoryError and get() falls back to pageable numpy memory."""
 
     MIN_BYTES = 1 << 20          # smaller results use plain numpy memory
     MAX_BYTES = 1 << 30          # larger ones too (pinning tens of GiB of host memory is not this pool's business)
 
-    def __init__(self, max_bytes=1 << 30):
+    def __init__(self, max_bytes=1 << 30, max_outstanding=None):
+        import os
         import threading
         self.max_bytes = max_bytes
+        self.max_outstanding = int(os.environ.get("SPC_PINNED_MAX_BYTES", 4 << 30)) if max_outstanding is None else max_outstanding
         self.idle = {}           # size class -> [ptr]
         self.idle_bytes = 0
+        self.outstanding = 0
         self.lock = threading.Lock()
+        self._ctype = {}         # one ctypes array type per SIZE CLASS (a type per distinct size would be cached for ever)
 
     @staticmethod
     def size_class(nbytes):
@@ -58,17 +65,26 @@ class _PinnedPool:
     def take(self, nbytes):
         cls = self.size_class(nbytes)
         with self.lock:
+            if self.outstanding + cls > self.max_outstanding:
+                raise MemoryError("pinned result buffers outstanding: %d bytes (cap %d)" % (self.outstanding, self.max_outstanding))
+            self.outstanding += cls
             lst = self.idle.get(cls)
             if lst:
                 self.idle_bytes -= cls
                 return lst.pop(), cls
         p = C.c_void_p()
-        _lib.call("spc_host_alloc", C.c_size_t(cls), C.byref(p))
+        try:
+            _lib.call("spc_host_alloc", C.c_size_t(cls), C.byref(p))
+        except Exception:
+            with self.lock:
+                self.outstanding -= cls
+            raise
         return p.value, cls
 
     def give(self, ptr, cls):
         try:
             with self.lock:
+                self.outstanding -= cls
                 if self.idle_bytes + cls <= self.max_bytes:
                     self.idle.setdefault(cls, []).append(ptr)
                     self.idle_bytes += cls
@@ -83,7 +99,10 @@ class _PinnedPool:
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         ptr, cls = self.take(nbytes)
-        raw = (C.c_byte * nbytes).from_address(ptr)
+        ctype = self._ctype.get(cls)
+        if ctype is None:
+            ctype = self._ctype[cls] = C.c_byte * cls
+        raw = ctype.from_address(ptr)
         weakref.finalize(raw, self.give, ptr, cls)       # numpy keeps `raw` alive as the base of every view
         return np.frombuffer(raw, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
 

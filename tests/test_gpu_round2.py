@@ -218,7 +218,8 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
 import numpy as np
 import dask, dask.array as da
 import oracle_np as O
-from spectral_cube_amd.dask_adapter import SpectralSmoothChunk, SpatialSmoothChunk, MomentChunk, SpectralInterpolateChunk
+from spectral_cube_amd.dask_adapter import (SpectralSmoothChunk, SpatialSmoothChunk, MomentChunk, Moments012Chunk,
+                                            SpectralInterpolateChunk, SigmaClipChunk)
 from spectral_cube_amd.kernels import Gaussian1DKernel, Gaussian2DKernel
 rng = np.random.default_rng(5)
 d = rng.standard_normal((48, 40, 56)).astype(np.float32)
@@ -246,6 +247,18 @@ for sched in ("synchronous", "threads"):                  # dask_spectral_cube.p
                            chunks=(arr.chunks[1], arr.chunks[2])).compute()
         e1 = O.moment(d, None, 1, cen, 0.5, world0=-3.0)
         assert np.array_equal(np.isnan(m1), np.isnan(e1)) and np.nanmax(np.abs(m1 - e1)) <= 1e-5 * 24.0
+        # round 3: moment 0, 1 and 2 from ONE staging of every chunk (drop_axis + new_axis: a (3, ny, nx) stack)
+        m012 = da.map_blocks(Moments012Chunk(cen, 0.5, world0=-3.0), arr, dtype=np.float64, drop_axis=[0], new_axis=[0],
+                             chunks=((3,), arr.chunks[1], arr.chunks[2])).compute()
+        e012 = O.moments012(d, np.isfinite(d), cen, 0.5, -3.0)
+        assert m012.shape == (3, 40, 56)
+        for got, exp, sc in zip(m012, e012, (np.nanmax(np.abs(e012[0])), 24.0, np.nanmax(np.abs(e012[2])))):
+            assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.nanmax(np.abs(got - exp)) <= 1e-5 * sc
+        assert np.array_equal(m012[1], m1, equal_nan=True)
+        # float64 chunks (what a float64 FITS cube hands over): converted while they are staged
+        out64 = da.map_blocks(SpectralSmoothChunk(k1), da.from_array(d.astype(np.float64), chunks=(-1, 16, 24)), dtype=np.float64).compute()
+        assert out64.dtype == np.float64
+        close(out64.astype(np.float32), O.spectral_smooth(d, None, k1), "spectral float64 " + sched)
         # interp_wrapper: the chunk grows along the spectral axis
         x = np.arange(48.0); grid = np.linspace(0.0, 47.0, 95)
         out = da.map_blocks(SpectralInterpolateChunk(x, grid), arr, dtype=arr.dtype,
