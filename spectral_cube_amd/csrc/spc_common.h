@@ -155,6 +155,26 @@ static inline int spc_check_cube_any_order(const spc_cube_f32* c) {
     return SPC_OK;
 }
 
+// mask predicate -> |v| <= lim && !(v <= lo) && !(v >= hi): three compares whatever the flags.  An absent bound is
+// NaN (the negated compare is then true for every v), >= / <= become strict compares against the neighbouring float,
+// a NaN threshold rejects everything (numpy: x > nan is False); lim = FLT_MAX under isfinite, +inf otherwise (NaN
+// samples fail |v| <= lim either way: they are never valid).
+static inline void spc_canonical_pred(uint32_t f, float thr_lo, float thr_hi, float* lim, float* lo, float* hi) {
+    *lim = (f & SPC_MASK_FINITE) ? 3.402823466e+38f : INFINITY;
+    *lo = NAN;
+    *hi = NAN;
+    if (f & (SPC_MASK_GT | SPC_MASK_GE)) {
+        if (thr_lo != thr_lo) *lim = -1.f;
+        else if (f & SPC_MASK_GT) *lo = thr_lo;
+        else *lo = (thr_lo == -INFINITY) ? NAN : nextafterf(thr_lo, -INFINITY);
+    }
+    if (f & (SPC_MASK_LT | SPC_MASK_LE)) {
+        if (thr_hi != thr_hi) *lim = -1.f;
+        else if (f & SPC_MASK_LT) *hi = thr_hi;
+        else *hi = (thr_hi == INFINITY) ? NAN : nextafterf(thr_hi, INFINITY);
+    }
+}
+
 // predicate part of the mask (array part is handled by the caller's loads)
 __device__ __forceinline__ bool spc_pred(uint32_t flags, float thr_lo, float thr_hi, float v) {
     bool inc = true;

@@ -382,6 +382,7 @@ int fill_common(ConvArgs& A, const spc_cube_f32* cube, const spc_mask* mask, con
                 int ntaps, int R) {
     int rc = spc_mask_to_dev(mask, cube, &A.mask);
     if (rc) return rc;
+    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.pred_lim, &A.pred_lo, &A.pred_hi);
     A.cube = cube->d_data;
     A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;

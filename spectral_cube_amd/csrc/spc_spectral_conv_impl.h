@@ -67,19 +67,22 @@ struct ConvArgs {
     // all-valid fast pass: one byte per 128-column tile, 0 = done by the fast kernel
     unsigned char* status;
     double ksum, inv_ksum;     // sum(k) in tap order, 1 / sum(k)
+    float pred_lim, pred_lo, pred_hi, pred_pad;   // spc_canonical_pred of the mask's predicate terms
     alignas(16) double k[72];  // taps padded to R, centred (R <= 65)
 };
 
 // ---- denominators from validity bits ------------------------------------------------------
-// Bit b of a lane's validity history = the sample that arrived b steps ago; when an output
-// completes, that sample carried tap k[b] (the newest sample takes k[0], see ring_body).
+// Bit b of a lane's history = the sample that arrived b steps ago was INVALID (0 = valid; out-of-range samples are
+// valid zeros, boundary='fill'); when an output completes, that sample carried tap k[b] (the newest sample takes
+// k[0], see the ring).  Two 32-bit words (bits 0..31, bit 32): 64-bit shifts are not single instructions.
 constexpr int kLutBits = 11, kLutSize = 1 << kLutBits;
 constexpr int lut_tables(int R) { return (R + kLutBits - 1) / kLutBits; }
 // threads per block of the general kernel: the tables are per block (48 KB for 33 taps), so the block size sets
 // how many waves share a CU: 2 x 512 threads (4 waves per SIMD) where the registers allow it (no mask array, not
-// fused: 120 VGPRs), 3 x 256 threads otherwise (139 VGPRs with a mask array; measured 3.7 ms against 4.1 ms)
+// fused), 3 x 256 threads otherwise
 constexpr int general_block(bool arr, bool fuse) { return (arr || fuse) ? 256 : 512; }
 
+// table t, entry w: sum of the taps 11 t + b whose bit b of w is CLEAR (valid)
 template <int R>
 __device__ __forceinline__ void lut_build(const ConvArgs& A, double* lut) {
 #pragma unroll
@@ -88,7 +91,7 @@ __device__ __forceinline__ void lut_build(const ConvArgs& A, double* lut) {
             double acc = 0.0;
 #pragma unroll
             for (int b = 0; b < kLutBits; ++b)
-                if (kLutBits * t + b < R) acc += ((w >> b) & 1) ? A.k[kLutBits * t + b] : 0.0;
+                if (kLutBits * t + b < R) acc += ((w >> b) & 1) ? 0.0 : A.k[kLutBits * t + b];
             lut[t * kLutSize + w] = acc;
         }
     }
@@ -98,8 +101,7 @@ __device__ __forceinline__ void lut_build(const ConvArgs& A, double* lut) {
 constexpr unsigned lut_mask(int bits) { return (((bits >= kLutBits) ? (unsigned)kLutSize : (bits > 0 ? (1u << (bits > 0 ? bits : 0)) : 1u)) - 1u) * 8u; }
 
 template <int R>
-__device__ __forceinline__ double lut_den(const double* lut, unsigned long long hist) {
-    const unsigned lo = (unsigned)hist, hi = (unsigned)(hist >> 32);
+__device__ __forceinline__ double lut_den(const double* lut, unsigned lo, unsigned hi) {
     const char* base = reinterpret_cast<const char*>(lut);
     double den = *reinterpret_cast<const double*>(base + ((lo << 3) & lut_mask(R)));
     if (R > kLutBits)
@@ -133,6 +135,20 @@ __device__ __forceinline__ double div_ksum(double num, const ConvArgs& A) {
     // (an infinite quotient has a NaN residual: max() drops the NaN, the infinity survives the FMA)
     const double r = fmax(fma(-q, A.ksum, num), -1.7976931348623157e308);
     return fma(r, A.inv_ksum, q);
+}
+
+// num / den for a looked-up denominator (a sum of taps: 1e-5 .. 1 times the kernel sum, never subnormal): the hardware
+// reciprocal (2^-23 relative), one Newton step (2^-46), the quotient and ONE residual step (exact in the FMA) - the
+// step every software division ends with; ~2^-90 from the rounded quotient, i.e. the same float32 after the final
+// rounding except within 2^-90 of a rounding boundary.  10 VALU slots (v_rcp_f64 is quarter rate) against the ~17 of
+// the compiler's IEEE division (two v_div_scale, two Newton steps, v_div_fmas, v_div_fixup).  den = 0 (an empty
+// window: num = 0 as well) gives NaN, which is astropy's answer for an invalid centre sample.
+__device__ __forceinline__ double div_den(double num, double den) {
+    double y = __builtin_amdgcn_rcp(den);
+    y = fma(fma(-den, y, 1.0), y, y);
+    const double q = num * y;
+    const double r = fmax(fma(-q, den, num), -1.7976931348623157e308);     // (infinite num: see div_ksum)
+    return fma(r, y, q);
 }
 
 // Buffer descriptor over one plane.  The base must be wave-uniform AND provably
@@ -177,78 +193,16 @@ __device__ __forceinline__ unsigned ldm1(const uint8_t* plane, int moff) {
     return __builtin_amdgcn_raw_buffer_load_b8(plane_srd(plane), moff, 0, 2);
 }
 
-// The R x R update + emission part of one revolution.
-//   v[s]  : classified input: the value when valid, NaN when invalid, 0 when out of range
-//   incb  : (FUSE only) bit s = sample s is in range and included by the mask
-//   okhist: validity of the lane's last 64 samples, bit 0 = newest (out-of-range samples are
-//           valid zeros, boundary='fill')
-// FULL (wave-uniform, run-time): this and the previous revolution were all valid, so every
-// output completing now has the whole kernel as its denominator.
+// ---- general kernel (masks / NaNs) -----------------------------------------------------------
+// One lane = one spaxel marching over z; a revolution = R input planes.  The loads of a revolution are issued
+// up front (one descriptor + a scalar plane offset each); every ring step then classifies ITS sample, feeds the R
+// numerators, and emits the output that just completed.  Classification lives inside the step on purpose: done as a
+// separate pass, the R per-lane validity masks (SGPR pairs) and the R uniform in-range conditions stayed live across
+// the whole ring - 431 spilled SGPRs, ~18 v_readlane / v_writelane per voxel next to the 33 FMAs, and another ~60
+// scalar instructions per voxel (rounds 1 - 2: 102 VALU instructions per voxel, 145 fused; now ~62 / ~75).
+// Out-of-range samples (the first / last revolution of a z slice) are valid zeros; that bookkeeping sits behind a
+// wave-uniform branch and costs interior revolutions nothing.
 template <int R, bool ARR, bool FUSE, bool EXT, bool SYM>
-__device__ __forceinline__ void ring_body(const ConvArgs& A, double (&num)[R], const double* lut,
-                                          const float (&v)[R], unsigned long long incb, unsigned long long& okhist,
-                                          unsigned long long& inc_hist, MomState& ms, int voff_out, int i0,
-                                          int zb, int ze, const bool FULL) {
-    constexpr int H = R / 2;
-    // outputs of this revolution: planes i0 - H .. i0 + H, addressed from the first one that exists
-    const int ob = max(i0 - H, 0);
-    const int obytes = FUSE ? 0 : (int)(A.out_plane_stride * 4);
-    const auto ro = plane_srd(FUSE ? (const void*)A.cube : (const void*)(A.out + (int64_t)ob * A.out_plane_stride));
-#pragma unroll
-    for (int s = 0; s < R; ++s) {
-        const bool ok = v[s] == v[s];
-        const double x = ok ? (double)v[s] : 0.0;
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-            const int a = (s - m + R) % R;          // age of the output living in slot m
-            // symmetric kernels: half the distinct weights, all of them stay in SGPRs
-            const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
-            if (a == 0) mul_w(num[m], A, j, x);
-            else fma_w(num[m], A, j, x);
-        }
-        if (!FULL) okhist = (okhist << 1) | (ok ? 1ull : 0ull);
-        if (FUSE && A.mask.flags) inc_hist = (inc_hist << 1) | ((incb >> s) & 1ull);
-        // ---- the output that just received its last contribution
-        const int e = (s + 1) % R;
-        const int o = i0 + s - H;
-        if (o >= zb && o < ze) {
-            float res;
-            if (FULL) {
-                res = (float)div_ksum(num[e], A);
-            } else {
-                const double dtot = lut_den<R>(lut, okhist);
-                // astropy returns the (filled) centre sample for an empty window; the host
-                // only dispatches kernels with a non-zero centre tap here, for which an empty
-                // window implies an invalid centre, i.e. NaN
-                res = (dtot != 0.0) ? (float)(num[e] / dtot) : NAN;
-            }
-            if (!FUSE) {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res), ro, voff_out, (int)((unsigned)(o - ob) * (unsigned)obytes), 0);
-            } else {
-                // no mask at all: every in-range channel is included
-                const bool inc_o = A.mask.flags ? (((inc_hist >> H) & 1ull) != 0ull) : true;
-                const bool okm = inc_o && (res == res);
-                const double wd = okm ? (double)res : 0.0;
-                const double c = A.cen_linear ? fma((double)o, A.cen_dc, A.cen_c0) : A.cen[o];
-                ms.s0 += wd;
-                ms.s1 = fma(wd, c, ms.s1);
-                ms.s2 = fma(wd, c * c, ms.s2);
-                ms.nvalid += okm ? 1 : 0;
-                if (EXT) {
-                    const float hi = okm ? res : -INFINITY;
-                    const float lo = okm ? res : INFINITY;
-                    if (hi > ms.bmax) { ms.bmax = hi; ms.imax = (int)o; }
-                    if (lo < ms.bmin) { ms.bmin = lo; ms.imin = (int)o; }
-                }
-            }
-        }
-    }
-    if (FULL) okhist = ~0ull;                        // R valid samples went by
-}
-
-template <int R, bool ARR, bool FUSE, bool EXT, bool SYM>
-// (fused: 3 waves per SIMD asked for - 168 VGPRs, a handful of spilled dwords - instead of the 180 the allocator
-// would take: 40.7 -> 31.7 ms for the masked C3 smooth -> moments)
 __global__ __launch_bounds__(general_block(ARR, FUSE), FUSE ? 3 : 1) void spectral_conv_kernel(const ConvArgs A) {
     constexpr int H = R / 2;
     static_assert(R <= 3 * kLutBits, "three denominator tables cover 33 taps");
@@ -260,24 +214,30 @@ __global__ __launch_bounds__(general_block(ARR, FUSE), FUSE ? 3 : 1) void spectr
     if (!__syncthreads_or(live ? 1 : 0)) return;
     lut_build<R>(A, lut);
     __syncthreads();
-    if (!live) return;
-    const int64_t y = col / A.nx, x = col - y * A.nx;
+    // fused: the steps read the channel coordinates from lanes 0 .. R - 1 of the wave (v_readlane), so a wave keeps
+    // ALL its lanes marching as long as one of them is live; the others redo the last spaxel and write nothing
+    if (FUSE ? !__any(live) : !live) return;
+    const int64_t colc = min(col, A.ny * A.nx - 1);
+    const int64_t y = colc / A.nx, x = colc - y * A.nx;
     const int nz = (int)A.nz;
     const int zb = (int)(blockIdx.y * A.zchunk);
     const int ze = min(nz, zb + (int)A.zchunk);
     const int voff_out = FUSE ? 0 : (int)((y * A.out_row_stride + x) * 4);
     const uint32_t flags = A.mask.flags;
-    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
+    // predicate terms (isfinite / thresholds) in their three-compare canonical form; without any, a sample the array
+    // term includes may still be NaN: included (it counts for the fused reduction's mask) but not valid
+    const bool has_pred = (flags & (SPC_MASK_FINITE | SPC_MASK_GT | SPC_MASK_GE | SPC_MASK_LT | SPC_MASK_LE)) != 0;   // uniform
+    const float plim = A.pred_lim, plo = A.pred_lo, phi = A.pred_hi;
     const int voff = (int)((y * A.row_stride + x) * 4);              // < 2 GiB per plane (checked on the host)
     const int moff = ARR ? (int)(y * A.mask.row_stride + x) : 0;
     double num[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) num[m] = 0.0;
-    unsigned long long inc_hist = 0ull;  // include bit of the last 64 inputs (bit 0 = newest)
-    unsigned long long okhist = ~0ull;   // validity of the last 64 inputs (what lies before the slice start is never emitted)
+    unsigned bad_lo = 0u, bad_hi = 0u;   // invalid bit of the last 33 inputs, bit 0 = newest (what lies before the slice start is never emitted)
+    unsigned inc_lo = 0u;                // include bit of the last 32 inputs (the fused reduction asks for the one of age H <= 16)
     MomState ms;
-    bool prev_allv = false;
     const int pbytes = (int)(A.plane_stride * 4), mbytes = ARR ? (int)A.mask.plane_stride : 0;
+    const int obytes = FUSE ? 0 : (int)(A.out_plane_stride * 4);
 
     const int T = (ze - zb) + 2 * H;      // number of input steps
     for (int t0 = 0; t0 < T; t0 += R) {
@@ -288,34 +248,105 @@ __global__ __launch_bounds__(general_block(ARR, FUSE), FUSE ? 3 : 1) void spectr
         const int pb = min(max(i0, 0), nz - 1);
         const auto rs = plane_srd(A.cube + (int64_t)pb * A.plane_stride);
         const auto rm = plane_srd(ARR ? (const void*)(A.mask.arr + (int64_t)pb * A.mask.plane_stride) : (const void*)A.cube);
+        const bool edge = (i0 < 0) || (i0 + R > nz);                  // uniform: some sample of this revolution is out of range
+        if (!edge) {
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)s * (unsigned)pbytes), /*nt*/ 2));
+                if (ARR) mk[s] = __builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)s * (unsigned)mbytes), 2);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < R; ++s) {
+                const int dz = min(max(i0 + s, 0), nz - 1) - pb;                 // clamped, uniform
+                const bool in = (i0 + s >= 0) && (i0 + s < nz);                  // uniform
+                const float ld = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)dz * (unsigned)pbytes), /*nt*/ 2));
+                v[s] = in ? ld : 0.f;                                             // out of range = a valid zero (boundary='fill')
+                if (ARR) mk[s] = __builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)dz * (unsigned)mbytes), 2);
+            }
+        }
+        // outputs of this revolution: planes i0 - H .. i0 + H, addressed from the first one that exists
+        const int ob = max(i0 - H, 0);
+        const auto ro = plane_srd(FUSE ? (const void*)A.cube : (const void*)(A.out + (int64_t)ob * A.out_plane_stride));
+        const bool emit_all = (i0 - H >= zb) && (i0 + R - 1 - H < ze);          // uniform
+        // fused reduction: the R channel coordinates of this revolution's outputs in ONE vector load (lane l holds
+        // c[i0 - H + l]); a step takes its own with two v_readlane - a scalar load per output would put a memory
+        // round trip (and a wait on the counter the table reads share) on every step
+        double cvec = 0.0;
+        if (FUSE) cvec = A.cen[min(max(i0 - H + (int)(threadIdx.x & 63), 0), nz - 1)];
 #pragma unroll
         for (int s = 0; s < R; ++s) {
-            const int dz = min(max(i0 + s, 0), nz - 1) - pb;                 // clamped, uniform
-            v[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)dz * (unsigned)pbytes), /*nt*/ 2));
-            if (ARR) mk[s] = __builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)dz * (unsigned)mbytes), 2);
-        }
-        // ---- classify: value | NaN (invalid) | 0 (out of range = valid zero, boundary='fill')
-        unsigned long long incb = 0ull;
-        bool bad = false;
+            // ---- classify sample s: value | invalid | out of range (= valid zero)
+            float vs = v[s];
+            // (without predicate terms lim = +inf and lo = hi = NaN: the three compares then only reject NaN)
+            const bool arrbit = ARR ? (mk[s] != 0) : true;
+            const bool ok = arrbit && (__builtin_fabsf(vs) <= plim) && !(vs <= plo) && !(vs >= phi);
+            // included by the mask (what the fused reduction's mask asks): a predicate term rejects NaN, so included ==
+            // valid; without one an included sample may still be NaN
+            const bool inc = FUSE ? (ok || (!has_pred && arrbit)) : ok;       // (mask logic: scalar and / or of the lane masks)
+            float xs = ok ? vs : 0.f;                                 // (an out-of-range sample was loaded as 0: it adds nothing)
+            unsigned badbit = ok ? 0u : 1u, incbit = inc ? 1u : 0u;   // as VECTOR integers: no lane mask stays live
+            if (edge) {                                               // uniform, and kept a BRANCH (the empty asm cannot be
+                asm volatile("");                                     // speculated): interior revolutions pay one s_cbranch
+                if (!((i0 + s >= 0) && (i0 + s < nz))) { badbit = 0u; incbit = 0u; }   // uniform: a valid zero, not part of the cube
+            }
+            asm volatile("" : "+v"(xs));                              // select in float32, THEN widen (one v_cndmask, not two)
+            const double xd = (double)xs;
+            bad_hi = __builtin_amdgcn_alignbit(bad_hi, bad_lo, 31);
+            bad_lo = (bad_lo << 1) | badbit;
+            if (FUSE) inc_lo = (inc_lo << 1) | incbit;
 #pragma unroll
-        for (int s = 0; s < R; ++s) {
-            const bool in = (i0 + s >= 0) && (i0 + s < nz);                  // uniform
-            bool inc = spc_pred(flags, tlo, thi, v[s]);
-            if (ARR) inc = inc && (mk[s] != 0);
-            const bool ok = inc && (v[s] == v[s]);
-            bad = bad || (in && !ok);
-            v[s] = in ? (ok ? v[s] : NAN) : 0.f;
-            if (FUSE && flags) incb |= ((in && inc) ? 1ull : 0ull) << s;
+            for (int m = 0; m < R; ++m) {
+                const int a = (s - m + R) % R;          // age of the output living in slot m
+                // symmetric kernels: half the distinct weights, all of them stay in SGPRs
+                const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
+                if (a == 0) mul_w(num[m], A, j, xd);
+                else fma_w(num[m], A, j, xd);
+            }
+            // ---- the output that just received its last contribution
+            const int e = (s + 1) % R;
+            const int o = i0 + s - H;
+            if (emit_all || (o >= zb && o < ze)) {
+                // every sample of this output's window valid, in every lane: the denominator is the whole kernel
+                const unsigned anybad = (R > 32) ? ((bad_hi & 1u) | bad_lo) : (bad_lo & (unsigned)((1ull << R) - 1ull));
+                float res;
+                if (__all(anybad == 0u)) {
+                    res = (float)div_ksum(num[e], A);
+                    asm volatile("; whole kernel" : "+v"(res));       // (distinct tails: merged, the scalar 1 / sum(k) of this
+                } else {                                              //  arm is copied to vector registers for every output)
+                    // astropy returns the (filled) centre sample for an empty window; the host only dispatches kernels
+                    // with a non-zero centre tap here, for which an empty window implies an invalid centre: NaN = 0 / 0
+                    res = (float)div_den(num[e], lut_den<R>(lut, bad_lo, bad_hi));
+                    asm volatile("; looked-up denominator" : "+v"(res));
+                }
+                if (!FUSE) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res), ro, voff_out, (int)((unsigned)(o - ob) * (unsigned)obytes), 0);
+                } else {
+                    // (no mask at all: every in-range channel carries an include bit)
+                    const bool inc_o = ((inc_lo >> H) & 1u) != 0u;
+                    const bool okm = inc_o && (res == res);
+                    float wf = okm ? res : 0.f;
+                    asm volatile("" : "+v"(wf));                    // select in float32, then widen
+                    const double wd = (double)wf;
+                    const unsigned long long cb = __builtin_bit_cast(unsigned long long, cvec);
+                    const double c = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(cb >> 32), s) << 32) |
+                                                                    (unsigned)__builtin_amdgcn_readlane((int)cb, s));
+                    ms.s0 += wd;
+                    ms.s1 = fma(wd, c, ms.s1);
+                    ms.s2 = fma(wd, c * c, ms.s2);
+                    ms.nvalid += okm ? 1 : 0;
+                    if (EXT) {
+                        const float hi = okm ? res : -INFINITY;
+                        const float lo = okm ? res : INFINITY;
+                        if (hi > ms.bmax) { ms.bmax = hi; ms.imax = (int)o; }
+                        if (lo < ms.bmin) { ms.bmin = lo; ms.imin = (int)o; }
+                    }
+                }
+            }
         }
-        const bool allv = !__any(bad);
-        // (the first revolution of a z slice starts from zeroed rings whose first H outputs lie
-        // before zb and are never emitted, so "previous revolution all valid" holds vacuously)
-        const bool full = allv && (prev_allv || t0 == 0);
-        ring_body<R, ARR, FUSE, EXT, SYM>(A, num, lut, v, incb, okhist, inc_hist, ms, voff_out, i0, zb, ze, full);
-        prev_allv = allv;
     }
 
-    if (FUSE) {
+    if (FUSE && live) {
         const int64_t o = y * A.mo_row_stride + x;
         const double nan = __longlong_as_double(0x7ff8000000000000LL);
         const double mu = ms.s1 / ms.s0;
