@@ -175,6 +175,15 @@ static inline void spc_canonical_pred(uint32_t f, float thr_lo, float thr_hi, fl
     }
 }
 
+// Buffer descriptor over (up to 4 GiB from) a wave-uniform base.  The base must be PROVABLY uniform, otherwise hipcc wraps
+// every buffer op in a waterfall loop: both halves go through readfirstlane.
+__device__ __forceinline__ auto spc_plane_srd(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)0xffffffffu, 0x00020000);
+}
+
 // predicate part of the mask (array part is handled by the caller's loads)
 __device__ __forceinline__ bool spc_pred(uint32_t flags, float thr_lo, float thr_hi, float v) {
     bool inc = true;

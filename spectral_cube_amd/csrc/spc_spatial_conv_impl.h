@@ -324,7 +324,9 @@ __device__ __forceinline__ float2v classify(float v, unsigned char mk, float lim
     return ok ? float2v{v, 1.f} : float2v{0.f, 0.f};
 }
 
-template <int R, bool ARR, bool PRED, bool ISO>
+// ABL (timing-only ablations, built with -DSPC_ABLATE and selected by SPC_SPATIAL_ABLATE; results are wrong by design):
+// 1 no output stores | 2 no mask loads | 4 no data loads | 8 no y-pass FMAs | 16 no x-pass FMAs
+template <int R, bool ARR, bool PRED, bool ISO, int ABL = 0>
 __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(const SpArgs A) {
     constexpr int H = R / 2;
     // float2 per LDS row.  Pitch = 28 (mod 32): a 32-lane group of the x pass spans parts of
@@ -382,16 +384,16 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
 #pragma unroll
             for (int s = 0; s < R; ++s) {
                 const int64_t ic = min(max(i0 + s, 0), ny - 1);
-                v[s] = p[ic * A.row_stride];
-                if (ARR) mk[s] = pm[ic * A.mask.row_stride];
+                v[s] = (ABL & 4) ? (float)(t + s) : p[ic * A.row_stride];
+                if (ARR) mk[s] = (ABL & 2) ? (unsigned char)1 : pm[ic * A.mask.row_stride];
             }
         } else {
             const float* q = p + (int64_t)i0 * A.row_stride;
             const uint8_t* qm = ARR ? pm + (int64_t)i0 * A.mask.row_stride : nullptr;
 #pragma unroll
             for (int s = 0; s < R; ++s) {
-                v[s] = q[(int64_t)s * A.row_stride];
-                if (ARR) mk[s] = qm[(int64_t)s * A.mask.row_stride];
+                v[s] = (ABL & 4) ? (float)(t + s) : q[(int64_t)s * A.row_stride];
+                if (ARR) mk[s] = (ABL & 2) ? (unsigned char)1 : qm[(int64_t)s * A.mask.row_stride];
             }
         }
     };
@@ -399,8 +401,8 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
     // row s of the revolution starting at i0 (the rolling prefetch of the next revolution: v[s] is free once step s has used it)
     auto load_row = [&](int i0, int s) {
         const int64_t ic = min(max(i0 + s, 0), ny - 1);
-        v[s] = p[ic * A.row_stride];
-        if (ARR) mk[s] = pm[ic * A.mask.row_stride];
+        v[s] = (ABL & 4) ? (float)(t + s + i0) : p[ic * A.row_stride];
+        if (ARR) mk[s] = (ABL & 2) ? (unsigned char)1 : pm[ic * A.mask.row_stride];
     };
     const int T = (ye - yb) + 2 * H;
     load_rows(yb - H);
@@ -425,7 +427,8 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
     #pragma unroll
                     for (int k = 0; k < kRun; ++k) {
                         const int widx = k + 2 * H - i;       // kx index for output k, input i
-                        if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
+                        if (ABL & 16) { if (widx == H) r[k] = in; }
+                        else if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
                     }
                 }
                 const int64_t xo = x0 + kRun * j;
@@ -446,7 +449,9 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
                         }
                     }
                 }
-                if (R <= kPairedStoreMaxR && pairable) {
+                if ((ABL & 1) && !(res[0] == 12345.678f && res[5] == 3.25f && res[7] == res[2])) {
+                    // ablation: no stores (the impossible condition keeps the arithmetic alive)
+                } else if (R <= kPairedStoreMaxR && pairable) {
                     store_run8_paired(dst, t & 1, f32x4{res[0], res[1], res[2], res[3]}, f32x4{res[4], res[5], res[6], res[7]});
                 } else if (xo + kRun <= A.nx && ((((uintptr_t)dst) & 15) == 0)) {
                     *reinterpret_cast<f32x4*>(dst) = f32x4{res[0], res[1], res[2], res[3]};
@@ -469,7 +474,8 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
 #pragma unroll
             for (int m = 0; m < R; ++m) {
                 const int a = (s - m + R) % R;
-                if (a == 0) pk_mul_w(acc[m], A.ky, 2 * H - a, x2);
+                if (ABL & 8) { if (a == 0) acc[m] = x2; }
+                else if (a == 0) pk_mul_w(acc[m], A.ky, 2 * H - a, x2);
                 else pk_fma_w(acc[m], A.ky, 2 * H - a, x2);
             }
             // row o = i0 + s - H is complete: park it in the group's LDS slot
@@ -486,6 +492,181 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
             lds_barrier();
             if (t0 + R < T) load_rows(i0 + R);            // every row has been used: in flight during the x pass
             xpass(0, R);
+            lds_barrier();
+        }
+    }
+}
+
+
+// ---- general (masked) kernel, grouped pipeline (round 3; dispatched for the 29-tap ring) ----------------------
+// The same march as spatial_sep_kernel - packed (num, den) rings along y, finished rows parked in LDS, runs of 8
+// along x - rebuilt around what the timing ablations of round 3 showed (profiles/r03_masked_spatial_ablation_*.log,
+// 512 x 2048^2 with a uint8 mask: 9.0 ms, of which 6.9 ms remain with NO memory traffic at all and 2.1 ms with no
+// FMAs and no memory traffic): the kernel is bound by VALU issue, and what memory adds on top is not latency but the
+// instructions that feed it.  Hence:
+//   * loads and stores go through ONE buffer descriptor per plane with a SCALAR row offset (no 64-bit address
+//     arithmetic per access: ~4 VALU instructions per voxel);
+//   * only ONE group of 8 rows is staged ahead (requested right after the barrier that ends a group's y pass, in
+//     flight during its x pass) instead of a whole revolution: 16 staging registers instead of 58 -> 128 VGPRs,
+//     FOUR blocks (16 waves) per CU, each with 20 KB of LDS;
+//   * the x pass divides without looking at the denominator (0 * (1 / 0) is the NaN an empty window needs for a kernel
+//     with a non-zero centre tap); the filled-centre rule of astropy for an empty window whose centre sample is valid
+//     (kernels with a zero centre tap) is a wave-uniform rare branch.
+// BT = threads per block = input columns per strip: 512 (two blocks of 8 waves per CU) wastes half as much as 256 on
+// the strip's halo columns in the y pass (28 of 512 instead of 28 of 256) and on idle lanes in the x pass (8 rows x 60
+// runs = 480 tasks for 512 lanes instead of 224 for 256).
+constexpr int grouped_txo(int R, int BT) { return ((BT - 2 * (R / 2)) / kRun) * kRun; }
+constexpr int grouped_pitch(int BT) { return BT == 256 ? 316 : 604; }     // float2 per LDS row, = 28 (mod 32): see spatial_sep_kernel
+template <int R, bool ARR, bool PRED, bool ISO, int BT, int ABL = 0>
+__global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(const SpArgs A) {
+    constexpr int H = R / 2;
+    constexpr int kG = 8;                                 // rows per group
+    constexpr int NG = (R + kG - 1) / kG;
+    constexpr int kPitch = grouped_pitch(BT);
+    static_assert(kPitch >= BT + BT / 8, "LDS row too short");
+    // (one buffer, two barriers per group: with two buffers - one barrier - the block needs 40 KB and only three fit
+    // a CU: 9.1 ms against 8.2 ms at 512 x 2048^2)
+    __shared__ float2v yres[kG * kPitch];
+
+    const int t = threadIdx.x;
+    const int64_t z = blockIdx.y;
+    constexpr int kTxo = grouped_txo(R, BT);              // output columns per strip
+    const int64_t x0 = (int64_t)blockIdx.x * kTxo;        // first output column of the strip
+    if (A.status) {   // both fast tiles this strip overlaps were finished by the all-valid kernel
+        const int ft = fast_txo(R);
+        const int f0 = (int)(x0 / ft), f1 = (int)(min(x0 + kTxo, A.nx) - 1) / ft;
+        if (spc_flag_get(A.status + z * A.fast_nstrips + f0) == 0 && spc_flag_get(A.status + z * A.fast_nstrips + f1) == 0) return;
+    }
+    const int nrun_eff = ((int)min((int64_t)kTxo, A.nx - x0) + kRun - 1) / kRun;
+    const int ncols = nrun_eff * kRun + 2 * H;
+    if ((t & ~63) >= ncols) return;
+    const int nthr = min(BT, (ncols + 63) & ~63);
+    const float inv_nrun = 1.0f / (float)nrun_eff;
+    const int ny = (int)A.ny;
+    const int yb = (int)(blockIdx.z * A.ychunk);
+    const int ye = (int)min((int64_t)ny, (int64_t)yb + A.ychunk);
+    const int64_t xin = x0 - H + t;                       // input column of this lane (y pass)
+    const bool col_in = (xin >= 0) && (xin < A.nx);
+    const bool edge_cols = (x0 - H < 0) || (x0 - H + BT > A.nx);     // block-uniform
+    const int64_t xc = min(max(xin, (int64_t)0), A.nx - 1);
+    const float lim = A.pred_lim, lo = A.pred_lo, hi = A.pred_hi;
+    // one descriptor per plane; accesses = descriptor + lane byte offset (VGPR) + row byte offset (SGPR)
+    const auto rs = spc_plane_srd(A.cube + z * A.plane_stride);
+    const auto rm = spc_plane_srd(ARR ? (const void*)(A.mask.arr + z * A.mask.plane_stride) : (const void*)A.cube);
+    const auto ro = spc_plane_srd(A.out + z * A.out_plane_stride);
+    const int voff = (int)(xc * 4), moff = (int)xc;
+    const unsigned rbytes = (unsigned)(A.row_stride * 4), mrbytes = ARR ? (unsigned)A.mask.row_stride : 0u;
+    const unsigned orbytes = (unsigned)(A.out_row_stride * 4);
+    const bool out_vec = (A.out_row_stride % 4 == 0) && ((((uintptr_t)(A.out + z * A.out_plane_stride)) & 15) == 0) && (x0 % 4 == 0);
+
+    float2v acc[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) acc[m] = float2v{0.f, 0.f};
+    float v[kG];
+    unsigned mk[kG];
+    const int T = (ye - yb) + 2 * H;
+    // rows of group gi counted from the first group of the first revolution
+    auto group_first = [&](int gi) { return yb - H + (gi / NG) * R + (gi % NG) * kG; };
+    auto group_rows = [&](int gi) { const int g = gi % NG; return ((g + 1) * kG < R ? (g + 1) * kG : R) - g * kG; };
+    auto fetch = [&](int first_row, int n) {
+#pragma unroll
+        for (int s = 0; s < kG; ++s) {
+            if (s < n) {
+                const int ic = min(max(first_row + s, 0), ny - 1);                    // uniform
+                v[s] = (ABL & 4) ? (float)(t + s) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)ic * rbytes), 0));
+                if (ARR) mk[s] = (ABL & 2) ? 1u : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)ic * mrbytes), 0);
+            }
+        }
+    };
+    fetch(group_first(0), group_rows(0));
+    for (int t0 = 0; t0 < T; t0 += R) {
+        const int i0 = yb - H + t0;                       // first input row of this revolution
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int s0 = g * kG, s1 = (g + 1) * kG < R ? (g + 1) * kG : R;          // static after unrolling
+            const bool edge = edge_cols || (i0 + s0 < 0) || (i0 + s1 > ny);           // block-uniform
+            // ---- y pass of the group
+#pragma unroll
+            for (int s = s0; s < s1; ++s) {
+                float2v x2 = classify<R, ARR, PRED>(v[s - s0], ARR ? (unsigned char)mk[s - s0] : (unsigned char)1, lim, lo, hi);
+                if (edge) {                                   // out of bounds = valid zero
+                    const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
+                    if (!in) x2 = float2v{0.f, 1.f};
+                }
+#pragma unroll
+                for (int m = 0; m < R; ++m) {
+                    const int a = (s - m + R) % R;
+                    if (ABL & 8) { if (a == 0) acc[m] = x2; }
+                    else if (a == 0) pk_mul_w(acc[m], A.ky, 2 * H - a, x2);
+                    else pk_fma_w(acc[m], A.ky, 2 * H - a, x2);
+                }
+                // row o = i0 + s - H is complete: park it in the group's LDS slot
+                yres[(s - s0) * kPitch + lds_phys(t)] = acc[(s + 1) % R];
+            }
+            lds_barrier();
+            // ---- rows of the NEXT group, into the registers this group has just used: in flight during the x pass
+            {
+                const int gi = (t0 / R) * NG + g + 1;
+                if (group_first(gi) < ye + H) fetch(group_first(gi), group_rows(gi));
+            }
+            // ---- x pass over the rows of this group
+            const int grows = s1 - s0;
+            for (int task = t; task < grows * nrun_eff; task += nthr) {
+                const int sl = (int)(((float)task + 0.5f) * inv_nrun);    // exact: task < 2^10, nrun <= 60
+                const int j = task - sl * nrun_eff;
+                const int o = i0 + s0 + sl - H;           // output row
+                if (o < yb || o >= ye) continue;
+                float2v r[kRun];
+#pragma unroll
+                for (int k = 0; k < kRun; ++k) r[k] = float2v{0.f, 0.f};
+                const float2v* src = yres + sl * kPitch;
+#pragma unroll
+                for (int i = 0; i < kRun + 2 * H; ++i) {
+                    const float2v in = src[lds_phys(kRun * j + i)];
+#pragma unroll
+                    for (int k = 0; k < kRun; ++k) {
+                        const int widx = k + 2 * H - i;       // kx index for output k, input i
+                        if (ABL & 16) { if (widx == H) r[k] = in; }
+                        else if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
+                    }
+                }
+                const int64_t xo = x0 + kRun * j;
+                float res[kRun];
+                bool empty = false;
+#pragma unroll
+                for (int k = 0; k < kRun; ++k) {
+                    res[k] = r[k].x * __builtin_amdgcn_rcpf(r[k].y);      // den = 0 (empty window): 0 * inf = NaN
+                    empty = empty || (r[k].y == 0.f);
+                }
+                if (__any(empty)) {
+                    // astropy returns the (filled) centre sample for an empty window: NaN when that sample is excluded
+                    // (always, for a kernel whose centre tap is not zero), the sample itself otherwise
+#pragma unroll
+                    for (int k = 0; k < kRun; ++k) {
+                        if (r[k].y == 0.f) {
+                            res[k] = NAN;
+                            if (xo + k < A.nx) {
+                                const float c = A.cube[z * A.plane_stride + (int64_t)o * A.row_stride + xo + k];
+                                bool inc = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, c);
+                                if (ARR) inc = inc && A.mask.arr[z * A.mask.plane_stride + (int64_t)o * A.mask.row_stride + xo + k] != 0;
+                                if (inc) res[k] = c;
+                            }
+                        }
+                    }
+                }
+                const int ooff = (int)((unsigned)o * orbytes + (unsigned)(xo * 4));   // (< 4 GiB per plane: checked on the host)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                if ((ABL & 1) && !(res[0] == 12345.678f && res[5] == 3.25f && res[7] == res[2])) {
+                    // ablation: no stores (the impossible condition keeps the arithmetic alive)
+                } else if (out_vec && xo + kRun <= A.nx) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{res[0], res[1], res[2], res[3]}), ro, ooff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{res[4], res[5], res[6], res[7]}), ro, ooff + 16, 0, 0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kRun; ++k)
+                        if (xo + k < A.nx) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[k]), ro, ooff + 4 * k, 0, 0);
+                }
+            }
             lds_barrier();
         }
     }
@@ -525,6 +706,52 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
     }
     const bool pred = (A.mask.flags & (SPC_MASK_GT | SPC_MASK_GE | SPC_MASK_LT | SPC_MASK_LE)) != 0;
     // non-isotropic kernels only come in the PRED flavour (a superset: absent bounds are NaN)
+#ifdef SPC_ABLATE
+    if constexpr (R == 29) {
+        const char* ab = getenv("SPC_SPATIAL_ABLATE");
+        const int abl = ab ? atoi(ab) : 0;
+        if (abl && iso && !pred && arr) {
+            switch (abl) {
+                case 1: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 1>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 2: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 2>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 3: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 3>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 6: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 6>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 7: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 7>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 8: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 8>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 16: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 16>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 24: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 24>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 31: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 31>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                default: spc_set_error("no such ablation"); return SPC_ERR_UNSUPPORTED;
+            }
+            SPC_LAUNCH_CHECK();
+            return SPC_OK;
+        }
+    }
+#endif
+    if constexpr (R == 29) {
+        // grouped pipeline; planes beyond the 4 GiB a buffer descriptor spans keep the round-2 kernel
+        const char* gk = getenv("SPC_SPATIAL_GROUPED");
+        // 0: round-2 kernel, 256 / 512: threads per block.  Measured at 512 x 2048^2 with a uint8 mask (same box): round-2
+        // kernel 9.01 ms, 256 threads 8.29 ms, 512 threads 8.76 ms (less halo and fewer idle x-pass lanes, but barriers
+        // over 8 waves and two blocks per CU)
+        const int want = gk ? atoi(gk) : 256;
+        const bool fits = (uint64_t)A.plane_stride * 4 < (1ull << 32) && (uint64_t)A.out_plane_stride * 4 < (1ull << 32) &&
+                          (!arr || (uint64_t)A.mask.plane_stride < (1ull << 32));
+        if (want && fits) {
+            const int bt = (want == 256 || A.nx < 384) ? 256 : 512;
+            const int txo = bt == 256 ? grouped_txo(R, 256) : grouped_txo(R, 512);
+            dim3 ggrid((unsigned)((A.nx + txo - 1) / txo), grid.y, grid.z), gblock(bt);
+#define SPC_GROUPED(ARRV, PREDV, ISOV)                                                                                              \
+            do { if (bt == 256) hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, ARRV, PREDV, ISOV, 256>), ggrid, gblock, 0, st, A);  \
+                 else hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, ARRV, PREDV, ISOV, 512>), ggrid, gblock, 0, st, A); } while (0)
+            if (iso && !pred) { if (arr) SPC_GROUPED(true, false, true); else SPC_GROUPED(false, false, true); }
+            else if (iso) { if (arr) SPC_GROUPED(true, true, true); else SPC_GROUPED(false, true, true); }
+            else { if (arr) SPC_GROUPED(true, true, false); else SPC_GROUPED(false, true, false); }
+#undef SPC_GROUPED
+            SPC_LAUNCH_CHECK();
+            return SPC_OK;
+        }
+    }
     if (iso && !pred) {
         if (arr) hipLaunchKernelGGL((spatial_sep_kernel<R, true, false, true>), grid, block, 0, st, A);
         else hipLaunchKernelGGL((spatial_sep_kernel<R, false, false, true>), grid, block, 0, st, A);
