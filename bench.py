@@ -254,7 +254,7 @@ class Workload:
 def pmc_traffic(shape):
     """HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc
     runs of this same command; FETCH_SIZE x2 gfx950 correction)"""
-    for name in ("r02_moments_c2_pmc.json", "r01_moments_c2_pmc.json"):
+    for name in ("r03_moments_c2_pmc.json", "r02_moments_c2_pmc.json", "r01_moments_c2_pmc.json"):
         f = os.path.join(REPO, "profiles", name)
         if os.path.exists(f) and tuple(shape) == (1024, 1024, 1024):
             with open(f) as fh:
@@ -513,11 +513,11 @@ def config_c3(device, scale):
     inc = tmask[:, :, :W].astype(bool)
     ms = event_ms(lambda: ops.spectral_conv_moments(cube, k, d_cen, dv=500.0, m1_add=cref + v[0], mask=mspec, want=("m1",),
                                                     out=o1, cen_host=cen - cref), device)
-    recs.append(cfg_record("C3 spectral_smooth(33 taps) -> moment1, fused, uint8 mask", "spectral_conv_kernel<33,ARR,FUSE>", ms,
+    recs.append(cfg_record("C3 spectral_smooth(33 taps) -> moment1, fused, uint8 mask", "spectral_conv_kernel<33,true,true,false,true> (ARR, FUSE, SYM)", ms,
                            vox * 5 + ny * nx * 8, vox, check_m1(inc, "C3 fused masked"), "4 + 1 read + 8 B/spaxel out",
                            mask_valid_fraction=float(tmask.mean())))
     ms = event_ms(lambda: ops.spectral_conv(cube, k, mask=mspec, out=sm), device)
-    recs.append(cfg_record("C3 spectral_smooth(33 taps) materialised, uint8 mask", "spectral_conv_kernel<33,ARR>", ms, vox * 9, vox,
+    recs.append(cfg_record("C3 spectral_smooth(33 taps) materialised, uint8 mask", "spectral_conv_kernel<33,true,false,false,true> (ARR, SYM)", ms, vox * 9, vox,
                            check_cube(sm, inc, "C3 smooth masked"), "4 + 1 read + 4 written",
                            mask_valid_fraction=float(tmask.mean())))
     return recs
@@ -569,7 +569,7 @@ def config_c4(device, scale):
     exp = O.spatial_smooth(tile[sub], inc, k2)[win]
     ver = {"max_scaled_err": _close(smoothed_window(sm), exp, float(np.nanmax(np.abs(exp))), "C4 smooth masked"),
            "voxels_checked": int(exp.size)}
-    recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 mask", "spatial_sep_kernel<29,ARR>", ms_s, vox * 9, vox, ver,
+    recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 mask", "spatial_sep_grouped_kernel<29,true,false,true,256,0> (ARR, ISO, 256 threads)", ms_s, vox * 9, vox, ver,
                            "4 + 1 read + 4 written", mask_valid_fraction=float(tmask.mean())))
 
     # the pipeline of the config: spatial_smooth -> moment0 (the smoothed cube keeps the ORIGINAL mask)
@@ -588,7 +588,7 @@ def config_c4(device, scale):
     ver = {"max_scaled_err": _close(o0["m0"].get()[:WY, :WX], exp_m0, float(np.nanmax(np.abs(exp_m0))), "C4 moment0 masked"),
            "spaxels_checked": int(exp_m0.size)}
     recs.append(cfg_record("C4 pipeline spatial_smooth(29x29) -> moment0, uint8 mask (materialised)",
-                           "spatial_sep_kernel<29,ARR> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "spatial_sep_grouped_kernel<29,true,false,true,256,0> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
                            "fused ideal: 4 + 1 read + 8 B/spaxel out (the materialised form moves 9 + 5 B/voxel)",
                            mask_valid_fraction=float(tmask.mean())))
 
