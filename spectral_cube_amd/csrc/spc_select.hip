@@ -29,6 +29,7 @@ struct SelArgs {
     // samples of a ray are the contiguous ones)
     int64_t x_stride, m_x_stride;
     int along_ray;
+    float pred_lim, pred_lo, pred_hi;      // spc_canonical_pred of the mask's predicate terms (filled by the launcher)
 };
 
 __device__ __forceinline__ uint32_t fkey(float v) {
@@ -323,6 +324,80 @@ __device__ __forceinline__ void count_keys(const uint32_t (&key)[KPL], uint32_t 
     }
 }
 
+// ---- the one read of the cube: TS rays into register keys ------------------------------------------------
+// Lane (r, j) takes samples z = j + L k (L = 256 / TS lanes per ray, k < KPL) of ray r; an excluded / NaN / out-of-range
+// sample becomes the largest key.  Round 2 formed every address as base + z * plane_stride in 64-bit vector arithmetic
+// (two quarter-rate 32-bit multiplies and a 64-bit multiply-add per array and key: ~30 VALU slots per key, more than the
+// four digit passes of the selection that follows) and guarded the tail with an exec-masked branch per key.  DESC: the
+// accesses go through ONE buffer descriptor per group of 8 keys (rebased by scalar arithmetic); a lane's offset (its
+// column and its first plane) is one 32-bit register, key u of the group adds u * L planes to it (one v_add_u32 with a
+// scalar operand), and samples beyond the last plane fall outside the descriptor's range (the hardware returns 0, no
+// fault).  The launcher picks DESC when 8 steps of L planes fit an unsigned 32-bit byte offset (sel_desc_fits); larger
+// planes keep the 64-bit form.
+// cen: select on |x - cen| when use_cen (mad_std); lim / lo / hi: spc_canonical_pred of the mask's predicate terms.
+static inline bool spc_env_on(const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : true; }
+static inline bool spc_env_set(const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : false; }
+static inline bool sel_desc_fits(int ts, int64_t plane_stride, int64_t x_stride) {
+    const int64_t L = 256 / ts;
+    return (9 * L * plane_stride + ts * x_stride) * 4 < (1ll << 32);
+}
+
+template <int TS, int KPL, bool ARR, bool DESC>
+__device__ __forceinline__ int sel_load_keys(const float* cube, int64_t plane_stride, int64_t x_stride, int64_t tile_off,
+                                             const uint8_t* marr, int64_t m_plane_stride, int64_t m_x_stride, int64_t m_tile_off,
+                                             int rc, int j, int nz, int tile_cols, bool col_in, float lim, float lo, float hi,
+                                             bool use_cen, float cen, uint32_t (&key)[KPL]) {
+    constexpr int L = 256 / TS;
+    constexpr int U = KPL < 8 ? KPL : 8;
+    int mine = 0;
+    // bytes of the tile's rays from its first sample to one past its last valid one
+    const uint64_t total = ((uint64_t)(nz - 1) * (uint64_t)plane_stride + (uint64_t)(tile_cols - 1) * (uint64_t)x_stride + 1u) * 4u;
+    const uint64_t mtotal = ARR ? ((uint64_t)(nz - 1) * (uint64_t)m_plane_stride + (uint64_t)(tile_cols - 1) * (uint64_t)m_x_stride + 1u) : 0u;
+    const unsigned voff = (unsigned)(((int64_t)rc * x_stride + (int64_t)j * plane_stride) * 4);
+    const unsigned moff = ARR ? (unsigned)((int64_t)rc * m_x_stride + (int64_t)j * m_plane_stride) : 0u;
+    const unsigned step = (unsigned)(L * plane_stride * 4), mstep = ARR ? (unsigned)(L * m_plane_stride) : 0u;     // (DESC: fit 32 bits)
+    const float* p = cube + tile_off + (int64_t)rc * x_stride;                 // (64-bit form)
+    const uint8_t* pm = ARR ? marr + m_tile_off + (int64_t)rc * m_x_stride : nullptr;
+#pragma unroll
+    for (int i0 = 0; i0 < KPL; i0 += U) {
+        float raw[U];
+        unsigned mk[U];
+        if (DESC) {
+            const uint64_t goff = (uint64_t)i0 * step, mgoff = (uint64_t)i0 * mstep;
+            const uint64_t left = total > goff ? total - goff : 0u, mleft = mtotal > mgoff ? mtotal - mgoff : 0u;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(cube + tile_off) + goff), 0,
+                                                              (int)(unsigned)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
+            const auto rm = __builtin_amdgcn_make_buffer_rsrc(ARR ? (void*)(reinterpret_cast<const char*>(marr + m_tile_off) + mgoff) : (void*)cube, 0,
+                                                              (int)(unsigned)(mleft < 0xffffffffull ? mleft : 0xffffffffull), 0x00020000);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                raw[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + (unsigned)u * step), 0, /*nt*/ 2));
+                mk[u] = ARR ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)(moff + (unsigned)u * mstep), 0, 2) : 1u;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int z = min(j + L * (i0 + u), nz - 1);
+                raw[u] = __builtin_nontemporal_load(p + (int64_t)z * plane_stride);
+                mk[u] = ARR ? pm[(int64_t)z * m_plane_stride] : 1u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int zlim = nz - L * (i0 + u);                                  // uniform: the sample exists iff j < zlim
+            const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
+            // (NaN fails |raw| <= lim; an infinite raw under "no isfinite" passes and |inf - cen| stays a valid key unless
+            //  cen is the same infinity: that NaN is dropped by v == v)
+            const bool ok = (j < zlim) && col_in && (__builtin_fabsf(raw[u]) <= lim) && !(raw[u] <= lo) && !(raw[u] >= hi) &&
+                            (mk[u] != 0) && (v == v);
+            key[i0 + u] = ok ? fkey(v) : 0xffffffffu;
+            mine += ok ? 1 : 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // U loads in flight, not KPL
+    }
+    return mine;
+}
+
 // LDS scratch of one block of TS rays
 template <int TS>
 struct SelShared {
@@ -445,7 +520,7 @@ __device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, dou
     return (float)((frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac) * scale);
 }
 
-template <int TS, int KPL, bool ARR>
+template <int TS, int KPL, bool ARR, bool DESC>
 __global__ __launch_bounds__(256, KPL == 128 ? 2 : 5) void select_reg_kernel(const SelArgs A) {
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = 256 / TS;
@@ -456,38 +531,17 @@ __global__ __launch_bounds__(256, KPL == 128 ? 2 : 5) void select_reg_kernel(con
     const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
     const int nz = (int)A.nz;
     const bool col_in = x0 + r < A.nx;
-    const int64_t xc = col_in ? x0 + r : A.nx - 1;
-    const float* p = A.cube + y * A.row_stride + xc * A.x_stride;
-    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc * A.m_x_stride : nullptr;
     const bool use_cen = A.center != nullptr;
     const float cen = (use_cen && col_in) ? A.center[y * A.nx + x0 + r] : 0.f;
     sel_reset<TS>(S);
     __syncthreads();
     // ---- the one read of the cube: keys into registers (excluded / NaN / beyond nz: the largest key)
     uint32_t key[KPL];
-    int mine = 0;
-    constexpr int U = KPL < 8 ? KPL : 8;
-#pragma unroll
-    for (int i0 = 0; i0 < KPL; i0 += U) {
-        float raw[U];
-        unsigned mk[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int z = min(j + kLanesPerRay * (i0 + u), nz - 1);
-            raw[u] = __builtin_nontemporal_load(p + (int64_t)z * A.plane_stride);
-            mk[u] = ARR ? pm[(int64_t)z * A.mask.plane_stride] : 1u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int z = j + kLanesPerRay * (i0 + u);
-            bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
-            const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
-            ok = ok && (v == v);
-            key[i0 + u] = ok ? fkey(v) : 0xffffffffu;
-            mine += ok ? 1 : 0;
-        }
-        __builtin_amdgcn_sched_barrier(0);                       // U loads in flight, not KPL
-    }
+    const int rc = col_in ? r : (int)(A.nx - 1 - x0);
+    const int tile_cols = (int)min((int64_t)TS, A.nx - x0);
+    const int64_t tile_off = y * A.row_stride + x0 * A.x_stride, m_tile_off = ARR ? y * A.mask.row_stride + x0 * A.m_x_stride : 0;
+    const int mine = sel_load_keys<TS, KPL, ARR, DESC>(A.cube, A.plane_stride, A.x_stride, tile_off, A.mask.arr, A.mask.plane_stride, A.m_x_stride,
+                                                 m_tile_off, rc, j, nz, tile_cols, col_in, A.pred_lim, A.pred_lo, A.pred_hi, use_cen, cen, key);
     if (mine) atomicAdd(&S.nvalid[r], (uint32_t)mine);
     __syncthreads();
     const int n = (int)S.nvalid[r];
@@ -515,9 +569,10 @@ struct ClipRegArgs {
     int maxiters;               // < 0: until convergence
     int cen_mean;               // centre: 0 median, 1 mean
     int spread_mad;             // spread: 0 std, 1 mad_std
+    float pred_lim, pred_lo, pred_hi;      // spc_canonical_pred of the mask's predicate terms (filled by the launcher)
 };
 
-template <int TS, int KPL, bool ARR, bool MAD>
+template <int TS, int KPL, bool ARR, bool MAD, bool DESC>
 __global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = 256 / TS;
@@ -528,29 +583,10 @@ __global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_cli
     const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
     const int nz = (int)A.nz;
     const bool col_in = x0 + r < A.nx;
-    const int64_t xc = col_in ? x0 + r : A.nx - 1;
-    const float* p = A.cube + y * A.row_stride + xc;
-    const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + xc : nullptr;
     uint32_t key[KPL];
-    constexpr int U = KPL < 8 ? KPL : 8;
-#pragma unroll
-    for (int i0 = 0; i0 < KPL; i0 += U) {
-        float raw[U];
-        unsigned mk[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int z = min(j + kLanesPerRay * (i0 + u), nz - 1);
-            raw[u] = __builtin_nontemporal_load(p + (int64_t)z * A.plane_stride);
-            mk[u] = ARR ? pm[(int64_t)z * A.mask.plane_stride] : 1u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int z = j + kLanesPerRay * (i0 + u);
-            const bool ok = (z < nz) && col_in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[u]) && (raw[u] == raw[u]) && (mk[u] != 0);
-            key[i0 + u] = ok ? fkey(raw[u]) : 0xffffffffu;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    sel_load_keys<TS, KPL, ARR, DESC>(A.cube, A.plane_stride, 1, y * A.row_stride + x0, A.mask.arr, A.mask.plane_stride, 1,
+                                ARR ? y * A.mask.row_stride + x0 : 0, col_in ? r : (int)(A.nx - 1 - x0), j, nz,
+                                (int)min((int64_t)TS, A.nx - x0), col_in, A.pred_lim, A.pred_lo, A.pred_hi, false, 0.f, key);
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
 #pragma unroll 1
     for (int it = 0; A.maxiters < 0 || it < A.maxiters; ++it) {
@@ -729,6 +765,7 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
     SPC_REQUIRE(q >= 0.0 && q <= 100.0, "Percentiles must be in the range [0, 100]");
     SelArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
+    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.pred_lim, &A.pred_lo, &A.pred_hi);
     if (rc) return rc;
     SPC_DEVICE(device);
     A.cube = cube->d_data;
@@ -746,6 +783,10 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
     const char* renv = getenv("SPC_SELECT_REG");
     if ((renv ? atoi(renv) != 0 : true) && cube->nz <= 4096 && cube->ny * ((cube->nx + 7) / 8) < (1LL << 31)) {
         const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
+        // (descriptor loads: measured no gain for the selection - 3.64 against 3.25 ms with a uint8 mask, 2.61 against 2.65 ms
+        //  without, 1024^3 - its time is in the digit passes; they pay for the clip kernel: 10.1 against 10.8 ms, mad_std 28.3
+        //  against 31.9 ms.  SPC_SELECT_DESC=1 switches them on here.)
+        const bool desc = sel_desc_fits(ts, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1) && spc_env_set("SPC_SELECT_DESC");
         const int lanes = 256 / ts;
         const int need = (int)((cube->nz + lanes - 1) / lanes);
         const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : (need <= 64 ? 64 : 128));   // 128: 2049 - 4096 channels, 8 spaxels per block
@@ -753,8 +794,10 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
         dim3 grid((unsigned)nblk);
 #define SPC_LAUNCH_REG(TS_, K_)                                                                                     \
         do {                                                                                                        \
-            if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true>), grid, dim3(256), 0, st, A);             \
-            else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false>), grid, dim3(256), 0, st, A);                \
+            if (desc) { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, true>), grid, dim3(256), 0, st, A);   \
+                        else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, true>), grid, dim3(256), 0, st, A); }    \
+            else { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, false>), grid, dim3(256), 0, st, A);       \
+                   else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, false>), grid, dim3(256), 0, st, A); }        \
         } while (0)
 #define SPC_LAUNCH_REG_K(TS_)                                                                                       \
         do {                                                                                                        \
@@ -879,6 +922,7 @@ extern "C" int spc_percentile_axis2_f32(int device, void* stream, const spc_cube
     }
     SelArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
+    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.pred_lim, &A.pred_lo, &A.pred_hi);
     if (rc) return rc;
     SPC_DEVICE(device);
     // the view: samples along x (step 1), rows = channels (step plane_stride), adjacent spaxels = adjacent rows y
@@ -892,14 +936,17 @@ extern "C" int spc_percentile_axis2_f32(int device, void* stream, const spc_cube
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
     const int ts = A.nz <= 512 ? 32 : (A.nz <= 1024 ? 16 : 8);
+    const bool desc = sel_desc_fits(ts, 1, std::max(A.x_stride, arr ? A.m_x_stride : 0)) && spc_env_set("SPC_SELECT_DESC");
     const int lanes = 256 / ts;
     const int need = (int)((A.nz + lanes - 1) / lanes);
     const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : (need <= 64 ? 64 : 128));
     dim3 grid((unsigned)(A.ny * ((A.nx + ts - 1) / ts)));
 #define SPC_LAUNCH_REG(TS_, K_)                                                                                     \
     do {                                                                                                            \
-        if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true>), grid, dim3(256), 0, st, A);                 \
-        else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false>), grid, dim3(256), 0, st, A);                    \
+        if (desc) { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, true>), grid, dim3(256), 0, st, A);       \
+                    else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, true>), grid, dim3(256), 0, st, A); }        \
+        else { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, false>), grid, dim3(256), 0, st, A);           \
+               else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, false>), grid, dim3(256), 0, st, A); }            \
     } while (0)
 #define SPC_LAUNCH_REG_K(TS_)                                                                                       \
     do {                                                                                                            \
@@ -928,6 +975,7 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     }
     ClipRegArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
+    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.pred_lim, &A.pred_lo, &A.pred_hi);
     if (rc) return rc;
     SPC_DEVICE(device);
     A.cube = cube->d_data;
@@ -939,6 +987,7 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
     const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
+    const bool desc = sel_desc_fits(ts, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1) && spc_env_on("SPC_SELECT_DESC");
     const int lanes = 256 / ts;
     const int need = (int)((cube->nz + lanes - 1) / lanes);
     const int kpl = need <= 16 ? 16 : (need <= 32 ? 32 : (need <= 64 ? 64 : 128));
@@ -946,11 +995,11 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
 #define SPC_LAUNCH_CLIP(TS_, K_)                                                                                    \
     do {                                                                                                            \
         if (A.spread_mad) {                                                                                         \
-            if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, true>), grid, dim3(256), 0, st, A);   \
-            else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, true>), grid, dim3(256), 0, st, A);      \
+            if (arr) { if (desc) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, true, true>), grid, dim3(256), 0, st, A); else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, true, false>), grid, dim3(256), 0, st, A); }   \
+            else { if (desc) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, true, true>), grid, dim3(256), 0, st, A); else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, true, false>), grid, dim3(256), 0, st, A); }      \
         } else {                                                                                                    \
-            if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, false>), grid, dim3(256), 0, st, A);  \
-            else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, false>), grid, dim3(256), 0, st, A);     \
+            if (arr) { if (desc) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, false, true>), grid, dim3(256), 0, st, A); else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, true, false, false>), grid, dim3(256), 0, st, A); }  \
+            else { if (desc) hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, false, true>), grid, dim3(256), 0, st, A); else hipLaunchKernelGGL((sigma_clip_reg_kernel<TS_, K_, false, false, false>), grid, dim3(256), 0, st, A); }     \
         }                                                                                                           \
     } while (0)
 #define SPC_LAUNCH_CLIP_K(TS_)                                                                                      \
