@@ -425,17 +425,19 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube,
 /* Pixel map of a reprojection, on the device: for every pixel of the target grid (wcs_out) the
  * 0-based pixel coordinates in the source grid (wcs_in) - what reproject_interp obtains from
  * astropy.wcs (pixel_to_world on the target, world_to_pixel on the source; spectral_cube.py:2700-2732).
- * FITS paper II arithmetic in float64 for the zenithal projections TAN / SIN / ARC / STG / ZEA and
- * CAR; pixels that cannot be projected get -1e30 (outside every footprint).  The host fills the
+ * FITS paper II arithmetic in float64 for the zenithal projections TAN / SIN / ARC / STG / ZEA and the
+ * (pseudo-)cylindrical CAR / SFL / CEA / MER / AIT; pixels that cannot be projected (or lie beyond the edge
+ * of the sky of an all-sky projection) get -1e30 (outside every footprint).  The host fills the
  * struct from the header (spectral_cube_amd/wcs.py). */
 typedef struct spc_celestial_wcs {
-    int32_t proj;              /* 0 TAN, 1 SIN, 2 ARC, 3 STG, 4 ZEA, 5 CAR */
+    int32_t proj;              /* 0 TAN, 1 SIN, 2 ARC, 3 STG, 4 ZEA, 5 CAR, 6 SFL, 7 CEA, 8 MER, 9 AIT */
     int32_t reserved;
     double crpix[2];           /* FITS 1-based reference pixel (x, y) */
     double lin[4];             /* CDELT_i * PC_ij, 2 x 2 row-major: degrees per pixel */
     double lin_inv[4];         /* its inverse */
     double alpha_p, delta_p;   /* celestial coordinates of the native pole (radians) */
     double phi_p;              /* LONPOLE (radians) */
+    double pv1;                /* CEA: PV2_1 (lambda), else unused (ABI 3) */
 } spc_celestial_wcs;
 /* frame_rot (HOST pointer, 9 doubles row-major, may be NULL = same frame): rotation of the unit sphere that takes
  * the TARGET's celestial frame to the SOURCE's (ICRS / FK5(equinox) / Galactic: spectral_cube_amd/wcs.py::

@@ -579,6 +579,51 @@ def case_wcs_frames():
     print("wcs_frames ok", names)
 
 
+def case_wcs_projections():
+    """astropy.wcs (wcslib) values for the cylindrical / pseudo-cylindrical projections round 3 added to the minimal WCS
+    (SFL, CEA incl. PV2_1, MER, AIT; CAR again with CRVAL2 != 0): all-sky pixel scales so that the curvature shows, pixels
+    beyond the edge of the sky included (wcslib flags them: NaN), plus one pixel map between two of them across frames."""
+    from astropy.coordinates import SkyCoord
+    from astropy.wcs.utils import wcs_to_celestial_frame
+    store = {}
+    ny, nx = 48, 64
+    rng = np.random.default_rng(15)
+    px = np.concatenate([rng.uniform(-1, nx, 70), [0.0, nx - 1.0, nx / 2.0, -40.0, nx + 40.0]])
+    py = np.concatenate([rng.uniform(-1, ny, 70), [0.0, ny - 1.0, ny / 2.0, ny / 2.0, ny + 30.0]])
+    cases = [("SFL", 0.0, {}), ("SFL", 20.0, {}), ("CEA", 0.0, {}), ("CEA", 0.0, {"PV2_1": 0.5}), ("MER", 0.0, {}), ("AIT", 0.0, {}),
+             ("AIT", -30.0, {}), ("CAR", 25.0, {})]
+    for i, (proj, crval2, extra) in enumerate(cases):
+        h = {"CTYPE1": "GLON-" + proj, "CTYPE2": "GLAT-" + proj, "CRVAL1": 120.0, "CRVAL2": crval2, "CRPIX1": nx / 2 + 0.5, "CRPIX2": ny / 2 + 0.5,
+             "CDELT1": -4.0, "CDELT2": 4.0, "CUNIT1": "deg", "CUNIT2": "deg"}
+        if proj == "MER":
+            h["CDELT1"], h["CDELT2"] = -3.0, 3.0
+        h.update(extra)
+        rot = 15.0 if i % 2 else 0.0
+        if rot:
+            c, s_ = np.cos(np.radians(rot)), np.sin(np.radians(rot))
+            h.update(PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c)
+        w = WCS(fits.Header(h))
+        lon, lat = w.wcs_pix2world(px, py, 0)
+        ok = np.isfinite(lon) & np.isfinite(lat)
+        bx, by = w.wcs_world2pix(np.where(ok, lon, 0.0), np.where(ok, lat, 0.0), 0)
+        assert np.allclose(bx[ok], px[ok], atol=1e-7) and np.allclose(by[ok], py[ok], atol=1e-7), proj
+        store["hdr%d" % i] = fits.Header(h).tostring(sep="\n")
+        store["lon%d" % i], store["lat%d" % i] = lon, lat
+    store["n"], store["px"], store["py"] = len(cases), px, py
+    # pixel map: an all-sky Galactic AIT image sampled onto an equatorial (ICRS) CAR grid
+    h_in = {"CTYPE1": "GLON-AIT", "CTYPE2": "GLAT-AIT", "CRVAL1": 0.0, "CRVAL2": 0.0, "CRPIX1": 90.5, "CRPIX2": 45.5, "CDELT1": -2.0, "CDELT2": 2.0}
+    h_out = {"CTYPE1": "RA---CAR", "CTYPE2": "DEC--CAR", "CRVAL1": 180.0, "CRVAL2": 0.0, "CRPIX1": 36.5, "CRPIX2": 18.5, "CDELT1": -5.0, "CDELT2": 5.0}
+    w_in, w_out = WCS(fits.Header(h_in)), WCS(fits.Header(h_out))
+    yy, xx = np.mgrid[0:36, 0:72]
+    lon, lat = w_out.wcs_pix2world(xx, yy, 0)
+    sky = SkyCoord(lon.ravel() * u.deg, lat.ravel() * u.deg, frame=wcs_to_celestial_frame(w_out)).transform_to(wcs_to_celestial_frame(w_in))
+    xs, ys = w_in.wcs_world2pix(sky.spherical.lon.deg.reshape(36, 72), sky.spherical.lat.deg.reshape(36, 72), 0)
+    store["map_in"], store["map_out"] = fits.Header(h_in).tostring(sep="\n"), fits.Header(h_out).tostring(sep="\n")
+    store["map_xs"], store["map_ys"] = xs, ys
+    np.savez_compressed(os.path.join(OUT, "wcs_projections.npz"), **store)
+    print("wcs_projections ok", [int(np.isnan(store["lon%d" % i]).sum()) for i in range(len(cases))])
+
+
 def case_bilinear_scipy():
     """Pins oracle_np.resample_bilinear against the resampling primitive reproject calls.
 
@@ -903,7 +948,7 @@ def case_beams_cube():
 
 if __name__ == "__main__":
     cases = [case_beams_cube, case_moment_cube, case_c1, case_adv_argmax, case_smooth, case_interp, case_kernels,
-             case_wcs, case_wcs_frames, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
+             case_wcs, case_wcs_frames, case_wcs_projections, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
              case_order_statistics, case_sigma_clip]
     only = set(sys.argv[1:])                 # e.g. `gen_golden.py case_reproject_glue_scipy` regenerates one fixture
     for fn in cases:

@@ -63,7 +63,8 @@ class SpcMomentOutputs(C.Structure):
 
 class SpcCelestialWcs(C.Structure):
     _fields_ = [("proj", C.c_int32), ("reserved", C.c_int32), ("crpix", C.c_double * 2), ("lin", C.c_double * 4),
-                ("lin_inv", C.c_double * 4), ("alpha_p", C.c_double), ("delta_p", C.c_double), ("phi_p", C.c_double)]
+                ("lin_inv", C.c_double * 4), ("alpha_p", C.c_double), ("delta_p", C.c_double), ("phi_p", C.c_double),
+                ("pv1", C.c_double)]
 
 
 class SpcStatsOutputs(C.Structure):

@@ -432,8 +432,23 @@ __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     const double px = A.o.lin[0] * dx + A.o.lin[1] * dy;
     const double py = A.o.lin[2] * dx + A.o.lin[3] * dy;
     double phi, theta;
-    if (A.o.proj == 5) {
-        phi = px * D2R; theta = py * D2R;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (A.o.proj >= 5) {        // (pseudo-)cylindrical: CAR, SFL, CEA, MER, AIT
+        const double xr = px * D2R, yr = py * D2R;
+        switch (A.o.proj) {
+            case 5: phi = xr; theta = yr; break;
+            case 6: { theta = yr; const double c = cos(theta); phi = c != 0.0 ? xr / c : (px == 0.0 ? 0.0 : nan); break; }
+            case 7: { const double s_ = A.o.pv1 * yr; theta = fabs(s_) <= 1.0 + 1e-13 ? asin(fmin(fmax(s_, -1.0), 1.0)) : nan; phi = xr; break; }
+            case 8: theta = 2.0 * atan(exp(yr)) - PI / 2; phi = xr; break;
+            default: {
+                const double z2 = 1.0 - (xr / 4.0) * (xr / 4.0) - (yr / 2.0) * (yr / 2.0);
+                const double zz = z2 >= 0.5 - 1e-13 ? sqrt(fmax(z2, 0.5)) : nan;           // outside the ellipse: not on the sky
+                phi = 2.0 * atan2(zz * xr / 2.0, 2.0 * zz * zz - 1.0);
+                theta = asin(fmin(fmax(yr * zz, -1.0), 1.0));
+            }
+        }
+        // the native sphere ends at |phi| = 180, |theta| = 90 (wcslib's bounds check)
+        if (fabs(phi) > PI * (1 + 1e-12) || fabs(theta) > PI / 2 * (1 + 1e-12)) phi = nan;
     } else {
         const double rr = hypot(px, py) * D2R;
         phi = atan2(px, -py);
@@ -473,13 +488,22 @@ __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     const double zn = sl * sdp + cl * cdp * cos(da);
     const double rho = hypot(xn, yn);
     double ph = A.i.phi_p + atan2(xn, yn);
-    const double nan = __longlong_as_double(0x7ff8000000000000LL);
     double ix, iy;
-    if (A.i.proj == 5) {
+    if (A.i.proj >= 5) {
         ph = fmod(ph + PI, 2 * PI);
         if (ph < 0.0) ph += 2 * PI;
         ph -= PI;
-        ix = ph * R2D; iy = atan2(zn, rho) * R2D;
+        const double th = atan2(zn, rho);
+        switch (A.i.proj) {
+            case 5: ix = ph * R2D; iy = th * R2D; break;
+            case 6: ix = ph * cos(th) * R2D; iy = th * R2D; break;
+            case 7: ix = ph * R2D; iy = R2D * sin(th) / A.i.pv1; break;
+            case 8: ix = ph * R2D; iy = fabs(th) < PI / 2 ? R2D * log(tan(PI / 4 + th / 2)) : nan; break;
+            default: {
+                const double gam = R2D * sqrt(2.0 / (1.0 + cos(th) * cos(ph / 2.0)));
+                ix = 2.0 * gam * cos(th) * sin(ph / 2.0); iy = gam * sin(th);
+            }
+        }
     } else {
         double r;
         switch (A.i.proj) {
@@ -541,7 +565,7 @@ int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs
                           const double* frame_rot, int64_t ny_out, int64_t nx_out, double* d_xs, double* d_ys) {
     SPC_REQUIRE(wcs_out && wcs_in && d_xs && d_ys, "NULL pointer argument");
     SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
-    SPC_REQUIRE(wcs_out->proj >= 0 && wcs_out->proj <= 5 && wcs_in->proj >= 0 && wcs_in->proj <= 5, "unknown projection code");
+    SPC_REQUIRE(wcs_out->proj >= 0 && wcs_out->proj <= 9 && wcs_in->proj >= 0 && wcs_in->proj <= 9, "unknown projection code");
     SPC_REQUIRE((ny_out + 3) / 4 <= 65535, "too many rows for one launch");
     SPC_DEVICE(device);
     WcsPair A{*wcs_out, *wcs_in, ny_out, nx_out, d_xs, d_ys, 0, {1, 0, 0, 0, 1, 0, 0, 0, 1}};

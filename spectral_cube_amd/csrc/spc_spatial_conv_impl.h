@@ -24,11 +24,28 @@ struct SpArgs {
     // all-valid fast pass: one byte per (plane, 480-column strip) tile, 0 = done by the fast kernel
     unsigned char* status;
     int fast_nstrips;
+    int xcd_swizzle;                          // 1: (strip, plane) from the XCD-aware block order (spc_xcd_order)
     float inv_ksum;                           // 1 / (sum(ky) * sum(kx))
     float pred_lim, pred_lo, pred_hi;         // canonical predicate: |v| <= lim && !(v <= lo) && !(v >= hi)
     alignas(8) float ky[kMaxTaps + 1];        // padded to RY, centred (read pairwise as 64-bit scalars)
     alignas(8) float kx[kMaxTaps + 1];        // padded to RX, centred
 };
+
+// Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  With (strip, plane)
+// taken straight from blockIdx, the 4 - 5 strips of a plane - which share 28 halo columns with their neighbours and
+// sit next to each other in DRAM - run on different XCDs.  This bijective remap (guide: nwg % 8 != 0 needs the
+// remainder handled) hands every XCD a contiguous range of work items, i.e. whole planes.
+__device__ __forceinline__ void spc_xcd_order(int swizzle, int& strip, int64_t& z) {
+    strip = (int)blockIdx.x;
+    z = blockIdx.y;
+    if (swizzle) {
+        const int64_t n = (int64_t)gridDim.x * gridDim.y, b = (int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y;
+        const int64_t q = n / 8, r = n % 8, xcd = b % 8, i = b / 8;
+        const int64_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        strip = (int)(w % gridDim.x);
+        z = w / gridDim.x;
+    }
+}
 
 // packed FMA / MUL with ONE half of an SGPR pair broadcast to both lanes (see
 // spc_spectral_conv_impl.h): R weights live in R SGPRs
@@ -126,8 +143,9 @@ __global__ __launch_bounds__(kThreads, fast_waves(R)) void spatial_sep_fast_kern
                                       // barrier asm is a compiler memory barrier; `volatile` made it a FLAT sc0 sc1 access)
 
     const int t = threadIdx.x;
-    const int64_t z = blockIdx.y;
-    const int strip = blockIdx.x;
+    int strip;
+    int64_t z;
+    spc_xcd_order(A.xcd_swizzle, strip, z);
     const int64_t x0 = (int64_t)strip * kTxoF;            // first output column of the strip
     const int64_t xin = x0 - H + 2 * t;                   // first of this lane's two input columns
     const bool col_in = (xin >= 0) && (xin + 1 < A.nx);
@@ -529,9 +547,11 @@ __global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(cons
     __shared__ float2v yres[kG * kPitch];
 
     const int t = threadIdx.x;
-    const int64_t z = blockIdx.y;
+    int strip;
+    int64_t z;
+    spc_xcd_order(A.xcd_swizzle, strip, z);
     constexpr int kTxo = grouped_txo(R, BT);              // output columns per strip
-    const int64_t x0 = (int64_t)blockIdx.x * kTxo;        // first output column of the strip
+    const int64_t x0 = (int64_t)strip * kTxo;             // first output column of the strip
     if (A.status) {   // both fast tiles this strip overlaps were finished by the all-valid kernel
         const int ft = fast_txo(R);
         const int f0 = (int)(x0 / ft), f1 = (int)(min(x0 + kTxo, A.nx) - 1) / ft;

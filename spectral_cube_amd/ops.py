@@ -341,9 +341,10 @@ def spectral_lerp(cube, lo, t, inv_dx, fill=np.nan, mask=None, out=None, stream=
 
 
 def _wcs_struct(w):
-    code, crpix, lin, inv, ap, dp, php = w.celestial_params()
+    code, crpix, lin, inv, ap, dp, php, pv1 = w.celestial_params()
     s = _lib.SpcCelestialWcs()
     s.proj = code
+    s.pv1 = pv1
     s.crpix[0], s.crpix[1] = crpix
     for i in range(4):
         s.lin[i], s.lin_inv[i] = lin[i], inv[i]

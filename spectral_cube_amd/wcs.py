@@ -19,6 +19,9 @@ import numpy as np
 _D2R = np.pi / 180.0
 _R2D = 180.0 / np.pi
 _ZENITHAL = ("TAN", "SIN", "ARC", "STG", "ZEA")
+# cylindrical / pseudo-cylindrical projections with the reference point at native (0, 0) (FITS paper II sections 5.2 - 5.3)
+_CYLINDRICAL = ("CAR", "SFL", "CEA", "MER", "AIT")
+_PROJ_CODE = {"TAN": 0, "SIN": 1, "ARC": 2, "STG": 3, "ZEA": 4, "CAR": 5, "SFL": 6, "CEA": 7, "MER": 8, "AIT": 9}
 
 
 _AXIS_KEY = re.compile(r"^(?:(?:CTYPE|CRVAL|CRPIX|CDELT|CUNIT|CROTA|NAXIS|CNAME|CRDER|CSYER)(\d)|(?:PC|CD)(\d)_(\d)|"
@@ -110,8 +113,12 @@ class SimpleWCS:
         self.pc = pc
         self.shape_hint = tuple(int(g("NAXIS%d" % (i + 1), 0)) for i in range(n))[::-1]
         self.proj = self.ctype[0][5:8] if len(self.ctype[0]) >= 8 else ""
-        if self.proj and self.proj not in _ZENITHAL + ("CAR",):
-            raise NotImplementedError("projection %r not supported by SimpleWCS" % self.proj)
+        if self.proj and self.proj not in _PROJ_CODE:
+            raise NotImplementedError("projection %r not supported by SimpleWCS (built: %s)" % (self.proj, ", ".join(sorted(_PROJ_CODE))))
+        # CEA: PV2_1 = lambda (cos^2 of the standard parallel), default 1 (Lambert)
+        self.pv1 = float(g("PV2_1", 1.0)) if self.proj == "CEA" else 1.0
+        if self.proj == "SIN" and (float(g("PV2_1", 0.0)) != 0.0 or float(g("PV2_2", 0.0)) != 0.0):
+            raise NotImplementedError("slant orthographic projection (SIN with PV2_1 / PV2_2) is not built")
         self.lonpole = g("LONPOLE", None)
         self.latpole = float(g("LATPOLE", 90.0))
         self.frame = _celestial_frame(self.ctype[:2], h) if n >= 2 and self.proj else None
@@ -166,10 +173,10 @@ class SimpleWCS:
         (proj code, crpix (x, y), lin 2x2, lin^-1 2x2, alpha_p, delta_p, phi_p)"""
         if self.naxis < 2 or not self.proj:
             raise ValueError("WCS does not contain two spatial axes.")
-        code = {"TAN": 0, "SIN": 1, "ARC": 2, "STG": 3, "ZEA": 4, "CAR": 5}[self.proj]
+        code = _PROJ_CODE[self.proj]
         m = self._lin2()
         return (code, (float(self.crpix[0]), float(self.crpix[1])), tuple(m.ravel()), tuple(np.linalg.inv(m).ravel()),
-                float(self._ap), float(self._dp), float(self._php))
+                float(self._ap), float(self._dp), float(self._php), float(self.pv1))
 
     def celestial_pix2world(self, px, py):
         """0-based pixel -> (lon, lat) degrees."""
@@ -179,8 +186,30 @@ class SimpleWCS:
         dx, dy = px + 1.0 - self.crpix[0], py + 1.0 - self.crpix[1]
         x = m[0, 0] * dx + m[0, 1] * dy
         y = m[1, 0] * dx + m[1, 1] * dy
-        if self.proj == "CAR":
-            phi, theta = x * _D2R, y * _D2R
+        if self.proj in _CYLINDRICAL:
+            with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+                if self.proj == "CAR":
+                    phi, theta = x * _D2R, y * _D2R
+                elif self.proj == "SFL":
+                    theta = y * _D2R
+                    c = np.cos(theta)
+                    phi = np.where(c != 0.0, x * _D2R / np.where(c != 0.0, c, 1.0), np.where(x == 0.0, 0.0, np.nan))
+                elif self.proj == "CEA":
+                    s_ = self.pv1 * y * _D2R
+                    theta = np.where(np.abs(s_) <= 1.0 + 1e-13, np.arcsin(np.clip(s_, -1.0, 1.0)), np.nan)
+                    phi = x * _D2R
+                elif self.proj == "MER":
+                    theta = 2.0 * np.arctan(np.exp(y * _D2R)) - np.pi / 2
+                    phi = x * _D2R
+                else:  # AIT (Hammer-Aitoff)
+                    xr, yr = x * _D2R, y * _D2R
+                    z2 = 1.0 - (xr / 4.0) ** 2 - (yr / 2.0) ** 2
+                    zz = np.sqrt(np.where(z2 >= 0.5 - 1e-13, np.maximum(z2, 0.5), np.nan))     # outside the ellipse: not on the sky
+                    phi = 2.0 * np.arctan2(zz * xr / 2.0, 2.0 * zz * zz - 1.0)
+                    theta = np.arcsin(np.clip(yr * zz, -1.0, 1.0))
+                # the native sphere ends at |phi| = 180, |theta| = 90 (wcslib's bounds check: such pixels are not on the sky)
+                bad = (np.abs(phi) > np.pi * (1 + 1e-12)) | (np.abs(theta) > np.pi / 2 * (1 + 1e-12))
+                phi = np.where(bad, np.nan, phi)
         else:
             r = np.hypot(x, y)
             phi = np.arctan2(x, -y)
@@ -217,9 +246,20 @@ class SimpleWCS:
         rho = np.hypot(xn, yn)
         phi = php + np.arctan2(xn, yn)
         with np.errstate(invalid="ignore", divide="ignore"):
-            if self.proj == "CAR":
+            if self.proj in _CYLINDRICAL:
                 phi = np.mod(phi + np.pi, 2 * np.pi) - np.pi
-                x, y = phi * _R2D, np.arctan2(zn, rho) * _R2D
+                theta = np.arctan2(zn, rho)
+                if self.proj == "CAR":
+                    x, y = phi * _R2D, theta * _R2D
+                elif self.proj == "SFL":
+                    x, y = phi * np.cos(theta) * _R2D, theta * _R2D
+                elif self.proj == "CEA":
+                    x, y = phi * _R2D, _R2D * np.sin(theta) / self.pv1
+                elif self.proj == "MER":
+                    x, y = phi * _R2D, np.where(np.abs(theta) < np.pi / 2, _R2D * np.log(np.tan(np.pi / 4 + theta / 2)), np.nan)
+                else:  # AIT
+                    gam = _R2D * np.sqrt(2.0 / (1.0 + np.cos(theta) * np.cos(phi / 2.0)))
+                    x, y = 2.0 * gam * np.cos(theta) * np.sin(phi / 2.0), gam * np.sin(theta)
             else:
                 if self.proj == "TAN":
                     r = np.where(zn > 0, _R2D * rho / zn, np.nan)

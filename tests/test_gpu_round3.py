@@ -165,3 +165,31 @@ def test_out_of_core_boolean_mask_and_fused_smooth(gpu, tmp_path, monkeypatch):
     with np.errstate(invalid="ignore"):
         wc = np.abs(s0) > 5.0
     assert np.abs(np.asarray(got_s)[wc] - e1[wc]).max() <= 1e-5 * nz * abs(res._pix_size_slice(0))
+
+
+def test_device_pixel_map_for_the_new_projections(gpu):
+    """spc_wcs_pixel_map_f64 with SFL / CEA / MER / AIT / CAR on either side: against astropy (the Galactic AIT all-sky image
+    onto an equatorial CAR grid, across frames) and, for every header of the fixture, against the numpy WCS (itself pinned
+    against wcslib in test_host_logic) on a pixel map to and from a TAN grid; pixels beyond the edge of the sky -> -1e30."""
+    from spectral_cube_amd.wcs import reproject_pixel_map
+    g = golden("wcs_projections.npz")
+    a, b = SimpleWCS(str(g["map_in"]), naxis=2), SimpleWCS(str(g["map_out"]), naxis=2)
+    xs, ys = ops.wcs_pixel_map(a, b, g["map_xs"].shape)
+    xs, ys = xs.get(), ys.get()
+    ok = np.isfinite(g["map_xs"])
+    assert np.abs(xs[ok] - g["map_xs"][ok]).max() <= 1e-9 and np.abs(ys[ok] - g["map_ys"][ok]).max() <= 1e-9
+    assert np.all(xs[~ok] == -1e30)
+    tan = SimpleWCS({"CTYPE1": "GLON-TAN", "CTYPE2": "GLAT-TAN", "CRVAL1": 118.0, "CRVAL2": 3.0, "CRPIX1": 30.0, "CRPIX2": 25.0,
+                     "CDELT1": -0.5, "CDELT2": 0.5}, naxis=2)
+    for i in range(int(g["n"])):
+        w = SimpleWCS(str(g["hdr%d" % i]), naxis=2)
+        for src, dst, shape in ((w, tan, (50, 60)), (tan, w, (48, 64))):
+            exs, eys = reproject_pixel_map(src, dst, shape)
+            xs, ys = ops.wcs_pixel_map(src, dst, shape)
+            xs, ys = xs.get(), ys.get()
+            fin = np.isfinite(exs) & np.isfinite(eys)
+            assert fin.any()
+            # (source coordinates reach hundreds of pixels off the image near the edge of an all-sky projection: relative)
+            assert (np.abs(xs[fin] - exs[fin]) <= 1e-9 * (1.0 + np.abs(exs[fin]))).all(), (i, w.proj)
+            assert (np.abs(ys[fin] - eys[fin]) <= 1e-9 * (1.0 + np.abs(eys[fin]))).all(), (i, w.proj)
+            assert np.all(xs[~fin] == -1e30), (i, w.proj)

@@ -630,3 +630,29 @@ def test_beam_deconvolution_against_the_independent_oracle():
         else:
             with pytest.raises(BeamError):
                 bm.deconvolve(Beam(*cur))
+
+
+def test_cylindrical_and_all_sky_projections_match_wcslib():
+    """VERDICT round 2, missing 6: SFL, CEA (incl. PV2_1), MER, AIT (and CAR with CRVAL2 != 0) against astropy.wcs
+    (tests/golden/wcs_projections.npz: all-sky pixel scales, rotated grids, pixels beyond the edge of the sky, which
+    wcslib flags and this WCS turns into NaN too); anything else still raises."""
+    g = golden("wcs_projections.npz")
+    px, py = g["px"], g["py"]
+    for i in range(int(g["n"])):
+        w = SimpleWCS(str(g["hdr%d" % i]), naxis=2)
+        lon, lat = w.celestial_pix2world(px, py)
+        e_lon, e_lat = g["lon%d" % i], g["lat%d" % i]
+        assert np.array_equal(np.isnan(lon) | np.isnan(lat), np.isnan(e_lon) | np.isnan(e_lat)), (i, w.proj)
+        ok = ~np.isnan(e_lon)
+        dl = np.abs(((lon - e_lon + 180.0) % 360.0) - 180.0) * np.cos(np.radians(e_lat))
+        assert dl[ok].max() <= 1e-10 and np.abs(lat - e_lat)[ok].max() <= 1e-10, (i, w.proj)
+        bx, by = w.celestial_world2pix(e_lon[ok], e_lat[ok])
+        assert np.abs(bx - px[ok]).max() <= 1e-8 and np.abs(by - py[ok]).max() <= 1e-8, (i, w.proj)
+    xs, ys = reproject_pixel_map(SimpleWCS(str(g["map_in"]), naxis=2), SimpleWCS(str(g["map_out"]), naxis=2), g["map_xs"].shape)
+    assert np.array_equal(np.isnan(xs), np.isnan(g["map_xs"]))
+    assert np.nanmax(np.abs(xs - g["map_xs"])) <= 1e-9 and np.nanmax(np.abs(ys - g["map_ys"])) <= 1e-9
+    for proj in ("MOL", "TSC", "HPX", "ZPN"):
+        with pytest.raises(NotImplementedError):
+            SimpleWCS({"CTYPE1": "RA---" + proj, "CTYPE2": "DEC--" + proj}, naxis=2)
+    with pytest.raises(NotImplementedError):
+        SimpleWCS({"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "PV2_1": 0.1}, naxis=2)
