@@ -159,6 +159,17 @@ def test_out_of_core_boolean_mask_and_fused_smooth(gpu, tmp_path, monkeypatch):
     got_s = big.spectral_smooth(k).moment1()
     assert big._dev is None
     assert_close(np.asarray(got_s), np.asarray(exp_s), atol=1e-9 * nz * 500.0, what="streamed fused smooth -> moment1")
+    # spatial_smooth -> moment0 of an all-valid streamed cube: the algebraic path (convolution commutes with the sums along
+    # z) only ever needs the streamed moment maps
+    from spectral_cube_amd import Gaussian2DKernel
+    k2 = Gaussian2DKernel(1.5)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    exp_sp = SpectralCube.read(d, hdr).spatial_smooth(k2).moment0()
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 5))
+    plain = SpectralCube.read(d.copy(), hdr)
+    got_sp = plain.spatial_smooth(k2).moment0()
+    assert plain._dev is None
+    assert_close(np.asarray(got_sp), np.asarray(exp_sp), atol=1e-12 * np.nanmax(np.abs(np.asarray(exp_sp))), what="streamed spatial_smooth -> moment0")
     sm = O.spectral_smooth(d, inc, k.array)
     e1 = O.moment(sm, inc, 1, res.spectral_axis - res.spectral_axis[0], res._pix_size_slice(0), world0=res.spectral_axis[0])
     s0 = O.moment(sm, inc, 0, res.spectral_axis - res.spectral_axis[0], 1.0)
