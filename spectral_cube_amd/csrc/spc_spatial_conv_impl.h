@@ -535,9 +535,13 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
 // runs = 480 tasks for 512 lanes instead of 224 for 256).
 constexpr int grouped_txo(int R, int BT) { return ((BT - 2 * (R / 2)) / kRun) * kRun; }
 constexpr int grouped_pitch(int BT) { return BT == 256 ? 316 : 604; }     // float2 per LDS row, = 28 (mod 32): see spatial_sep_kernel
-template <int R, bool ARR, bool PRED, bool ISO, int BT, int ABL = 0>
+// SYM (with ISO): the taps are symmetric (every Gaussian) and addressed folded, k[min(j, 2H - j)]: 15 distinct weights
+// = 8 SGPR pairs instead of 15 - unfolded the kernel spilled 57 SGPRs (104 v_readlane + 57 v_writelane per revolution).
+template <int R, bool ARR, bool PRED, bool ISO, int BT, bool SYM, int ABL = 0>
 __global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(const SpArgs A) {
     constexpr int H = R / 2;
+    static_assert(!SYM || ISO, "folded weights are for kx == ky");
+    auto wj = [](int j) { return SYM ? (j <= H ? j : 2 * H - j) : j; };
     constexpr int kG = 8;                                 // rows per group
     constexpr int NG = (R + kG - 1) / kG;
     constexpr int kPitch = grouped_pitch(BT);
@@ -617,8 +621,8 @@ __global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(cons
                 for (int m = 0; m < R; ++m) {
                     const int a = (s - m + R) % R;
                     if (ABL & 8) { if (a == 0) acc[m] = x2; }
-                    else if (a == 0) pk_mul_w(acc[m], A.ky, 2 * H - a, x2);
-                    else pk_fma_w(acc[m], A.ky, 2 * H - a, x2);
+                    else if (a == 0) pk_mul_w(acc[m], A.ky, wj(2 * H - a), x2);
+                    else pk_fma_w(acc[m], A.ky, wj(2 * H - a), x2);
                 }
                 // row o = i0 + s - H is complete: park it in the group's LDS slot
                 yres[(s - s0) * kPitch + lds_phys(t)] = acc[(s + 1) % R];
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(cons
                     for (int k = 0; k < kRun; ++k) {
                         const int widx = k + 2 * H - i;       // kx index for output k, input i
                         if (ABL & 16) { if (widx == H) r[k] = in; }
-                        else if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, widx, in);
+                        else if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISO ? A.ky : A.kx, wj(widx), in);
                     }
                 }
                 const int64_t xo = x0 + kRun * j;
@@ -732,15 +736,15 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
         const int abl = ab ? atoi(ab) : 0;
         if (abl && iso && !pred && arr) {
             switch (abl) {
-                case 1: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 1>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 2: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 2>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 3: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 3>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 6: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 6>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 7: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 7>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 8: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 8>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 16: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 16>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 24: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 24>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
-                case 31: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 512, 31>), dim3((unsigned)((A.nx + grouped_txo(R, 512) - 1) / grouped_txo(R, 512)), grid.y, grid.z), dim3(512), 0, st, A); break;
+                case 1: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 1>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 2: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 2>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 3: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 3>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 6: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 6>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 7: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 7>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 8: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 8>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 16: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 16>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 24: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 24>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
+                case 31: hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, true, false, true, 256, true, 31>), dim3((unsigned)((A.nx + grouped_txo(R, 256) - 1) / grouped_txo(R, 256)), grid.y, grid.z), dim3(256), 0, st, A); break;
                 default: spc_set_error("no such ablation"); return SPC_ERR_UNSUPPORTED;
             }
             SPC_LAUNCH_CHECK();
@@ -761,12 +765,14 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
             const int bt = (want == 256 || A.nx < 384) ? 256 : 512;
             const int txo = bt == 256 ? grouped_txo(R, 256) : grouped_txo(R, 512);
             dim3 ggrid((unsigned)((A.nx + txo - 1) / txo), grid.y, grid.z), gblock(bt);
-#define SPC_GROUPED(ARRV, PREDV, ISOV)                                                                                              \
-            do { if (bt == 256) hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, ARRV, PREDV, ISOV, 256>), ggrid, gblock, 0, st, A);  \
-                 else hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, ARRV, PREDV, ISOV, 512>), ggrid, gblock, 0, st, A); } while (0)
-            if (iso && !pred) { if (arr) SPC_GROUPED(true, false, true); else SPC_GROUPED(false, false, true); }
-            else if (iso) { if (arr) SPC_GROUPED(true, true, true); else SPC_GROUPED(false, true, true); }
-            else { if (arr) SPC_GROUPED(true, true, false); else SPC_GROUPED(false, true, false); }
+#define SPC_GROUPED(ARRV, PREDV, ISOV, SYMV)                                                                                              \
+            do { if (bt == 256) hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, ARRV, PREDV, ISOV, 256, SYMV>), ggrid, gblock, 0, st, A);  \
+                 else hipLaunchKernelGGL((spatial_sep_grouped_kernel<R, ARRV, PREDV, ISOV, 512, SYMV>), ggrid, gblock, 0, st, A); } while (0)
+            const bool symk = iso && is_sym(A.ky, R);
+            if (symk && !pred) { if (arr) SPC_GROUPED(true, false, true, true); else SPC_GROUPED(false, false, true, true); }
+            else if (symk) { if (arr) SPC_GROUPED(true, true, true, true); else SPC_GROUPED(false, true, true, true); }
+            else if (iso) { if (arr) SPC_GROUPED(true, true, true, false); else SPC_GROUPED(false, true, true, false); }
+            else { if (arr) SPC_GROUPED(true, true, false, false); else SPC_GROUPED(false, true, false, false); }
 #undef SPC_GROUPED
             SPC_LAUNCH_CHECK();
             return SPC_OK;
