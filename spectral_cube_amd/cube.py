@@ -281,10 +281,52 @@ class SpectralCube:
         ``_get_filled_data(fill=self._fill_value)``) what goes to disk is the FILLED data: excluded
         voxels carry the fill value (NaN by default).  ``filled=False`` writes the raw voxels."""
         from . import io_fits
+        plan = self._strip_plan(filled)
+        if plan is not None:             # out of core: strips in, operator, strips out (streaming.map_strips)
+            from . import streaming
+            src, fn, nz_out = plan
+            sink = streaming.FitsSink(os.fspath(filename), self._header, (nz_out,) + tuple(self._shape[1:]), overwrite=overwrite)
+            streaming.map_strips(src, fn, nz_out, sink)
+            return
         dev = self._device_data()
         if filled and self._mask is not None:
             dev = ops.fill_masked(dev, self._mask_spec(), self._fill_value)
         io_fits.save_cube(os.fspath(filename), dev, header=self._header, overwrite=overwrite)
+
+    def _strip_plan(self, filled=True):
+        """(streamed source cube, fn(strip, mask spec, stream) -> result strip, result channels) when this cube is - or
+        is a pending per-spaxel operator (spectral_smooth, spectral_interpolate, sigma_clip_spectrally) on - a cube that
+        does not fit the HBM budget; None otherwise."""
+        fill = self._fill_value
+        if self._stream_source() is not None:
+            if filled and self._mask is not None:
+                return self, (lambda dev, mspec, stream: ops.fill_masked(dev, mspec, fill, stream)), self._shape[0]
+            # (the strip buffer itself is recycled by the pipeline: hand out a copy)
+            return self, (lambda dev, mspec, stream: ops.fill_masked(dev, None, fill, stream)), self._shape[0]
+        lz = self._lazy
+        parent = getattr(lz, "parent", None)
+        if self._dev is not None or lz is None or parent is None or getattr(lz, "strip_fn", None) is None:
+            return None
+        if parent._stream_source() is None:
+            return None
+        keeps_parent_mask = self._mask is parent._mask
+        if filled and self._mask is not None and keeps_parent_mask:
+            fn = lambda dev, mspec, stream: ops.fill_masked(lz.strip_fn(dev, mspec, stream), mspec, fill, stream)  # noqa: E731
+        else:
+            fn = lz.strip_fn             # (spectral_interpolate: the new mask is ~isnan(result), the data are their own fill)
+        return parent, fn, self._shape[0]
+
+    def stream_into(self, out):
+        """Out-of-core counterpart of ``filled_data``: fill the float32 (nz, ny, nx) host array / memory map *out* with
+        the filled data of this cube, strip by strip (the cube, or the pending per-spaxel operator on a cube, larger than
+        the HBM budget).  Returns *out*."""
+        from . import streaming
+        plan = self._strip_plan(True)
+        if plan is None:
+            raise ValueError("this cube fits the device: use filled_data")
+        src, fn, nz_out = plan
+        streaming.map_strips(src, fn, nz_out, streaming.NdarraySink(out))
+        return out
 
     @classmethod
     def from_device(cls, dev, wcs=None, header=None, mask=None, **kw):
@@ -829,6 +871,13 @@ class SpectralCube:
         extra = set(kwargs) - allowed
         if extra:
             raise NotImplementedError("sigma_clip options not built on the device path: %s" % sorted(extra))
+        if self._stream_source() is not None:
+            # out of core: a pending operator; write() / stream_into() run it strip by strip
+            parent, sig = self, float(threshold)
+            thunk = _Thunk(lambda: ops.sigma_clip_axis0(parent._device_data(), sigma=sig, mask=parent._mask_spec(), **kwargs))
+            thunk.parent = parent
+            thunk.strip_fn = lambda dev, mspec, stream: ops.sigma_clip_axis0(dev, sigma=sig, mask=mspec, stream=stream, **kwargs)
+            return self._new_cube_with(lazy=thunk, shape=self._shape)
         dev = ops.sigma_clip_axis0(self._device_data(), sigma=float(threshold), mask=self._mask_spec(), **kwargs)
         return self._new_cube_with(dev=dev)
 
@@ -864,6 +913,9 @@ class SpectralCube:
 
             def __call__(self):
                 return ops.spectral_conv(parent._device_data(), karr, mask=parent._mask_spec())
+
+            def strip_fn(self, dev, mspec, stream):          # one row strip of an out-of-core parent
+                return ops.spectral_conv(dev, karr, mask=mspec, stream=stream)
 
         return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
 
@@ -971,7 +1023,10 @@ class SpectralCube:
         crval = g_sorted[0] if not rout else g_sorted[-1]
         cdelt = outdiff if not rout else -outdiff
         newwcs = self._wcs.with_spectral(crval, cdelt, 1.0)
-        out = self._new_cube_with(lazy=_Thunk(run), shape=(len(grid),) + self._shape[1:], wcs=newwcs,
+        thunk = _Thunk(run)
+        thunk.parent = parent
+        thunk.strip_fn = lambda dev, mspec, stream: ops.spectral_lerp(dev, plan[0], plan[1], plan[2], fill, mask=mspec, stream=stream)
+        out = self._new_cube_with(lazy=thunk, shape=(len(grid),) + self._shape[1:], wcs=newwcs,
                                   mask=False)
         out._mask = M.NotNaNMask(out)
         return out

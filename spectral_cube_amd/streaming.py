@@ -394,3 +394,180 @@ def statistics(cube, rows=None):
     for y0, y1, dev, mspec in Strips(cube, compute, rows):
         parts.append(ops.stats_global(dev, mask=mspec, stream=compute))      # (waits for its own records)
     return combine_statistics(parts)
+
+
+# ---- cube -> cube operators of a streamed cube: result strips back to the host ---------------------------------
+class NdarraySink:
+    """(nz, ny, nx) float32 host array / memory map receiving row strips"""
+
+    swap = False
+
+    def __init__(self, array):
+        if array.dtype != np.float32 or array.ndim != 3:
+            raise TypeError("the result array must be float32 (nz, ny, nx)")
+        self.array = array
+        self.shape = tuple(array.shape)
+
+    def write(self, view_u8, z0, z1, y0, y1):
+        nx = self.shape[2]
+        n = (z1 - z0) * (y1 - y0) * nx
+        np.copyto(self.array[z0:z1, y0:y1], np.frombuffer(view_u8, dtype=np.float32, count=n).reshape(z1 - z0, y1 - y0, nx))
+
+    def close(self):
+        if hasattr(self.array, "flush"):
+            self.array.flush()
+
+
+class FitsSink:
+    """BITPIX = -32 FITS file of a given shape, written strip by strip: the header and the (sparse) payload are laid down
+    first, every chunk arrives byte-swapped by the device and goes out with one os.pwrite per plane segment (the strip's
+    rows of a plane are contiguous in the file)"""
+
+    swap = True
+
+    def __init__(self, path, header, shape, overwrite=False):
+        from . import io_fits
+        if os.path.exists(path) and not overwrite:
+            raise OSError("File %r already exists (use overwrite=True)" % path)
+        self.shape = tuple(int(s) for s in shape)
+        nz, ny, nx = self.shape
+        hdr = io_fits.parse_header(header) if header is not None else {}
+        cards = [io_fits._card("SIMPLE", True), io_fits._card("BITPIX", -32), io_fits._card("NAXIS", 3), io_fits._card("NAXIS1", nx),
+                 io_fits._card("NAXIS2", ny), io_fits._card("NAXIS3", nz)]
+        for k, v in hdr.items():
+            if k in ("SIMPLE", "BITPIX", "BSCALE", "BZERO", "BLANK", "EXTEND", "WCSAXES") or k.startswith("NAXIS"):
+                continue
+            cards.append(io_fits._card(k, v))
+        cards.append("END".ljust(80))
+        text = "".join(cards)
+        text += " " * ((-len(text)) % io_fits.BLOCK)
+        self.base = len(text)
+        total = nz * ny * nx * 4
+        self.fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.pwrite(self.fd, text.encode("ascii"), 0)
+        os.ftruncate(self.fd, self.base + total + (-total) % io_fits.BLOCK)      # zero padding included
+
+    def write(self, view_u8, z0, z1, y0, y1):
+        nz, ny, nx = self.shape
+        seg = (y1 - y0) * nx * 4
+        mv = memoryview(view_u8)
+        for k, z in enumerate(range(z0, z1)):
+            part, done, off = mv[k * seg:(k + 1) * seg], 0, self.base + (z * ny + y0) * nx * 4
+            while done < seg:
+                done += os.pwrite(self.fd, part[done:], off + done)
+
+    def close(self):
+        if self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
+
+
+class StripWriter:
+    """result strips (nz, rows, nx) float32 from the device into a sink: chunks of planes come down through pinned
+    buffers on their own stream (after the event the producer recorded), writer threads hand them to the sink while the
+    next strip is being staged and computed"""
+
+    def __init__(self, sink, device, nbuffers=8, chunk_bytes=32 << 20, writers=4):
+        from concurrent.futures import ThreadPoolExecutor
+        from .device import Event
+        self.sink, self.device, self.Event = sink, device, Event
+        self.chunk_bytes, self.nbuf = int(chunk_bytes), int(nbuffers)
+        self.cap = None
+        self.pinned, self.busy = [], []
+        self.d_swap = []
+        self.down = Stream(device)
+        self.pool = ThreadPoolExecutor(max_workers=writers)
+        self.i = 0
+        self.keep = []                   # (event, strip) pairs: a strip stays alive until its last chunk has left the device
+        self.bytes = 0
+
+    def put(self, y0, y1, strip, produced_on):
+        """queue the strip (rows [y0, y1) of the result); `produced_on`: the stream its kernel ran on"""
+        nz, rows, nx = strip.shape
+        seg = rows * nx * 4
+        ppc = max(1, min(nz, self.chunk_bytes // seg))
+        if self.cap is None or ppc * seg > self.cap:
+            if self.pinned:
+                self._drain()
+                _give_pinned(self.cap, self.pinned)
+            self.cap = -(-(ppc * seg) // (1 << 20)) << 20
+            self.pinned = _take_pinned(self.cap, self.nbuf)
+            self.busy = [None] * self.nbuf
+            self.d_swap = [DeviceArray((self.cap,), np.uint8, self.device) for _ in range(self.nbuf)] if self.sink.swap else []
+        ev = self.Event(self.device)
+        ev.record(produced_on)
+        self.down.wait_event(ev)
+        last = None
+        for z0 in range(0, nz, ppc):
+            z1 = min(nz, z0 + ppc)
+            k = self.i % self.nbuf
+            self.i += 1
+            if self.busy[k] is not None:
+                self.busy[k].result()            # the writer that last used this buffer (re-raises its error)
+            b, n = self.pinned[k], (z1 - z0) * seg
+            src = strip.ptr + z0 * seg
+            if self.sink.swap:                    # BITPIX -32 byte swap on the device (its own inverse)
+                _lib.call("spc_fits_to_f32", self.device, self.down.handle, C.c_void_p(src), -32, 1.0, 0.0, 0, 0, n // 4,
+                          C.c_void_p(self.d_swap[k].ptr))
+                src = self.d_swap[k].ptr
+            _lib.call("spc_memcpy_d2h", self.device, C.c_void_p(b.ptr), C.c_void_p(src), C.c_size_t(n), self.down.handle)
+            done = self.Event(self.device)
+            done.record(self.down)
+            last = done
+            self.busy[k] = self.pool.submit(self._write, done, b, z0, z1, y0, y1)
+            self.bytes += n
+        self.keep.append((last, strip))
+        while len(self.keep) > 2:                 # at most two result strips wait on the device
+            evk, _ = self.keep.pop(0)
+            evk.synchronize()
+
+    def _write(self, done, b, z0, z1, y0, y1):
+        done.synchronize()
+        self.sink.write(b.view, z0, z1, y0, y1)
+
+    def _drain(self):
+        for f in self.busy:
+            if f is not None:
+                f.result()
+        self.busy = [None] * len(self.busy)
+
+    def close(self):
+        try:
+            self._drain()
+            self.down.synchronize()
+        finally:
+            self.pool.shutdown(wait=True)
+            if self.pinned:
+                _give_pinned(self.cap, self.pinned)
+                self.pinned = []
+            self.keep = []
+            self.sink.close()
+
+
+def map_strips(cube, fn, nz_out, sink, rows=None, stats=None):
+    """out[:, y0:y1] = fn(strip, mask spec, stream) for every row strip of a streamed cube; fn returns a float32
+    (nz_out, rows, nx) DeviceArray produced on `stream`.  The operators this serves work per spaxel (spectral_smooth,
+    spectral_interpolate, sigma_clip_spectrally, the plain filled copy): no halo."""
+    nz, ny, nx = cube._shape
+    if tuple(sink.shape) != (nz_out, ny, nx):
+        raise ValueError("the sink has shape %s, the result %s" % (tuple(sink.shape), (nz_out, ny, nx)))
+    compute = Stream(cube.device)
+    if rows is None:
+        src = cube._stream_source()
+        terms = _mask_terms(cube)
+        # two input strips + two result strips (+ the operator's own scratch) within half the budget
+        per_row = nx * (nz * (4 + (1 if terms is not None and terms[3] is not None else 0)) + 2 * nz_out * 4)
+        rows = max(8, int((hbm_budget(cube.device) // 2) // (2 * per_row)) // 8 * 8)
+        rows = min(src.shape[1], rows)
+    st = Strips(cube, compute, rows)
+    w = StripWriter(sink, cube.device)
+    n = 0
+    try:
+        for y0, y1, dev, mspec in st:
+            res = fn(dev, mspec, compute)
+            w.put(y0, y1, res, compute)
+            n += 1
+    finally:
+        w.close()
+    if stats is not None:
+        stats.update(bytes_in=st.bytes, bytes_out=w.bytes, strips=n, rows=st.rows)

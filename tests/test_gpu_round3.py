@@ -204,3 +204,58 @@ def test_device_pixel_map_for_the_new_projections(gpu):
             assert (np.abs(xs[fin] - exs[fin]) <= 1e-9 * (1.0 + np.abs(exs[fin]))).all(), (i, w.proj)
             assert (np.abs(ys[fin] - eys[fin]) <= 1e-9 * (1.0 + np.abs(eys[fin]))).all(), (i, w.proj)
             assert np.all(xs[~fin] == -1e30), (i, w.proj)
+
+
+def test_out_of_core_cube_to_cube_operators(gpu, tmp_path, monkeypatch):
+    """read -> per-spaxel operator -> write without the cube (or its result) ever fitting the HBM budget: the filled copy,
+    spectral_smooth, spectral_interpolate and sigma_clip_spectrally of a streamed cube, written strip by strip to a FITS file
+    (device byte swap, one pwrite per plane segment) or into a host array, equal the resident results bit for bit."""
+    from spectral_cube_amd import Gaussian1DKernel, io_fits, streaming, synth
+    nz, ny, nx = 64, 136, 40
+    d = synth.gaussian_line_cube((nz, ny, nx), 33)
+    d[:, 3:6, 2:5] = np.nan
+    inc = synth.boolean_mask(d, 33).astype(bool)
+    hdr = _c1_header()
+    path = _write_cube(tmp_path, d, hdr)
+    k = Gaussian1DKernel(2.0)
+    grid_axis = None
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    res = SpectralCube.read(path)
+    grid = np.linspace(res.spectral_axis[1], res.spectral_axis[-2], 2 * nz + 3)
+    exp_fill = np.asarray(res.with_mask(inc).filled_data)
+    exp_sm = res.with_mask(inc).spectral_smooth(k)
+    exp_sm = ops.fill_masked(exp_sm._device_data(), res.with_mask(inc)._mask_spec(), np.nan).get()
+    exp_it = np.asarray(res.spectral_interpolate(grid, suppress_smooth_warning=True).filled_data)
+    exp_cl = res.sigma_clip_spectrally(2.5)
+    exp_cl = ops.fill_masked(exp_cl._device_data(), res._mask_spec(), np.nan).get()
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 6))
+    big = SpectralCube.read(path)
+    assert big._stream_source() is not None
+    # (a) the filled copy of a masked streamed cube into a host array
+    out = np.empty((nz, ny, nx), np.float32)
+    assert big.with_mask(inc).stream_into(out) is out
+    assert np.array_equal(out, exp_fill, equal_nan=True)
+    # (b) spectral_smooth -> FITS
+    p_sm = str(tmp_path / "sm.fits")
+    big.with_mask(inc).spectral_smooth(k).write(p_sm)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    back = SpectralCube.read(p_sm)
+    assert back.shape == (nz, ny, nx) and np.array_equal(np.asarray(back.unmasked_data), exp_sm, equal_nan=True)
+    np.testing.assert_allclose(back.spectral_axis, res.spectral_axis)
+    with pytest.raises(OSError):
+        big.write(p_sm)                                   # exists, no overwrite
+    # (c) spectral_interpolate (more channels out than in) -> FITS, (d) sigma clip -> host array
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 6))
+    p_it = str(tmp_path / "it.fits")
+    up = big.spectral_interpolate(grid, suppress_smooth_warning=True)
+    up.write(p_it)
+    out_cl = big.sigma_clip_spectrally(2.5).stream_into(np.empty((nz, ny, nx), np.float32))
+    assert big._dev is None and up._dev is None
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    back = SpectralCube.read(p_it)
+    assert back.shape == (len(grid), ny, nx) and np.array_equal(np.asarray(back.unmasked_data), exp_it, equal_nan=True)
+    np.testing.assert_allclose(back.spectral_axis, grid, rtol=1e-12, atol=1e-9)
+    assert np.array_equal(out_cl, exp_cl, equal_nan=True)
+    # and the astropy-independent reader agrees that the file is a valid FITS image
+    img = io_fits.find_image(p_it)
+    assert io_fits.cube_shape(img) == (len(grid), ny, nx) and os.path.getsize(p_it) % 2880 == 0
