@@ -332,14 +332,14 @@ __device__ __forceinline__ void count_keys(const uint32_t (&key)[KPL], uint32_t 
 // accesses go through ONE buffer descriptor per group of 8 keys (rebased by scalar arithmetic); a lane's offset (its
 // column and its first plane) is one 32-bit register, key u of the group adds u * L planes to it (one v_add_u32 with a
 // scalar operand), and samples beyond the last plane fall outside the descriptor's range (the hardware returns 0, no
-// fault).  The launcher picks DESC when 8 steps of L planes fit an unsigned 32-bit byte offset (sel_desc_fits); larger
+// fault).  The launcher picks DESC when 9 steps of L planes stay below 2 GiB of byte offset (sel_desc_fits); larger
 // planes keep the 64-bit form.
 // cen: select on |x - cen| when use_cen (mad_std); lim / lo / hi: spc_canonical_pred of the mask's predicate terms.
 static inline bool spc_env_on(const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : true; }
 static inline bool spc_env_set(const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : false; }
 static inline bool sel_desc_fits(int ts, int64_t plane_stride, int64_t x_stride) {
     const int64_t L = 256 / ts;
-    return (9 * L * plane_stride + ts * x_stride) * 4 < (1ll << 32);
+    return (9 * L * plane_stride + ts * x_stride) * 4 < (1ll << 31);
 }
 
 template <int TS, int KPL, bool ARR, bool DESC>

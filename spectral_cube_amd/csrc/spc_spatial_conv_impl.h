@@ -753,14 +753,15 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
     }
 #endif
     if constexpr (R == 29) {
-        // grouped pipeline; planes beyond the 4 GiB a buffer descriptor spans keep the round-2 kernel
+        // grouped pipeline; planes of 2 GiB and more keep the round-2 kernel
         const char* gk = getenv("SPC_SPATIAL_GROUPED");
         // 0: round-2 kernel, 256 / 512: threads per block.  Measured at 512 x 2048^2 with a uint8 mask (same box): round-2
         // kernel 9.01 ms, 256 threads 8.29 ms, 512 threads 8.76 ms (less halo and fewer idle x-pass lanes, but barriers
         // over 8 waves and two blocks per CU)
         const int want = gk ? atoi(gk) : 256;
-        const bool fits = (uint64_t)A.plane_stride * 4 < (1ull << 32) && (uint64_t)A.out_plane_stride * 4 < (1ull << 32) &&
-                          (!arr || (uint64_t)A.mask.plane_stride < (1ull << 32));
+        // (byte offsets inside a plane stay below 2 GiB, like the spectral kernels: larger planes keep 64-bit addressing)
+        const bool fits = (uint64_t)A.plane_stride * 4 < (1ull << 31) && (uint64_t)A.out_plane_stride * 4 < (1ull << 31) &&
+                          (!arr || (uint64_t)A.mask.plane_stride < (1ull << 31));
         if (want && fits) {
             const int bt = (want == 256 || A.nx < 384) ? 256 : 512;
             const int txo = bt == 256 ? grouped_txo(R, 256) : grouped_txo(R, 512);

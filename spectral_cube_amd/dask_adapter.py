@@ -43,6 +43,18 @@ class _ThreadStage:
         self.device = device
         self.stream = Stream(device)
         self.ptr, self.cap = 0, 0
+        self.dev = {}               # tag -> DeviceArray reused from chunk to chunk
+
+    def buffer(self, tag, shape, dtype):
+        """the thread's device buffer for *tag*: chunks of one graph have (nearly) all the same shape, and giving a block
+        back to the library's pool drains the DEVICE (spc_free: nothing queued may still use it) - with 8 worker threads
+        freeing an input and an output per chunk the workers end up waiting for each other's kernels"""
+        shape = tuple(int(s) for s in shape)
+        a = self.dev.get(tag)
+        if a is None or a.shape != shape or a.dtype != np.dtype(dtype):
+            self.stream.synchronize()
+            a = self.dev[tag] = DeviceArray(shape, dtype, self.device)
+        return a
 
     def pinned(self, nbytes):
         if nbytes > self.cap:
@@ -83,7 +95,7 @@ def _stage(chunk, device):
     ptr = st.pinned(n * 4)
     view = np.frombuffer((C.c_byte * (n * 4)).from_address(ptr), dtype=np.float32, count=n).reshape(chunk.shape)
     np.copyto(view, chunk, casting="unsafe")
-    dev = DeviceArray(chunk.shape, np.float32, device)
+    dev = st.buffer("in", chunk.shape, np.float32)
     _lib.call("spc_memcpy_h2d", device, C.c_void_p(dev.ptr), C.c_void_p(ptr), C.c_size_t(n * 4), st.stream.handle)
     return dev, st
 
@@ -116,7 +128,7 @@ class SpectralSmoothChunk:
         if chunk.size == 0:
             return chunk
         dev, st = _stage(chunk, self.device)
-        return _fetch(ops.spectral_conv(dev, self.kernel, stream=st.stream), st, chunk.dtype)
+        return _fetch(ops.spectral_conv(dev, self.kernel, stream=st.stream, out=st.buffer("out", chunk.shape, np.float32)), st, chunk.dtype)
 
 
 class SpatialSmoothChunk:
@@ -130,7 +142,7 @@ class SpatialSmoothChunk:
         if chunk.size == 0:
             return chunk
         dev, st = _stage(chunk, self.device)
-        return _fetch(ops.spatial_conv(dev, self.kernel, stream=st.stream), st, chunk.dtype)
+        return _fetch(ops.spatial_conv(dev, self.kernel, stream=st.stream, out=st.buffer("out", chunk.shape, np.float32)), st, chunk.dtype)
 
 
 class SigmaClipChunk:
@@ -173,9 +185,12 @@ class MomentChunk:
         cref = self.pix_cen[nz // 2]
         key = ("m0", "m1", "m2")[self.order]
         dev, st = _stage(chunk, self.device)
-        r = ops.moments(dev, DeviceArray.from_numpy(self.pix_cen - cref, self.device, st.stream),
-                        dv=self.pix_size, m1_add=cref + self.world0, want=(key,), stream=st.stream)
-        return _fetch(r[key], st)
+        cen = st.buffer("cen", (nz,), np.float64)
+        cen.upload(self.pix_cen - cref, st.stream)
+        out = {key: st.buffer("map", chunk.shape[1:], np.float64)}
+        ws = st.buffer("ws", (max(1, int(_lib.load().spc_moments_workspace_bytes(*chunk.shape))),), np.uint8)
+        ops.moments(dev, cen, dv=self.pix_size, m1_add=cref + self.world0, want=(key,), stream=st.stream, out=out, workspace=ws)
+        return _fetch(out[key], st)
 
 
 class Moments012Chunk:
@@ -196,11 +211,14 @@ class Moments012Chunk:
         nz, cy, cx = chunk.shape
         cref = self.pix_cen[nz // 2]
         dev, st = _stage(chunk, self.device)
-        block = DeviceArray((3, cy, cx), np.float64, self.device)
+        block = st.buffer("maps", (3, cy, cx), np.float64)
         out = {k: DeviceArray((cy, cx), np.float64, self.device, ptr=block.ptr + i * cy * cx * 8, owner=block)
                for i, k in enumerate(("m0", "m1", "m2"))}
-        ops.moments(dev, DeviceArray.from_numpy(self.pix_cen - cref, self.device, st.stream), dv=self.pix_size,
-                    m1_add=cref + self.world0, want=("m0", "m1", "m2"), stream=st.stream, out=out)
+        cen = st.buffer("cen", (nz,), np.float64)
+        cen.upload(self.pix_cen - cref, st.stream)
+        ws = st.buffer("ws", (max(1, int(_lib.load().spc_moments_workspace_bytes(nz, cy, cx))),), np.uint8)
+        ops.moments(dev, cen, dv=self.pix_size, m1_add=cref + self.world0, want=("m0", "m1", "m2"), stream=st.stream, out=out,
+                    workspace=ws)
         return _fetch(block, st)
 
 
@@ -218,4 +236,5 @@ class SpectralInterpolateChunk:
             return chunk
         lo, t, inv, _, _, fill = self.plan
         dev, st = _stage(chunk, self.device)
-        return _fetch(ops.spectral_lerp(dev, lo, t, inv, fill, stream=st.stream), st)
+        out = st.buffer("out", (len(lo),) + tuple(chunk.shape[1:]), np.float32)
+        return _fetch(ops.spectral_lerp(dev, lo, t, inv, fill, stream=st.stream, out=out), st)

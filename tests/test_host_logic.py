@@ -656,3 +656,66 @@ def test_cylindrical_and_all_sky_projections_match_wcslib():
             SimpleWCS({"CTYPE1": "RA---" + proj, "CTYPE2": "DEC--" + proj}, naxis=2)
     with pytest.raises(NotImplementedError):
         SimpleWCS({"CTYPE1": "RA---SIN", "CTYPE2": "DEC--SIN", "PV2_1": 0.1}, naxis=2)
+
+
+# ---- round 3: out-of-core plumbing that needs no GPU -----------------------------------------------------------
+def test_streaming_budget_and_strip_plan(monkeypatch):
+    from spectral_cube_amd import streaming
+    assert streaming.parse_bytes("64M") == 64 << 20 and streaming.parse_bytes("2GiB") == 2 << 30 and streaming.parse_bytes("1500") == 1500
+    assert streaming.parse_bytes("1.5k") == 1536
+    monkeypatch.setenv("SPC_HBM_BUDGET", "8G")
+    assert streaming.hbm_budget(0) == 8 << 30
+    # two strips in flight within half the budget, multiples of 8 rows, never more than the cube has
+    rows = streaming.plan_rows((4096, 2048, 2048), 8 << 30)
+    assert rows % 8 == 0 and 2 * rows * 4096 * 2048 * 4 <= (8 << 30) // 2 and rows == 64
+    assert streaming.plan_rows((4096, 2048, 2048), 8 << 30, mask_array=True) < rows or rows == 8
+    assert streaming.plan_rows((16, 20, 32), 1 << 40) == 20
+    assert streaming.plan_rows((4096, 2048, 2048), 1 << 20) == 8      # the floor
+
+
+def test_streaming_sources_and_sinks_move_the_right_bytes(tmp_path):
+    """NdarraySource / FitsSource.read_into (what the reader threads run) and FitsSink / NdarraySink.write (what the writer
+    threads run) against numpy slicing and this package's own FITS reader: pure host code, plain memory as the 'pinned' buffer."""
+    import ctypes
+    from spectral_cube_amd import io_fits, streaming
+    rng = np.random.default_rng(9)
+    nz, ny, nx = 7, 12, 10
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    buf = (ctypes.c_uint8 * (nz * ny * nx * 8))()
+    # float32, float64 (converted while staged), bool mask (as uint8), a non-contiguous view
+    for arr, out_dtype in ((d, np.float32), (d.astype(np.float64), np.float32), (d > 0, np.uint8), (d[:, ::-1], np.float32)):
+        src = streaming.NdarraySource(arr, out_dtype)
+        n = src.read_into(buf, 2, 6, 3, 11)
+        got = np.frombuffer(buf, dtype=out_dtype, count=4 * 8 * nx).reshape(4, 8, nx)
+        assert n == got.nbytes and np.array_equal(got, np.asarray(arr[2:6, 3:11]).astype(out_dtype))
+    # FITS: BITPIX -32 and a scaled 16-bit file; the staged bytes are the big-endian plane segments of the strip
+    p32 = str(tmp_path / "a.fits")
+    io_fits.write_fits(p32, d, {"CTYPE3": "VRAD"})
+    src = streaming.FitsSource(p32)
+    assert src.shape == (nz, ny, nx) and src.sample_bytes == 4
+    n = src.read_into(buf, 1, 5, 4, 9)
+    got = np.frombuffer(buf, dtype=">f4", count=4 * 5 * nx).reshape(4, 5, nx)
+    assert n == got.nbytes and np.array_equal(got.astype(np.float32), d[1:5, 4:9])
+    src.release()
+    # sinks: strips written in any order rebuild the cube; the FITS sink's file reads back through the package's reader
+    out = np.full((nz, ny, nx), -1.0, np.float32)
+    sink = streaming.NdarraySink(out)
+    fsink = streaming.FitsSink(str(tmp_path / "b.fits"), {"CTYPE3": "VRAD", "BUNIT": "K"}, (nz, ny, nx))
+    for (y0, y1) in ((8, 12), (0, 8)):
+        for (z0, z1) in ((4, 7), (0, 4)):
+            blk = np.ascontiguousarray(d[z0:z1, y0:y1])
+            ctypes.memmove(buf, blk.ctypes.data, blk.nbytes)
+            sink.write(buf, z0, z1, y0, y1)
+            be = blk.astype(">f4")
+            ctypes.memmove(buf, be.ctypes.data, be.nbytes)
+            fsink.write(buf, z0, z1, y0, y1)
+    sink.close(); fsink.close()
+    assert np.array_equal(out, d)
+    img = io_fits.find_image(str(tmp_path / "b.fits"))
+    assert io_fits.cube_shape(img) == (nz, ny, nx) and os.path.getsize(str(tmp_path / "b.fits")) % 2880 == 0
+    raw = np.fromfile(str(tmp_path / "b.fits"), dtype=">f4", count=nz * ny * nx, offset=img.data_offset).reshape(nz, ny, nx)
+    assert np.array_equal(raw.astype(np.float32), d) and io_fits.cube_header(img)["BUNIT"] == "K"
+    with pytest.raises(OSError):
+        streaming.FitsSink(str(tmp_path / "b.fits"), {}, (nz, ny, nx))
+    with pytest.raises(TypeError):
+        streaming.NdarraySink(np.zeros((2, 2, 2)))
