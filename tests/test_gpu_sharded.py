@@ -243,3 +243,45 @@ def test_chunked_moments_hide_the_stitch(gpu):
             D.ChunkedMoments(dd, dm, d_cen, 500.0, 0.0, comm, chunks=5)
     finally:
         comm.close()
+
+
+def test_rccl_collectives_with_one_rank_on_this_gpu(gpu):
+    """The device side of the stitch for real - RCCL communicator, spc_allgather_rows, the grouped all-gathers of
+    ChunkedMoments on a second stream behind stream events - with the one rank a 1-GPU box allows (RCCL refuses two ranks on
+    one device): rendezvous-carried unique id, comm init, in-order map assembly, sharded_moments through RcclComm; all
+    equal to the unsharded kernels, bit for bit.  (Multi-rank ordering is the driver's 8-GPU tier.)"""
+    from spectral_cube_amd import _lib, ops
+    from spectral_cube_amd.device import Stream
+    from spectral_cube_amd.rendezvous import SingleProcess
+    shape = (128, 256, 96)
+    d = synth.gaussian_line_cube(shape, 43)
+    d[5:9, 17, 3] = np.nan
+    inc = synth.boolean_mask(d, 43)
+    comm = D.RcclComm(0, SingleProcess())
+    try:
+        cube, maskd = DeviceArray.from_numpy(d), DeviceArray.from_numpy(inc)
+        v = synth.spectral_axis(shape[0])
+        cen = v - v[0]
+        cref = cen[shape[0] // 2]
+        d_cen = DeviceArray.from_numpy(cen - cref)
+        mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=maskd)
+        ref = ops.moments(cube, d_cen, dv=500.0, m1_add=cref + v[0], mask=mspec, want=("m0", "m1", "m2"))
+        ch = D.ChunkedMoments(cube, maskd, d_cen, 500.0, cref + v[0], comm, chunks=4)
+        s1, s2 = Stream(0), Stream(0)
+        for _ in range(3):                                   # back to back: the events of one call are reused by the next
+            maps = ch(s1, s2)
+        s1.synchronize()
+        for k in ("m0", "m1", "m2"):
+            assert np.array_equal(maps[k].get(), ref[k].get(), equal_nan=True), k
+        assert [ch.global_rows(0, c) for c in range(4)] == [(0, 64), (64, 128), (128, 192), (192, 256)]
+        # the plain all-gather and the driver that uses it
+        strip = ref["m1"]
+        got = comm.allgather_rows(strip, shape[1]).get()
+        assert np.array_equal(got, ref["m1"].get(), equal_nan=True)
+        sc = SpectralCube.read(d, _hdr(*shape)).with_mask(inc.astype(bool))
+        sm = D.sharded_moments(sc, shape[1], comm)
+        e = sc.moments012()
+        for o in (0, 1, 2):
+            assert np.array_equal(sm[o], np.asarray(e[o]), equal_nan=True)
+    finally:
+        comm.close()
