@@ -537,8 +537,11 @@ constexpr int grouped_txo(int R, int BT) { return ((BT - 2 * (R / 2)) / kRun) * 
 constexpr int grouped_pitch(int BT) { return BT == 256 ? 316 : 604; }     // float2 per LDS row, = 28 (mod 32): see spatial_sep_kernel
 // SYM (with ISO): the taps are symmetric (every Gaussian) and addressed folded, k[min(j, 2H - j)]: 15 distinct weights
 // = 8 SGPR pairs instead of 15 - unfolded the kernel spilled 57 SGPRs (104 v_readlane + 57 v_writelane per revolution).
+#ifndef SPC_GROUPED_PF
+#define SPC_GROUPED_PF 1          // groups of rows staged ahead (experiment: 2 needs 16 more registers -> 3 blocks per CU)
+#endif
 template <int R, bool ARR, bool PRED, bool ISO, int BT, bool SYM, int ABL = 0>
-__global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(const SpArgs A) {
+__global__ __launch_bounds__(BT, SPC_GROUPED_PF == 1 ? 1024 / BT : 768 / BT) void spatial_sep_grouped_kernel(const SpArgs A) {
     constexpr int H = R / 2;
     static_assert(!SYM || ISO, "folded weights are for kx == ky");
     auto wj = [](int j) { return SYM ? (j <= H ? j : 2 * H - j) : j; };
@@ -586,23 +589,26 @@ __global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(cons
     float2v acc[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) acc[m] = float2v{0.f, 0.f};
-    float v[kG];
-    unsigned mk[kG];
+    constexpr int PF = SPC_GROUPED_PF;
+    static_assert(PF == 1 || NG % PF == 0, "the staging slot of a group must be static");
+    float v[PF][kG];
+    unsigned mk[PF][kG];
     const int T = (ye - yb) + 2 * H;
     // rows of group gi counted from the first group of the first revolution
     auto group_first = [&](int gi) { return yb - H + (gi / NG) * R + (gi % NG) * kG; };
     auto group_rows = [&](int gi) { const int g = gi % NG; return ((g + 1) * kG < R ? (g + 1) * kG : R) - g * kG; };
-    auto fetch = [&](int first_row, int n) {
+    auto fetch = [&](int slot, int first_row, int n) {
 #pragma unroll
         for (int s = 0; s < kG; ++s) {
             if (s < n) {
                 const int ic = min(max(first_row + s, 0), ny - 1);                    // uniform
-                v[s] = (ABL & 4) ? (float)(t + s) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)ic * rbytes), 0));
-                if (ARR) mk[s] = (ABL & 2) ? 1u : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)ic * mrbytes), 0);
+                v[slot][s] = (ABL & 4) ? (float)(t + s) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)ic * rbytes), 0));
+                if (ARR) mk[slot][s] = (ABL & 2) ? 1u : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)ic * mrbytes), 0);
             }
         }
     };
-    fetch(group_first(0), group_rows(0));
+#pragma unroll
+    for (int q = 0; q < PF; ++q) fetch(q, group_first(q), group_rows(q));
     for (int t0 = 0; t0 < T; t0 += R) {
         const int i0 = yb - H + t0;                       // first input row of this revolution
 #pragma unroll
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(cons
             // ---- y pass of the group
 #pragma unroll
             for (int s = s0; s < s1; ++s) {
-                float2v x2 = classify<R, ARR, PRED>(v[s - s0], ARR ? (unsigned char)mk[s - s0] : (unsigned char)1, lim, lo, hi);
+                float2v x2 = classify<R, ARR, PRED>(v[g % PF][s - s0], ARR ? (unsigned char)mk[g % PF][s - s0] : (unsigned char)1, lim, lo, hi);
                 if (edge) {                                   // out of bounds = valid zero
                     const bool in = col_in && (i0 + s >= 0) && (i0 + s < ny);
                     if (!in) x2 = float2v{0.f, 1.f};
@@ -630,8 +636,8 @@ __global__ __launch_bounds__(BT, 1024 / BT) void spatial_sep_grouped_kernel(cons
             lds_barrier();
             // ---- rows of the NEXT group, into the registers this group has just used: in flight during the x pass
             {
-                const int gi = (t0 / R) * NG + g + 1;
-                if (group_first(gi) < ye + H) fetch(group_first(gi), group_rows(gi));
+                const int gi = (t0 / R) * NG + g + PF;
+                if (group_first(gi) < ye + H) fetch(g % PF, group_first(gi), group_rows(gi));
             }
             // ---- x pass over the rows of this group
             const int grows = s1 - s0;
