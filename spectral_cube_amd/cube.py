@@ -418,6 +418,25 @@ class SpectralCube:
     def spectral_unit(self):
         return self._wcs.spectral_unit if self._wcs is not None else ""
 
+    def with_spectral_unit(self, unit, velocity_convention=None, rest_value=None):
+        """The same cube with its spectral axis in another unit OF THE SAME KIND (m/s <-> km/s, Hz <-> GHz, ...:
+        spectral_cube.py:1345-1388 for that case; base_class.py `with_spectral_unit`): the WCS is rescaled, the voxels and the mask
+        are shared.  Moments then come out in the new unit (tests/test_moments.py:145-155).  Changing the KIND of axis
+        (frequency <-> velocity, another velocity convention or rest value) is the reference's spectral_axis machinery, outside
+        the dense path: NotImplementedError."""
+        unit = str(getattr(unit, "to_string", lambda: unit)()).replace(" ", "")
+        if velocity_convention is not None or rest_value is not None:
+            raise NotImplementedError("changing the velocity convention / rest value is not built: only same-kind unit changes are")
+        try:
+            scale = spectral_unit_scale(self.spectral_unit, unit)
+        except ValueError as exc:
+            raise NotImplementedError(str(exc))
+        w = self._wcs
+        newwcs = w.with_spectral(w.crval[2] * scale, w.cdelt[2] * w.pc[2, 2] * scale, w.crpix[2], cunit=unit)
+        out = self._new_cube_with(data=self._data, dev=self._dev, wcs=newwcs, lazy=self._lazy, shape=self._shape, same_data=True)
+        out._mask_cache = self._mask_cache
+        return out
+
     def with_mask(self, mask, inherit_mask=True):
         """spectral_cube.py:1390-1441: AND the new mask with the existing one."""
         if isinstance(mask, np.ndarray):

@@ -314,8 +314,10 @@ class SimpleWCS:
         out.pc = out.pc.copy(); out.pc[2, 2] = 1.0
         if cunit is not None:
             out.cunit = list(out.cunit); out.cunit[2] = cunit
-        out.header = dict(out.header)
+        out.header = {k: v for k, v in out.header.items() if k not in ("PC3_3", "CD3_3", "PC003003")}   # folded into CDELT3
         out.header.update(CRVAL3=float(crval), CDELT3=float(cdelt), CRPIX3=float(crpix))
+        if cunit is not None:
+            out.header["CUNIT3"] = cunit
         return out
 
     def to_header(self):

@@ -259,3 +259,27 @@ def test_out_of_core_cube_to_cube_operators(gpu, tmp_path, monkeypatch):
     # and the astropy-independent reader agrees that the file is a valid FITS image
     img = io_fits.find_image(p_it)
     assert io_fits.cube_shape(img) == (len(grid), ny, nx) and os.path.getsize(p_it) % 2880 == 0
+
+
+def test_preserve_unit_with_spectral_unit(gpu):
+    """tests/test_moments.py:145-170 (test_preserve_unit / test_with_flux_unit): the moment cube read in m/s, switched to
+    km/s with with_spectral_unit: moment 0 in K km/s, moment 1 in km/s, moment 2 in km2/s2 - the reference's golden table
+    rescaled - and the unit strings follow; a change of KIND of axis is refused."""
+    from test_oracle_golden import MOMENTS
+    g = golden("moment_cube.npz")
+    sc = SpectralCube.read(g["data"], str(g["header"]))
+    assert sc.spectral_unit == "m/s"
+    kms = sc.with_spectral_unit("km/s")
+    np.testing.assert_allclose(kms.spectral_axis, np.asarray(sc.spectral_axis) / 1e3, rtol=1e-14)
+    m0, m1 = kms.moment0(axis=0), kms.moment1(axis=0)
+    np.testing.assert_allclose(m0, np.asarray(MOMENTS[0][0]) / 1e3, rtol=2e-7)
+    np.testing.assert_allclose(m1, np.asarray(MOMENTS[1][0]) / 1e3, rtol=2e-7)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(kms.moment2(axis=0), np.asarray(MOMENTS[2][0]) / 1e6, rtol=2e-7)
+    assert "km/s" in m0.unit and m1.unit == "km/s"
+    assert kms._dev is sc._dev or kms._data is sc._data            # the voxels are shared
+    with pytest.raises(NotImplementedError):
+        sc.with_spectral_unit("GHz")
+    with pytest.raises(NotImplementedError):
+        sc.with_spectral_unit("km/s", velocity_convention="radio")
