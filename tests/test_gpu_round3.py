@@ -283,3 +283,23 @@ def test_preserve_unit_with_spectral_unit(gpu):
         sc.with_spectral_unit("GHz")
     with pytest.raises(NotImplementedError):
         sc.with_spectral_unit("km/s", velocity_convention="radio")
+
+
+def test_projection_reproject_2d_across_frames(gpu):
+    """tests/test_regrid.py:409-434 of the reference (test_reproject_2D): a 5 x 5 Projection on the RA/DEC-SIN header
+    reprojected onto GLON-SIN / GLAT-SIN, 5 x 4 pixels: shape, beam kept, the target's WCS; values = the oracle's bilinear
+    resampler on astropy's cross-frame pixel map (tests/golden/wcs_frames.npz)."""
+    from spectral_cube_amd.cube import Projection
+    from spectral_cube_amd.beam import Beam
+    g = golden("wcs_frames.npz")
+    rng = np.random.default_rng(55)
+    img = rng.random((5, 5)).astype(np.float32)
+    w_in, w_out = SimpleWCS(str(g["in0"]), naxis=2), SimpleWCS(dict(SimpleWCS(str(g["out0"]), naxis=2).header, NAXIS1=4, NAXIS2=5), naxis=2)
+    bm = Beam(1.0 / 3600)
+    proj = Projection(img, unit="K", wcs=w_in, beam=bm)
+    res = proj.reproject(w_out.header)
+    assert res.shape == (5, 4) and res.beam == bm and res.wcs.frame == ("galactic",)
+    np.testing.assert_allclose(res.wcs.crval, [134.37608, -31.939241], atol=1e-12)
+    exp, foot = O.resample_bilinear(img[None], g["xs0"], g["ys0"])
+    assert np.isfinite(exp).any()
+    assert_close(np.asarray(res), exp[0].astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="Projection.reproject across frames")
