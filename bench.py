@@ -569,7 +569,7 @@ def config_c4(device, scale):
     exp = O.spatial_smooth(tile[sub], inc, k2)[win]
     ver = {"max_scaled_err": _close(smoothed_window(sm), exp, float(np.nanmax(np.abs(exp))), "C4 smooth masked"),
            "voxels_checked": int(exp.size)}
-    recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 mask", "spatial_sep_grouped_kernel<29,true,false,true,256,0> (ARR, ISO, 256 threads)", ms_s, vox * 9, vox, ver,
+    recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 mask", "spatial_sep_grouped_kernel<29,true,false,true,256,true,0> (ARR, ISO, 256 threads, SYM)", ms_s, vox * 9, vox, ver,
                            "4 + 1 read + 4 written", mask_valid_fraction=float(tmask.mean())))
 
     # the pipeline of the config: spatial_smooth -> moment0 (the smoothed cube keeps the ORIGINAL mask)
@@ -588,7 +588,7 @@ def config_c4(device, scale):
     ver = {"max_scaled_err": _close(o0["m0"].get()[:WY, :WX], exp_m0, float(np.nanmax(np.abs(exp_m0))), "C4 moment0 masked"),
            "spaxels_checked": int(exp_m0.size)}
     recs.append(cfg_record("C4 pipeline spatial_smooth(29x29) -> moment0, uint8 mask (materialised)",
-                           "spatial_sep_grouped_kernel<29,true,false,true,256,0> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "spatial_sep_grouped_kernel<29,true,false,true,256,true,0> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
                            "fused ideal: 4 + 1 read + 8 B/spaxel out (the materialised form moves 9 + 5 B/voxel)",
                            mask_valid_fraction=float(tmask.mean())))
 
