@@ -45,7 +45,8 @@ class _PinnedPool:
     beyond the cap array() raises MemoryError and get() falls back to pageable numpy memory."""
 
     MIN_BYTES = 1 << 20          # smaller results use plain numpy memory
-    MAX_BYTES = 1 << 30          # larger ones too (pinning tens of GiB of host memory is not this pool's business)
+    MAX_BYTES = 256 << 20        # larger ones come down in chunks through the staging buffers (DeviceArray._get_chunked):
+                                 # page-locking a fresh 1 GiB buffer costs ~150 ms, more than the copy it would speed up
 
     def __init__(self, max_bytes=1 << 30, max_outstanding=None):
         import os
@@ -206,9 +207,52 @@ class DeviceArray:
             out = np.empty(self.shape, dtype=self.dtype)
         if stream is not None:
             _lib.call("spc_stream_sync", self.device, _sh(stream))
+        if self.nbytes > _PinnedPool.MAX_BYTES and out.flags.c_contiguous:
+            self._get_chunked(out)           # cube-sized: through pinned chunks, several host copies in flight
+            return out
         _lib.call("spc_memcpy_d2h", self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
                   self.nbytes, None)
         return out
+
+    def _get_chunked(self, out, chunk_bytes=64 << 20, nbuffers=8, workers=6):
+        """Cube-sized results: one synchronous copy into fresh pageable memory runs at ~20 GB/s (the runtime stages it on
+        one thread and the pages are touched for the first time).  Here 64 MiB chunks come down asynchronously into pinned
+        buffers (the out-of-core pipeline's cache) and worker threads copy them into *out* - the first touch of the
+        destination pages is spread over the workers - while the next chunks are in flight."""
+        import ctypes
+        from concurrent.futures import ThreadPoolExecutor
+        from .streaming import _give_pinned, _take_pinned
+        dst = out.reshape(-1).view(np.uint8)
+        n = self.nbytes
+        nchunks = (n + chunk_bytes - 1) // chunk_bytes
+        nbuf = min(nbuffers, nchunks)
+        pinned = _take_pinned(chunk_bytes, nbuf)
+        stream = Stream(self.device)
+        events, futs = [None] * nbuf, [None] * nbuf
+
+        def land(k, ev, off, m):
+            ev.synchronize()
+            ctypes.memmove(dst[off:off + m].ctypes.data, pinned[k].ptr, m)
+
+        try:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                for i in range(nchunks):
+                    k = i % nbuf
+                    if futs[k] is not None:
+                        futs[k].result()
+                    off = i * chunk_bytes
+                    m = min(chunk_bytes, n - off)
+                    _lib.call("spc_memcpy_d2h", self.device, C.c_void_p(pinned[k].ptr), C.c_void_p(self.ptr + off), C.c_size_t(m),
+                              stream.handle)
+                    ev = Event(self.device)
+                    ev.record(stream)
+                    futs[k] = pool.submit(land, k, ev, off, m)
+                for f in futs:
+                    if f is not None:
+                        f.result()
+        finally:
+            stream.synchronize()
+            _give_pinned(chunk_bytes, pinned)
 
     def rows(self, y0, y1):
         """view of rows [y0, y1) of a (nz, ny, nx) array: same row/plane strides as the
