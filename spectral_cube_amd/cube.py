@@ -286,7 +286,7 @@ class SpectralCube:
             from . import streaming
             src, fn, nz_out = plan
             sink = streaming.FitsSink(os.fspath(filename), self._header, (nz_out,) + tuple(self._shape[1:]), overwrite=overwrite)
-            streaming.map_strips(src, fn, nz_out, sink)
+            streaming.map_strips(src, fn, nz_out, sink, halo=self._strip_halo())
             return
         dev = self._device_data()
         if filled and self._mask is not None:
@@ -311,7 +311,10 @@ class SpectralCube:
             return None
         keeps_parent_mask = self._mask is parent._mask
         if filled and self._mask is not None and keeps_parent_mask:
-            fn = lambda dev, mspec, stream: ops.fill_masked(lz.strip_fn(dev, mspec, stream), mspec, fill, stream)  # noqa: E731
+            def fn(dev, mspec, stream):      # the parent's mask, evaluated on the parent's voxels (as _mask_spec does)
+                from . import streaming
+                keep = streaming.original_include(parent, dev, mspec, stream)
+                return ops.fill_masked(lz.strip_fn(dev, mspec, stream), keep, fill, stream)
         else:
             fn = lz.strip_fn             # (spectral_interpolate: the new mask is ~isnan(result), the data are their own fill)
         return parent, fn, self._shape[0]
@@ -325,8 +328,11 @@ class SpectralCube:
         if plan is None:
             raise ValueError("this cube fits the device: use filled_data")
         src, fn, nz_out = plan
-        streaming.map_strips(src, fn, nz_out, streaming.NdarraySink(out))
+        streaming.map_strips(src, fn, nz_out, streaming.NdarraySink(out), halo=self._strip_halo())
         return out
+
+    def _strip_halo(self):
+        return int(getattr(self._lazy, "halo", 0)) if (self._lazy is not None and self._dev is None) else 0
 
     @classmethod
     def from_device(cls, dev, wcs=None, header=None, mask=None, **kw):
@@ -552,6 +558,12 @@ class SpectralCube:
         if fused_kernel is None and self._stream_source() is not None:
             from . import streaming
             return streaming.moments(self, want, d_cen, dv, cref + spec0)
+        lz = self._lazy
+        if (fused_kernel is None and self._dev is None and lz is not None and getattr(lz, "op", None) == "spatial_smooth"
+                and lz.parent._stream_source() is not None and lz.parent._mask is self._mask):
+            # out-of-core parent, not the all-valid algebraic case: smooth strip + halo rows, reduce the strip's own rows
+            from . import streaming
+            return streaming.moments(lz.parent, want, d_cen, dv, cref + spec0, pre=lz.strip_fn, halo=lz.halo)
         if fused_kernel is not None:
             parent, karr = fused_kernel
             try:
@@ -956,6 +968,11 @@ class SpectralCube:
 
             def __call__(self):
                 return ops.spatial_conv(parent._device_data(), karr, mask=parent._mask_spec())
+
+            halo = karr.shape[0] // 2        # rows a strip of an out-of-core parent needs from its neighbours
+
+            def strip_fn(self, dev, mspec, stream):
+                return ops.spatial_conv(dev, karr, mask=mspec, stream=stream)
 
         return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
 

@@ -191,23 +191,26 @@ class StripPipeline:
     the device, and a buffer is only overwritten once the consumer's stream has passed the event recorded after ITS
     kernels (done()).  Iteration yields (y0, y1, DeviceArray) with `consumer_stream` already waiting for the strip."""
 
-    def __init__(self, source, device, rows, consumer_stream, slots=2, chunk_bytes=None, nbuffers=None, readers=None):
+    def __init__(self, source, device, rows, consumer_stream, slots=2, chunk_bytes=None, nbuffers=None, readers=None, halo=0):
         from .device import Event
         self.source, self.device, self.rows, self.consumer = source, device, int(rows), consumer_stream
+        self.halo = int(halo)          # extra rows loaded on each side of a strip (clipped at the cube's edges): spatial stencils
         self.slots = slots
         self.chunk_bytes = int(chunk_bytes or (_env_int("SPC_STREAM_CHUNK_MB", 32) << 20))
         self.nbuf = int(nbuffers or _env_int("SPC_STREAM_BUFFERS", 16))
         self.readers = int(readers or _env_int("SPC_STREAM_READERS", 8))
         nz, ny, nx = source.shape
         self.bounds = [(y0, min(ny, y0 + self.rows)) for y0 in range(0, ny, self.rows)]
-        seg = self.rows * nx * source.sample_bytes
+        self.loaded = [(max(0, y0 - self.halo), min(ny, y1 + self.halo)) for y0, y1 in self.bounds]     # rows a strip holds
+        self.ext = min(ny, self.rows + 2 * self.halo)
+        seg = self.ext * nx * source.sample_bytes
         self.ppc = max(1, min(nz, self.chunk_bytes // max(1, seg)))      # planes per chunk
         cap = -(-(self.ppc * seg) // (1 << 20)) << 20       # whole MiB: sets of equal size are shared between passes
         self.cap = cap
         self.pinned = _take_pinned(cap, self.nbuf)
         self.d_raw = [DeviceArray((cap,), np.uint8, device) for _ in range(self.nbuf)] if source.decode else None
         self.copy = Stream(device)
-        self.bufs = [DeviceArray((nz, self.rows, nx), source.out_dtype, device) for _ in range(min(slots, len(self.bounds)))]
+        self.bufs = [DeviceArray((nz, self.ext, nx), source.out_dtype, device) for _ in range(min(slots, len(self.bounds)))]
         self.done_evt = [None] * len(self.bufs)
         self.Event = Event
         self.bytes = 0
@@ -234,7 +237,7 @@ class StripPipeline:
                 b.free_evt.synchronize()
                 b.free_evt = None
             s, z0, z1 = tasks[i]
-            y0, y1 = self.bounds[s]
+            y0, y1 = self.loaded[s]
             pending[i] = pool.submit(src.read_into, b.view, z0, z1, y0, y1)
 
         try:
@@ -245,7 +248,8 @@ class StripPipeline:
             for i, (s, z0, z1) in enumerate(tasks):
                 n = pending.pop(i).result()
                 y0, y1 = self.bounds[s]
-                rows = y1 - y0
+                h0, h1 = self.loaded[s]
+                rows = h1 - h0
                 slot = s % len(self.bufs)
                 if z0 == 0 and self.done_evt[slot] is not None:      # the consumer's kernels on the strip that held this slot
                     self.copy.wait_event(self.done_evt[slot])
@@ -269,6 +273,7 @@ class StripPipeline:
                 if i == last_of[s]:
                     self.consumer.wait_event(ev)             # the strip is complete when its last chunk has landed
                     strip = DeviceArray((nz, rows, nx), src.out_dtype, dev, ptr=self.bufs[slot].ptr, owner=self.bufs[slot])
+                    strip.top = y0 - h0            # the strip's own rows are [top, top + (y1 - y0)) of what was loaded
                     yield y0, y1, strip
                     d = self.Event(dev)                      # recorded after whatever the consumer queued on its stream
                     d.record(self.consumer)
@@ -298,7 +303,7 @@ class Strips:
     """(y0, y1, data strip, MaskSpec or None) of a streamed cube on `stream`; data and the mask's array term come
     through two pipelines in lockstep"""
 
-    def __init__(self, cube, stream, rows=None):
+    def __init__(self, cube, stream, rows=None, halo=0):
         from . import ops
         self.ops = ops
         src = cube._stream_source()
@@ -307,12 +312,12 @@ class Strips:
         if rows is None:
             rows = plan_rows(src.shape, hbm_budget(cube.device), mask_array=has_arr)
         self.rows = rows
-        self.data = StripPipeline(src, cube.device, rows, stream)
+        self.data = StripPipeline(src, cube.device, rows, stream, halo=halo)
         self.mask = None
         if has_arr:
             m = np.broadcast_to(self.terms[3], src.shape)
             self.mask = StripPipeline(NdarraySource(m, np.uint8), cube.device, rows, stream,
-                                      nbuffers=max(4, self.data.nbuf // 2), readers=max(2, self.data.readers // 2))
+                                      nbuffers=max(4, self.data.nbuf // 2), readers=max(2, self.data.readers // 2), halo=halo)
 
     @property
     def bytes(self):
@@ -355,24 +360,54 @@ def _mask_terms(cube):
     return flags, lo, hi, m
 
 
+def original_include(cube, dev, mspec, stream):
+    """the mask of the streamed cube *cube* evaluated on ITS strip `dev`, as an array-only MaskSpec: what a derived cube
+    that keeps its parent's mask (spectral_smooth / spatial_smooth results, cube.py `_mask_spec`) is reduced and filled
+    with - the isfinite / threshold terms are bound to the parent's voxels, not to the operator's output"""
+    from . import masks as M, ops
+    if mspec is None:
+        return None
+    nan_excluded = M.contains(cube._mask, M.NotNaNMask)
+    if mspec.array is not None and not nan_excluded and not (mspec.flags & ~_lib.MASK_ARRAY):
+        return mspec
+    inc = ops.mask_include(dev, mspec, nan_excluded=nan_excluded, stream=stream)
+    return ops.MaskSpec(_lib.MASK_ARRAY, 0.0, 0.0, inc)
+
+
 _TYPES = dict(m0=np.float64, m1=np.float64, m2=np.float64, mu=np.float64, s0=np.float64, argmax=np.int64, argmin=np.int64,
               vmax=np.float32, vmin=np.float32, nvalid=np.int32)
 
 
-def moments(cube, want, d_cen, dv, m1_add, kernel=None, cen_host=None, rows=None, stats=None):
+def moments(cube, want, d_cen, dv, m1_add, kernel=None, cen_host=None, rows=None, stats=None, pre=None, halo=0):
     """the maps of ops.moments / ops.spectral_conv_moments for a streamed cube: {name: (ny, nx) DeviceArray}, every
-    strip's kernel writing its rows of the final maps.  stats (dict) receives bytes staged and strips."""
+    strip's kernel writing its rows of the final maps.  stats (dict) receives bytes staged and strips.
+    pre(strip, mask spec, stream) -> strip of the same shape: an operator applied to the strip before it is reduced (the
+    smoothed cube of spatial_smooth(...).moment(...): strips carry `halo` extra rows per side, which are smoothed against
+    an artificial edge and never reduced; the smoothed cube keeps the ORIGINAL mask)."""
     from . import ops
     nz, ny, nx = cube._shape
     maps = {k: DeviceArray((ny, nx), _TYPES[k], cube.device) for k in want}
     compute = Stream(cube.device)
-    st = Strips(cube, compute, rows)
+    if rows is None and halo:
+        terms = _mask_terms(cube)
+        per_row = nz * nx * (4 + (1 if terms is not None and terms[3] is not None else 0) + 4)      # + the operator's result
+        rows = max(8, int((hbm_budget(cube.device) // 2) // (2 * per_row)) // 8 * 8 - 2 * halo)
+        rows = max(8, min(ny, rows))
+    st = Strips(cube, compute, rows, halo=halo)
     need = _lib.load().spc_moments_workspace_bytes(nz, st.rows, nx)
     ws = DeviceArray((max(int(need), 1),), np.uint8, cube.device)        # ONE scratch for every strip's launch
     n = 0
     for y0, y1, dev, mspec in st:
         out = {k: _rows_view(maps[k], y0, y1) for k in want}
-        if kernel is None:
+        if pre is not None:
+            top = getattr(dev, "top", 0)
+            keep = original_include(cube, dev, mspec, compute)      # (evaluated on the PARENT's voxels, before `pre`)
+            sm = pre(dev, mspec, compute)
+            ops.moments(sm.rows(top, top + (y1 - y0)), d_cen, dv=dv, m1_add=m1_add,
+                        mask=keep.rows(top, top + (y1 - y0)) if keep is not None else None,
+                        want=want, stream=compute, out=out, workspace=ws)
+            compute.synchronize()          # `sm` goes back to the pool when the next strip replaces it
+        elif kernel is None:
             ops.moments(dev, d_cen, dv=dv, m1_add=m1_add, mask=mspec, want=want, stream=compute, out=out, workspace=ws)
         else:
             ops.spectral_conv_moments(dev, kernel, d_cen, dv=dv, m1_add=m1_add, mask=mspec, want=want, stream=compute,
@@ -544,7 +579,7 @@ class StripWriter:
             self.sink.close()
 
 
-def map_strips(cube, fn, nz_out, sink, rows=None, stats=None):
+def map_strips(cube, fn, nz_out, sink, rows=None, stats=None, halo=0):
     """out[:, y0:y1] = fn(strip, mask spec, stream) for every row strip of a streamed cube; fn returns a float32
     (nz_out, rows, nx) DeviceArray produced on `stream`.  The operators this serves work per spaxel (spectral_smooth,
     spectral_interpolate, sigma_clip_spectrally, the plain filled copy): no halo."""
@@ -557,14 +592,22 @@ def map_strips(cube, fn, nz_out, sink, rows=None, stats=None):
         terms = _mask_terms(cube)
         # two input strips + two result strips (+ the operator's own scratch) within half the budget
         per_row = nx * (nz * (4 + (1 if terms is not None and terms[3] is not None else 0)) + 2 * nz_out * 4)
-        rows = max(8, int((hbm_budget(cube.device) // 2) // (2 * per_row)) // 8 * 8)
-        rows = min(src.shape[1], rows)
-    st = Strips(cube, compute, rows)
+        rows = max(8, int((hbm_budget(cube.device) // 2) // (2 * per_row)) // 8 * 8 - 2 * halo)
+        rows = max(8, min(src.shape[1], rows))
+    st = Strips(cube, compute, rows, halo=halo)
     w = StripWriter(sink, cube.device)
     n = 0
     try:
         for y0, y1, dev, mspec in st:
             res = fn(dev, mspec, compute)
+            top = getattr(dev, "top", 0)
+            if halo and res.shape[1] != y1 - y0:
+                # the strip's own rows of the extended result, compacted on the device (the halo rows saw an artificial edge)
+                own = DeviceArray((res.shape[0], y1 - y0, nx), np.float32, cube.device)
+                row = nx * 4
+                _lib.call("spc_memcpy3d_d2d", cube.device, C.c_void_p(own.ptr), row, (y1 - y0) * row,
+                          C.c_void_p(res.ptr + top * row), row, res.shape[1] * row, row, y1 - y0, res.shape[0], compute.handle)
+                res = own
             w.put(y0, y1, res, compute)
             n += 1
     finally:

@@ -223,8 +223,8 @@ def test_out_of_core_cube_to_cube_operators(gpu, tmp_path, monkeypatch):
     res = SpectralCube.read(path)
     grid = np.linspace(res.spectral_axis[1], res.spectral_axis[-2], 2 * nz + 3)
     exp_fill = np.asarray(res.with_mask(inc).filled_data)
-    exp_sm = res.with_mask(inc).spectral_smooth(k)
-    exp_sm = ops.fill_masked(exp_sm._device_data(), res.with_mask(inc)._mask_spec(), np.nan).get()
+    exp_sm = np.asarray(res.with_mask(inc).spectral_smooth(k).filled_data)      # (the parent's mask on the parent's voxels)
+    assert np.isnan(exp_sm[:, 3:6, 2:5]).all()
     exp_it = np.asarray(res.spectral_interpolate(grid, suppress_smooth_warning=True).filled_data)
     exp_cl = res.sigma_clip_spectrally(2.5)
     exp_cl = ops.fill_masked(exp_cl._device_data(), res._mask_spec(), np.nan).get()
@@ -303,3 +303,45 @@ def test_projection_reproject_2d_across_frames(gpu):
     exp, foot = O.resample_bilinear(img[None], g["xs0"], g["ys0"])
     assert np.isfinite(exp).any()
     assert_close(np.asarray(res), exp[0].astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="Projection.reproject across frames")
+
+
+def test_out_of_core_spatial_smooth_with_halo_rows(gpu, tmp_path, monkeypatch):
+    """spatial_smooth of a streamed cube: strips carry the kernel's half width in extra rows on each side (clipped at the
+    cube's edges), the smoothed halo rows - which saw an artificial edge - are dropped.  The written cube and the moments of
+    the smoothed cube (masked data: NOT the algebraic shortcut) equal the resident results bit for bit; strips of 8 rows
+    against a halo of 6 make every strip depend on two neighbours on each side."""
+    from spectral_cube_amd import Gaussian2DKernel, synth
+    monkeypatch.setenv("SPC_MOMENTS_NSPLIT", "1")
+    nz, ny, nx = 24, 90, 70
+    d = synth.gaussian_line_cube((nz, ny, nx), 34)
+    d[:, 40:43, 10:13] = np.nan
+    inc = synth.boolean_mask(d, 34).astype(bool)
+    hdr = _c1_header()
+    k2 = Gaussian2DKernel(1.5)                     # 13 x 13: halo 6
+    assert k2.array.shape == (13, 13)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    res = SpectralCube.read(d, hdr).with_mask(inc)
+    sm = res.spatial_smooth(k2)
+    exp_cube = np.asarray(sm.filled_data)           # the parent's mask, on the parent's voxels: the NaN block stays excluded
+    assert np.isnan(exp_cube[:, 40:43, 10:13]).all()
+    exp_m0, exp_m1 = np.asarray(sm.moment0()), np.asarray(sm.moment1())
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 12))
+    big = SpectralCube.read(d.copy(), hdr).with_mask(inc)
+    assert big._stream_source() is not None
+    out = big.spatial_smooth(k2).stream_into(np.empty((nz, ny, nx), np.float32))
+    assert np.array_equal(out, exp_cube, equal_nan=True)
+    p = str(tmp_path / "sp.fits")
+    big.spatial_smooth(k2).write(p)
+    got_m0, got_m1 = np.asarray(big.spatial_smooth(k2).moment0()), np.asarray(big.spatial_smooth(k2).moment1())
+    assert big._dev is None
+    for g_, e_ in ((got_m0, exp_m0), (got_m1, exp_m1)):
+        assert np.array_equal(np.isnan(g_), np.isnan(e_))
+        bad = ~np.isnan(e_) & (g_ != e_)
+        assert not bad.any(), (int(bad.sum()), np.argwhere(bad)[:5].tolist(), float(np.nanmax(np.abs(g_ - e_) / np.abs(e_))))
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    assert np.array_equal(np.asarray(SpectralCube.read(p).unmasked_data), exp_cube, equal_nan=True)
+    # against the oracle as well
+    e = O.spatial_smooth(d, inc & np.isfinite(d), k2.array)
+    ok = inc & np.isfinite(d) & np.isfinite(e)
+    assert np.array_equal(np.isfinite(out), ok)
+    assert np.abs(out[ok] - e[ok]).max() <= 1e-5 * np.abs(e[ok]).max()
