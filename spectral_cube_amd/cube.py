@@ -490,8 +490,9 @@ class SpectralCube:
                     nbytes = 4 * int(np.prod(self._shape, dtype=np.int64))
                     raise streaming.HugeCubeError(
                         "this operation needs the whole cube in HBM: %.2f GiB against a budget of %.2f GiB (SPC_HBM_BUDGET). "
-                        "Out-of-core cubes stream moment / moments012 / argmax / argmin / max / min along the spectral "
-                        "axis, spectral_smooth(...).moment, statistics() and the whole-cube reductions"
+                        "Out-of-core cubes stream moment / moments012 / argmax / argmin / max / min / median / percentile / mad_std "
+                        "along the spectral axis, statistics() and the whole-cube reductions, and spectral_smooth / spatial_smooth / "
+                        "spectral_interpolate / sigma_clip_spectrally into write(), stream_into() or a following moment"
                         % (nbytes / 2**30, streaming.hbm_budget(self.device) / 2**30))
                 self._dev = DeviceArray.from_numpy(self._data, self.device, dtype=np.float32)
         return self._dev
@@ -559,11 +560,14 @@ class SpectralCube:
             from . import streaming
             return streaming.moments(self, want, d_cen, dv, cref + spec0)
         lz = self._lazy
-        if (fused_kernel is None and self._dev is None and lz is not None and getattr(lz, "op", None) == "spatial_smooth"
-                and lz.parent._stream_source() is not None and lz.parent._mask is self._mask):
-            # out-of-core parent, not the all-valid algebraic case: smooth strip + halo rows, reduce the strip's own rows
+        if (fused_kernel is None and self._dev is None and lz is not None and getattr(lz, "strip_fn", None) is not None
+                and getattr(lz, "parent", None) is not None and lz.parent._stream_source() is not None
+                and lz.parent._mask is self._mask and tuple(lz.parent._shape) == tuple(self._shape)):
+            # out-of-core parent and a pending cube -> cube operator that keeps the parent's mask (spatial_smooth outside the
+            # all-valid algebraic case: strip + halo rows, the strip's own rows reduced; sigma_clip_spectrally; a
+            # spectral_smooth too wide to fuse): operator and reduction strip by strip
             from . import streaming
-            return streaming.moments(lz.parent, want, d_cen, dv, cref + spec0, pre=lz.strip_fn, halo=lz.halo)
+            return streaming.moments(lz.parent, want, d_cen, dv, cref + spec0, pre=lz.strip_fn, halo=int(getattr(lz, "halo", 0)))
         if fused_kernel is not None:
             parent, karr = fused_kernel
             try:
@@ -848,6 +852,8 @@ class SpectralCube:
         return self._reduce("min", axis)
 
     def _order_stat(self, q, axis, what, center=None, scale=1.0):
+        if axis not in (0, 1, 2):
+            raise ValueError("axis must be None, 0, 1 or 2")
         if axis == 1:            # rays along y: the same kernels on a view with the first two axes exchanged
             return ops.percentile_axis0(self._device_data().swap01(), q, mask=self._mask_spec().swap01(),
                                         center=center, scale=scale)
@@ -860,6 +866,9 @@ class SpectralCube:
             return ops.percentile_axis0(flipped.swap01(), q, center=center, scale=scale)
         if axis != 0:
             raise ValueError("axis must be None, 0, 1 or 2")
+        if self._stream_source() is not None:       # out of core: per spaxel, so strip by strip
+            from . import streaming
+            return streaming.percentile_axis0(self, q, center=center, scale=scale)
         return ops.percentile_axis0(self._device_data(), q, mask=self._mask_spec(), center=center, scale=scale)
 
     def _order_wcs(self, axis):

@@ -388,7 +388,7 @@ def moments(cube, want, d_cen, dv, m1_add, kernel=None, cen_host=None, rows=None
     nz, ny, nx = cube._shape
     maps = {k: DeviceArray((ny, nx), _TYPES[k], cube.device) for k in want}
     compute = Stream(cube.device)
-    if rows is None and halo:
+    if rows is None and pre is not None:
         terms = _mask_terms(cube)
         per_row = nz * nx * (4 + (1 if terms is not None and terms[3] is not None else 0) + 4)      # + the operator's result
         rows = max(8, int((hbm_budget(cube.device) // 2) // (2 * per_row)) // 8 * 8 - 2 * halo)
@@ -417,6 +417,21 @@ def moments(cube, want, d_cen, dv, m1_add, kernel=None, cen_host=None, rows=None
     if stats is not None:
         stats.update(bytes=st.bytes, strips=n, rows=st.rows)
     return maps
+
+
+def percentile_axis0(cube, q, center=None, scale=1.0, rows=None):
+    """ops.percentile_axis0 of a streamed cube (median / percentile / the two selections of mad_std along the spectral
+    axis: every spaxel is whole in a row strip): (ny, nx) float32 DeviceArray.  center: the (ny, nx) float32 map of the
+    first selection (mad_std), read row strip by row strip"""
+    from . import ops
+    nz, ny, nx = cube._shape
+    out = DeviceArray((ny, nx), np.float32, cube.device)
+    compute = Stream(cube.device)
+    for y0, y1, dev, mspec in Strips(cube, compute, rows):
+        ops.percentile_axis0(dev, q, mask=mspec, center=_rows_view(center, y0, y1) if center is not None else None, scale=scale,
+                             stream=compute, out=_rows_view(out, y0, y1))
+    compute.synchronize()
+    return out
 
 
 def statistics(cube, rows=None):

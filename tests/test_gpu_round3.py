@@ -134,8 +134,22 @@ def test_out_of_core_moments_and_argmax_equal_the_resident_result(gpu, tmp_path,
     m0 = big.moment0()
     assert_close(np.asarray(m0), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="streamed m0 vs oracle")
     # operators that need the whole cube say so, with the budget in the message
+    # order statistics along the spectral axis are per spaxel: they stream too (bit-exact selections)
+    masked_s, masked_r = big.with_mask(big > thr), res.with_mask(res > thr)
+    got_os = [np.asarray(masked_s.median(axis=0)), np.asarray(masked_s.percentile(30.0, axis=0)), np.asarray(masked_s.mad_std(axis=0)),
+              np.asarray(big.median(axis=0))]
+    assert big._dev is None
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    exp_os = [np.asarray(masked_r.median(axis=0)), np.asarray(masked_r.percentile(30.0, axis=0)), np.asarray(masked_r.mad_std(axis=0)),
+              np.asarray(res.median(axis=0))]
+    for g_, e_ in zip(got_os, exp_os):
+        assert g_.dtype == e_.dtype and np.array_equal(g_, e_, equal_nan=True)
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.array_equal(got_os[3], np.nanmedian(d, axis=0), equal_nan=True)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(budget))
     with pytest.raises(streaming.HugeCubeError, match="SPC_HBM_BUDGET"):
-        big.median(axis=0)
+        big.median(axis=1)
 
 
 def test_out_of_core_boolean_mask_and_fused_smooth(gpu, tmp_path, monkeypatch):
@@ -250,12 +264,15 @@ def test_out_of_core_cube_to_cube_operators(gpu, tmp_path, monkeypatch):
     up = big.spectral_interpolate(grid, suppress_smooth_warning=True)
     up.write(p_it)
     out_cl = big.sigma_clip_spectrally(2.5).stream_into(np.empty((nz, ny, nx), np.float32))
+    monkeypatch.setenv("SPC_MOMENTS_NSPLIT", "1")
+    got_clm = np.asarray(big.sigma_clip_spectrally(2.5).moment1())       # pending operator -> reduction, strip by strip
     assert big._dev is None and up._dev is None
     monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
     back = SpectralCube.read(p_it)
     assert back.shape == (len(grid), ny, nx) and np.array_equal(np.asarray(back.unmasked_data), exp_it, equal_nan=True)
     np.testing.assert_allclose(back.spectral_axis, grid, rtol=1e-12, atol=1e-9)
     assert np.array_equal(out_cl, exp_cl, equal_nan=True)
+    assert np.array_equal(got_clm, np.asarray(res.sigma_clip_spectrally(2.5).moment1()), equal_nan=True)
     # and the astropy-independent reader agrees that the file is a valid FITS image
     img = io_fits.find_image(p_it)
     assert io_fits.cube_shape(img) == (len(grid), ny, nx) and os.path.getsize(p_it) % 2880 == 0
