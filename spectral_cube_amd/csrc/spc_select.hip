@@ -13,6 +13,11 @@
 #include "spc_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+
+#ifndef SPC_SEL_INFLIGHT
+#define SPC_SEL_INFLIGHT 8
+#endif
 
 namespace {
 
@@ -29,7 +34,8 @@ struct SelArgs {
     // samples of a ray are the contiguous ones)
     int64_t x_stride, m_x_stride;
     int along_ray;
-    float pred_lim, pred_lo, pred_hi;      // spc_canonical_pred of the mask's predicate terms (filled by the launcher)
+    uint32_t key_min, key_span;            // sel_key_range of the mask's predicate terms (filled by the launcher)
+    int ablate;                            // timing experiments only (SPC_SELECT_ABLATE): 1 = no descent, 2.. = passes
 };
 
 __device__ __forceinline__ uint32_t fkey(float v) {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256) void select_axis0_kernel(const SelArgs A) {
             // numpy's linear interpolation between the two order statistics (a + (b - a) * t; the
             // median of an even count is their mean)
             const double t = frac[c];
-            res = (float)((t == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * t) * (double)A.scale);
+            res = (float)((a == bb ? a : (t == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * t)) * (double)A.scale);   // (a == b: also +-inf)
         }
         A.out[y * A.nx + x + c] = res;
     }
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
         if (n[c] > 0) {
             const double a = (double)funkey(plo[c]), bb = (double)funkey(phi[c]);
             const double tt = frac[c];
-            res = (float)((tt == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * tt) * (double)A.scale);
+            res = (float)((a == bb ? a : (tt == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * tt)) * (double)A.scale);
         }
         A.out[y * A.nx + x + c] = res;
     }
@@ -326,76 +332,146 @@ __device__ __forceinline__ void count_keys(const uint32_t (&key)[KPL], uint32_t 
 
 // ---- the one read of the cube: TS rays into register keys ------------------------------------------------
 // Lane (r, j) takes samples z = j + L k (L = 256 / TS lanes per ray, k < KPL) of ray r; an excluded / NaN / out-of-range
-// sample becomes the largest key.  Round 2 formed every address as base + z * plane_stride in 64-bit vector arithmetic
-// (two quarter-rate 32-bit multiplies and a 64-bit multiply-add per array and key: ~30 VALU slots per key, more than the
-// four digit passes of the selection that follows) and guarded the tail with an exec-masked branch per key.  DESC: the
-// accesses go through ONE buffer descriptor per group of 8 keys (rebased by scalar arithmetic); a lane's offset (its
-// column and its first plane) is one 32-bit register, key u of the group adds u * L planes to it (one v_add_u32 with a
-// scalar operand), and samples beyond the last plane fall outside the descriptor's range (the hardware returns 0, no
-// fault).  The launcher picks DESC when 9 steps of L planes stay below 2 GiB of byte offset (sel_desc_fits); larger
-// planes keep the 64-bit form.
-// cen: select on |x - cen| when use_cen (mad_std); lim / lo / hi: spc_canonical_pred of the mask's predicate terms.
+// sample becomes the largest key.
+//  * Validity is ONE unsigned range test on the key: NaN samples, isfinite and the threshold comparisons of the mask all
+//    select an interval of the order-preserving key (sel_key_range on the host), so (key - kmin) < span replaces round 2's
+//    five float compares and their scalar ANDs (35 - 40 issue slots per key with the addressing below - as much as the
+//    four digit passes of the selection that follows).  A lane whose column lies beyond the image gets span 0.
+//  * DESC: a key slot is addressed through a buffer descriptor whose base is advanced by L planes per slot in SCALAR
+//    arithmetic; a lane's offset (its column and its first plane) is one 32-bit register shared by all its loads.  Slots
+//    that can run past the last plane (only the upper half of the slots can, by the launcher's choice of KPL) send the
+//    lanes beyond it to offset 0 of the last slot that exists - always inside the cube - and drop the sample by the
+//    validity test.  The launcher picks DESC when L planes and TS columns stay below 2 GiB of byte offset
+//    (sel_desc_fits); larger planes keep 64-bit per-lane addresses (clamped to the last plane).
+// cen: select on |x - cen| when CEN (mad_std).
 static inline bool spc_env_on(const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : true; }
 static inline bool spc_env_set(const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : false; }
-static inline bool sel_desc_fits(int ts, int64_t plane_stride, int64_t x_stride) {
-    const int64_t L = 256 / ts;
-    return (9 * L * plane_stride + ts * x_stride) * 4 < (1ll << 31);
+static inline bool sel_desc_fits(int ts, int64_t plane_stride, int64_t x_stride, int bt = 256) {
+    const int64_t L = bt / ts;
+    return (L * plane_stride + ts * x_stride) * 4 < (1ll << 31);
+}
+static inline uint32_t sel_host_key(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// mask predicate (isfinite, > >= < <= thresholds; NaN never valid) -> the keys it includes: [*kmin, *kmin + *span)
+static inline void sel_key_range(uint32_t flags, float thr_lo, float thr_hi, uint32_t* kmin, uint32_t* span) {
+    float lim, lo, hi;
+    spc_canonical_pred(flags, thr_lo, thr_hi, &lim, &lo, &hi);              // |v| <= lim && !(v <= lo) && !(v >= hi)
+    *kmin = 0u;
+    *span = 0u;
+    if (!(lim >= 0.f)) return;
+    uint64_t a = sel_host_key(-lim), b = sel_host_key(lim);
+    if (lo == lo) a = std::max<uint64_t>(a, (uint64_t)sel_host_key(lo == 0.f ? 0.f : lo) + 1u);      // v > lo; both zeros: > +0
+    if (hi == hi) {
+        const uint64_t h = sel_host_key(hi == 0.f ? -0.f : hi);                                     // v < hi; both zeros: < -0
+        if (h == 0u) return;
+        b = std::min<uint64_t>(b, h - 1u);
+    }
+    if (b < a) return;
+    *kmin = (uint32_t)a;
+    *span = (uint32_t)(b - a + 1u);
 }
 
-template <int TS, int KPL, bool ARR, bool DESC>
-__device__ __forceinline__ int sel_load_keys(const float* cube, int64_t plane_stride, int64_t x_stride, int64_t tile_off,
-                                             const uint8_t* marr, int64_t m_plane_stride, int64_t m_x_stride, int64_t m_tile_off,
-                                             int rc, int j, int nz, int tile_cols, bool col_in, float lim, float lo, float hi,
-                                             bool use_cen, float cen, uint32_t (&key)[KPL]) {
-    constexpr int L = 256 / TS;
-    constexpr int U = KPL < 8 ? KPL : 8;
+__device__ __forceinline__ uint32_t fkey_bits(uint32_t u) {
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
+}
+
+template <int TS, int KPL, bool ARR, bool DESC, bool CEN, int BT>
+__device__ __forceinline__ int sel_load_keys_impl(const float* cube, int64_t plane_stride, int64_t x_stride, int64_t tile_off,
+                                                  const uint8_t* marr, int64_t m_plane_stride, int64_t m_x_stride, int64_t m_tile_off,
+                                                  int rc, int j, int nz, bool col_in, uint32_t kmin, uint32_t span1,
+                                                  float cen, uint32_t (&key)[KPL]) {
+    constexpr int L = BT / TS;
+    // loads in flight per lane: the raw samples land in the key registers themselves (converted in place), so a whole
+    // group costs no registers beyond the mask bytes.  Round 2 / 3a kept 8 in flight (2 KB per wave, 40 KB per CU): the
+    // load phase ran at 2.1 TB/s - latency-bound - and made up 2.0 of the kernel's 2.9 ms at 1024^3.
+    constexpr int U = KPL < SPC_SEL_INFLIGHT ? KPL : SPC_SEL_INFLIGHT;
+    constexpr int kChk0 = (KPL == 16) ? 0 : KPL / 2;             // first slot that can run past the last plane
     int mine = 0;
-    // bytes of the tile's rays from its first sample to one past its last valid one
-    const uint64_t total = ((uint64_t)(nz - 1) * (uint64_t)plane_stride + (uint64_t)(tile_cols - 1) * (uint64_t)x_stride + 1u) * 4u;
-    const uint64_t mtotal = ARR ? ((uint64_t)(nz - 1) * (uint64_t)m_plane_stride + (uint64_t)(tile_cols - 1) * (uint64_t)m_x_stride + 1u) : 0u;
+    const uint32_t span_l = col_in ? span1 : 0u;
+    const int last = (nz - 1) / L;                               // the last slot that holds a sample (uniform)
+    // which of the slots kChk0 .. KPL - 1 hold a sample of THIS lane: a bit each (sign-extended bit extracts below - no
+    // compare, no scalar mask per slot)
+    const int nk = min(max((nz - j + L - 1) / L - kChk0, 0), KPL - kChk0);
+    const unsigned long long vbits = nk >= 64 ? ~0ull : ((1ull << nk) - 1ull);
+    const uint32_t vb0 = (uint32_t)vbits, vb1 = (uint32_t)(vbits >> 32);
     const unsigned voff = (unsigned)(((int64_t)rc * x_stride + (int64_t)j * plane_stride) * 4);
     const unsigned moff = ARR ? (unsigned)((int64_t)rc * m_x_stride + (int64_t)j * m_plane_stride) : 0u;
-    const unsigned step = (unsigned)(L * plane_stride * 4), mstep = ARR ? (unsigned)(L * m_plane_stride) : 0u;     // (DESC: fit 32 bits)
+    const uint64_t step = (uint64_t)(L * plane_stride) * 4u, mstep = ARR ? (uint64_t)(L * m_plane_stride) : 0u;
+    const char* kb = reinterpret_cast<const char*>(cube + tile_off);          // slot base (DESC), advanced in scalar arithmetic
+    const char* mb = ARR ? reinterpret_cast<const char*>(marr + m_tile_off) : nullptr;
     const float* p = cube + tile_off + (int64_t)rc * x_stride;                 // (64-bit form)
     const uint8_t* pm = ARR ? marr + m_tile_off + (int64_t)rc * m_x_stride : nullptr;
 #pragma unroll
     for (int i0 = 0; i0 < KPL; i0 += U) {
-        float raw[U];
         unsigned mk[U];
-        if (DESC) {
-            const uint64_t goff = (uint64_t)i0 * step, mgoff = (uint64_t)i0 * mstep;
-            const uint64_t left = total > goff ? total - goff : 0u, mleft = mtotal > mgoff ? mtotal - mgoff : 0u;
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<const char*>(cube + tile_off) + goff), 0,
-                                                              (int)(unsigned)(left < 0xffffffffull ? left : 0xffffffffull), 0x00020000);
-            const auto rm = __builtin_amdgcn_make_buffer_rsrc(ARR ? (void*)(reinterpret_cast<const char*>(marr + m_tile_off) + mgoff) : (void*)cube, 0,
-                                                              (int)(unsigned)(mleft < 0xffffffffull ? mleft : 0xffffffffull), 0x00020000);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                raw[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff + (unsigned)u * step), 0, /*nt*/ 2));
-                mk[u] = ARR ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)(moff + (unsigned)u * mstep), 0, 2) : 1u;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int z = min(j + L * (i0 + u), nz - 1);
-                raw[u] = __builtin_nontemporal_load(p + (int64_t)z * plane_stride);
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u;
+            const bool chk = i >= kChk0;
+            // all ones when the slot holds a sample of this lane
+            const uint32_t vmu = chk ? (uint32_t)__builtin_amdgcn_sbfe((int)((i - kChk0) < 32 ? vb0 : vb1), (i - kChk0) & 31, 1) : 0xffffffffu;
+            if (DESC) {
+                if (i > 0) {
+                    const bool adv = !chk || (i <= last);
+                    kb += adv ? step : 0u;
+                    if (ARR) mb += adv ? mstep : 0u;
+                }
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, (int)0xffffffffu, 0x00020000);
+                key[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(voff & vmu), 0, /*nt*/ 2);
+                if (ARR) {
+                    const auto rm = __builtin_amdgcn_make_buffer_rsrc((void*)mb, 0, (int)0xffffffffu, 0x00020000);
+                    mk[u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)(moff & vmu), 0, 2);
+                } else {
+                    mk[u] = 1u;
+                }
+            } else {
+                const int z = chk ? min(j + L * i, nz - 1) : j + L * i;
+                key[i] = __float_as_uint(__builtin_nontemporal_load(p + (int64_t)z * plane_stride));
                 mk[u] = ARR ? pm[(int64_t)z * m_plane_stride] : 1u;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);                       // (all loads of the group first)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int zlim = nz - L * (i0 + u);                                  // uniform: the sample exists iff j < zlim
-            const float v = use_cen ? fabsf(raw[u] - cen) : raw[u];
-            // (NaN fails |raw| <= lim; an infinite raw under "no isfinite" passes and |inf - cen| stays a valid key unless
-            //  cen is the same infinity: that NaN is dropped by v == v)
-            const bool ok = (j < zlim) && col_in && (__builtin_fabsf(raw[u]) <= lim) && !(raw[u] <= lo) && !(raw[u] >= hi) &&
-                            (mk[u] != 0) && (v == v);
-            key[i0 + u] = ok ? fkey(v) : 0xffffffffu;
+            const int i = i0 + u;
+            const uint32_t raw = key[i];
+            uint32_t k = fkey_bits(raw);
+            // (beyond the last plane: the excluded key fails the range test)
+            if (i >= kChk0) k |= ~(uint32_t)__builtin_amdgcn_sbfe((int)((i - kChk0) < 32 ? vb0 : vb1), (i - kChk0) & 31, 1);
+            bool ok = (k - kmin) < span_l;
+            if (ARR) ok = ok && (mk[u] != 0u);
+            if (CEN) {
+                // (an infinite raw under "no isfinite" passes and |inf - cen| stays a valid key unless cen is the same
+                //  infinity: that NaN sorts above +inf)
+                k = __float_as_uint(fabsf(__uint_as_float(raw) - cen)) | 0x80000000u;
+                ok = ok && (k <= 0xff800000u);
+            }
+            key[i] = ok ? k : 0xffffffffu;
             mine += ok ? 1 : 0;
         }
         __builtin_amdgcn_sched_barrier(0);                       // U loads in flight, not KPL
     }
     return mine;
+}
+
+template <int TS, int KPL, bool ARR, bool DESC, int BT = 256>
+__device__ __forceinline__ int sel_load_keys(const float* cube, int64_t plane_stride, int64_t x_stride, int64_t tile_off,
+                                             const uint8_t* marr, int64_t m_plane_stride, int64_t m_x_stride, int64_t m_tile_off,
+                                             int rc, int j, int nz, bool col_in, uint32_t kmin, uint32_t span1,
+                                             bool use_cen, float cen, uint32_t (&key)[KPL]) {
+    // (block-uniform branch; the memory clobbers keep the compiler from hoisting the - identical - loads of both arms above
+    //  the branch, where all KPL of them would be in flight at once and spill)
+    if (use_cen) {
+        asm volatile("; keys of |x - centre|" ::: "memory");
+        return sel_load_keys_impl<TS, KPL, ARR, DESC, true, BT>(cube, plane_stride, x_stride, tile_off, marr, m_plane_stride, m_x_stride,
+                                                            m_tile_off, rc, j, nz, col_in, kmin, span1, cen, key);
+    }
+    asm volatile("; keys of x" ::: "memory");
+    return sel_load_keys_impl<TS, KPL, ARR, DESC, false, BT>(cube, plane_stride, x_stride, tile_off, marr, m_plane_stride, m_x_stride,
+                                                         m_tile_off, rc, j, nz, col_in, kmin, span1, 0.f, key);
 }
 
 // LDS scratch of one block of TS rays
@@ -407,20 +483,20 @@ struct SelShared {
 };
 
 // every thread of the block: zero what a descent needs (followed by a barrier at the caller)
-template <int TS>
+template <int TS, int BT = 256>
 __device__ __forceinline__ void sel_reset(SelShared<TS>& S) {
     const int t = threadIdx.x;
     if (t < TS) { S.nvalid[t] = 0u; S.nextkey[t] = 0xffffffffu; S.ncand[t] = 0u; }
-    for (int i = t; i < 3 * TS * 16; i += 256) (&S.hist[0][0][0])[i] = 0u;
+    for (int i = t; i < 3 * TS * 16; i += BT) (&S.hist[0][0][0])[i] = 0u;
 }
 
 // The descent over the registers of the block (all 256 threads call it; barriers inside).  r / j: ray and slice of this
 // lane, n: valid samples of the ray.  Returns the keys of the two order statistics numpy's 'linear' percentile q
 // interpolates between and the interpolation fraction.  S must have been reset (sel_reset + barrier).
-template <int TS, int KPL, class XF>
+template <int TS, int KPL, int BT = 256, class XF = KeyIdentity>
 __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&key)[KPL], const XF& xf, int r, int j, int n, double q,
-                                           uint32_t& key_lo, uint32_t& key_hi, double& frac) {
-    constexpr int kLanesPerRay = 256 / TS;
+                                           uint32_t& key_lo, uint32_t& key_hi, double& frac, int max_pass = 8) {
+    constexpr int kLanesPerRay = BT / TS;
     const double pos = q / 100.0 * (double)(n > 0 ? n - 1 : 0);
     const double fl = floor(pos);
     int k = (int)fl;                                             // rank still to be found inside the current prefix
@@ -431,7 +507,7 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
     int eq = 0;
     bool done = false;                                           // block-uniform
 #pragma unroll 1
-    for (int pass = 0; pass < 8 && !done; ++pass) {
+    for (int pass = 0; pass < max_pass && !done; ++pass) {
         const int b = 28 - 4 * pass;
         unsigned long long accE = 0ull, accO = 0ull;             // even / odd digits, 8 bits each (<= 64 keys per lane)
         // (the first pass has no prefix; `pass` is made opaque so that its digit extraction - which does not depend on
@@ -517,13 +593,14 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
 // numpy's interpolation between the two order statistics (the mean of two for a median), in float64, rounded once
 __device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, double frac, double scale) {
     const double a = (double)funkey(key_lo), bb = (double)funkey(key_hi);
-    return (float)((frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac) * scale);
+    // (equal order statistics - also two infinities of one sign, whose difference is NaN - are the result)
+    return (float)((a == bb ? a : (frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac)) * scale);
 }
 
-template <int TS, int KPL, bool ARR, bool DESC>
-__global__ __launch_bounds__(256, KPL == 128 ? 2 : 5) void select_reg_kernel(const SelArgs A) {
+template <int TS, int KPL, bool ARR, bool DESC, int BT = 256>
+__global__ __launch_bounds__(BT, BT == 256 ? (KPL == 128 ? 2 : 5) : (BT == 512 ? 4 : 1)) void select_reg_kernel(const SelArgs A) {
     __shared__ SelShared<TS> S;
-    constexpr int kLanesPerRay = 256 / TS;
+    constexpr int kLanesPerRay = BT / TS;
     const int t = threadIdx.x;
     // ray of the tile, slice of the ray: adjacent lanes hold adjacent spaxels - or, for rays along x, adjacent samples
     const int r = A.along_ray ? t / kLanesPerRay : t % TS, j = A.along_ray ? t % kLanesPerRay : t / TS;
@@ -533,21 +610,33 @@ __global__ __launch_bounds__(256, KPL == 128 ? 2 : 5) void select_reg_kernel(con
     const bool col_in = x0 + r < A.nx;
     const bool use_cen = A.center != nullptr;
     const float cen = (use_cen && col_in) ? A.center[y * A.nx + x0 + r] : 0.f;
-    sel_reset<TS>(S);
+    sel_reset<TS, BT>(S);
     __syncthreads();
     // ---- the one read of the cube: keys into registers (excluded / NaN / beyond nz: the largest key)
     uint32_t key[KPL];
     const int rc = col_in ? r : (int)(A.nx - 1 - x0);
-    const int tile_cols = (int)min((int64_t)TS, A.nx - x0);
     const int64_t tile_off = y * A.row_stride + x0 * A.x_stride, m_tile_off = ARR ? y * A.mask.row_stride + x0 * A.m_x_stride : 0;
-    const int mine = sel_load_keys<TS, KPL, ARR, DESC>(A.cube, A.plane_stride, A.x_stride, tile_off, A.mask.arr, A.mask.plane_stride, A.m_x_stride,
-                                                 m_tile_off, rc, j, nz, tile_cols, col_in, A.pred_lim, A.pred_lo, A.pred_hi, use_cen, cen, key);
+    const int mine = sel_load_keys<TS, KPL, ARR, DESC, BT>(A.cube, A.plane_stride, A.x_stride, tile_off, A.mask.arr, A.mask.plane_stride, A.m_x_stride,
+                                                 m_tile_off, rc, j, nz, col_in, A.key_min, A.key_span, use_cen, cen, key);
     if (mine) atomicAdd(&S.nvalid[r], (uint32_t)mine);
     __syncthreads();
     const int n = (int)S.nvalid[r];
     uint32_t key_lo, key_hi;
     double frac;
-    ray_select<TS, KPL>(S, key, KeyIdentity{}, r, j, n, A.q, key_lo, key_hi, frac);
+#ifdef SPC_ABLATE
+    if (A.ablate == 1) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) x ^= key[i];
+        if (j == 0 && col_in) A.out[y * A.nx + x0 + r] = __uint_as_float(x + n);
+        return;
+    }
+#endif
+#ifdef SPC_ABLATE
+    ray_select<TS, KPL, BT>(S, key, KeyIdentity{}, r, j, n, A.q, key_lo, key_hi, frac, A.ablate >= 2 ? A.ablate - 1 : 8);
+#else
+    ray_select<TS, KPL, BT>(S, key, KeyIdentity{}, r, j, n, A.q, key_lo, key_hi, frac);
+#endif
     if (j == 0 && col_in) A.out[y * A.nx + x0 + r] = n > 0 ? sel_value(key_lo, key_hi, frac, (double)A.scale) : NAN;
 }
 
@@ -569,13 +658,13 @@ struct ClipRegArgs {
     int maxiters;               // < 0: until convergence
     int cen_mean;               // centre: 0 median, 1 mean
     int spread_mad;             // spread: 0 std, 1 mad_std
-    float pred_lim, pred_lo, pred_hi;      // spc_canonical_pred of the mask's predicate terms (filled by the launcher)
+    uint32_t key_min, key_span;            // sel_key_range of the mask's predicate terms (filled by the launcher)
 };
 
-template <int TS, int KPL, bool ARR, bool MAD, bool DESC>
-__global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+template <int TS, int KPL, bool ARR, bool MAD, bool DESC, int BT = 256>
+__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     __shared__ SelShared<TS> S;
-    constexpr int kLanesPerRay = 256 / TS;
+    constexpr int kLanesPerRay = BT / TS;
     __shared__ double part_s[TS][kLanesPerRay], part_q[TS][kLanesPerRay];
     const int t = threadIdx.x;
     const int r = t % TS, j = t / TS;
@@ -584,14 +673,14 @@ __global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_cli
     const int nz = (int)A.nz;
     const bool col_in = x0 + r < A.nx;
     uint32_t key[KPL];
-    sel_load_keys<TS, KPL, ARR, DESC>(A.cube, A.plane_stride, 1, y * A.row_stride + x0, A.mask.arr, A.mask.plane_stride, 1,
+    sel_load_keys<TS, KPL, ARR, DESC, BT>(A.cube, A.plane_stride, 1, y * A.row_stride + x0, A.mask.arr, A.mask.plane_stride, 1,
                                 ARR ? y * A.mask.row_stride + x0 : 0, col_in ? r : (int)(A.nx - 1 - x0), j, nz,
-                                (int)min((int64_t)TS, A.nx - x0), col_in, A.pred_lim, A.pred_lo, A.pred_hi, false, 0.f, key);
+                                col_in, A.key_min, A.key_span, false, 0.f, key);
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
 #pragma unroll 1
     for (int it = 0; A.maxiters < 0 || it < A.maxiters; ++it) {
         // ---- valid count, sum, sum of squares of the ray (what spc_stats_axis_f32 gives the unfused path)
-        sel_reset<TS>(S);
+        sel_reset<TS, BT>(S);
         int cnt = 0;
         double s = 0.0, ss = 0.0;
 #pragma unroll
@@ -623,7 +712,7 @@ __global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_cli
         if (!A.cen_mean || MAD) {
             uint32_t key_lo, key_hi;
             double frac;
-            ray_select<TS, KPL>(S, key, KeyIdentity{}, r, j, n, 50.0, key_lo, key_hi, frac);
+            ray_select<TS, KPL, BT>(S, key, KeyIdentity{}, r, j, n, 50.0, key_lo, key_hi, frac);
             med = n > 0 ? sel_value(key_lo, key_hi, frac, 1.0) : NAN;
             if (!A.cen_mean) cen = (double)med;
         }
@@ -632,7 +721,7 @@ __global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_cli
             // in float32 like spc_percentile_axis0_f32's argument): a second descent over the transformed keys
             const KeyAbsDev xf{med};
             __syncthreads();                                     // the first descent's last reads of S
-            sel_reset<TS>(S);
+            sel_reset<TS, BT>(S);
             __syncthreads();
             int nm = n;
             if (__syncthreads_or((n > 0 && !(fabsf(med) <= 3.4028234664e38f)) ? 1 : 0)) {
@@ -646,7 +735,7 @@ __global__ __launch_bounds__(256, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_cli
             }
             uint32_t key_lo, key_hi;
             double frac;
-            ray_select<TS, KPL>(S, key, xf, r, j, nm, 50.0, key_lo, key_hi, frac);
+            ray_select<TS, KPL, BT>(S, key, xf, r, j, nm, 50.0, key_lo, key_hi, frac);
             const float spread = nm > 0 ? sel_value(key_lo, key_hi, frac, (double)1.482602218505602f) : NAN;
             sd = (double)spread;
             if (A.cen_mean) cen = (double)(float)mean;           // (the loop of separate kernels hands a float32 mean map over)
@@ -765,7 +854,7 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
     SPC_REQUIRE(q >= 0.0 && q <= 100.0, "Percentiles must be in the range [0, 100]");
     SelArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
-    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.pred_lim, &A.pred_lo, &A.pred_hi);
+    sel_key_range(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.key_min, &A.key_span);
     if (rc) return rc;
     SPC_DEVICE(device);
     A.cube = cube->d_data;
@@ -773,6 +862,7 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
     A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
     A.q = q; A.center = d_center; A.scale = scale; A.out = d_out;
     A.x_stride = 1; A.m_x_stride = 1; A.along_ray = 0;
+    { const char* ab = getenv("SPC_SELECT_ABLATE"); A.ablate = ab ? atoi(ab) : 0; }
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     const bool v4 = (cube->nx % 4 == 0) && (cube->row_stride % 4 == 0) && (cube->plane_stride % 4 == 0) &&
                     ((((uintptr_t)cube->d_data) & 15) == 0) &&
@@ -782,6 +872,34 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
     // per block; any strides (a y-ray view included)
     const char* renv = getenv("SPC_SELECT_REG");
     if ((renv ? atoi(renv) != 0 : true) && cube->nz <= 4096 && cube->ny * ((cube->nx + 7) / 8) < (1LL << 31)) {
+        // Blocks of 512 threads (round 3): the lanes of a wave cover 64 / 32 / 16 / 8 ADJACENT spaxels for rays of up to 512 /
+        // 1024 / 2048 / 4096 samples - a plane's samples of a block are one 256 / 128 / 64 / 32-byte run.  With 256 threads
+        // (16 spaxels, 64-byte runs at 1024 channels) the one read of the cube ran at 2.1 TB/s and made up 2.0 of the 2.9 ms
+        // at 1024^3 (timing-only ablation, tests/bench_select_ablate.py); 32 spaxels: 0.92 ms.  SPC_SELECT_BT=256: the former table.
+        {
+            const char* be = getenv("SPC_SELECT_BT");
+            if (!(be && atoi(be) == 256)) {
+                const int64_t nzr = cube->nz;
+                const int ts2 = nzr <= 512 ? 64 : (nzr <= 1024 ? 32 : (nzr <= 2048 ? 16 : 8));
+                const int kpl2 = nzr <= 128 ? 16 : (nzr <= 256 ? 32 : 64);
+                const bool desc2 = sel_desc_fits(ts2, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1, 512) && spc_env_on("SPC_SELECT_DESC");
+                dim3 grid2((unsigned)(cube->ny * ((cube->nx + ts2 - 1) / ts2)));
+#define SPC_LAUNCH_BT(TS_, K_)                                                                                                       \
+                do {                                                                                                                \
+                    if (desc2) { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, true, 512>), grid2, dim3(512), 0, st, A);   \
+                                 else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, true, 512>), grid2, dim3(512), 0, st, A); }    \
+                    else { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, false, 512>), grid2, dim3(512), 0, st, A);        \
+                           else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, false, 512>), grid2, dim3(512), 0, st, A); }         \
+                } while (0)
+                if (ts2 == 64) { if (kpl2 == 16) SPC_LAUNCH_BT(64, 16); else if (kpl2 == 32) SPC_LAUNCH_BT(64, 32); else SPC_LAUNCH_BT(64, 64); }
+                else if (ts2 == 32) SPC_LAUNCH_BT(32, 64);
+                else if (ts2 == 16) SPC_LAUNCH_BT(16, 64);
+                else SPC_LAUNCH_BT(8, 64);
+#undef SPC_LAUNCH_BT
+                SPC_LAUNCH_CHECK();
+                return SPC_OK;
+            }
+        }
         const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
         // (descriptor loads: measured no gain for the selection - 3.64 against 3.25 ms with a uint8 mask, 2.61 against 2.65 ms
         //  without, 1024^3 - its time is in the digit passes; they pay for the clip kernel: 10.1 against 10.8 ms, mad_std 28.3
@@ -902,7 +1020,7 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     if (n == 0) { *h_out = NAN; return SPC_OK; }
     auto unkey = [](uint32_t kk) { uint32_t u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk; float f; memcpy(&f, &u, 4); return (double)f; };
     const double a = unkey(key_lo), b = unkey(key_hi);
-    *h_out = (frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac;
+    *h_out = (a == b) ? a : ((frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac);
     return SPC_OK;
 }
 
@@ -922,7 +1040,7 @@ extern "C" int spc_percentile_axis2_f32(int device, void* stream, const spc_cube
     }
     SelArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
-    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.pred_lim, &A.pred_lo, &A.pred_hi);
+    sel_key_range(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.key_min, &A.key_span);
     if (rc) return rc;
     SPC_DEVICE(device);
     // the view: samples along x (step 1), rows = channels (step plane_stride), adjacent spaxels = adjacent rows y
@@ -975,7 +1093,7 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     }
     ClipRegArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
-    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.pred_lim, &A.pred_lo, &A.pred_hi);
+    sel_key_range(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.key_min, &A.key_span);
     if (rc) return rc;
     SPC_DEVICE(device);
     A.cube = cube->d_data;
@@ -986,6 +1104,8 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     A.spread_mad = spread_is_mad ? 1 : 0;
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
+    // (256-thread blocks here: with 512 threads - wider runs per plane, see spc_percentile_axis0_f32 - the clip loop, which is
+    //  compute and barrier bound and runs until the LAST ray of the block has converged, measured 12 ms against 9.5 - 10 ms)
     const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
     const bool desc = sel_desc_fits(ts, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1) && spc_env_on("SPC_SELECT_DESC");
     const int lanes = 256 / ts;

@@ -292,7 +292,7 @@ def test_chunk_functions_under_dask_map_blocks(gpu, tmp_path):
     assert r.returncode == 0 and "DASK_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (515, 2, 37), (1030, 2, 21), (2050, 1, 12), (4100, 1, 5)])
+@pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (130, 2, 70), (260, 3, 67), (515, 2, 37), (1030, 2, 21), (2050, 1, 12), (4100, 1, 5)])
 def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
     """np.nanmedian / np.nanpercentile of masked rays through every selection kernel: the register-resident rays
     (32 / 16 / 8 spaxels per block and 16 - 128 keys per lane by ray length, lengths that are no multiple of the lanes per ray, tiles hanging
@@ -317,8 +317,10 @@ def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
         e30 = np.nanpercentile(fz.astype(np.float64), 30.0, axis=0)
         emad = np.nanmedian(np.abs(fz - emed[None]), axis=0)
         emed_nomask = np.nanmedian(d, axis=0)
-    for env in ({}, {"SPC_SELECT_REG": "0"}, {"SPC_SELECT_REG": "0", "SPC_SELECT_RADIX16": "0"}):
-        for k in ("SPC_SELECT_REG", "SPC_SELECT_RADIX16"):
+    # (default: 512-thread blocks, descriptor loads; then 64-bit addresses, the 256-thread table with and without descriptors)
+    for env in ({}, {"SPC_SELECT_DESC": "0"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "1"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "0"},
+                {"SPC_SELECT_REG": "0"}, {"SPC_SELECT_REG": "0", "SPC_SELECT_RADIX16": "0"}):
+        for k in ("SPC_SELECT_REG", "SPC_SELECT_RADIX16", "SPC_SELECT_BT", "SPC_SELECT_DESC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -330,6 +332,52 @@ def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
         np.testing.assert_allclose(got30, e30, rtol=3e-6, atol=1e-7, equal_nan=True)
         mad = ops.percentile_axis0(dd, 50.0, mask=spec, center=med).get()
         assert np.array_equal(mad, emad, equal_nan=True), env
+
+
+def test_order_statistics_mask_predicates_as_key_intervals(gpu):
+    """The register-resident selection and the clip kernel test a sample's validity with ONE unsigned range test on its
+    order-preserving key (sel_key_range: NaN, isfinite and every threshold comparison select a key interval).  Every
+    comparison x thresholds at the awkward values (+-0, +-inf, NaN, a denormal, FLT_MAX) x data holding +-0, +-inf, NaN,
+    denormals: the median of what numpy's comparison keeps (masks.py:670-758 semantics), bit for bit."""
+    import warnings
+    from spectral_cube_amd import ops, _lib
+    from spectral_cube_amd.device import DeviceArray
+    rng = np.random.default_rng(77)
+    nz, ny, nx = 96, 3, 40
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    # (no +-FLT_MAX samples: numpy's float32 mean of two of them overflows to inf, the float64 interpolation here does not)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e38, -1e38, 0.3, -0.3], np.float32)
+    pick = rng.random(d.shape) < 0.4
+    d[pick] = special[rng.integers(0, len(special), int(pick.sum()))]
+    dd = DeviceArray.from_numpy(d)
+    cmpf = {_lib.MASK_GT: np.greater, _lib.MASK_GE: np.greater_equal, _lib.MASK_LT: np.less, _lib.MASK_LE: np.less_equal}
+    thr = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, 3.4028235e38, 0.3, -0.3]
+    cases = [(f, t, None) for f in cmpf for t in thr]
+    cases += [(_lib.MASK_GT | _lib.MASK_LT, -0.3, 0.3), (_lib.MASK_GE | _lib.MASK_LE, -0.0, 0.0), (_lib.MASK_GE | _lib.MASK_LT, 0.0, np.inf),
+              (_lib.MASK_GT | _lib.MASK_LE | _lib.MASK_FINITE, -np.inf, np.inf), (_lib.MASK_FINITE, None, None), (0, None, None)]
+    for flags, a, b in cases:
+        inc = ~np.isnan(d)
+        lo = hi = 0.0
+        with np.errstate(invalid="ignore"):
+            if flags & _lib.MASK_FINITE:
+                inc &= np.isfinite(d)
+            for f in (_lib.MASK_GT, _lib.MASK_GE):
+                if flags & f:
+                    lo = a
+                    inc &= cmpf[f](d, np.float32(a))
+            for f in (_lib.MASK_LT, _lib.MASK_LE):
+                if flags & f:
+                    hi = a if b is None else b
+                    inc &= cmpf[f](d, np.float32(hi))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            exp = np.nanmedian(np.where(inc, d, np.nan).astype(np.float32), axis=0)
+        got = ops.percentile_axis0(dd, 50.0, mask=ops.MaskSpec(flags, lo, hi)).get()
+        assert np.array_equal(got, exp, equal_nan=True), (flags, a, b)
+        # the clip kernel loads through the same test: nothing clipped (huge sigma) -> the filled cube
+        if np.isfinite(d[inc]).all():
+            clipped = ops.sigma_clip_axis0(dd, sigma=1e30, mask=ops.MaskSpec(flags, lo, hi), maxiters=1).get()
+            assert np.array_equal(clipped, np.where(inc, d, np.nan).astype(np.float32), equal_nan=True), (flags, a, b)
 
 
 @pytest.mark.parametrize("ntaps,sym", [(9, True), (17, True), (33, True), (33, False), (13, False)])
