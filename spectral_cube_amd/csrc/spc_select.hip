@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void select_axis0_kernel(const SelArgs A) {
             // numpy's linear interpolation between the two order statistics (a + (b - a) * t; the
             // median of an even count is their mean)
             const double t = frac[c];
-            res = (float)((a == bb ? a : (t == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * t)) * (double)A.scale);   // (a == b: also +-inf)
+            res = (float)(((A.q == 50.0 && a == bb) ? a : (t == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * t)) * (double)A.scale);   // (median of equal infinities)
         }
         A.out[y * A.nx + x + c] = res;
     }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
         if (n[c] > 0) {
             const double a = (double)funkey(plo[c]), bb = (double)funkey(phi[c]);
             const double tt = frac[c];
-            res = (float)((a == bb ? a : (tt == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * tt)) * (double)A.scale);
+            res = (float)(((A.q == 50.0 && a == bb) ? a : (tt == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * tt)) * (double)A.scale);
         }
         A.out[y * A.nx + x + c] = res;
     }
@@ -478,36 +478,108 @@ __device__ __forceinline__ int sel_load_keys(const float* cube, int64_t plane_st
 template <int TS>
 struct SelShared {
     uint32_t hist[3][TS][16];
-    uint32_t nvalid[TS], nextkey[TS], ncand[TS], sel_key[TS], sel_below[TS], sel_eq[TS];
+    uint32_t nvalid[TS], nextkey[TS], ncand[TS], sel_key[TS], sel_below[TS], sel_eq[TS], nlow[TS];
     uint32_t cand[TS][kCandMax];
+    int level;                                                  // (SelCache: the pass a descent resumes after)
+};
+
+// What a descent knew after each of its first four passes (4, 8, 12, 16 key bits), per ray: the prefix, how many keys
+// lie below the prefix' bin and how many inside it.  A later descent over the SAME keys for another rank resumes after
+// the deepest pass whose bin still holds that rank (the clip loop: the median moves by a few ranks per iteration).
+template <int TS>
+struct SelCache {
+    uint32_t prefix[4][TS], below[4][TS], eq[4][TS];
 };
 
 // every thread of the block: zero what a descent needs (followed by a barrier at the caller)
 template <int TS, int BT = 256>
 __device__ __forceinline__ void sel_reset(SelShared<TS>& S) {
     const int t = threadIdx.x;
-    if (t < TS) { S.nvalid[t] = 0u; S.nextkey[t] = 0xffffffffu; S.ncand[t] = 0u; }
+    if (t < TS) { S.nvalid[t] = 0u; S.nextkey[t] = 0xffffffffu; S.ncand[t] = 0u; S.nlow[t] = 0u; }
+    if (t == 0) S.level = 3;
     for (int i = t; i < 3 * TS * 16; i += BT) (&S.hist[0][0][0])[i] = 0u;
 }
 
-// The descent over the registers of the block (all 256 threads call it; barriers inside).  r / j: ray and slice of this
-// lane, n: valid samples of the ray.  Returns the keys of the two order statistics numpy's 'linear' percentile q
+// 16 bits of the key known: few samples are left in the bin.  All rays of the block small enough -> rank them directly
+// (k: rank inside the bin; on success prefix / below / eq describe the selected KEY).  Block-uniform result.
+template <int TS, int KPL, int BT, class XF>
+__device__ __forceinline__ bool sel_rank_candidates(SelShared<TS>& S, const uint32_t (&key)[KPL], const XF& xf, int r, int j, int n, int k,
+                                                    uint32_t& prefix, int& below, int& eq) {
+    constexpr int kLanesPerRay = BT / TS;
+    const bool big = (n > 0) && (eq > kCandMax);
+    if (__syncthreads_or(big ? 1 : 0)) return false;
+    if (n > 0) {
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const uint32_t ki = xf(key[i]);
+            if (((ki ^ prefix) >> 16) == 0u) {
+                const uint32_t slot = atomicAdd(&S.ncand[r], 1u);
+                S.cand[r][slot] = ki;
+            }
+        }
+    }
+    __syncthreads();
+    if (n > 0) {
+        for (int idx = j; idx < eq; idx += kLanesPerRay) {
+            const uint32_t c = S.cand[r][idx];
+            int less = 0, same_before = 0, same = 0;
+            for (int m = 0; m < eq; ++m) {
+                const uint32_t o = S.cand[r][m];
+                less += (o < c) ? 1 : 0;
+                same += (o == c) ? 1 : 0;
+                same_before += (o == c && m < idx) ? 1 : 0;
+            }
+            if (less + same_before == k) { S.sel_key[r] = c; S.sel_below[r] = (uint32_t)(below + less); S.sel_eq[r] = (uint32_t)same; }
+        }
+    }
+    __syncthreads();
+    if (n > 0) { prefix = S.sel_key[r]; below = (int)S.sel_below[r]; eq = (int)S.sel_eq[r]; }
+    return true;
+}
+
+// The descent over the registers of the block (all threads call it; barriers inside).  r / j: ray and slice of this
+// lane, n: valid samples of the ray, rank0: samples of the key set that sort below them (the clip loop keeps its keys
+// and moves a window over them).  Returns the keys of the two order statistics numpy's 'linear' percentile q
 // interpolates between and the interpolation fraction.  S must have been reset (sel_reset + barrier).
+// C: cache of this key set's descents (filled; consulted when `resume`, block-uniform), or nullptr.
 template <int TS, int KPL, int BT = 256, class XF = KeyIdentity>
 __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&key)[KPL], const XF& xf, int r, int j, int n, double q,
-                                           uint32_t& key_lo, uint32_t& key_hi, double& frac, int max_pass = 8) {
-    constexpr int kLanesPerRay = BT / TS;
+                                           uint32_t& key_lo, uint32_t& key_hi, double& frac, int max_pass = 8, int rank0 = 0,
+                                           SelCache<TS>* C = nullptr, bool resume = false) {
     const double pos = q / 100.0 * (double)(n > 0 ? n - 1 : 0);
     const double fl = floor(pos);
-    int k = (int)fl;                                             // rank still to be found inside the current prefix
-    const int khi = min((int)ceil(pos), max(n - 1, 0));
+    int k = rank0 + (int)fl;                                     // rank still to be found inside the current prefix
+    const int khi = rank0 + min((int)ceil(pos), max(n - 1, 0));
     frac = pos - fl;
     int below = 0;                                               // keys smaller than everything matching the prefix
     uint32_t prefix = 0u;
     int eq = 0;
     bool done = false;                                           // block-uniform
+    int start = 0;
+    if (C != nullptr && resume) {
+        // the deepest cached pass whose bin holds rank k (the bins are nested); the block resumes after the shallowest
+        // of its rays' answers (rays without samples do not care)
+        int lvl = 3;
+        if (n > 0) {
+            lvl = -1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if ((uint32_t)k - C->below[p][r] < C->eq[p][r]) lvl = p;
+        }
+        if (j == 0 && lvl < 3) atomicMin(&S.level, lvl);
+        __syncthreads();
+        const int sl = S.level;
+        if (sl >= 0) {
+            prefix = C->prefix[sl][r];
+            below = (int)C->below[sl][r];
+            eq = (int)C->eq[sl][r];
+            k -= below;
+            start = sl + 1;
+        }
+    }
+    const bool from16 = (start == 4);                            // resuming with 16 bits known: straight to the candidates
 #pragma unroll 1
-    for (int pass = 0; pass < max_pass && !done; ++pass) {
+    for (int pass = start; pass < max_pass && !done && !from16; ++pass) {
         const int b = 28 - 4 * pass;
         unsigned long long accE = 0ull, accO = 0ull;             // even / odd digits, 8 bits each (<= 64 keys per lane)
         // (the first pass has no prefix; `pass` is made opaque so that its digit extraction - which does not depend on
@@ -540,37 +612,42 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
             }
         }
         prefix |= dsel << b;
-        if (pass == 3) {
-            // 16 bits known: few samples are left in the bin.  All rays of the block small enough -> rank them directly
-            const bool big = (n > 0) && (eq > kCandMax);
-            if (!__syncthreads_or(big ? 1 : 0)) {
-                if (n > 0) {
+        if (C != nullptr && pass < 4 && j == 0) { C->prefix[pass][r] = prefix; C->below[pass][r] = (uint32_t)below; C->eq[pass][r] = (uint32_t)eq; }
+        if (pass == 3) done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq);
+    }
+    if (from16) {
+        // resumed with 16 bits known (no pass ran): the candidates of the bin, or - a bin of many ties - the last passes
+        done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq);
+        if (!done) {
+#pragma unroll 1
+            for (int pass = 4; pass < max_pass; ++pass) {
+                const int b = 28 - 4 * pass;
+                unsigned long long accE = 0ull, accO = 0ull;
+                count_keys<KPL, false>(key, prefix, b, xf, accE, accO);
+                uint32_t* h = S.hist[pass % 3][r];
+                uint32_t* hz = S.hist[(pass + 1) % 3][r];
 #pragma unroll
-                    for (int i = 0; i < KPL; ++i) {
-                        const uint32_t ki = xf(key[i]);
-                        if (((ki ^ prefix) >> 16) == 0u) {
-                            const uint32_t slot = atomicAdd(&S.ncand[r], 1u);
-                            S.cand[r][slot] = ki;
-                        }
-                    }
+                for (int d = 0; d < 8; ++d) {
+                    const uint32_t c0 = (uint32_t)(accE >> (8 * d)) & 0xffu, c1 = (uint32_t)(accO >> (8 * d)) & 0xffu;
+                    if (c0) atomicAdd(&h[2 * d], c0);
+                    if (c1) atomicAdd(&h[2 * d + 1], c1);
+                }
+                if (j == 0) {
+#pragma unroll
+                    for (int d = 0; d < 16; ++d) hz[d] = 0u;
                 }
                 __syncthreads();
-                if (n > 0) {
-                    for (int idx = j; idx < eq; idx += kLanesPerRay) {
-                        const uint32_t c = S.cand[r][idx];
-                        int less = 0, same_before = 0, same = 0;
-                        for (int m = 0; m < eq; ++m) {
-                            const uint32_t o = S.cand[r][m];
-                            less += (o < c) ? 1 : 0;
-                            same += (o == c) ? 1 : 0;
-                            same_before += (o == c && m < idx) ? 1 : 0;
-                        }
-                        if (less + same_before == k) { S.sel_key[r] = c; S.sel_below[r] = (uint32_t)(below + less); S.sel_eq[r] = (uint32_t)same; }
+                uint32_t dsel = 15u;
+                bool found = false;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const int c = (int)h[d];
+                    if (!found) {
+                        if (k < c) { dsel = d; found = true; eq = c; }
+                        else { k -= c; below += c; }
                     }
                 }
-                __syncthreads();
-                if (n > 0) { prefix = S.sel_key[r]; below = (int)S.sel_below[r]; eq = (int)S.sel_eq[r]; }
-                done = true;
+                prefix |= dsel << b;
             }
         }
     }
@@ -591,10 +668,11 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
 }
 
 // numpy's interpolation between the two order statistics (the mean of two for a median), in float64, rounded once
-__device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, double frac, double scale) {
+__device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, double frac, double scale, bool median = true) {
     const double a = (double)funkey(key_lo), bb = (double)funkey(key_hi);
-    // (equal order statistics - also two infinities of one sign, whose difference is NaN - are the result)
-    return (float)((a == bb ? a : (frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac)) * scale);
+    // (np.nanmedian of an odd count is the middle sample itself - also an infinity; np.nanpercentile's lerp a + (b - a) t
+    //  between two equal infinities is NaN, and so is it here)
+    return (float)(((median && a == bb) ? a : (frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac)) * scale);
 }
 
 template <int TS, int KPL, bool ARR, bool DESC, int BT = 256>
@@ -637,7 +715,7 @@ __global__ __launch_bounds__(BT, BT == 256 ? (KPL == 128 ? 2 : 5) : (BT == 512 ?
 #else
     ray_select<TS, KPL, BT>(S, key, KeyIdentity{}, r, j, n, A.q, key_lo, key_hi, frac);
 #endif
-    if (j == 0 && col_in) A.out[y * A.nx + x0 + r] = n > 0 ? sel_value(key_lo, key_hi, frac, (double)A.scale) : NAN;
+    if (j == 0 && col_in) A.out[y * A.nx + x0 + r] = n > 0 ? sel_value(key_lo, key_hi, frac, (double)A.scale, A.q == 50.0) : NAN;
 }
 
 // ---- sigma clipping with the rays resident in registers -------------------------------------------------
@@ -661,9 +739,20 @@ struct ClipRegArgs {
     uint32_t key_min, key_span;            // sel_key_range of the mask's predicate terms (filled by the launcher)
 };
 
+// |x - centre| of the samples inside the clip window (the MAD's keys)
+struct KeyAbsDevWin {
+    float center;
+    uint32_t wlo, wspan;
+    __device__ __forceinline__ uint32_t operator()(uint32_t k) const {
+        const float v = fabsf(funkey(k) - center);
+        return ((k - wlo) < wspan && v == v) ? fkey(v) : 0xffffffffu;
+    }
+};
+
 template <int TS, int KPL, bool ARR, bool MAD, bool DESC, int BT = 256>
 __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     __shared__ SelShared<TS> S;
+    __shared__ SelCache<TS> C;
     constexpr int kLanesPerRay = BT / TS;
     __shared__ double part_s[TS][kLanesPerRay], part_q[TS][kLanesPerRay];
     const int t = threadIdx.x;
@@ -677,17 +766,30 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip
                                 ARR ? y * A.mask.row_stride + x0 : 0, col_in ? r : (int)(A.nx - 1 - x0), j, nz,
                                 col_in, A.key_min, A.key_span, false, 0.f, key);
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    // The keys stay as loaded.  Clipping v < lo || v > hi removes the two ENDS of a ray's sorted samples, so what is left
+    // is a window of keys [wlo, wlo + wspan): an iteration counts and sums the samples inside it, asks the resident key
+    // set for the rank (samples below the window) + (n - 1) / 2 - a descent that resumes from the cached bins of the
+    // earlier iterations' descents, the median moving by a few ranks only (round 3a re-ran all four passes over keys it
+    // had overwritten: 1.9 ms per iteration at 1024^3) - and narrows the window.
+    uint32_t wlo = 0u, wspan = 0xff800001u;                      // every valid key (the excluded one lies above)
+    int n_prev = -1;
+    bool cached = false;                                         // block-uniform: C holds an earlier iteration's descent
 #pragma unroll 1
     for (int it = 0; A.maxiters < 0 || it < A.maxiters; ++it) {
+        // (the keys never change, so everything an iteration derives from them alone - 64 floats, doubles, digits - would be
+        //  hoisted out of the loop and spilled: they are made opaque once per iteration, which costs no instruction)
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) asm volatile("" : "+v"(key[i]));
         // ---- valid count, sum, sum of squares of the ray (what spc_stats_axis_f32 gives the unfused path)
         sel_reset<TS, BT>(S);
-        int cnt = 0;
+        int cnt = 0, low = 0;
         double s = 0.0, ss = 0.0;
 #pragma unroll
         for (int i = 0; i < KPL; ++i) {
-            const bool ok = key[i] != 0xffffffffu;
+            const bool ok = (key[i] - wlo) < wspan;
             const double v = ok ? (double)funkey(key[i]) : 0.0;
             cnt += ok ? 1 : 0;
+            low += (key[i] < wlo) ? 1 : 0;
             s += v;
             ss = fma(v, v, ss);
             if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
@@ -696,11 +798,15 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip
         part_q[r][j] = ss;
         __syncthreads();                                         // (also orders sel_reset before the counts)
         if (cnt) atomicAdd(&S.nvalid[r], (uint32_t)cnt);
+        if (low) atomicAdd(&S.nlow[r], (uint32_t)low);
         double sum = 0.0, ssq = 0.0;
 #pragma unroll 4
         for (int l = 0; l < kLanesPerRay; ++l) { sum += part_s[r][l]; ssq += part_q[r][l]; }
         __syncthreads();
-        const int n = (int)S.nvalid[r];
+        const int n = (int)S.nvalid[r], nl = (int)S.nlow[r];
+        // (the previous iteration clipped nothing anywhere in the block: astropy stops there)
+        if (it > 0 && !__syncthreads_or(n != n_prev ? 1 : 0)) break;
+        n_prev = n;
         double mean = nan, sd = nan;
         if (n > 0) {
             mean = sum / (double)n;
@@ -712,14 +818,15 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip
         if (!A.cen_mean || MAD) {
             uint32_t key_lo, key_hi;
             double frac;
-            ray_select<TS, KPL, BT>(S, key, KeyIdentity{}, r, j, n, 50.0, key_lo, key_hi, frac);
+            ray_select<TS, KPL, BT>(S, key, KeyIdentity{}, r, j, n, 50.0, key_lo, key_hi, frac, 8, nl, &C, cached);
+            cached = true;
             med = n > 0 ? sel_value(key_lo, key_hi, frac, 1.0) : NAN;
             if (!A.cen_mean) cen = (double)med;
         }
         if (MAD) {
             // spread = 1.4826 x the median of |x - median| (astropy mad_std; float32 deviations like numpy's, the scale
             // in float32 like spc_percentile_axis0_f32's argument): a second descent over the transformed keys
-            const KeyAbsDev xf{med};
+            const KeyAbsDevWin xf{med, wlo, wspan};
             __syncthreads();                                     // the first descent's last reads of S
             sel_reset<TS, BT>(S);
             __syncthreads();
@@ -742,29 +849,24 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip
         }
         const float lo = (float)__dsub_rn(cen, __dmul_rn(A.lo_s, sd));
         const float hi = (float)__dadd_rn(cen, __dmul_rn(A.hi_s, sd));
-        int changed = 0;
-#pragma unroll
-        for (int i = 0; i < KPL; ++i) {
-            // (opaque copy: otherwise the 64 floats of the statistics loop are kept alive across the selection)
-            uint32_t kk = key[i];
-            asm volatile("" : "+v"(kk));
-            const float v = funkey(kk);                           // (the excluded key is a NaN pattern: compares false)
-            const bool out_of = (key[i] != 0xffffffffu) && (v < lo || v > hi);
-            key[i] = out_of ? 0xffffffffu : key[i];
-            changed |= out_of ? 1 : 0;
-            if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+        // v < lo  <=>  key < key(lo), v > hi  <=>  key > key(hi); a bound of either zero keeps both zeros; NaN bounds clip nothing
+        if (wspan != 0u) {
+            const uint32_t klo = (lo == lo) ? fkey(lo == 0.f ? -0.f : lo) : 0u;
+            const uint32_t khi = (hi == hi) ? fkey(hi == 0.f ? 0.f : hi) : 0xff800000u;
+            const uint32_t nlo = max(wlo, klo), nhi = min(wlo + (wspan - 1u), khi);
+            wlo = nlo;
+            wspan = nhi >= nlo ? nhi - nlo + 1u : 0u;
         }
-        if (!__syncthreads_or(changed)) break;
     }
     // ---- the clipped rays, written once
     if (col_in) {
-        float* q = A.out + y * A.nx + x0 + r;
+        float* q = A.out + y * A.nx + x0 + r + (int64_t)j * A.ny * A.nx;
+        const int64_t qstep = (int64_t)kLanesPerRay * A.ny * A.nx;
 #pragma unroll
         for (int i = 0; i < KPL; ++i) {
             const int z = j + kLanesPerRay * i;
-            uint32_t kk = key[i];
-            asm volatile("" : "+v"(kk));
-            if (z < nz) q[(int64_t)z * A.ny * A.nx] = funkey(kk);   // (the excluded key is a NaN)
+            if (z < nz) *q = ((key[i] - wlo) < wspan) ? funkey(key[i]) : NAN;
+            q += qstep;
             if (i % 8 == 7) __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1020,7 +1122,7 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     if (n == 0) { *h_out = NAN; return SPC_OK; }
     auto unkey = [](uint32_t kk) { uint32_t u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk; float f; memcpy(&f, &u, 4); return (double)f; };
     const double a = unkey(key_lo), b = unkey(key_hi);
-    *h_out = (a == b) ? a : ((frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac);
+    *h_out = (q == 50.0 && a == b) ? a : ((frac == 0.5) ? 0.5 * (a + b) : a + (b - a) * frac);
     return SPC_OK;
 }
 

@@ -402,7 +402,7 @@ def sharded_percentile(strip, q, transport, mask=None, center=None, passes=None)
         return float("nan")
     a, b, frac = unkey(r[0]), unkey(r[1]), r[2]
     with np.errstate(invalid="ignore"):
-        return float(a if a == b else (0.5 * (a + b) if frac == 0.5 else a + (b - a) * frac))
+        return float(a if (float(q) == 50.0 and a == b) else (0.5 * (a + b) if frac == 0.5 else a + (b - a) * frac))
 
 
 def sharded_smooth_moment0(strip_cube, kernel, ny_total, comm):
