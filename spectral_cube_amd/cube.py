@@ -52,6 +52,11 @@ class UnitsError(ValueError):
     """stands in for astropy.units.UnitsError"""
 
 
+class WCSCelestialError(ValueError):
+    """spectral_cube.utils.WCSCelestialError (utils.py:95): an image without two celestial axes was asked for a
+    celestial operation (lower_dimensional_structures.py:450-538)."""
+
+
 class BeamUnitsError(Exception):
     """spectral_cube.utils.BeamUnitsError (base_class.py:134-137)"""
 
@@ -134,7 +139,7 @@ class Projection(np.ndarray):
 
     def _celestial(self):
         if self.ndim != 2 or self.wcs is None or getattr(self.wcs, "naxis", 0) < 2:
-            raise ValueError("WCS does not contain two spatial axes.")      # _raise_wcs_no_celestial
+            raise WCSCelestialError("WCS does not contain two spatial axes.")      # _raise_wcs_no_celestial
         return self.wcs
 
     def convolve_to(self, beam, convolve=None, **kwargs):

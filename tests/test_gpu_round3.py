@@ -362,3 +362,39 @@ def test_out_of_core_spatial_smooth_with_halo_rows(gpu, tmp_path, monkeypatch):
     ok = inc & np.isfinite(d) & np.isfinite(e)
     assert np.array_equal(np.isfinite(out), ok)
     assert np.abs(out[ok] - e[ok]).max() <= 1e-5 * np.abs(e[ok]).max()
+
+
+def test_reference_reproject_3d_case_car_to_sin(gpu):
+    """tests/test_regrid.py:511-587 (test_reproject_3D_memory) without its memory accounting: the cube of
+    tests/utilities.py:14-37 (GLON-CAR / GLAT-CAR at 0, 0, 1 arcsec pixels, VRAD in km/s) reprojected onto GLON-SIN /
+    GLAT-SIN at 0.001, 0.001 deg with CRPIX 2, half the image size; ``filled=False``, ``filled=True``, and a masked cube
+    (``cube > 0.1``: masked voxels enter as NaN).  The reference asserts the result's CRVAL / CRPIX; the values here are
+    held to the oracle resampler at the host pixel map (both projections pinned against wcslib,
+    tests/golden/wcs_projections.npz)."""
+    from spectral_cube_amd import synth
+    from spectral_cube_amd.wcs import reproject_pixel_map
+    nz, ny, nx = 40, 200, 200
+    d = synth.gaussian_line_cube((nz, ny, nx), 77)
+    px = 1.0 / 3600.0
+    hdr = dict(NAXIS=3, NAXIS1=nx, NAXIS2=ny, NAXIS3=nz, CDELT1=-px, CDELT2=px, CRPIX1=nx / 2.0, CRPIX2=ny / 2.0, CRVAL1=0.0, CRVAL2=0.0,
+               CTYPE1="GLON-CAR", CTYPE2="GLAT-CAR", CUNIT1="deg", CUNIT2="deg", CRVAL3=-20.0, CUNIT3="km/s", CDELT3=1.0, CRPIX3=1,
+               CTYPE3="VRAD", BUNIT="K", BMAJ=3 * px, BMIN=3 * px, BPA=0.0)
+    cube = SpectralCube.read(d, hdr)
+    hout = dict(hdr, CTYPE1="GLON-SIN", CTYPE2="GLAT-SIN", CRVAL1=0.001, CRVAL2=0.001, CRPIX1=2.0, CRPIX2=2.0, NAXIS1=nx // 2, NAXIS2=ny // 2)
+    xs, ys = reproject_pixel_map(SimpleWCS(hdr, naxis=2), SimpleWCS(hout, naxis=2), (ny // 2, nx // 2))
+    exp, foot = O.resample_bilinear(d, xs, ys)
+    assert foot.any() and np.isfinite(exp).any()
+    for filled in (False, True):
+        res = cube.reproject(hout, filled=filled)
+        assert res.shape == (nz, ny // 2, nx // 2)
+        assert res.wcs.crval[0] == 0.001 and res.wcs.crpix[0] == 2.0 and res.wcs.ctype[0].startswith("GLON-SIN")
+        assert_close(res._device_data().get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="CAR -> SIN, filled=%s" % filled)
+        np.testing.assert_allclose(res.spectral_axis, cube.spectral_axis, rtol=1e-12)
+    mcube = cube.with_mask(cube > 0.1)
+    assert mcube.mask.include().any() and not mcube.mask.include().all()
+    res = mcube.reproject(hout, filled=True)
+    expm, _ = O.resample_bilinear(np.where(d > 0.1, d, np.nan).astype(np.float32), xs, ys)
+    got = res._device_data().get()
+    assert np.array_equal(np.isnan(got), np.isnan(expm))
+    assert_close(got, expm, atol=1e-5 * np.nanmax(np.abs(exp)), what="CAR -> SIN, masked")
+    assert res.wcs.crval[0] == 0.001 and res.wcs.crpix[0] == 2.0
