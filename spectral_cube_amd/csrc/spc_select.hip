@@ -750,7 +750,7 @@ struct KeyAbsDevWin {
 };
 
 template <int TS, int KPL, bool ARR, bool MAD, bool DESC, int BT = 256>
-__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 3 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? (BT == 512 ? 2 : 3) : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     __shared__ SelShared<TS> S;
     __shared__ SelCache<TS> C;
     constexpr int kLanesPerRay = BT / TS;
@@ -1206,8 +1206,24 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     A.spread_mad = spread_is_mad ? 1 : 0;
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
-    // (256-thread blocks here: with 512 threads - wider runs per plane, see spc_percentile_axis0_f32 - the clip loop, which is
-    //  compute and barrier bound and runs until the LAST ray of the block has converged, measured 12 ms against 9.5 - 10 ms)
+    // 256-thread blocks for the median forms: with 512 threads (wider runs per plane, see spc_percentile_axis0_f32) the read +
+    // write floor of the kernel drops from 4.2 to 2.3 ms at 1024^3, but an iteration with a descent costs 2.0 instead of 1.4 ms
+    // (more barriers across 8 waves, the cached descents resume at the shallowest of 32 rays' levels, the loop ends with the
+    // slowest of 32 rays): 10.4 against 8.6 ms for astropy's defaults.  Without a descent (centre = mean, spread = std) or
+    // with a single iteration the wider blocks win: 2.3 - 3.4 against 4.2 ms.  SPC_SIGMA_BT=256 / 512 forces either.
+    {
+        const char* be = getenv("SPC_SIGMA_BT");
+        const int force = be ? atoi(be) : 0;
+        const bool wide = force == 512 || (force != 256 && (A.cen_mean || A.maxiters == 1));
+        if (wide && cube->nz > 512 && cube->nz <= 1024 && !A.spread_mad &&
+            sel_desc_fits(32, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1, 512)) {
+            dim3 grid2((unsigned)(cube->ny * ((cube->nx + 31) / 32)));
+            if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<32, 64, true, false, true, 512>), grid2, dim3(512), 0, st, A);
+            else hipLaunchKernelGGL((sigma_clip_reg_kernel<32, 64, false, false, true, 512>), grid2, dim3(512), 0, st, A);
+            SPC_LAUNCH_CHECK();
+            return SPC_OK;
+        }
+    }
     const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
     const bool desc = sel_desc_fits(ts, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1) && spc_env_on("SPC_SELECT_DESC");
     const int lanes = 256 / ts;

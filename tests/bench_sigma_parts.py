@@ -15,7 +15,10 @@ def timeit(fn, n=3):
     fn(); synchronize(); e0, e1 = Event(), Event(); e0.record()
     for _ in range(n): fn()
     e1.record(); e1.synchronize(); return e0.elapsed_ms(e1) / n
-for cen in ("median", "mean"):
+for bt in ("256", "512"):
+  os.environ["SPC_SIGMA_BT"] = bt
+  print("SPC_SIGMA_BT", bt)
+  for cen in ("median", "mean"):
     for it in (1, 2, 3, 5, None):
         kw = dict(cenfunc=cen)
         kw["maxiters"] = it

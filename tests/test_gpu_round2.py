@@ -470,6 +470,10 @@ def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
         sig = 2.5
         monkeypatch.delenv("SPC_SIGMA_CLIP_FUSED", raising=False)
         got = ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get()
+        for bt in ("256", "512"):                                    # (both block shapes, whatever the launcher would pick)
+            monkeypatch.setenv("SPC_SIGMA_BT", bt)
+            assert np.array_equal(ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get(), got, equal_nan=True), (kw, bt)
+        monkeypatch.delenv("SPC_SIGMA_BT")
         monkeypatch.setenv("SPC_SIGMA_CLIP_FUSED", "0")
         ref = ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get()
         assert np.array_equal(got, ref, equal_nan=True), kw
