@@ -750,7 +750,7 @@ struct KeyAbsDevWin {
 };
 
 template <int TS, int KPL, bool ARR, bool MAD, bool DESC, int BT = 256>
-__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? (BT == 512 ? 2 : 3) : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     __shared__ SelShared<TS> S;
     __shared__ SelCache<TS> C;
     constexpr int kLanesPerRay = BT / TS;
