@@ -311,6 +311,12 @@ def run_single(args, device):
         "roofline": roofline(wl, k_ms, traffic, traffic_src),
         "verify": verify,
     }
+    # ---- SURVEY 8(f) rows on the same resident cube: statistics(), median, sigma clipping -------------
+    if not args.no_configs:
+        try:
+            line["next_rows"] = next_rows_records(cube, maskd, blk, m, device)
+        except AssertionError as exc:                       # a failed oracle check is reported, never hidden
+            line["next_rows"] = {"error": "oracle check failed: %r" % (exc,)}
     # ---- north-star record: the fixed 4096x2048x2048 cube on this one GPU ------------------------
     del wl, out, cube, maskd, blk, m
     gc.collect()
@@ -664,6 +670,62 @@ def config_c5(device, scale):
     recs.append(cfg_record("C5 reproject 4096 x 1024^2 onto the grid rotated by 30 deg (bilinear)", "bilinear_lds_kernel<64>", ms,
                            nzo * ny * nx * 8, nzo * ny * nx, ver, "~4 read + 4 written per output voxel"))
     return recs
+
+
+def next_rows_records(cube, maskd, tile, tmask, device):
+    """SURVEY.md section 8(f) rows timed on the configs[1] cube while it is resident (kernel time by HIP events, algorithmic
+    bytes, fraction of 8 TB/s), each checked against the oracle / numpy on the cube's first rows: f1 statistics(), f4 the median
+    along the spectral axis (bit-exact) and sigma_clip_spectrally (astropy defaults, 3 sigma)."""
+    import warnings
+    import numpy as np
+    from spectral_cube_amd import _lib, ops
+    from spectral_cube_amd.device import DeviceArray
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_np as O
+    nz, ny, nx = cube.shape
+    vox = nz * ny * nx
+    rows = tile.shape[1]
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=maskd)
+    inc = tmask.astype(bool) & ~np.isnan(tile)
+    out = {}
+    # f1: one pass, five statistics
+    ms = event_ms(lambda: ops.stats_global(cube, mask=spec), device)
+    st = ops.stats_global(cube.rows(0, rows), mask=spec.rows(0, rows))
+    sel = tile[inc].astype(np.float64)
+    assert st["npts"] == sel.size and st["min"] == sel.min() and st["max"] == sel.max(), "statistics(): count / extrema"
+    assert abs(st["sum"] - sel.sum()) <= 1e-10 * np.abs(sel).sum() and abs(st["sumsq"] - (sel * sel).sum()) <= 1e-10 * (sel * sel).sum()
+    out["f1_statistics"] = cfg_record("f1 statistics(): npts / min / max / sum / sumsq in one pass, 1024^3 + uint8 mask", "stats_global_kernel", ms,
+                                      vox * 5, vox, {"rows_checked": rows, "npts_min_max": "exact", "sum_sumsq_rel_err": "<= 1e-10"},
+                                      "4 B data + 1 B mask read per voxel")
+    # f4: median along the spectral axis, rays resident in registers
+    med = DeviceArray((ny, nx), np.float32, device)
+    ms = event_ms(lambda: ops.percentile_axis0(cube, 50.0, mask=spec, out=med), device)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = np.nanmedian(np.where(inc, tile, np.nan).astype(np.float32), axis=0)
+    assert np.array_equal(med.get()[:rows], exp, equal_nan=True), "median(axis=0) differs from np.nanmedian"
+    out["f4_median_axis0"] = cfg_record("f4 median(axis=0), 1024^3 + uint8 mask", "select_reg_kernel<32,64,ARR,DESC,512> (one read of the cube)",
+                                        ms, vox * 5 + ny * nx * 4, vox, {"rows_checked": rows, "vs_np_nanmedian": "bit-identical"},
+                                        "4 B data + 1 B mask read per voxel, one float32 map out")
+    # f4: sigma clipping, the whole loop in one kernel
+    keep = {}
+
+    def clip():
+        keep["r"] = None                                    # (the previous result goes back to the pool first)
+        keep["r"] = ops.sigma_clip_axis0(cube, sigma=3.0, mask=spec)
+    ms = event_ms(clip, device, n=3, warm=1)
+    got = fetch_rows(keep["r"], 0, rows)
+    exp = O.sigma_clip(tile, inc, 3.0)
+    differ = float(np.mean(np.isnan(got) != np.isnan(exp)))
+    both = ~np.isnan(got) & ~np.isnan(exp)
+    assert differ < 2e-4 and np.array_equal(got[both], exp[both]), ("sigma clip vs oracle", differ)
+    keep.clear()
+    out["f4_sigma_clip"] = cfg_record("f4 sigma_clip_spectrally(3), astropy defaults (median / std, <= 5 iterations), 1024^3 + uint8 mask",
+                                      "sigma_clip_reg_kernel<16,64,ARR,std,DESC,256> (one read + one write of the cube)", ms, vox * 9, vox,
+                                      {"rows_checked": rows, "clipped_set_vs_oracle": "identical up to %.1e of the samples (float32 bounds)" % max(differ, 0.0),
+                                       "kept_values": "bit-identical"},
+                                      "4 B data + 1 B mask read, 4 B written per voxel")
+    return out
 
 
 def config_records(args, device):
