@@ -287,11 +287,10 @@ class SpectralCube:
         voxels carry the fill value (NaN by default).  ``filled=False`` writes the raw voxels."""
         from . import io_fits
         plan = self._strip_plan(filled)
-        if plan is not None:             # out of core: strips in, operator, strips out (streaming.map_strips)
+        if plan is not None:             # out of core: strips in, operator, strips out (streaming.map_strips / map_slabs)
             from . import streaming
-            src, fn, nz_out = plan
-            sink = streaming.FitsSink(os.fspath(filename), self._header, (nz_out,) + tuple(self._shape[1:]), overwrite=overwrite)
-            streaming.map_strips(src, fn, nz_out, sink, halo=self._strip_halo())
+            sink = streaming.FitsSink(os.fspath(filename), self._header, tuple(self._shape), overwrite=overwrite)
+            self._run_plan(plan, sink)
             return
         dev = self._device_data()
         if filled and self._mask is not None:
@@ -310,6 +309,9 @@ class SpectralCube:
             return self, (lambda dev, mspec, stream: ops.fill_masked(dev, None, fill, stream)), self._shape[0]
         lz = self._lazy
         parent = getattr(lz, "parent", None)
+        if (self._dev is None and lz is not None and parent is not None and getattr(lz, "slab_fn", None) is not None
+                and parent._stream_source() is not None):
+            return parent, lz.slab_fn, self._shape[0]        # (reprojection: NaN outside the footprint is its own fill)
         if self._dev is not None or lz is None or parent is None or getattr(lz, "strip_fn", None) is None:
             return None
         if parent._stream_source() is None:
@@ -332,9 +334,16 @@ class SpectralCube:
         plan = self._strip_plan(True)
         if plan is None:
             raise ValueError("this cube fits the device: use filled_data")
-        src, fn, nz_out = plan
-        streaming.map_strips(src, fn, nz_out, streaming.NdarraySink(out), halo=self._strip_halo())
+        self._run_plan(plan, streaming.NdarraySink(out))
         return out
+
+    def _run_plan(self, plan, sink):
+        from . import streaming
+        src, fn, nz_out = plan
+        if getattr(self._lazy, "slab_fn", None) is not None and self._dev is None:
+            streaming.map_slabs(src, fn, tuple(self._shape[1:]), sink)        # per-channel operator: slabs of whole planes
+        else:
+            streaming.map_strips(src, fn, nz_out, sink, halo=self._strip_halo())
 
     def _strip_halo(self):
         return int(getattr(self._lazy, "halo", 0)) if (self._lazy is not None and self._dev is None) else 0
@@ -495,9 +504,9 @@ class SpectralCube:
                     nbytes = 4 * int(np.prod(self._shape, dtype=np.int64))
                     raise streaming.HugeCubeError(
                         "this operation needs the whole cube in HBM: %.2f GiB against a budget of %.2f GiB (SPC_HBM_BUDGET). "
-                        "Out-of-core cubes stream moment / moments012 / argmax / argmin / max / min / median / percentile / mad_std "
-                        "along the spectral axis, statistics() and the whole-cube reductions, and spectral_smooth / spatial_smooth / "
-                        "spectral_interpolate / sigma_clip_spectrally into write(), stream_into() or a following moment"
+                        "Out-of-core cubes stream moments, argmax / argmin, the nan-reductions and median / percentile / mad_std along any "
+                        "axis, statistics(), and spectral_smooth / spatial_smooth / spectral_interpolate / sigma_clip_spectrally / reproject "
+                        "(celestial) into write(), stream_into() or a following moment"
                         % (nbytes / 2**30, streaming.hbm_budget(self.device) / 2**30))
                 self._dev = DeviceArray.from_numpy(self._data, self.device, dtype=np.float32)
         return self._dev
@@ -679,7 +688,18 @@ class SpectralCube:
             d_cen = DeviceArray.from_numpy(cen, self.device)
             size = self._pix_size_slice(axis)
             key = {0: "m0", 1: "m1", 2: "m2"}.get(order)
-            if key is None:          # order > 2: second pass about the first moment (_moments.py:185-193)
+            if self._stream_source() is not None:
+                # out of core: the image planes are whole in a slab of channels, the (nz, nx) / (nz, ny) map grows slab by slab
+                from . import streaming
+                width, f64 = self._shape[2 if axis == 1 else 1], {"m0": np.float64, "m1": np.float64, "m2": np.float64, "o": np.float64}
+                first = key or "m1"
+                mu = streaming.slab_maps(self, lambda dev, ms, st, o, z0, z1: ops.moments_spatial(
+                    dev, d_cen, axis, size, mask=ms, want=(first,), stream=st, out=o), (first,), width, f64)[first]
+                if key is None:
+                    mu = streaming.slab_maps(self, lambda dev, ms, st, o, z0, z1: ops.moment_order_spatial(
+                        dev, d_cen, axis, order, streaming._rows_view(mu, z0, z1), mask=ms, stream=st, out=o["o"]), ("o",), width, f64)["o"]
+                out = mu.get()
+            elif key is None:          # order > 2: second pass about the first moment (_moments.py:185-193)
                 mu = ops.moments_spatial(self._device_data(), d_cen, axis, size, mask=self._mask_spec(),
                                          want=("m1",))["m1"]
                 out = ops.moment_order_spatial(self._device_data(), d_cen, axis, order, mu,
@@ -741,6 +761,10 @@ class SpectralCube:
         if axis == 0:
             return self._moment_device((key,))[key].get()
         if axis in (1, 2):
+            if self._stream_source() is not None:
+                from . import streaming
+                return streaming.slab_maps(self, lambda dev, ms, st, o, z0, z1: ops.argextrema_axis(dev, axis, mask=ms, want=(key,), stream=st, out=o),
+                                           (key,), self._shape[2 if axis == 1 else 1], {key: np.int64})[key].get()
             return ops.argextrema_axis(self._device_data(), axis, mask=self._mask_spec(), want=(key,))[key].get()
         if axis is not None:
             raise ValueError("axis must be None, 0, 1 or 2")
@@ -795,11 +819,15 @@ class SpectralCube:
             if len(axes) != 2 or any(a not in (0, 1, 2) for a in axes):
                 raise ValueError("axis must be None, 0, 1, 2 or a tuple of these")
             if axes == [1, 2]:                           # per channel (spectra): one dedicated pass, nz records
-                vals = ops.stats_planes(self._device_data(), mask=self._mask_spec())
+                if self._stream_source() is not None:
+                    from . import streaming
+                    vals = streaming.stats_planes(self)
+                else:
+                    vals = ops.stats_planes(self._device_data(), mask=self._mask_spec())
                 axis = (1, 2)
                 return self._finish_reduce(op, vals, axis, ddof)
             first, second = axes[1], axes[0]            # drop the higher axis on the device, the lower one here
-            r = ops.stats_axis(self._device_data(), first, mask=self._mask_spec(), want=need)
+            r = self._stats_axis_maps(first, need)
             part = {k: r[k].get().astype(np.float64) for k in need}
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore", RuntimeWarning)
@@ -815,9 +843,15 @@ class SpectralCube:
         else:
             if axis not in (0, 1, 2):
                 raise ValueError("axis must be None, 0, 1 or 2")
-            r = ops.stats_axis(self._device_data(), axis, mask=self._mask_spec(), want=need)
+            r = self._stats_axis_maps(axis, need)
             vals = {k: r[k].get().astype(np.float64) for k in need}
         return self._finish_reduce(op, vals, axis, ddof)
+
+    def _stats_axis_maps(self, axis, need):
+        if self._stream_source() is not None:          # out of core: strips (axis 0) or slabs of planes (axis 1 / 2)
+            from . import streaming
+            return streaming.stats_axis(self, axis, need)
+        return ops.stats_axis(self._device_data(), axis, mask=self._mask_spec(), want=need)
 
     def _finish_reduce(self, op, vals, axis, ddof=0):
         n = vals["count"]
@@ -859,6 +893,22 @@ class SpectralCube:
     def _order_stat(self, q, axis, what, center=None, scale=1.0):
         if axis not in (0, 1, 2):
             raise ValueError("axis must be None, 0, 1 or 2")
+        if axis in (1, 2) and self._stream_source() is not None:
+            # out of core: the rays along y / x are whole in a slab of channels; row z of the (nz, nx) / (nz, ny) map per slab row
+            from . import streaming
+
+            def one(dev, ms, st, o, z0, z1):
+                cen = streaming._rows_view(center, z0, z1) if center is not None else None
+                if axis == 1:
+                    ops.percentile_axis0(dev.swap01(), q, mask=ms.swap01() if ms is not None else None, center=cen, scale=scale, stream=st, out=o["q"])
+                    return
+                try:
+                    ops.percentile_axis2(dev, q, mask=ms, center=cen, scale=scale, stream=st, out=o["q"])
+                except _lib.HipUnsupported:
+                    flipped = ops.fill_masked_transposed(dev, ms, np.nan, stream=st)
+                    ops.percentile_axis0(flipped.swap01(), q, center=cen, scale=scale, stream=st, out=o["q"])
+                    st.synchronize()
+            return streaming.slab_maps(self, one, ("q",), self._shape[2 if axis == 1 else 1], {"q": np.float32})["q"]
         if axis == 1:            # rays along y: the same kernels on a view with the first two axes exchanged
             return ops.percentile_axis0(self._device_data().swap01(), q, mask=self._mask_spec().swap01(),
                                         center=center, scale=scale)
@@ -1123,6 +1173,32 @@ class SpectralCube:
         else:
             _lib.require_gpu()
             xs, ys = ops.wcs_pixel_map(self._wcs, newwcs, (ny_out, nx_out), self.device)
+        if self._stream_source() is not None:
+            # out of core: every channel is resampled on its own, so the cube goes through the device in slabs of whole
+            # planes; the result stays pending until write() / stream_into() (it does not fit the budget either)
+            from . import streaming
+            if zs is not None:
+                raise streaming.HugeCubeError("resampling the spectral axis of a cube above the HBM budget (SPC_HBM_BUDGET) as well is "
+                                              "not built: reproject onto a celestial header, then spectral_interpolate")
+            probe = DeviceArray.from_numpy(np.zeros((1,) + tuple(self._shape[1:]), np.float32), self.device)
+            _, foot = ops.resample_bilinear(probe, xs, ys, fill=np.nan, order=order)
+            footprint = foot.get().astype(bool)
+            if not footprint.any():
+                raise ValueError("All values in reprojected cube are nan.  This can be caused"
+                                 " by an error in which coordinates do not 'round-trip'.  Try "
+                                 "setting ``roundtrip_coords=False``.  You might also check "
+                                 "whether the WCS transformation produces valid pixel->world "
+                                 "and world->pixel coordinates in each axis.")
+            parent, fill = self, float(self._fill_value)
+            thunk = _Thunk(lambda: parent._device_data())           # (never resident: raises HugeCubeError with the budget)
+            thunk.parent = parent
+            thunk.slab_fn = lambda dev, mspec, stream: ops.resample_bilinear(dev, xs, ys, fill=fill, mask=mspec if filled else None,
+                                                                            order=order, stream=stream, want_footprint=False)[0]
+            shape = (nz, ny_out, nx_out)
+            out = self._new_cube_with(lazy=thunk, wcs=newwcs, mask=False, shape=shape)
+            out._mask = M.BooleanArrayMask(footprint[None], newwcs, shape=shape)
+            out._footprint = footprint
+            return out
         mask = self._mask_spec() if filled else None
         flag = DeviceArray((1,), np.uint32, self.device)
         dev, foot = ops.resample_bilinear(self._device_data(), xs, ys, fill=float(self._fill_value),

@@ -164,14 +164,24 @@ def moments(cube, cen, dv=1.0, m1_add=0.0, mask=None, want=_WANT_ALL, stream=Non
     return bufs
 
 
-def argextrema_axis(cube, axis, mask=None, want=("argmax", "argmin"), stream=None):
+def _given(out, name, shape, dtype, device):
+    """out[name] when the caller preallocated it (checked), else a new DeviceArray"""
+    a = out.get(name) if out else None
+    if a is None:
+        return DeviceArray(shape, dtype, device)
+    if tuple(a.shape) != tuple(shape) or a.dtype != np.dtype(dtype):
+        raise ValueError("preallocated output %r must be %s %s" % (name, tuple(shape), np.dtype(dtype)))
+    return a
+
+
+def argextrema_axis(cube, axis, mask=None, want=("argmax", "argmin"), stream=None, out=None):
     """argmax / argmin along a spatial axis (spectral_cube.py:793-819 with axis = 1 or 2): int64
     maps (nz, nx) / (nz, ny); first index on ties, 0 for rays without an included sample."""
     nz, ny, nx = cube.shape
     if axis not in (1, 2):
         raise ValueError("axis must be 1 or 2 (axis 0 comes out of ops.moments)")
     shape = (nz, nx) if axis == 1 else (nz, ny)
-    bufs = {n: DeviceArray(shape, np.int64, cube.device) for n in want if n in ("argmax", "argmin")}
+    bufs = {n: _given(out, n, shape, np.int64, cube.device) for n in want if n in ("argmax", "argmin")}
     c, m = _cube_c(cube), _mask_c(mask, cube)
     ptr = lambda n: C.c_void_p(bufs[n].ptr) if n in bufs else None  # noqa: E731
     _lib.call("spc_argextrema_axis_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis),
@@ -191,14 +201,14 @@ def moment_order(cube, cen, order, mu, s0, mask=None, stream=None):
     return out
 
 
-def moments_spatial(cube, cen2d, axis, pix_size, mask=None, want=_WANT_ALL, stream=None):
+def moments_spatial(cube, cen2d, axis, pix_size, mask=None, want=_WANT_ALL, stream=None, out=None):
     """moment 0/1/2 along a spatial axis (golden tables
     spectral_cube/tests/test_moments.py:19-49)."""
     nz, ny, nx = cube.shape
     if axis not in (1, 2):
         raise ValueError("axis must be 1 or 2")
     shape = (nz, nx) if axis == 1 else (nz, ny)
-    bufs = {n: DeviceArray(shape, np.float64, cube.device) for n in want}
+    bufs = {n: _given(out, n, shape, np.float64, cube.device) for n in want}
     c, m = _cube_c(cube), _mask_c(mask, cube)
     ptr = lambda n: C.c_void_p(bufs[n].ptr) if n in bufs else None  # noqa: E731
     _lib.call("spc_moments_spatial_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis),
@@ -206,13 +216,13 @@ def moments_spatial(cube, cen2d, axis, pix_size, mask=None, want=_WANT_ALL, stre
     return bufs
 
 
-def moment_order_spatial(cube, cen2d, axis, order, mu, mask=None, stream=None):
+def moment_order_spatial(cube, cen2d, axis, order, mu, mask=None, stream=None, out=None):
     """sum v (c - mu)^order / sum v along a spatial axis: the second pass for order > 2
     (dask_spectral_cube.py:1094-1099 with axis != 0); *mu* = the m1 map of moments_spatial."""
     nz, ny, nx = cube.shape
     if axis not in (1, 2):
         raise ValueError("axis must be 1 or 2")
-    out = DeviceArray((nz, nx) if axis == 1 else (nz, ny), np.float64, cube.device)
+    out = _given({"o": out} if out is not None else None, "o", (nz, nx) if axis == 1 else (nz, ny), np.float64, cube.device)
     c, m = _cube_c(cube), _mask_c(mask, cube)
     _lib.call("spc_moment_order_spatial_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis),
               C.c_void_p(cen2d.ptr), int(order), C.c_void_p(mu.ptr), C.c_void_p(out.ptr))

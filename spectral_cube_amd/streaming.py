@@ -147,6 +147,14 @@ def plan_rows(shape, budget, mask_array=False, align=8):
     return min(ny, rows)
 
 
+def plan_planes(shape, budget, mask_array=False, out_factor=1.0):
+    """planes per slab for the operators that need whole image planes (reprojection, statistics along y / x): two slabs
+    in flight + their mask slabs + a result of `out_factor` times a slab's size within half the budget, at least one"""
+    nz, ny, nx = shape
+    per_plane = ny * nx * (4 + (1 if mask_array else 0) + 4.0 * out_factor)
+    return int(max(1, min(nz, (budget // 2) // (2 * per_plane))))
+
+
 # pinned staging buffers are expensive to make (page-locking ~0.5 GiB per pass costs as much as staging a few GiB) and
 # cheap to keep: a pipeline borrows its set from here and hands it back in close()
 _PINNED_IDLE = {}
@@ -191,26 +199,38 @@ class StripPipeline:
     the device, and a buffer is only overwritten once the consumer's stream has passed the event recorded after ITS
     kernels (done()).  Iteration yields (y0, y1, DeviceArray) with `consumer_stream` already waiting for the strip."""
 
-    def __init__(self, source, device, rows, consumer_stream, slots=2, chunk_bytes=None, nbuffers=None, readers=None, halo=0):
+    def __init__(self, source, device, rows, consumer_stream, slots=2, chunk_bytes=None, nbuffers=None, readers=None, halo=0, axis=1):
         from .device import Event
         self.source, self.device, self.rows, self.consumer = source, device, int(rows), consumer_stream
         self.halo = int(halo)          # extra rows loaded on each side of a strip (clipped at the cube's edges): spatial stencils
+        self.axis = int(axis)          # 1: row strips (nz, rows, nx);  0: slabs of `rows` whole planes (rows, ny, nx)
+        if self.axis not in (0, 1) or (self.axis == 0 and self.halo):
+            raise ValueError("strips along y (axis 1, optional halo rows) or slabs of planes (axis 0)")
         self.slots = slots
         self.chunk_bytes = int(chunk_bytes or (_env_int("SPC_STREAM_CHUNK_MB", 32) << 20))
         self.nbuf = int(nbuffers or _env_int("SPC_STREAM_BUFFERS", 16))
         self.readers = int(readers or _env_int("SPC_STREAM_READERS", 8))
         nz, ny, nx = source.shape
-        self.bounds = [(y0, min(ny, y0 + self.rows)) for y0 in range(0, ny, self.rows)]
-        self.loaded = [(max(0, y0 - self.halo), min(ny, y1 + self.halo)) for y0, y1 in self.bounds]     # rows a strip holds
-        self.ext = min(ny, self.rows + 2 * self.halo)
-        seg = self.ext * nx * source.sample_bytes
-        self.ppc = max(1, min(nz, self.chunk_bytes // max(1, seg)))      # planes per chunk
+        n_ax = ny if self.axis == 1 else nz
+        self.bounds = [(a, min(n_ax, a + self.rows)) for a in range(0, n_ax, self.rows)]
+        if self.axis == 1:
+            self.loaded = [(max(0, y0 - self.halo), min(ny, y1 + self.halo)) for y0, y1 in self.bounds]     # rows a strip holds
+            self.ext = min(ny, self.rows + 2 * self.halo)
+            seg = self.ext * nx * source.sample_bytes
+            self.ppc = max(1, min(nz, self.chunk_bytes // max(1, seg)))      # planes per chunk
+            shape = (nz, self.ext, nx)
+        else:
+            self.loaded = [(0, ny)] * len(self.bounds)
+            self.ext = ny
+            seg = ny * nx * source.sample_bytes
+            self.ppc = max(1, min(self.rows, nz, self.chunk_bytes // max(1, seg)))
+            shape = (min(self.rows, nz), ny, nx)
         cap = -(-(self.ppc * seg) // (1 << 20)) << 20       # whole MiB: sets of equal size are shared between passes
         self.cap = cap
         self.pinned = _take_pinned(cap, self.nbuf)
         self.d_raw = [DeviceArray((cap,), np.uint8, device) for _ in range(self.nbuf)] if source.decode else None
         self.copy = Stream(device)
-        self.bufs = [DeviceArray((nz, self.ext, nx), source.out_dtype, device) for _ in range(min(slots, len(self.bounds)))]
+        self.bufs = [DeviceArray(shape, source.out_dtype, device) for _ in range(min(slots, len(self.bounds)))]
         self.done_evt = [None] * len(self.bufs)
         self.Event = Event
         self.bytes = 0
@@ -223,7 +243,10 @@ class StripPipeline:
         from concurrent.futures import ThreadPoolExecutor
         src, dev = self.source, self.device
         nz, ny, nx = src.shape
-        tasks = [(s, z0, min(nz, z0 + self.ppc)) for s in range(len(self.bounds)) for z0 in range(0, nz, self.ppc)]
+        if self.axis == 1:
+            tasks = [(s, z0, min(nz, z0 + self.ppc)) for s in range(len(self.bounds)) for z0 in range(0, nz, self.ppc)]
+        else:
+            tasks = [(s, z0, min(b, z0 + self.ppc)) for s, (a, b) in enumerate(self.bounds) for z0 in range(a, b, self.ppc)]
         last_of = {}
         for i, (s, _, _) in enumerate(tasks):
             last_of[s] = i
@@ -251,12 +274,13 @@ class StripPipeline:
                 h0, h1 = self.loaded[s]
                 rows = h1 - h0
                 slot = s % len(self.bufs)
-                if z0 == 0 and self.done_evt[slot] is not None:      # the consumer's kernels on the strip that held this slot
+                first_z = 0 if self.axis == 1 else y0
+                if z0 == first_z and self.done_evt[slot] is not None:      # the consumer's kernels on the strip that held this slot
                     self.copy.wait_event(self.done_evt[slot])
                     self.done_evt[slot] = None
                 b = self.pinned[i % self.nbuf]
                 # a short last strip is stored densely: (nz, rows, nx) at the head of the slot
-                dst = self.bufs[slot].ptr + z0 * rows * nx * isz
+                dst = self.bufs[slot].ptr + (z0 - first_z) * rows * nx * isz
                 if src.decode is None:
                     _lib.call("spc_memcpy_h2d", dev, C.c_void_p(dst), C.c_void_p(b.ptr), C.c_size_t(n), self.copy.handle)
                 else:
@@ -272,8 +296,9 @@ class StripPipeline:
                     nxt += 1
                 if i == last_of[s]:
                     self.consumer.wait_event(ev)             # the strip is complete when its last chunk has landed
-                    strip = DeviceArray((nz, rows, nx), src.out_dtype, dev, ptr=self.bufs[slot].ptr, owner=self.bufs[slot])
-                    strip.top = y0 - h0            # the strip's own rows are [top, top + (y1 - y0)) of what was loaded
+                    strip = DeviceArray((nz, rows, nx) if self.axis == 1 else (y1 - y0, ny, nx), src.out_dtype, dev,
+                                        ptr=self.bufs[slot].ptr, owner=self.bufs[slot])
+                    strip.top = (y0 - h0) if self.axis == 1 else 0     # the strip's own rows are [top, top + (y1 - y0)) of what was loaded
                     yield y0, y1, strip
                     d = self.Event(dev)                      # recorded after whatever the consumer queued on its stream
                     d.record(self.consumer)
@@ -303,21 +328,22 @@ class Strips:
     """(y0, y1, data strip, MaskSpec or None) of a streamed cube on `stream`; data and the mask's array term come
     through two pipelines in lockstep"""
 
-    def __init__(self, cube, stream, rows=None, halo=0):
+    def __init__(self, cube, stream, rows=None, halo=0, axis=1, out_factor=1.0):
         from . import ops
         self.ops = ops
         src = cube._stream_source()
         self.terms = _mask_terms(cube)
         has_arr = self.terms is not None and self.terms[3] is not None
         if rows is None:
-            rows = plan_rows(src.shape, hbm_budget(cube.device), mask_array=has_arr)
+            rows = (plan_rows(src.shape, hbm_budget(cube.device), mask_array=has_arr) if axis == 1 else
+                    plan_planes(src.shape, hbm_budget(cube.device), mask_array=has_arr, out_factor=out_factor))
         self.rows = rows
-        self.data = StripPipeline(src, cube.device, rows, stream, halo=halo)
+        self.data = StripPipeline(src, cube.device, rows, stream, halo=halo, axis=axis)
         self.mask = None
         if has_arr:
             m = np.broadcast_to(self.terms[3], src.shape)
             self.mask = StripPipeline(NdarraySource(m, np.uint8), cube.device, rows, stream,
-                                      nbuffers=max(4, self.data.nbuf // 2), readers=max(2, self.data.readers // 2), halo=halo)
+                                      nbuffers=max(4, self.data.nbuf // 2), readers=max(2, self.data.readers // 2), halo=halo, axis=axis)
 
     @property
     def bytes(self):
@@ -531,8 +557,8 @@ class StripWriter:
         self.keep = []                   # (event, strip) pairs: a strip stays alive until its last chunk has left the device
         self.bytes = 0
 
-    def put(self, y0, y1, strip, produced_on):
-        """queue the strip (rows [y0, y1) of the result); `produced_on`: the stream its kernel ran on"""
+    def put(self, y0, y1, strip, produced_on, z_base=0):
+        """queue the strip (rows [y0, y1) of the result's planes z_base ..); `produced_on`: the stream its kernel ran on"""
         nz, rows, nx = strip.shape
         seg = rows * nx * 4
         ppc = max(1, min(nz, self.chunk_bytes // seg))
@@ -564,7 +590,7 @@ class StripWriter:
             done = self.Event(self.device)
             done.record(self.down)
             last = done
-            self.busy[k] = self.pool.submit(self._write, done, b, z0, z1, y0, y1)
+            self.busy[k] = self.pool.submit(self._write, done, b, z_base + z0, z_base + z1, y0, y1)
             self.bytes += n
         self.keep.append((last, strip))
         while len(self.keep) > 2:                 # at most two result strips wait on the device
@@ -629,3 +655,62 @@ def map_strips(cube, fn, nz_out, sink, rows=None, stats=None, halo=0):
         w.close()
     if stats is not None:
         stats.update(bytes_in=st.bytes, bytes_out=w.bytes, strips=n, rows=st.rows)
+
+
+def map_slabs(cube, fn, out_yx, sink, planes=None, stats=None):
+    """out[z0:z1] = fn(slab, mask spec, stream) for every slab of whole planes of a streamed cube; fn returns a float32
+    (z1 - z0, ny_out, nx_out) DeviceArray produced on `stream`.  The operators this serves work per channel
+    (reprojection of the celestial plane): the channels of a slab are independent."""
+    nz, ny, nx = cube._shape
+    ny_out, nx_out = out_yx
+    if tuple(sink.shape) != (nz, ny_out, nx_out):
+        raise ValueError("the sink has shape %s, the result %s" % (tuple(sink.shape), (nz, ny_out, nx_out)))
+    compute = Stream(cube.device)
+    st = Strips(cube, compute, planes, axis=0, out_factor=2.0 * ny_out * nx_out / float(ny * nx))
+    w = StripWriter(sink, cube.device)
+    n = 0
+    try:
+        for z0, z1, dev, mspec in st:
+            w.put(0, ny_out, fn(dev, mspec, compute), compute, z_base=z0)
+            n += 1
+    finally:
+        w.close()
+    if stats is not None:
+        stats.update(bytes_in=st.bytes, bytes_out=w.bytes, slabs=n, planes=st.rows)
+
+
+def slab_maps(cube, fn, names, width, dtypes, planes=None):
+    """{name: (nz, width) DeviceArray}: maps whose FIRST axis is the spectral one (statistics along y or x of a streamed
+    cube), assembled on the device slab by slab: fn(slab, mask spec, stream, {name: rows z0:z1 of the map}, z0, z1)."""
+    nz = cube._shape[0]
+    maps = {k: DeviceArray((nz, width), dtypes[k], cube.device) for k in names}
+    compute = Stream(cube.device)
+    for z0, z1, dev, mspec in Strips(cube, compute, planes, axis=0, out_factor=0.0):
+        fn(dev, mspec, compute, {k: _rows_view(maps[k], z0, z1) for k in names}, z0, z1)
+    compute.synchronize()
+    return maps
+
+
+def stats_axis(cube, axis, want):
+    """ops.stats_axis of a streamed cube: along the spectral axis strip by strip (every spaxel whole), along y or x
+    slab by slab (every image plane whole); the maps are assembled on the device"""
+    from . import ops
+    nz, ny, nx = cube._shape
+    dt = ops._STAT_DTYPES
+    if axis == 0:
+        maps = {k: DeviceArray((ny, nx), dt[k], cube.device) for k in want}
+        compute = Stream(cube.device)
+        for y0, y1, dev, mspec in Strips(cube, compute):
+            ops.stats_axis(dev, 0, mask=mspec, want=want, stream=compute, out={k: _rows_view(maps[k], y0, y1) for k in want})
+        compute.synchronize()
+        return maps
+    return slab_maps(cube, lambda dev, mspec, stream, out, z0, z1: ops.stats_axis(dev, axis, mask=mspec, want=want, stream=stream, out=out),
+                     want, nx if axis == 1 else ny, dt)
+
+
+def stats_planes(cube):
+    """ops.stats_planes (one record per channel) of a streamed cube, slab by slab"""
+    from . import ops
+    compute = Stream(cube.device)
+    parts = [ops.stats_planes(dev, mask=mspec, stream=compute) for z0, z1, dev, mspec in Strips(cube, compute, axis=0, out_factor=0.0)]
+    return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
