@@ -311,6 +311,12 @@ class SpectralCube:
         parent = getattr(lz, "parent", None)
         if (self._dev is None and lz is not None and parent is not None and getattr(lz, "slab_fn", None) is not None
                 and parent._stream_source() is not None):
+            if filled and self._mask is not None and getattr(lz, "keeps_mask", False) and self._mask is parent._mask:
+                def slab_filled(dev, mspec, stream):     # (convolve_to: the parent's mask, on the parent's voxels)
+                    from . import streaming
+                    keep = streaming.original_include(parent, dev, mspec, stream)
+                    return ops.fill_masked(lz.slab_fn(dev, mspec, stream), keep, fill, stream)
+                return parent, slab_filled, self._shape[0]
             return parent, lz.slab_fn, self._shape[0]        # (reprojection: NaN outside the footprint is its own fill)
         if self._dev is not None or lz is None or parent is None or getattr(lz, "strip_fn", None) is None:
             return None
@@ -1072,6 +1078,18 @@ class SpectralCube:
         karr = beam.deconvolve(self.beam).as_kernel(pixscale)
         is_jybm = str(self._unit).replace(" ", "").upper() in ("JY/BEAM", "JYBEAM-1", "JY/BM")
         ratio = beam.sr / self.beam.sr if is_jybm else 1.0
+        if self._stream_source() is not None:
+            # out of core: one kernel for every channel, so slabs of whole planes; pending until write() / stream_into()
+            parent = self
+
+            def slab(dev, mspec, stream):
+                res = ops.spatial_conv(dev, karr, mask=mspec, stream=stream)
+                if ratio != 1.0:
+                    ops.scale_inplace(res, ratio, stream=stream)
+                return res
+            thunk = _Thunk(lambda: parent._device_data())           # (never resident: raises HugeCubeError with the budget)
+            thunk.parent, thunk.slab_fn, thunk.keeps_mask = parent, slab, True
+            return self._new_cube_with(lazy=thunk, shape=self._shape).with_beam(beam, raise_error_jybm=False)
         dev = ops.spatial_conv(self._device_data(), karr, mask=self._mask_spec())
         if ratio != 1.0:
             ops.scale_inplace(dev, ratio)

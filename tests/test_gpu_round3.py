@@ -460,6 +460,17 @@ def test_out_of_core_slabs_of_planes(gpu, tmp_path, monkeypatch):
     assert np.array_equal(np.asarray(back.unmasked_data), exp_rp, equal_nan=True)
     np.testing.assert_allclose(back.wcs.pixel_scale_matrix, rp.wcs.pixel_scale_matrix, rtol=1e-12)
     np.testing.assert_allclose(back.spectral_axis, res.spectral_axis, rtol=1e-12)
+    # convolve_to: one kernel for every channel (an elliptical, rotated one: the non-separable stencil), Jy/beam scaling
+    from spectral_cube_amd.beam import Beam
+    pix = abs(float(hdr["CDELT1"]))
+    hb = dict(hdr, BMAJ=3.0 * pix, BMIN=2.0 * pix, BPA=20.0, BUNIT="Jy/beam")
+    tgt = Beam(5.0 * pix, 3.5 * pix, 60.0)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    exp_cv = np.asarray(SpectralCube.read(d, hb).with_mask(inc).convolve_to(tgt).filled_data)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 5))
+    bcv = SpectralCube.read(d.copy(), hb).with_mask(inc).convolve_to(tgt)
+    assert bcv._dev is None and bcv.beam == tgt
+    assert np.array_equal(bcv.stream_into(np.empty(d.shape, np.float32)), exp_cv, equal_nan=True)
     far = dict(target, CRVAL1=float(SimpleWCS(hdr).crval[0]) + 40.0)
     monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 5))
     with pytest.raises(ValueError, match="All values in reprojected cube are nan"):
