@@ -94,6 +94,38 @@ best = min(ts)
 print("%-58s %8.1f ms  %6.1f GB/s in + %.1f GB/s out  %8.0f Mvoxel/s   all runs (ms): %s" % (
     "host array -> spectral_smooth(33 taps) -> host array", best * 1e3, nbytes / best / 1e9, nbytes / best / 1e9,
     nz * ny * nx / best / 1e6, " ".join("%.0f" % (t * 1e3) for t in ts)), flush=True)
+# operators on whole planes: row strips with halo rows (spatial_smooth), slabs of channels (reproject, statistics along y)
+from spectral_cube_amd import Gaussian2DKernel
+
+
+def cube_to_cube(label, make, out_shape):
+    dst = np.empty(out_shape, np.float32)
+    ts = []
+    for _ in range(3):
+        synchronize(); t0 = time.perf_counter()
+        make().stream_into(dst)
+        synchronize(); ts.append(time.perf_counter() - t0)
+    best = min(ts)
+    print("%-58s %8.1f ms  %6.1f GB/s in + %.1f GB/s out  %8.0f Mvoxel/s   all runs (ms): %s" % (
+        label, best * 1e3, nbytes / best / 1e9, dst.nbytes / best / 1e9, nz * ny * nx / best / 1e6, " ".join("%.0f" % (t * 1e3) for t in ts)), flush=True)
+
+
+cube_to_cube("host array -> spatial_smooth(29x29), slabs of planes -> host array", lambda: arr.spatial_smooth(Gaussian2DKernel(8 / 2.35482)), shape)
+c_, s_ = np.cos(np.radians(30)), np.sin(np.radians(30))
+target = {k: v for k, v in hdr.items() if not k.endswith("3")}
+target.update(NAXIS=2, NAXIS1=nx, NAXIS2=ny, CRPIX1=nx / 2.0, CRPIX2=ny / 2.0, CRVAL1=10.0 - 1e-4 * nx / 2, CRVAL2=20.0 + 1e-4 * ny / 2,
+              PC1_1=c_, PC1_2=-s_, PC2_1=s_, PC2_2=c_)
+arr.allow_huge_operations = True
+cube_to_cube("host array -> reproject (30 deg), slabs of planes -> host array", lambda: arr.reproject(target), shape)
+ts = []
+for _ in range(3):
+    synchronize(); t0 = time.perf_counter()
+    arr.median(axis=1)
+    synchronize(); ts.append(time.perf_counter() - t0)
+best = min(ts)
+print("%-58s %8.1f ms  %6.1f GB/s  %8.0f Mvoxel/s   all runs (ms): %s" % (
+    "host array -> slabs of planes -> median along y", best * 1e3, nbytes / best / 1e9, nz * ny * nx / best / 1e6,
+    " ".join("%.0f" % (t * 1e3) for t in ts)), flush=True)
 os.remove(outp)
 os.environ["SPC_HBM_BUDGET"] = str(1 << 42)
 res = SpectralCube.read(path)
