@@ -980,7 +980,11 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
         // at 1024^3 (timing-only ablation, tests/bench_select_ablate.py); 32 spaxels: 0.92 ms.  SPC_SELECT_BT=256: the former table.
         {
             const char* be = getenv("SPC_SELECT_BT");
-            if (!(be && atoi(be) == 256)) {
+            // (rays of up to 256 samples keep the 256-thread table - 32 spaxels per block already, and the per-ray costs of the
+            //  descent dominate: 2.26 against 2.46 ms at 256 x 2048 x 2048 - and so do rays above 2048 samples with a mask ARRAY,
+            //  whose 8 spaxels per block make 8-byte runs of mask bytes either way: 4.1 against 5.1 ms at 4096 x 512 x 512)
+            const bool keep256 = cube->nz <= 256 || (cube->nz > 2048 && arr);
+            if (!(be && atoi(be) == 256) && (!keep256 || (be && atoi(be) == 512))) {
                 const int64_t nzr = cube->nz;
                 const int ts2 = nzr <= 512 ? 64 : (nzr <= 1024 ? 32 : (nzr <= 2048 ? 16 : 8));
                 const int kpl2 = nzr <= 128 ? 16 : (nzr <= 256 ? 32 : 64);

@@ -318,7 +318,7 @@ def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
         emad = np.nanmedian(np.abs(fz - emed[None]), axis=0)
         emed_nomask = np.nanmedian(d, axis=0)
     # (default: 512-thread blocks, descriptor loads; then 64-bit addresses, the 256-thread table with and without descriptors)
-    for env in ({}, {"SPC_SELECT_DESC": "0"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "1"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "0"},
+    for env in ({}, {"SPC_SELECT_DESC": "0"}, {"SPC_SELECT_BT": "512"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "1"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "0"},
                 {"SPC_SELECT_REG": "0"}, {"SPC_SELECT_REG": "0", "SPC_SELECT_RADIX16": "0"}):
         for k in ("SPC_SELECT_REG", "SPC_SELECT_RADIX16", "SPC_SELECT_BT", "SPC_SELECT_DESC"):
             monkeypatch.delenv(k, raising=False)
