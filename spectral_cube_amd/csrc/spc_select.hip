@@ -984,10 +984,36 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
             //  descent dominate: 2.26 against 2.46 ms at 256 x 2048 x 2048 - and so do rays above 2048 samples with a mask ARRAY,
             //  whose 8 spaxels per block make 8-byte runs of mask bytes either way: 4.1 against 5.1 ms at 4096 x 512 x 512)
             const bool keep256 = cube->nz <= 256 || (cube->nz > 2048 && arr);
-            if (!(be && atoi(be) == 256) && (!keep256 || (be && atoi(be) == 512))) {
+            // Short rays (up to 256 samples): few lanes per ray.  What a pass costs beyond counting the keys - the lane's share
+            // of the histogram atomics, the barrier, every lane's walk over the 16 totals - is paid per LANE, and with 8 lanes
+            // on a ray of 100 samples it is most of the pass (0.8 - 1.1 ms per pass at 100 x 2048 x 4096 against 0.25 ms for
+            // the same bytes in rays of 1024): 2 lanes per ray up to 128 samples, 4 up to 256, 64 keys each - and 128 / 64
+            // adjacent spaxels per block.  SPC_SELECT_SHORT=0: the former table.
+            if (cube->nz <= 256 && !(be && atoi(be) != 0) && spc_env_on("SPC_SELECT_SHORT")) {
+                const int64_t nzr = cube->nz;
+                const int tss = nzr <= 128 ? 128 : 64;
+                const int kpls = nzr <= 32 ? 16 : (nzr <= 64 ? 32 : 64);
+                const bool descs = sel_desc_fits(tss, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1, 256) && spc_env_on("SPC_SELECT_DESC");
+                dim3 grids((unsigned)(cube->ny * ((cube->nx + tss - 1) / tss)));
+#define SPC_LAUNCH_SHORT(TS_, K_)                                                                                                    \
+                do {                                                                                                                \
+                    if (descs) { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, true, 256>), grids, dim3(256), 0, st, A);   \
+                                 else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, true, 256>), grids, dim3(256), 0, st, A); }    \
+                    else { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, false, 256>), grids, dim3(256), 0, st, A);        \
+                           else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, false, 256>), grids, dim3(256), 0, st, A); }         \
+                } while (0)
+                if (tss == 64) SPC_LAUNCH_SHORT(64, 64);
+                else if (kpls == 16) SPC_LAUNCH_SHORT(128, 16);
+                else if (kpls == 32) SPC_LAUNCH_SHORT(128, 32);
+                else SPC_LAUNCH_SHORT(128, 64);
+#undef SPC_LAUNCH_SHORT
+                SPC_LAUNCH_CHECK();
+                return SPC_OK;
+            }
+            if (!(be && atoi(be) == 256) && !keep256) {
                 const int64_t nzr = cube->nz;
                 const int ts2 = nzr <= 512 ? 64 : (nzr <= 1024 ? 32 : (nzr <= 2048 ? 16 : 8));
-                const int kpl2 = nzr <= 128 ? 16 : (nzr <= 256 ? 32 : 64);
+                const int kpl2 = 64;
                 const bool desc2 = sel_desc_fits(ts2, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1, 512) && spc_env_on("SPC_SELECT_DESC");
                 dim3 grid2((unsigned)(cube->ny * ((cube->nx + ts2 - 1) / ts2)));
 #define SPC_LAUNCH_BT(TS_, K_)                                                                                                       \
@@ -997,7 +1023,8 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
                     else { if (arr) hipLaunchKernelGGL((select_reg_kernel<TS_, K_, true, false, 512>), grid2, dim3(512), 0, st, A);        \
                            else hipLaunchKernelGGL((select_reg_kernel<TS_, K_, false, false, 512>), grid2, dim3(512), 0, st, A); }         \
                 } while (0)
-                if (ts2 == 64) { if (kpl2 == 16) SPC_LAUNCH_BT(64, 16); else if (kpl2 == 32) SPC_LAUNCH_BT(64, 32); else SPC_LAUNCH_BT(64, 64); }
+                (void)kpl2;
+                if (ts2 == 64) SPC_LAUNCH_BT(64, 64);
                 else if (ts2 == 32) SPC_LAUNCH_BT(32, 64);
                 else if (ts2 == 16) SPC_LAUNCH_BT(16, 64);
                 else SPC_LAUNCH_BT(8, 64);
@@ -1227,6 +1254,21 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
             SPC_LAUNCH_CHECK();
             return SPC_OK;
         }
+    }
+    // short rays: few lanes per ray (see spc_percentile_axis0_f32): 2 for 65 .. 128 samples, 4 up to 256
+    if (cube->nz > 64 && cube->nz <= 256 && !A.spread_mad && spc_env_on("SPC_SIGMA_SHORT") &&
+        sel_desc_fits(cube->nz <= 128 ? 128 : 64, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1, 256)) {
+        const int tss = cube->nz <= 128 ? 128 : 64;
+        dim3 grids((unsigned)(cube->ny * ((cube->nx + tss - 1) / tss)));
+        if (tss == 128) {
+            if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<128, 64, true, false, true, 256>), grids, dim3(256), 0, st, A);
+            else hipLaunchKernelGGL((sigma_clip_reg_kernel<128, 64, false, false, true, 256>), grids, dim3(256), 0, st, A);
+        } else {
+            if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<64, 64, true, false, true, 256>), grids, dim3(256), 0, st, A);
+            else hipLaunchKernelGGL((sigma_clip_reg_kernel<64, 64, false, false, true, 256>), grids, dim3(256), 0, st, A);
+        }
+        SPC_LAUNCH_CHECK();
+        return SPC_OK;
     }
     const int ts = cube->nz <= 512 ? 32 : (cube->nz <= 1024 ? 16 : 8);
     const bool desc = sel_desc_fits(ts, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1) && spc_env_on("SPC_SELECT_DESC");

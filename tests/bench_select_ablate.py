@@ -18,10 +18,10 @@ for shape in shapes:
         fn(); synchronize(); e0, e1 = Event(), Event(); e0.record()
         for _ in range(n): fn()
         e1.record(); e1.synchronize(); return e0.elapsed_ms(e1) / n
-    for desc, bt in (("0", "0"), ("1", "0"), ("0", "512"), ("1", "512"), ("0", "1024"), ("1", "1024")):
+    for desc, bt in (("1", "256"), ("1", "512")):
         os.environ["SPC_SELECT_DESC"] = desc
         os.environ["SPC_SELECT_BT"] = bt
-        for ab, what in (("0", "full"), ("1", "load only")):
+        for ab, what in (("0", "full"), ("1", "load only"), ("2", "1 pass"), ("3", "2 passes"), ("4", "3 passes"), ("5", "4 passes (no candidates)")):
             os.environ["SPC_SELECT_ABLATE"] = ab
             print("bt=%s desc=%s %-26s no mask %.3f ms | u8 mask %.3f ms" % (bt, desc, what, timeit(lambda: ops.percentile_axis0(cube, 50.0)),
                   timeit(lambda: ops.percentile_axis0(cube, 50.0, mask=mspec))), flush=True)

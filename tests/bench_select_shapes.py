@@ -17,7 +17,7 @@ for shape in ((100, 2048, 4096), (256, 2048, 2048), (512, 1024, 2048), (1024, 10
     _replicate_rows(cube, tile, 4); _replicate_rows(mask, tmask, 1)
     mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=mask)
     row = []
-    for bt in ("256", "512"):
+    for bt in ("256", "512", "0"):
         os.environ["SPC_SELECT_BT"] = bt
         row.append("bt=%s: no mask %.3f ms, u8 mask %.3f ms" % (bt, timeit(lambda: ops.percentile_axis0(cube, 50.0)), timeit(lambda: ops.percentile_axis0(cube, 50.0, mask=mspec))))
     os.environ.pop("SPC_SELECT_BT")

@@ -292,7 +292,7 @@ def test_chunk_functions_under_dask_map_blocks(gpu, tmp_path):
     assert r.returncode == 0 and "DASK_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (130, 2, 70), (260, 3, 67), (515, 2, 37), (1030, 2, 21), (2050, 1, 12), (4100, 1, 5)])
+@pytest.mark.parametrize("shape", [(7, 5, 9), (40, 3, 70), (64, 2, 130), (100, 3, 200), (130, 2, 70), (260, 3, 67), (515, 2, 37), (1030, 2, 21), (2050, 1, 12), (4100, 1, 5)])
 def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
     """np.nanmedian / np.nanpercentile of masked rays through every selection kernel: the register-resident rays
     (32 / 16 / 8 spaxels per block and 16 - 128 keys per lane by ray length, lengths that are no multiple of the lanes per ray, tiles hanging
@@ -318,9 +318,9 @@ def test_percentile_axis0_every_kernel(gpu, shape, monkeypatch):
         emad = np.nanmedian(np.abs(fz - emed[None]), axis=0)
         emed_nomask = np.nanmedian(d, axis=0)
     # (default: 512-thread blocks, descriptor loads; then 64-bit addresses, the 256-thread table with and without descriptors)
-    for env in ({}, {"SPC_SELECT_DESC": "0"}, {"SPC_SELECT_BT": "512"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "1"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "0"},
+    for env in ({}, {"SPC_SELECT_DESC": "0"}, {"SPC_SELECT_SHORT": "0"}, {"SPC_SELECT_BT": "512"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "1"}, {"SPC_SELECT_BT": "256", "SPC_SELECT_DESC": "0"},
                 {"SPC_SELECT_REG": "0"}, {"SPC_SELECT_REG": "0", "SPC_SELECT_RADIX16": "0"}):
-        for k in ("SPC_SELECT_REG", "SPC_SELECT_RADIX16", "SPC_SELECT_BT", "SPC_SELECT_DESC"):
+        for k in ("SPC_SELECT_REG", "SPC_SELECT_RADIX16", "SPC_SELECT_BT", "SPC_SELECT_DESC", "SPC_SELECT_SHORT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -447,7 +447,7 @@ def test_spectral_smooth_wide_symmetric_rings(gpu, ntaps, monkeypatch):
     assert np.mean(got[ok] != ref[ok]) < 0.01          # different float64 summation order: rare float32 flips only
 
 
-@pytest.mark.parametrize("shape", [(9, 4, 11), (60, 3, 70), (515, 2, 37), (1030, 2, 21), (2100, 2, 9)])
+@pytest.mark.parametrize("shape", [(9, 4, 11), (60, 3, 70), (100, 3, 150), (200, 2, 70), (515, 2, 37), (1030, 2, 21), (2100, 2, 9)])
 def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
     """sigma clipping with the rays resident in registers (one kernel for all iterations) against the oracle's
     restatement of astropy.stats.sigma_clip(axis=0) and against the loop of separate kernels (the same clipped set:
@@ -474,6 +474,9 @@ def test_sigma_clip_fused_kernel(gpu, shape, monkeypatch):
             monkeypatch.setenv("SPC_SIGMA_BT", bt)
             assert np.array_equal(ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get(), got, equal_nan=True), (kw, bt)
         monkeypatch.delenv("SPC_SIGMA_BT")
+        monkeypatch.setenv("SPC_SIGMA_SHORT", "0")                   # (and without the few-lanes-per-ray table of short rays)
+        assert np.array_equal(ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get(), got, equal_nan=True), kw
+        monkeypatch.delenv("SPC_SIGMA_SHORT")
         monkeypatch.setenv("SPC_SIGMA_CLIP_FUSED", "0")
         ref = ops.sigma_clip_axis0(dd, sigma=sig, mask=spec, **kw).get()
         assert np.array_equal(got, ref, equal_nan=True), kw
