@@ -720,18 +720,41 @@ inline bool is_sym(const float* k, int R) {
     return true;
 }
 
+// the general (ring) kernel's three forms for one mask kind.  Its own function so that the fully unrolled 49- and 65-tap
+// rings - minutes of compile time each - can be instantiated in translation units of their own (csrc/spc_spatial_conv_r65m.hip:
+// the mask-array forms), which `make -j` builds side by side.
+template <int R, bool ARR>
+int launch_sep_general(const SpArgs& A, hipStream_t st, dim3 grid, bool iso, bool pred) {
+    dim3 block(kThreads);
+    if (iso && !pred) hipLaunchKernelGGL((spatial_sep_kernel<R, ARR, false, true>), grid, block, 0, st, A);
+    else if (iso) hipLaunchKernelGGL((spatial_sep_kernel<R, ARR, true, true>), grid, block, 0, st, A);
+    else hipLaunchKernelGGL((spatial_sep_kernel<R, ARR, true, false>), grid, block, 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+// the all-valid pass (one kernel: 4 minutes of compile time at 65 taps - spc_spatial_conv_r65f.hip)
+template <int R>
+int launch_sep_fast(const SpArgs& A, hipStream_t st, bool iso) {
+    dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1), block(kThreads);
+    if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true>), fgrid, block, 0, st, A);
+    else if constexpr (R <= 33) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
+    // (49 / 65 taps: the host only asks for this pass when kx == ky - two weight sets do not fit the SGPR file)
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+#ifdef SPC_SPLIT_MASKED
+extern template int launch_sep_general<SPC_SPLIT_MASKED, true>(const SpArgs&, hipStream_t, dim3, bool, bool);
+extern template int launch_sep_fast<SPC_SPLIT_MASKED>(const SpArgs&, hipStream_t, bool);
+#endif
+
 template <int R>
 int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
-    dim3 block(kThreads);
     bool iso = true;
     for (int i = 0; i < R; ++i) iso = iso && (A.ky[i] == A.kx[i]);
     if constexpr (R <= 33 || R == 49 || R == 65) {
         if (A.status) {      // speculative all-valid pass (the general kernel below redoes dirty tiles)
-            dim3 fgrid((unsigned)A.fast_nstrips, (unsigned)A.nz, 1);
-            if (iso) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, true>), fgrid, block, 0, st, A);
-            else if constexpr (R <= 33) hipLaunchKernelGGL((spatial_sep_fast_kernel<R, false>), fgrid, block, 0, st, A);
-            // (49 / 65 taps: the host only asks for this pass when kx == ky - two weight sets do not fit the SGPR file)
-            SPC_LAUNCH_CHECK();
+            const int rc = launch_sep_fast<R>(A, st, iso);
+            if (rc != SPC_OK) return rc;
         }
     }
     const bool pred = (A.mask.flags & (SPC_MASK_GT | SPC_MASK_GE | SPC_MASK_LT | SPC_MASK_LE)) != 0;
@@ -785,18 +808,7 @@ int launch_sep(const SpArgs& A, hipStream_t st, dim3 grid, bool arr) {
             return SPC_OK;
         }
     }
-    if (iso && !pred) {
-        if (arr) hipLaunchKernelGGL((spatial_sep_kernel<R, true, false, true>), grid, block, 0, st, A);
-        else hipLaunchKernelGGL((spatial_sep_kernel<R, false, false, true>), grid, block, 0, st, A);
-    } else if (iso) {
-        if (arr) hipLaunchKernelGGL((spatial_sep_kernel<R, true, true, true>), grid, block, 0, st, A);
-        else hipLaunchKernelGGL((spatial_sep_kernel<R, false, true, true>), grid, block, 0, st, A);
-    } else {
-        if (arr) hipLaunchKernelGGL((spatial_sep_kernel<R, true, true, false>), grid, block, 0, st, A);
-        else hipLaunchKernelGGL((spatial_sep_kernel<R, false, true, false>), grid, block, 0, st, A);
-    }
-    SPC_LAUNCH_CHECK();
-    return SPC_OK;
+    return arr ? launch_sep_general<R, true>(A, st, grid, iso, pred) : launch_sep_general<R, false>(A, st, grid, iso, pred);
 }
 
 
