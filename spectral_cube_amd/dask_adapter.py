@@ -86,17 +86,53 @@ def _ctx(device):
     return st
 
 
+_helpers = None
+_helpers_lock = threading.Lock()
+
+
+def _copy_pool():
+    """threads that copy pieces of a chunk into the pinned buffers (numpy releases the GIL for these copies).  A dask chunk
+    of apply_function_parallel_spectral is a (nz, cy, cx) window of the cube - rows of cx samples, a KiB or so apart in
+    memory - and one thread moves such a window at 3 - 5 GB/s: with one copy per worker the link idles."""
+    global _helpers
+    with _helpers_lock:
+        if _helpers is None:
+            from concurrent.futures import ThreadPoolExecutor
+            import os
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 4
+            _helpers = ThreadPoolExecutor(max_workers=max(2, min(32, ncpu // 2)), thread_name_prefix="spc-stage")
+    return _helpers
+
+
 def _stage(chunk, device):
     """chunk (any real dtype, any strides) -> float32 DeviceArray, through the thread's pinned buffer and stream.
-    Returns (DeviceArray, thread stage); the copy is queued, not awaited."""
+    Returns (DeviceArray, thread stage); the copy is queued, not awaited.  The chunk is cut into runs of planes: helper
+    threads convert / copy them into the pinned buffer side by side, and every run goes up as soon as it has been copied -
+    the H2D of run k overlaps the host copy of run k + 1."""
     st = _ctx(device)
     n = int(chunk.size)
     st.stream.synchronize()                                  # the previous chunk's H2D has left the buffer
     ptr = st.pinned(n * 4)
     view = np.frombuffer((C.c_byte * (n * 4)).from_address(ptr), dtype=np.float32, count=n).reshape(chunk.shape)
-    np.copyto(view, chunk, casting="unsafe")
     dev = st.buffer("in", chunk.shape, np.float32)
-    _lib.call("spc_memcpy_h2d", device, C.c_void_p(dev.ptr), C.c_void_p(ptr), C.c_size_t(n * 4), st.stream.handle)
+    nz = chunk.shape[0] if chunk.ndim == 3 else 0
+    plane = n // nz if nz else 0
+    pieces = min(8, nz, (n * 4) >> 24) if nz else 0          # runs of >= 16 MiB
+    if pieces < 2:
+        np.copyto(view, chunk, casting="unsafe")
+        _lib.call("spc_memcpy_h2d", device, C.c_void_p(dev.ptr), C.c_void_p(ptr), C.c_size_t(n * 4), st.stream.handle)
+        return dev, st
+    pool = _copy_pool()
+    cuts = [nz * k // pieces for k in range(pieces + 1)]
+    jobs = [pool.submit(np.copyto, view[a:b], chunk[a:b], casting="unsafe") for a, b in zip(cuts[:-1], cuts[1:])]
+    for (a, b), job in zip(zip(cuts[:-1], cuts[1:]), jobs):
+        job.result()
+        off = a * plane * 4
+        _lib.call("spc_memcpy_h2d", device, C.c_void_p(dev.ptr + off), C.c_void_p(ptr + off), C.c_size_t((b - a) * plane * 4),
+                  st.stream.handle)
     return dev, st
 
 
