@@ -36,7 +36,18 @@ struct SelArgs {
     int along_ray;
     uint32_t key_min, key_span;            // sel_key_range of the mask's predicate terms (filled by the launcher)
     int ablate;                            // timing experiments only (SPC_SELECT_ABLATE): 1 = no descent, 2.. = passes
+    int xcd_group;                         // tiles of a row kept on one XCD (sel_tile_of_block)
 };
+
+// Block -> tile order that keeps `g` neighbouring tiles of a row on ONE XCD (blocks go round the 8 XCDs by index): a tile
+// of 16 spaxels is half a 128-byte line per plane, and the block holding the other half should find it in the same L2.
+__device__ __forceinline__ int64_t sel_tile_of_block(int64_t bid, int64_t nblocks, int g) {
+    if (g <= 1) return bid;
+    const int64_t span = 8 * (int64_t)g, whole = nblocks / span * span;
+    if (bid >= whole) return bid;
+    const int64_t base = bid / span * span, r = bid - base;
+    return base + (r % 8) * g + r / 8;
+}
 
 __device__ __forceinline__ uint32_t fkey(float v) {
     const uint32_t u = __float_as_uint(v);
@@ -683,7 +694,8 @@ __global__ __launch_bounds__(BT, BT == 256 ? (KPL == 128 ? 2 : 5) : (BT == 512 ?
     // ray of the tile, slice of the ray: adjacent lanes hold adjacent spaxels - or, for rays along x, adjacent samples
     const int r = A.along_ray ? t / kLanesPerRay : t % TS, j = A.along_ray ? t % kLanesPerRay : t / TS;
     const int64_t tiles_x = (A.nx + TS - 1) / TS;
-    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
+    const int64_t tile = sel_tile_of_block(blockIdx.x, gridDim.x, A.xcd_group);
+    const int64_t y = tile / tiles_x, x0 = (tile % tiles_x) * TS;
     const int nz = (int)A.nz;
     const bool col_in = x0 + r < A.nx;
     const bool use_cen = A.center != nullptr;
@@ -737,6 +749,7 @@ struct ClipRegArgs {
     int cen_mean;               // centre: 0 median, 1 mean
     int spread_mad;             // spread: 0 std, 1 mad_std
     uint32_t key_min, key_span;            // sel_key_range of the mask's predicate terms (filled by the launcher)
+    int xcd_group;              // tiles of a row kept on one XCD (sel_tile_of_block)
 };
 
 // |x - centre| of the samples inside the clip window (the MAD's keys)
@@ -758,7 +771,8 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip
     const int t = threadIdx.x;
     const int r = t % TS, j = t / TS;
     const int64_t tiles_x = (A.nx + TS - 1) / TS;
-    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
+    const int64_t tile = sel_tile_of_block(blockIdx.x, gridDim.x, A.xcd_group);
+    const int64_t y = tile / tiles_x, x0 = (tile % tiles_x) * TS;
     const int nz = (int)A.nz;
     const bool col_in = x0 + r < A.nx;
     uint32_t key[KPL];
@@ -965,6 +979,10 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
     A.q = q; A.center = d_center; A.scale = scale; A.out = d_out;
     A.x_stride = 1; A.m_x_stride = 1; A.along_ray = 0;
     { const char* ab = getenv("SPC_SELECT_ABLATE"); A.ablate = ab ? atoi(ab) : 0; }
+    // (16 neighbouring tiles of a row per XCD: a block's half - or quarter - of a 128-byte line is found in the L2 that fetched it
+    //  for its neighbour.  1024^3: the clip kernel's read + write floor 4.21 -> 3.28 ms, the 256-thread selection 2.97 -> 2.65 ms;
+    //  groups of 2 / 4 / 8: 3.95 / 3.54 / 3.32 - 3.6 ms; no effect on the 512-thread selection.  SPC_XCD_GROUP=0: block = tile)
+    { const char* xg = getenv("SPC_XCD_GROUP"); A.xcd_group = xg ? atoi(xg) : 16; }
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     const bool v4 = (cube->nx % 4 == 0) && (cube->row_stride % 4 == 0) && (cube->plane_stride % 4 == 0) &&
                     ((((uintptr_t)cube->d_data) & 15) == 0) &&
@@ -1235,6 +1253,10 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     A.out = d_out;
     A.lo_s = sigma_lower; A.hi_s = sigma_upper; A.maxiters = maxiters; A.cen_mean = center_is_mean ? 1 : 0;
     A.spread_mad = spread_is_mad ? 1 : 0;
+    // (16 neighbouring tiles of a row per XCD: a block's half - or quarter - of a 128-byte line is found in the L2 that fetched it
+    //  for its neighbour.  1024^3: the clip kernel's read + write floor 4.21 -> 3.28 ms, the 256-thread selection 2.97 -> 2.65 ms;
+    //  groups of 2 / 4 / 8: 3.95 / 3.54 / 3.32 - 3.6 ms; no effect on the 512-thread selection.  SPC_XCD_GROUP=0: block = tile)
+    { const char* xg = getenv("SPC_XCD_GROUP"); A.xcd_group = xg ? atoi(xg) : 16; }
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
     // 256-thread blocks for the median forms: with 512 threads (wider runs per plane, see spc_percentile_axis0_f32) the read +
