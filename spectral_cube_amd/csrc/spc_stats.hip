@@ -80,16 +80,21 @@ __global__ __launch_bounds__(256) void stats_global_kernel(const StatArgs A) {
     Acc a = acc_zero();
     const int t = threadIdx.x;
     constexpr int U = 4;
-    for (int64_t r = 0; r < A.nrows; ++r) {
-        const int64_t off = (A.nrows == 1) ? 0 : (r / A.ny) * A.row_a + (r % A.ny) * A.row_b;
-        const int64_t moff = (A.nrows == 1) ? 0 : (r / A.ny) * A.mask.plane_stride + (r % A.ny) * A.mask.row_stride;
+    // one contiguous run: every block strides through it.  Rows of a strided view (a strip of a cube): the blocks share the ROWS
+    // out - round 3a walked them one after the other with all blocks striding inside each, which left a row of 1024 samples to
+    // one block and the others idle (64 MB in 19 ms)
+    const bool rows = A.nrows > 1;
+    for (int64_t r = rows ? blockIdx.x : 0; r < A.nrows; r += rows ? gridDim.x : 1) {
+        const int64_t off = !rows ? 0 : (r / A.ny) * A.row_a + (r % A.ny) * A.row_b;
+        const int64_t moff = !rows ? 0 : (r / A.ny) * A.mask.plane_stride + (r % A.ny) * A.mask.row_stride;
         const float* p = A.cube + off;
         const uint8_t* pm = ARR ? A.mask.arr + moff : nullptr;
         const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
         const int64_t n4 = al ? A.rowlen / 4 : 0;
         // 16-byte body, U chunks in flight per thread
-        const int64_t stride = (int64_t)gridDim.x * 256;
-        int64_t i = (int64_t)blockIdx.x * 256 + t;
+        const int64_t stride = rows ? 256 : (int64_t)gridDim.x * 256;
+        const int64_t first = rows ? 0 : (int64_t)blockIdx.x * 256;
+        int64_t i = first + t;
         for (; i + (U - 1) * stride < n4; i += U * stride) {
             f32x4 v[U];
             uint32_t m[U];
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void stats_global_kernel(const StatArgs A) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu));
         }
-        for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * 256 + t; j < A.rowlen; j += stride) {
+        for (int64_t j = n4 * 4 + first + t; j < A.rowlen; j += stride) {
             const float v = p[j];
             acc_add(a, v, included(A.mask, v, ARR ? pm[j] : 1u));
         }
@@ -610,7 +615,7 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, con
     else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
     // enough blocks to fill the chip, few enough that the host-side finish is trivial
     const int64_t per_block = 256 * 4 * 4;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, (A.rowlen + per_block - 1) / per_block));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, contig ? (A.rowlen + per_block - 1) / per_block : (A.nrows + 3) / 4));
     SpcWorkspace ws(d_workspace, workspace_bytes);
     SPC_WS_TAKE(d_partial, ws, double, 5 * (size_t)nblocks);
     A.partial = d_partial;
