@@ -931,21 +931,23 @@ __global__ __launch_bounds__(256) void gselect_kernel(const GSelArgs A) {
             if (k > A.prefix) mymin = min(mymin, k);
         }
     };
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t r = 0; r < A.nrows; ++r) {
-        const int64_t off = (A.nrows == 1) ? 0 : (r / A.ny) * A.row_a + (r % A.ny) * A.row_b;
-        const int64_t moff = (A.nrows == 1) ? 0 : (r / A.ny) * A.mask.plane_stride + (r % A.ny) * A.mask.row_stride;
+    // (one contiguous run: every block strides through it; rows of a strided view: the blocks share the rows out)
+    const bool rows = A.nrows > 1;
+    const int64_t stride = rows ? 256 : (int64_t)gridDim.x * 256, first = rows ? 0 : (int64_t)blockIdx.x * 256;
+    for (int64_t r = rows ? blockIdx.x : 0; r < A.nrows; r += rows ? gridDim.x : 1) {
+        const int64_t off = !rows ? 0 : (r / A.ny) * A.row_a + (r % A.ny) * A.row_b;
+        const int64_t moff = !rows ? 0 : (r / A.ny) * A.mask.plane_stride + (r % A.ny) * A.mask.row_stride;
         const float* p = A.cube + off;
         const uint8_t* pm = ARR ? A.mask.arr + moff : nullptr;
         const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
         const int64_t n4 = al ? A.rowlen / 4 : 0;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + t; i < n4; i += stride) {
+        for (int64_t i = first + t; i < n4; i += stride) {
             const f32x4s v = __builtin_nontemporal_load(reinterpret_cast<const f32x4s*>(p) + i);
             const uint32_t m = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm) + i) : 0x01010101u;
 #pragma unroll
             for (int c = 0; c < 4; ++c) take(v[c], (m >> (8 * c)) & 0xffu);
         }
-        for (int64_t j = n4 * 4 + (int64_t)blockIdx.x * 256 + t; j < A.rowlen; j += stride) take(p[j], ARR ? pm[j] : 1u);
+        for (int64_t j = n4 * 4 + first + t; j < A.rowlen; j += stride) take(p[j], ARR ? pm[j] : 1u);
     }
     if (MODE == 0) {
         __syncthreads();
@@ -1121,7 +1123,7 @@ extern "C" int spc_percentile_global_f32(int device, void* stream, const spc_cub
     if (contig) { A.nrows = 1; A.rowlen = A.nz * A.ny * A.nx; A.row_a = 0; A.row_b = 0; }
     else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
     const int64_t per_block = 256 * 4 * 8;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (A.rowlen + per_block - 1) / per_block));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, contig ? (A.rowlen + per_block - 1) / per_block : (A.nrows + 3) / 4));
     SpcWorkspace ws(d_workspace, workspace_bytes);
     SPC_WS_TAKE(d_hist, ws, unsigned long long, 257);  // 256 counters + (as uint32) the "next key" cell
     A.hist = d_hist;
@@ -1348,7 +1350,7 @@ extern "C" int spc_key_histogram_f32(int device, void* stream, const spc_cube_f3
     if (contig) { A.nrows = 1; A.rowlen = A.nz * A.ny * A.nx; A.row_a = 0; A.row_b = 0; }
     else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
     const int64_t per_block = 256 * 4 * 8;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (A.rowlen + per_block - 1) / per_block));
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, contig ? (A.rowlen + per_block - 1) / per_block : (A.nrows + 3) / 4));
     SpcWorkspace ws(d_workspace, workspace_bytes);
     SPC_WS_TAKE(d_hist, ws, unsigned long long, 257);
     A.hist = d_hist;
