@@ -494,12 +494,17 @@ struct SelShared {
     int level;                                                  // (SelCache: the pass a descent resumes after)
 };
 
-// What a descent knew after each of its first four passes (4, 8, 12, 16 key bits), per ray: the prefix, how many keys
-// lie below the prefix' bin and how many inside it.  A later descent over the SAME keys for another rank resumes after
-// the deepest pass whose bin still holds that rank (the clip loop: the median moves by a few ranks per iteration).
+// The histograms an earlier descent over the SAME keys counted in its first four passes (4, 8, 12, 16 key bits), per ray, each with
+// the prefix it was counted under.  A later descent for another rank (the clip loop: the median moves by a few ranks per iteration)
+// walks them instead of counting - pass p's cached histogram serves as long as the new path's prefix above it is the one it was
+// counted under, also when the new rank picks ANOTHER digit from it - and starts counting at the first pass whose cached
+// histogram belongs to another bin (block-wide: the earliest of its rays' answers).  `prefix / below / eq / krel`: the walk's state
+// after each pass, handed from the one lane per ray that walks to the others.
 template <int TS>
 struct SelCache {
-    uint32_t prefix[4][TS], below[4][TS], eq[4][TS];
+    uint16_t hist[4][TS][16];
+    uint32_t pre[4][TS];
+    uint32_t prefix[4][TS], below[4][TS], eq[4][TS], krel[4][TS];
 };
 
 // every thread of the block: zero what a descent needs (followed by a barrier at the caller)
@@ -568,23 +573,43 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
     bool done = false;                                           // block-uniform
     int start = 0;
     if (C != nullptr && resume) {
-        // the deepest cached pass whose bin holds rank k (the bins are nested); the block resumes after the shallowest
-        // of its rays' answers (rays without samples do not care)
-        int lvl = 3;
-        if (n > 0) {
-            lvl = -1;
+        if (j == 0) {                                            // one lane per ray walks the cached histograms
+            int lvl = 3;                                         // (rays without samples do not care)
+            if (n > 0) {
+                lvl = -1;
+                uint32_t pf = 0u;
+                int bl = 0, kk = k;
+                bool live = true;
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if ((uint32_t)k - C->below[p][r] < C->eq[p][r]) lvl = p;
+                for (int p = 0; p < 4; ++p) {
+                    live = live && (p == 0 || pf == C->pre[p][r]);
+                    if (live) {
+                        uint32_t dsel = 15u;
+                        int e = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int d = 0; d < 16; ++d) {
+                            const int c = (int)C->hist[p][r][d];
+                            if (!found) {
+                                if (kk < c) { dsel = d; found = true; e = c; }
+                                else { kk -= c; bl += c; }
+                            }
+                        }
+                        pf |= dsel << (28 - 4 * p);
+                        C->prefix[p][r] = pf; C->below[p][r] = (uint32_t)bl; C->eq[p][r] = (uint32_t)e; C->krel[p][r] = (uint32_t)kk;
+                        lvl = p;
+                    }
+                }
+            }
+            if (lvl < 3) atomicMin(&S.level, lvl);
         }
-        if (j == 0 && lvl < 3) atomicMin(&S.level, lvl);
         __syncthreads();
         const int sl = S.level;
         if (sl >= 0) {
             prefix = C->prefix[sl][r];
             below = (int)C->below[sl][r];
             eq = (int)C->eq[sl][r];
-            k -= below;
+            k = (int)C->krel[sl][r];
             start = sl + 1;
         }
     }
@@ -614,16 +639,18 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
         __syncthreads();
         uint32_t dsel = 15u;
         bool found = false;
+        const bool keep = C != nullptr && pass < 4 && j == 0;    // this pass's histogram and the prefix it was counted under
+        if (keep) C->pre[pass][r] = prefix;
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
             const int c = (int)h[d];
+            if (keep) C->hist[pass][r][d] = (uint16_t)c;
             if (!found) {
                 if (k < c) { dsel = d; found = true; eq = c; }
                 else { k -= c; below += c; }
             }
         }
         prefix |= dsel << b;
-        if (C != nullptr && pass < 4 && j == 0) { C->prefix[pass][r] = prefix; C->below[pass][r] = (uint32_t)below; C->eq[pass][r] = (uint32_t)eq; }
         if (pass == 3) done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq);
     }
     if (from16) {
@@ -829,6 +856,18 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip
         }
         double cen = mean;
         float med = NAN;
+#ifdef SPC_ABLATE
+        if (A.xcd_group >= 1000 && it > 0) {                     // timing only: later iterations without their descent / without resuming
+            if (A.xcd_group == 1000) { med = (float)mean; if (!A.cen_mean) cen = mean; }
+            else {
+                uint32_t key_lo, key_hi;
+                double frac;
+                ray_select<TS, KPL, BT>(S, key, KeyIdentity{}, r, j, n, 50.0, key_lo, key_hi, frac, 8, nl, &C, false);
+                med = n > 0 ? sel_value(key_lo, key_hi, frac, 1.0) : NAN;
+                if (!A.cen_mean) cen = (double)med;
+            }
+        } else
+#endif
         if (!A.cen_mean || MAD) {
             uint32_t key_lo, key_hi;
             double frac;
