@@ -520,7 +520,7 @@ __device__ __forceinline__ void sel_reset(SelShared<TS>& S) {
 // (k: rank inside the bin; on success prefix / below / eq describe the selected KEY).  Block-uniform result.
 template <int TS, int KPL, int BT, class XF>
 __device__ __forceinline__ bool sel_rank_candidates(SelShared<TS>& S, const uint32_t (&key)[KPL], const XF& xf, int r, int j, int n, int k,
-                                                    uint32_t& prefix, int& below, int& eq) {
+                                                    uint32_t& prefix, int& below, int& eq, int cshift = 16) {
     constexpr int kLanesPerRay = BT / TS;
     const bool big = (n > 0) && (eq > kCandMax);
     if (__syncthreads_or(big ? 1 : 0)) return false;
@@ -528,7 +528,7 @@ __device__ __forceinline__ bool sel_rank_candidates(SelShared<TS>& S, const uint
 #pragma unroll
         for (int i = 0; i < KPL; ++i) {
             const uint32_t ki = xf(key[i]);
-            if (((ki ^ prefix) >> 16) == 0u) {
+            if (((ki ^ prefix) >> cshift) == 0u) {
                 const uint32_t slot = atomicAdd(&S.ncand[r], 1u);
                 S.cand[r][slot] = ki;
             }
@@ -651,7 +651,9 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
             }
         }
         prefix |= dsel << b;
-        if (pass == 3) done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq);
+        // 16 bits known: rank the bin's candidates directly when every ray's bin is small - and ask again after every further
+        // pass (data in a narrow relative range share their leading bits: their bins get small two passes later)
+        if (pass >= 3 && pass < 7) done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq, 28 - 4 * pass);
     }
     if (from16) {
         // resumed with 16 bits known (no pass ran): the candidates of the bin, or - a bin of many ties - the last passes
@@ -686,6 +688,7 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
                     }
                 }
                 prefix |= dsel << b;
+                if (pass < 7 && sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq, 28 - 4 * pass)) break;
             }
         }
     }
