@@ -15,7 +15,6 @@ the HIP library / a GPU ``load_cube`` raises.
 """
 import ctypes as C
 import os
-import threading
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
