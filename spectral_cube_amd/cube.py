@@ -253,23 +253,19 @@ class SpectralCube:
                 meta = dict(kw.pop("meta", None) or {})
                 if "BUNIT" in hdr:
                     meta["BUNIT"] = hdr["BUNIT"]
+                table = cls._beams_table_for(os.fspath(data), fshape[0]) if "beams" not in kw else None
+                if table is not None:            # a BEAMS extension makes it a varying-resolution cube (io/fits.py:216-228)
+                    cls, kw = VaryingResolutionSpectralCube, dict(kw, beam_table=table)
                 cube = cls(None, header=hdr, device=device, meta=meta, _source=src, _shape=fshape, **kw)
-                cube._mask = M.LazyMask(np.isfinite, cube=cube)
+                finite = M.LazyMask(np.isfinite, cube=cube)
+                beam_mask = cube._mask if isinstance(cube, VaryingResolutionSpectralCube) else None
+                cube._mask = finite if beam_mask is None else (finite & beam_mask)
                 return cube
             dev, hdr = io_fits.load_cube(os.fspath(data), device=device, hdu=hdu)
             meta = dict(kw.pop("meta", None) or {})
             if "BUNIT" in hdr:
                 meta["BUNIT"] = hdr["BUNIT"]
-            table = io_fits.read_beams_table(os.fspath(data)) if "beams" not in kw else None
-            if table is not None and len(table["BMAJ"]) != dev.shape[0] and "POL" in table:
-                # full-polarisation tables list every channel once per Stokes plane (cube_utils._split_stokes
-                # hands each component its rows); this path reads one plane: keep the first polarisation's rows
-                keep = table["POL"] == table["POL"][0]
-                table = {k: v[keep] for k, v in table.items()}
-            if table is not None and len(table["BMAJ"]) != dev.shape[0]:
-                warnings.warn("BEAMS table with %d rows does not match the %d channels of the cube: ignored"
-                              % (len(table["BMAJ"]), dev.shape[0]), BeamWarning)
-                table = None
+            table = cls._beams_table_for(os.fspath(data), dev.shape[0]) if "beams" not in kw else None
             if table is not None:            # a BEAMS extension makes it a varying-resolution cube (io/fits.py:216-228)
                 cls, kw = VaryingResolutionSpectralCube, dict(kw, beam_table=table)
             cube = cls(None, header=hdr, device=device, _dev=dev, meta=meta, **kw)
@@ -279,6 +275,22 @@ class SpectralCube:
         beam_mask = cube._mask if isinstance(cube, VaryingResolutionSpectralCube) else None
         cube._mask = finite if beam_mask is None else (finite & beam_mask)
         return cube
+
+    @staticmethod
+    def _beams_table_for(path, nchan):
+        """the file's BEAMS table when it has one row per channel (io/fits.py:216-228), else None"""
+        from . import io_fits
+        table = io_fits.read_beams_table(path)
+        if table is not None and len(table["BMAJ"]) != nchan and "POL" in table:
+            # full-polarisation tables list every channel once per Stokes plane (cube_utils._split_stokes
+            # hands each component its rows); this path reads one plane: keep the first polarisation's rows
+            keep = table["POL"] == table["POL"][0]
+            table = {k: v[keep] for k, v in table.items()}
+        if table is not None and len(table["BMAJ"]) != nchan:
+            warnings.warn("BEAMS table with %d rows does not match the %d channels of the cube: ignored"
+                          % (len(table["BMAJ"]), nchan), BeamWarning)
+            table = None
+        return table
 
     def write(self, filename, overwrite=False, format=None, filled=True):
         """Write the cube as FITS (io/fits.py:262-294; device byte swap, pinned read-back, no host
@@ -1375,23 +1387,36 @@ class VaryingResolutionSpectralCube(SpectralCube):
                 plans.append(plans[-1])             # same beam as the previous channel: share the launch
             else:
                 plans.append((bm, dk.as_kernel(pixscale), beam.sr / bm.sr if is_jybm else 1.0))
-        src, spec = self._device_data(), self._mask_spec()
-        out = DeviceArray(self._shape, np.float32, self.device)
-        nz, z0 = self._shape[0], 0
-        while z0 < nz:
-            z1 = z0 + 1
-            while z1 < nz and plans[z1] is plans[z0]:
-                z1 += 1
-            o = out.planes(z0, z1)
-            if plans[z0] is None:
-                ops.fill_masked(src.planes(z0, z1), spec.planes(z0, z1), np.nan, out=o)
-            else:
-                _, karr, ratio = plans[z0]
-                ops.spatial_conv(src.planes(z0, z1), karr, mask=spec.planes(z0, z1), out=o)
-                if ratio != 1.0:
-                    ops.scale_inplace(o, ratio)
-            z0 = z1
-        new = SpectralCube._new_cube_with(self, dev=out)
+        def runs(src, spec, zbase, stream=None):
+            """channels zbase .. of the cube held in `src` (their mask in `spec`): runs of channels that share a plan, one launch each"""
+            n = src.shape[0]
+            out = DeviceArray(src.shape, np.float32, self.device)
+            a = 0
+            while a < n:
+                b = a + 1
+                while b < n and plans[zbase + b] is plans[zbase + a]:
+                    b += 1
+                o, m = out.planes(a, b), (spec.planes(a, b) if spec is not None else None)
+                if plans[zbase + a] is None:
+                    ops.fill_masked(src.planes(a, b), m, np.nan, out=o, stream=stream)
+                else:
+                    _, karr, ratio = plans[zbase + a]
+                    ops.spatial_conv(src.planes(a, b), karr, mask=m, out=o, stream=stream)
+                    if ratio != 1.0:
+                        ops.scale_inplace(o, ratio, stream=stream)
+                a = b
+            return out
+
+        if self._stream_source() is not None:
+            # out of core: slabs of whole planes (every channel has its own kernel, the slab knows its first channel);
+            # pending until write() / stream_into()
+            parent = self
+            thunk = _Thunk(lambda: parent._device_data())           # (never resident: raises HugeCubeError with the budget)
+            thunk.parent, thunk.keeps_mask = parent, True
+            thunk.slab_fn = lambda dev, mspec, stream: runs(dev, mspec, int(getattr(dev, "z0", 0)), stream)
+            new = SpectralCube._new_cube_with(self, lazy=thunk, shape=self._shape)
+            return new.with_beam(beam, raise_error_jybm=False)
+        new = SpectralCube._new_cube_with(self, dev=runs(self._device_data(), self._mask_spec(), 0))
         return new.with_beam(beam, raise_error_jybm=False)
 
     def spectral_interpolate(self, *args, **kwargs):

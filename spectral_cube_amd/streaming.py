@@ -299,6 +299,7 @@ class StripPipeline:
                     strip = DeviceArray((nz, rows, nx) if self.axis == 1 else (y1 - y0, ny, nx), src.out_dtype, dev,
                                         ptr=self.bufs[slot].ptr, owner=self.bufs[slot])
                     strip.top = (y0 - h0) if self.axis == 1 else 0     # the strip's own rows are [top, top + (y1 - y0)) of what was loaded
+                    strip.z0 = y0 if self.axis == 0 else 0            # (a slab's first channel)
                     yield y0, y1, strip
                     d = self.Event(dev)                      # recorded after whatever the consumer queued on its stream
                     d.record(self.consumer)

@@ -471,6 +471,22 @@ def test_out_of_core_slabs_of_planes(gpu, tmp_path, monkeypatch):
     bcv = SpectralCube.read(d.copy(), hb).with_mask(inc).convolve_to(tgt)
     assert bcv._dev is None and bcv.beam == tgt
     assert np.array_equal(bcv.stream_into(np.empty(d.shape, np.float32)), exp_cv, equal_nan=True)
+    # ... and of a file with a BEAMS table (one kernel per run of channels; a streamed slab knows its first channel)
+    from spectral_cube_amd import io_fits, VaryingResolutionSpectralCube
+    pb = _write_cube(tmp_path, np.where(np.isnan(d), 0.0, d).astype(np.float32), hb, name="beams.fits")
+    majs = (3.0 + 0.5 * (np.arange(nz) // 7 % 3)) * pix           # runs of 7 channels share a beam
+    io_fits.append_beams_table(pb, majs, 0.7 * majs, 10.0 * (np.arange(nz) // 7 % 3))
+    tgt2 = Beam(6.0 * pix, 5.0 * pix, 30.0)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(1 << 40))
+    vres = SpectralCube.read(pb)
+    assert isinstance(vres, VaryingResolutionSpectralCube)
+    exp_v = np.asarray(vres.convolve_to(tgt2).filled_data)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 5))
+    vbig = SpectralCube.read(pb)
+    assert isinstance(vbig, VaryingResolutionSpectralCube) and vbig._stream_source() is not None
+    vcv = vbig.convolve_to(tgt2)
+    assert vcv._dev is None and vcv.beam == tgt2 and not isinstance(vcv, VaryingResolutionSpectralCube)
+    assert np.array_equal(vcv.stream_into(np.empty(d.shape, np.float32)), exp_v, equal_nan=True)
     far = dict(target, CRVAL1=float(SimpleWCS(hdr).crval[0]) + 40.0)
     monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 5))
     with pytest.raises(ValueError, match="All values in reprojected cube are nan"):
