@@ -587,7 +587,15 @@ class SpectralCube:
         dv = self._pix_size_slice(0)
         if fused_kernel is not None and fused_kernel[0]._stream_source() is not None:
             from . import streaming                     # out-of-core parent: the fused kernels, strip by strip
-            return streaming.moments(fused_kernel[0], want, d_cen, dv, cref + spec0, kernel=fused_kernel[1], cen_host=cen - cref)
+            try:
+                return streaming.moments(fused_kernel[0], want, d_cen, dv, cref + spec0, kernel=fused_kernel[1], cen_host=cen - cref)
+            except _lib.HipUnsupported:
+                # a kernel wider than the rings on a strip that holds an invalid sample (or an extremum requested): the
+                # resident path materialises the smoothed cube; here the smoothed STRIP is materialised, then reduced.
+                # The maps are rebuilt from the first strip on (a strip's rows are written whole, nothing is accumulated).
+                lz = self._lazy
+                return streaming.moments(lz.parent, want, d_cen, dv, cref + spec0, pre=lz.strip_fn,
+                                         halo=int(getattr(lz, "halo", 0)))
         if fused_kernel is None and self._stream_source() is not None:
             from . import streaming
             return streaming.moments(self, want, d_cen, dv, cref + spec0)

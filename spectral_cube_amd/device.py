@@ -208,6 +208,11 @@ class DeviceArray:
         if stream is not None:
             _lib.call("spc_stream_sync", self.device, _sh(stream))
         if self.nbytes > _PinnedPool.MAX_BYTES and out.flags.c_contiguous:
+            # the chunks come down on a NON-BLOCKING stream of their own, which is not ordered after the null stream the
+            # way the synchronous copy below is: kernels launched with stream=None (every resident cube path) must have
+            # finished before the first chunk leaves (hipStreamSynchronize(NULL) waits for the legacy default stream)
+            if stream is None:
+                _lib.call("spc_stream_sync", self.device, None)
             self._get_chunked(out)           # cube-sized: through pinned chunks, several host copies in flight
             return out
         _lib.call("spc_memcpy_d2h", self.device, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),

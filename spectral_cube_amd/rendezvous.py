@@ -23,9 +23,10 @@ The transport protocol (what ``distributed.py`` asks of a rendezvous object):
 ``tests/test_distributed_cpu.py`` runs the same drivers over a torch.distributed
 (gloo) transport with this protocol, and over this class, with world_size 2.
 """
+import json
 import os
-import pickle
 import secrets
+import stat
 import shutil
 import tempfile
 import time
@@ -33,6 +34,63 @@ import time
 
 class RendezvousTimeout(RuntimeError):
     pass
+
+
+# ---- payload encoding ----------------------------------------------------------------------------
+# The directory is shared state on the node: what is read back from it is DATA, never code.  Objects travel as JSON
+# (deserialising Python object streams from a planted file would run them); tuples and numpy scalars / small arrays -
+# what the drivers exchange: ranks, timings, statistics records, digests - keep their type through tags.
+def _enc(o):
+    import numpy as np
+    if isinstance(o, tuple):
+        return {"__tuple__": [_enc(x) for x in o]}
+    if isinstance(o, list):
+        return [_enc(x) for x in o]
+    if isinstance(o, dict):
+        if not all(isinstance(k, str) for k in o):
+            raise TypeError("rendezvous objects take string dictionary keys")
+        return {"__dict__": {k: _enc(v) for k, v in o.items()}}
+    if isinstance(o, (bytes, bytearray)):
+        return {"__bytes__": bytes(o).hex()}
+    if isinstance(o, np.ndarray):
+        return {"__nd__": [o.dtype.str, list(o.shape), np.ascontiguousarray(o).tobytes().hex()]}
+    if isinstance(o, np.generic):
+        return _enc(o.item())
+    if isinstance(o, float):
+        if o != o or o in (float("inf"), float("-inf")):
+            return {"__float__": repr(o)}
+        return o
+    if o is None or isinstance(o, (bool, int, str)):
+        return o
+    raise TypeError("cannot send %s through the rendezvous" % type(o).__name__)
+
+
+def _dec(o):
+    if isinstance(o, list):
+        return [_dec(x) for x in o]
+    if isinstance(o, dict):
+        if "__tuple__" in o:
+            return tuple(_dec(x) for x in o["__tuple__"])
+        if "__dict__" in o:
+            return {k: _dec(v) for k, v in o["__dict__"].items()}
+        if "__bytes__" in o:
+            return bytes.fromhex(o["__bytes__"])
+        if "__float__" in o:
+            return float(o["__float__"])
+        if "__nd__" in o:
+            import numpy as np
+            dt, shape, hx = o["__nd__"]
+            return np.frombuffer(bytes.fromhex(hx), dtype=np.dtype(dt)).reshape(shape).copy()
+        raise ValueError("unknown rendezvous tag")
+    return o
+
+
+def dumps(obj):
+    return json.dumps(_enc(obj), separators=(",", ":")).encode("ascii")
+
+
+def loads(raw):
+    return _dec(json.loads(bytes(raw).decode("ascii")))
 
 
 class FileRendezvous:
@@ -43,7 +101,15 @@ class FileRendezvous:
             raise ValueError("bad rank %d / world %d" % (rank, world_size))
         self.path, self.rank, self.world_size, self.timeout = os.fspath(path), int(rank), int(world_size), timeout
         self._seq = 0
-        os.makedirs(self.path, exist_ok=True)
+        os.makedirs(self.path, mode=0o700, exist_ok=True)
+        # the directory name is predictable (/dev/shm/spc_rdv_<port>_<ppid>_...): it must be OURS and closed to others,
+        # or whoever made it first could feed the ranks their payloads
+        st = os.stat(self.path)
+        if st.st_uid != os.geteuid():
+            raise PermissionError("rendezvous directory %s belongs to uid %d, not to this process (uid %d)"
+                                  % (self.path, st.st_uid, os.geteuid()))
+        if stat.S_IMODE(st.st_mode) & 0o077:
+            os.chmod(self.path, 0o700)
         self._sid = self._handshake()
 
     # ---- construction from the launcher's environment ----------------------------------------
@@ -103,7 +169,7 @@ class FileRendezvous:
                 if all(h is not None for h in hellos):
                     if hellos != seen:
                         seen, sid = hellos, secrets.token_hex(8)
-                        self._put("session", pickle.dumps((sid, hellos)))
+                        self._put("session", dumps((sid, [h.decode("ascii", "replace") for h in hellos])))
                     if all(self._get("ack.%d" % r) == sid.encode() for r in range(1, self.world_size)):
                         self._put("go", sid.encode())
                         return sid
@@ -111,16 +177,24 @@ class FileRendezvous:
         while True:
             raw = self._get("session")
             if raw is not None:
-                try:
-                    sid, hellos = pickle.loads(raw)
-                except Exception:
-                    sid, hellos = None, ()
-                if len(hellos) == self.world_size and hellos[self.rank] == nonce.encode():
+                sid, hellos = self._session(raw, None)
+                if sid is not None and len(hellos) == self.world_size and hellos[self.rank] == nonce:
                     self._put("ack.%d" % self.rank, sid.encode())
                     # rank 0 may still re-issue the session if ANOTHER rank's hello was stale when it read it:
                     # the first collective's file name carries the id, so wait until rank 0 has settled on it
                     return self._settled(sid, nonce)
             wait()
+
+    @staticmethod
+    def _session(raw, default):
+        """(session id, [nonce per rank]) of a `session` file; (default, ()) for anything that is not one"""
+        try:
+            sid, hellos = loads(raw)
+            if not isinstance(sid, str) or not isinstance(hellos, list) or not all(isinstance(h, str) for h in hellos):
+                raise ValueError
+            return sid, hellos
+        except Exception:
+            return default, ()
 
     def _settled(self, sid, nonce):
         """rank 0 writes `go.<sid>` once every acknowledgement matches; until then a newer session may appear"""
@@ -130,11 +204,8 @@ class FileRendezvous:
                 return sid
             raw = self._get("session")
             if raw is not None:
-                try:
-                    cur, hellos = pickle.loads(raw)
-                except Exception:
-                    cur, hellos = sid, ()
-                if cur != sid and len(hellos) == self.world_size and hellos[self.rank] == nonce.encode():
+                cur, hellos = self._session(raw, sid)
+                if cur != sid and len(hellos) == self.world_size and hellos[self.rank] == nonce:
                     sid = cur
                     self._put("ack.%d" % self.rank, sid.encode())
             if time.monotonic() - t0 > self.timeout:
@@ -190,7 +261,7 @@ class FileRendezvous:
         return self.allgather_bytes(payload if self.rank == 0 else b"")[0]
 
     def allgather_object(self, obj):
-        return [pickle.loads(b) for b in self.allgather_bytes(pickle.dumps(obj))]
+        return [loads(b) for b in self.allgather_bytes(dumps(obj))]
 
     def barrier(self):
         self.allgather_bytes(b"")

@@ -10,9 +10,11 @@ strip k + 1 (file -> pinned buffers -> H2D -> device decode for FITS; strided H2
 kernels of strip k run on their own stream; the 2-D maps are assembled on the device - a strip's kernel
 writes rows [y0, y1) of the final map in place.
 
-What streams: moment 0 / 1 / 2, argmax / argmin / max / min along the spectral axis and of the whole cube,
-spectral_smooth(...).moment (the fused kernels), statistics() and the axis=None reductions.  Everything else
-asks for the resident cube and raises HugeCubeError with the budget in the message.
+What streams: moments of any order along any axis, argmax / argmin / max / min, statistics() and the
+axis=None reductions, median / percentile / mad_std along the spectral axis, sigma_clip_spectrally; the cube -> cube
+operators (spectral_smooth, spatial_smooth - halo strips before a moment, slabs of whole planes to a sink -,
+spectral_interpolate, convolve_to, reproject) through map_strips into a host array or a FITS file, or fused with
+a following moment.  What still needs the resident cube raises HugeCubeError with the budget in the message.
 
 SPC_HBM_BUDGET (bytes; K / M / G suffixes) overrides the default budget = 80 % of the free HBM.
 """
@@ -134,6 +136,12 @@ class FitsSource:
             if self._fd is not None:
                 os.close(self._fd)
                 self._fd = None
+
+    def __del__(self):                   # the descriptor lives as long as the cubes that read from this source
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 # ---- the strip pipeline ------------------------------------------------------------------------------------
@@ -313,6 +321,9 @@ def _mask_terms(cube):
     """device terms of the cube's mask, array term kept on the HOST (strips of it travel with the data)"""
     if cube._mask is None:
         return None
+    cached = getattr(cube, "_stream_terms", None)
+    if cached is not None and cached[0] is cube._mask:        # (an inverted / composite boolean mask materialises a host
+        return cached[1]                                      # array: once per cube, not once per caller)
     terms = cube._mask._device_terms(cube)
     if terms is None:
         raise NotImplementedError("a streamed (out-of-core) cube takes masks made of isfinite / threshold comparisons on "
@@ -322,6 +333,10 @@ def _mask_terms(cube):
         flags |= _lib.MASK_ARRAY
     lo = float(lo) if flags & (_lib.MASK_GT | _lib.MASK_GE) else 0.0
     hi = float(hi) if flags & (_lib.MASK_LT | _lib.MASK_LE) else 0.0
+    try:
+        cube._stream_terms = (cube._mask, (flags, lo, hi, m))
+    except AttributeError:
+        pass
     return flags, lo, hi, m
 
 
@@ -368,23 +383,6 @@ class Strips:
 def _rows_view(arr, y0, y1):
     ny, nx = arr.shape
     return DeviceArray((y1 - y0, nx), arr.dtype, arr.device, ptr=arr.ptr + y0 * nx * arr.dtype.itemsize, owner=arr)
-
-
-def _mask_terms(cube):
-    """device terms of the cube's mask, array term kept on the HOST (strips of it travel with the data)"""
-    from . import masks as M
-    if cube._mask is None:
-        return None
-    terms = cube._mask._device_terms(cube)
-    if terms is None:
-        raise NotImplementedError("a streamed (out-of-core) cube takes masks made of isfinite / threshold comparisons on "
-                                  "the cube itself and boolean arrays; this mask needs the whole cube on the host")
-    flags, lo, hi, m = terms
-    if m is not None:
-        flags |= _lib.MASK_ARRAY
-    lo = float(lo) if flags & (_lib.MASK_GT | _lib.MASK_GE) else 0.0
-    hi = float(hi) if flags & (_lib.MASK_LT | _lib.MASK_LE) else 0.0
-    return flags, lo, hi, m
 
 
 def original_include(cube, dev, mspec, stream):
@@ -520,9 +518,25 @@ class FitsSink:
         text += " " * ((-len(text)) % io_fits.BLOCK)
         self.base = len(text)
         total = nz * ny * nx * 4
-        self.fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-        os.pwrite(self.fd, text.encode("ascii"), 0)
-        os.ftruncate(self.fd, self.base + total + (-total) % io_fits.BLOCK)      # zero padding included
+        # The payload goes to a sibling file that takes the target's name when the last strip has landed: the target may
+        # be the very file the strips are read from (cube.write(path, overwrite=True) of a streamed cube read from path:
+        # O_TRUNC on it would destroy the input before the first strip is read), and a failed run leaves no half-written
+        # file under the target's name.
+        self.path = os.fspath(path)
+        self.part = "%s.spc-part-%d-%x" % (self.path, os.getpid(), id(self) & 0xffffff)
+        self.fd = os.open(self.part, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        size = self.base + total + (-total) % io_fits.BLOCK                       # zero padding included
+        try:
+            os.pwrite(self.fd, text.encode("ascii"), 0)
+            try:
+                # blocks reserved up front: the writer threads then fill allocated pages instead of growing a sparse file
+                # one page fault at a time (tmpfs / ext4: the extents are laid out once, contiguously)
+                os.posix_fallocate(self.fd, 0, size)
+            except OSError:
+                os.ftruncate(self.fd, size)
+        except BaseException:
+            self.abort()
+            raise
 
     def write(self, view_u8, z0, z1, y0, y1):
         nz, ny, nx = self.shape
@@ -533,10 +547,23 @@ class FitsSink:
             while done < seg:
                 done += os.pwrite(self.fd, part[done:], off + done)
 
-    def close(self):
+    def close(self, ok=True):
         if self.fd is not None:
             os.close(self.fd)
             self.fd = None
+            if ok:
+                os.replace(self.part, self.path)
+            else:
+                self.abort()
+
+    def abort(self):
+        if self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
+        try:
+            os.unlink(self.part)
+        except OSError:
+            pass
 
 
 class StripWriter:
@@ -608,17 +635,24 @@ class StripWriter:
                 f.result()
         self.busy = [None] * len(self.busy)
 
-    def close(self):
+    def close(self, ok=True):
+        """ok=False: the producer failed - a sink that knows how (FitsSink) discards what was written"""
         try:
             self._drain()
             self.down.synchronize()
+        except BaseException:
+            ok = False
+            raise
         finally:
             self.pool.shutdown(wait=True)
             if self.pinned:
                 _give_pinned(self.cap, self.pinned)
                 self.pinned = []
             self.keep = []
-            self.sink.close()
+            if ok or not hasattr(self.sink, "abort"):
+                self.sink.close()
+            else:
+                self.sink.abort()
 
 
 def map_strips(cube, fn, nz_out, sink, rows=None, stats=None, halo=0):
@@ -638,7 +672,7 @@ def map_strips(cube, fn, nz_out, sink, rows=None, stats=None, halo=0):
         rows = max(8, min(src.shape[1], rows))
     st = Strips(cube, compute, rows, halo=halo)
     w = StripWriter(sink, cube.device)
-    n = 0
+    n, done = 0, False
     try:
         for y0, y1, dev, mspec in st:
             res = fn(dev, mspec, compute)
@@ -652,8 +686,9 @@ def map_strips(cube, fn, nz_out, sink, rows=None, stats=None, halo=0):
                 res = own
             w.put(y0, y1, res, compute)
             n += 1
+        done = True
     finally:
-        w.close()
+        w.close(ok=done)
     if stats is not None:
         stats.update(bytes_in=st.bytes, bytes_out=w.bytes, strips=n, rows=st.rows)
 
@@ -669,13 +704,14 @@ def map_slabs(cube, fn, out_yx, sink, planes=None, stats=None):
     compute = Stream(cube.device)
     st = Strips(cube, compute, planes, axis=0, out_factor=2.0 * ny_out * nx_out / float(ny * nx))
     w = StripWriter(sink, cube.device)
-    n = 0
+    n, done = 0, False
     try:
         for z0, z1, dev, mspec in st:
             w.put(0, ny_out, fn(dev, mspec, compute), compute, z_base=z0)
             n += 1
+        done = True
     finally:
-        w.close()
+        w.close(ok=done)
     if stats is not None:
         stats.update(bytes_in=st.bytes, bytes_out=w.bytes, slabs=n, planes=st.rows)
 
