@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 3
+#define SPC_ABI_VERSION 4
 
 typedef enum {
     SPC_OK = 0,
@@ -426,18 +426,26 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube,
  * 0-based pixel coordinates in the source grid (wcs_in) - what reproject_interp obtains from
  * astropy.wcs (pixel_to_world on the target, world_to_pixel on the source; spectral_cube.py:2700-2732).
  * FITS paper II arithmetic in float64 for the zenithal projections TAN / SIN / ARC / STG / ZEA and the
- * (pseudo-)cylindrical CAR / SFL / CEA / MER / AIT; pixels that cannot be projected (or lie beyond the edge
- * of the sky of an all-sky projection) get -1e30 (outside every footprint).  The host fills the
+ * (pseudo-)cylindrical CAR / SFL / CEA / MER / AIT, with astropy's SIP stage on either side (all_pix2world /
+ * all_world2pix); pixels that cannot be projected (or lie beyond the edge of the sky of an all-sky projection, or
+ * where the SIP inverse does not converge) get -1e30 (outside every footprint).  The host fills the
  * struct from the header (spectral_cube_amd/wcs.py). */
+#define SPC_SIP_MAX_ORDER 9
+#define SPC_SIP_TERMS 55           /* coefficients of u^p v^q, p + q <= 9: row p starts at p * 10 - p * (p - 1) / 2 */
 typedef struct spc_celestial_wcs {
     int32_t proj;              /* 0 TAN, 1 SIN, 2 ARC, 3 STG, 4 ZEA, 5 CAR, 6 SFL, 7 CEA, 8 MER, 9 AIT */
-    int32_t reserved;
+    int32_t sip_order;         /* 0 = no SIP distortion; else max(A_ORDER, B_ORDER) <= 9 (ABI 4; was `reserved`) */
     double crpix[2];           /* FITS 1-based reference pixel (x, y) */
     double lin[4];             /* CDELT_i * PC_ij, 2 x 2 row-major: degrees per pixel */
     double lin_inv[4];         /* its inverse */
     double alpha_p, delta_p;   /* celestial coordinates of the native pole (radians) */
     double phi_p;              /* LONPOLE (radians) */
     double pv1;                /* CEA: PV2_1 (lambda), else unused (ABI 3) */
+    double plane0[2];          /* (x0, y0) degrees: the projection of the user's fiducial point (PV1_0 != 0 with PV1_1 /
+                                * PV1_2; wcslib prjoff), added before deprojection, subtracted after projection (ABI 4) */
+    double sip_a[SPC_SIP_TERMS];   /* SIP forward polynomials (Shupe et al. 2005): u' = u + A(u, v), v' = v + B(u, v) with */
+    double sip_b[SPC_SIP_TERMS];   /* (u, v) = pixel - CRPIX; as the TARGET they are evaluated, as the SOURCE they are
+                                    * inverted by Newton's method - the limit of astropy's all_world2pix iteration (ABI 4) */
 } spc_celestial_wcs;
 /* frame_rot (HOST pointer, 9 doubles row-major, may be NULL = same frame): rotation of the unit sphere that takes
  * the TARGET's celestial frame to the SOURCE's (ICRS / FK5(equinox) / Galactic: spectral_cube_amd/wcs.py::

@@ -624,6 +624,105 @@ def case_wcs_projections():
     print("wcs_projections ok", [int(np.isnan(store["lon%d" % i]).sum()) for i in range(len(cases))])
 
 
+def case_wcs_strict():
+    """astropy.wcs values for the parts of a celestial header round 4 added to the minimal WCS - the SIP polynomials
+    (all_pix2world / all_world2pix: what reproject_interp's pixel_to_world / world_to_pixel call, spectral_cube.py:
+    2700-2732), the longitude-axis parameters PV1_0 .. PV1_4, celestial CUNITs other than degrees, PCi_j beside CDi_j,
+    fields AT the celestial pole - and the list of keywords the build refuses, with what astropy does with each (so the
+    refusals are documented against the real thing).  Every header is stored as text, every expectation as numbers."""
+    store = {}
+    ny, nx = 300, 400
+    base = {"CRVAL1": 83.6, "CRVAL2": -5.4, "CRPIX1": 200.5, "CRPIX2": 150.5, "CDELT1": -2.0 / 3600, "CDELT2": 2.0 / 3600,
+            "CUNIT1": "deg", "CUNIT2": "deg", "NAXIS": 2, "NAXIS1": nx, "NAXIS2": ny}
+    tan = dict(base, CTYPE1="RA---TAN", CTYPE2="DEC--TAN")
+    rng = np.random.default_rng(404)
+    px = np.concatenate([rng.uniform(-0.5, nx - 0.5, 60), [0.0, nx - 1.0, 0.0, nx - 1.0, 199.5]])
+    py = np.concatenate([rng.uniform(-0.5, ny - 0.5, 60), [0.0, 0.0, ny - 1.0, ny - 1.0, 149.5]])
+    c, s_ = np.cos(np.radians(25.0)), np.sin(np.radians(25.0))
+    sip2 = dict(A_ORDER=2, B_ORDER=2, A_2_0=1e-4, B_0_2=1e-4)                      # the round-3 verdict's case
+    sip4 = dict(A_ORDER=4, B_ORDER=3, A_2_0=2.1e-5, A_1_1=-1.3e-5, A_0_2=7e-6, A_3_0=-4e-8, A_2_1=3e-8, A_1_2=1.5e-8, A_0_3=-2e-8,
+                A_4_0=5e-11, A_2_2=-3e-11, A_0_4=2e-11, A_4_1=9.0,                  # (p + q > A_ORDER: astropy does not read it)
+                B_2_0=-9e-6, B_1_1=1.7e-5, B_0_2=-2.5e-5, B_3_0=1e-8, B_2_1=-2.5e-8, B_1_2=3.5e-8, B_0_3=2e-8,
+                AP_ORDER=2, BP_ORDER=2, AP_2_0=-2.1e-5, BP_0_2=2.5e-5)              # (inverse polynomials: all_world2pix ignores them)
+    heads = [
+        ("sip2", dict(base, CTYPE1="RA---TAN-SIP", CTYPE2="DEC--TAN-SIP", **sip2)),
+        ("sip2_nosuffix", dict(tan, **sip2)),                                      # astropy applies the coefficients anyway
+        ("sip4_rot", dict(base, CTYPE1="RA---TAN-SIP", CTYPE2="DEC--TAN-SIP", PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c, **sip4)),
+        ("sip_order1", dict(tan, A_ORDER=1, B_ORDER=1, A_1_0=0.01, B_0_1=0.02)),   # order 1: astropy does not read SIP at all
+        ("pv1_12", dict(tan, PV1_1=10.0, PV1_2=80.0)),
+        ("pv1_012", dict(tan, PV1_0=1.0, PV1_1=10.0, PV1_2=80.0)),
+        ("pv1_0_alone", dict(tan, PV1_0=1.0)),
+        ("pv1_3", dict(tan, PV1_3=170.0, LONPOLE=160.0)),                          # PV1_3 wins over LONPOLE
+        ("car_pv1", dict(base, CTYPE1="GLON-CAR", CTYPE2="GLAT-CAR", CRVAL1=30.0, CRVAL2=40.0, CDELT1=-0.05, CDELT2=0.05,
+                         PV1_1=0.0, PV1_2=40.0, PV1_0=1.0)),                        # oblique-free CAR about (30, 40)
+        ("car_pv1_nooffset", dict(base, CTYPE1="GLON-CAR", CTYPE2="GLAT-CAR", CRVAL1=30.0, CRVAL2=40.0, CDELT1=-0.05, CDELT2=0.05,
+                                  PV1_1=5.0, PV1_2=20.0)),
+        ("car_latpole", dict(base, CTYPE1="RA---CAR", CTYPE2="DEC--CAR", CRVAL1=30.0, CRVAL2=10.0, CDELT1=-0.05, CDELT2=0.05,
+                             LONPOLE=50.0, PV1_4=-60.0, LATPOLE=60.0)),              # two solutions for delta_p; PV1_4 wins over LATPOLE
+        ("car_latpole_n", dict(base, CTYPE1="RA---CAR", CTYPE2="DEC--CAR", CRVAL1=30.0, CRVAL2=10.0, CDELT1=-0.05, CDELT2=0.05,
+                               LONPOLE=50.0, LATPOLE=60.0)),
+        ("arcsec", dict(tan, CUNIT1="arcsec", CUNIT2="arcsec", CDELT1=-2.0, CDELT2=2.0, CRVAL1=83.6 * 3600, CRVAL2=-5.4 * 3600)),
+        ("arcmin_cd", {k: v for k, v in dict(tan, CUNIT1="arcmin", CUNIT2="arcmin", CRVAL1=83.6 * 60, CRVAL2=-5.4 * 60,
+                                             CD1_1=-c / 30, CD1_2=s_ / 30, CD2_1=s_ / 30, CD2_2=c / 30).items()
+                       if not k.startswith("CDELT")}),
+        ("pc_and_cd", dict(tan, CD1_1=-1e-3, CD1_2=0.0, CD2_1=0.0, CD2_2=1e-3, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c)),   # PC wins
+        ("crota_and_cd", {k: v for k, v in dict(tan, CROTA2=30.0, CD1_1=-c / 1800, CD1_2=s_ / 1800, CD2_1=s_ / 1800,
+                                                 CD2_2=c / 1800).items() if not k.startswith("CDELT")}),                # CD wins
+        ("crota1", dict(tan, CROTA1=30.0)),                                        # ignored
+        ("tan_pv2", dict(tan, PV2_1=0.5, PV2_2=0.1)),                              # this astropy ignores them; the build refuses
+        ("pole_in_field", dict(tan, CRVAL1=10.0, CRVAL2=89.97)),
+        ("south_pole_sin", dict(base, CTYPE1="RA---SIN", CTYPE2="DEC--SIN", CRVAL1=200.0, CRVAL2=-89.995)),
+    ]
+    for name, h in heads:
+        w = WCS(fits.Header(h))
+        lon, lat = w.all_pix2world(px, py, 0)
+        store["hdr_" + name] = fits.Header(h).tostring(sep="\n")
+        store["lon_" + name], store["lat_" + name] = np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64)
+        if w.sip is not None:
+            # the inverse astropy computes (fixed-point on the forward polynomials), driven to its limit
+            bx, by = w.all_world2pix(lon, lat, 0, tolerance=1e-13, maxiter=100)
+            assert np.abs(bx - px).max() < 1e-9 and np.abs(by - py).max() < 1e-9, name
+            dx, dy = w.all_world2pix(lon, lat, 0)                                   # its default stop: 1e-4 pixel
+            store["default_tol_err_" + name] = np.array([np.abs(dx - px).max(), np.abs(dy - py).max()])
+    store["names"] = np.array([n for n, _ in heads])
+    store["px"], store["py"] = px, py
+    # what astropy makes of the order-1 / no-suffix / ignored-keyword headers, for the record in the fixture
+    w_plain = WCS(fits.Header(tan))
+    l0, b0 = w_plain.all_pix2world(px, py, 0)
+    for name in ("sip_order1", "crota1", "tan_pv2", "pv1_0_alone"):
+        assert np.array_equal(store["lon_" + name], l0) and np.array_equal(store["lat_" + name], b0), name
+    assert np.abs(store["lon_sip2"] - store["lon_sip2_nosuffix"]).max() == 0.0
+    # ---- pixel maps the way reproject_interp forms them (same frame on both sides): target pixels -> sky -> source pixels
+    def pmap(h_in, h_out, shape, tol=1e-13):
+        w_in, w_out = WCS(fits.Header(h_in)), WCS(fits.Header(h_out))
+        # (every 9th column / 7th row and the last ones: the fixture stays small, the device test evaluates the whole grid
+        # and compares at these pixels)
+        yy, xx = np.meshgrid(np.unique(np.r_[0:shape[0]:7, shape[0] - 1]), np.unique(np.r_[0:shape[1]:9, shape[1] - 1]), indexing="ij")
+        lon, lat = w_out.all_pix2world(xx, yy, 0)
+        if w_in.sip is not None:
+            return (yy, xx) + tuple(w_in.all_world2pix(lon, lat, 0, tolerance=tol, maxiter=100))
+        return (yy, xx) + tuple(w_in.all_world2pix(lon, lat, 0))
+    maps = [
+        ("verdict_sip", dict(tan, CRPIX1=190.0, CRPIX2=160.0), dict(heads[0][1]), (ny, nx)),                 # SIP target
+        ("sip_source", dict(heads[2][1]), dict(tan, CDELT1=-2.5 / 3600, CDELT2=2.5 / 3600), (240, 320)),     # SIP source: the inverse
+        ("sip_both", dict(heads[2][1]), dict(heads[0][1], CRVAL1=83.61), (ny, nx)),
+        ("verdict_pv1", dict(tan), dict(heads[4][1]), (ny, nx)),                                             # PV1_1 / PV1_2 target
+        ("polar", dict(tan, CRVAL1=10.0, CRVAL2=89.5, CDELT1=-20.0 / 3600, CDELT2=20.0 / 3600),
+         dict(tan, CRVAL1=10.0, CRVAL2=89.9, CDELT1=-20.0 / 3600, CDELT2=20.0 / 3600), (ny, nx)),            # the verdict's polar pair
+        ("polar_arc_zea", dict(base, CTYPE1="RA---ARC", CTYPE2="DEC--ARC", CRVAL1=250.0, CRVAL2=-89.8, CDELT1=-30.0 / 3600, CDELT2=30.0 / 3600),
+         dict(base, CTYPE1="RA---ZEA", CTYPE2="DEC--ZEA", CRVAL1=100.0, CRVAL2=-89.95, CDELT1=-30.0 / 3600, CDELT2=30.0 / 3600), (ny, nx)),
+    ]
+    for name, h_in, h_out, shape in maps:
+        yy, xx, xs, ys = pmap(h_in, h_out, shape)
+        store["map_shape_" + name], store["map_yy_" + name], store["map_xx_" + name] = np.array(shape), yy, xx
+        store["map_in_" + name] = fits.Header(h_in).tostring(sep="\n")
+        store["map_out_" + name] = fits.Header(h_out).tostring(sep="\n")
+        store["map_xs_" + name], store["map_ys_" + name] = np.asarray(xs, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+    store["map_names"] = np.array([m[0] for m in maps])
+    np.savez_compressed(os.path.join(OUT, "wcs_strict.npz"), **store)
+    print("wcs_strict ok", {k[16:]: v.tolist() for k, v in store.items() if k.startswith("default_tol_err_")})
+
+
 def case_bilinear_scipy():
     """Pins oracle_np.resample_bilinear against the resampling primitive reproject calls.
 
@@ -948,7 +1047,7 @@ def case_beams_cube():
 
 if __name__ == "__main__":
     cases = [case_beams_cube, case_moment_cube, case_c1, case_adv_argmax, case_smooth, case_interp, case_kernels,
-             case_wcs, case_wcs_frames, case_wcs_projections, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
+             case_wcs, case_wcs_frames, case_wcs_projections, case_wcs_strict, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
              case_order_statistics, case_sigma_clip]
     only = set(sys.argv[1:])                 # e.g. `gen_golden.py case_reproject_glue_scipy` regenerates one fixture
     for fn in cases:

@@ -22,7 +22,7 @@ SPC_ERR_COMM = -5
 MASK_NONE, MASK_ARRAY, MASK_FINITE = 0, 1, 2
 MASK_GT, MASK_GE, MASK_LT, MASK_LE = 4, 8, 16, 32
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
@@ -62,9 +62,9 @@ class SpcMomentOutputs(C.Structure):
 
 
 class SpcCelestialWcs(C.Structure):
-    _fields_ = [("proj", C.c_int32), ("reserved", C.c_int32), ("crpix", C.c_double * 2), ("lin", C.c_double * 4),
+    _fields_ = [("proj", C.c_int32), ("sip_order", C.c_int32), ("crpix", C.c_double * 2), ("lin", C.c_double * 4),
                 ("lin_inv", C.c_double * 4), ("alpha_p", C.c_double), ("delta_p", C.c_double), ("phi_p", C.c_double),
-                ("pv1", C.c_double)]
+                ("pv1", C.c_double), ("plane0", C.c_double * 2), ("sip_a", C.c_double * 55), ("sip_b", C.c_double * 55)]
 
 
 class SpcStatsOutputs(C.Structure):

@@ -422,15 +422,35 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
 // costs 0.8 s for 1024^2 pixels - a hundred times the resampling kernel it feeds.
 struct WcsPair { spc_celestial_wcs o, i; int64_t ny, nx; double* xs; double* ys; int has_rot; double rot[9]; };
 
+// SIP polynomial sum_{p + q <= n} c[p][q] u^p v^q and its two partial derivatives (Horner in v inside Horner in u;
+// row p of the triangular table starts at p * 10 - p * (p - 1) / 2)
+__device__ __forceinline__ void sip_eval(const double* c, int n, double u, double v, double& f, double& fu, double& fv) {
+    f = 0.0; fu = 0.0; fv = 0.0;
+    for (int p = n; p >= 0; --p) {
+        const double* row = c + (p * (SPC_SIP_MAX_ORDER + 1) - p * (p - 1) / 2);
+        double r = 0.0, rv = 0.0;
+        for (int q = n - p; q >= 0; --q) { rv = rv * v + r; r = r * v + row[q]; }
+        fu = fu * u + f;          // d/du of (f * u + r)
+        f = f * u + r;
+        fv = fv * u + rv;
+    }
+}
+
 __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     const int64_t x = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
     const int64_t y = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= A.nx || y >= A.ny) return;
     const double D2R = 0.017453292519943295, R2D = 57.29577951308232, PI = 3.141592653589793;
     // target pixel -> native spherical -> celestial
-    const double dx = (double)x + 1.0 - A.o.crpix[0], dy = (double)y + 1.0 - A.o.crpix[1];
-    const double px = A.o.lin[0] * dx + A.o.lin[1] * dy;
-    const double py = A.o.lin[2] * dx + A.o.lin[3] * dy;
+    double dx = (double)x + 1.0 - A.o.crpix[0], dy = (double)y + 1.0 - A.o.crpix[1];
+    if (A.o.sip_order > 0) {       // astropy's all_pix2world: the SIP polynomials, then wcslib's core
+        double f, g, t0, t1;
+        sip_eval(A.o.sip_a, A.o.sip_order, dx, dy, f, t0, t1);
+        sip_eval(A.o.sip_b, A.o.sip_order, dx, dy, g, t0, t1);
+        dx += f; dy += g;
+    }
+    const double px = A.o.lin[0] * dx + A.o.lin[1] * dy + A.o.plane0[0];
+    const double py = A.o.lin[2] * dx + A.o.lin[3] * dy + A.o.plane0[1];
     double phi, theta;
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     if (A.o.proj >= 5) {        // (pseudo-)cylindrical: CAR, SFL, CEA, MER, AIT
@@ -463,8 +483,11 @@ __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     double st = sin(theta), ct = cos(theta);
     double dphi = phi - A.o.phi_p;
     double sdp = sin(A.o.delta_p), cdp = cos(A.o.delta_p);
-    double lon = A.o.alpha_p + atan2(-ct * sin(dphi), st * cdp - ct * sdp * cos(dphi));
-    double lat = asin(fmin(fmax(st * sdp + ct * cdp * cos(dphi), -1.0), 1.0));
+    // celestial unit vector about the native pole's meridian; the latitude from atan2 of its components (asin of the third
+    // alone loses half the digits near the celestial poles: 1e-5 pixel at declination 89.9 - wcslib switches to acos there)
+    const double xc = st * cdp - ct * sdp * cos(dphi), yc = -ct * sin(dphi), zc = st * sdp + ct * cdp * cos(dphi);
+    double lon = A.o.alpha_p + atan2(yc, xc);
+    double lat = atan2(zc, hypot(xc, yc));
     double lon_deg = fmod(lon * R2D, 360.0);
     if (lon_deg < 0.0) lon_deg += 360.0;
     lon = lon_deg * D2R;
@@ -515,8 +538,30 @@ __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
         }
         ix = r * sin(ph); iy = -r * cos(ph);
     }
-    double sx = A.i.lin_inv[0] * ix + A.i.lin_inv[1] * iy + A.i.crpix[0] - 1.0;
-    double sy = A.i.lin_inv[2] * ix + A.i.lin_inv[3] * iy + A.i.crpix[1] - 1.0;
+    ix -= A.i.plane0[0]; iy -= A.i.plane0[1];
+    double su = A.i.lin_inv[0] * ix + A.i.lin_inv[1] * iy;
+    double sv = A.i.lin_inv[2] * ix + A.i.lin_inv[3] * iy;
+    if (A.i.sip_order > 0) {
+        // astropy's all_world2pix inverts the FORWARD polynomials (a fixed-point iteration stopped at 1e-4 pixel); this is
+        // Newton's method on the same equations, to 1e-13: u + A(u, v) = su, v + B(u, v) = sv.  No convergence (far outside
+        // the image, where the polynomial folds over): not a pixel of the source.
+        double u = su, v = sv;
+        bool done = false;
+        for (int it = 0; it < 50 && !done; ++it) {
+            double f, fu, fv, g, gu, gv;
+            sip_eval(A.i.sip_a, A.i.sip_order, u, v, f, fu, fv);
+            sip_eval(A.i.sip_b, A.i.sip_order, u, v, g, gu, gv);
+            const double r0 = u + f - su, r1 = v + g - sv;
+            const double j00 = 1.0 + fu, j01 = fv, j10 = gu, j11 = 1.0 + gv;
+            const double det = j00 * j11 - j01 * j10;
+            const double du = (j11 * r0 - j01 * r1) / det, dv = (j00 * r1 - j10 * r0) / det;
+            u -= du; v -= dv;
+            done = fabs(du) <= 1e-13 * fmax(1.0, fabs(u)) && fabs(dv) <= 1e-13 * fmax(1.0, fabs(v));     // false for NaN
+        }
+        su = done ? u : nan; sv = done ? v : nan;
+    }
+    double sx = su + A.i.crpix[0] - 1.0;
+    double sy = sv + A.i.crpix[1] - 1.0;
     const bool fin = (fabs(sx) <= 1.79e308) && (fabs(sy) <= 1.79e308);      // false for NaN / Inf
     A.xs[y * A.nx + x] = fin ? sx : -1e30;
     A.ys[y * A.nx + x] = fin ? sy : -1e30;
@@ -566,6 +611,8 @@ int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs
     SPC_REQUIRE(wcs_out && wcs_in && d_xs && d_ys, "NULL pointer argument");
     SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
     SPC_REQUIRE(wcs_out->proj >= 0 && wcs_out->proj <= 9 && wcs_in->proj >= 0 && wcs_in->proj <= 9, "unknown projection code");
+    SPC_REQUIRE(wcs_out->sip_order >= 0 && wcs_out->sip_order <= SPC_SIP_MAX_ORDER && wcs_in->sip_order >= 0 &&
+                wcs_in->sip_order <= SPC_SIP_MAX_ORDER, "SIP order must be 0 (none) .. 9");
     SPC_REQUIRE((ny_out + 3) / 4 <= 65535, "too many rows for one launch");
     SPC_DEVICE(device);
     WcsPair A{*wcs_out, *wcs_in, ny_out, nx_out, d_xs, d_ys, 0, {1, 0, 0, 0, 1, 0, 0, 0, 1}};

@@ -212,10 +212,12 @@ class SpectralCube:
         self._source = _source            # streaming.FitsSource / NdarraySource of an out-of-core cube, or None
         self._shape = tuple(data.shape) if data is not None else (
             tuple(_dev.shape) if _dev is not None else tuple(_shape))
+        # (strict=False: a header with celestial keywords the minimal WCS does not model still gives a cube - moments along the
+        # spectral axis need no celestial transform; the first celestial USE raises, naming the keyword: wcs.py)
         if wcs is None and header is not None:
-            wcs = SimpleWCS(header)
+            wcs = SimpleWCS(header, strict=False)
         elif wcs is not None and not isinstance(wcs, SimpleWCS):
-            wcs = SimpleWCS(wcs)
+            wcs = SimpleWCS(wcs, strict=False)
         self._wcs = wcs
         self._header = dict(wcs.header) if wcs is not None else {}
         self._mask = mask
@@ -1194,6 +1196,9 @@ class SpectralCube:
         if order not in (0, 1):
             raise NotImplementedError("order %r: the device resampler does 'bilinear' and 'nearest-neighbor'" % (order,))
         newwcs = header if isinstance(header, SimpleWCS) else SimpleWCS(header)
+        if self._wcs is not None:
+            self._wcs._require_celestial()     # (a cube is read with a lenient WCS: keywords it does not model are refused here)
+        newwcs._require_celestial()
         hdr = newwcs.header
         if "NAXIS1" in hdr and "NAXIS2" in hdr:
             ny_out, nx_out = int(hdr["NAXIS2"]), int(hdr["NAXIS1"])

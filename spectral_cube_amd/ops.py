@@ -351,10 +351,14 @@ def spectral_lerp(cube, lo, t, inv_dx, fill=np.nan, mask=None, out=None, stream=
 
 
 def _wcs_struct(w):
-    code, crpix, lin, inv, ap, dp, php, pv1 = w.celestial_params()
+    code, crpix, lin, inv, ap, dp, php, pv1, plane0, (sip_order, sip_a, sip_b) = w.celestial_params()
     s = _lib.SpcCelestialWcs()
     s.proj = code
     s.pv1 = pv1
+    s.plane0[0], s.plane0[1] = plane0
+    s.sip_order = int(sip_order)
+    for i in range(len(sip_a)):
+        s.sip_a[i], s.sip_b[i] = sip_a[i], sip_b[i]
     s.crpix[0], s.crpix[1] = crpix
     for i in range(4):
         s.lin[i], s.lin_inv[i] = lin[i], inv[i]

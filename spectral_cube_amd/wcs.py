@@ -26,6 +26,7 @@ _PROJ_CODE = {"TAN": 0, "SIN": 1, "ARC": 2, "STG": 3, "ZEA": 4, "CAR": 5, "SFL":
 
 _AXIS_KEY = re.compile(r"^(?:(?:CTYPE|CRVAL|CRPIX|CDELT|CUNIT|CROTA|NAXIS|CNAME|CRDER|CSYER)(\d)|(?:PC|CD)(\d)_(\d)|"
                        r"PC00(\d)00(\d)|(?:PV|PS)(\d)_\d+)$")
+_SPECTRAL_ALGORITHMS = ("F2W", "F2V", "F2A", "W2F", "W2V", "W2A", "V2F", "V2W", "V2A", "A2F", "A2W", "A2V", "LOG", "TAB", "GRI", "GRA")
 _SPECTRAL_KEYS = ("RESTFRQ", "RESTFREQ", "RESTWAV", "SPECSYS", "SSYSOBS", "VELREF", "VELOSYS", "ZSOURCE", "SSYSSRC")
 
 
@@ -78,10 +79,67 @@ def parse_header(header):
     return out
 
 
-class SimpleWCS:
-    """3-axis (x, y, spectral) or 2-axis (x, y) FITS WCS."""
+# ---- keywords that alter the celestial transform ------------------------------------------------------
+# reproject hands complete astropy.wcs.WCS objects to reproject_interp (spectral_cube.py:2700-2732), i.e. wcslib's
+# core transformation PLUS astropy's distortion stages (all_pix2world / all_world2pix).  What SimpleWCS models of that
+# is listed here; a keyword of these families that it does not model RAISES - a header is never silently read as a
+# simpler one (checked against astropy 4.3.1 in oracle/gen_golden.py::case_wcs_strict):
+#   modelled   CTYPE / CRVAL / CRPIX / CDELT / CUNIT (deg, arcmin, arcsec, mas, rad) / PCi_j / CDi_j / CROTA2,
+#              LONPOLE / LATPOLE, PV1_0..PV1_4 (fiducial offset, phi_0, theta_0, LONPOLE, LATPOLE on the longitude axis),
+#              PV2_1 (CEA), the SIP polynomials A_p_q / B_p_q (-SIP suffix or not: astropy applies them either way)
+#   ignored like astropy ignores them   AP_p_q / BP_p_q (the inverse polynomials: all_world2pix inverts A / B itself),
+#              A_DMAX / B_DMAX, CROTA1, CROTA2 beside PCi_j or CDi_j, CDi_j beside PCi_j, alternate descriptions (CTYPE1A ...)
+#   refused    PV2_m on projections that take no parameter (a TAN header with PV cards is SCAMP's TPV distortion in newer
+#              astropy), slant SIN, PSi_m, CPDIS / CQDIS / DPj / DQj look-up distortions, D2IM* detector corrections,
+#              projections / units / axis orders outside the lists above
+_SIP_COEF = re.compile(r"^(A|B|AP|BP)_(\d+)_(\d+)$")
+_SIP_META = re.compile(r"^(A|B|AP|BP)_(ORDER|DMAX)$")
+_PV_KEY = re.compile(r"^(PV|PS)(\d+)_(\d+)$")
+_REFUSED = re.compile(r"^(CPDIS\d|CQDIS\d|CPERR\d|CQERR\d|DP\d|DQ\d|D2IMDIS\d|D2IMERR\d|D2IMEXT|D2IM\d|AXISCORR|DVERR\d)")
+_ANGLE_TO_DEG = {"": 1.0, "deg": 1.0, "degree": 1.0, "degrees": 1.0, "arcmin": 1.0 / 60.0, "arcsec": 1.0 / 3600.0,
+                 "mas": 1.0 / 3.6e6, "rad": 180.0 / np.pi}
+SIP_MAX_ORDER = 9            # (the limit of astropy's Sip / of spc_celestial_wcs)
 
-    def __init__(self, header=None, naxis=None):
+
+def _sip_index(p, q):
+    """position of the coefficient of u^p v^q in the triangular tables of spc_celestial_wcs (row p holds 10 - p entries)"""
+    return p * (SIP_MAX_ORDER + 1) - p * (p - 1) // 2 + q
+
+
+def _poly(c, u, v):
+    """sum_p sum_q c[p, q] u^p v^q (Horner in both variables; c is (n + 1, n + 1), zero where p + q > n)"""
+    n = c.shape[0] - 1
+    out = np.zeros(np.broadcast(u, v).shape)
+    for p_ in range(n, -1, -1):
+        row = np.zeros_like(out)
+        for q_ in range(n - p_, -1, -1):
+            row = row * v + c[p_, q_]
+        out = out * u + row
+    return out
+
+
+def _poly_grad(c, u, v):
+    """(d/du, d/dv) of _poly"""
+    n = c.shape[0] - 1
+    cu = np.zeros_like(c)
+    cv = np.zeros_like(c)
+    for p_ in range(n + 1):
+        for q_ in range(n + 1 - p_):
+            if p_ >= 1:
+                cu[p_ - 1, q_] = p_ * c[p_, q_]
+            if q_ >= 1:
+                cv[p_, q_ - 1] = q_ * c[p_, q_]
+    return _poly(cu, u, v), _poly(cv, u, v)
+
+
+class SimpleWCS:
+    """3-axis (x, y, spectral) or 2-axis (x, y) FITS WCS.
+
+    strict=True (default): a header keyword that changes the celestial transform and is not modelled raises
+    NotImplementedError here; strict=False (the WCS a cube is READ with: its moments along the spectral axis need no
+    celestial transform) records it and raises at the first celestial use instead."""
+
+    def __init__(self, header=None, naxis=None, strict=True):
         h = parse_header(header)
         self.header = h
         n = int(naxis or h.get("WCSAXES", h.get("NAXIS", 3)))
@@ -93,8 +151,9 @@ class SimpleWCS:
         self.crpix = np.array([float(g("CRPIX%d" % (i + 1), 0.0)) for i in range(n)])
         self.cdelt = np.array([float(g("CDELT%d" % (i + 1), 1.0)) for i in range(n)])
         pc = np.eye(n)
+        has_pc = any(("PC%d_%d" % (i + 1, j + 1)) in h or ("PC%03d%03d" % (i + 1, j + 1)) in h for i in range(n) for j in range(n))
         has_cd = any(("CD%d_%d" % (i + 1, j + 1)) in h for i in range(n) for j in range(n))
-        if has_cd:
+        if has_cd and not has_pc:            # (wcslib: PCi_j wins when a header carries both)
             cd = np.zeros((n, n))
             for i in range(n):
                 for j in range(n):
@@ -115,27 +174,136 @@ class SimpleWCS:
         self.proj = self.ctype[0][5:8] if len(self.ctype[0]) >= 8 else ""
         if self.proj and self.proj not in _PROJ_CODE:
             raise NotImplementedError("projection %r not supported by SimpleWCS (built: %s)" % (self.proj, ", ".join(sorted(_PROJ_CODE))))
+        self._unsupported = []
+        celestial = n >= 2 and bool(self.proj)
         # CEA: PV2_1 = lambda (cos^2 of the standard parallel), default 1 (Lambert)
         self.pv1 = float(g("PV2_1", 1.0)) if self.proj == "CEA" else 1.0
         if self.proj == "SIN" and (float(g("PV2_1", 0.0)) != 0.0 or float(g("PV2_2", 0.0)) != 0.0):
             raise NotImplementedError("slant orthographic projection (SIN with PV2_1 / PV2_2) is not built")
-        self.lonpole = g("LONPOLE", None)
-        self.latpole = float(g("LATPOLE", 90.0))
-        self.frame = _celestial_frame(self.ctype[:2], h) if n >= 2 and self.proj else None
-        for i in (0, 1):
-            if i < n and self.cunit[i] not in ("", "deg"):
-                raise NotImplementedError("celestial CUNIT must be deg")
+        # PV1_m on the longitude axis (FITS paper II section 2.5; wcslib wcsset / celset): m = 0 fiducial offset flag,
+        # 1, 2 = native coordinates (phi_0, theta_0) of the fiducial point, 3, 4 = LONPOLE, LATPOLE (these win over the
+        # keywords of that name)
+        self.lonpole = g("PV1_3", g("LONPOLE", None))
+        self.latpole = float(g("PV1_4", g("LATPOLE", 90.0)))
+        native0 = (0.0, 90.0) if self.proj in _ZENITHAL else (0.0, 0.0)
+        self.user_fiducial = ("PV1_1" in h) or ("PV1_2" in h)
+        self.phi0 = float(g("PV1_1", native0[0]))
+        self.theta0 = float(g("PV1_2", native0[1]))
+        self.offset = bool(float(g("PV1_0", 0.0)) != 0.0) and self.user_fiducial
+        self.x0 = self.y0 = 0.0
+        self.sip_a = self.sip_b = None
+        self.frame = _celestial_frame(self.ctype[:2], h) if celestial else None
+        if celestial:
+            self._celestial_units()
+            self._scan_keywords()
+        if self._unsupported and strict:
+            raise NotImplementedError(self._unsupported[0])
         self._setup_pole()
+        if celestial and self.offset:
+            # the projection plane is shifted so that the fiducial point (phi_0, theta_0) lands on (0, 0) (wcslib prjoff)
+            x0, y0 = self._native_to_plane(np.float64(self.phi0 * _D2R), np.float64(self.theta0 * _D2R))
+            self.x0, self.y0 = float(x0), float(y0)
+
+    # -- what the header asks for beyond the linear + spherical part -----------------------------------
+    def _celestial_units(self):
+        """celestial CUNITs other than degrees are scaled to degrees (what wcsset does with them)"""
+        for i in (0, 1):
+            u_ = self.cunit[i]
+            f = _ANGLE_TO_DEG.get(u_, _ANGLE_TO_DEG.get(u_.lower()))
+            if f is None:
+                self._unsupported.append("celestial CUNIT%d = %r: deg, arcmin, arcsec, mas or rad" % (i + 1, u_))
+                continue
+            if f != 1.0:
+                self.crval = self.crval.copy()
+                self.crval[i] *= f
+                if np.all(self.cdelt == 1.0) and any(("CD%d_%d" % (i + 1, j + 1)) in self.header for j in range(self.naxis)) \
+                        and not any(k.startswith("PC") for k in self.header):
+                    self.pc = self.pc.copy()
+                    self.pc[i, :] *= f
+                else:
+                    self.cdelt = self.cdelt.copy()
+                    self.cdelt[i] *= f
+                self.cunit = list(self.cunit)
+                self.cunit[i] = "deg"
+
+    def _scan_keywords(self):
+        h, bad = self.header, self._unsupported
+        for i in (0, 1):
+            c = self.ctype[i]
+            tail = c[8:] if len(c) > 8 else ""
+            if tail not in ("", "-SIP"):
+                bad.append("CTYPE%d = %r: distortion code %r is not built (only -SIP)" % (i + 1, c, tail))
+        if self.ctype[1][5:8] != self.proj or len(self.ctype[1]) < 8:
+            bad.append("CTYPE1 = %r / CTYPE2 = %r: the two celestial axes name different projections" % (self.ctype[0], self.ctype[1]))
+        lead = (self.ctype[0][:4].upper(), self.ctype[1][:4].upper())
+        if lead[0] in ("DEC-",) or lead[0].endswith("LAT") or lead[1] in ("RA--",) or lead[1].endswith("LON"):
+            bad.append("CTYPE1 = %r / CTYPE2 = %r: latitude before longitude is not built (axis 1 must be the longitude)"
+                       % (self.ctype[0], self.ctype[1]))
+        orders, coefs = {}, {}
+        for key, val in h.items():
+            k = str(key).upper()
+            if _REFUSED.match(k):
+                bad.append("%s: look-up / detector distortions (astropy's cpdis / det2im stages) are not built" % k)
+                continue
+            m = _PV_KEY.match(k)
+            if m:
+                kind, ax, idx = m.group(1), int(m.group(2)), int(m.group(3))
+                if ax > 2:
+                    continue                       # (the spectral axis: see spectral_pix2world)
+                if kind == "PS":
+                    bad.append("%s: string-valued projection parameters are not built" % k)
+                elif ax == 1 and idx > 4:
+                    bad.append("%s: longitude-axis parameters beyond PV1_4 are not built (TPV / SCAMP distortion?)" % k)
+                elif ax == 2 and not (self.proj == "CEA" and idx == 1) and float(val) != 0.0:
+                    bad.append("%s = %r: projection %s takes no such parameter here (a -TAN header with PV cards is SCAMP's TPV "
+                               "distortion in newer astropy; ZPN / AZP / SZP / COP ... are not built)" % (k, val, self.proj))
+                continue
+            m = _SIP_META.match(k)
+            if m:
+                if m.group(2) == "ORDER":
+                    orders[m.group(1)] = int(val)
+                continue
+            m = _SIP_COEF.match(k)
+            if m:
+                coefs.setdefault(m.group(1), {})[(int(m.group(2)), int(m.group(3)))] = float(val)
+        # SIP (Shupe et al. 2005) exactly as astropy reads it (astropy/wcs/wcs.py::_read_sip_kw): the forward polynomials
+        # need A_ORDER > 1 and B_ORDER > 1; terms with p + q > order are not read
+        na, nb = orders.get("A"), orders.get("B")
+        if (na is None) != (nb is None):
+            bad.append("A_ORDER / B_ORDER: SIP needs both")
+        elif na is None:
+            if coefs.get("A") or coefs.get("B"):
+                bad.append("SIP coefficients A_p_q / B_p_q without A_ORDER / B_ORDER")
+        elif na > 1 or nb > 1:
+            if not (na > 1 and nb > 1):
+                bad.append("A_ORDER = %d, B_ORDER = %d: astropy reads SIP only when both exceed 1" % (na, nb))
+            elif max(na, nb) > SIP_MAX_ORDER:
+                bad.append("SIP order %d > %d" % (max(na, nb), SIP_MAX_ORDER))
+            else:
+                n_ = max(na, nb)
+                a, b = np.zeros((n_ + 1, n_ + 1)), np.zeros((n_ + 1, n_ + 1))
+                for (tab, lim, name) in ((a, na, "A"), (b, nb, "B")):
+                    for (p_, q_), v in coefs.get(name, {}).items():
+                        if p_ + q_ <= lim:
+                            tab[p_, q_] = v
+                if np.any(a) or np.any(b):
+                    self.sip_a, self.sip_b = a, b
+
+    def _require_celestial(self):
+        if self.naxis < 2 or not self.proj:
+            raise ValueError("WCS does not contain two spatial axes.")
+        if self._unsupported:
+            raise NotImplementedError(self._unsupported[0])
 
     # -- FITS paper II section 2.4: celestial coordinates of the native pole
     def _setup_pole(self):
         if self.naxis < 2 or not self.proj:
             return
         a0, d0 = self.crval[0] * _D2R, self.crval[1] * _D2R
-        th0 = (90.0 if self.proj in _ZENITHAL else 0.0) * _D2R
-        ph0 = 0.0
+        th0 = self.theta0 * _D2R
+        ph0 = self.phi0 * _D2R
         if self.lonpole is None:
-            lonpole = 0.0 if d0 >= th0 else 180.0
+            lonpole = self.phi0 + (0.0 if d0 >= th0 else 180.0)
         else:
             lonpole = float(self.lonpole)
         php = lonpole * _D2R
@@ -148,6 +316,7 @@ class SimpleWCS:
             den = np.sqrt(1.0 - (ct0 * np.sin(dphi)) ** 2)
             arg = np.clip(np.sin(d0) / den, -1.0, 1.0)
             cands = [base + np.arccos(arg), base - np.arccos(arg)]
+            cands = [(c + np.pi) % (2 * np.pi) - np.pi for c in cands]
             cands = [c for c in cands if -np.pi / 2 - 1e-12 <= c <= np.pi / 2 + 1e-12]
             if not cands:
                 raise ValueError("invalid LONPOLE/LATPOLE for this header")
@@ -168,24 +337,30 @@ class SimpleWCS:
     def _lin2(self):
         return (self.cdelt[:, None] * self.pc)[:2, :2]
 
+    def sip_tables(self):
+        """(order, A table, B table): the SIP polynomials in the triangular layout of spc_celestial_wcs, order 0 = none"""
+        ta, tb = np.zeros(_sip_index(SIP_MAX_ORDER, 0) + 1), np.zeros(_sip_index(SIP_MAX_ORDER, 0) + 1)
+        if self.sip_a is None:
+            return 0, ta, tb
+        n_ = self.sip_a.shape[0] - 1
+        for p_ in range(n_ + 1):
+            for q_ in range(n_ + 1 - p_):
+                ta[_sip_index(p_, q_)] = self.sip_a[p_, q_]
+                tb[_sip_index(p_, q_)] = self.sip_b[p_, q_]
+        return n_, ta, tb
+
     def celestial_params(self):
         """the numbers spc_wcs_pixel_map_f64 needs (include/spcube_hip.h: spc_celestial_wcs):
-        (proj code, crpix (x, y), lin 2x2, lin^-1 2x2, alpha_p, delta_p, phi_p)"""
-        if self.naxis < 2 or not self.proj:
-            raise ValueError("WCS does not contain two spatial axes.")
+        (proj code, crpix (x, y), lin 2x2, lin^-1 2x2, alpha_p, delta_p, phi_p, pv1, (x0, y0), (sip order, A, B))"""
+        self._require_celestial()
         code = _PROJ_CODE[self.proj]
         m = self._lin2()
         return (code, (float(self.crpix[0]), float(self.crpix[1])), tuple(m.ravel()), tuple(np.linalg.inv(m).ravel()),
-                float(self._ap), float(self._dp), float(self._php), float(self.pv1))
+                float(self._ap), float(self._dp), float(self._php), float(self.pv1), (float(self.x0), float(self.y0)),
+                self.sip_tables())
 
-    def celestial_pix2world(self, px, py):
-        """0-based pixel -> (lon, lat) degrees."""
-        px = np.asarray(px, dtype=np.float64)
-        py = np.asarray(py, dtype=np.float64)
-        m = self._lin2()
-        dx, dy = px + 1.0 - self.crpix[0], py + 1.0 - self.crpix[1]
-        x = m[0, 0] * dx + m[0, 1] * dy
-        y = m[1, 0] * dx + m[1, 1] * dy
+    # -- projection plane <-> native sphere (FITS paper II section 5), radians in / degrees on the plane ---------
+    def _plane_to_native(self, x, y):
         if self.proj in _CYLINDRICAL:
             with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
                 if self.proj == "CAR":
@@ -224,27 +399,10 @@ class SimpleWCS:
                 theta = np.pi / 2 - 2.0 * np.arctan(rr / 2.0)
             else:  # ZEA
                 theta = np.pi / 2 - 2.0 * np.arcsin(np.clip(rr / 2.0, -1.0, 1.0))
-        ap, dp, php = self._ap, self._dp, self._php
-        dphi = phi - php
-        st, ct = np.sin(theta), np.cos(theta)
-        lon = ap + np.arctan2(-ct * np.sin(dphi), st * np.cos(dp) - ct * np.sin(dp) * np.cos(dphi))
-        lat = np.arcsin(np.clip(st * np.sin(dp) + ct * np.cos(dp) * np.cos(dphi), -1.0, 1.0))
-        lon = np.mod(lon * _R2D, 360.0)
-        return lon, lat * _R2D
+        return phi, theta
 
-    def celestial_world2pix(self, lon, lat):
-        """(lon, lat) degrees -> 0-based pixel; NaN where not projectable."""
-        lon = np.asarray(lon, dtype=np.float64) * _D2R
-        lat = np.asarray(lat, dtype=np.float64) * _D2R
-        ap, dp, php = self._ap, self._dp, self._php
-        da = lon - ap
-        sl, cl = np.sin(lat), np.cos(lat)
-        # native unit vector (accurate near the native pole, unlike asin())
-        xn = -cl * np.sin(da)
-        yn = sl * np.cos(dp) - cl * np.sin(dp) * np.cos(da)
-        zn = sl * np.sin(dp) + cl * np.cos(dp) * np.cos(da)
-        rho = np.hypot(xn, yn)
-        phi = php + np.arctan2(xn, yn)
+    def _native_vec_to_plane(self, phi, rho, zn):
+        """native longitude phi and the (cos theta, sin theta) = (rho, zn) pair of a unit vector -> plane (degrees)"""
         with np.errstate(invalid="ignore", divide="ignore"):
             if self.proj in _CYLINDRICAL:
                 phi = np.mod(phi + np.pi, 2 * np.pi) - np.pi
@@ -272,15 +430,99 @@ class SimpleWCS:
                 else:  # ZEA
                     r = 2.0 * _R2D * rho / np.sqrt(2.0 * (1.0 + zn))
                 x, y = r * np.sin(phi), -r * np.cos(phi)
+        return x, y
+
+    def _native_to_plane(self, phi, theta):
+        return self._native_vec_to_plane(phi, np.cos(theta), np.sin(theta))
+
+    def celestial_pix2world(self, px, py):
+        """0-based pixel -> (lon, lat) degrees (astropy's all_pix2world: SIP, then wcslib's core)."""
+        self._require_celestial()
+        px = np.asarray(px, dtype=np.float64)
+        py = np.asarray(py, dtype=np.float64)
+        m = self._lin2()
+        dx, dy = px + 1.0 - self.crpix[0], py + 1.0 - self.crpix[1]
+        if self.sip_a is not None:
+            dx, dy = dx + _poly(self.sip_a, dx, dy), dy + _poly(self.sip_b, dx, dy)
+        x = m[0, 0] * dx + m[0, 1] * dy + self.x0
+        y = m[1, 0] * dx + m[1, 1] * dy + self.y0
+        phi, theta = self._plane_to_native(x, y)
+        ap, dp, php = self._ap, self._dp, self._php
+        dphi = phi - php
+        st, ct = np.sin(theta), np.cos(theta)
+        # celestial unit vector about the native pole's meridian; the latitude from atan2 of its components (asin of the
+        # third alone loses half the digits near the celestial poles - wcslib's sphx2s switches to acos there)
+        xc = st * np.cos(dp) - ct * np.sin(dp) * np.cos(dphi)
+        yc = -ct * np.sin(dphi)
+        zc = st * np.sin(dp) + ct * np.cos(dp) * np.cos(dphi)
+        lon = ap + np.arctan2(yc, xc)
+        lat = np.arctan2(zc, np.hypot(xc, yc))
+        lon = np.mod(lon * _R2D, 360.0)
+        return lon, lat * _R2D
+
+    def _sip_invert(self, uu, vv, maxiter=50, tol=1e-13):
+        """(u, v) with u + A(u, v) = uu, v + B(u, v) = vv: Newton from (uu, vv).  astropy's all_world2pix inverts the
+        forward polynomials too (fixed-point, stopped at 1e-4 pixel by default); this is that iteration's limit.
+        Points where it does not converge (far outside the image, where the polynomial folds over) come back NaN."""
+        u, v = np.array(uu, dtype=np.float64, copy=True), np.array(vv, dtype=np.float64, copy=True)
+        with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+            done = np.zeros(u.shape, dtype=bool)
+            for _ in range(maxiter):
+                f = u + _poly(self.sip_a, u, v) - uu
+                g_ = v + _poly(self.sip_b, u, v) - vv
+                au, av = _poly_grad(self.sip_a, u, v)
+                bu, bv = _poly_grad(self.sip_b, u, v)
+                j00, j01, j10, j11 = 1.0 + au, av, bu, 1.0 + bv
+                det = j00 * j11 - j01 * j10
+                du = (j11 * f - j01 * g_) / det
+                dv = (j00 * g_ - j10 * f) / det
+                u = np.where(done, u, u - du)
+                v = np.where(done, v, v - dv)
+                done |= (np.abs(du) <= tol * np.maximum(1.0, np.abs(u))) & (np.abs(dv) <= tol * np.maximum(1.0, np.abs(v)))
+                if done.all():
+                    break
+            u = np.where(done, u, np.nan)
+            v = np.where(done, v, np.nan)
+        return u, v
+
+    def celestial_world2pix(self, lon, lat):
+        """(lon, lat) degrees -> 0-based pixel; NaN where not projectable (astropy's all_world2pix)."""
+        self._require_celestial()
+        lon = np.asarray(lon, dtype=np.float64) * _D2R
+        lat = np.asarray(lat, dtype=np.float64) * _D2R
+        ap, dp, php = self._ap, self._dp, self._php
+        da = lon - ap
+        sl, cl = np.sin(lat), np.cos(lat)
+        # native unit vector (accurate near the native pole, unlike asin())
+        xn = -cl * np.sin(da)
+        yn = sl * np.cos(dp) - cl * np.sin(dp) * np.cos(da)
+        zn = sl * np.sin(dp) + cl * np.cos(dp) * np.cos(da)
+        rho = np.hypot(xn, yn)
+        phi = php + np.arctan2(xn, yn)
+        x, y = self._native_vec_to_plane(phi, rho, zn)
+        x, y = x - self.x0, y - self.y0
         minv = np.linalg.inv(self._lin2())
         dx = minv[0, 0] * x + minv[0, 1] * y
         dy = minv[1, 0] * x + minv[1, 1] * y
+        if self.sip_a is not None:
+            dx, dy = self._sip_invert(dx, dy)
         return dx + self.crpix[0] - 1.0, dy + self.crpix[1] - 1.0
 
     # -- spectral ---------------------------------------------------------
+    def _require_linear_spectral(self):
+        """the spectral axis is read as LINEAR in its CTYPE3 quantity.  wcslib (which the reference's world / reproject
+        calls go through) also knows non-linear axes - CTYPE3 = 'VOPT-F2W' (optical velocity sampled evenly in frequency),
+        '-LOG', '-TAB', the grism codes, and AIPS' 'FELO-xxx' which it translates to VOPT-F2W: those are refused, not read
+        as linear."""
+        c = str(self.ctype[2]).strip().upper()
+        if c.startswith("FELO") or (len(c) >= 8 and c[4] == "-" and c[5:8] in _SPECTRAL_ALGORITHMS):
+            raise NotImplementedError("CTYPE3 = %r: non-linear spectral axes (wcslib's spectral algorithm codes) are not built"
+                                      % self.ctype[2])
+
     def spectral_pix2world(self, pz):
         if self.naxis < 3:
             raise ValueError("no spectral axis")
+        self._require_linear_spectral()
         pz = np.asarray(pz, dtype=np.float64)
         if abs(self.pc[2, 0]) + abs(self.pc[2, 1]) + abs(self.pc[0, 2]) + abs(self.pc[1, 2]) > 0:
             raise NotImplementedError("spectral and celestial axes must be separable")
@@ -290,6 +532,7 @@ class SimpleWCS:
         """world coordinate (in this axis' CUNIT3) -> 0-based channel (fractional); linear axis"""
         if self.naxis < 3:
             raise ValueError("no spectral axis")
+        self._require_linear_spectral()
         w = np.asarray(w, dtype=np.float64)
         return (w - self.crval[2]) / (self.cdelt[2] * self.pc[2, 2]) + self.crpix[2] - 1.0
 

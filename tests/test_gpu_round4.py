@@ -1,0 +1,135 @@
+"""GPU: what round 4 added - the device pixel map with SIP / PV1 / polar-safe rotation (astropy fixtures), the ADVICE
+round-3 fixes (chunked read-back ordered after the null stream, streamed fused smooth -> moment falling back when the
+kernel is too wide to fuse, FITS -> the same FITS)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close, golden
+from spectral_cube_amd import SpectralCube, SimpleWCS, _lib, ops
+from spectral_cube_amd.device import DeviceArray
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["verdict_sip", "sip_source", "sip_both", "verdict_pv1", "polar", "polar_arc_zea"])
+def test_device_pixel_map_sip_pv1_polar(gpu, name):
+    """spc_wcs_pixel_map_f64 against astropy's all_pix2world -> all_world2pix (tests/golden/wcs_strict.npz): the round-3
+    verdict's cases - SIP target (was 4 px off), PV1_1 / PV1_2 target (was 1014 px off), the polar pair (was 1e-5 px off) -
+    plus SIP on the source side (the inverse) and on both sides; 1e-9 pixel"""
+    g = golden("wcs_strict.npz")
+    w_in, w_out = SimpleWCS(str(g["map_in_" + name]), naxis=2), SimpleWCS(str(g["map_out_" + name]), naxis=2)
+    shape = tuple(int(v) for v in g["map_shape_" + name])
+    xs, ys = (a.get() for a in ops.wcs_pixel_map(w_in, w_out, shape))
+    yy, xx = g["map_yy_" + name], g["map_xx_" + name]
+    assert np.abs(xs[yy, xx] - g["map_xs_" + name]).max() < 1e-9 and np.abs(ys[yy, xx] - g["map_ys_" + name]).max() < 1e-9
+    # and the whole grid against the host map (numpy, the same arithmetic)
+    from spectral_cube_amd.wcs import reproject_pixel_map
+    hx, hy = reproject_pixel_map(w_in, w_out, shape)
+    ok = np.isfinite(hx) & np.isfinite(hy)
+    assert ok.all() and np.abs(xs - hx).max() < 1e-9 and np.abs(ys - hy).max() < 1e-9
+
+
+def test_device_sip_inverse_without_solution_is_outside(gpu):
+    """a source whose SIP polynomial folds over beyond the image: no pixel, not garbage"""
+    base = {"CTYPE1": "RA---TAN-SIP", "CTYPE2": "DEC--TAN-SIP", "CRVAL1": 83.6, "CRVAL2": -5.4, "CRPIX1": 20.5, "CRPIX2": 15.5,
+            "CDELT1": -2.0 / 3600, "CDELT2": 2.0 / 3600}
+    src = SimpleWCS(dict(base, A_ORDER=2, B_ORDER=2, A_2_0=-2e-3, B_0_2=-2e-3), naxis=2)        # u + A(u) <= 125: nothing maps beyond
+    dst = SimpleWCS({k: v for k, v in dict(base, CTYPE1="RA---TAN", CTYPE2="DEC--TAN", CRPIX1=-800.0).items()}, naxis=2)
+    xs, ys = (a.get() for a in ops.wcs_pixel_map(src, dst, (30, 40)))
+    assert np.all(xs == -1e30) and np.all(ys == -1e30)
+    cube = SpectralCube.read(np.ones((3, 30, 40), dtype=np.float32), dict(src.header, CTYPE3="VRAD", CDELT3=1.0, CRVAL3=0.0, CRPIX3=1.0))
+    with pytest.raises(ValueError, match="All values in reprojected cube are nan"):
+        cube.reproject(dict(dst.header, NAXIS1=40, NAXIS2=30))
+
+
+def test_reproject_onto_a_sip_header_end_to_end(gpu):
+    """cube.reproject onto the verdict's RA---TAN-SIP header: the values follow astropy's map (fixture) through the
+    oracle's bilinear restatement, 1e-5"""
+    g = golden("wcs_strict.npz")
+    name = "verdict_sip"
+    shape = tuple(int(v) for v in g["map_shape_" + name])
+    rng = np.random.default_rng(5)
+    yy0, xx0 = np.mgrid[0:shape[0], 0:shape[1]]
+    d = np.stack([np.sin(xx0 / 9.0) * np.cos(yy0 / 7.0) + 0.1 * k for k in range(3)]).astype(np.float32)
+    hin = dict(SimpleWCS(str(g["map_in_" + name]), naxis=2).header, CTYPE3="VRAD", CDELT3=1.0, CRVAL3=0.0, CRPIX3=1.0, CUNIT3="km/s")
+    cube = SpectralCube.read(d, hin)
+    res = cube.reproject(str(g["map_out_" + name]))
+    got = np.asarray(res.filled_data)
+    yy, xx = g["map_yy_" + name], g["map_xx_" + name]
+    exs, eys = g["map_xs_" + name], g["map_ys_" + name]
+    full_x, full_y = np.full(shape, -1e30), np.full(shape, -1e30)
+    full_x[yy, xx], full_y[yy, xx] = exs, eys
+    exp, _ = O.reproject_separable(d.astype(np.float64), full_x, full_y, None)
+    sel = np.zeros(shape, dtype=bool)
+    sel[yy, xx] = True
+    assert_close(got[:, sel], exp[:, sel].astype(np.float32), atol=1e-5 * np.abs(d).max(), what="reproject onto SIP")
+    assert np.isfinite(got[:, sel]).mean() > 0.8
+
+
+def test_chunked_readback_waits_for_the_null_stream(gpu):
+    """DeviceArray.get() of a result above 256 MiB comes down in chunks on a stream of its own; it
+    must see what kernels on the NULL stream (every resident cube path) wrote.  A long null-stream smoothing into a 512 MiB
+    output, read back at once, with the pinned chunk buffers already warm."""
+    nz, ny, nx = 512, 512, 512
+    rng = np.random.default_rng(3)
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    dev = DeviceArray.from_numpy(d)
+    warm = dev.get()                                   # pins the chunk buffers (the slow first call hid the race)
+    assert np.array_equal(warm, d)
+    from spectral_cube_amd import Gaussian1DKernel
+    karr = Gaussian1DKernel(6.0).array                 # 49 taps: ~10 ms of kernel at this size
+    for _ in range(3):
+        out = ops.spectral_conv(dev, karr)             # launched on the null stream, no sync
+        got = out.get()
+        # spot-check whole planes at the END of the buffer (the last chunks: what a racing copy would fetch half-written)
+        exp = O.spectral_smooth(d[:, -8:, :].astype(np.float64), np.ones((nz, 8, nx), bool), karr)
+        assert_close(got[:, -8:, :], exp.astype(np.float32), atol=1e-5 * np.abs(exp).max(), what="chunked read-back")
+        del out
+
+
+def test_streamed_fused_smooth_moment_falls_back_for_wide_kernels(gpu, monkeypatch):
+    """out-of-core parent, spectral_smooth with more taps than the fused rings take (> 33) on a
+    cube with NaNs, then moment: the fused call raises HipUnsupported inside the strip loop; the streamed path now
+    materialises the smoothed STRIP and reduces it (what the resident path always did) - same maps as the resident cube."""
+    from spectral_cube_amd import Gaussian1DKernel
+    nz, ny, nx = 96, 40, 64
+    rng = np.random.default_rng(8)
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32) + 2.0
+    d[rng.random(d.shape) < 0.05] = np.nan
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 0.5, "CUNIT3": "km/s",
+           "CRPIX1": 1, "CRPIX2": 1, "CRPIX3": 1, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": -16.0}
+    kern = Gaussian1DKernel(5.5)                      # 45 taps
+    assert kern.array.size > 33
+    res = SpectralCube.read(d, hdr)
+    exp = {o: np.asarray(res.spectral_smooth(kern).moment(order=o)) for o in (0, 1)}
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(d.nbytes // 3))
+    big = SpectralCube.read(d.copy(), hdr)
+    assert big._stream_source() is not None
+    for o in (0, 1):
+        got = np.asarray(big.spectral_smooth(kern).moment(order=o))
+        assert_close(got, exp[o], atol=1e-6 * np.nanmax(np.abs(exp[o])), what="streamed wide smooth -> moment %d" % o)
+
+
+def test_streamed_write_onto_its_own_source_file(gpu, tmp_path, monkeypatch):
+    """write(path, overwrite=True) of a streamed cube read FROM path used to truncate the input before
+    the first strip was read.  The sink now fills a sibling file and renames it at the end."""
+    from spectral_cube_amd import io_fits
+    nz, ny, nx = 24, 32, 48
+    rng = np.random.default_rng(9)
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 0.5, "CUNIT3": "km/s",
+           "CRPIX1": 1, "CRPIX2": 1, "CRPIX3": 1, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": -16.0}
+    path = os.path.join(tmp_path, "cube.fits")
+    SpectralCube.read(d, hdr).write(path)
+    monkeypatch.setenv("SPC_HBM_BUDGET", str(nz * 8 * nx * 4 * 3))
+    cube = SpectralCube.read(path)
+    assert cube._stream_source() is not None
+    masked = cube.with_mask(cube > 0.0)
+    masked.write(path, overwrite=True)                 # NaN where excluded, onto the file being read
+    assert [f for f in os.listdir(tmp_path) if "spc-part" in f] == []
+    monkeypatch.delenv("SPC_HBM_BUDGET")
+    back = np.asarray(SpectralCube.read(path).unmasked_data)
+    assert_close(back, np.where(d > 0.0, d, np.nan).astype(np.float32), what="file written onto itself")

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libspcube_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.spc_abi_version() == 3
+    assert lib.spc_abi_version() == 4
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -546,17 +546,18 @@ def test_header_keys_are_selected_by_axis_not_by_digit():
     travel with the spectral axis; NAXIS3 is defined."""
     from spectral_cube_amd.wcs import join_celestial_spectral, key_axes
     cel = SimpleWCS({"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CRVAL1": 1.0, "CRVAL2": 2.0, "CRPIX1": 3.0, "CRPIX2": 4.0,
-                     "CDELT1": -1e-3, "CDELT2": 1e-3, "PV2_3": 0.25, "A_3_0": 1e-9, "B_0_3": 2e-9, "NAXIS1": 5, "NAXIS2": 6}, naxis=2)
+                     "CDELT1": -1e-3, "CDELT2": 1e-3, "PV1_3": 180.0, "A_ORDER": 3, "B_ORDER": 3, "A_3_0": 1e-9, "B_0_3": 2e-9, "NAXIS1": 5,
+                     "NAXIS2": 6}, naxis=2)
     spec = SimpleWCS({"CTYPE1": "GLON-CAR", "CTYPE2": "GLAT-CAR", "CTYPE3": "VRAD", "CRVAL3": 5.0, "CDELT3": 2.0, "CRPIX3": 1.0,
                       "CUNIT3": "km/s", "PC1_3": 0.0, "PC3_3": 1.0, "RESTFRQ": 1.4e9, "SPECSYS": "LSRK", "NAXIS3": 7})
     j = join_celestial_spectral(cel, spec)
     h = j.header
-    assert h["PV2_3"] == 0.25 and h["A_3_0"] == 1e-9 and h["B_0_3"] == 2e-9
+    assert h["PV1_3"] == 180.0 and h["A_3_0"] == 1e-9 and h["B_0_3"] == 2e-9 and j.sip_a is not None
     assert "PC1_3" not in h and h["PC3_3"] == 1.0 and h["CTYPE3"] == "VRAD" and h["CTYPE1"] == "RA---TAN"
     assert h["NAXIS3"] == 7 and h["RESTFRQ"] == 1.4e9 and h["SPECSYS"] == "LSRK"
     assert join_celestial_spectral(cel, spec, nz=11).header["NAXIS3"] == 11
     d = j.drop_spectral().header
-    assert "CTYPE3" not in d and "PC3_3" not in d and d["PV2_3"] == 0.25 and d["A_3_0"] == 1e-9
+    assert "CTYPE3" not in d and "PC3_3" not in d and d["PV1_3"] == 180.0 and d["A_3_0"] == 1e-9
     assert key_axes("PV2_3") == {2} and key_axes("PC1_3") == {1, 3} and key_axes("A_3_0") == set()
 
 
