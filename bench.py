@@ -185,6 +185,22 @@ def cpu_baseline(shape, seconds):
 
 
 # ---- helpers ---------------------------------------------------------------------------------------
+class Ms(float):
+    """a duration in ms = the MEDIAN of the timed launches (median of >= 10 timed runs), carrying
+    min / max / mean / n so that every `frac` of the line can be set beside the rocprofv3 trace under profiles/"""
+
+    def __new__(cls, samples):
+        import numpy as np
+        a = np.asarray(list(samples), dtype=np.float64)
+        self = super().__new__(cls, float(np.median(a)))
+        self.stats = {"median": float(np.median(a)), "min": float(a.min()), "max": float(a.max()), "mean": float(a.mean()), "n": int(a.size)}
+        return self
+
+
+def ms_stats(ms):
+    return getattr(ms, "stats", {"median": float(ms), "min": float(ms), "max": float(ms), "mean": float(ms), "n": 1})
+
+
 class Workload:
     """one rank's resident cube + everything a step needs"""
 
@@ -221,7 +237,7 @@ class Workload:
                          want=("m0", "m1", "m2"), stream=stream or self.stream, workspace=self.ws, out=out)
 
     def kernel_ms(self, out, n):
-        """mean launch duration by HIP events on the kernel's stream"""
+        """median launch duration (Ms: + min / max / mean) by HIP events on the kernel's stream"""
         from spectral_cube_amd.device import Event
         e0, e1 = Event(self.device), Event(self.device)
         kt = []
@@ -231,7 +247,7 @@ class Workload:
             e1.record(self.stream)
             e1.synchronize()
             kt.append(e0.elapsed_ms(e1))
-        return float(self.np.mean(kt))
+        return Ms(kt)
 
     def verify(self, maps, tile, tmask, rows):
         """first `rows` rows of (m0, m1, m2) host maps vs the oracle on the host tile"""
@@ -251,23 +267,38 @@ class Workload:
         return {"rows_checked": int(rows), "max_scaled_err_m0_m1_m2": errs, "nan_pattern": "identical"}
 
 
-def pmc_traffic(shape):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (separate rocprofv3 --pmc
-    runs of this same command; FETCH_SIZE x2 gfx950 correction)"""
-    for name in ("r03_moments_c2_pmc.json", "r02_moments_c2_pmc.json", "r01_moments_c2_pmc.json"):
-        f = os.path.join(REPO, "profiles", name)
-        if os.path.exists(f) and tuple(shape) == (1024, 1024, 1024):
-            with open(f) as fh:
-                return json.load(fh)["hbm_traffic_bytes_per_launch"], "profiles/" + name
-    return None, None
+PMC_FILE = os.path.join("profiles", "r04_pmc_traffic_by_record.json")
+_PMC = None
+PMC_ON = True         # (set False by a run at non-default shapes: the committed counters were taken at the default ones)
+
+
+def pmc_traffic(record):
+    """(HBM bytes per launch, source) of the bench record `record` from the PMC passes committed under profiles/:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command at THIS shape (tests/prof_bench_r04.sh,
+    summarised per (kernel, grid) = per record by tests/prof_bench_summary_r04.py; FETCH_SIZE x 2: the gfx950 correction of
+    MI355X_MICROARCH.md).  (None, None) for a record the file does not hold, or at other shapes than the default."""
+    global _PMC
+    if not PMC_ON:
+        return None, None
+    if _PMC is None:
+        try:
+            with open(os.path.join(REPO, PMC_FILE)) as fh:
+                _PMC = json.load(fh)
+        except (OSError, ValueError):
+            _PMC = {}
+    rec = _PMC.get("records", {}).get(record)
+    if not rec:
+        return None, None
+    return rec["hbm_traffic_bytes_per_launch"], "%s#%s" % (PMC_FILE, record)
 
 
 def roofline(wl, k_ms, traffic=None, traffic_src=None):
     achieved = wl.alg_bytes / (k_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": PEAK_GBS, "unit": "GB/s", "frac": achieved / PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-            "kernel": "moments_kernel<VEC=4,ZW=4,U=8,ARR,noEXT,NT>", "kernel_ms": k_ms,
-            "algorithmic_bytes": wl.alg_bytes}
+            "traffic_over_algorithmic": (traffic / wl.alg_bytes) if traffic else None,
+            "kernel": "moments_kernel<VEC=4,ZW=4,U=8,ARR,noEXT,NT>", "kernel_ms": float(k_ms), "kernel_ms_stats": ms_stats(k_ms),
+            "timing": "median of n launches, HIP events on the kernel's stream", "algorithmic_bytes": wl.alg_bytes}
 
 
 # ---- N = 1 -------------------------------------------------------------------------------------------
@@ -297,7 +328,7 @@ def run_single(args, device):
     elapsed = time.perf_counter() - t0
 
     k_ms = wl.kernel_ms(out, min(20, max(5, args.steps)))
-    traffic, traffic_src = pmc_traffic(shape)
+    traffic, traffic_src = pmc_traffic("C2")
     verify = wl.verify([out[k].get() for k in ("m0", "m1", "m2")], blk, m, blk.shape[1])
     line = {
         "metric": METRIC, "value": nz * ny * nx * args.steps / elapsed / 1e6, "unit": "Mvoxel/s", "n_gpus": 1,
@@ -372,9 +403,9 @@ def north_star_record(shape, device, args):
                            "ms_per_call": elapsed / args.steps * 1e3, "note": SCALE_BASIS_NOTE},
            "workload": "north star: %dx%dx%d fp32 cube + uint8 mask resident on ONE GPU, fused moment0+1+2, "
                        "device-tiled synthetic data (one seeded %d-row host tile repeated along y)" % (shape + (tile.shape[1],)),
-           "kernel_ms": k_ms, "value": nz * ny * nx / (k_ms * 1e-3) / 1e6, "unit": "Mvoxel/s",
+           "kernel_ms": float(k_ms), "kernel_ms_stats": ms_stats(k_ms), "value": nz * ny * nx / (k_ms * 1e-3) / 1e6, "unit": "Mvoxel/s",
            "mask_valid_fraction": float(np.count_nonzero(tmask)) / tmask.size,
-           "roofline": roofline(wl, k_ms), "verify": verify, "target_frac": 0.60}
+           "roofline": roofline(wl, k_ms, *pmc_traffic("north_star")), "verify": verify, "target_frac": 0.60}
     del wl, out, cube, maskd
     gc.collect()
     pool_trim(device)
@@ -426,8 +457,8 @@ def fetch_rows(dev, y0, y1):
     return tmp.get()
 
 
-def event_ms(fn, device, n=5, warm=2):
-    """mean duration of fn() by HIP events on the stream its kernels are launched on (the null stream)"""
+def event_ms(fn, device, n=10, warm=2):
+    """median duration of fn() (Ms: + min / max / mean) by HIP events on the stream its kernels are launched on (the null stream)"""
     import numpy as np
     from spectral_cube_amd.device import Event, synchronize
     for _ in range(warm):
@@ -441,14 +472,17 @@ def event_ms(fn, device, n=5, warm=2):
         e1.record(None)
         e1.synchronize()
         ts.append(e0.elapsed_ms(e1))
-    return float(np.mean(ts))
+    return Ms(ts)
 
 
 def cfg_record(name, kernel, ms, alg_bytes, voxels, verify, bytes_note, **extra):
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    rec = {"name": name, "kernel": kernel, "kernel_ms": ms, "algorithmic_bytes": int(alg_bytes), "bytes_per_voxel": bytes_note,
-           "achieved_GBps": gbs, "frac": gbs / PEAK_GBS, "value": voxels / (ms * 1e-3) / 1e6, "unit": "Mvoxel/s",
-           "verify": verify}
+    traffic, src = pmc_traffic(extra.pop("pmc", name))
+    rec = {"name": name, "kernel": kernel, "kernel_ms": float(ms), "kernel_ms_stats": ms_stats(ms),
+           "algorithmic_bytes": int(alg_bytes), "bytes_per_voxel": bytes_note,
+           "achieved_GBps": gbs, "frac": gbs / PEAK_GBS, "traffic": traffic, "traffic_source": src,
+           "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+           "value": voxels / (ms * 1e-3) / 1e6, "unit": "Mvoxel/s", "verify": verify}
     rec.update(extra)
     return rec
 
@@ -562,7 +596,7 @@ def config_c4(device, scale):
             got[z] = rows[:, :WX]
         return got
 
-    ms = event_ms(lambda: ops.spatial_conv(cube, k2, out=sm), device, n=3, warm=1)
+    ms = event_ms(lambda: ops.spatial_conv(cube, k2, out=sm), device, n=5, warm=1)
     exp = O.spatial_smooth(tile[sub], None, k2)[win]
     ver = {"max_scaled_err": _close(smoothed_window(sm), exp, float(np.abs(exp).max()), "C4 smooth"), "voxels_checked": int(exp.size)}
     recs.append(cfg_record("C4 spatial_smooth(29x29), all valid", "spatial_sep_fast_kernel<29>", ms, vox * 8, vox, ver, "4 read + 4 written"))
@@ -571,7 +605,7 @@ def config_c4(device, scale):
     replicate_planes(maskd, tmask)
     mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=maskd)
     inc = tmask[sub].astype(bool)
-    ms_s = event_ms(lambda: ops.spatial_conv(cube, k2, mask=mspec, out=sm), device, n=3, warm=1)
+    ms_s = event_ms(lambda: ops.spatial_conv(cube, k2, mask=mspec, out=sm), device, n=5, warm=1)
     exp = O.spatial_smooth(tile[sub], inc, k2)[win]
     ver = {"max_scaled_err": _close(smoothed_window(sm), exp, float(np.nanmax(np.abs(exp))), "C4 smooth masked"),
            "voxels_checked": int(exp.size)}
@@ -587,7 +621,7 @@ def config_c4(device, scale):
     def pipeline_masked():
         ops.spatial_conv(cube, k2, mask=mspec, out=sm)
         ops.moments(sm, cen, dv=500.0, mask=mspec, want=("m0",), out=o0, workspace=ws)
-    ms = event_ms(pipeline_masked, device, n=3, warm=1)
+    ms = event_ms(pipeline_masked, device, n=5, warm=1)
     incw = tmask[win].astype(bool)
     exp_m0 = (nz // 2) * 500.0 * np.where(incw, exp, 0.0).sum(axis=0)
     exp_m0[~incw.any(axis=0)] = np.nan
@@ -659,7 +693,7 @@ def config_c5(device, scale):
     w_in, w_out = SimpleWCS(hdr, naxis=2), SimpleWCS(dict(hdr, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c), naxis=2)
     xs, ys = ops.wcs_pixel_map(w_in, w_out, (ny, nx), device)
     rep = DeviceArray((nzo, ny, nx), np.float32, device)
-    ms = event_ms(lambda: ops.resample_bilinear(out, xs, ys, out=rep, want_footprint=False), device, n=3, warm=1)
+    ms = event_ms(lambda: ops.resample_bilinear(out, xs, ys, out=rep, want_footprint=False), device, n=5, warm=1)
     hx, hy = xs.get(), ys.get()
     chans = [0, 1, nzo // 2 + 1, nzo - 1]
     src = np.stack([out.planes(c_, c_ + 1).get()[0] for c_ in chans])
@@ -713,7 +747,7 @@ def next_rows_records(cube, maskd, tile, tmask, device):
     def clip():
         keep["r"] = None                                    # (the previous result goes back to the pool first)
         keep["r"] = ops.sigma_clip_axis0(cube, sigma=3.0, mask=spec)
-    ms = event_ms(clip, device, n=3, warm=1)
+    ms = event_ms(clip, device, n=5, warm=1)
     got = fetch_rows(keep["r"], 0, rows)
     exp = O.sigma_clip(tile, inc, 3.0)
     differ = float(np.mean(np.isnan(got) != np.isnan(exp)))
@@ -747,6 +781,59 @@ def config_records(args, device):
 
 
 # ---- N > 1: strong scaling of the north-star cube -----------------------------------------------
+STITCH_EXIT = 4
+
+
+def require_device_stitch(stitch, local_world, ndev, rank=0):
+    """With one GPU per rank the stitch MUST be the RCCL all-gather: a run that fell back to the host rendezvous would put a
+    78 ms/step host copy into `value` and still look like a scaling point (profiles/r03_bench_n2_on_1gpu_hostfallback.log).
+    Ranks that SHARE a device (a 1-GPU box driven with --gpus 2: RCCL refuses two ranks on one device) may fall back - the
+    line says stitch = host-fallback; SPC_BENCH_ALLOW_HOST_STITCH=1 lifts the check."""
+    if stitch == "rccl" or local_world > ndev or os.environ.get("SPC_BENCH_ALLOW_HOST_STITCH", "0") == "1":
+        return
+    print("[bench] rank %d: %d ranks on %d devices and the stitch is %r, not rccl: refusing to benchmark the host fallback "
+          "(SPC_BENCH_ALLOW_HOST_STITCH=1 to run it anyway)" % (rank, local_world, ndev, stitch), file=sys.stderr, flush=True)
+    sys.exit(STITCH_EXIT)
+
+
+def rccl_self_check(comm, device, rdv, init_ms, stitch_bytes):
+    """before any timing, per rank: a 1 MiB all-gather whose content is checked word by word on the host (rank r sends
+    r * 2^20 + i), then the median time of the all-gather at the size the stitch uses, S(N) = 3 maps x rows x NX x 8 B per
+    rank.  One line per rank on stderr; a wrong gather exits non-zero."""
+    import numpy as np
+    from spectral_cube_amd.device import DeviceArray, Event, Stream
+    world, rank = rdv.world_size, rdv.rank
+    n = (1 << 20) // 8 // world
+    send = DeviceArray.from_numpy(np.arange(n, dtype=np.int64) + (rank << 20), device)
+    recv = DeviceArray((world, n), np.int64, device)
+    st = Stream(device)
+    comm.allgather_rows_device(send, recv, st)
+    st.synchronize()
+    got = recv.get()
+    exp = np.arange(n, dtype=np.int64)[None, :] + (np.arange(world, dtype=np.int64)[:, None] << 20)
+    ok = bool(np.array_equal(got, exp))
+    big_s = DeviceArray((max(stitch_bytes, 8) // 8,), np.float64, device)
+    big_r = DeviceArray((world, max(stitch_bytes, 8) // 8), np.float64, device)
+    e0, e1, ts = Event(device), Event(device), []
+    for i in range(12):
+        rdv.barrier()
+        e0.record(st)
+        comm.allgather_rows_device(big_s, big_r, st)
+        e1.record(st)
+        e1.synchronize()
+        if i >= 2:
+            ts.append(e0.elapsed_ms(e1))
+    ms = Ms(ts)
+    print("[bench] rank %d/%d on device %d: RCCL self-check %s - init %.1f ms, 1 MiB all-gather checksum %s, all-gather of S(N) = "
+          "%.2f MiB per rank: median %.3f ms (min %.3f, max %.3f)" % (rank, world, device, "ok" if ok else "FAILED", init_ms,
+          "%d" % int(got.sum() % 1000003) if ok else "MISMATCH", stitch_bytes / 2**20, ms, ms.stats["min"], ms.stats["max"]),
+          file=sys.stderr, flush=True)
+    oks = rdv.allgather_object(ok)
+    if not all(oks):
+        sys.exit(5)
+    return {"init_ms": init_ms, "checksum_ok": True, "allgather_ms_at_stitch_size": float(ms), "stitch_bytes_per_rank": int(stitch_bytes)}
+
+
 def run_sharded(args, device, rdv):
     import numpy as np
     from spectral_cube_amd import synth
@@ -763,6 +850,7 @@ def run_sharded(args, device, rdv):
 
     # RcclComm completes the id broadcast on every rank whether or not rank 0 could make an id (the sequence of
     # rendezvous collectives is the same on all ranks whatever fails); rccl or host-fallback is then decided TOGETHER
+    t_init = time.perf_counter()
     try:
         comm, stitch = RcclComm(device, rdv), "rccl"
     except Exception as exc:          # loud, reported fallback for the STITCH only
@@ -774,6 +862,11 @@ def run_sharded(args, device, rdv):
         if comm is not None:
             comm.close()
         comm, stitch = HostGatherComm(rdv), "host-fallback"
+    from spectral_cube_amd import _lib as _spclib
+    require_device_stitch(stitch, int(os.environ.get("LOCAL_WORLD_SIZE", world)), _spclib.device_count(), rank)
+    self_check = None
+    if stitch == "rccl":
+        self_check = rccl_self_check(comm, device, rdv, (time.perf_counter() - t_init) * 1e3, 3 * rows * NX * 8)
 
     # send buffer = the rank's three map strips back to back; receive buffer (world, 3, rows, NX):
     # map k of the whole cube = recv[:, k] read along y
@@ -912,6 +1005,7 @@ def run_sharded(args, device, rdv):
                       "ms_per_step": elapsed_pipe / args.steps * 1e3,
                       "note": "all-gather of step k on its own stream under the kernel of step k+1 (double buffered)"},
         "roofline": roofline(wl, k_ms_max),
+        "rccl_self_check": self_check,
         "cpu_baseline": None,
         "scale_basis": {"workload": "%dx%dx%d fp32 + uint8 mask, fused moment0+1+2" % (NZ, NY, NX), "n_gpus": world,
                         "value": total * args.steps / best / 1e6, "unit": "Mvoxel/s", "ms_per_call": best / args.steps * 1e3,
@@ -980,6 +1074,13 @@ def dry_run(args):
         sys.exit(3)
     rdv = FileRendezvous.from_env(timeout=60) if world > 1 else SingleProcess()
     try:
+        # SPC_BENCH_DRYRUN_STITCH / _DEVICES: the stitch decision of run_sharded without a GPU (host-fallback with a device
+        # per rank must end the launch with a non-zero status)
+        if "SPC_BENCH_DRYRUN_STITCH" in os.environ:
+            flags = rdv.allgather_object(os.environ["SPC_BENCH_DRYRUN_STITCH"] if rank == world - 1 else "rccl")
+            stitch = "rccl" if all(f == "rccl" for f in flags) else "host-fallback"
+            require_device_stitch(stitch, int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                                  int(os.environ.get("SPC_BENCH_DRYRUN_DEVICES", world)), rank)
         token = rdv.bcast_bytes(b"id-from-rank-0" if rank == 0 else None)
         ranks = rdv.allgather_object((rank, int(os.environ.get("LOCAL_RANK", -1)), os.getpid()))
         rdv.barrier()
@@ -1003,6 +1104,8 @@ def main():
         args.gpus = world                                   # under a launcher its world size wins
     if os.environ.get("SPC_BENCH_DRYRUN", "0") == "1":
         return dry_run(args)
+    global PMC_ON
+    PMC_ON = (tuple(args.shape) == (1024, 1024, 1024) and tuple(args.north_star_shape) == NORTH_STAR and args.configs_scale == 1)
     from spectral_cube_amd import _lib
     from spectral_cube_amd.rendezvous import FileRendezvous, SingleProcess
     _lib.require_gpu()

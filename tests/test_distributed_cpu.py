@@ -230,3 +230,18 @@ def test_bench_launch_fails_when_a_rank_fails():
 def test_bench_without_gpu_fails_loudly_not_silently():
     p = _bench(["--gpus", "1", "--steps", "1", "--no-north-star", "--no-cpu-baseline"])
     assert p.returncode != 0 and "no HIP device" in p.stderr and not p.stdout.strip()
+
+
+def test_bench_refuses_to_time_the_host_fallback_when_every_rank_has_a_device():
+    """RCCL failing on ONE rank of a launch with a GPU per rank makes every rank fall back to the
+    host stitch together - and the launch must then END with a non-zero status instead of printing a 78 ms/step scaling
+    point.  Ranks sharing a device (--gpus 2 on a 1-GPU box) may fall back; the override is explicit."""
+    p = _bench(["--gpus", "2"], SPC_BENCH_DRYRUN="1", SPC_BENCH_DRYRUN_STITCH="host-fallback", SPC_BENCH_DRYRUN_DEVICES="2")
+    assert p.returncode == 4 and "refusing to benchmark the host fallback" in p.stderr and not p.stdout.strip().endswith("}")
+    p = _bench(["--gpus", "2"], SPC_BENCH_DRYRUN="1", SPC_BENCH_DRYRUN_STITCH="host-fallback", SPC_BENCH_DRYRUN_DEVICES="1")
+    assert p.returncode == 0, p.stderr                        # two ranks on one device: the fallback is allowed (and reported)
+    p = _bench(["--gpus", "2"], SPC_BENCH_DRYRUN="1", SPC_BENCH_DRYRUN_STITCH="host-fallback", SPC_BENCH_DRYRUN_DEVICES="2",
+               SPC_BENCH_ALLOW_HOST_STITCH="1")
+    assert p.returncode == 0, p.stderr
+    p = _bench(["--gpus", "2"], SPC_BENCH_DRYRUN="1", SPC_BENCH_DRYRUN_STITCH="rccl", SPC_BENCH_DRYRUN_DEVICES="2")
+    assert p.returncode == 0, p.stderr
