@@ -11,7 +11,7 @@ __version__ = "0.1.0"
 from ._lib import HipLibraryError, HipInvalidArgument, HipUnsupported  # noqa: F401
 from .cube import (SpectralCube, Projection, VarianceWarning, SmoothingWarning,  # noqa: F401
                    UnitsError, BeamUnitsError, WCSCelestialError, VaryingResolutionSpectralCube, BeamWarning,
-                   NonFiniteBeamsWarning)
+                   NonFiniteBeamsWarning, PrecisionWarning)
 from .beam import Beam, BeamError  # noqa: F401
 from .masks import (BooleanArrayMask, LazyMask, LazyComparisonMask, CompositeMask,  # noqa: F401
                     FunctionMask, InvertedMask)
