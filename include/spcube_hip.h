@@ -475,6 +475,18 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
                               int order, uint32_t* d_any_valid,
                               void* d_workspace, size_t workspace_bytes);
 
+/* spline resample: reproject_interp(order='biquadratic' | 'bicubic') for channels that map onto themselves
+ * (spectral_cube.py:2667-2676 documents the orders; :2726-2732 is the call).  order 2 / 3 =
+ * scipy.ndimage.map_coordinates(order, mode='constant', cval=nan) on the planes replicated by one border pixel: B-spline
+ * prefilter with mirror boundaries along y and x, 3 x 3 / 4 x 4 gather, float64 throughout, NaN outside
+ * [-0.5, n - 0.5].  The cube must hold finite samples only (scipy's recursive prefilter turns ONE non-finite sample into
+ * an all-NaN result; the caller checks and raises the reference's "All values in reprojected cube are nan").
+ * d_workspace: nz x (ny + 2) x (nx + 2) float64 coefficients (the caller resamples a slab of channels at a time). (ABI 4) */
+int spc_resample_spline_f32(int device, void* stream, const spc_cube_f32* cube, int order, int64_t ny_out,
+                            int64_t nx_out, const double* d_xs, const double* d_ys, float* d_out,
+                            int64_t out_row_stride, int64_t out_plane_stride, uint8_t* d_footprint,
+                            void* d_workspace, size_t workspace_bytes);
+
 /* ---- multi-GPU stitch (RCCL over xGMI) -----------------------------------
  * One process per GPU; each rank owns a row strip of the 2-D map.  The id is
  * created on rank 0 (spc_comm_unique_id) and distributed by the host

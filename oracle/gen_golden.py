@@ -817,6 +817,49 @@ def case_reproject_glue_scipy():
     print("nearest-neighbour and 3-D map_coordinates argument sets ok")
 
 
+def case_reproject_spline_scipy():
+    """reproject_interp(order='biquadratic' | 'bicubic') as reproject publishes it: the cube replicated by one border pixel,
+    ONE scipy.ndimage.map_coordinates(order=2 | 3, mode='constant', cval=nan) call on it (for a cube header: all three
+    coordinates, the channel coordinate integral), NaN where a coordinate leaves [-0.5, n - 0.5].  The oracle's restatement of
+    scipy's spline arithmetic (oracle_np.resample_spline: mirror-boundary recursive prefilter + mirror-folded gather) is
+    asserted against it here; one NaN sample makes scipy return NaN everywhere (the prefilter runs along every axis)."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(77)
+    store = {}
+    shapes = [(3, 9, 11), (2, 40, 37), (1, 2, 5), (4, 3, 3), (2, 70, 130)]
+    for n, shape in enumerate(shapes):
+        nz, ny, nx = shape
+        d = rng.standard_normal(shape)
+        oy, ox = 19, 23
+        xs = rng.uniform(-1.2, nx + 0.2, (oy, ox))
+        ys = rng.uniform(-1.2, ny + 0.2, (oy, ox))
+        xs[0, 0], ys[0, 0] = -0.5, ny - 0.5
+        xs[0, 1], ys[0, 1] = nx - 0.5, -0.5
+        xs[1, 1], ys[1, 1] = float(nx // 2), float(ny // 2)                       # a node: the sample itself
+        xs[2, 2] = np.nan
+        padded = np.pad(d, 1, mode="edge")
+        zz = np.broadcast_to(np.arange(nz, dtype=np.float64)[:, None, None], (nz, oy, ox))
+        coords = np.array([zz + 1, np.broadcast_to(ys, zz.shape) + 1, np.broadcast_to(xs, zz.shape) + 1])
+        reset = ~((xs >= -0.5) & (xs <= nx - 0.5) & (ys >= -0.5) & (ys <= ny - 0.5))
+        store["data%d" % n], store["xs%d" % n], store["ys%d" % n] = d, xs, ys
+        for order in (2, 3):
+            exp = map_coordinates(padded, np.where(np.isnan(coords), -5.0, coords), order=order, mode="constant", cval=np.nan)
+            exp[np.broadcast_to(reset, exp.shape)] = np.nan
+            got, foot = O.resample_spline(d, xs, ys, order)
+            close(got, exp, rtol=0, atol=1e-12 * np.abs(d).max(), what="spline order %d %s" % (order, shape))
+            assert np.array_equal(foot[0], ~reset)
+            assert abs(exp[0, 1, 1] - d[0, ny // 2, nx // 2]) < 1e-12
+            store["expected%d_%d" % (order, n)] = exp
+    d = store["data0"].copy()
+    d[1, 4, 5] = np.nan
+    exp = map_coordinates(np.pad(d, 1, mode="edge"), np.array([np.ones((4, 4)), np.full((4, 4), 3.3), np.full((4, 4), 2.7)]), order=3,
+                          mode="constant", cval=np.nan)
+    assert np.isnan(exp).all() and np.isnan(O.resample_spline(d, np.full((4, 4), 1.7), np.full((4, 4), 2.3), 3)[0]).all()
+    store["n"] = len(shapes)
+    np.savez_compressed(os.path.join(OUT, "reproject_spline_scipy.npz"), **store)
+    print("reproject_spline_scipy ok")
+
+
 def case_statistics():
     """statistics() and sum / mean / std / max / min (axis None, 0, 1, 2) of the Dask class
     on a masked fp32 cube with NaNs and a fully masked column; plus the reference's own
@@ -1047,7 +1090,7 @@ def case_beams_cube():
 
 if __name__ == "__main__":
     cases = [case_beams_cube, case_moment_cube, case_c1, case_adv_argmax, case_smooth, case_interp, case_kernels,
-             case_wcs, case_wcs_frames, case_wcs_projections, case_wcs_strict, case_bilinear_scipy, case_reproject_glue_scipy, case_statistics, case_fits_files,
+             case_wcs, case_wcs_frames, case_wcs_projections, case_wcs_strict, case_bilinear_scipy, case_reproject_glue_scipy, case_reproject_spline_scipy, case_statistics, case_fits_files,
              case_order_statistics, case_sigma_clip]
     only = set(sys.argv[1:])                 # e.g. `gen_golden.py case_reproject_glue_scipy` regenerates one fixture
     for fn in cases:

@@ -351,6 +351,100 @@ def resample_nearest(plane_or_cube, xs, ys):
     return out, foot
 
 
+def _spline_pole(order):
+    """the single pole of the B-spline prefilter of degree 2 / 3 (scipy ndimage ni_splines.c get_filter_poles)"""
+    if order == 2:
+        return np.sqrt(8.0) - 3.0
+    if order == 3:
+        return np.sqrt(3.0) - 2.0
+    raise ValueError("spline order 2 or 3")
+
+
+def spline_prefilter_axis(a, order, axis):
+    """B-spline coefficients of the samples along one axis with MIRROR boundaries, float64: the recursive filter of
+    ``scipy.ndimage.spline_filter1d`` (ni_splines.c: gain, _init_causal_mirror, the causal / anticausal recursions,
+    _init_anticausal_mirror) - what ``map_coordinates(prefilter=True, mode='constant')`` runs along every axis (for that
+    mode scipy filters with the mirror boundary).  A line of one sample is left alone, like scipy."""
+    a = np.moveaxis(np.array(a, dtype=np.float64, copy=True), axis, 0)
+    n = a.shape[0]
+    if n < 2:
+        return np.moveaxis(a, 0, axis)
+    z = _spline_pole(order)
+    a *= (1.0 - z) * (1.0 - 1.0 / z)
+    z_n_1 = z ** (n - 1)
+    c0 = a[0] + z_n_1 * a[n - 1]
+    z_i = z
+    for i in range(1, n - 1):
+        c0 = c0 + z_i * (a[i] + z_n_1 * a[n - 1 - i])
+        z_i *= z
+    a[0] = c0 / (1.0 - z_n_1 * z_n_1)
+    for i in range(1, n):
+        a[i] += z * a[i - 1]
+    a[n - 1] = (z * a[n - 2] + a[n - 1]) * z / (z * z - 1.0)
+    for i in range(n - 2, -1, -1):
+        a[i] = z * (a[i + 1] - a[i])
+    return np.moveaxis(a, 0, axis)
+
+
+def _spline_weights(x, order):
+    """(first support index, weights) of scipy's get_spline_interpolation_weights for coordinates x"""
+    if order == 3:
+        f = np.floor(x)
+        y = x - f
+        zz = 1.0 - y
+        w1 = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0
+        w2 = (zz * zz * (zz - 2.0) * 3.0 + 4.0) / 6.0
+        w0 = zz * zz * zz / 6.0
+        return f.astype(np.int64) - 1, [w0, w1, w2, 1.0 - w0 - w1 - w2]
+    f = np.floor(x + 0.5)
+    y = x - f
+    w1 = 0.75 - y * y
+    t = 0.5 - y
+    w0 = 0.5 * t * t
+    return f.astype(np.int64) - 1, [w0, w1, 1.0 - w0 - w1]
+
+
+def resample_spline(plane_or_cube, xs, ys, order):
+    """``reproject_interp(order='biquadratic' | 'bicubic')`` (the orders ``BaseSpectralCube.reproject`` documents,
+    spectral_cube.py:2667-2676) for a cube whose channels map onto themselves: reproject's published steps - replicate the
+    border by one pixel, ``scipy.ndimage.map_coordinates(order=2 | 3, mode='constant', cval=nan)`` at coordinates + 1, NaN
+    where a coordinate is outside [-0.5, n - 0.5] - with scipy's spline arithmetic restated: mirror-boundary prefilter along
+    y and x (along z the filter is undone exactly by sampling at integer channels), mirror-folded support indices.
+    A non-finite sample ANYWHERE in the cube makes scipy's recursive prefilter (which runs along z too) return NaN
+    everywhere: so does this.  Pinned against scipy in oracle/gen_golden.py (tests/golden/reproject_spline_scipy.npz).
+    Returns (data, footprint)."""
+    a = np.asarray(plane_or_cube)
+    cube = a if a.ndim == 3 else a[None]
+    nz, ny, nx = cube.shape
+    xs = np.asarray(xs, dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        inside = ((xs >= -0.5) & (xs <= nx - 0.5) & (ys >= -0.5) & (ys <= ny - 0.5))
+    inside &= np.isfinite(xs) & np.isfinite(ys)
+    out = np.full((nz,) + xs.shape, np.nan)
+    if np.isfinite(cube).all():
+        xq, yq = np.where(inside, xs, 0.0) + 1.0, np.where(inside, ys, 0.0) + 1.0
+        ix, wx = _spline_weights(xq, order)
+        iy, wy = _spline_weights(yq, order)
+
+        def fold(i, n):                       # mirror about the first / last sample
+            i = np.abs(i)
+            return np.where(i > n - 1, 2 * (n - 1) - i, i)
+        for k in range(nz):
+            c = np.pad(cube[k].astype(np.float64), 1, mode="edge")
+            c = spline_prefilter_axis(spline_prefilter_axis(c, order, 0), order, 1)
+            v = np.zeros(xs.shape)
+            for j, wyj in enumerate(wy):
+                yy = fold(iy + j, ny + 2)
+                for i, wxi in enumerate(wx):
+                    v = v + wyj * wxi * c[yy, fold(ix + i, nx + 2)]
+            out[k] = np.where(inside, v, np.nan)
+    foot = np.broadcast_to(inside, out.shape).copy()
+    if a.ndim == 2:
+        return out[0], foot[0]
+    return out, foot
+
+
 def reproject_separable(cube, xs, ys, zs=None):
     """Spatial bilinear resample, optionally composed with a linear resample
     along z at fractional channel positions *zs* (trilinear with a separable

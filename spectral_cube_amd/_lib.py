@@ -98,6 +98,7 @@ SIGNATURES = {
     "spc_key_to_f32": (_f, [C.c_uint32]),
     "spc_clip_bounds_f32": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
     "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _P(C.c_double), _i64, _i64, _vp, _vp]),
+    "spc_resample_spline_f32": (_i, [_i, _vp, _P(SpcCube), _i, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz]),
     "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _vp, _sz]),
     "spc_pool_trim": (_i, [_i]),
     "spc_pool_stats": (_i, [_i, _P(C.c_int64), _P(C.c_int64)]),

@@ -567,6 +567,164 @@ __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     A.ys[y * A.nx + x] = fin ? sy : -1e30;
 }
 
+// ---- spline resampling (order 2 / 3): scipy.ndimage.map_coordinates on the edge-padded planes ------------------------
+// reproject_interp(order='biquadratic' | 'bicubic') (the orders BaseSpectralCube.reproject documents, spectral_cube.py:
+// 2667-2676): replicate the border by one pixel, B-spline prefilter with MIRROR boundaries along y and x (scipy filters
+// along z as well; sampled at integer channels that filter is undone exactly), then a 3 x 3 / 4 x 4 gather with
+// mirror-folded support indices.  All float64, like scipy (oracle/oracle_np.py::resample_spline restates the same steps and
+// is pinned against scipy).  The coefficients of a slab of planes live in the caller's workspace as float64.
+struct SplArgs {
+    const float* cube; int64_t nz, ny, nx, row_stride, plane_stride;
+    double* coef;                 // (nz, ny + 2, nx + 2)
+    int order; double pole;
+    int64_t ny_out, nx_out; const double* xs; const double* ys;
+    float* out; int64_t out_row_stride, out_plane_stride;
+    uint8_t* footprint;
+};
+
+// initial value of the causal recursion for a mirror boundary (ni_splines.c::_init_causal_mirror): the sum runs over the
+// whole line in scipy; |pole|^k < 1e-17 beyond 64 terms (|pole| <= 0.268), so the loop stops there and the reflected term
+// pole^(n - 1) only takes part for lines short enough for it to matter
+template <class Get>
+__device__ __forceinline__ double spline_causal_init(Get get, int64_t n, double z) {
+    const bool short_line = n <= 66;
+    const double z_n_1 = short_line ? pow(z, (double)(n - 1)) : 0.0;
+    double c0 = get(0) + z_n_1 * (short_line ? get(n - 1) : 0.0);
+    double z_i = z;
+    const int64_t last = short_line ? n - 1 : 65;
+    for (int64_t i = 1; i < last; ++i) {
+        c0 += z_i * (get(i) + (short_line ? z_n_1 * get(n - 1 - i) : 0.0));
+        z_i *= z;
+    }
+    return c0 / (1.0 - z_n_1 * z_n_1);
+}
+
+// along y: one thread per padded column, rows in sequence (a wave reads / writes 64 consecutive columns of a row)
+__global__ __launch_bounds__(256) void spline_y_kernel(const SplArgs A) {
+    const int64_t xp = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t z = blockIdx.y;
+    const int64_t nyp = A.ny + 2, nxp = A.nx + 2;
+    if (xp >= nxp) return;
+    const int64_t xc = min(max(xp - 1, (int64_t)0), A.nx - 1);
+    const float* src = A.cube + z * A.plane_stride + xc;
+    double* c = A.coef + z * nyp * nxp + xp;
+    const double zp = A.pole, gain = (1.0 - zp) * (1.0 - 1.0 / zp);
+    auto get = [&](int64_t i) { return gain * (double)src[min(max(i - 1, (int64_t)0), A.ny - 1) * A.row_stride]; };
+    double prev = spline_causal_init(get, nyp, zp);
+    c[0] = prev;
+    for (int64_t i = 1; i < nyp; ++i) {
+        prev = get(i) + zp * prev;
+        c[i * nxp] = prev;
+    }
+    double nxt = (zp * c[(nyp - 2) * nxp] + prev) * zp / (zp * zp - 1.0);
+    c[(nyp - 1) * nxp] = nxt;
+    for (int64_t i = nyp - 2; i >= 0; --i) {
+        nxt = zp * (nxt - c[i * nxp]);
+        c[i * nxp] = nxt;
+    }
+}
+
+// along x, in place: a block takes 64 padded rows and walks them in 64-column tiles through LDS (coalesced tile loads, a
+// thread per row inside the tile); the causal carry goes left to right, the anticausal one back
+__global__ __launch_bounds__(64) void spline_x_kernel(const SplArgs A) {
+    __shared__ double tile[64][65];
+    const int t = threadIdx.x;
+    const int64_t nyp = A.ny + 2, nxp = A.nx + 2;
+    const int64_t r0 = (int64_t)blockIdx.x * 64, z = blockIdx.y;
+    double* base = A.coef + z * nyp * nxp;
+    const int64_t nrows = min((int64_t)64, nyp - r0);
+    const double zp = A.pole, gain = (1.0 - zp) * (1.0 - 1.0 / zp);
+    const int64_t myrow = r0 + min((int64_t)t, nrows - 1);
+    double* line = base + myrow * nxp;
+    auto get = [&](int64_t i) { return gain * line[i]; };
+    double carry = spline_causal_init(get, nxp, zp);            // (strided reads of <= 66 samples per row)
+    const int64_t ntile = (nxp + 63) / 64;
+    for (int64_t k = 0; k < ntile; ++k) {
+        const int64_t x0 = k * 64, w = min((int64_t)64, nxp - x0);
+        for (int64_t r = 0; r < nrows; ++r) if (t < w) tile[r][t] = base[(r0 + r) * nxp + x0 + t];
+        __syncthreads();
+        if (t < nrows) {
+            for (int64_t i = 0; i < w; ++i) {
+                carry = (x0 + i == 0) ? carry : gain * tile[t][i] + zp * carry;
+                tile[t][i] = carry;
+            }
+        }
+        __syncthreads();
+        for (int64_t r = 0; r < nrows; ++r) if (t < w) base[(r0 + r) * nxp + x0 + t] = tile[r][t];
+        __syncthreads();
+    }
+    double nxt = 0.0;
+    for (int64_t k = ntile - 1; k >= 0; --k) {
+        const int64_t x0 = k * 64, w = min((int64_t)64, nxp - x0);
+        for (int64_t r = 0; r < nrows; ++r) if (t < w) tile[r][t] = base[(r0 + r) * nxp + x0 + t];
+        __syncthreads();
+        if (t < nrows) {
+            for (int64_t i = w - 1; i >= 0; --i) {
+                if (x0 + i == nxp - 1) nxt = (zp * line[nxp - 2] + tile[t][i]) * zp / (zp * zp - 1.0);
+                else nxt = zp * (nxt - tile[t][i]);
+                tile[t][i] = nxt;
+            }
+        }
+        __syncthreads();
+        for (int64_t r = 0; r < nrows; ++r) if (t < w) base[(r0 + r) * nxp + x0 + t] = tile[r][t];
+        __syncthreads();
+    }
+}
+
+// support start and weights of scipy's get_spline_interpolation_weights
+__device__ __forceinline__ int64_t spline_weights(double x, int order, double* w) {
+    if (order == 3) {
+        const double f = floor(x), y = x - f, zz = 1.0 - y;
+        w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+        w[2] = (zz * zz * (zz - 2.0) * 3.0 + 4.0) / 6.0;
+        w[0] = zz * zz * zz / 6.0;
+        w[3] = 1.0 - w[0] - w[1] - w[2];
+        return (int64_t)f - 1;
+    }
+    const double f = floor(x + 0.5), y = x - f, tt = 0.5 - y;
+    w[1] = 0.75 - y * y;
+    w[0] = 0.5 * tt * tt;
+    w[2] = 1.0 - w[0] - w[1];
+    w[3] = 0.0;
+    return (int64_t)f - 1;
+}
+
+__global__ __launch_bounds__(256) void spline_gather_kernel(const SplArgs A) {
+    const int64_t x = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int64_t y = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= A.nx_out || y >= A.ny_out) return;
+    const double sx = A.xs[y * A.nx_out + x], sy = A.ys[y * A.nx_out + x];
+    const bool inside = sx >= -0.5 && sx <= (double)A.nx - 0.5 && sy >= -0.5 && sy <= (double)A.ny - 0.5;     // false for NaN
+    if (A.footprint && blockIdx.z == 0) A.footprint[y * A.nx_out + x] = inside ? 1 : 0;
+    const float nanf = __int_as_float(0x7fc00000);
+    const int64_t nyp = A.ny + 2, nxp = A.nx + 2;
+    double wx[4], wy[4];
+    int64_t ix[4], iy[4];
+    const int nt = A.order + 1;
+    if (inside) {
+        const int64_t x0 = spline_weights(sx + 1.0, A.order, wx), y0 = spline_weights(sy + 1.0, A.order, wy);
+        for (int k = 0; k < 4; ++k) {                      // mirror about the first / last sample
+            int64_t i = x0 + k; i = i < 0 ? -i : i; ix[k] = min(i > nxp - 1 ? 2 * (nxp - 1) - i : i, nxp - 1);
+            int64_t j = y0 + k; j = j < 0 ? -j : j; iy[k] = min(j > nyp - 1 ? 2 * (nyp - 1) - j : j, nyp - 1);
+        }
+    }
+    for (int64_t z = blockIdx.z; z < A.nz; z += gridDim.z) {
+        float v = nanf;
+        if (inside) {
+            const double* c = A.coef + z * nyp * nxp;
+            double acc = 0.0;
+            for (int j = 0; j < nt; ++j) {
+                const double* row = c + iy[j] * nxp;
+                double r = 0.0;
+                for (int i = 0; i < nt; ++i) r += wx[i] * row[ix[i]];
+                acc += wy[j] * r;
+            }
+            v = (float)acc;
+        }
+        A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -622,6 +780,40 @@ int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs
     }
     hipLaunchKernelGGL(wcs_pixel_map_kernel, dim3((unsigned)((nx_out + 63) / 64), (unsigned)((ny_out + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_resample_spline_f32(int device, void* stream, const spc_cube_f32* cube, int order, int64_t ny_out, int64_t nx_out,
+                            const double* d_xs, const double* d_ys, float* d_out, int64_t out_row_stride,
+                            int64_t out_plane_stride, uint8_t* d_footprint, void* d_workspace, size_t workspace_bytes) {
+    int rc = spc_check_cube(cube);
+    if (rc) return rc;
+    SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
+    SPC_REQUIRE(d_xs && d_ys && d_out, "NULL pointer argument");
+    SPC_REQUIRE(order == 2 || order == 3, "order must be 2 (biquadratic) or 3 (bicubic), got %d", order);
+    SPC_REQUIRE(cube->ny >= 1 && cube->nx >= 1, "empty plane");
+    const size_t need = (size_t)cube->nz * (size_t)(cube->ny + 2) * (size_t)(cube->nx + 2) * sizeof(double);
+    SPC_REQUIRE(d_workspace && workspace_bytes >= need, "workspace too small: %zu bytes, need %zu (nz x (ny + 2) x (nx + 2) float64)",
+                workspace_bytes, need);
+    SPC_REQUIRE((ny_out + 3) / 4 <= 65535 && cube->nz <= 65535, "too many rows / channels for one launch (resample a slab of channels)");
+    SPC_DEVICE(device);
+    SplArgs A{};
+    A.cube = cube->d_data; A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.coef = (double*)d_workspace; A.order = order;
+    A.pole = order == 3 ? sqrt(3.0) - 2.0 : sqrt(8.0) - 3.0;
+    A.ny_out = ny_out; A.nx_out = nx_out; A.xs = d_xs; A.ys = d_ys; A.out = d_out;
+    A.out_row_stride = out_row_stride ? out_row_stride : nx_out;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : ny_out * A.out_row_stride;
+    A.footprint = d_footprint;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(spline_y_kernel, dim3((unsigned)((cube->nx + 2 + 255) / 256), (unsigned)cube->nz), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(spline_x_kernel, dim3((unsigned)((cube->ny + 2 + 63) / 64), (unsigned)cube->nz), dim3(64), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    const unsigned zs = (unsigned)std::min<int64_t>(cube->nz, 64);
+    hipLaunchKernelGGL(spline_gather_kernel, dim3((unsigned)((nx_out + 63) / 64), (unsigned)((ny_out + 3) / 4), zs), dim3(256), 0, st, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }

@@ -1217,9 +1217,9 @@ class SpectralCube:
         2-axis header keeps this cube's spectral axis.  Masked voxels enter as ``fill_value`` when
         ``filled``; the new mask is the footprint; an output without a single non-NaN value raises the
         reference's ValueError."""
-        order = {"nearest-neighbor": 0, "bilinear": 1}.get(order, order)
-        if order not in (0, 1):
-            raise NotImplementedError("order %r: the device resampler does 'bilinear' and 'nearest-neighbor'" % (order,))
+        order = {"nearest-neighbor": 0, "bilinear": 1, "biquadratic": 2, "bicubic": 3}.get(order, order)
+        if order not in (0, 1, 2, 3):
+            raise ValueError("order %r: 'nearest-neighbor' (0), 'bilinear' (1), 'biquadratic' (2) or 'bicubic' (3)" % (order,))
         newwcs = header if isinstance(header, SimpleWCS) else SimpleWCS(header)
         if self._wcs is not None:
             self._wcs._require_celestial()     # (a cube is read with a lenient WCS: keywords it does not model are refused here)
@@ -1240,8 +1240,13 @@ class SpectralCube:
                 zs = None                         # the same channels: a purely spatial reprojection
         elif self._wcs is not None and self._wcs.naxis >= 3:
             newwcs = join_celestial_spectral(newwcs, self._wcs, nz)
-        if zs is not None and (order == 0 or nz < 2):
-            raise NotImplementedError("resampling the spectral axis as well needs order='bilinear' and at least two channels")
+        if zs is not None and (order != 1 or nz < 2):
+            raise NotImplementedError("resampling the spectral axis as well needs order='bilinear' and at least two channels "
+                                      "(spectral_interpolate first, then reproject with order %r)" % (order,))
+        if order >= 2 and self._stream_source() is not None:
+            from . import streaming
+            raise streaming.HugeCubeError("order 'biquadratic' / 'bicubic' of a cube above the HBM budget (SPC_HBM_BUDGET) is not built: "
+                                          "the spline prefilter couples every sample of the cube")
         if os.environ.get("SPC_WCS_HOST_MAP", "0") == "1":         # cross-check: the numpy map (0.8 s per 1024^2 pixels)
             xs, ys = reproject_pixel_map(self._wcs, newwcs, (ny_out, nx_out))
             xs = np.where(np.isfinite(xs), xs, -1e30)
@@ -1277,8 +1282,24 @@ class SpectralCube:
             return out
         mask = self._mask_spec() if filled else None
         flag = DeviceArray((1,), np.uint32, self.device)
-        dev, foot = ops.resample_bilinear(self._device_data(), xs, ys, fill=float(self._fill_value),
-                                          mask=mask, order=order, any_valid=flag)
+        if order >= 2:
+            # scipy's recursive spline prefilter (which reproject_interp runs along all three axes of the NaN-filled cube)
+            # turns ONE non-finite sample into NaN everywhere: the reference then raises "All values ... are nan"
+            src = self._device_data()
+            if mask is not None:
+                src = ops.fill_masked(src, mask, float(self._fill_value))
+            finite = ops.stats_global(src, mask=ops.MaskSpec(_lib.MASK_FINITE))["npts"]
+            if int(finite) != int(np.prod(self._shape, dtype=np.int64)):
+                raise ValueError("All values in reprojected cube are nan.  This can be caused"
+                                 " by an error in which coordinates do not 'round-trip'.  Try "
+                                 "setting ``roundtrip_coords=False``.  You might also check "
+                                 "whether the WCS transformation produces valid pixel->world "
+                                 "and world->pixel coordinates in each axis.")
+            dev, foot = ops.resample_spline(src, xs, ys, order)
+            flag = None
+        else:
+            dev, foot = ops.resample_bilinear(self._device_data(), xs, ys, fill=float(self._fill_value),
+                                              mask=mask, order=order, any_valid=flag)
         footprint = foot.get().astype(bool)
         valid3d = footprint[None]
         if zs is not None:
@@ -1292,6 +1313,8 @@ class SpectralCube:
             if not inside.all():
                 valid3d = footprint[None] & inside[:, None, None]
             nothing = (not inside.any()) or ops.stats_global(dev)["npts"] == 0
+        elif flag is None:
+            nothing = not footprint.any()
         else:
             nothing = int(flag.get()[0]) == 0
         if nothing:

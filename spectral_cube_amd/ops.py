@@ -416,6 +416,44 @@ def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_fo
     return out, foot
 
 
+def resample_spline(cube, xs, ys, order, stream=None, want_footprint=True, out=None, slab_bytes=2 << 30):
+    """biquadratic (order 2) / bicubic (order 3) spatial resample of every channel at (xs, ys): scipy's
+    map_coordinates(order, mode='constant', cval=nan) on the border-replicated planes, the resampler of
+    reproject_interp(order='biquadratic' | 'bicubic') (spectral_cube.py:2667-2676, 2726-2732).  The cube must hold
+    finite samples only (the caller checks: scipy's prefilter makes everything NaN otherwise).  The float64 spline
+    coefficients of a slab of channels at a time live in a scratch buffer of at most *slab_bytes*."""
+    dev = cube.device
+    if order not in (2, 3):
+        raise ValueError("spline order 2 or 3")
+    if isinstance(xs, DeviceArray) and isinstance(ys, DeviceArray):
+        d_xs, d_ys = xs, ys
+        ny_out, nx_out = xs.shape
+    else:
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        ny_out, nx_out = xs.shape
+        d_xs, d_ys = DeviceArray.from_numpy(xs, dev), DeviceArray.from_numpy(ys, dev)
+    nz, ny, nx = cube.shape
+    if out is None:
+        out = DeviceArray((nz, ny_out, nx_out), np.float32, dev)
+    foot = DeviceArray((ny_out, nx_out), np.uint8, dev) if want_footprint else None
+    per_plane = (ny + 2) * (nx + 2) * 8
+    planes = int(max(1, min(nz, slab_bytes // per_plane, 65535)))
+    coef = DeviceArray((planes * per_plane,), np.uint8, dev)
+    for z0 in range(0, nz, planes):
+        z1 = min(nz, z0 + planes)
+        c = _cube_c(cube.planes(z0, z1))
+        _lib.call("spc_resample_spline_f32", dev, _sh(stream), C.byref(c), int(order), ny_out, nx_out, C.c_void_p(d_xs.ptr),
+                  C.c_void_p(d_ys.ptr), C.c_void_p(out.ptr + z0 * ny_out * nx_out * 4), 0, 0,
+                  C.c_void_p(foot.ptr) if (foot is not None and z0 == 0) else None, C.c_void_p(coef.ptr), C.c_size_t(coef.nbytes))
+    if stream is not None:
+        _lib.call("spc_stream_sync", dev, _sh(stream))
+    else:
+        _lib.call("spc_stream_sync", dev, None)          # `coef` goes back to the pool: the kernels must be done with it
+    out._plan = (d_xs, d_ys)
+    return out, foot
+
+
 # ---- statistics (SURVEY.md section 8f rank 1) ----------------------------------------------
 STAT_KEYS = ("count", "min", "max", "sum", "sumsq")
 _STAT_DTYPES = {"count": np.int32, "min": np.float32, "max": np.float32, "sum": np.float64, "sumsq": np.float64}

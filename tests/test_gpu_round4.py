@@ -133,3 +133,61 @@ def test_streamed_write_onto_its_own_source_file(gpu, tmp_path, monkeypatch):
     monkeypatch.delenv("SPC_HBM_BUDGET")
     back = np.asarray(SpectralCube.read(path).unmasked_data)
     assert_close(back, np.where(d > 0.0, d, np.nan).astype(np.float32), what="file written onto itself")
+
+
+@pytest.mark.parametrize("order", [2, 3])
+def test_spline_resample_against_scipy_fixture(gpu, order):
+    """spc_resample_spline_f32 (reproject order 'biquadratic' / 'bicubic') against scipy.ndimage.map_coordinates on the
+    border-replicated cube (tests/golden/reproject_spline_scipy.npz): float32 results of float32 inputs, 1e-5 of the data
+    range; NaN pattern (outside [-0.5, n - 0.5], NaN coordinates) identical; footprint identical"""
+    g = golden("reproject_spline_scipy.npz")
+    for n in range(int(g["n"])):
+        d, xs, ys = g["data%d" % n].astype(np.float32), g["xs%d" % n], g["ys%d" % n]
+        exp, efoot = O.resample_spline(d.astype(np.float64), xs, ys, order)
+        # (the oracle on the float32-rounded samples; the fixture itself - float64 samples - within the rounding of the inputs)
+        out, foot = ops.resample_spline(DeviceArray.from_numpy(d), np.where(np.isnan(xs), -1e30, xs), ys, order)
+        got = out.get()
+        assert_close(got, exp.astype(np.float32), atol=1e-5 * np.abs(d).max(), what="spline order %d case %d" % (order, n))
+        assert_close(got, g["expected%d_%d" % (order, n)].astype(np.float32), atol=2e-5 * np.abs(d).max(), what="vs scipy fixture")
+        assert np.array_equal(foot.get().astype(bool), efoot[0])
+
+
+def test_spline_resample_large_planes_and_slabs(gpu):
+    """planes wider than the causal-init horizon and the 64-column tiles, several slabs of coefficients"""
+    rng = np.random.default_rng(12)
+    nz, ny, nx = 7, 203, 331
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    yy, xx = np.mgrid[0:150, 0:170]
+    xs = 0.9 * xx * nx / 170.0 + 0.31 * np.sin(yy / 9.0) - 0.4
+    ys = 0.95 * yy * ny / 150.0 + 0.27 * np.cos(xx / 7.0) - 0.45
+    for order in (2, 3):
+        exp, _ = O.resample_spline(d.astype(np.float64), xs, ys, order)
+        out, _ = ops.resample_spline(DeviceArray.from_numpy(d), xs, ys, order, slab_bytes=3 * (ny + 2) * (nx + 2) * 8)
+        assert_close(out.get(), exp.astype(np.float32), atol=1e-5 * np.abs(d).max(), what="large spline order %d" % order)
+
+
+def test_reproject_bicubic_and_biquadratic_end_to_end(gpu):
+    """cube.reproject(order='bicubic' | 'biquadratic' | 3 | 2) (spectral_cube.py:2667-2676): values = the oracle's scipy-pinned
+    spline on this package's pixel map; a masked / NaN sample anywhere makes the reference's result all NaN -> its ValueError"""
+    from spectral_cube_amd.wcs import reproject_pixel_map
+    rng = np.random.default_rng(4)
+    nz, ny, nx = 3, 48, 56
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    d = np.stack([np.sin(xx / 5.0) * np.cos(yy / 6.0) + 0.2 * k for k in range(nz)]).astype(np.float32)
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 0.5, "CUNIT3": "km/s",
+           "CRPIX1": 28.0, "CRPIX2": 24.0, "CRPIX3": 1, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": -16.0}
+    c, s_ = np.cos(np.radians(20.0)), np.sin(np.radians(20.0))
+    tgt = dict({k: v for k, v in hdr.items() if not k.endswith("3")}, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c, NAXIS=2, NAXIS1=50, NAXIS2=44)
+    cube = SpectralCube(d, header=hdr)
+    xs, ys = reproject_pixel_map(SimpleWCS(hdr).drop_spectral(), SimpleWCS(tgt, naxis=2), (44, 50))
+    for order, code in (("bicubic", 3), ("biquadratic", 2), (3, 3)):
+        res = cube.reproject(tgt, order=order)
+        exp, foot = O.resample_spline(d.astype(np.float64), xs, ys, code)
+        assert_close(np.asarray(res.filled_data), exp.astype(np.float32), atol=1e-5 * np.abs(d).max(), what="reproject %r" % (order,))
+        assert foot[0].sum() > 800
+    bad = d.copy()
+    bad[1, 10, 10] = np.nan
+    with pytest.raises(ValueError, match="All values in reprojected cube are nan"):
+        SpectralCube.read(bad, hdr).reproject(tgt, order="bicubic")
+    with pytest.raises(ValueError, match="order"):
+        cube.reproject(tgt, order="quintic")
