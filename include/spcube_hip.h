@@ -447,11 +447,13 @@ typedef struct spc_celestial_wcs {
     double sip_b[SPC_SIP_TERMS];   /* (u, v) = pixel - CRPIX; as the TARGET they are evaluated, as the SOURCE they are
                                     * inverted by Newton's method - the limit of astropy's all_world2pix iteration (ABI 4) */
 } spc_celestial_wcs;
-/* frame_rot (HOST pointer, 9 doubles row-major, may be NULL = same frame): rotation of the unit sphere that takes
- * the TARGET's celestial frame to the SOURCE's (ICRS / FK5(equinox) / Galactic: spectral_cube_amd/wcs.py::
- * frame_rotation) - reproject_interp transforms the target's sky coordinates to the source's frame before it
- * asks the source WCS for pixels (the reference's own test goes RA/DEC -> GLON/GLAT, tests/test_regrid.py:99-135).
- * (ABI 3: this argument is new.) */
+/* frame_rot (HOST pointer, 15 doubles, may be NULL = same frame): [0..8] row-major rotation of the unit sphere that
+ * takes the TARGET's celestial frame to the SOURCE's (ICRS / FK5(equinox) / FK4-NO-E(equinox) / Galactic:
+ * spectral_cube_amd/wcs.py::frame_transform) - reproject_interp transforms the target's sky coordinates to the source's
+ * frame before it asks the source WCS for pixels (the reference's own test goes RA/DEC -> GLON/GLAT,
+ * tests/test_regrid.py:99-135); [9..11] the E-terms of aberration removed from the unit vector BEFORE the rotation (an
+ * FK4 target; zeros = none), [12..14] the E-terms added AFTER it (an FK4 source; zeros = none).
+ * (ABI 3: the argument; ABI 4: 15 doubles instead of 9.) */
 int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs_out,
                           const spc_celestial_wcs* wcs_in, const double* frame_rot,
                           int64_t ny_out, int64_t nx_out, double* d_xs, double* d_ys);

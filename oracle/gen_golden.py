@@ -579,6 +579,64 @@ def case_wcs_frames():
     print("wcs_frames ok", names)
 
 
+def case_wcs_fk4():
+    """Pixel maps with FK4 / FK4-NO-E headers (RADESYS, or RA/DEC with EQUINOX < 1984) the way reproject_interp gets them:
+    astropy.wcs for the pixels, astropy.coordinates between the frames (wcs_to_celestial_frame: FK4(equinox=B...), whose
+    epoch of observation defaults to the equinox).  FK4 is not a rotation of the other frames: the E-terms of aberration
+    (0.34 arcsec) are removed / added on its side - 0.17 pixel at the 2 arcsec scale used here."""
+    from astropy.wcs.utils import wcs_to_celestial_frame
+    from astropy.coordinates import SkyCoord
+    # (numpy 1.26 hands np.concatenate a dtype keyword astropy 4.3.1's Quantity dispatch does not know - met by
+    # CartesianRepresentation.norm() in the FK4 transforms; pass it through: an environment shim like those of ref_env/bootstrap.py)
+    from astropy.units.quantity_helper import function_helpers as FH
+    if not getattr(FH, "_spc_concat_patched", False):
+        orig = FH.FUNCTION_HELPERS[np.concatenate]
+
+        def concat(arrays, axis=0, out=None, **kw):
+            args, kwargs, unit, out_ = orig(arrays, axis=axis, out=out)
+            kwargs.update(kw)
+            return args, kwargs, unit, out_
+        FH.FUNCTION_HELPERS[np.concatenate] = concat
+        FH._spc_concat_patched = True
+    store = {}
+    base = {"CRVAL1": 83.6, "CRVAL2": -5.4, "CRPIX1": 20.5, "CRPIX2": 24.5, "CDELT1": -2.0 / 3600, "CDELT2": 2.0 / 3600,
+            "CUNIT1": "deg", "CUNIT2": "deg", "CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN"}
+    gal = dict(base, CTYPE1="GLON-TAN", CTYPE2="GLAT-TAN", CRVAL1=208.99, CRVAL2=-19.38)
+    b50 = dict(base, CRVAL1=82.98, CRVAL2=-5.43)                    # the same field in B1950 coordinates
+    shape = (40, 48)
+    pairs = [
+        (dict(b50, EQUINOX=1950.0), dict(base, RADESYS="ICRS")),                                 # FK4 (by EQUINOX alone) <- ICRS
+        (dict(base, RADESYS="ICRS"), dict(b50, RADESYS="FK4", EQUINOX=1950.0)),                 # ICRS <- FK4
+        (dict(b50, RADESYS="FK4", EQUINOX=1950.0), dict(gal)),                                  # FK4 <- Galactic (IAU 1958 in B1950)
+        (dict(gal), dict(b50, RADESYS="FK4-NO-E", EQUINOX=1950.0)),                             # Galactic <- FK4-NO-E
+        (dict(b50, RADESYS="FK4", EQUINOX=1950.0), dict(base, RADESYS="FK5", EQUINOX=2000.0)),  # FK4 <- FK5
+        (dict(b50, RADESYS="FK4", EQUINOX=1950.0), dict(b50, RADESYS="FK4", EQUINOX=1975.0, CRVAL1=83.29)),   # FK4 <- FK4, Newcomb
+        (dict(b50, RADESYS="FK4-NO-E", EQUINOX=1950.0), dict(b50, RADESYS="FK4", EQUINOX=1950.0)),           # E-terms alone
+        (dict(b50, RADESYS="FK4", EQUINOX=1900.0, CRVAL1=82.36, CRVAL2=-5.47), dict(base, RADESYS="FK5", EQUINOX=1975.0, CRVAL1=83.29)),
+    ]
+    for i, (h_in, h_out) in enumerate(pairs):
+        w_in, w_out = WCS(fits.Header(h_in)), WCS(fits.Header(h_out))
+        yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+        lon, lat = w_out.wcs_pix2world(xx, yy, 0)
+        sky = SkyCoord(lon.ravel() * u.deg, lat.ravel() * u.deg, frame=wcs_to_celestial_frame(w_out))
+        sky = sky.transform_to(wcs_to_celestial_frame(w_in))
+        xs, ys = w_in.wcs_world2pix(sky.spherical.lon.deg.reshape(shape), sky.spherical.lat.deg.reshape(shape), 0)
+        assert np.isfinite(xs).all() and np.abs(xs).max() < 500, (i, np.abs(xs).max())
+        store["in%d" % i] = fits.Header(h_in).tostring(sep="\n")
+        store["out%d" % i] = fits.Header(h_out).tostring(sep="\n")
+        store["xs%d" % i], store["ys%d" % i] = np.asarray(xs, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+        fi, fo = wcs_to_celestial_frame(w_in), wcs_to_celestial_frame(w_out)
+        store["frames%d" % i] = np.array([fi.name, "%r" % getattr(getattr(fi, "equinox", None), "byear", None),
+                                          fo.name, "%r" % getattr(getattr(fo, "equinox", None), "byear", None)])
+    store["n"] = len(pairs)
+    from astropy.coordinates.builtin_frames.fk4 import fk4_e_terms
+    from astropy.time import Time
+    store["eterms_b1950"] = np.array(fk4_e_terms(Time(1950.0, format="byear")))
+    store["eterms_b1900"] = np.array(fk4_e_terms(Time(1900.0, format="byear")))
+    np.savez_compressed(os.path.join(OUT, "wcs_fk4.npz"), **store)
+    print("wcs_fk4 ok", [list(store["frames%d" % i]) for i in range(len(pairs))])
+
+
 def case_wcs_projections():
     """astropy.wcs (wcslib) values for the cylindrical / pseudo-cylindrical projections round 3 added to the minimal WCS
     (SFL, CEA incl. PV2_1, MER, AIT; CAR again with CRVAL2 != 0): all-sky pixel scales so that the curvature shows, pixels
@@ -1090,7 +1148,7 @@ def case_beams_cube():
 
 if __name__ == "__main__":
     cases = [case_beams_cube, case_moment_cube, case_c1, case_adv_argmax, case_smooth, case_interp, case_kernels,
-             case_wcs, case_wcs_frames, case_wcs_projections, case_wcs_strict, case_bilinear_scipy, case_reproject_glue_scipy, case_reproject_spline_scipy, case_statistics, case_fits_files,
+             case_wcs, case_wcs_frames, case_wcs_fk4, case_wcs_projections, case_wcs_strict, case_bilinear_scipy, case_reproject_glue_scipy, case_reproject_spline_scipy, case_statistics, case_fits_files,
              case_order_statistics, case_sigma_clip]
     only = set(sys.argv[1:])                 # e.g. `gen_golden.py case_reproject_glue_scipy` regenerates one fixture
     for fn in cases:

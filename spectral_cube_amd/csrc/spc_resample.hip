@@ -420,7 +420,8 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
 // Same sequence of operations as spectral_cube_amd/wcs.py (celestial_pix2world of the target followed
 // by celestial_world2pix of the source), which is validated against astropy.wcs; on the host this map
 // costs 0.8 s for 1024^2 pixels - a hundred times the resampling kernel it feeds.
-struct WcsPair { spc_celestial_wcs o, i; int64_t ny, nx; double* xs; double* ys; int has_rot; double rot[9]; };
+// has_rot: bit 0 = rotate, bit 1 = remove the E-terms vector et[0..2] before (FK4 target), bit 2 = add et[3..5] after (FK4 source)
+struct WcsPair { spc_celestial_wcs o, i; int64_t ny, nx; double* xs; double* ys; int has_rot; double rot[9]; double et[6]; };
 
 // SIP polynomial sum_{p + q <= n} c[p][q] u^p v^q and its two partial derivatives (Horner in v inside Horner in u;
 // row p of the triangular table starts at p * 10 - p * (p - 1) / 2)
@@ -492,11 +493,28 @@ __global__ __launch_bounds__(256) void wcs_pixel_map_kernel(const WcsPair A) {
     if (lon_deg < 0.0) lon_deg += 360.0;
     lon = lon_deg * D2R;
     lat = (lat * R2D) * D2R;
-    if (A.has_rot) {       // target frame -> source frame: a rotation of the unit vector (wcs.py::reproject_pixel_map)
-        const double cla = cos(lat), vx = cla * cos(lon), vy = cla * sin(lon), vz = sin(lat);
-        const double wx = A.rot[0] * vx + A.rot[1] * vy + A.rot[2] * vz;
-        const double wy = A.rot[3] * vx + A.rot[4] * vy + A.rot[5] * vz;
-        const double wz = A.rot[6] * vx + A.rot[7] * vy + A.rot[8] * vz;
+    if (A.has_rot) {       // target frame -> source frame (wcs.py::frame_transform): a rotation of the unit vector, with the
+                           // E-terms of aberration taken off / put on where a side is FK4
+        const double cla = cos(lat);
+        double vx = cla * cos(lon), vy = cla * sin(lon), vz = sin(lat);
+        if (A.has_rot & 2) {
+            const double dv = A.et[0] * vx + A.et[1] * vy + A.et[2] * vz;
+            const double ax = vx - A.et[0] + dv * vx, ay = vy - A.et[1] + dv * vy, az = vz - A.et[2] + dv * vz;
+            const double n = sqrt(ax * ax + ay * ay + az * az);
+            vx = ax / n; vy = ay / n; vz = az / n;
+        }
+        double wx = A.rot[0] * vx + A.rot[1] * vy + A.rot[2] * vz;
+        double wy = A.rot[3] * vx + A.rot[4] * vy + A.rot[5] * vz;
+        double wz = A.rot[6] * vx + A.rot[7] * vy + A.rot[8] * vz;
+        if (A.has_rot & 4) {
+            const double x0 = wx, y0 = wy, z0 = wz;
+            for (int it = 0; it < 10; ++it) {
+                const double den = 1.0 + A.et[3] * wx + A.et[4] * wy + A.et[5] * wz;
+                wx = (A.et[3] + x0) / den; wy = (A.et[4] + y0) / den; wz = (A.et[5] + z0) / den;
+            }
+            const double n = sqrt(wx * wx + wy * wy + wz * wz);
+            wx /= n; wy /= n; wz /= n;
+        }
         double l2 = fmod(atan2(wy, wx) * R2D, 360.0);
         if (l2 < 0.0) l2 += 360.0;
         lon = l2 * D2R;
@@ -773,10 +791,13 @@ int spc_wcs_pixel_map_f64(int device, void* stream, const spc_celestial_wcs* wcs
                 wcs_in->sip_order <= SPC_SIP_MAX_ORDER, "SIP order must be 0 (none) .. 9");
     SPC_REQUIRE((ny_out + 3) / 4 <= 65535, "too many rows for one launch");
     SPC_DEVICE(device);
-    WcsPair A{*wcs_out, *wcs_in, ny_out, nx_out, d_xs, d_ys, 0, {1, 0, 0, 0, 1, 0, 0, 0, 1}};
-    if (frame_rot) {
+    WcsPair A{*wcs_out, *wcs_in, ny_out, nx_out, d_xs, d_ys, 0, {1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0, 0, 0, 0}};
+    if (frame_rot) {        // ABI 4: 15 doubles - the rotation, the E-terms removed before it, the E-terms added after it
         A.has_rot = 1;
         for (int k = 0; k < 9; ++k) A.rot[k] = frame_rot[k];
+        for (int k = 0; k < 6; ++k) A.et[k] = frame_rot[9 + k];
+        if (A.et[0] != 0.0 || A.et[1] != 0.0 || A.et[2] != 0.0) A.has_rot |= 2;
+        if (A.et[3] != 0.0 || A.et[4] != 0.0 || A.et[5] != 0.0) A.has_rot |= 4;
     }
     hipLaunchKernelGGL(wcs_pixel_map_kernel, dim3((unsigned)((nx_out + 63) / 64), (unsigned)((ny_out + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, A);

@@ -229,7 +229,8 @@ class SpectralCube:
             data = np.asarray(data)
             if data.ndim != 3:
                 raise ValueError("SpectralCube needs a 3-D (spectral, y, x) array")
-            _warn_if_narrowed(dtype=data.dtype)
+            if _data_id is None:              # (once per source: cubes derived from it share its data id)
+                _warn_if_narrowed(dtype=data.dtype)
         self._data = data                 # host ndarray or None
         self._dev = _dev                  # DeviceArray float32 or None
         self._lazy = _lazy                # pending (op, parent, args) - see spectral_smooth
@@ -1259,8 +1260,7 @@ class SpectralCube:
             # planes; the result stays pending until write() / stream_into() (it does not fit the budget either)
             from . import streaming
             if zs is not None:
-                raise streaming.HugeCubeError("resampling the spectral axis of a cube above the HBM budget (SPC_HBM_BUDGET) as well is "
-                                              "not built: reproject onto a celestial header, then spectral_interpolate")
+                return self._reproject_streamed_with_spectral_axis(newwcs, zs, (ny_out, nx_out), order, filled)
             probe = DeviceArray.from_numpy(np.zeros((1,) + tuple(self._shape[1:]), np.float32), self.device)
             _, foot = ops.resample_bilinear(probe, xs, ys, fill=np.nan, order=order)
             footprint = foot.get().astype(bool)
@@ -1325,6 +1325,41 @@ class SpectralCube:
                              "and world->pixel coordinates in each axis.")
         out = self._new_cube_with(dev=dev, wcs=newwcs, mask=False, shape=dev.shape)
         out._mask = M.BooleanArrayMask(valid3d, newwcs, shape=dev.shape)
+        out._footprint = footprint
+        return out
+
+    def _reproject_streamed_with_spectral_axis(self, newwcs, zs, shape_yx, order, filled):
+        """reproject of a cube above the HBM budget onto a CUBE header whose spectral axis differs from this cube's: the
+        reference's one reproject_interp call (spectral_cube.py:2726-2732) resamples all three axes at once; for a separable
+        WCS that is the celestial resampling of every source channel followed by the linear blend of the two resampled
+        planes around every output channel (oracle_np.reproject_separable).  Out of core the two steps run one after the
+        other: source slabs -> resampled planes in a float32 HOST array (nz x ny_out x nx_out: host memory, not HBM), then
+        row strips of that array -> output channels, pending until write() / stream_into() / a reduction."""
+        nz = self._shape[0]
+        ny_out, nx_out = shape_yx
+        celestial = join_celestial_spectral(newwcs, self._wcs, nz)          # the target's sky grid, this cube's channels
+        spatial = self.reproject(celestial, order=order, filled=filled)      # (pending; raises the all-NaN ValueError itself)
+        mid = np.empty((nz, ny_out, nx_out), dtype=np.float32)
+        spatial.stream_into(mid)
+        footprint = spatial._footprint
+        midcube = SpectralCube(mid, wcs=celestial, device=self.device, allow_huge_operations=self.allow_huge_operations)
+        inside = (zs >= -0.5) & (zs <= nz - 0.5)
+        zc = np.clip(np.where(inside, zs, 0.0), 0.0, nz - 1.0)
+        z0 = np.minimum(np.floor(zc).astype(np.int64), nz - 2)
+        lo = np.where(inside, z0, -1).astype(np.int32)
+        t, ones = zc - z0, np.ones(len(zs))
+        if not inside.any():
+            raise ValueError("All values in reprojected cube are nan.  This can be caused"
+                             " by an error in which coordinates do not 'round-trip'.  Try "
+                             "setting ``roundtrip_coords=False``.  You might also check "
+                             "whether the WCS transformation produces valid pixel->world "
+                             "and world->pixel coordinates in each axis.")
+        thunk = _Thunk(lambda: ops.spectral_lerp(midcube._device_data(), lo, t, ones, np.nan))
+        thunk.parent = midcube
+        thunk.strip_fn = lambda dev, mspec, stream: ops.spectral_lerp(dev, lo, t, ones, np.nan, mask=mspec, stream=stream)
+        shape = (len(zs), ny_out, nx_out)
+        out = self._new_cube_with(lazy=thunk, wcs=newwcs, mask=False, shape=shape)
+        out._mask = M.BooleanArrayMask(footprint[None] & inside[:, None, None], newwcs, shape=shape)
         out._footprint = footprint
         return out
 

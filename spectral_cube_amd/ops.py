@@ -374,9 +374,16 @@ def wcs_pixel_map(wcs_in, wcs_out, shape_out, device=0, stream=None):
     d_xs, d_ys = DeviceArray((ny, nx), np.float64, device), DeviceArray((ny, nx), np.float64, device)
     so, si = _wcs_struct(wcs_out), _wcs_struct(wcs_in)
     # target frame -> source frame (ICRS / FK5 / Galactic; NotImplementedError for pairs that are not built; None = same)
-    from .wcs import frame_rotation
-    rot = frame_rotation(getattr(wcs_out, "frame", None), getattr(wcs_in, "frame", None))
-    rp = None if rot is None else (C.c_double * 9)(*np.ascontiguousarray(rot, dtype=np.float64).ravel())
+    # (ABI 4: 15 doubles - rotation, E-terms removed before it (FK4 target), E-terms added after it (FK4 source))
+    from .wcs import frame_transform
+    tr = frame_transform(getattr(wcs_out, "frame", None), getattr(wcs_in, "frame", None))
+    rp = None
+    if tr is not None:
+        remove, rot, add = tr
+        vals = list(np.ascontiguousarray(rot, dtype=np.float64).ravel())
+        vals += list(remove) if remove is not None else [0.0, 0.0, 0.0]
+        vals += list(add) if add is not None else [0.0, 0.0, 0.0]
+        rp = (C.c_double * 15)(*vals)
     _lib.call("spc_wcs_pixel_map_f64", device, _sh(stream), C.byref(so), C.byref(si), rp, ny, nx,
               C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr))
     return d_xs, d_ys

@@ -581,8 +581,8 @@ class SimpleWCS:
 # reproject_interp hands full WCS objects to astropy (spectral_cube.py:2700-2732), which turns the target's
 # pixels into sky coordinates IN THE TARGET'S FRAME, transforms them to the source's frame and only then asks
 # the source WCS for pixels.  The frame of a header follows astropy.wcs.utils.wcs_to_celestial_frame; the
-# transformations between ICRS, FK5(equinox) and Galactic are constant rotations of the unit sphere (restated
-# from their published definitions below); FK4 (Besselian equinoxes: E-terms of aberration) is not built.
+# transformations between ICRS, FK5(equinox), FK4-NO-E(equinox) and Galactic are constant rotations of the unit sphere
+# (restated from their published definitions below); FK4 adds the E-terms of aberration on its side.
 def _celestial_frame(ctype, header):
     """('icrs',) | ('fk5', equinox_jyear) | ('fk4', equinox_byear) | ('galactic',) | ('other', lon, lat)"""
     x, y = str(ctype[0])[:4].upper(), str(ctype[1])[:4].upper()
@@ -635,6 +635,61 @@ _FK5J2000_TO_GAL = (_rot(180.0 - 122.9319185680026, "z") @ _rot(90.0 - 27.128251
                     @ _rot(192.8594812065348, "z"))
 
 
+# ---- FK4 (Besselian equinoxes) ------------------------------------------------------------------------
+# What astropy.coordinates does for RADESYS = 'FK4' / 'FK4-NO-E' (or RA/DEC with EQUINOX < 1984), restated from the
+# published definitions it cites: FK4 carries the elliptic ("E") terms of aberration, a small vector removed from /
+# added to the unit vector (Explanatory Supplement 1992 / Seidelmann; max 0.34 arcsec); without them the frame is
+# related to FK5 J2000 by Standish's (1982) matrix plus Murray's (1989, eq. 29) rotation-rate correction at the
+# epoch of observation (= the equinox for a header, which carries no other), to Galactic by the IAU 1958 pole in
+# B1950, and precessed with Newcomb's angles.
+def _byear_to_jd(byear):
+    return 2415020.31352 + (float(byear) - 1900.0) * 365.242198781         # (ERFA epb2jd)
+
+
+def _precess_newcomb(b1, b2):
+    """precession between two Besselian equinoxes, Newcomb (Explanatory Supplement 1961 / Kinoshita): angles in arcsec"""
+    t1 = (b1 - 1850.0) / 1000.0
+    dt = (b2 - 1850.0) / 1000.0 - t1
+    zeta = np.polyval((17.995, 30.240 - 0.27 * t1, 23035.545 + t1 * 139.720 + 0.060 * t1 * t1, 0.0), dt) / 3600.0
+    z = np.polyval((18.325, 109.480 + 0.39 * t1, 23035.545 + t1 * 139.720 + 0.060 * t1 * t1, 0.0), dt) / 3600.0
+    theta = np.polyval((-41.8, -42.65 - 0.37 * t1, 20051.12 - 85.29 * t1 - 0.37 * t1 * t1, 0.0), dt) / 3600.0
+    return _rot(-z, "z") @ _rot(theta, "y") @ _rot(-zeta, "z")
+
+
+# FK4 (no E-terms) B1950 -> FK5 J2000 (Standish 1982) and its drift per Julian century of the observation epoch (Murray 1989)
+_B1950_TO_J2000 = np.array([[0.9999256794956877, -0.0111814832204662, -0.0048590038153592],
+                            [0.0111814832391717, 0.9999374848933135, -0.0000271625947142],
+                            [0.0048590037723143, -0.0000271702937440, 0.9999881946023742]])
+_FK4_DRIFT = np.array([[-0.0026455262, -1.1539918689, +2.1111346190],
+                       [+1.1540628161, -0.0129042997, +0.0236021478],
+                       [-2.1112979048, -0.0056024448, +0.0102587734]]) * 1.0e-6
+# FK4 (no E-terms) B1950 -> Galactic: IAU 1958 (pole 12h49m, +27.4 deg; longitude of the celestial pole 123 deg)
+_FK4B1950_TO_GAL = _rot(180.0 - 123.0, "z") @ _rot(90.0 - 27.4, "y") @ _rot(192.25, "z")
+
+
+def _fk4_to_fk5j2000(byear):
+    jyear_obs = 2000.0 + (_byear_to_jd(byear) - 2451545.0) / 365.25       # epoch of observation = the equinox
+    return (_B1950_TO_J2000 + _FK4_DRIFT * ((jyear_obs - 1950.0) / 100.0)) @ _precess_newcomb(float(byear), 1950.0)
+
+
+def fk4_e_terms(byear):
+    """the E-terms of aberration vector at a Besselian equinox (constant of aberration 20.49552 arcsec = 0.0056932 deg;
+    eccentricity and longitude of perigee of the solar orbit, obliquity IAU 1980: Explanatory Supplement 1992)"""
+    jd = _byear_to_jd(byear)
+    t50 = (jd - _byear_to_jd(1950.0)) / 36525.0
+    k = np.radians(0.0056932)
+    e = np.polyval((-0.000000126, -0.00004193, 0.01673011), t50)
+    g = np.radians(np.polyval((0.012, 1.65, 6190.67, 1015489.951), t50) / 3600.0)
+    t2k = (jd - 2451545.0) / 36525.0
+    o = np.radians(np.polyval((0.001813, -0.00059, -46.8150, 84381.448), t2k) / 3600.0)
+    return np.array([e * k * np.sin(g), -e * k * np.cos(g) * np.cos(o), -e * k * np.cos(g) * np.sin(o)])
+
+
+def _linear(frame):
+    """the frame without its E-terms (FK4 -> FK4-NO-E at the same equinox)"""
+    return ("fk4-no-e", float(frame[1])) if frame[0] == "fk4" else tuple(frame)
+
+
 def _to_fk5j2000(frame):
     if frame[0] == "icrs":
         return _ICRS_TO_FK5J2000
@@ -642,15 +697,71 @@ def _to_fk5j2000(frame):
         return _FK5J2000_TO_GAL.T
     if frame[0] == "fk5":
         return _precess_from_j2000(2000.0) @ _precess_from_j2000(float(frame[1])).T
-    raise NotImplementedError("celestial frame %r: only ICRS, FK5 and Galactic are related to each other here "
-                              "(FK4 / ecliptic / helioprojective headers reproject only onto their own frame)" % (frame,))
+    if frame[0] == "fk4-no-e":
+        return _fk4_to_fk5j2000(float(frame[1]))
+    raise NotImplementedError("celestial frame %r: ICRS, FK5, FK4, FK4-NO-E and Galactic are related to each other here "
+                              "(ecliptic / helioprojective / unnamed headers reproject only onto their own frame - astropy's "
+                              "wcs_to_celestial_frame knows no others either)" % (frame,))
+
+
+def _linear_rotation(a, b):
+    """3 x 3 matrix between two frames without E-terms, along the route astropy's transformation graph takes"""
+    if a == b:
+        return np.eye(3)
+    if a[0] == "fk4-no-e" and b[0] == "fk4-no-e":
+        return _precess_newcomb(a[1], b[1])
+    if a[0] == "fk4-no-e" and b[0] == "galactic":              # the IAU 1958 definition itself, not via FK5
+        return _FK4B1950_TO_GAL @ _precess_newcomb(a[1], 1950.0)
+    if a[0] == "galactic" and b[0] == "fk4-no-e":
+        return (_FK4B1950_TO_GAL @ _precess_newcomb(b[1], 1950.0)).T
+    if b[0] == "fk4-no-e":
+        # FK5 J2000 -> FK4-NO-E(equinox): Newcomb's precession FROM B1950 (his polynomials are not their own inverse: the
+        # transpose of the matrix TO B1950 differs by microarcseconds), after the transposed Standish / Murray matrix
+        jyear_obs = 2000.0 + (_byear_to_jd(b[1]) - 2451545.0) / 365.25
+        back = _precess_newcomb(1950.0, float(b[1])) @ (_B1950_TO_J2000 + _FK4_DRIFT * ((jyear_obs - 1950.0) / 100.0)).T
+        return back @ _to_fk5j2000(a)
+    return _to_fk5j2000(b).T @ _to_fk5j2000(a)
+
+
+def frame_transform(frame_from, frame_to):
+    """how unit vectors of *frame_from* become unit vectors of *frame_to*: None when the two are the same frame, else
+    (remove, rot, add): subtract the E-terms vector `remove` (v - D + (D.v) v, renormalised; None = no such step), rotate by
+    the 3 x 3 `rot`, add the E-terms `add` (ten fixed-point rounds of v = (D + v0) / (1 + D.v), renormalised; None = no such
+    step) - FK4 on either side brings its step, everything else is a rotation."""
+    if frame_from is None or frame_to is None or tuple(frame_from) == tuple(frame_to):
+        return None
+    a, b = _linear(frame_from), _linear(frame_to)
+    rot = _linear_rotation(a, b)                # NotImplementedError for frames that are not built
+    remove = fk4_e_terms(frame_from[1]) if frame_from[0] == "fk4" else None
+    add = fk4_e_terms(frame_to[1]) if frame_to[0] == "fk4" else None
+    return remove, rot, add
 
 
 def frame_rotation(frame_from, frame_to):
-    """3 x 3 matrix taking unit vectors of *frame_from* to *frame_to*, or None when the two are the same frame"""
-    if frame_from is None or frame_to is None or tuple(frame_from) == tuple(frame_to):
+    """3 x 3 matrix taking unit vectors of *frame_from* to *frame_to* (frames without E-terms), None for the same frame"""
+    tr = frame_transform(frame_from, frame_to)
+    if tr is None:
         return None
-    return _to_fk5j2000(frame_to).T @ _to_fk5j2000(frame_from)
+    if tr[0] is not None or tr[2] is not None:
+        raise ValueError("FK4 frames are not a pure rotation: use frame_transform")
+    return tr[1]
+
+
+def apply_frame_transform(tr, v):
+    """unit vectors v (3, ...) through frame_transform's (remove, rot, add)"""
+    remove, rot, add = tr
+    if remove is not None:
+        d = remove.reshape((3,) + (1,) * (v.ndim - 1))
+        v = v - d + np.sum(d * v, axis=0) * v
+        v = v / np.sqrt(np.sum(v * v, axis=0))
+    v = np.tensordot(rot, v, axes=1)
+    if add is not None:
+        d = add.reshape((3,) + (1,) * (v.ndim - 1))
+        v0 = v
+        for _ in range(10):
+            v = (d + v0) / (1.0 + np.sum(d * v, axis=0))
+        v = v / np.sqrt(np.sum(v * v, axis=0))
+    return v
 
 
 _SPECTRAL_SI = {"m/s": ("speed", 1.0), "km/s": ("speed", 1e3), "cm/s": ("speed", 1e-2),
@@ -754,11 +865,11 @@ def reproject_pixel_map(wcs_in, wcs_out, shape_out):
     ny, nx = shape_out
     yy, xx = np.mgrid[0:ny, 0:nx]
     lon, lat = wcs_out.celestial_pix2world(xx, yy)
-    rot = frame_rotation(wcs_out.frame, wcs_in.frame)         # NotImplementedError for pairs that are not built
-    if rot is not None:
+    tr = frame_transform(wcs_out.frame, wcs_in.frame)         # NotImplementedError for pairs that are not built
+    if tr is not None:
         lo, la = lon * _D2R, lat * _D2R
         v = np.stack([np.cos(la) * np.cos(lo), np.cos(la) * np.sin(lo), np.sin(la)])
-        w = np.tensordot(rot, v, axes=1)
+        w = apply_frame_transform(tr, v)
         lon = np.mod(np.arctan2(w[1], w[0]) * _R2D, 360.0)
         lat = np.arctan2(w[2], np.hypot(w[0], w[1])) * _R2D
     return wcs_in.celestial_world2pix(lon, lat)

@@ -523,11 +523,13 @@ def test_celestial_frame_of_a_header_follows_astropy():
         assert seen[name][0].replace("-", "").replace("noe", "noeterms") == name or seen[name][0] == name, (rec, seen[name])
     icrs = SimpleWCS(base, naxis=2)
     assert icrs.frame == ("icrs",)
-    # FK4 needs the E-terms of aberration: not built, and it must say so instead of equating the frames
-    with pytest.raises(NotImplementedError, match="FK4|fk4"):
+    # FK4 is not a rotation of the other frames (E-terms of aberration): frame_rotation says so, frame_transform carries them
+    # (round 4: built and pinned against astropy, tests/golden/wcs_fk4.npz)
+    from spectral_cube_amd.wcs import frame_transform
+    with pytest.raises(ValueError, match="FK4"):
         frame_rotation(seen["fk4"], icrs.frame)
-    with pytest.raises(NotImplementedError):
-        reproject_pixel_map(SimpleWCS(dict(base, EQUINOX=1950.0), naxis=2), icrs, (4, 4))
+    remove, rot, add = frame_transform(seen["fk4"], icrs.frame)
+    assert remove is not None and add is None and np.allclose(rot @ rot.T, np.eye(3), atol=1e-9)
     ecl = SimpleWCS(dict(base, CTYPE1="ELON-TAN", CTYPE2="ELAT-TAN"), naxis=2)
     with pytest.raises(NotImplementedError):
         reproject_pixel_map(icrs, ecl, (4, 4))
@@ -735,3 +737,19 @@ def test_float64_sources_warn_that_they_are_narrowed():
         with W.catch_warnings():
             W.simplefilter("error", PrecisionWarning)
             SpectralCube(np.zeros((3, 2, 2), dtype=dt), header=hdr)
+
+
+def test_fk4_pixel_maps_against_astropy():
+    """FK4 (B1950 and other Besselian equinoxes, with the E-terms of aberration) and FK4-NO-E
+    headers against ICRS / FK5 / Galactic / each other: astropy.wcs + astropy.coordinates (tests/golden/wcs_fk4.npz,
+    oracle/gen_golden.py::case_wcs_fk4), 1e-9 pixel; the E-terms vector itself to the last digit"""
+    from spectral_cube_amd.wcs import fk4_e_terms
+    g = golden("wcs_fk4.npz")
+    assert np.abs(fk4_e_terms(1950.0) - g["eterms_b1950"]).max() < 1e-20 and np.abs(fk4_e_terms(1900.0) - g["eterms_b1900"]).max() < 1e-20
+    for i in range(int(g["n"])):
+        a, b = SimpleWCS(str(g["in%d" % i]), naxis=2), SimpleWCS(str(g["out%d" % i]), naxis=2)
+        xs, ys = reproject_pixel_map(a, b, g["xs%d" % i].shape)
+        assert np.abs(xs - g["xs%d" % i]).max() <= 1e-9 and np.abs(ys - g["ys%d" % i]).max() <= 1e-9, i
+    # leaving the E-terms out (what equating FK4 with FK4-NO-E would do) is a 0.1 pixel error at this scale
+    a, b = SimpleWCS(str(g["in6"]), naxis=2), SimpleWCS(str(g["out6"]), naxis=2)
+    assert np.abs(g["xs6"] - np.arange(g["xs6"].shape[1])[None, :]).max() > 0.05
