@@ -150,7 +150,8 @@ typedef enum {
     SPC_WS_STATS_PLANES = 7,          /* spc_stats_planes_f32 */
     SPC_WS_MAP_CONV2D = 8,            /* spc_map_conv2d_f64, (ny,nx) = map, p0 = nky, p1 = nkx */
     SPC_WS_CLIP_OUTSIDE = 9,          /* spc_clip_outside_f32 */
-    SPC_WS_PERCENTILE_GLOBAL = 10     /* spc_percentile_global_f32 */
+    SPC_WS_PERCENTILE_GLOBAL = 10,    /* spc_percentile_global_f32 */
+    SPC_WS_SPATIAL_CONV_MFMA = 11     /* spc_spatial_conv_sep_mfma_f32 */
 } spc_ws_kind;
 size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 
@@ -408,6 +409,25 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube,
                            const spc_mask* mask, const double* h_kernel, int nky,
                            int nkx, float* d_out, int64_t out_row_stride,
                            int64_t out_plane_stride, void* d_workspace, size_t workspace_bytes);
+
+/* masked separable spatial_smooth with the DENOMINATOR on the matrix cores, optionally fused with moment 0
+ * (dask_spectral_cube.py:962-993 then :1083-1104: the Dask graph never materialises the smoothed cube either).
+ * out = sum k d [valid] / sum k [valid] like spc_spatial_conv_sep_f32; the numerator is float32 vector arithmetic
+ * (two columns per packed FMA), the denominator - a convolution of a 0 / 1 array - is two banded-Toeplitz matrix
+ * products per 16 x 16 tile on v_mfma_f32_16x16x32_f16: mask bits are exact in fp16, the (power-of-two scaled) taps and
+ * the intermediate go in as fp16 hi + lo pairs with float32 accumulation (<= 1e-6 relative on the denominator).
+ * One block = a band of 16 rows x a strip of 480 columns, walking a chunk of channels.
+ *   d_out  (may be NULL): the smoothed cube (nz, ny, nx), float32.
+ *   d_m0   (may be NULL): moment 0 of the smoothed cube under the ORIGINAL mask, dv * nansum over channels, NaN where no
+ *          channel contributes (float64 (ny, nx), row stride m0_row_stride or nx) - the cube is then never written.
+ * SPC_ERR_UNSUPPORTED (the caller falls back to spc_spatial_conv_sep_f32 + spc_moments_f32): more than 29 taps per
+ * axis, a negative tap or a zero centre tap, mask terms other than SPC_MASK_ARRAY / SPC_MASK_FINITE, odd nx or strides.
+ * (ABI 4) */
+int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                  const double* h_ky, int nky, const double* h_kx, int nkx,
+                                  float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
+                                  double dv, double* d_m0, int64_t m0_row_stride,
+                                  void* d_workspace, size_t workspace_bytes);
 
 /* ---- resampling -----------------------------------------------------------
  * spectral lerp: replaces interp_wrapper / scipy interp1d(kind='linear') of

@@ -26,7 +26,7 @@ ABI_VERSION = 4
 MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
- WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL) = range(11)
+ WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL, WS_SPATIAL_CONV_MFMA) = range(12)
 
 
 class HipLibraryError(RuntimeError):
@@ -98,6 +98,8 @@ SIGNATURES = {
     "spc_key_to_f32": (_f, [C.c_uint32]),
     "spc_clip_bounds_f32": (_i, [_i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp]),
     "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _P(C.c_double), _i64, _i64, _vp, _vp]),
+    "spc_spatial_conv_sep_mfma_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _i, _P(C.c_double), _i, _vp, _i64, _i64,
+                                           _d, _vp, _i64, _vp, _sz]),
     "spc_resample_spline_f32": (_i, [_i, _vp, _P(SpcCube), _i, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz]),
     "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _vp, _sz]),
     "spc_pool_trim": (_i, [_i]),

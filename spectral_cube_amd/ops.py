@@ -423,6 +423,31 @@ def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_fo
     return out, foot
 
 
+def spatial_conv_mfma(cube, kernel2d, mask=None, stream=None, out=None, want_cube=True, want_m0=False, dv=1.0, m0=None):
+    """masked separable spatial_smooth with the denominator on the matrix cores (spc_spatial_conv_sep_mfma_f32), optionally
+    fused with moment 0 of the smoothed cube under the ORIGINAL mask (the cube is then never written when want_cube is
+    False).  Returns (smoothed cube or None, m0 map float64 or None).  HipUnsupported: kernels of more than 29 taps per axis,
+    non-separable or negative kernels, mask terms other than the array / isfinite - the caller falls back to spatial_conv
+    (+ moments)."""
+    k = np.asarray(kernel2d, dtype=np.float64)
+    fac = separable_factors(k)
+    if fac is None:
+        raise _lib.HipUnsupported("spatial_conv_mfma: the kernel is not an outer product")
+    ky, kx = (np.ascontiguousarray(f, dtype=np.float64) for f in fac)
+    dev = cube.device
+    nz, ny, nx = cube.shape
+    if want_cube and out is None:
+        out = DeviceArray((nz, ny, nx), np.float32, dev)
+    if want_m0 and m0 is None:
+        m0 = DeviceArray((ny, nx), np.float64, dev)
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    ws, wsn = workspace(dev, stream, _lib.WS_SPATIAL_CONV_MFMA, nz, ny, nx)
+    _lib.call("spc_spatial_conv_sep_mfma_f32", dev, _sh(stream), C.byref(c), C.byref(m),
+              ky.ctypes.data_as(C.POINTER(C.c_double)), len(ky), kx.ctypes.data_as(C.POINTER(C.c_double)), len(kx),
+              C.c_void_p(out.ptr) if want_cube else None, 0, 0, float(dv), C.c_void_p(m0.ptr) if want_m0 else None, 0, ws, wsn)
+    return (out if want_cube else None), (m0 if want_m0 else None)
+
+
 def resample_spline(cube, xs, ys, order, stream=None, want_footprint=True, out=None, slab_bytes=2 << 30):
     """biquadratic (order 2) / bicubic (order 3) spatial resample of every channel at (xs, ys): scipy's
     map_coordinates(order, mode='constant', cval=nan) on the border-replicated planes, the resampler of

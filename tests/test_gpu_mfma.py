@@ -1,0 +1,78 @@
+"""GPU: masked separable spatial_smooth with the denominator on the matrix cores, fused with moment 0
+(spc_spatial_conv_sep_mfma_f32).  Oracle: oracle_np.spatial_smooth (astropy semantics, float64) and its nansum."""
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close
+from spectral_cube_amd import Gaussian2DKernel, _lib, ops
+from spectral_cube_amd.device import DeviceArray
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(shape, seed, valid=0.8, nan_frac=0.0):
+    rng = np.random.default_rng(seed)
+    d = (rng.standard_normal(shape) + 2.0).astype(np.float32)
+    m = (rng.random(shape) < valid)
+    if nan_frac:
+        d[rng.random(shape) < nan_frac] = np.nan
+    return d, m
+
+
+@pytest.mark.parametrize("shape, fwhm, valid", [((3, 40, 64), 8.0, 0.8), ((5, 33, 130), 8.0, 0.5), ((2, 70, 962), 8.0, 0.05),
+                                                 ((4, 16, 480), 4.0, 0.9), ((3, 50, 1000), 8.0, 1.0)])
+def test_mfma_smoothed_cube_against_the_oracle(gpu, shape, fwhm, valid):
+    """the smoothed cube itself (d_out): 1e-5 of the data range, NaN pattern identical; includes partial strips, bands
+    that cross both plane edges, a sparse mask (windows with ONE valid far-tail sample: the fp16 hi/lo denominator must
+    hold 1e-6 there) and an all-valid mask array"""
+    d, m = _case(shape, 3)
+    k2 = Gaussian2DKernel(fwhm / 2.3548200450309493).array
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    out, _ = ops.spatial_conv_mfma(cube, k2, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk))
+    exp = O.spatial_smooth(d, m, k2)
+    assert_close(out.get(), exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="mfma smooth %s" % (shape,))
+
+
+def test_mfma_fused_moment0_against_the_oracle(gpu):
+    """d_m0 without d_out: dv * nansum over channels of the smoothed cube under the ORIGINAL mask; all-masked spaxels NaN;
+    NaN samples under a true mask bit are interpolated over by the convolution AND counted by the (array-only) mask"""
+    shape = (37, 45, 530)
+    d, m = _case(shape, 9, valid=0.7, nan_frac=0.01)
+    m[:, 3:6, 10:14] = False
+    k2 = Gaussian2DKernel(8 / 2.3548200450309493).array
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    for flags, inc in ((_lib.MASK_ARRAY, m), (_lib.MASK_ARRAY | _lib.MASK_FINITE, m & np.isfinite(d))):
+        _, m0 = ops.spatial_conv_mfma(cube, k2, mask=ops.MaskSpec(flags, array=mk), want_cube=False, want_m0=True, dv=500.0)
+        sm = O.spatial_smooth(d, m, k2)                      # (NaN samples are invalid for the convolution either way)
+        filled = np.where(inc, sm, np.nan)
+        exp = 500.0 * np.nansum(filled, axis=0)
+        exp[np.all(np.isnan(filled), axis=0)] = np.nan
+        assert np.isnan(exp).sum() >= 12
+        assert_close(m0.get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="mfma moment0 flags %d" % flags)
+
+
+def test_mfma_many_channels_several_chunks(gpu):
+    """more channels than a chunk holds: float32 sums inside a chunk, float64 across chunks"""
+    shape = (150, 16, 96)
+    d, m = _case(shape, 5, valid=0.6)
+    k2 = Gaussian2DKernel(2.0).array                         # 17 taps: padded to the 29-tap ring
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    out, m0 = ops.spatial_conv_mfma(cube, k2, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk), want_cube=True, want_m0=True, dv=2.0)
+    sm = O.spatial_smooth(d, m, k2)
+    assert_close(out.get(), sm.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(sm)), what="mfma smooth 17 taps")
+    exp = 2.0 * np.nansum(np.where(m, sm, np.nan), axis=0)
+    assert_close(m0.get(), exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="mfma moment0 chunks")
+
+
+def test_mfma_refuses_what_it_does_not_do(gpu):
+    d, m = _case((2, 16, 32), 1)
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=mk)
+    with pytest.raises(_lib.HipUnsupported):
+        ops.spatial_conv_mfma(cube, Gaussian2DKernel(5.0).array, mask=spec)                  # 41 taps
+    with pytest.raises(_lib.HipUnsupported):
+        ops.spatial_conv_mfma(cube, Gaussian2DKernel(2.0).array, mask=ops.MaskSpec(_lib.MASK_ARRAY | _lib.MASK_GT, 0.5, 0.0, mk))
+    neg = np.outer([-0.1, 1.0, -0.1], [0.2, 1.0, 0.2])
+    with pytest.raises(_lib.HipUnsupported):
+        ops.spatial_conv_mfma(cube, neg, mask=spec)
