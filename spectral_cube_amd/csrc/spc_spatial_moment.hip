@@ -98,8 +98,14 @@ __device__ __forceinline__ void split4(f32x4 q, u32x2& hi, u32x2& lo) {
     lo = u32x2{__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
 }
 
-template <bool ARR, bool STORE, bool MOM>
+// ISOSYM: kx == ky and symmetric taps (every Gaussian2DKernel with one stddev): both passes read the SAME scalar weights,
+// addressed folded - k[min(j, 2H - j)], 15 distinct values = 8 SGPR pairs.  With two unfolded sets (60 SGPRs of weights)
+// the kernel spilled ~700 scalar registers, and every spill is a VALU v_readlane / v_writelane.
+// FIN: the mask keeps finite samples only (isfinite): "included by the mask" and "valid for the convolution" are then the
+// same bit; without it a NaN under a true mask bit is interpolated over by the convolution but still summed by the moment
+template <bool ARR, bool STORE, bool MOM, bool ISOSYM, bool FIN>
 __global__ __launch_bounds__(kThreads, 2) void spatial_sep_mfma_kernel(const SmArgs A) {
+    auto wj = [](int j) { return ISOSYM ? (j <= H ? j : 2 * H - j) : j; };
     __shared__ float2v ybuf[2][4][kPitch2];                   // the band's 16 finished y-pass rows as 8 row pairs (36 KB)
     __shared__ float den[kBand * kDenPitch];                  // (31 KB)
     __shared__ __attribute__((aligned(16))) unsigned char cbits[(kBitGroups + 1) * kCols]; // conv-validity bits, byte = 8 rows of one column (+ a spill row)
@@ -170,15 +176,22 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_sep_mfma_kernel(const SmA
 
     float2v v[2][8];
     unsigned mk[2][8];
+    // Loads go through one buffer descriptor per plane: lane byte offset in a VGPR, row byte offset in an SGPR that is
+    // recomputed where it is used.  With plain pointers the compiler hoisted the 2 x 44 loop-invariant 64-bit row addresses
+    // out of the channel loop and spilled ~600 scalar registers (every spill a VALU v_readlane / v_writelane).
+    const int voff = (int)(xc * 4), moff = (int)xc;
+    const unsigned rbytes = (unsigned)(A.row_stride * 4), mrbytes = (unsigned)A.mrow_stride;
     auto fetch = [&](int slot, int64_t z, int g) {            // rows 8 g .. 8 g + 7 of the band's 44 input rows
-        const float* p = A.cube + z * A.plane_stride + xc;
-        const uint8_t* pm = ARR ? A.marr + z * A.mplane_stride + xc : nullptr;
+        const auto rs = spc_plane_srd(A.cube + z * A.plane_stride);
+        const auto rm = spc_plane_srd(ARR ? (const void*)(A.marr + z * A.mplane_stride) : (const void*)A.cube);
+        int ybase = y0 - H + 8 * g;
+        asm volatile("" : "+s"(ybase));                       // opaque: the row offsets below are not loop invariants
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             if (8 * g + s < kInRows) {
-                const int64_t ic = min(max(y0 - H + 8 * g + s, 0), ny - 1);
-                v[slot][s] = __builtin_nontemporal_load(reinterpret_cast<const float2v*>(p + ic * A.row_stride));
-                if (ARR) mk[slot][s] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(pm + ic * A.mrow_stride));
+                const int ic = min(max(ybase + s, 0), ny - 1);
+                v[slot][s] = __builtin_bit_cast(float2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (int)((unsigned)ic * rbytes), 0));
+                if (ARR) mk[slot][s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rm, moff, (int)((unsigned)ic * mrbytes), 0);
             }
         }
     };
@@ -191,32 +204,48 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_sep_mfma_kernel(const SmA
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
             if (g + 1 < 6) fetch((g + 1) & 1, z, g + 1);      // the next group is in flight during this group's FMAs
-            unsigned cb0 = 0, cb1 = 0, ib0 = 0, ib1 = 0;
+            unsigned cb = 0, ib = 0;                          // bits 0-7: column 2t, bits 8-15: column 2t + 1
+            int yrow0 = y0 - H + 8 * g;
+            asm volatile("" : "+s"(yrow0));                   // (opaque: 44 row-in-bounds masks are not hoisted into SGPRs)
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) {
                 const int s = 8 * g + s8;
                 if (s < kInRows) {
                     const float2v d = v[g & 1][s8];
-                    bool m0 = true, m1 = true;
-                    if (ARR) { m0 = (mk[g & 1][s8] & 0xffu) != 0; m1 = (mk[g & 1][s8] & 0xff00u) != 0; }
-                    // include = the cube's mask on its own voxel (array term and, under isfinite, |v| <= FLT_MAX);
-                    // conv-valid = include and not NaN (astropy interpolates over NaN whatever the mask says)
-                    bool i0 = m0 && (A.lim == INFINITY || __builtin_fabsf(d.x) <= A.lim);
-                    bool i1 = m1 && (A.lim == INFINITY || __builtin_fabsf(d.y) <= A.lim);
-                    bool ok0 = m0 && __builtin_fabsf(d.x) <= A.lim, ok1 = m1 && __builtin_fabsf(d.y) <= A.lim;
-                    if (edge_cols || edge_rows) {            // out of bounds = a valid zero that is not a voxel
-                        const bool in = col_in && (y0 - H + s >= 0) && (y0 - H + s < ny);
-                        if (!in) { ok0 = ok1 = true; i0 = i1 = false; }
+                    // branch-free: bitwise & on the compare results (&& / || became 88 divergent branches per channel)
+                    bool ok0 = __builtin_fabsf(d.x) <= A.lim, ok1 = __builtin_fabsf(d.y) <= A.lim;     // false for NaN
+                    bool i0 = true, i1 = true;
+                    if (ARR) {
+                        const bool m0 = (mk[g & 1][s8] & 0xffu) != 0, m1 = mk[g & 1][s8] > 0xffu;
+                        ok0 = ok0 & m0; ok1 = ok1 & m1;
+                        i0 = m0; i1 = m1;
                     }
-                    float2v dm = float2v{ok0 ? d.x : 0.f, ok1 ? d.y : 0.f};
-                    if ((edge_cols || edge_rows) && !(col_in && (y0 - H + s >= 0) && (y0 - H + s < ny))) dm = float2v{0.f, 0.f};
-                    cb0 |= (ok0 ? 1u : 0u) << s8; cb1 |= (ok1 ? 1u : 0u) << s8;
-                    ib0 |= (i0 ? 1u : 0u) << s8; ib1 |= (i1 ? 1u : 0u) << s8;
+                    if (edge_cols || edge_rows) {            // out of bounds = a valid zero that is not a voxel (block-uniform branch)
+                        const bool row_in = (unsigned)(yrow0 + s8) < (unsigned)ny;          // uniform
+                        const bool in = col_in & row_in;
+                        ok0 = in ? ok0 : true; ok1 = in ? ok1 : true;
+                        i0 = i0 & in; i1 = i1 & in;
+                        const float2v dz = float2v{in ? d.x : 0.f, in ? d.y : 0.f};
+                        const float2v dm_e = float2v{ok0 ? dz.x : 0.f, ok1 ? dz.y : 0.f};
+                        cb |= (ok0 ? (1u << s8) : 0u) | (ok1 ? (256u << s8) : 0u);
+                        if (!FIN) ib |= (i0 ? (1u << s8) : 0u) | (i1 ? (256u << s8) : 0u);
+                        else ib |= ((ok0 & in) ? (1u << s8) : 0u) | ((ok1 & in) ? (256u << s8) : 0u);
 #pragma unroll
-                    for (int o = 0; o < kBand; ++o) {
-                        const int a = s - o;              // tap distance: weight ky[2H - a]
-                        if (a == 0) pk_mul_w(acc[o], A.ky, 2 * H, dm);
-                        else if (a > 0 && a <= 2 * H) pk_fma_w(acc[o], A.ky, 2 * H - a, dm);
+                        for (int o = 0; o < kBand; ++o) {
+                            const int a = s - o;
+                            if (a == 0) pk_mul_w(acc[o], A.ky, wj(2 * H), dm_e);
+                            else if (a > 0 && a <= 2 * H) pk_fma_w(acc[o], A.ky, wj(2 * H - a), dm_e);
+                        }
+                    } else {
+                        const float2v dm = float2v{ok0 ? d.x : 0.f, ok1 ? d.y : 0.f};
+                        cb |= (ok0 ? (1u << s8) : 0u) | (ok1 ? (256u << s8) : 0u);
+                        if (!FIN) ib |= (i0 ? (1u << s8) : 0u) | (i1 ? (256u << s8) : 0u);
+#pragma unroll
+                        for (int o = 0; o < kBand; ++o) {
+                            const int a = s - o;              // tap distance: weight ky[2H - a]
+                            if (a == 0) pk_mul_w(acc[o], A.ky, wj(2 * H), dm);
+                            else if (a > 0 && a <= 2 * H) pk_fma_w(acc[o], A.ky, wj(2 * H - a), dm);
+                        }
                     }
                     if (s >= 2 * H) {                        // output row o = s - 2H is complete
                         const int o = s - 2 * H;
@@ -229,8 +258,10 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_sep_mfma_kernel(const SmA
                     }
                 }
             }
-            *reinterpret_cast<unsigned short*>(&cbits[g * kCols + c0]) = (unsigned short)(cb0 | (cb1 << 8));
-            *reinterpret_cast<unsigned short*>(&ibits[g * kCols + c0]) = (unsigned short)(ib0 | (ib1 << 8));
+            *reinterpret_cast<unsigned short*>(&cbits[g * kCols + c0]) = (unsigned short)cb;
+            // the bits the moment sums over: in an edge block "valid zero" samples are not voxels; under FIN they are the
+            // conv-valid bits otherwise
+            if (MOM && (!FIN || edge_cols || edge_rows)) *reinterpret_cast<unsigned short*>(&ibits[g * kCols + c0]) = (unsigned short)ib;
         }
         lds_barrier();
         if (z + 1 < z_end) fetch(0, z + 1, 0);                // next channel's first rows: in flight during the rest
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_sep_mfma_kernel(const SmA
 #pragma unroll
                             for (int k = 0; k < kRun; ++k) {
                                 const int widx = k + 2 * H - i;
-                                if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], A.kx, widx, in[b & 1][i4]);
+                                if (widx >= 0 && widx <= 2 * H) pk_fma_w(r[k], ISOSYM ? A.ky : A.kx, wj(widx), in[b & 1][i4]);
                             }
                         }
                     }
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_sep_mfma_kernel(const SmA
                     // include bits of the 16 outputs: rows oa, ob have their centre samples at input rows oa + 14, ob + 14
                     // (one byte group: oa is even), columns 8 j + 14 .. 8 j + 21
                     const int sc = oa + H;
-                    const unsigned char* ip = &ibits[(sc >> 3) * kCols + kRun * j + 8];
+                    const unsigned char* ip = ((!FIN || edge_cols || edge_rows) ? ibits : cbits) + (sc >> 3) * kCols + kRun * j + 8;
                     const unsigned long long lo8 = *reinterpret_cast<const unsigned long long*>(ip);
                     const unsigned long long hi8 = *reinterpret_cast<const unsigned long long*>(ip + 8);
                     const unsigned long long w = (lo8 >> 48) | (hi8 << 16);       // byte k = input column 8 j + 14 + k
@@ -400,6 +431,317 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_sep_mfma_kernel(const SmA
     }
 }
 
+// =====================================================================================================================
+// Second form (round 4, measured against the first: profiles/r04_masked_spatial_mfma.log): BOTH convolutions on the matrix
+// pipe.  The first form keeps the numerator on the vector ALU and, counted by SQ_INSTS_VALU, issues as many vector
+// instructions as the ring kernel it was to beat: what the matrix pipe takes off (29 of 58 FMA slots per voxel) the band
+// structure puts back (classification of 44 input rows per 16 output rows, the feed of the matrix products, the epilogue).
+// Here the vector ALU only classifies, converts and divides:
+//
+//   numerator    Y^T = DM^T . Ty^T, Out^T = Tx . Y^T   on v_mfma_f32_16x16x4_f32 (float32 in, float32 accumulate: the same
+//                arithmetic as the vector FMA chain, at the same rate, on the OTHER pipe)
+//   denominator  as above, fp16 hi + lo on v_mfma_f32_16x16x32_f16
+//
+// A wave owns 32 output rows x 128 output columns and walks a chunk of channels; the waves of a block do not talk to each
+// other (no LDS staging, no barriers in the channel loop).  Per channel it visits the 10 input column tiles (16 columns)
+// of its region: lane (m = lane & 15, g = lane >> 4) loads column m, rows 4 i + g (i = 0 .. 14) - exactly the A operand
+// of the first product; the C layout of every first product (lane: output row n, input columns 4 g + r) is the B layout
+// of the second, and numerator and denominator of an output tile end up in the same lane and register (output row n,
+// output columns 4 g + r): the division and the moment sums need no exchange either.
+struct Sm2Args {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    const uint8_t* marr;                      // uint8 mask array with the cube's strides, or nullptr
+    float* out;
+    int64_t out_row_stride, out_plane_stride;
+    float* partial;
+    unsigned char* seen;
+    int nstrips, nbands, zchunk, nchunk;
+    float lim, sy, sx, scale;                 // scale = sy * sx (den_true = D / scale)
+    float ky[R + 3], kx[R + 3];
+};
+
+constexpr int k2Rows = 32, k2ColsW = 128, k2Tiles = k2ColsW / 16, k2InTiles = k2Tiles + 2, k2Steps = 15;
+
+template <bool ARR, bool STORE, bool MOM, bool FIN>
+__global__ __launch_bounds__(kThreads, 2) void spatial_mfma2_kernel(const Sm2Args A) {
+    __shared__ u32x2 lut[16];
+    __shared__ float taps[2][32];                             // scaled taps (denominator)
+    __shared__ float rawt[2][32];                             // the taps as they are (numerator)
+    __shared__ half8 dconst[4 * 2 * 64];                      // fp16 operands of the denominator products: [tyB hi, tyB lo, txA hi, txA lo][step][lane] (8 KB)
+    __shared__ f32x4 msum_lds[MOM ? kThreads / 64 * 2 * k2Tiles * 64 : 1];     // (64 KB with the moment)
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ln = lane & 15, lg = lane >> 4;
+    // (chunk, strip, band): contiguous work items per XCD, the band running fastest
+    int chunk, strip, band;
+    {
+        const int64_t n = (int64_t)gridDim.x, b = blockIdx.x;
+        const int64_t q = n / 8, r = n % 8, xcd = b % 8, i = b / 8;
+        const int64_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        band = (int)(w % A.nbands);
+        strip = (int)((w / A.nbands) % A.nstrips);
+        chunk = (int)(w / ((int64_t)A.nbands * A.nstrips));
+    }
+    const int ny = (int)A.ny, nx = (int)A.nx;
+    const int y0 = band * k2Rows;
+    const int xw = strip * (4 * k2ColsW) + wave * k2ColsW;    // first output column of this wave
+    if (t < 16) {
+        const unsigned a = ((t & 1) ? 0x3C00u : 0u) | ((t & 2) ? 0x3C000000u : 0u);
+        const unsigned b = ((t & 4) ? 0x3C00u : 0u) | ((t & 8) ? 0x3C000000u : 0u);
+        lut[t] = u32x2{a, b};
+    }
+    if (t < 32) {
+        taps[0][t] = t < R ? A.ky[t] * A.sy : 0.f; taps[1][t] = t < R ? A.kx[t] * A.sx : 0.f;
+        rawt[0][t] = t < R ? A.ky[t] : 0.f; rawt[1][t] = t < R ? A.kx[t] : 0.f;
+    }
+    __syncthreads();
+    const int z_begin = chunk * A.zchunk, z_end = (int)min((int64_t)z_begin + A.zchunk, A.nz);
+
+    // ---- constant operands of this lane
+    // first product B: step i' (0..10), k = lg: input row rho = 4 i' + lg (relative to the row tile), weight ky[n + 28 - rho]
+    float tyB[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int j = ln + 2 * H - (4 * i + lg);
+        tyB[i] = (j >= 0 && j <= 2 * H) ? rawt[0][j] : 0.f;
+    }
+    // second product A: step (tau, r), k = lg: input column kc = 16 tau + 4 lg + r relative to the output tile, weight kx[m + 28 - kc]
+    float txA[12];
+#pragma unroll
+    for (int st = 0; st < 12; ++st) {
+        const int j = ln + 2 * H - (16 * (st >> 2) + 4 * lg + (st & 3));
+        txA[st] = (j >= 0 && j <= 2 * H) ? rawt[1][j] : 0.f;
+    }
+    // denominator, first product B (fp16 hi / lo): step s, slot e <-> i' = 8 s + e, rho = 4 i' + lg
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        half8 tyBh, tyBl, txAh, txAl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ip = 8 * s + e;
+            const int jy = ln + 2 * H - (4 * ip + lg);
+            const float wy = (ip < 11 && jy >= 0 && jy <= 2 * H) ? taps[0][jy] : 0.f;
+            const _Float16 hy = (_Float16)wy;
+            tyBh[e] = hy; tyBl[e] = (_Float16)(wy - (float)hy);
+            // second product A: step 0: slots 0-3 <-> (tau 0, r = e), 4-7 <-> (tau 1, r = e - 4); step 1: slots 0-3 <-> (tau 2, r = e), 4-7 empty
+            const int tau = 2 * s + (e >> 2), r = e & 3;
+            const int jx = ln + 2 * H - (16 * tau + 4 * lg + r);
+            const float wx = (tau < 3 && jx >= 0 && jx <= 2 * H) ? taps[1][jx] : 0.f;
+            const _Float16 hx = (_Float16)wx;
+            txAh[e] = hx; txAl[e] = (_Float16)(wx - (float)hx);
+        }
+        if (wave == 0) {                                      // (the operands depend on the lane, not on the wave)
+            dconst[(0 * 2 + s) * 64 + lane] = tyBh; dconst[(1 * 2 + s) * 64 + lane] = tyBl;
+            dconst[(2 * 2 + s) * 64 + lane] = txAh; dconst[(3 * 2 + s) * 64 + lane] = txAl;
+        }
+    }
+
+    __syncthreads();
+    if (xw >= nx) return;                                     // (no barrier below: a whole wave may leave)
+    // ---- addresses: per-lane byte offsets of this lane's 15 input rows at input tile 0 (rows clamped into the plane)
+    unsigned rowoff[k2Steps];
+    unsigned rowin = 0;                                        // bit i: row 4 i + lg of the region lies inside the plane
+    const int col0 = xw - H + ln;                              // this lane's column in input tile 0
+#pragma unroll
+    for (int i = 0; i < k2Steps; ++i) {
+        const int yr = y0 - H + 4 * i + lg;
+        rowin |= ((yr >= 0 && yr < ny) ? 1u : 0u) << i;
+        rowoff[i] = (unsigned)(min(max(yr, 0), ny - 1) * (int)A.row_stride) * 4u;
+    }
+    const bool rows_inside = (y0 - H >= 0) && (y0 - H + 60 <= ny);   // uniform
+    // epilogue positions: output row y0 + 16 b + ln, columns xw + 16 a + 4 lg + r
+    unsigned eoff[2];
+    bool erow[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int yo = y0 + 16 * b + ln;
+        erow[b] = yo < ny;
+        eoff[b] = (unsigned)(min(yo, ny - 1) * (int)A.row_stride + xw + 4 * lg) * 4u;
+    }
+
+    // moment sums of the wave's 2 x 8 output tiles: in LDS (16 KB per wave) so that the loop over the input tiles stays a
+    // loop - with the sums in registers (64 of them, statically indexed) the tile loop had to be unrolled ten times and
+    // the kernel spilled 350 vector and 300 scalar registers
+    f32x4* macc = msum_lds + (wave * 2 * k2Tiles) * 64 + lane;
+    unsigned mseen[2] = {0u, 0u};
+    if (MOM) {
+#pragma unroll
+        for (int i = 0; i < 2 * k2Tiles; ++i) macc[i * 64] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int z = z_begin; z < z_end; ++z) {
+        const auto rs = spc_plane_srd(A.cube + (int64_t)z * A.plane_stride);
+        const auto rm = spc_plane_srd(ARR ? (const void*)(A.marr + (int64_t)z * A.plane_stride) : (const void*)A.cube);
+        float raw[k2Steps];
+        unsigned mkb[k2Steps];
+        auto issue_loads = [&](int u) {
+            const int cu = col0 + 16 * u;
+            const int cc = min(max(cu, 0), nx - 1);            // (clamped: the value is overridden when the column is outside)
+            const unsigned cb = (unsigned)cc * 4u;
+#pragma unroll
+            for (int i = 0; i < k2Steps; ++i) {
+                raw[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(rowoff[i] + cb), 0, 0));
+                if (ARR) mkb[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)((rowoff[i] + cb) >> 2), 0, 0);
+            }
+        };
+        f32x4 Y0[2], Y1[2], Y2[2];                             // rolling window of three input tiles, per row tile
+        u32x2 Qh0[2], Qh1[2], Qh2[2], Ql0[2], Ql1[2], Ql2[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            Y0[b] = Y1[b] = Y2[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            Qh0[b] = Qh1[b] = Qh2[b] = Ql0[b] = Ql1[b] = Ql2[b] = u32x2{0u, 0u};
+        }
+        issue_loads(0);
+#pragma unroll 1
+        for (int u = 0; u < k2InTiles; ++u) {
+            // ---- classify the 15 samples of input tile u
+            float dm[k2Steps];
+            unsigned vbits = 0;
+            const int cu = col0 + 16 * u;
+            const bool colin = (cu >= 0) && (cu < nx);
+            const bool tile_inside = rows_inside && (xw - H + 16 * u >= 0) && (xw - H + 16 * u + 16 <= nx);   // uniform
+            if (tile_inside) {
+#pragma unroll
+                for (int i = 0; i < k2Steps; ++i) {
+                    bool ok = __builtin_fabsf(raw[i]) <= A.lim;
+                    if (ARR) ok = ok & (mkb[i] != 0);
+                    dm[i] = ok ? raw[i] : 0.f;
+                    vbits |= (ok ? 1u : 0u) << i;
+                }
+            } else {                                           // samples outside the plane are valid zeros
+#pragma unroll
+                for (int i = 0; i < k2Steps; ++i) {
+                    bool ok = __builtin_fabsf(raw[i]) <= A.lim;
+                    if (ARR) ok = ok & (mkb[i] != 0);
+                    const bool in = colin & (((rowin >> i) & 1u) != 0);
+                    ok = in ? ok : true;
+                    dm[i] = (ok & in) ? raw[i] : 0.f;
+                    vbits |= (ok ? 1u : 0u) << i;
+                }
+            }
+            if (u + 1 < k2InTiles) issue_loads(u + 1);          // in flight during this tile's matrix work
+            // ---- first products: numerator Y (float32) and denominator Q (fp16 hi / lo) for both row tiles
+#pragma unroll
+            for (int b = 0; b < 2; ++b) { Y0[b] = Y1[b]; Y1[b] = Y2[b]; Qh0[b] = Qh1[b]; Qh1[b] = Qh2[b]; Ql0[b] = Ql1[b]; Ql1[b] = Ql2[b]; }
+            {
+                f32x4 ya = {0.f, 0.f, 0.f, 0.f}, yb = {0.f, 0.f, 0.f, 0.f};      // two independent chains
+#pragma unroll
+                for (int i = 0; i < 11; ++i) {
+                    ya = __builtin_amdgcn_mfma_f32_16x16x4f32(dm[i], tyB[i], ya, 0, 0, 0);
+                    yb = __builtin_amdgcn_mfma_f32_16x16x4f32(dm[4 + i], tyB[i], yb, 0, 0, 0);
+                }
+                Y2[0] = ya; Y2[1] = yb;
+            }
+            {
+                // (the two row tiles' chains interleaved: a dependent matrix instruction waits longer than an independent one)
+                f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+                const unsigned bits0 = vbits & 0x7ffu, bits1 = (vbits >> 4) & 0x7ffu;     // the 11 rows of each row tile
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const unsigned byte0 = (bits0 >> (8 * s)) & 0xffu, byte1 = (bits1 >> (8 * s)) & 0xffu;
+                    const half8 va0 = make_half8(lut[byte0 & 15], lut[byte0 >> 4]), va1 = make_half8(lut[byte1 & 15], lut[byte1 >> 4]);
+                    const half8 bh = dconst[(0 * 2 + s) * 64 + lane], bl = dconst[(1 * 2 + s) * 64 + lane];
+                    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(va0, bh, q0, 0, 0, 0);
+                    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(va1, bh, q1, 0, 0, 0);
+                    q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(va0, bl, q0, 0, 0, 0);
+                    q1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(va1, bl, q1, 0, 0, 0);
+                }
+                split4(q0, Qh2[0], Ql2[0]);
+                split4(q1, Qh2[1], Ql2[1]);
+            }
+            // ---- second products and the epilogue of output tile a = u - 2
+            const int a = u - 2;
+            if (a >= 0 && xw + 16 * a < nx) {                  // uniform (nx is a multiple of 16: checked on the host)
+                f32x4 oo[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dd[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    oo[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(txA[r], Y0[0][r], oo[0], 0, 0, 0);
+                    oo[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(txA[r], Y0[1][r], oo[1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    oo[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(txA[4 + r], Y1[0][r], oo[0], 0, 0, 0);
+                    oo[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(txA[4 + r], Y1[1][r], oo[1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    oo[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(txA[8 + r], Y2[0][r], oo[0], 0, 0, 0);
+                    oo[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(txA[8 + r], Y2[1][r], oo[1], 0, 0, 0);
+                }
+                {
+                    const u32x2 zero2 = {0u, 0u};
+                    const half8 ah0 = dconst[(2 * 2 + 0) * 64 + lane], ah1 = dconst[(2 * 2 + 1) * 64 + lane];
+                    const half8 al0 = dconst[(3 * 2 + 0) * 64 + lane], al1 = dconst[(3 * 2 + 1) * 64 + lane];
+                    const half8 bh00 = make_half8(Qh0[0], Qh1[0]), bl00 = make_half8(Ql0[0], Ql1[0]), bh10 = make_half8(Qh2[0], zero2), bl10 = make_half8(Ql2[0], zero2);
+                    const half8 bh01 = make_half8(Qh0[1], Qh1[1]), bl01 = make_half8(Ql0[1], Ql1[1]), bh11 = make_half8(Qh2[1], zero2), bl11 = make_half8(Ql2[1], zero2);
+                    dd[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh00, dd[0], 0, 0, 0);
+                    dd[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bh01, dd[1], 0, 0, 0);
+                    dd[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl00, dd[0], 0, 0, 0);
+                    dd[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah0, bl01, dd[1], 0, 0, 0);
+                    dd[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh00, dd[0], 0, 0, 0);
+                    dd[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al0, bh01, dd[1], 0, 0, 0);
+                    dd[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh10, dd[0], 0, 0, 0);
+                    dd[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bh11, dd[1], 0, 0, 0);
+                    dd[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl10, dd[0], 0, 0, 0);
+                    dd[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah1, bl11, dd[1], 0, 0, 0);
+                    dd[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh10, dd[0], 0, 0, 0);
+                    dd[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al1, bh11, dd[1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const f32x4 o = oo[b], d = dd[b];
+                    // lane: output row y0 + 16 b + ln, output columns xw + 16 a + 4 lg + 0..3
+                    f32x4 val;
+                    val.x = o.x * (A.scale * __builtin_amdgcn_rcpf(d.x));     // den = 0 (empty window): 0 * inf = NaN
+                    val.y = o.y * (A.scale * __builtin_amdgcn_rcpf(d.y));
+                    val.z = o.z * (A.scale * __builtin_amdgcn_rcpf(d.z));
+                    val.w = o.w * (A.scale * __builtin_amdgcn_rcpf(d.w));
+                    if (STORE && erow[b]) {
+                        float* po = A.out + (int64_t)z * A.out_plane_stride + (int64_t)(y0 + 16 * b + ln) * A.out_row_stride + xw + 16 * a + 4 * lg;
+                        *reinterpret_cast<f32x4*>(po) = val;
+                    }
+                    if (MOM) {
+                        // the ORIGINAL mask on the output voxels themselves (array term; under isfinite the sample as well)
+                        bool i0 = erow[b], i1 = erow[b], i2 = erow[b], i3 = erow[b];
+                        if (ARR) {
+                            const unsigned m4 = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rm, (int)((eoff[b] >> 2) + 16 * a), 0, 0);
+                            i0 = i0 & ((m4 & 0xffu) != 0); i1 = i1 & ((m4 & 0xff00u) != 0);
+                            i2 = i2 & ((m4 & 0xff0000u) != 0); i3 = i3 & ((m4 & 0xff000000u) != 0);
+                        }
+                        if (FIN) {
+                            const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(eoff[b] + 64 * a), 0, 0));
+                            i0 = i0 & (__builtin_fabsf(c4.x) <= A.lim); i1 = i1 & (__builtin_fabsf(c4.y) <= A.lim);
+                            i2 = i2 & (__builtin_fabsf(c4.z) <= A.lim); i3 = i3 & (__builtin_fabsf(c4.w) <= A.lim);
+                        }
+                        i0 = i0 & (val.x == val.x); i1 = i1 & (val.y == val.y);      // nansum: a NaN value is skipped
+                        i2 = i2 & (val.z == val.z); i3 = i3 & (val.w == val.w);
+                        f32x4* slot = macc + (b * k2Tiles + a) * 64;
+                        *slot = *slot + f32x4{i0 ? val.x : 0.f, i1 ? val.y : 0.f, i2 ? val.z : 0.f, i3 ? val.w : 0.f};
+                        mseen[b] |= ((i0 ? 1u : 0u) | (i1 ? 2u : 0u) | (i2 ? 4u : 0u) | (i3 ? 8u : 0u)) << (4 * a);
+                    }
+                }
+            }
+        }
+    }
+
+    if (MOM) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (erow[b]) {
+                const int64_t base = ((int64_t)chunk * A.ny + (y0 + 16 * b + ln)) * A.nx + xw + 4 * lg;
+                for (int a = 0; a < k2Tiles; ++a) {
+                    if (xw + 16 * a < nx) {
+                        *reinterpret_cast<f32x4*>(A.partial + base + 16 * a) = macc[(b * k2Tiles + a) * 64];
+                        const unsigned sb = (mseen[b] >> (4 * a)) & 15u;
+                        *reinterpret_cast<unsigned*>(A.seen + base + 16 * a) = (sb & 1u) | ((sb & 2u) << 7) | ((sb & 4u) << 14) | ((sb & 8u) << 21);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // moment 0 = dv * sum over the chunks (float64), NaN where no channel contributed (nansum_allbadtonan,
 // dask_spectral_cube.py:54-59)
 __global__ __launch_bounds__(256) void spatial_moment_finish_kernel(const float* partial, const unsigned char* seen, int nchunk,
@@ -416,9 +758,17 @@ __global__ __launch_bounds__(256) void spatial_moment_finish_kernel(const float*
     m0[y * m0_row_stride + x] = any ? dv * s : __longlong_as_double(0x7ff8000000000000LL);
 }
 
+inline bool use_form2(const spc_cube_f32* cube, const MaskDev& md) {
+    const char* env = getenv("SPC_SPATIAL_MFMA_FORM");
+    if (env && atoi(env) == 1) return false;
+    if ((cube->nx & 15) || (cube->row_stride & 3) || (cube->plane_stride & 3) || (((uintptr_t)cube->d_data) & 15)) return false;
+    if ((md.flags & SPC_MASK_ARRAY) && (md.row_stride != cube->row_stride || md.plane_stride != cube->plane_stride || (((uintptr_t)md.arr) & 3))) return false;
+    return true;
+}
+
 inline int chunk_planes(int64_t nz, int64_t ny, int64_t nx) {
     // enough blocks to fill the chip several times over, chunks of at most 64 channels (float32 sums inside a chunk)
-    const int64_t tiles = ((ny + kBand - 1) / kBand) * ((nx + kTxo - 1) / kTxo);
+    const int64_t tiles = ((ny + k2Rows - 1) / k2Rows) * ((nx + 4 * k2ColsW - 1) / (4 * k2ColsW));
     int64_t want_chunks = std::max<int64_t>(1, (4096 + tiles - 1) / tiles);
     int64_t zc = std::max<int64_t>(1, (nz + want_chunks - 1) / want_chunks);
     zc = std::min<int64_t>(zc, 64);
@@ -476,6 +826,8 @@ extern "C" int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc
     A.nchunk = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
     const int64_t nblocks = (int64_t)A.nstrips * A.nbands * A.nchunk;
     SPC_REQUIRE(nblocks < (1ll << 31), "too many blocks");
+    if (cube->ny * cube->row_stride * 4 >= (1ll << 32) || ((md.flags & SPC_MASK_ARRAY) && cube->ny * md.row_stride >= (1ll << 32)))
+        SPC_UNSUPPORTED("spatial_conv_sep_mfma: a plane must stay below 4 GiB (buffer addressing)");
     hipStream_t st = (hipStream_t)stream;
     if (d_m0) {
         SpcWorkspace ws(d_workspace, workspace_bytes);
@@ -484,8 +836,42 @@ extern "C" int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc
         A.partial = d_partial; A.seen = d_seen;
     }
     const bool arr = A.marr != nullptr;
+    if (use_form2(cube, md)) {
+        Sm2Args B{};
+        B.cube = A.cube; B.nz = A.nz; B.ny = A.ny; B.nx = A.nx; B.row_stride = A.row_stride; B.plane_stride = A.plane_stride;
+        B.marr = A.marr; B.out = A.out; B.out_row_stride = A.out_row_stride; B.out_plane_stride = A.out_plane_stride;
+        B.partial = A.partial; B.seen = A.seen; B.zchunk = A.zchunk; B.nchunk = A.nchunk;
+        B.lim = A.lim; B.sy = A.sy; B.sx = A.sx; B.scale = A.sy * A.sx;
+        for (int i = 0; i < R + 3; ++i) { B.ky[i] = A.ky[i]; B.kx[i] = A.kx[i]; }
+        B.nstrips = (int)((cube->nx + 4 * k2ColsW - 1) / (4 * k2ColsW));
+        B.nbands = (int)((cube->ny + k2Rows - 1) / k2Rows);
+        const int64_t nb2 = (int64_t)B.nstrips * B.nbands * B.nchunk;
+        const bool fin2 = (md.flags & SPC_MASK_FINITE) != 0;
+        const bool storev = d_out && ((B.out_row_stride & 3) == 0) && ((B.out_plane_stride & 3) == 0) && ((((uintptr_t)d_out) & 15) == 0);
+        if (!d_out || storev) {
+            dim3 g2((unsigned)nb2), b2(kThreads);
+#define SPC_SM2(ARR_, STORE_, MOM_) do { if (fin2) hipLaunchKernelGGL((spatial_mfma2_kernel<ARR_, STORE_, MOM_, true>), g2, b2, 0, st, B); \
+                                         else hipLaunchKernelGGL((spatial_mfma2_kernel<ARR_, STORE_, MOM_, false>), g2, b2, 0, st, B); } while (0)
+            if (d_out && d_m0) { if (arr) SPC_SM2(true, true, true); else SPC_SM2(false, true, true); }
+            else if (d_out) { if (arr) SPC_SM2(true, true, false); else SPC_SM2(false, true, false); }
+            else { if (arr) SPC_SM2(true, false, true); else SPC_SM2(false, false, true); }
+            SPC_LAUNCH_CHECK();
+            if (d_m0) {
+                const int64_t n = cube->ny * cube->nx;
+                hipLaunchKernelGGL(spatial_moment_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B.partial, B.seen, B.nchunk,
+                                   cube->ny, cube->nx, dv, d_m0, m0_row_stride ? m0_row_stride : cube->nx);
+                SPC_LAUNCH_CHECK();
+            }
+            return SPC_OK;
+        }
+    }
     dim3 grid((unsigned)nblocks), block(kThreads);
-#define SPC_SM_LAUNCH(ARR_, STORE_, MOM_) hipLaunchKernelGGL((spatial_sep_mfma_kernel<ARR_, STORE_, MOM_>), grid, block, 0, st, A)
+    bool isosym = true;
+    for (int i = 0; i < R; ++i) isosym = isosym && (A.ky[i] == A.kx[i]) && (A.ky[i] == A.ky[R - 1 - i]);
+    const bool fin = (md.flags & SPC_MASK_FINITE) != 0;
+#define SPC_SM_LAUNCH2(ARR_, STORE_, MOM_, IS_) do { if (fin) hipLaunchKernelGGL((spatial_sep_mfma_kernel<ARR_, STORE_, MOM_, IS_, true>), grid, block, 0, st, A); \
+                                                     else hipLaunchKernelGGL((spatial_sep_mfma_kernel<ARR_, STORE_, MOM_, IS_, false>), grid, block, 0, st, A); } while (0)
+#define SPC_SM_LAUNCH(ARR_, STORE_, MOM_) do { if (isosym) SPC_SM_LAUNCH2(ARR_, STORE_, MOM_, true); else SPC_SM_LAUNCH2(ARR_, STORE_, MOM_, false); } while (0)
     if (d_out && d_m0) { if (arr) SPC_SM_LAUNCH(true, true, true); else SPC_SM_LAUNCH(false, true, true); }
     else if (d_out) { if (arr) SPC_SM_LAUNCH(true, true, false); else SPC_SM_LAUNCH(false, true, false); }
     else { if (arr) SPC_SM_LAUNCH(true, false, true); else SPC_SM_LAUNCH(false, false, true); }

@@ -45,5 +45,16 @@ for _ in range(reps):
             for z in range(nz):
                 _lib.call("spc_memcpy_h2d", 0, C.c_void_p(maskc.ptr + z * mp.nbytes), mp.ctypes.data_as(C.c_void_p), mp.nbytes, None)
         ops.spatial_conv(cube, np.outer(g29, g29), out=out, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskc))
+    elif op in ("spmfma_store", "spmfma_mom"):
+        if _ == 0:
+            mp = (rng.random((ny, nx)) > 0.2).astype(np.uint8)
+            maskc = DeviceArray(shape, np.uint8)
+            for z in range(nz):
+                _lib.call("spc_memcpy_h2d", 0, C.c_void_p(maskc.ptr + z * mp.nbytes), mp.ctypes.data_as(C.c_void_p), mp.nbytes, None)
+            m0 = DeviceArray((ny, nx), np.float64)
+        if op == "spmfma_store":
+            ops.spatial_conv_mfma(cube, np.outer(g29, g29), mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskc), out=out)
+        else:
+            ops.spatial_conv_mfma(cube, np.outer(g29, g29), mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskc), want_cube=False, want_m0=True, m0=m0)
 synchronize()
 print("done", op)
