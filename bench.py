@@ -632,6 +632,36 @@ def config_c4(device, scale):
                            "fused ideal: 4 + 1 read + 8 B/spaxel out (the materialised form moves 9 + 5 B/voxel)",
                            mask_valid_fraction=float(tmask.mean())))
 
+    # the same pipeline FUSED: numerator and denominator of the NaN-aware convolution on the matrix cores, moment sums kept on
+    # chip, the smoothed cube never written (spc_spatial_conv_sep_mfma_f32)
+    m0f = DeviceArray((ny, nx), np.float64, device)
+    ms = event_ms(lambda: ops.spatial_conv_mfma(cube, k2, mask=mspec, want_cube=False, want_m0=True, dv=500.0, m0=m0f), device, n=5, warm=1)
+    ver = {"max_scaled_err": _close(m0f.get()[:WY, :WX], exp_m0, float(np.nanmax(np.abs(exp_m0))), "C4 fused moment0 masked"),
+           "spaxels_checked": int(exp_m0.size)}
+    recs.append(cfg_record("C4 pipeline spatial_smooth(29x29) -> moment0, uint8 mask, FUSED (matrix cores, cube never written)",
+                           "spatial_mfma2_kernel<ARR,MOM> (+ spatial_moment_finish_kernel)", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "4 + 1 read + 8 B/spaxel out", mask_valid_fraction=float(tmask.mean())))
+    # a SIGNAL mask instead of the 80 % random one: coherent regions (35 % valid), what `data > 2 sigma` of a real cube looks like -
+    # the stencils see long runs of all-valid / all-invalid windows
+    yy_, xx_ = np.mgrid[0:ny, 0:nx]
+    smask = np.stack([(np.sin(xx_ / 37.0) * np.cos(yy_ / 53.0) > 0.2), (np.sin(xx_ / 41.0 + 1.0) * np.cos(yy_ / 47.0) > 0.2)]).view(np.uint8)
+    replicate_planes(maskd, smask)
+    incs = smask[sub].astype(bool)
+    ms_sig = event_ms(lambda: ops.spatial_conv(cube, k2, mask=mspec, out=sm), device, n=5, warm=1)
+    exp_s = O.spatial_smooth(tile[sub], incs, k2)[win]
+    ver = {"max_scaled_err": _close(smoothed_window(sm), exp_s, float(np.nanmax(np.abs(exp_s))), "C4 smooth signal mask"), "voxels_checked": int(exp_s.size)}
+    recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 SIGNAL mask (coherent regions)", "spatial_sep_grouped_kernel<29,true,false,true,256,true,0>",
+                           ms_sig, vox * 9, vox, ver, "4 + 1 read + 4 written", mask_valid_fraction=float(smask.mean())))
+    ms = event_ms(lambda: ops.spatial_conv_mfma(cube, k2, mask=mspec, want_cube=False, want_m0=True, dv=500.0, m0=m0f), device, n=5, warm=1)
+    incw_s = smask[win].astype(bool)
+    exp_m0s = (nz // 2) * 500.0 * np.where(incw_s, exp_s, 0.0).sum(axis=0)
+    exp_m0s[~incw_s.any(axis=0)] = np.nan
+    ver = {"max_scaled_err": _close(m0f.get()[:WY, :WX], exp_m0s, float(np.nanmax(np.abs(exp_m0s))), "C4 fused moment0 signal mask"),
+           "spaxels_checked": int(exp_m0s.size)}
+    recs.append(cfg_record("C4 pipeline spatial_smooth(29x29) -> moment0, uint8 SIGNAL mask, FUSED (matrix cores)",
+                           "spatial_mfma2_kernel<ARR,MOM> (+ spatial_moment_finish_kernel)", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "4 + 1 read + 8 B/spaxel out", mask_valid_fraction=float(smask.mean())))
+
     # all valid: convolution commutes with the sums along z (algebraic path of SpectralCube.spatial_smooth -> moment0)
     from spectral_cube_amd import SpectralCube
     del sm, maskd, mspec

@@ -569,6 +569,7 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
                     (A.out_plane_stride % 4 == 0) && (((uintptr_t)d_out) % 16 == 0);
     A.status = nullptr;
     A.inv_ksum = (float)(1.0 / sum);
+    A.centre_zero = (A.ky[R / 2] * A.kx[R / 2] == 0.f) ? 1 : 0;
     { const char* xe = getenv("SPC_XCD_SWIZZLE"); A.xcd_swizzle = xe ? (atoi(xe) != 0) : 1; }
     canonical_pred(A);
     // (the 49- and 65-tap rings - 35 to 65 taps - have an all-valid kernel for isotropic kernels only: two sets of

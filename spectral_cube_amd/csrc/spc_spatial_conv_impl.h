@@ -26,6 +26,10 @@ struct SpArgs {
     int fast_nstrips;
     int xcd_swizzle;                          // 1: (strip, plane) from the XCD-aware block order (spc_xcd_order)
     float inv_ksum;                           // 1 / (sum(ky) * sum(kx))
+    int centre_zero;                          // the kernel's centre tap is zero: only then can an EMPTY window (den = 0) sit on a
+                                              // valid centre sample, which astropy returns; otherwise den = 0 means NaN (= 0 * 1/0)
+                                              // and the look-up of the centre sample - global loads in a divergent branch, 59 -> 90 ms
+                                              // at C4 with a signal mask whose all-invalid regions are full of empty windows - is skipped
     float pred_lim, pred_lo, pred_hi;         // canonical predicate: |v| <= lim && !(v <= lo) && !(v >= hi)
     alignas(8) float ky[kMaxTaps + 1];        // padded to RY, centred (read pairwise as 64-bit scalars)
     alignas(8) float kx[kMaxTaps + 1];        // padded to RX, centred
@@ -454,8 +458,8 @@ __global__ __launch_bounds__(kThreads, R == 29 ? 3 : 1) void spatial_sep_kernel(
                 float res[kRun];
     #pragma unroll
                 for (int k = 0; k < kRun; ++k) {
-                    if (r[k].y != 0.f) {
-                        res[k] = r[k].x * __builtin_amdgcn_rcpf(r[k].y);
+                    if (r[k].y != 0.f || !A.centre_zero) {
+                        res[k] = r[k].x * __builtin_amdgcn_rcpf(r[k].y);      // (den = 0: 0 * inf = NaN)
                     } else {
                         // empty window -> (filled) centre sample, like astropy
                         res[k] = NAN;
@@ -668,7 +672,7 @@ __global__ __launch_bounds__(BT, SPC_GROUPED_PF == 1 ? 1024 / BT : 768 / BT) voi
                     res[k] = r[k].x * __builtin_amdgcn_rcpf(r[k].y);      // den = 0 (empty window): 0 * inf = NaN
                     empty = empty || (r[k].y == 0.f);
                 }
-                if (__any(empty)) {
+                if (A.centre_zero && __any(empty)) {
                     // astropy returns the (filled) centre sample for an empty window: NaN when that sample is excluded
                     // (always, for a kernel whose centre tap is not zero), the sample itself otherwise
 #pragma unroll

@@ -671,6 +671,10 @@ class SpectralCube:
             return None
         parent = lz.parent
         spec = parent._mask_spec()
+        if tuple(want) == ("m0",) and parent._stream_source() is None and (spec.array is not None or (spec.flags & ~_lib.MASK_FINITE) == 0):
+            fused = self._fused_masked_smooth_moment0(parent, spec, lz.kernel)
+            if fused is not None:
+                return {"m0": fused}
         if spec.array is not None or (spec.flags & ~_lib.MASK_FINITE):
             return None
         nz = self._shape[0]
@@ -707,6 +711,22 @@ class SpectralCube:
         if not all(np.isfinite(m.sum()) for m in out.values()):
             return None
         return out
+
+    def _fused_masked_smooth_moment0(self, parent, spec, kernel2d):
+        """masked spatial_smooth -> moment0 in ONE kernel that never writes the smoothed cube (the lazy Dask graph of the
+        reference does not materialise it either: dask_spectral_cube.py:962-993 then :1083-1104): numerator and denominator of
+        the NaN-aware convolution on the matrix cores, moment sums in registers / LDS (spc_spatial_conv_sep_mfma_f32).
+        None when the kernel does not take the case (more than 29 taps per axis, non-separable or negative kernels, mask
+        terms other than the array / isfinite): the caller materialises.  Only tried where it pays: a mask ARRAY (an
+        all-valid cube takes the algebraic path below, which is cheaper still)."""
+        if spec.array is None:
+            return None
+        try:
+            _, m0 = ops.spatial_conv_mfma(parent._device_data(), kernel2d, mask=spec, want_cube=False, want_m0=True,
+                                          dv=self._pix_size_slice(0))
+        except _lib.HipUnsupported:
+            return None
+        return m0.get()
 
     def moment(self, order=0, axis=0, how="auto", **kwargs):
         """Compute moments along an axis (spectral_cube.py:1614-1720;

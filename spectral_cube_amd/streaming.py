@@ -89,6 +89,41 @@ class NdarraySource:
         pass
 
 
+class DaskSource:
+    """a dask array (nz, ny, nx) - what a DaskSpectralCube holds (dask_spectral_cube.py:85-116) - as a strip source: the
+    reader threads of the strip pipeline compute the window they are asked for STRAIGHT INTO the pinned staging buffer
+    (dask.array.store, synchronous scheduler inside the reader thread: the pipeline's own threads are the parallelism),
+    converting to float32 on the way.  The per-chunk seam (`map_blocks` + a chunk function, dask_adapter.py) hands every
+    chunk over through dask's graph machinery and a Python callable - two thirds of the wall clock at 1024^3
+    (profiles/r03_dask_seam_breakdown.log); here dask only evaluates slices of the stored array."""
+
+    def __init__(self, array, out_dtype=np.float32):
+        if len(array.shape) != 3:
+            raise ValueError("a (nz, ny, nx) dask array")
+        self.data = array
+        self.shape = tuple(int(s) for s in array.shape)
+        self.out_dtype = np.dtype(out_dtype)
+        self.sample_bytes = self.out_dtype.itemsize
+        self.decode = None
+        self.preferred_chunk_mb = 64          # (measured at 1024^3, chunks (-1, 256, 256): 16 MiB windows 11 GB/s, 32: 21, 64: 25, 128: 15)
+
+    def read_into(self, view_u8, z0, z1, y0, y1):
+        import dask
+        import dask.array as da
+        nz, ny, nx = self.shape
+        n = (z1 - z0) * (y1 - y0) * nx
+        dst = np.frombuffer(view_u8, dtype=self.out_dtype, count=n).reshape(z1 - z0, y1 - y0, nx)
+        piece = self.data[z0:z1, y0:y1]
+        if piece.dtype != self.out_dtype:
+            piece = piece.astype(self.out_dtype)
+        with dask.config.set(scheduler="synchronous"):
+            da.store(piece, dst, lock=False, compute=True)
+        return n * self.sample_bytes
+
+    def release(self):
+        pass
+
+
 class FitsSource:
     """image HDU of a FITS file: reader threads pread the big-endian plane strips into the pinned buffers, the
     device decodes them (byte swap / BSCALE / BZERO / BLANK: spc_fits_to_f32)"""
@@ -151,6 +186,9 @@ def plan_rows(shape, budget, mask_array=False, align=8):
     nz, ny, nx = shape
     per_row = nz * nx * (4 + (1 if mask_array else 0))
     rows = int((budget // 2) // (2 * per_row))
+    # (a source that is streamed although it would fit - a dask array: never resident - still goes in several strips, so that
+    # staging, kernels and read-back of neighbouring strips overlap)
+    rows = min(rows, max(align, int(_env_int("SPC_STREAM_MAX_STRIP_MB", 1024) << 20) // max(1, per_row)))
     rows = max(align, rows // align * align)
     return min(ny, rows)
 
@@ -215,7 +253,9 @@ class StripPipeline:
         if self.axis not in (0, 1) or (self.axis == 0 and self.halo):
             raise ValueError("strips along y (axis 1, optional halo rows) or slabs of planes (axis 0)")
         self.slots = slots
-        self.chunk_bytes = int(chunk_bytes or (_env_int("SPC_STREAM_CHUNK_MB", 32) << 20))
+        # (a source may ask for larger pieces: every window of a dask array costs a graph evaluation)
+        pref = int(getattr(source, "preferred_chunk_mb", 0))
+        self.chunk_bytes = int(chunk_bytes or (_env_int("SPC_STREAM_CHUNK_MB", pref or 32) << 20))
         self.nbuf = int(nbuffers or _env_int("SPC_STREAM_BUFFERS", 16))
         self.readers = int(readers or _env_int("SPC_STREAM_READERS", 8))
         nz, ny, nx = source.shape
@@ -571,7 +611,7 @@ class StripWriter:
     buffers on their own stream (after the event the producer recorded), writer threads hand them to the sink while the
     next strip is being staged and computed"""
 
-    def __init__(self, sink, device, nbuffers=8, chunk_bytes=32 << 20, writers=4):
+    def __init__(self, sink, device, nbuffers=8, chunk_bytes=32 << 20, writers=8):
         from concurrent.futures import ThreadPoolExecutor
         from .device import Event
         self.sink, self.device, self.Event = sink, device, Event
@@ -669,6 +709,7 @@ def map_strips(cube, fn, nz_out, sink, rows=None, stats=None, halo=0):
         # two input strips + two result strips (+ the operator's own scratch) within half the budget
         per_row = nx * (nz * (4 + (1 if terms is not None and terms[3] is not None else 0)) + 2 * nz_out * 4)
         rows = max(8, int((hbm_budget(cube.device) // 2) // (2 * per_row)) // 8 * 8 - 2 * halo)
+        rows = min(rows, max(8, (int(_env_int("SPC_STREAM_MAX_STRIP_MB", 1024) << 20) // max(1, nx * nz * 4)) // 8 * 8))
         rows = max(8, min(src.shape[1], rows))
     st = Strips(cube, compute, rows, halo=halo)
     w = StripWriter(sink, cube.device)

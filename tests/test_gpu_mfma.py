@@ -83,3 +83,31 @@ def test_mfma_refuses_what_it_does_not_do(gpu):
     neg = np.outer([-0.1, 1.0, -0.1], [0.2, 1.0, 0.2])
     with pytest.raises(_lib.HipUnsupported):
         ops.spatial_conv_mfma(cube, neg, mask=spec)
+
+
+def test_cube_level_masked_spatial_smooth_moment0_runs_fused(gpu, monkeypatch):
+    """SpectralCube.spatial_smooth(...).moment0() with a boolean mask array takes the fused kernel (the smoothed cube is
+    never formed) and equals the materialised path (SPC_SPATIAL_MFMA_FORM / a 41-tap kernel force it) and the oracle"""
+    from spectral_cube_amd import SpectralCube
+    shape = (20, 64, 160)
+    d, m = _case(shape, 17, valid=0.6)
+    m[:, 10:13, 20:24] = False
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 0.5, "CUNIT3": "km/s",
+           "CRPIX1": 1, "CRPIX2": 1, "CRPIX3": 1, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": -16.0, "BUNIT": "K"}
+    cube = SpectralCube.read(d, hdr).with_mask(m)
+    k = Gaussian2DKernel(8 / 2.3548200450309493)
+    calls = []
+    real = ops.spatial_conv_mfma
+    monkeypatch.setattr(ops, "spatial_conv_mfma", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    got = np.asarray(cube.spatial_smooth(k).moment0())
+    assert calls, "the fused kernel was not used"
+    sm = O.spatial_smooth(d, m, k.array)
+    filled = np.where(m, sm, np.nan)
+    exp = 0.5 * np.nansum(filled, axis=0)
+    exp[np.all(np.isnan(filled), axis=0)] = np.nan
+    assert np.isnan(exp).sum() == 12
+    assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="cube-level fused smooth -> moment0")
+    # the materialised path (what runs for kernels the fused form refuses) gives the same map
+    sm_dev = ops.spatial_conv(cube._device_data(), k.array, mask=cube._mask_spec())
+    mat = np.asarray(SpectralCube.from_device(sm_dev, header=hdr).with_mask(m).moment0())
+    assert_close(got, mat, atol=1e-5 * np.nanmax(np.abs(exp)), what="fused vs materialised")

@@ -229,3 +229,65 @@ def test_streamed_reproject_onto_a_cube_header_with_another_spectral_axis(gpu, m
     out = got_cube.stream_into(np.empty(exp.shape, np.float32))
     assert np.array_equal(out, exp, equal_nan=True)
     np.testing.assert_allclose(got_cube.spectral_axis, exp_cube.spectral_axis, rtol=1e-12)
+
+
+DASK_CUBE_WORKER = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import numpy as np
+import dask, dask.array as da
+import oracle_np as O
+from spectral_cube_amd.dask_adapter import DaskCubeOps
+from spectral_cube_amd.kernels import Gaussian1DKernel, Gaussian2DKernel
+rng = np.random.default_rng(6)
+nz, ny, nx = 48, 72, 88
+d = rng.standard_normal((nz, ny, nx)).astype(np.float32) + 1.0
+d[5:9, 3, 7] = np.nan                                     # masked voxels arrive NaN-filled (FilledArrayHandler, dask_spectral_cube.py:205-230)
+hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 0.5, "CUNIT3": "km/s",
+       "CRPIX1": 1, "CRPIX2": 1, "CRPIX3": 1, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": -3.0}
+def close(a, b, scale, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what
+    ok = np.isfinite(b)
+    assert np.abs(a[ok] - b[ok]).max() <= 1e-5 * scale, (what, np.abs(a[ok] - b[ok]).max())
+for dtype, chunks in ((np.float32, (-1, 24, 32)), (np.float64, (16, 36, -1))):
+    arr = da.from_array(d.astype(dtype), chunks=chunks)
+    ops = DaskCubeOps(arr, hdr)
+    inc = np.isfinite(d)
+    cen = np.arange(nz) * 0.5
+    e = O.moments012(d, inc, cen, 0.5, -3.0)
+    for got, exp, sc in zip(ops.moments012(), e, (np.nanmax(np.abs(e[0])), 24.0, np.nanmax(np.abs(e[2])))):
+        close(got, exp, sc, "moments")
+    close(ops.moment(order=1), e[1], 24.0, "moment1")
+    k1, k2 = Gaussian1DKernel(1.5), Gaussian2DKernel(1.2)
+    sm = ops.spectral_smooth(k1)
+    assert isinstance(sm, da.Array) and sm.dtype == np.float32 and (dtype != np.float32 or sm.chunks == arr.chunks)
+    exp = O.spectral_smooth(d, inc, k1.array)
+    close(sm.compute(), np.where(inc, exp, np.nan), np.nanmax(np.abs(exp)), "spectral_smooth")      # (filled: the mask is kept)
+    exp = O.spatial_smooth(d, inc, k2.array)
+    close(ops.spatial_smooth(k2).compute(), np.where(inc, exp, np.nan), np.nanmax(np.abs(exp)), "spatial_smooth")
+    clipped = ops.sigma_clip_spectrally(2.5).compute()
+    expc = O.sigma_clip(d, inc, 2.5)
+    assert np.mean(np.isnan(clipped) != np.isnan(expc)) < 1e-3
+print("DASK_CUBE_OK", dask.__version__)
+'''
+
+
+def test_cube_level_dask_entry(gpu, tmp_path):
+    """VERDICT round 3, item 5: the operators of a dask-backed cube one level above the per-chunk seam - windows of the dask
+    array go straight into the strip pipeline's pinned buffers (streaming.DaskSource), the strip kernels run, cube -> cube
+    results come back as a dask array over the host sink.  dask lives in the image's conda interpreter only: subprocess."""
+    import subprocess
+    from conftest import REPO
+    py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py) or subprocess.run([py, "-c", "import dask.array"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with dask on this box")
+    script = tmp_path / "dask_cube_worker.py"
+    script.write_text(DASK_CUBE_WORKER)
+    env = dict(os.environ)
+    sys_cxx = "/usr/lib/x86_64-linux-gnu/libstdc++.so.6"
+    if os.path.exists(sys_cxx):
+        env["LD_PRELOAD"] = sys_cxx
+    r = subprocess.run([py, "-B", str(script), REPO], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "DASK_CUBE_OK" in r.stdout, r.stdout + r.stderr
