@@ -353,6 +353,13 @@ typedef enum { SPC_MAP_MUL = 0, SPC_MAP_SECOND_MOMENT_SUM = 1, SPC_MAP_DIV_ADD =
 int spc_map_arith_f64(int device, void* stream, int op, const double* d_a, const double* d_b, const double* d_c,
                       double s, double* d_out, int64_t n);
 
+/* The checks the algebraic smooth -> moment paths make before they trust their shortcut, on the device: *d_flags (one
+ * uint32 in HBM, cleared by this call on the same stream) gets bit 0 if any of the n int32 counts differs from
+ * `expect` (a spaxel with an invalid voxel), bit 1 if any of the n float64 values is not finite.  Either array may be
+ * NULL.  Asynchronous: the caller reads back four bytes instead of two maps. (ABI 4) */
+int spc_map_check(int device, void* stream, const int32_t* d_counts, int32_t expect, const double* d_values,
+                  int64_t n, uint32_t* d_flags);
+
 /* moments along a spatial axis (axis = 1 or 2), reference golden tables
  * spectral_cube/tests/test_moments.py:19-49.  d_cen is a (ny,nx) float64 map
  * of offsets along that axis (spectral_cube.py:1476-1503), pix_size the pixel

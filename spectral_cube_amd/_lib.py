@@ -100,6 +100,7 @@ SIGNATURES = {
     "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _P(C.c_double), _i64, _i64, _vp, _vp]),
     "spc_spatial_conv_sep_mfma_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _i, _P(C.c_double), _i, _vp, _i64, _i64,
                                            _d, _vp, _i64, _vp, _sz]),
+    "spc_map_check": (_i, [_i, _vp, _vp, C.c_int32, _vp, _i64, _vp]),
     "spc_resample_spline_f32": (_i, [_i, _vp, _P(SpcCube), _i, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz]),
     "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _vp, _sz]),
     "spc_pool_trim": (_i, [_i]),

@@ -788,6 +788,16 @@ int spc_map_conv2d_f64(int device, void* stream, const double* d_in, int64_t ny,
 
 // ---- elementwise arithmetic on float64 maps (the algebra around spc_map_conv2d_f64 without a trip to the host)
 namespace {
+__global__ __launch_bounds__(256) void map_check_kernel(const int32_t* counts, int32_t expect, const double* values, int64_t n, uint32_t* flags) {
+    unsigned bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (counts && counts[i] != expect) bad |= 1u;
+        if (values && !(fabs(values[i]) <= 1.7976931348623157e308)) bad |= 2u;
+    }
+    if (__any(bad & 1u) && (threadIdx.x & 63) == 0) atomicOr(flags, 1u);
+    if (__any(bad & 2u) && (threadIdx.x & 63) == 0) atomicOr(flags, 2u);
+}
+
 __global__ __launch_bounds__(256) void map_arith_kernel(int op, const double* a, const double* b, const double* c, double s,
                                                         double* out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -814,6 +824,18 @@ int spc_map_arith_f64(int device, void* stream, int op, const double* d_a, const
     if (n == 0) return SPC_OK;
     SPC_DEVICE(device);
     hipLaunchKernelGGL(map_arith_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, d_a, d_b, d_c, s, d_out, n);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_map_check(int device, void* stream, const int32_t* d_counts, int32_t expect, const double* d_values, int64_t n,
+                  uint32_t* d_flags) {
+    SPC_REQUIRE(d_flags && n >= 0, "NULL pointer argument");
+    SPC_DEVICE(device);
+    SPC_HIP(hipMemsetAsync(d_flags, 0, sizeof(uint32_t), (hipStream_t)stream));
+    if (n == 0 || (!d_counts && !d_values)) return SPC_OK;
+    const unsigned nb = (unsigned)std::min<int64_t>((n + 1023) / 1024, 4096);
+    hipLaunchKernelGGL(map_check_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, d_counts, expect, d_values, n, d_flags);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }

@@ -681,15 +681,16 @@ class SpectralCube:
         higher = ("m1" in want) or ("m2" in want)
         # moment 0 alone: the kernel scales by the channel width (m0 = dv * S0), the convolved map is the result
         r = parent._moment_device((("s0", "mu", "m2") if higher else ("m0",)) + ("nvalid",))
-        if int(r["nvalid"].get().min()) != nz:
-            return None
         if not higher:
-            c0 = ops.map_conv2d(r["m0"], lz.kernel).get()        # the sums never leave the device
-            # a NaN / Inf sum anywhere (one reduction: the total is non-finite iff a term is; cannot happen when the
-            # mask keeps finite samples only): not this path
-            if not (spec.flags & _lib.MASK_FINITE) and not np.isfinite(c0.sum()):
+            # every spaxel has nz valid voxels, and no NaN / Inf sum anywhere (cannot happen when the mask keeps finite samples
+            # only): both checked on the device - four bytes come back instead of the count map and a host reduction of the
+            # result (17.5 -> 14 ms at C4)
+            c0d = ops.map_conv2d(r["m0"], lz.kernel)             # the sums never leave the device
+            if ops.map_check(r["nvalid"], nz, None if (spec.flags & _lib.MASK_FINITE) else c0d):
                 return None
-            return {"m0": c0}
+            return {"m0": c0d.get()}
+        if ops.map_check(r["nvalid"], nz):
+            return None
         # S1 = mu * S0 and S2 = (m2 + mu^2) * S0 about the reference channel are smoothed like S0; the moments of the
         # smoothed cube are their ratios.  All of it on the device: only the requested maps come back.  A spaxel whose
         # spectrum sums to zero (0/0 in mu), a zero smoothed sum or a non-finite sample shows up as a non-finite value

@@ -448,6 +448,17 @@ def spatial_conv_mfma(cube, kernel2d, mask=None, stream=None, out=None, want_cub
     return (out if want_cube else None), (m0 if want_m0 else None)
 
 
+def map_check(counts=None, expect=0, values=None, stream=None):
+    """device-side checks of the algebraic smooth -> moment paths (spc_map_check): bit 0 = a count differs from *expect*, bit 1 = a
+    value is not finite.  Returns the flags (an int; reads back four bytes)."""
+    ref = counts if counts is not None else values
+    n = int(np.prod(ref.shape, dtype=np.int64))
+    flags = DeviceArray((1,), np.uint32, ref.device)
+    _lib.call("spc_map_check", ref.device, _sh(stream), C.c_void_p(counts.ptr) if counts is not None else None, int(expect),
+              C.c_void_p(values.ptr) if values is not None else None, n, C.c_void_p(flags.ptr))
+    return int(flags.get(stream)[0])
+
+
 def resample_spline(cube, xs, ys, order, stream=None, want_footprint=True, out=None, slab_bytes=2 << 30):
     """biquadratic (order 2) / bicubic (order 3) spatial resample of every channel at (xs, ys): scipy's
     map_coordinates(order, mode='constant', cval=nan) on the border-replicated planes, the resampler of

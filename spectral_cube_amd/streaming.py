@@ -105,6 +105,7 @@ class DaskSource:
         self.out_dtype = np.dtype(out_dtype)
         self.sample_bytes = self.out_dtype.itemsize
         self.decode = None
+        self.max_strip_mb = _env_int("SPC_STREAM_MAX_STRIP_MB", 1024)     # never resident, so always streamed: strips small enough to overlap
         self.preferred_chunk_mb = 64          # (measured at 1024^3, chunks (-1, 256, 256): 16 MiB windows 11 GB/s, 32: 21, 64: 25, 128: 15)
 
     def read_into(self, view_u8, z0, z1, y0, y1):
@@ -180,7 +181,7 @@ class FitsSource:
 
 
 # ---- the strip pipeline ------------------------------------------------------------------------------------
-def plan_rows(shape, budget, mask_array=False, align=8):
+def plan_rows(shape, budget, mask_array=False, align=8, max_strip_mb=0):
     """rows per strip: two strips in flight (one computing, one being staged) + their mask strips within
     half the budget, at least `align` rows, a multiple of `align` (16-byte aligned row starts for any nx % 4 == 0)"""
     nz, ny, nx = shape
@@ -188,7 +189,8 @@ def plan_rows(shape, budget, mask_array=False, align=8):
     rows = int((budget // 2) // (2 * per_row))
     # (a source that is streamed although it would fit - a dask array: never resident - still goes in several strips, so that
     # staging, kernels and read-back of neighbouring strips overlap)
-    rows = min(rows, max(align, int(_env_int("SPC_STREAM_MAX_STRIP_MB", 1024) << 20) // max(1, per_row)))
+    if max_strip_mb:
+        rows = min(rows, max(align, (int(max_strip_mb) << 20) // max(1, per_row)))
     rows = max(align, rows // align * align)
     return min(ny, rows)
 
@@ -391,7 +393,7 @@ class Strips:
         self.terms = _mask_terms(cube)
         has_arr = self.terms is not None and self.terms[3] is not None
         if rows is None:
-            rows = (plan_rows(src.shape, hbm_budget(cube.device), mask_array=has_arr) if axis == 1 else
+            rows = (plan_rows(src.shape, hbm_budget(cube.device), mask_array=has_arr, max_strip_mb=getattr(src, "max_strip_mb", 0)) if axis == 1 else
                     plan_planes(src.shape, hbm_budget(cube.device), mask_array=has_arr, out_factor=out_factor))
         self.rows = rows
         self.data = StripPipeline(src, cube.device, rows, stream, halo=halo, axis=axis)
@@ -709,7 +711,8 @@ def map_strips(cube, fn, nz_out, sink, rows=None, stats=None, halo=0):
         # two input strips + two result strips (+ the operator's own scratch) within half the budget
         per_row = nx * (nz * (4 + (1 if terms is not None and terms[3] is not None else 0)) + 2 * nz_out * 4)
         rows = max(8, int((hbm_budget(cube.device) // 2) // (2 * per_row)) // 8 * 8 - 2 * halo)
-        rows = min(rows, max(8, (int(_env_int("SPC_STREAM_MAX_STRIP_MB", 1024) << 20) // max(1, nx * nz * 4)) // 8 * 8))
+        if getattr(src, "max_strip_mb", 0):
+            rows = min(rows, max(8, ((int(src.max_strip_mb) << 20) // max(1, nx * nz * 4)) // 8 * 8))
         rows = max(8, min(src.shape[1], rows))
     st = Strips(cube, compute, rows, halo=halo)
     w = StripWriter(sink, cube.device)
