@@ -78,7 +78,7 @@ def base(kernel):
 
 out, table = {}, []
 for name, kernel, ms, alg in records:
-    parts = [p.strip() for p in kernel.split(" + ")]
+    parts = [p.strip() for p in re.sub(r"\([^)]*\)", "", kernel).split(" + ") if p.strip()]      # (notes in parentheses may hold a '+')
     chosen = []
     for i, part in enumerate(parts):
         cands = [(k, v) for k, v in groups.items() if k[0].startswith(base(part)) and len(v) >= 3]
