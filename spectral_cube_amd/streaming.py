@@ -566,7 +566,7 @@ class FitsSink:
         # file under the target's name.
         self.path = os.fspath(path)
         self.part = "%s.spc-part-%d-%x" % (self.path, os.getpid(), id(self) & 0xffffff)
-        self.fd = os.open(self.part, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        self.fd = os.open(self.part, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
         size = self.base + total + (-total) % io_fits.BLOCK                       # zero padding included
         try:
             os.pwrite(self.fd, text.encode("ascii"), 0)
@@ -576,6 +576,17 @@ class FitsSink:
                 os.posix_fallocate(self.fd, 0, size)
             except OSError:
                 os.ftruncate(self.fd, size)
+            # The strips arrive as one piece per plane (rows x nx samples): with the 64-row strips of a 2 GiB test budget that is
+            # 256 KiB per os.pwrite, 32768 calls for 8 GiB, each under the file's write lock: 4.7 GB/s where 64 MiB writes reach
+            # 15 - 20 GB/s on the same file system (tests/bench_filewrite.py, bench_stream_parts.py).  A shared mapping
+            # (SPC_FITS_SINK_MMAP=1) lets the writer threads copy side by side, but a fresh file then costs a page-cache fault
+            # per 4 KiB: 4.1 GB/s - no better, so the pwrite form stays the default.  The pieces grow with the strip: a cube
+            # that is out of core for 288 GB of HBM has strips of hundreds of rows (10+ MiB per piece).
+            self.map = None
+            if os.environ.get("SPC_FITS_SINK_MMAP", "0") == "1":
+                import mmap
+                self.mm = mmap.mmap(self.fd, size, access=mmap.ACCESS_WRITE)
+                self.map = np.frombuffer(self.mm, dtype=np.uint8)
         except BaseException:
             self.abort()
             raise
@@ -583,14 +594,30 @@ class FitsSink:
     def write(self, view_u8, z0, z1, y0, y1):
         nz, ny, nx = self.shape
         seg = (y1 - y0) * nx * 4
+        if self.map is not None:
+            src = np.frombuffer(view_u8, dtype=np.uint8, count=(z1 - z0) * seg)
+            for k, z in enumerate(range(z0, z1)):
+                off = self.base + (z * ny + y0) * nx * 4
+                np.copyto(self.map[off:off + seg], src[k * seg:(k + 1) * seg])
+            return
         mv = memoryview(view_u8)
         for k, z in enumerate(range(z0, z1)):
             part, done, off = mv[k * seg:(k + 1) * seg], 0, self.base + (z * ny + y0) * nx * 4
             while done < seg:
                 done += os.pwrite(self.fd, part[done:], off + done)
 
+    def _unmap(self):
+        if getattr(self, "map", None) is not None:
+            self.map = None
+            try:
+                self.mm.close()
+            except (BufferError, ValueError):
+                pass
+            self.mm = None
+
     def close(self, ok=True):
         if self.fd is not None:
+            self._unmap()
             os.close(self.fd)
             self.fd = None
             if ok:
@@ -600,6 +627,7 @@ class FitsSink:
 
     def abort(self):
         if self.fd is not None:
+            self._unmap()
             os.close(self.fd)
             self.fd = None
         try:

@@ -16,7 +16,10 @@ rng = np.random.default_rng(0)
 d8 = (rng.standard_normal((8, ny, nx)) + 1.0).astype(np.float32)
 hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-4, "CDELT2": 1e-4, "CDELT3": 500.0, "CUNIT3": "m/s",
        "CRPIX1": 1.0, "CRPIX2": 1.0, "CRPIX3": 1.0, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": 0.0, "BUNIT": "K"}
-tmp = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+# SPC_BENCH_DIR: where the FITS files live (default /dev/shm; tmpfs on the GPU box takes os.pwrite at 7.5 GB/s into a fresh file,
+# its /tmp - a disk-backed file system, page cache - at 15 - 20 GB/s: tests/bench_filewrite.py)
+_base = os.environ.get("SPC_BENCH_DIR", "/dev/shm" if os.path.isdir("/dev/shm") else None)
+tmp = tempfile.mkdtemp(dir=_base)
 path = os.path.join(tmp, "cube.fits")
 with open(path, "wb") as f:
     cards = [io_fits._card("SIMPLE", True), io_fits._card("BITPIX", -32), io_fits._card("NAXIS", 3), io_fits._card("NAXIS1", nx),
