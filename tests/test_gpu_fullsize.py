@@ -159,6 +159,22 @@ def test_c4_spatial_smooth_moment0_4096x2048x2048(gpu):
         got_planes[z] = row[:, :160]
     assert_close(got_planes, exp_sm, atol=1e-5 * np.nanmax(np.abs(exp_sm)), what="C4 smoothed planes")
     assert_close(m0[:96, :160], exp_m0, atol=1e-5 * np.nanmax(np.abs(exp_m0)), what="C4 moment0")
+    # round 4: the same pipeline FUSED on the matrix cores (the smoothed cube never written): the whole 2048 x 2048 map against the
+    # materialised one (the two share nothing but the inputs), the window against the oracle, and the size-independent properties of the
+    # construction - planes repeat with period 2, so the map is (nz / 2) x the map of a 2-plane cube, and the map of the first half of
+    # the channels is exactly half of it in every spaxel both halves see
+    del sm
+    _, m0f = ops.spatial_conv_mfma(cube, k2, mask=mspec, want_cube=False, want_m0=True, dv=500.0)
+    m0f = m0f.get()
+    assert_close(m0f[:96, :160], exp_m0, atol=1e-5 * np.nanmax(np.abs(exp_m0)), what="C4 fused moment0 vs oracle")
+    assert_close(m0f, m0, atol=1e-5 * np.nanmax(np.abs(m0)), what="C4 fused vs materialised, whole map")
+    _, m2p = ops.spatial_conv_mfma(cube.planes(0, 2), k2, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mask.planes(0, 2)), want_cube=False,
+                                   want_m0=True, dv=500.0)
+    assert_close(m0f, (shape[0] // 2) * m2p.get(), atol=1e-5 * np.nanmax(np.abs(m0)), what="C4 fused: periodicity in z")
+    half = shape[0] // 2
+    _, mh = ops.spatial_conv_mfma(cube.planes(0, half), k2, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mask.planes(0, half)), want_cube=False,
+                                  want_m0=True, dv=500.0)
+    assert_close(2.0 * mh.get(), m0f, atol=1e-5 * np.nanmax(np.abs(m0)), what="C4 fused: additivity over channel halves")
 
 
 def test_c5_spectral_interpolate_2048_to_4096(gpu):
