@@ -18,6 +18,9 @@
 #ifndef SPC_SEL_INFLIGHT
 #define SPC_SEL_INFLIGHT 8
 #endif
+#ifndef SPC_SEL_INFLIGHT_WIDE
+#define SPC_SEL_INFLIGHT_WIDE 32
+#endif
 
 namespace {
 
@@ -398,7 +401,10 @@ __device__ __forceinline__ int sel_load_keys_impl(const float* cube, int64_t pla
     // loads in flight per lane: the raw samples land in the key registers themselves (converted in place), so a whole
     // group costs no registers beyond the mask bytes.  Round 2 / 3a kept 8 in flight (2 KB per wave, 40 KB per CU): the
     // load phase ran at 2.1 TB/s - latency-bound - and made up 2.0 of the kernel's 2.9 ms at 1024^3.
-    constexpr int U = KPL < SPC_SEL_INFLIGHT ? KPL : SPC_SEL_INFLIGHT;
+    // 512-thread blocks (round 4, tests/bench_select_bt.py at 1024^3): 16 / 32 / 64 in flight - no mask 1.95 / 1.87 / 1.93 ms against 2.00,
+    // uint8 mask 2.18 / 2.33 ms against 2.24 (its bytes wait in registers of their own); the 256-thread table loses with more than 8.
+    constexpr int kWant = BT == 512 ? (ARR ? 16 : SPC_SEL_INFLIGHT_WIDE) : SPC_SEL_INFLIGHT;
+    constexpr int U = KPL < kWant ? KPL : kWant;
     constexpr int kChk0 = (KPL == 16) ? 0 : KPL / 2;             // first slot that can run past the last plane
     int mine = 0;
     const uint32_t span_l = col_in ? span1 : 0u;
