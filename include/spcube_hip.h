@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 4
+#define SPC_ABI_VERSION 5
 
 typedef enum {
     SPC_OK = 0,
@@ -193,6 +193,48 @@ int spc_moment_order_f32(int device, void* stream, const spc_cube_f32* cube,
                          const double* d_mu, const double* d_s0, double* d_out,
                          int64_t out_row_stride);
 
+/* ---- float64 cubes: moments along the spectral axis in the SOURCE's precision ------------------
+ * The reference keeps a float64 source in float64 (np.result_type(dtype, 0.0), spectral_cube/masks.py:225; a
+ * BITPIX = -64 / 32 / 64 FITS image arrives as float64 through astropy, io/fits.py:63-172) and so are its moment maps
+ * (spectral_cube/_moments.py:30-193, dask_spectral_cube.py:1083-1104).  Same arguments and outputs as spc_moments_f32 /
+ * spc_moment_order_f32 with 8-byte samples, float64 thresholds and float64 extrema; no workspace.  There is no d_m2:
+ * moment 2 is spc_moment_order_f64(order = 2) about the first pass's d_mu - the reference's own two-pass form
+ * (_moments.py:185-193), which keeps float64 precision where S2 / S0 - mu^2 would not.  nz < 2^21. */
+typedef struct {
+    const double* d_data;
+    int64_t nz, ny, nx;
+    int64_t row_stride;          /* elements */
+    int64_t plane_stride;        /* elements */
+} spc_cube_f64;
+
+typedef struct {
+    uint32_t flags;              /* SPC_MASK_* */
+    double thr_lo;
+    double thr_hi;
+    const uint8_t* d_array;
+    int64_t row_stride;          /* elements; 0 = same as the cube's */
+    int64_t plane_stride;        /* elements; 0 = same as the cube's */
+} spc_mask_f64;
+
+typedef struct {
+    double* d_m0; double* d_m1;                 /* (ny,nx) float64 */
+    double* d_mu;      /* S1/S0 without m1_add (input of spc_moment_order_f64) */
+    double* d_s0;      /* raw S0 */
+    int64_t* d_argmax; int64_t* d_argmin;       /* (ny,nx) int64 */
+    double* d_vmax; double* d_vmin;             /* max/min over valid voxels (NaN if none) */
+    int32_t* d_nvalid;
+    int64_t out_row_stride;                     /* elements; 0 = nx */
+} spc_moment_outputs_f64;
+
+int spc_moments_f64(int device, void* stream, const spc_cube_f64* cube,
+                    const spc_mask_f64* mask, const double* d_cen, double dv,
+                    double m1_add, const spc_moment_outputs_f64* out);
+
+int spc_moment_order_f64(int device, void* stream, const spc_cube_f64* cube,
+                         const spc_mask_f64* mask, const double* d_cen, int order,
+                         const double* d_mu, const double* d_s0, double* d_out,
+                         int64_t out_row_stride);
+
 /* ---- FITS payload -> float32 -------------------
  * Converts n raw big-endian FITS image samples (already in HBM) to native
  * float32: what astropy.io.fits does on the host behind
@@ -203,6 +245,12 @@ int spc_moment_order_f32(int device, void* stream, const spc_cube_f32* cube,
 int spc_fits_to_f32(int device, void* stream, const void* d_raw, int bitpix,
                     double bscale, double bzero, int has_blank, int64_t blank,
                     int64_t n, float* d_out);
+
+/* The wide sample types in their own precision: bitpix in {-64, 32, 64} -> native float64 (what astropy hands the
+ * reference for such an image, spectral_cube/io/fits.py:63-172); feeds spc_moments_f64. */
+int spc_fits_to_f64(int device, void* stream, const void* d_raw, int bitpix,
+                    double bscale, double bzero, int has_blank, int64_t blank,
+                    int64_t n, double* d_out);
 
 /* d_data[i] *= factor over n contiguous floats: the Jy/beam rescaling by the ratio of beam
  * areas in convolve_to (spectral_cube/dask_spectral_cube.py:1450-1457). */

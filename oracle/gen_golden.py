@@ -1020,6 +1020,71 @@ def case_fits_files():
     print("fits files ok")
 
 
+def case_moments_f64():
+    """wide sources.  A BITPIX = -64 cube whose line sits on a baseline float32 cannot resolve
+    (1000 K + a 2 mK .. 1 K line: one float32 ulp at 1000 is 61 uK), and a BITPIX = 32 cube with BSCALE / BZERO (astropy
+    scales it to float64): the reference keeps both in float64 (masks.py:225) and its moments are float64 sums of float64
+    samples (_moments.py:30-193, dask_spectral_cube.py:1083-1104).  Stored: the two files as astropy wrote them and the
+    reference's moment 0 / 1 / 2 / 3, argmax / argmin and max along the spectral axis, NumPy and Dask back-ends, without and
+    with a `> threshold` mask whose threshold float32 cannot represent either."""
+    import io
+    rng = np.random.default_rng(640)
+    nz, ny, nx = 40, 7, 10
+    h = c1_header(nz, ny, nx)
+    z = np.arange(nz)[:, None, None]
+    amp = 10.0 ** rng.uniform(-2.7, 0.0, size=(ny, nx))
+    z0 = rng.uniform(8, 32, size=(ny, nx))
+    sig = rng.uniform(1.5, 4.0, size=(ny, nx))
+    d64 = 1000.0 + amp * np.exp(-0.5 * ((z - z0) / sig) ** 2) + 2e-4 * rng.standard_normal((nz, ny, nx))
+    d64[3:6, 2, 4] = np.nan
+    d64[:, 5, 1] = np.nan                                     # a ray without a sample
+    store = {}
+
+    def write(name, hdu):
+        buf = io.BytesIO()
+        hdu.writeto(buf)
+        store[name + "_file"] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+        return buf.getvalue()
+
+    raw64 = write("f64", fits.PrimaryHDU(data=d64, header=h))
+    i32 = rng.integers(-2**31 + 1, 2**31 - 1, size=(nz, ny, nx)).astype(np.int32)
+    i32[:, 0, 0] = -2**31
+    hdu = fits.PrimaryHDU(data=i32, header=h)
+    hdu.header["BSCALE"], hdu.header["BZERO"], hdu.header["BLANK"] = 1e-9, 3.0, -2**31
+    raw32 = write("i32", hdu)
+    thr = {"f64": 1000.0003, "i32": 2.9000000001}
+    for name, raw in (("f64", raw64), ("i32", raw32)):
+        for use_dask in (False, True):
+            with fits.open(io.BytesIO(raw)) as hl:
+                sc = SpectralCube.read(hl, use_dask=use_dask)
+                assert np.asarray(val(sc.unmasked_data[:])).dtype.itemsize == 8 and sc._data.dtype.kind == "f"
+                for masked in (False, True):
+                    c = sc.with_mask(sc > thr[name] * u.K) if masked else sc
+                    tag = "%s_%s_%s" % (name, "m" if masked else "u", "dask" if use_dask else "np")
+                    for order in range(4):
+                        store["mom%d_%s" % (order, tag)] = np.asarray(val(c.moment(order=order, axis=0)), dtype=np.float64)
+                    store["argmax_" + tag] = np.asarray(c.argmax(axis=0))
+                    store["argmin_" + tag] = np.asarray(c.argmin(axis=0))
+                    store["max_" + tag] = np.asarray(val(c.max(axis=0)), dtype=np.float64)
+                    if not use_dask:
+                        data = np.asarray(val(sc.unmasked_data[:]))
+                        store["data_" + name] = data
+                        include = np.asarray(c.mask.include())
+                        cen, size, world0 = hot_inputs(c)
+                        store["cen0"], store["size0"], store["world0"] = cen[0], size[0], world0
+                        for order in range(4):
+                            mine = O.moment(data, include, order, cen[0], size[0], axis=0, world0=world0)
+                            close(mine, store["mom%d_%s" % (order, tag)], rtol=1e-10 if order < 3 else 1e-8, atol=1e-12, what="oracle f64 " + tag)
+        # NumPy and Dask back-ends agree to float64 rounding
+        for masked in "um":
+            for order in range(4):
+                close(store["mom%d_%s_%s_np" % (order, name, masked)], store["mom%d_%s_%s_dask" % (order, name, masked)], rtol=1e-9, atol=1e-12,
+                      what="np vs dask")
+    store["thr_f64"], store["thr_i32"] = thr["f64"], thr["i32"]
+    np.savez_compressed(os.path.join(OUT, "moments_f64.npz"), **store)
+    print("moments_f64 ok")
+
+
 def case_order_statistics():
     """median / percentile / mad_std along the spectral axis of the Dask class on a masked fp32
     cube with NaNs, fully masked rays, odd and even valid counts."""
@@ -1148,7 +1213,7 @@ def case_beams_cube():
 
 if __name__ == "__main__":
     cases = [case_beams_cube, case_moment_cube, case_c1, case_adv_argmax, case_smooth, case_interp, case_kernels,
-             case_wcs, case_wcs_frames, case_wcs_fk4, case_wcs_projections, case_wcs_strict, case_bilinear_scipy, case_reproject_glue_scipy, case_reproject_spline_scipy, case_statistics, case_fits_files,
+             case_wcs, case_wcs_frames, case_wcs_fk4, case_wcs_projections, case_wcs_strict, case_bilinear_scipy, case_reproject_glue_scipy, case_reproject_spline_scipy, case_statistics, case_fits_files, case_moments_f64,
              case_order_statistics, case_sigma_clip]
     only = set(sys.argv[1:])                 # e.g. `gen_golden.py case_reproject_glue_scipy` regenerates one fixture
     for fn in cases:

@@ -22,7 +22,7 @@ SPC_ERR_COMM = -5
 MASK_NONE, MASK_ARRAY, MASK_FINITE = 0, 1, 2
 MASK_GT, MASK_GE, MASK_LT, MASK_LE = 4, 8, 16, 32
 COMM_ID_BYTES = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
@@ -58,6 +58,19 @@ class SpcMomentOutputs(C.Structure):
                 ("d_mu", C.c_void_p), ("d_s0", C.c_void_p),
                 ("d_argmax", C.c_void_p), ("d_argmin", C.c_void_p),
                 ("d_vmax", C.c_void_p), ("d_vmin", C.c_void_p),
+                ("d_nvalid", C.c_void_p), ("out_row_stride", C.c_int64)]
+
+
+class SpcMask64(C.Structure):
+    """spc_mask_f64: the mask of a float64 cube (thresholds compared in float64)"""
+    _fields_ = [("flags", C.c_uint32), ("thr_lo", C.c_double), ("thr_hi", C.c_double),
+                ("d_array", C.c_void_p), ("row_stride", C.c_int64), ("plane_stride", C.c_int64)]
+
+
+class SpcMomentOutputs64(C.Structure):
+    """spc_moment_outputs_f64 (no d_m2: moment 2 of a float64 cube is the second pass, spc_moment_order_f64)"""
+    _fields_ = [("d_m0", C.c_void_p), ("d_m1", C.c_void_p), ("d_mu", C.c_void_p), ("d_s0", C.c_void_p),
+                ("d_argmax", C.c_void_p), ("d_argmin", C.c_void_p), ("d_vmax", C.c_void_p), ("d_vmin", C.c_void_p),
                 ("d_nvalid", C.c_void_p), ("out_row_stride", C.c_int64)]
 
 
@@ -128,6 +141,9 @@ SIGNATURES = {
     "spc_moments_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _vp, _d, _d,
                              _P(SpcMomentOutputs), _vp, _sz]),
     "spc_moment_order_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _vp, _i, _vp, _vp, _vp, _i64]),
+    # (spc_cube_f64 has the layout of spc_cube_f32: a pointer and five int64)
+    "spc_moments_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _vp, _d, _d, _P(SpcMomentOutputs64)]),
+    "spc_moment_order_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _vp, _i, _vp, _vp, _vp, _i64]),
     "spc_moments_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _d, _vp, _vp, _vp]),
     "spc_moment_order_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _i, _vp, _vp]),
     "spc_spectral_conv_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _i64, _i64, _vp, _sz]),
@@ -150,6 +166,7 @@ SIGNATURES = {
     "spc_map_arith_f64": (_i, [_i, _vp, _i, _vp, _vp, _vp, _d, _vp, _i64]),
     "spc_scale_f32": (_i, [_i, _vp, _vp, _i64, _d]),
     "spc_fits_to_f32": (_i, [_i, _vp, _vp, _i, _d, _d, _i, _i64, _i64, _vp]),
+    "spc_fits_to_f64": (_i, [_i, _vp, _vp, _i, _d, _d, _i, _i64, _i64, _vp]),
     "spc_stats_global_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _vp, _sz]),
     "spc_stats_axis_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _P(SpcStatsOutputs)]),
     "spc_comm_unique_id": (_i, [_P(C.c_uint8)]),

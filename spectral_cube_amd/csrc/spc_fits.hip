@@ -115,6 +115,48 @@ extern "C" int spc_fits_to_f32(int device, void* stream, const void* d_raw, int 
     return SPC_OK;
 }
 
+// ---- the wide sample types in their own precision: BITPIX = -64 / 32 / 64 -> float64 (what astropy hands the reference:
+// float64 for -64, and raw * BSCALE + BZERO in float64 - or the integers, which np.result_type(dtype, 0.0) makes float64 in
+// masks.py:225 - for 32 / 64).  Feeds spc_moments_f64.
+namespace {
+__global__ __launch_bounds__(256) void fits_to_f64_kernel(const FitsArgs A, double* out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < A.n; i += stride) {
+        double v;
+        if (A.bitpix == -64) {
+            v = __longlong_as_double((long long)__builtin_bswap64(__builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(A.raw) + i)));
+        } else {
+            const int64_t r = A.bitpix == 32 ? (int64_t)(int32_t)__builtin_bswap32(reinterpret_cast<const uint32_t*>(A.raw)[i])
+                                             : (int64_t)__builtin_bswap64(reinterpret_cast<const uint64_t*>(A.raw)[i]);
+            if (A.has_blank && r == A.blank) { out[i] = nan; continue; }
+            v = (double)r;
+        }
+        if (A.scaled) { v *= A.bscale; v += A.bzero; }
+        out[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int spc_fits_to_f64(int device, void* stream, const void* d_raw, int bitpix, double bscale,
+                               double bzero, int has_blank, int64_t blank, int64_t n, double* d_out) {
+    SPC_REQUIRE(d_raw && d_out, "NULL pointer argument");
+    SPC_REQUIRE(n >= 0, "negative sample count");
+    SPC_REQUIRE(bitpix == 32 || bitpix == 64 || bitpix == -64, "BITPIX must be one of 32, 64, -64 (got %d)", bitpix);
+    if (n == 0) return SPC_OK;
+    SPC_DEVICE(device);
+    FitsArgs A{};
+    A.raw = (const uint8_t*)d_raw; A.out = nullptr; A.n = n; A.bitpix = bitpix;
+    A.bscale = bscale; A.bzero = bzero;
+    A.scaled = (bscale != 1.0 || bzero != 0.0) ? 1 : 0;
+    A.has_blank = (has_blank && bitpix > 0) ? 1 : 0;
+    A.blank = blank;
+    const unsigned nblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (n + 1023) / 1024));
+    hipLaunchKernelGGL(fits_to_f64_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, A, d_out);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
 
 // out[i] *= factor over n contiguous floats (the Jy/beam rescaling of convolve_to,
 // spectral_cube/dask_spectral_cube.py:1450-1457); NaNs stay NaNs.

@@ -46,25 +46,59 @@ class VarianceWarning(UserWarning):
 
 class PrecisionWarning(UserWarning):
     """the source holds samples float32 cannot represent exactly (a float64 array, a BITPIX = -64 / 32 / 64 FITS image): the
-    reference keeps such a cube in float64 (``np.result_type(dtype, 0.0)``, masks.py:225); the HIP path stages every cube
-    as float32 (sums are carried in float64, the SAMPLES are rounded to 24 bits: ~6e-8 relative per sample, inside the 1e-5
-    contract of the float32 configurations, but not the reference's float64 result).  Raised once per cube."""
+    reference keeps such a cube in float64 (``np.result_type(dtype, 0.0)``, masks.py:225).  The moments along the spectral
+    axis (moment 0 / 1 / 2 / N, argmax / argmin, moments012) of a resident cube are computed from the float64 samples
+    (spc_moments_f64); every other operator stages the cube as float32 (sums are carried in float64, the SAMPLES are
+    rounded to 24 bits: ~6e-8 relative per sample, inside the 1e-5 contract of the float32 configurations, but not the
+    reference's float64 result).  Raised once per source, the first time its samples are narrowed."""
 
 
 _NARROWED = "%s samples are narrowed to float32 on their way to HBM (the reference would keep float64, masks.py:225): results " \
             "agree with a float64 computation to ~1e-7 relative, not to float64 precision"
 
 
-def _warn_if_narrowed(dtype=None, bitpix=None):
+def _is_wide_dtype(dtype):
+    dt = np.dtype(dtype)
+    return (dt.kind == "f" and dt.itemsize > 4) or (dt.kind in "iu" and dt.itemsize >= 4)
+
+
+def _warn_if_narrowed(dtype=None, bitpix=None, stacklevel=3):
     if dtype is not None:
-        dt = np.dtype(dtype)
-        wide = (dt.kind == "f" and dt.itemsize > 4) or (dt.kind in "iu" and dt.itemsize >= 4)
-        what = str(dt)
+        wide, what = _is_wide_dtype(dtype), str(np.dtype(dtype))
     else:
         wide = bitpix in (-64, 32, 64)
         what = "BITPIX = %s" % bitpix
     if wide:
-        warnings.warn(_NARROWED % what, PrecisionWarning, stacklevel=3)
+        warnings.warn(_NARROWED % what, PrecisionWarning, stacklevel=stacklevel)
+
+
+class _DataToken:
+    """identity of a cube's voxel values, shared by the cubes derived from it without touching them (with_mask,
+    with_fill_value, with_spectral_unit): lazy masks compare it (``_is_same_data``), and a wide source keeps what its
+    float64 path needs here - the FITS image the samples come from, the float64 device copy, whether the narrowing to
+    float32 has been announced."""
+    __slots__ = ("wide_file", "dev64", "warned")
+
+    def __init__(self):
+        self.wide_file = None        # (path, hdu, bitpix) of a resident BITPIX = -64 / 32 / 64 image
+        self.dev64 = None            # float64 DeviceArray, staged by the first spectral moment
+        self.warned = False
+
+
+class _WideView:
+    """what a mask is lowered against for the float64 kernels: the cube's identity (lazy masks bound to the cube stay
+    device terms), ``_wide`` (comparison thresholds keep their float64 value: numpy compares a float64 cube in float64),
+    and the float64 samples for the terms that are evaluated on the host"""
+    _wide = True
+
+    def __init__(self, cube):
+        self._cube, self._data_id = cube, cube._data_id
+
+    def _host_data(self):
+        c = self._cube
+        if c._data_id.wide_file is None:
+            return c._data
+        return c._device_data64().get()
 
 
 class SmoothingWarning(UserWarning):
@@ -229,8 +263,6 @@ class SpectralCube:
             data = np.asarray(data)
             if data.ndim != 3:
                 raise ValueError("SpectralCube needs a 3-D (spectral, y, x) array")
-            if _data_id is None:              # (once per source: cubes derived from it share its data id)
-                _warn_if_narrowed(dtype=data.dtype)
         self._data = data                 # host ndarray or None
         self._dev = _dev                  # DeviceArray float32 or None
         self._lazy = _lazy                # pending (op, parent, args) - see spectral_smooth
@@ -258,7 +290,8 @@ class SpectralCube:
         # cubes that share the same voxel values (with_mask, with_fill_value) share
         # this token; lazy masks use it to decide whether their predicate may be
         # evaluated by the kernel on the data it is reading
-        self._data_id = _data_id if _data_id is not None else object()
+        self._data_id = _data_id if _data_id is not None else _DataToken()
+        self._mask64_cache = None
 
     # ---- construction helpers ------------------------------------------------
     @classmethod
@@ -271,9 +304,9 @@ class SpectralCube:
             from . import io_fits, streaming
             img = io_fits.find_image(os.fspath(data), hdu)
             fshape = tuple(io_fits.cube_shape(img))
-            _warn_if_narrowed(bitpix=img.bitpix)
             _lib.require_gpu()
             if 4 * int(np.prod(fshape, dtype=np.int64)) > streaming.hbm_budget(device):
+                _warn_if_narrowed(bitpix=img.bitpix)         # the strips are staged as float32
                 # larger than the HBM budget: the cube stays in the file and goes through the device in row
                 # strips (streaming.py; the role of _moments.py:89-125 / cube_utils.py:277-301 in the reference)
                 src = streaming.FitsSource(os.fspath(data), hdu)
@@ -289,14 +322,26 @@ class SpectralCube:
                 beam_mask = cube._mask if isinstance(cube, VaryingResolutionSpectralCube) else None
                 cube._mask = finite if beam_mask is None else (finite & beam_mask)
                 return cube
-            dev, hdr = io_fits.load_cube(os.fspath(data), device=device, hdu=hdu)
+            wide = img.bitpix in (-64, 32, 64)
+            if wide:
+                # samples float32 cannot hold: nothing is staged yet - the spectral moments read the image as float64
+                # (_device_data64), any other operator as float32 (with a PrecisionWarning), whichever comes first
+                dev, hdr = None, io_fits.cube_header(img)
+            else:
+                dev, hdr = io_fits.load_cube(os.fspath(data), device=device, hdu=hdu)
             meta = dict(kw.pop("meta", None) or {})
             if "BUNIT" in hdr:
                 meta["BUNIT"] = hdr["BUNIT"]
-            table = cls._beams_table_for(os.fspath(data), dev.shape[0]) if "beams" not in kw else None
+            table = cls._beams_table_for(os.fspath(data), fshape[0]) if "beams" not in kw else None
             if table is not None:            # a BEAMS extension makes it a varying-resolution cube (io/fits.py:216-228)
                 cls, kw = VaryingResolutionSpectralCube, dict(kw, beam_table=table)
-            cube = cls(None, header=hdr, device=device, _dev=dev, meta=meta, **kw)
+            if wide:
+                path_, hdu_ = os.fspath(data), hdu
+                cube = cls(None, header=hdr, device=device, meta=meta, _shape=fshape,
+                           _lazy=lambda: io_fits.load_cube(path_, device=device, hdu=hdu_)[0], **kw)
+                cube._data_id.wide_file = (path_, hdu_, img.bitpix)
+            else:
+                cube = cls(None, header=hdr, device=device, _dev=dev, meta=meta, **kw)
         else:
             cube = cls(np.asarray(data), header=header, device=device, **kw)
         finite = M.LazyMask(np.isfinite, cube=cube)
@@ -540,6 +585,7 @@ class SpectralCube:
     def _device_data(self):
         """float32 DeviceArray of the cube values (uploads / materialises lazily)."""
         if self._dev is None:
+            self._note_narrowed()
             if self._lazy is not None:
                 self._dev = self._lazy()
                 self._lazy = None
@@ -556,6 +602,55 @@ class SpectralCube:
                         % (nbytes / 2**30, streaming.hbm_budget(self.device) / 2**30))
                 self._dev = DeviceArray.from_numpy(self._data, self.device, dtype=np.float32)
         return self._dev
+
+    # ---- wide sources (float64 arrays, BITPIX = -64 / 32 / 64 images): the spectral moments in their own precision ------
+    def _is_wide(self):
+        if self._data_id.wide_file is not None:
+            return True
+        return self._data is not None and _is_wide_dtype(self._data.dtype)
+
+    def _note_narrowed(self, stacklevel=4):
+        """PrecisionWarning, once per source, when a wide source is about to be used as float32"""
+        tok = self._data_id
+        if tok.warned or not self._is_wide():
+            return
+        tok.warned = True
+        if tok.wide_file is not None:
+            _warn_if_narrowed(bitpix=tok.wide_file[2], stacklevel=stacklevel)
+        else:
+            _warn_if_narrowed(dtype=self._data.dtype, stacklevel=stacklevel)
+
+    def _wide_resident(self):
+        """True when the spectral moments of this cube run on its float64 samples: a wide source whose values this cube
+        still is (no pending operator) and whose float64 copy fits the HBM budget"""
+        if not self._is_wide() or (self._lazy is not None and self._data_id.wide_file is None):
+            return False
+        if self._data_id.dev64 is not None:
+            return True
+        from . import streaming
+        return 8 * int(np.prod(self._shape, dtype=np.int64)) <= streaming.hbm_budget(self.device)
+
+    def _device_data64(self):
+        """float64 DeviceArray of a wide source (uploaded / decoded from the FITS image once, shared by the cubes that share
+        the data)"""
+        tok = self._data_id
+        if tok.dev64 is None:
+            _lib.require_gpu()
+            if tok.wide_file is not None:
+                from . import io_fits
+                path, hdu, _ = tok.wide_file
+                tok.dev64 = io_fits.load_cube(path, device=self.device, hdu=hdu, dtype=np.float64)[0]
+            else:
+                tok.dev64 = DeviceArray.from_numpy(self._data, self.device, dtype=np.float64)
+        return tok.dev64
+
+    def _mask_spec64(self):
+        """the mask lowered for the float64 kernels: thresholds in float64, host-evaluated terms on the float64 samples"""
+        if self._mask64_cache is None:
+            flags, lo, hi, arr = M.lower_mask(self._mask, _WideView(self), self._shape)
+            darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
+            self._mask64_cache = ops.MaskSpec(flags, lo, hi, darr)
+        return self._mask64_cache
 
     def _mask_spec(self):
         """lower the mask tree once and keep the uint8 array resident in HBM."""
@@ -613,6 +708,11 @@ class SpectralCube:
         spec0 = self.spectral_axis[0]
         d_cen = DeviceArray.from_numpy(cen - cref, self.device)
         dv = self._pix_size_slice(0)
+        if fused_kernel is None and self._wide_resident():
+            # a float64 source: its own precision (the reference's maps are float64 sums of float64 samples)
+            return ops.moments_f64(self._device_data64(), d_cen, dv=dv, m1_add=cref + spec0, mask=self._mask_spec64(), want=want)
+        if fused_kernel is None and self._is_wide():
+            self._note_narrowed()
         if fused_kernel is not None and fused_kernel[0]._stream_source() is not None:
             from . import streaming                     # out-of-core parent: the fused kernels, strip by strip
             try:
@@ -754,8 +854,10 @@ class SpectralCube:
                 cen = self._pix_cen_axis(0)
                 cref = cen[self._shape[0] // 2]
                 d_cen = DeviceArray.from_numpy(cen - cref, self.device)
-                out = ops.moment_order(self._device_data(), d_cen, order, r["mu"], r["s0"],
-                                       mask=self._mask_spec()).get()
+                if self._wide_resident():
+                    out = ops.moment_order_f64(self._device_data64(), d_cen, order, r["mu"], r["s0"], mask=self._mask_spec64()).get()
+                else:
+                    out = ops.moment_order(self._device_data(), d_cen, order, r["mu"], r["s0"], mask=self._mask_spec()).get()
                 # dv cancels: sum(I dv (c-M1)^N) / sum(I dv)
             axunit = self.spectral_unit
         else:

@@ -181,8 +181,9 @@ class Staging:
 
 
 def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, readers=8, stats=None, rows=None,
-              staging=None):
-    """Stream the image payload of *path* into a (nz, ny, nx) float32 DeviceArray.
+              staging=None, dtype=np.float32):
+    """Stream the image payload of *path* into a (nz, ny, nx) float32 DeviceArray (``dtype=np.float64``: a BITPIX = -64 / 32 /
+    64 image in its own precision, spc_fits_to_f64 - what astropy hands the reference, io/fits.py:63-172).
 
     chunk_bytes / nbuffers: size and count of the pinned staging buffers; readers: threads
     filling them with os.preadv; rows=(y0, y1): load only that row strip of every plane (the
@@ -203,7 +204,10 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
     bps = _BYTES[img.bitpix]
     if staging is not None:
         chunk_bytes, nbuffers = staging.chunk_bytes, staging.nbuffers
-    out = DeviceArray((nz, ny, nx), np.float32, device)
+    wide = np.dtype(dtype) == np.float64
+    if wide and img.bitpix not in (-64, 32, 64):
+        raise ValueError("dtype=float64 is for BITPIX = -64 / 32 / 64 images (this one: %d)" % img.bitpix)
+    out = DeviceArray((nz, ny, nx), np.float64 if wide else np.float32, device)
     seg = ny * nx * bps                                # one plane's strip: contiguous in the file
     total = nz * seg
     if rows is None:                                   # whole planes: the payload is ONE contiguous run
@@ -271,9 +275,9 @@ def load_cube(path, device=0, hdu=None, chunk_bytes=128 << 20, nbuffers=8, reade
                 ev.record(stream)
                 b.free_evt = ev
                 first = (i * chunk) // bps
-                _lib.call("spc_fits_to_f32", device, stream.handle, C.c_void_p(raw.ptr), img.bitpix,
+                _lib.call("spc_fits_to_f64" if wide else "spc_fits_to_f32", device, stream.handle, C.c_void_p(raw.ptr), img.bitpix,
                           img.bscale, img.bzero, 1 if has_blank else 0, int(img.blank) if has_blank else 0,
-                          n // bps, C.c_void_p(out.ptr + first * 4))
+                          n // bps, C.c_void_p(out.ptr + first * (8 if wide else 4)))
                 if nxt < nchunks:
                     submit(nxt)
                     nxt += 1

@@ -185,6 +185,10 @@ class LazyComparisonMask(LazyMask):
             weak = type(self._value) in (float, int)
             if v != v:
                 return None          # a NaN threshold includes nothing: left to the host form (all False)
+            if getattr(data, "_wide", False):
+                # the float64 kernels (cube._mask_spec64): float64 samples against a float64 threshold, as numpy compares them
+                flag = _CMP[self._cmp]
+                return (flag, v, np.inf, None) if flag in (_lib.MASK_GT, _lib.MASK_GE) else (flag, -np.inf, v, None)
             if weak or float(np.float32(v)) == v or not np.isfinite(v):
                 v = float(np.float32(v))          # +-inf stay +-inf: `cube > -inf` is a real comparison
                 flag = _CMP[self._cmp]

