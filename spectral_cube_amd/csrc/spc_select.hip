@@ -18,6 +18,9 @@
 #ifndef SPC_SEL_INFLIGHT
 #define SPC_SEL_INFLIGHT 8
 #endif
+#ifndef SPC_SEL_FIRST_VOTE
+#define SPC_SEL_FIRST_VOTE 1
+#endif
 #ifndef SPC_SEL_INFLIGHT_WIDE
 #define SPC_SEL_INFLIGHT_WIDE 32
 #endif
@@ -498,6 +501,8 @@ struct SelShared {
     uint32_t nvalid[TS], nextkey[TS], ncand[TS], sel_key[TS], sel_below[TS], sel_eq[TS], nlow[TS];
     uint32_t cand[TS][kCandMax];
     int level;                                                  // (SelCache: the pass a descent resumes after)
+    int vote[8];                                                // "a ray's bin is too large to rank" after pass p / [7]: at the resume
+    int narrow;                                                 // a ray keeps > 3/4 of its samples in one leading digit: no early votes
 };
 
 // The histograms an earlier descent over the SAME keys counted in its first four passes (4, 8, 12, 16 key bits), per ray, each with
@@ -511,6 +516,7 @@ struct SelCache {
     uint16_t hist[4][TS][16];
     uint32_t pre[4][TS];
     uint32_t prefix[4][TS], below[4][TS], eq[4][TS], krel[4][TS];
+    int first_done;                                             // the pass after which the FIRST descent ranked its candidates (block-wide)
 };
 
 // every thread of the block: zero what a descent needs (followed by a barrier at the caller)
@@ -519,6 +525,8 @@ __device__ __forceinline__ void sel_reset(SelShared<TS>& S) {
     const int t = threadIdx.x;
     if (t < TS) { S.nvalid[t] = 0u; S.nextkey[t] = 0xffffffffu; S.ncand[t] = 0u; S.nlow[t] = 0u; }
     if (t == 0) S.level = 3;
+    if (t < 8) S.vote[t] = 0;
+    if (t == 8) S.narrow = 0;
     for (int i = t; i < 3 * TS * 16; i += BT) (&S.hist[0][0][0])[i] = 0u;
 }
 
@@ -526,10 +534,12 @@ __device__ __forceinline__ void sel_reset(SelShared<TS>& S) {
 // (k: rank inside the bin; on success prefix / below / eq describe the selected KEY).  Block-uniform result.
 template <int TS, int KPL, int BT, class XF>
 __device__ __forceinline__ bool sel_rank_candidates(SelShared<TS>& S, const uint32_t (&key)[KPL], const XF& xf, int r, int j, int n, int k,
-                                                    uint32_t& prefix, int& below, int& eq, int cshift = 16) {
+                                                    uint32_t& prefix, int& below, int& eq, int cshift = 16, int cap = kCandMax, int slot = 7) {
     constexpr int kLanesPerRay = BT / TS;
-    const bool big = (n > 0) && (eq > kCandMax);
-    if (__syncthreads_or(big ? 1 : 0)) return false;
+    // the vote: one flag word per asking point of a descent (zeroed by sel_reset), one barrier
+    if ((n > 0) & (eq > cap) & (j == 0)) S.vote[slot] = 1;
+    __syncthreads();
+    if (S.vote[slot] != 0) return false;
     if (n > 0) {
 #pragma unroll
         for (int i = 0; i < KPL; ++i) {
@@ -567,7 +577,7 @@ __device__ __forceinline__ bool sel_rank_candidates(SelShared<TS>& S, const uint
 template <int TS, int KPL, int BT = 256, class XF = KeyIdentity>
 __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&key)[KPL], const XF& xf, int r, int j, int n, double q,
                                            uint32_t& key_lo, uint32_t& key_hi, double& frac, int max_pass = 8, int rank0 = 0,
-                                           SelCache<TS>* C = nullptr, bool resume = false) {
+                                           SelCache<TS>* C = nullptr, bool resume = false, bool early = true) {
     const double pos = q / 100.0 * (double)(n > 0 ? n - 1 : 0);
     const double fl = floor(pos);
     int k = rank0 + (int)fl;                                     // rank still to be found inside the current prefix
@@ -619,9 +629,23 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
             start = sl + 1;
         }
     }
-    const bool from16 = (start == 4);                            // resuming with 16 bits known: straight to the candidates
+    // Ranking eq candidates costs a lane eq^2 / (lanes per ray) compares, a pass ~5 slots for each of its KPL keys: before 16 bits
+    // are known the vote only passes where ranking is the cheaper of the two - 32 candidates with 16 lanes per ray, 11 with 2.
+    constexpr int kL = BT / TS;
+    constexpr int kEarlyCap = kL >= 16 ? 32 : (kL >= 8 ? 22 : (kL >= 4 ? 16 : 11));
+    if (C != nullptr && !resume && j == 0) {
+        // a first descent may stop before its fourth pass: what it does not count must not look like a cached histogram
+        C->pre[1][r] = 0xffffffffu; C->pre[2][r] = 0xffffffffu; C->pre[3][r] = 0xffffffffu;
+    }
+    // A vote that fails costs a barrier: a resumed descent (the clip loop: the same keys, a window that moved by a few ranks) only asks
+    // where the first descent of the block was answered - its bins are the same size give or take the clipped samples.
+    const int vote_from = (C != nullptr && resume) ? min(C->first_done, 3) : (early ? SPC_SEL_FIRST_VOTE : 3);     // block-uniform
+    int done_pass = 3;
+    // resumed with enough bits known: the candidates of the bin straight away when every ray's bin is small (no pass runs)
+    if (start >= 2 && start - 1 >= vote_from)
+        done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq, 32 - 4 * start, start < 4 ? kEarlyCap : kCandMax);
 #pragma unroll 1
-    for (int pass = start; pass < max_pass && !done && !from16; ++pass) {
+    for (int pass = start; pass < max_pass && !done; ++pass) {
         const int b = 28 - 4 * pass;
         unsigned long long accE = 0ull, accO = 0ull;             // even / odd digits, 8 bits each (<= 64 keys per lane)
         // (the first pass has no prefix; `pass` is made opaque so that its digit extraction - which does not depend on
@@ -657,47 +681,20 @@ __device__ __forceinline__ void ray_select(SelShared<TS>& S, const uint32_t (&ke
             }
         }
         prefix |= dsel << b;
-        // 16 bits known: rank the bin's candidates directly when every ray's bin is small - and ask again after every further
-        // pass (data in a narrow relative range share their leading bits: their bins get small two passes later)
-        if (pass >= 3 && pass < 7) done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq, 28 - 4 * pass);
-    }
-    if (from16) {
-        // resumed with 16 bits known (no pass ran): the candidates of the bin, or - a bin of many ties - the last passes
-        done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq);
-        if (!done) {
-#pragma unroll 1
-            for (int pass = 4; pass < max_pass; ++pass) {
-                const int b = 28 - 4 * pass;
-                unsigned long long accE = 0ull, accO = 0ull;
-                count_keys<KPL, false>(key, prefix, b, xf, accE, accO);
-                uint32_t* h = S.hist[pass % 3][r];
-                uint32_t* hz = S.hist[(pass + 1) % 3][r];
-#pragma unroll
-                for (int d = 0; d < 8; ++d) {
-                    const uint32_t c0 = (uint32_t)(accE >> (8 * d)) & 0xffu, c1 = (uint32_t)(accO >> (8 * d)) & 0xffu;
-                    if (c0) atomicAdd(&h[2 * d], c0);
-                    if (c1) atomicAdd(&h[2 * d + 1], c1);
-                }
-                if (j == 0) {
-#pragma unroll
-                    for (int d = 0; d < 16; ++d) hz[d] = 0u;
-                }
-                __syncthreads();
-                uint32_t dsel = 15u;
-                bool found = false;
-#pragma unroll
-                for (int d = 0; d < 16; ++d) {
-                    const int c = (int)h[d];
-                    if (!found) {
-                        if (k < c) { dsel = d; found = true; eq = c; }
-                        else { k -= c; below += c; }
-                    }
-                }
-                prefix |= dsel << b;
-                if (pass < 7 && sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq, 28 - 4 * pass)) break;
-            }
+        // (a ray that keeps more than 3/4 of its samples in one leading digit - positive data, a narrow relative range - will not have
+        //  a small bin two passes later: the early votes of the whole block are dropped.  Written here, read behind the next pass's
+        //  barrier.)
+        if (pass == 0 && j == 0 && n > 0 && 4 * eq > 3 * n) S.narrow = 1;
+        // Few samples are left in the bin: rank its candidates directly when every ray's bin is small, and ask again after every
+        // further pass (data in a narrow relative range share their leading bits: their bins get small two passes later).  Round 4:
+        // asked from the second pass on - a failed vote costs one barrier, and samples around zero (baseline-subtracted spectra)
+        // have few keys per binade near their median: 8 or 12 bits leave <= 32 (median 1024^3: 1.86 -> 1.64 ms).
+        if (pass >= vote_from && pass < 7 && (pass >= 3 || S.narrow == 0)) {
+            done = sel_rank_candidates<TS, KPL, BT>(S, key, xf, r, j, n, k, prefix, below, eq, 28 - 4 * pass, pass < 3 ? kEarlyCap : kCandMax, pass);
+            if (done) done_pass = min(pass, 3);
         }
     }
+    if (C != nullptr && !resume && threadIdx.x == 0) C->first_done = done_pass;
     // prefix = the key of rank floor(pos); `eq` samples carry it, `below` are smaller
     key_lo = prefix;
     key_hi = prefix;
@@ -904,7 +901,7 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip
             }
             uint32_t key_lo, key_hi;
             double frac;
-            ray_select<TS, KPL, BT>(S, key, xf, r, j, nm, 50.0, key_lo, key_hi, frac);
+            ray_select<TS, KPL, BT>(S, key, xf, r, j, nm, 50.0, key_lo, key_hi, frac, 8, 0, nullptr, false, /*early*/ false);
             const float spread = nm > 0 ? sel_value(key_lo, key_hi, frac, (double)1.482602218505602f) : NAN;
             sd = (double)spread;
             if (A.cen_mean) cen = (double)(float)mean;           // (the loop of separate kernels hands a float32 mean map over)
