@@ -292,12 +292,22 @@ def pmc_traffic(record):
     return rec["hbm_traffic_bytes_per_launch"], "%s#%s" % (PMC_FILE, record)
 
 
+def moments_zw(wl):
+    """waves per block of the launch spc_moments_f32 picks (spc_moments.hip make_plan): 8 on planes up to 8 MiB with
+    512 or more channels, else 4"""
+    shape = getattr(wl, "shape", None)
+    if not shape:
+        return 4
+    nz, ny, nx = shape
+    return 8 if (nz >= 512 and ny * nx <= (1 << 21)) else 4
+
+
 def roofline(wl, k_ms, traffic=None, traffic_src=None):
     achieved = wl.alg_bytes / (k_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": PEAK_GBS, "unit": "GB/s", "frac": achieved / PEAK_GBS,
             "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "traffic_over_algorithmic": (traffic / wl.alg_bytes) if traffic else None,
-            "kernel": "moments_kernel<VEC=4,ZW=4,U=8,ARR,noEXT,NT>", "kernel_ms": float(k_ms), "kernel_ms_stats": ms_stats(k_ms),
+            "kernel": "moments_kernel<VEC=4,ZW=%d,U=8,ARR,sums,PRED=0>" % moments_zw(wl), "kernel_ms": float(k_ms), "kernel_ms_stats": ms_stats(k_ms),
             "timing": "median of n launches, HIP events on the kernel's stream", "algorithmic_bytes": wl.alg_bytes}
 
 

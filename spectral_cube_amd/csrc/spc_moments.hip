@@ -16,6 +16,18 @@
 // planes of the same 64*VEC columns and are combined through LDS; gridDim.y
 // splits z further when the map is too small to fill 256 CUs, with a second
 // tiny combine kernel over fp64 partial sums.
+//
+// Issue budget (round 4, tests/micro/read_patterns.hip): this march reads 6.7 - 7.1 TB/s when nothing is
+// computed, so the instructions per voxel decide whether the kernel is bound by HBM or by issue.  The mask
+// predicate is therefore a template parameter in the canonical form of spc_canonical_pred (one compare when
+// the mask has no threshold term, three otherwise - never the five flag-guarded compares of spc_pred), the
+// valid count is only carried when it is asked for (otherwise one scalar "any valid" bit per column), the
+// include select happens in float32 before the widening, the channel coordinate of a plane is a scalar load
+// (the wave index goes through readfirstlane, so a plane's address and coordinate are provably uniform).
+// 27.7 -> 12.4 instructions per voxel; the kernel now runs within 2 - 7 % of the same two streams read with no
+// arithmetic at all (tests/micro/mask_patterns.hip), which is what is left of the 8 TB/s in this access pattern
+// (profiles/r04_moments_issue.log).  SPC_MOMENTS_XCD=1 hands the blocks of one XCD neighbouring column groups
+// (+3 % on the bare read, nothing on the kernel: off).
 #include "spc_common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -37,32 +49,50 @@ struct MomArgs {
     int nsplit;              // gridDim.y
     int64_t zchunk;          // planes per split
     double* ws;              // partial sums workspace (nsplit > 1)
+    float lim, lo, hi;       // the mask predicate in canonical form: |v| <= lim && !(v <= lo) && !(v >= hi)
+    int xcd_group;           // blocks of one XCD take neighbouring column groups
 };
 
 // per-column running state
 struct Acc {
     double s0, s1, s2;
     int n;
+    bool any;                // EXT == 0: "a valid sample was met" instead of the count (a lane mask in scalar registers)
     float bmax, bmin;
     int imax, imin;
 };
 
+// EXT: 0 = the three sums (+ any-valid bit), 1 = + valid count, 2 = + extrema and their channels
+constexpr int kSums = 0, kCount = 1, kExtrema = 2;
+
 __device__ __forceinline__ void acc_init(Acc& a, int z0) {
     a.s0 = a.s1 = a.s2 = 0.0;
     a.n = 0;
+    a.any = false;
     a.bmax = -INFINITY; a.bmin = INFINITY;
     a.imax = z0; a.imin = z0;
 }
 
-template <bool EXT>
-__device__ __forceinline__ void acc_add(Acc& a, float v, bool inc, double c, double c2, int z) {
-    const bool ok = inc && (v == v);
-    const double wd = ok ? (double)v : 0.0;
+// PRED 0: |v| <= lim (lim = +inf: not NaN; FLT_MAX: finite), 1: the full canonical form
+template <int PRED>
+__device__ __forceinline__ bool mom_pred(float v, float lim, float lo, float hi) {
+    bool ok = fabsf(v) <= lim;
+    if (PRED) ok = ok && !(v <= lo) && !(v >= hi);
+    return ok;
+}
+
+// ok already holds every term of the mask and rejects NaN
+template <int EXT>
+__device__ __forceinline__ void acc_add(Acc& a, float v, bool ok, double c, double c2, int z) {
+    float w = ok ? v : 0.f;                  // select in float32 (one v_cndmask), then widen:
+    asm volatile("" : "+v"(w));              // left alone LLVM widens first and selects both halves
+    const double wd = (double)w;
     a.s0 += wd;
     a.s1 = fma(wd, c, a.s1);
     a.s2 = fma(wd, c2, a.s2);
-    a.n += ok ? 1 : 0;
-    if (EXT) {
+    if (EXT >= kCount) a.n += ok ? 1 : 0;
+    else a.any = a.any || ok;
+    if (EXT == kExtrema) {
         const float hi = ok ? v : -INFINITY;
         const float lo = ok ? v : INFINITY;
         if (hi > a.bmax) { a.bmax = hi; a.imax = z; }
@@ -71,10 +101,10 @@ __device__ __forceinline__ void acc_add(Acc& a, float v, bool inc, double c, dou
 }
 
 // merge b into a; ties keep the smaller channel index (first-index rule)
-template <bool EXT>
+template <int EXT>
 __device__ __forceinline__ void acc_merge(Acc& a, const Acc& b) {
     a.s0 += b.s0; a.s1 += b.s1; a.s2 += b.s2; a.n += b.n;
-    if (EXT) {
+    if (EXT == kExtrema) {
         if (b.bmax > a.bmax || (b.bmax == a.bmax && b.imax < a.imax)) { a.bmax = b.bmax; a.imax = b.imax; }
         if (b.bmin < a.bmin || (b.bmin == a.bmin && b.imin < a.imin)) { a.bmin = b.bmin; a.imin = b.imin; }
     }
@@ -133,13 +163,20 @@ __device__ __forceinline__ unsigned vget(const uint16_t& v, int i) { return (v >
 __device__ __forceinline__ unsigned vget(const uint32_t& v, int i) { return (v >> (8 * i)) & 0xffu; }
 __device__ __forceinline__ unsigned vget(const unsigned char& v, int) { return v; }
 
-template <int VEC, int ZW, int U, bool ARR, bool EXT, bool NT>
+template <int VEC, int ZW, int U, bool ARR, int EXT, int PRED>
 __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
     using F = typename VecT<VEC>::F;
     using M = typename VecT<VEC>::M;
     const int lane = threadIdx.x;
-    const int w = threadIdx.y;
-    const int64_t g = (int64_t)blockIdx.x * kLanes + lane;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);   // blockDim.x = 64: one wave per y
+    // the hardware hands consecutive blocks to consecutive XCDs: give the blocks of one XCD one contiguous range of
+    // column groups (their 1-KiB row segments then follow each other in that XCD's L2 channels and DRAM pages)
+    int64_t blk = blockIdx.x;
+    if (A.xcd_group) {
+        const int64_t nb = gridDim.x, q = nb >> 3, r = nb & 7, k = blk & 7;
+        blk = k * q + (k < r ? k : r) + (blk >> 3);
+    }
+    const int64_t g = blk * kLanes + lane;
     const bool live = g < A.ngroups;
     const int64_t gg = live ? g : 0;
     const int64_t y = gg / A.groups_per_row;
@@ -150,8 +187,7 @@ __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
 
     const float* p = A.cube + y * A.row_stride + x;
     const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + x : nullptr;
-    const uint32_t flags = A.mask.flags;
-    const float tlo = A.mask.thr_lo, thi = A.mask.thr_hi;
+    const float lim = A.lim, lo = A.lo, hi = A.hi;
 
     Acc acc[VEC];
 #pragma unroll
@@ -166,24 +202,20 @@ __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t zz = z + (int64_t)u * ZW;
-                const F* src = reinterpret_cast<const F*>(p + zz * A.plane_stride);
-                v[u] = NT ? __builtin_nontemporal_load(src) : *src;
-                if (ARR) {
-                    const M* ms = reinterpret_cast<const M*>(pm + zz * A.mask.plane_stride);
-                    m[u] = NT ? __builtin_nontemporal_load(ms) : *ms;
-                }
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const F*>(p + zz * A.plane_stride));
+                if (ARR) m[u] = __builtin_nontemporal_load(reinterpret_cast<const M*>(pm + zz * A.mask.plane_stride));
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t zz = z + (int64_t)u * ZW;
-                const double c = A.cen[zz];
+                const double c = A.cen[zz];                      // uniform address: a scalar load
                 const double c2 = c * c;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
                     const float val = vget(v[u], i);
-                    bool inc = spc_pred(flags, tlo, thi, val);
-                    if (ARR) inc = inc && (vget(m[u], i) != 0);
-                    acc_add<EXT>(acc[i], val, inc, c, c2, (int)zz);
+                    bool ok = mom_pred<PRED>(val, lim, lo, hi);
+                    if (ARR) ok = ok && (vget(m[u], i) != 0);
+                    acc_add<EXT>(acc[i], val, ok, c, c2, (int)zz);
                 }
             }
         }
@@ -197,11 +229,15 @@ __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {
                 const float val = vget(v, i);
-                bool inc = spc_pred(flags, tlo, thi, val);
-                if (ARR) inc = inc && (vget(m, i) != 0);
-                acc_add<EXT>(acc[i], val, inc, c, c2, (int)z);
+                bool ok = mom_pred<PRED>(val, lim, lo, hi);
+                if (ARR) ok = ok && (vget(m, i) != 0);
+                acc_add<EXT>(acc[i], val, ok, c, c2, (int)z);
             }
         }
+    }
+    if (EXT < kCount) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i].n = acc[i].any ? 1 : 0;
     }
 
     // ---- combine the ZW waves of the block through LDS (one VEC element at a time)
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
     }
 }
 
-template <bool EXT>
+template <int EXT>
 __global__ __launch_bounds__(256) void moments_combine_kernel(const MomArgs A, int vec) {
     const int64_t ncols = A.ngroups * vec;
     const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -357,43 +393,36 @@ __global__ __launch_bounds__(256) void moment_order_v4_kernel(const OrdArgs A) {
     }
 }
 
-struct Plan { int vec, zw, u, nsplit; int64_t zchunk; bool nt; };
+struct Plan { int vec, zw, u, nsplit; int64_t zchunk; };
 
-template <int VEC, int ZW, int U, bool ARR, bool EXT>
-int launch_main(const MomArgs& A, hipStream_t st, bool nt) {
+template <int VEC, int ZW, int U, bool ARR, int EXT>
+int launch_main(const MomArgs& A, hipStream_t st, bool thresholds) {
     dim3 block(kLanes, ZW);
     dim3 grid((unsigned)((A.ngroups + kLanes - 1) / kLanes), (unsigned)A.nsplit);
-    if (nt) hipLaunchKernelGGL((moments_kernel<VEC, ZW, U, ARR, EXT, true>), grid, block, 0, st, A);
-    else hipLaunchKernelGGL((moments_kernel<VEC, ZW, U, ARR, EXT, false>), grid, block, 0, st, A);
+    if (thresholds) hipLaunchKernelGGL((moments_kernel<VEC, ZW, U, ARR, EXT, 1>), grid, block, 0, st, A);
+    else hipLaunchKernelGGL((moments_kernel<VEC, ZW, U, ARR, EXT, 0>), grid, block, 0, st, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
 
-template <int VEC, int ZW, bool ARR, bool EXT>
-int launch_u(const MomArgs& A, hipStream_t st, const Plan& p) {
-    switch (p.u) {
-        case 2: return launch_main<VEC, ZW, 2, ARR, EXT>(A, st, p.nt);
-        case 8: return launch_main<VEC, ZW, 8, ARR, EXT>(A, st, p.nt);
-        default: return launch_main<VEC, ZW, 4, ARR, EXT>(A, st, p.nt);
+// 16-byte lanes: ZW in {1, 4, 8}, U in {2, 4, 8}; the narrower lanes (odd nx, unaligned views): ZW in {1, 4}, U = 4
+template <bool ARR, int EXT>
+int launch_plan(const MomArgs& A, hipStream_t st, const Plan& p, bool thr) {
+    if (p.vec == 4) {
+        switch (p.zw * 16 + p.u) {
+            case 1 * 16 + 2: return launch_main<4, 1, 2, ARR, EXT>(A, st, thr);
+            case 1 * 16 + 4: return launch_main<4, 1, 4, ARR, EXT>(A, st, thr);
+            case 1 * 16 + 8: return launch_main<4, 1, 8, ARR, EXT>(A, st, thr);
+            case 4 * 16 + 2: return launch_main<4, 4, 2, ARR, EXT>(A, st, thr);
+            case 4 * 16 + 4: return launch_main<4, 4, 4, ARR, EXT>(A, st, thr);
+            case 4 * 16 + 8: return launch_main<4, 4, 8, ARR, EXT>(A, st, thr);
+            case 8 * 16 + 2: return launch_main<4, 8, 2, ARR, EXT>(A, st, thr);
+            case 8 * 16 + 4: return launch_main<4, 8, 4, ARR, EXT>(A, st, thr);
+            default: return launch_main<4, 8, 8, ARR, EXT>(A, st, thr);
+        }
     }
-}
-
-template <int VEC, bool ARR, bool EXT>
-int launch_zw(const MomArgs& A, hipStream_t st, const Plan& p) {
-    switch (p.zw) {
-        case 4: return launch_u<VEC, 4, ARR, EXT>(A, st, p);
-        case 2: return launch_u<VEC, 2, ARR, EXT>(A, st, p);
-        default: return launch_u<VEC, 1, ARR, EXT>(A, st, p);
-    }
-}
-
-template <bool ARR, bool EXT>
-int launch_vec(const MomArgs& A, hipStream_t st, const Plan& p) {
-    switch (p.vec) {
-        case 4: return launch_zw<4, ARR, EXT>(A, st, p);
-        case 2: return launch_zw<2, ARR, EXT>(A, st, p);
-        default: return launch_zw<1, ARR, EXT>(A, st, p);
-    }
+    if (p.vec == 2) return p.zw > 1 ? launch_main<2, 4, 4, ARR, EXT>(A, st, thr) : launch_main<2, 1, 4, ARR, EXT>(A, st, thr);
+    return p.zw > 1 ? launch_main<1, 4, 4, ARR, EXT>(A, st, thr) : launch_main<1, 1, 4, ARR, EXT>(A, st, thr);
 }
 
 int env_int(const char* name, int dflt) {
@@ -414,16 +443,18 @@ Plan make_plan(const spc_cube_f32* c, const MaskDev& m, bool ext) {
     if (vec != 1 && vec != 2 && vec != 4) vec = 4;
     while (vec > 1 && !aligned(vec)) vec >>= 1;
     p.vec = vec;
-    // MI355X sweep at 1024^3 (tests/tune_moments.py, profiles/r01_tune_moments.log):
-    // u8 mask: VEC4 ZW4 U8 = 6.33 TB/s; no mask: U4 = 5.90 TB/s; +argmax: U2 fastest
+    // MI355X sweeps at 1024^3 (tests/tune_moments.py; profiles/r01_tune_moments.log, r04_moments_issue.log)
     const bool arr_ = (m.flags & SPC_MASK_ARRAY) != 0;
-    p.u = env_int("SPC_MOMENTS_U", ext ? 2 : (arr_ ? 8 : 4));
-    p.nt = env_int("SPC_MOMENTS_NT", 1) != 0;
+    (void)arr_;
+    p.u = env_int("SPC_MOMENTS_U", ext ? 2 : 8);
+    if (p.u != 2 && p.u != 4 && p.u != 8) p.u = 4;
     const int64_t ngroups = c->ny * (c->nx / p.vec);
     const int64_t nblocks = (ngroups + kLanes - 1) / kLanes;
     // in-block z split: ZW waves share the columns when z is long enough
-    p.zw = env_int("SPC_MOMENTS_ZW", c->nz >= 16 ? 4 : 1);
-    if (p.zw != 1 && p.zw != 2 && p.zw != 4) p.zw = 1;
+    // eight waves per block pay on planes up to 8 MiB (C2: 0.866 -> 0.827 ms), not on the north star's 16 MiB planes (13.06 -> 13.22 ms)
+    p.zw = env_int("SPC_MOMENTS_ZW", c->nz >= 512 && !ext && c->ny * c->nx <= (1 << 21) ? 8 : (c->nz >= 16 ? 4 : 1));
+    if (p.zw != 1 && p.zw != 4 && p.zw != 8) p.zw = 1;
+    if (p.vec != 4) { p.u = 4; if (p.zw > 4) p.zw = 4; }
     // grid z split only when the map alone cannot fill the chip (256 CUs x ~8 blocks)
     int nsplit = 1;
     const int64_t target = 2048;
@@ -470,6 +501,9 @@ int spc_moments_f32(int device, void* stream, const spc_cube_f32* cube, const sp
     A.out_row_stride = out->out_row_stride ? out->out_row_stride : cube->nx;
     const bool ext = out->d_argmax || out->d_argmin || out->d_vmax || out->d_vmin;
     Plan p = make_plan(cube, A.mask, ext);
+    spc_canonical_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, &A.lim, &A.lo, &A.hi);
+    const bool thr = (A.mask.flags & (SPC_MASK_GT | SPC_MASK_GE | SPC_MASK_LT | SPC_MASK_LE)) != 0;
+    A.xcd_group = env_int("SPC_MOMENTS_XCD", 0);    // measured: +- 1 % either way on the real kernel (profiles/r04_moments_issue.log)
     A.groups_per_row = cube->nx / p.vec;
     A.ngroups = cube->ny * A.groups_per_row;
     A.nsplit = p.nsplit;
@@ -484,16 +518,17 @@ int spc_moments_f32(int device, void* stream, const spc_cube_f32* cube, const sp
     }
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
-    if (arr && ext) rc = launch_vec<true, true>(A, st, p);
-    else if (arr) rc = launch_vec<true, false>(A, st, p);
-    else if (ext) rc = launch_vec<false, true>(A, st, p);
-    else rc = launch_vec<false, false>(A, st, p);
+    const int what = ext ? kExtrema : (out->d_nvalid ? kCount : kSums);
+    if (arr) rc = what == kExtrema ? launch_plan<true, kExtrema>(A, st, p, thr)
+                : what == kCount ? launch_plan<true, kCount>(A, st, p, thr) : launch_plan<true, kSums>(A, st, p, thr);
+    else rc = what == kExtrema ? launch_plan<false, kExtrema>(A, st, p, thr)
+            : what == kCount ? launch_plan<false, kCount>(A, st, p, thr) : launch_plan<false, kSums>(A, st, p, thr);
     if (rc) return rc;
     if (A.nsplit > 1) {
         const int64_t ncols = cube->ny * cube->nx;
         dim3 grid((unsigned)((ncols + 255) / 256));
-        if (ext) hipLaunchKernelGGL(moments_combine_kernel<true>, grid, dim3(256), 0, st, A, p.vec);
-        else hipLaunchKernelGGL(moments_combine_kernel<false>, grid, dim3(256), 0, st, A, p.vec);
+        if (ext) hipLaunchKernelGGL(moments_combine_kernel<kExtrema>, grid, dim3(256), 0, st, A, p.vec);
+        else hipLaunchKernelGGL(moments_combine_kernel<kCount>, grid, dim3(256), 0, st, A, p.vec);
         SPC_LAUNCH_CHECK();
     }
     return SPC_OK;
