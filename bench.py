@@ -805,8 +805,9 @@ def next_rows_records(cube, maskd, tile, tmask, device):
 def config_records(args, device):
     import gc
     from spectral_cube_amd.device import pool_trim
-    which = ("C3", "C4", "C5") if not args.configs_only else tuple(w.strip().upper() for w in args.configs_only.split(","))
     fns = {"C3": config_c3, "C4": config_c4, "C5": config_c5}
+    which = ("C3", "C4", "C5") if not args.configs_only else tuple(w.strip().upper() for w in args.configs_only.split(","))
+    which = tuple(w for w in which if w in fns)             # "--configs-only none": the headline and the next rows alone
     out = {}
     for w in which:
         t0 = time.perf_counter()

@@ -113,18 +113,41 @@ static inline hipError_t spc_flags_clear(unsigned char* d_flags, size_t n, hipSt
 }
 
 // ---- device-side mask evaluation -----------------------------------------
+// mask predicate -> |v| <= lim && !(v <= lo) && !(v >= hi): three compares whatever the flags.  An absent bound is
+// NaN (the negated compare is then true for every v), >= / <= become strict compares against the neighbouring float,
+// a NaN threshold rejects everything (numpy: x > nan is False); lim = FLT_MAX under isfinite, +inf otherwise (NaN
+// samples fail |v| <= lim either way: they are never valid).
+static inline void spc_canonical_pred(uint32_t f, float thr_lo, float thr_hi, float* lim, float* lo, float* hi) {
+    *lim = (f & SPC_MASK_FINITE) ? 3.402823466e+38f : INFINITY;
+    *lo = NAN;
+    *hi = NAN;
+    if (f & (SPC_MASK_GT | SPC_MASK_GE)) {
+        if (thr_lo != thr_lo) *lim = -1.f;
+        else if (f & SPC_MASK_GT) *lo = thr_lo;
+        else *lo = (thr_lo == -INFINITY) ? NAN : nextafterf(thr_lo, -INFINITY);
+    }
+    if (f & (SPC_MASK_LT | SPC_MASK_LE)) {
+        if (thr_hi != thr_hi) *lim = -1.f;
+        else if (f & SPC_MASK_LT) *hi = thr_hi;
+        else *hi = (thr_hi == INFINITY) ? NAN : nextafterf(thr_hi, INFINITY);
+    }
+}
+
 struct MaskDev {
     uint32_t flags;
     float thr_lo, thr_hi;
     const uint8_t* arr;
     int64_t row_stride, plane_stride;
+    float lim, lo, hi;           // the predicate terms in canonical form (spc_canonical_pred), set by spc_mask_to_dev
 };
 
 static inline int spc_mask_to_dev(const spc_mask* m, const spc_cube_f32* c, MaskDev* out) {
     out->flags = 0; out->thr_lo = 0.f; out->thr_hi = 0.f; out->arr = nullptr;
     out->row_stride = c->row_stride; out->plane_stride = c->plane_stride;
+    spc_canonical_pred(0u, 0.f, 0.f, &out->lim, &out->lo, &out->hi);
     if (!m) return SPC_OK;
     out->flags = m->flags; out->thr_lo = m->thr_lo; out->thr_hi = m->thr_hi;
+    spc_canonical_pred(m->flags, m->thr_lo, m->thr_hi, &out->lim, &out->lo, &out->hi);
     if (m->flags & SPC_MASK_ARRAY) {
         SPC_REQUIRE(m->d_array != nullptr, "SPC_MASK_ARRAY set but d_array is NULL");
         out->arr = m->d_array;
@@ -156,26 +179,6 @@ static inline int spc_check_cube_any_order(const spc_cube_f32* c) {
     return SPC_OK;
 }
 
-// mask predicate -> |v| <= lim && !(v <= lo) && !(v >= hi): three compares whatever the flags.  An absent bound is
-// NaN (the negated compare is then true for every v), >= / <= become strict compares against the neighbouring float,
-// a NaN threshold rejects everything (numpy: x > nan is False); lim = FLT_MAX under isfinite, +inf otherwise (NaN
-// samples fail |v| <= lim either way: they are never valid).
-static inline void spc_canonical_pred(uint32_t f, float thr_lo, float thr_hi, float* lim, float* lo, float* hi) {
-    *lim = (f & SPC_MASK_FINITE) ? 3.402823466e+38f : INFINITY;
-    *lo = NAN;
-    *hi = NAN;
-    if (f & (SPC_MASK_GT | SPC_MASK_GE)) {
-        if (thr_lo != thr_lo) *lim = -1.f;
-        else if (f & SPC_MASK_GT) *lo = thr_lo;
-        else *lo = (thr_lo == -INFINITY) ? NAN : nextafterf(thr_lo, -INFINITY);
-    }
-    if (f & (SPC_MASK_LT | SPC_MASK_LE)) {
-        if (thr_hi != thr_hi) *lim = -1.f;
-        else if (f & SPC_MASK_LT) *hi = thr_hi;
-        else *hi = (thr_hi == INFINITY) ? NAN : nextafterf(thr_hi, INFINITY);
-    }
-}
-
 // Buffer descriptor over (up to 4 GiB from) a wave-uniform base.  The base must be PROVABLY uniform, otherwise hipcc wraps
 // every buffer op in a waterfall loop: both halves go through readfirstlane.
 __device__ __forceinline__ auto spc_plane_srd(const void* base) {
@@ -185,7 +188,13 @@ __device__ __forceinline__ auto spc_plane_srd(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)0xffffffffu, 0x00020000);
 }
 
-// predicate part of the mask (array part is handled by the caller's loads)
+// predicate part of the mask AND "not NaN", in the canonical form: three compares and no flag tests (spc_pred below costs five
+// flag-guarded compares and ~11 scalar instructions per sample whatever the mask: round 4 found the reductions bound by that)
+__device__ __forceinline__ bool spc_pred_valid(const MaskDev& m, float v) {
+    return (fabsf(v) <= m.lim) & !(v <= m.lo) & !(v >= m.hi);
+}
+
+// predicate part of the mask (array part is handled by the caller's loads); a NaN sample passes unless isfinite is asked for
 __device__ __forceinline__ bool spc_pred(uint32_t flags, float thr_lo, float thr_hi, float v) {
     bool inc = true;
     if (flags & SPC_MASK_FINITE) inc = inc && (fabsf(v) <= 3.402823466e+38f);  // false for NaN/inf

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void moment_order_v4_kernel(const OrdArgs A) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float val = v[u][c];
-                const bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, val) && (val == val) && (((m[u] >> (8 * c)) & 0xffu) != 0);
+                const bool ok = spc_pred_valid(A.mask, val) & (((m[u] >> (8 * c)) & 0xffu) != 0);
                 const double d = cz - mu[c];
                 double pw = d;
                 for (int k = 1; k < A.order; ++k) pw *= d;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void moments_axis1_kernel(const SpMomArgs A) {
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
                 const float val = v[u][c];
-                const bool ok = in && spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, val) && (val == val) && (mk[u][c] != 0);
+                const bool ok = in & spc_pred_valid(A.mask, val) & (mk[u][c] != 0);
                 acc3_add<ORD>(a[c], val, ok, cc[u][c], A.order, muv[c]);
             }
         }
@@ -159,13 +159,13 @@ __global__ __launch_bounds__(256) void moments_axis2_kernel(const SpMomArgs A) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float val = q[c];
-            const bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, val) && (val == val) && (((m >> (8 * c)) & 0xffu) != 0);
+            const bool ok = spc_pred_valid(A.mask, val) & (((m >> (8 * c)) & 0xffu) != 0);
             acc3_add<ORD>(a, val, ok, cc[c], A.order, muv);
         }
     }
     for (int64_t x = n4 * 4 + lane; x < A.nx; x += 64) {
         const float val = p[x];
-        const bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, val) && (val == val) && (!ARR || pm[x] != 0);
+        const bool ok = spc_pred_valid(A.mask, val) && (!ARR || pm[x] != 0);
         acc3_add<ORD>(a, val, ok, cen[x], A.order, muv);
     }
     a.s0 = wave_sum(a.s0); a.s1 = wave_sum(a.s1); a.s2 = wave_sum(a.s2);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void select_axis0_kernel(const SelArgs A) {
         }
 #pragma unroll
         for (int c = 0; c < VEC; ++c) {
-            bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw[c]) && (raw[c] == raw[c]);
+            bool ok = spc_pred_valid(A.mask, raw[c]);
             if (ARR) ok = ok && (mk[c] != 0);
             const float v = use_cen ? fabsf(raw[c] - cen[c]) : raw[c];
             r.v[c] = v;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void select16_axis0_kernel(const SelArgs A) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float raw = q4[c];
-                bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, raw) && (raw == raw) && (((m >> (8 * c)) & 0xffu) != 0);
+                bool ok = spc_pred_valid(A.mask, raw) & (((m >> (8 * c)) & 0xffu) != 0);
                 const float v = use_cen ? fabsf(raw - cen[c]) : raw;
                 ok = ok && (v == v);
                 const uint32_t k = fkey(v);
@@ -828,6 +828,10 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip
 #pragma unroll
         for (int i = 0; i < KPL; ++i) asm volatile("" : "+v"(key[i]));
         // ---- valid count, sum, sum of squares of the ray (what spc_stats_axis_f32 gives the unfused path)
+        // (the previous iteration's descent ends with lanes reading S.nextkey[r] behind its last barrier: without this barrier a
+        //  wave that is already here resets the word under them - the upper of an even count's two middle samples came back as
+        //  the "excluded" key in one launch out of four, tests/stress_clip_determinism.py)
+        if (it > 0) __syncthreads();
         sel_reset<TS, BT>(S);
         int cnt = 0, low = 0;
         double s = 0.0, ss = 0.0;
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(256) void gselect_kernel(const GSelArgs A) {
     const int copy = t & 15;
     uint32_t mymin = 0xffffffffu;
     auto take = [&](float v, unsigned mk) {
-        const bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v) && (mk != 0);
+        const bool ok = spc_pred_valid(A.mask, v) & (mk != 0);
         if (!ok) return;
         if (A.has_center) v = __builtin_fabsf(v - A.center);
         const uint32_t k = fkey(v);

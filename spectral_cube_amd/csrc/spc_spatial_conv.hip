@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void spatial_conv2d_tiled_kernel(const SpArgs 
         float2v val = float2v{0.f, 1.f};                   // outside the image: a valid zero
         if (iy >= 0 && iy < A.ny && ix >= 0 && ix < A.nx) {
             const float v = p[iy * A.row_stride + ix];
-            bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v);
+            bool ok = spc_pred_valid(A.mask, v);
             if (ARR) ok = ok && pm[iy * A.mask.row_stride + ix] != 0;
             val = ok ? float2v{v, 1.f} : float2v{0.f, 0.f};
         }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void spatial_conv2d_allvalid_kernel(const SpAr
                 const int64_t ixh = ix + h * kT2X;
                 if (ixh >= 0 && ixh < A.nx) {
                     const float v = p[iy * A.row_stride + ixh];
-                    bad = bad || !(spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v));
+                    bad = bad || !spc_pred_valid(A.mask, v);
                     if (h == 0) val.x = v; else val.y = v;
                 }
             }

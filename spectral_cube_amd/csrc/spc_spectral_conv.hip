@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 3) void spectral_conv_wide_kernel(const ConvAr
             const int64_t i = o0 - H + r;
             if (i < 0 || i >= A.nz) return double2w{0.0, 1.0};       // outside the cube: a valid zero
             const float v = p[i * A.plane_stride];
-            bool ok = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, v) && (v == v);
+            bool ok = spc_pred_valid(A.mask, v);
             if (ARR) ok = ok && pm[i * A.mask.plane_stride] != 0;
             if (ALLV) bad = bad || !ok;
             return ok ? double2w{(double)v, 1.0} : double2w{0.0, 0.0};

@@ -54,7 +54,7 @@ __device__ __forceinline__ Acc acc_wave_reduce(Acc a) {
 }
 
 __device__ __forceinline__ bool included(const MaskDev& m, float v, unsigned mk) {
-    return spc_pred(m.flags, m.thr_lo, m.thr_hi, v) && (v == v) && (mk != 0);
+    return spc_pred_valid(m, v) & (mk != 0);
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -74,12 +74,44 @@ struct StatArgs {
 };
 
 // ---- whole cube -------------------------------------------------------------------------
-template <bool ARR>
+// Round 4: a global reduction is free to read the cube LINEARLY (7.1 TB/s, tests/micro/copy_patterns.hip), so what it costs
+// per sample decides the rate.  One accumulator set per vector component (four independent float64 chains instead of one
+// serial chain of 16 dependent additions per iteration), the excluded sample becomes a NaN that v_min / v_max ignore (one
+// select instead of two), the valid count is a scalar population count of the compare mask (per wave, not per lane), the
+// predicate is the canonical three-compare form: ~13 instructions per sample against ~28.
+struct Acc4 {
+    double sum[4], ssq[4];
+    float mn[4], mx[4];
+};
+
+template <bool ARR, bool THR>
+__device__ __forceinline__ void acc4_add(Acc4& a, int& cnt, const MaskDev& mk, const f32x4& v, uint32_t m) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        bool ok = THR ? spc_pred_valid(mk, v[c]) : (fabsf(v[c]) <= mk.lim);    // no threshold terms: one compare
+        if (ARR) ok = ok & (((m >> (8 * c)) & 0xffu) != 0);
+        cnt += __builtin_popcountll(__ballot(ok));          // wave-wide: every lane carries the same count
+        float w = ok ? v[c] : 0.f;
+        asm volatile("" : "+v"(w));                          // select before widening (one v_cndmask)
+        const double d = (double)w;
+        a.sum[c] += d;
+        a.ssq[c] = fma(d, d, a.ssq[c]);
+        const float e = ok ? v[c] : __builtin_nanf("");      // fminf / fmaxf return the other operand
+        a.mn[c] = fminf(a.mn[c], e);
+        a.mx[c] = fmaxf(a.mx[c], e);
+    }
+}
+
+template <bool ARR, bool THR>
 __global__ __launch_bounds__(256) void stats_global_kernel(const StatArgs A) {
     __shared__ double s_red[4][5];
     Acc a = acc_zero();
+    Acc4 q;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { q.sum[c] = 0.0; q.ssq[c] = 0.0; q.mn[c] = INFINITY; q.mx[c] = -INFINITY; }
+    int wave_cnt = 0;                                        // valid samples met by this WAVE in the 16-byte body
     const int t = threadIdx.x;
-    constexpr int U = 4;
+    constexpr int U = 8;
     // one contiguous run: every block strides through it.  Rows of a strided view (a strip of a cube): the blocks share the ROWS
     // out - round 3a walked them one after the other with all blocks striding inside each, which left a row of 1024 samples to
     // one block and the others idle (64 MB in 19 ms)
@@ -91,34 +123,47 @@ __global__ __launch_bounds__(256) void stats_global_kernel(const StatArgs A) {
         const uint8_t* pm = ARR ? A.mask.arr + moff : nullptr;
         const bool al = ((((uintptr_t)p) & 15) == 0) && (!ARR || ((((uintptr_t)pm) & 3) == 0));
         const int64_t n4 = al ? A.rowlen / 4 : 0;
-        // 16-byte body, U chunks in flight per thread
-        const int64_t stride = rows ? 256 : (int64_t)gridDim.x * 256;
-        const int64_t first = rows ? 0 : (int64_t)blockIdx.x * 256;
+        // 16-byte body: a block takes U consecutive chunks of 256 x 16 bytes (U x 4 KiB contiguous), then strides on
+        const int64_t stride = rows ? 256 * U : (int64_t)gridDim.x * 256 * U;
+        const int64_t first = rows ? 0 : (int64_t)blockIdx.x * 256 * U;
         int64_t i = first + t;
-        for (; i + (U - 1) * stride < n4; i += U * stride) {
+        for (; (i - t) + U * 256 <= n4; i += stride) {       // whole groups: block-uniform
             f32x4 v[U];
             uint32_t m[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i + u * stride);
-                m[u] = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm) + i + u * stride) : 0x01010101u;
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i + u * 256);
+                m[u] = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm) + i + u * 256) : 0x01010101u;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc_add(a, v[u][c], included(A.mask, v[u][c], (m[u] >> (8 * c)) & 0xffu));
+            for (int u = 0; u < U; ++u) acc4_add<ARR, THR>(q, wave_cnt, A.mask, v[u], m[u]);
         }
-        for (; i < n4; i += stride) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(p)[i];
-            const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[i] : 0x01010101u;
+        // the last, partial group of chunks of this block
+        for (int u = 0; u < U; ++u) {
+            const int64_t k = i + u * 256;
+            if (k - t + 255 < n4) {                          // whole chunk inside: wave-uniform, all lanes load
+                const f32x4 v = reinterpret_cast<const f32x4*>(p)[k];
+                const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[k] : 0x01010101u;
+                acc4_add<ARR, THR>(q, wave_cnt, A.mask, v, m);
+            } else if (k < n4) {                             // a ragged chunk: per-lane accumulators
+                const f32x4 v = reinterpret_cast<const f32x4*>(p)[k];
+                const uint32_t m = ARR ? reinterpret_cast<const uint32_t*>(pm)[k] : 0x01010101u;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu));
+                for (int c = 0; c < 4; ++c) acc_add(a, v[c], included(A.mask, v[c], (m >> (8 * c)) & 0xffu));
+            }
         }
-        for (int64_t j = n4 * 4 + first + t; j < A.rowlen; j += stride) {
+        // samples beyond the last whole 16 bytes (or the whole run when it is not aligned)
+        for (int64_t j = n4 * 4 + (rows ? 0 : (int64_t)blockIdx.x * 256) + t; j < A.rowlen; j += rows ? 256 : (int64_t)gridDim.x * 256) {
             const float v = p[j];
             acc_add(a, v, included(A.mask, v, ARR ? pm[j] : 1u));
         }
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a.sum += q.sum[c]; a.ssq += q.ssq[c];
+        a.mn = fminf(a.mn, q.mn[c]); a.mx = fmaxf(a.mx, q.mx[c]);
+    }
+    if ((t & 63) == 0) a.cnt += wave_cnt;                    // once per wave
     a = acc_wave_reduce(a);
     const int w = t >> 6;
     if ((t & 63) == 0) {
@@ -585,6 +630,12 @@ __global__ __launch_bounds__(256) void clip_outside_kernel(const ClipArgs A) {
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(A.nchanged, mine);
 }
 
+int env_blocks() {
+    const char* e = getenv("SPC_STATS_BLOCKS");              // tuning hook; 2048 = 8 blocks per CU
+    const int v = e ? atoi(e) : 2048;
+    return v > 0 ? v : 2048;
+}
+
 int fill_common(StatArgs& A, const spc_cube_f32* cube, const spc_mask* mask) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
@@ -614,13 +665,16 @@ int spc_stats_global_f32(int device, void* stream, const spc_cube_f32* cube, con
     if (contig) { A.nrows = 1; A.rowlen = A.nz * A.ny * A.nx; A.row_a = 0; A.row_b = 0; }
     else { A.nrows = A.nz * A.ny; A.rowlen = A.nx; A.row_a = A.plane_stride; A.row_b = A.row_stride; }
     // enough blocks to fill the chip, few enough that the host-side finish is trivial
-    const int64_t per_block = 256 * 4 * 4;
-    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(4096, contig ? (A.rowlen + per_block - 1) / per_block : (A.nrows + 3) / 4));
+    const int64_t per_block = 256 * 4 * 8;                   // one group: 8 chunks of 256 x 16 bytes
+    const int nblocks = (int)std::max<int64_t>(1, std::min<int64_t>(env_blocks(), contig ? (A.rowlen + per_block - 1) / per_block : (A.nrows + 3) / 4));
     SpcWorkspace ws(d_workspace, workspace_bytes);
     SPC_WS_TAKE(d_partial, ws, double, 5 * (size_t)nblocks);
     A.partial = d_partial;
-    if (arr) hipLaunchKernelGGL(stats_global_kernel<true>, dim3(nblocks), dim3(256), 0, st, A);
-    else hipLaunchKernelGGL(stats_global_kernel<false>, dim3(nblocks), dim3(256), 0, st, A);
+    const bool thr = (A.mask.flags & (SPC_MASK_GT | SPC_MASK_GE | SPC_MASK_LT | SPC_MASK_LE)) != 0;
+    if (arr && thr) hipLaunchKernelGGL((stats_global_kernel<true, true>), dim3(nblocks), dim3(256), 0, st, A);
+    else if (arr) hipLaunchKernelGGL((stats_global_kernel<true, false>), dim3(nblocks), dim3(256), 0, st, A);
+    else if (thr) hipLaunchKernelGGL((stats_global_kernel<false, true>), dim3(nblocks), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((stats_global_kernel<false, false>), dim3(nblocks), dim3(256), 0, st, A);
     hipError_t e = hipGetLastError();
     std::vector<double> h((size_t)5 * nblocks);
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_partial, sizeof(double) * 5 * nblocks, hipMemcpyDeviceToHost, st);

@@ -422,3 +422,38 @@ def test_c2_sigma_clip_1024cubed_periodic_rows(gpu):
         ok = ~np.isnan(got) & ~np.isnan(exp)
         assert np.array_equal(got[ok], exp[ok])
         assert np.array_equal(got, whole[:, :ty], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_sigma_clip_1024cubed_is_reproducible_from_launch_to_launch(gpu):
+    """The one-kernel sigma clip keeps a block's rays resident across its iterations and reuses one set of shared words
+    for every descent: a wave that entered the next iteration used to reset the word another wave was still reading
+    (the upper middle sample of an even count), and one launch in four clipped one 8-row period differently
+    (round 4, tests/stress_clip_determinism.py: 22 of 60 launches; 0 of 80 with the barrier).  Twelve launches over
+    the same input must give the same samples: count / sum / sum of squares / extrema of the result and the per-ray
+    counts and sums, period by period."""
+    shape, ty = (1024, 1024, 1024), 8
+    _need(shape[0] * shape[1] * shape[2] * (4 + 4 + 1) * 1.2)
+    rng = np.random.default_rng(77)
+    tile = rng.standard_normal((shape[0], ty, shape[2])).astype(np.float32)
+    tile[rng.random(tile.shape) < 0.02] *= 15.0
+    tile[:, 2, 16:24] = np.nan
+    tmask = rng.random(tile.shape) < 0.9
+    cube, mask = DeviceArray(shape, np.float32), DeviceArray(shape, np.uint8)
+    _replicate_rows(cube, tile, 4)
+    _replicate_rows(mask, tmask.astype(np.uint8), 1)
+    ms = ops.MaskSpec(_lib.MASK_ARRAY, array=mask)
+    ref = None
+    for launch in range(12):
+        out = ops.sigma_clip_axis0(cube, sigma=3.0, mask=ms)
+        st = ops.stats_global(out)
+        per_ray = ops.stats_axis(out, 0, want=("count", "sum"))
+        cnt, s = per_ray["count"].get(), per_ray["sum"].get()
+        del out
+        key = tuple(st[k] for k in ("npts", "sum", "sumsq", "min", "max"))
+        ref = key if ref is None else ref
+        assert key == ref, "launch %d: %r != %r" % (launch, key, ref)
+        cnt = cnt.reshape(shape[1] // ty, ty, shape[2])
+        s = s.reshape(shape[1] // ty, ty, shape[2])
+        assert np.array_equal(cnt, np.broadcast_to(cnt[0], cnt.shape)), "launch %d: counts differ between periods" % launch
+        assert np.array_equal(s, np.broadcast_to(s[0], s.shape), equal_nan=True), "launch %d: sums differ between periods" % launch
