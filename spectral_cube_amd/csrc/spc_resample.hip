@@ -31,7 +31,7 @@ struct LerpArgs {
 
 __device__ __forceinline__ float load_filled(const float* p, const uint8_t* pm, const MaskDev& m, int64_t off, int64_t moff) {
     const float v = p[off];
-    bool inc = spc_pred(m.flags, m.thr_lo, m.thr_hi, v);
+    bool inc = spc_pred_valid(m, v);                         // (an excluded sample becomes NaN: rejecting NaN itself changes nothing)
     if (pm) inc = inc && pm[moff] != 0;
     return inc ? v : NAN;
 }
@@ -55,7 +55,7 @@ __device__ __forceinline__ typename LV<VEC>::F load_filled_v(const float* p, con
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const float x = lget(v, i);
-            bool inc = spc_pred(m.flags, m.thr_lo, m.thr_hi, x);
+            bool inc = spc_pred_valid(m, x);
             if (pm) inc = inc && pm[moff + i] != 0;
             lset(v, i, inc ? x : NAN);
         }

@@ -224,39 +224,40 @@ struct WmArgs {
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
+template <int U>
 __global__ __launch_bounds__(256) void weighted_moments_kernel(const WmArgs A) {
-    constexpr int ZW = 4, U = 4;
+    constexpr int ZW = 4;
     __shared__ double sh[ZW - 1][4][4][64];            // wave, {s0, s1, s2, chk}, column, lane
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (the wave index through readfirstlane: a plane's address offset and its three weights are then provably uniform -
+    //  scalar loads instead of three per-lane loads per plane, round 4)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t x = ((int64_t)blockIdx.x * 64 + lane) * 4;
     const int64_t y = blockIdx.y;
     const bool live = x < A.nx;
     const float* p = A.cube + y * A.row_stride + (live ? x : 0);
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     float chk[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int64_t k0 = w; k0 < A.nz; k0 += ZW * U) {
+    auto add = [&](const f32x4w& v, int64_t k) {
+        const double w0 = A.w[3 * k], w1 = A.w[3 * k + 1], w2 = A.w[3 * k + 2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double d = (double)v[c];
+            s0[c] = fma(d, w0, s0[c]);
+            s1[c] = fma(d, w1, s1[c]);
+            s2[c] = fma(d, w2, s2[c]);
+            chk[c] = fmaf(v[c], 0.f, chk[c]);               // NaN iff a NaN / Inf was read
+        }
+    };
+    int64_t k0 = w;
+    for (; k0 + (int64_t)(U - 1) * ZW < A.nz; k0 += ZW * U) {   // U planes (stride ZW) in flight per lane
         f32x4w v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t k = min(k0 + (int64_t)u * ZW, A.nz - 1);
-            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4w*>(p + k * A.plane_stride));
-        }
+        for (int u = 0; u < U; ++u)
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4w*>(p + (k0 + (int64_t)u * ZW) * A.plane_stride));
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * ZW;
-            if (k < A.nz) {                                 // wave-uniform
-                const double w0 = A.w[3 * k], w1 = A.w[3 * k + 1], w2 = A.w[3 * k + 2];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const double d = (double)v[u][c];
-                    s0[c] = fma(d, w0, s0[c]);
-                    s1[c] = fma(d, w1, s1[c]);
-                    s2[c] = fma(d, w2, s2[c]);
-                    chk[c] = fmaf(v[u][c], 0.f, chk[c]);    // NaN iff a NaN / Inf was read
-                }
-            }
-        }
+        for (int u = 0; u < U; ++u) add(v[u], k0 + (int64_t)u * ZW);
     }
+    for (; k0 < A.nz; k0 += ZW) add(*reinterpret_cast<const f32x4w*>(p + k0 * A.plane_stride), k0);
     if (w > 0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -336,7 +337,9 @@ int try_weighted_moments(ConvArgs& A, const spc_cube_f32* cube, const double* h_
     WmArgs W{};
     W.cube = A.cube; W.nz = A.nz; W.ny = A.ny; W.nx = A.nx; W.row_stride = A.row_stride; W.plane_stride = A.plane_stride;
     W.w = d_w; W.dv = A.dv; W.m1_add = A.m1_add; W.mo = A.mo; W.mo_row_stride = A.mo_row_stride; W.status = d_status;
-    hipLaunchKernelGGL(weighted_moments_kernel, dim3((unsigned)((A.nx + 255) / 256), (unsigned)A.ny), dim3(256), 0, st, W);
+    static const int wm_u = [] { const char* e = getenv("SPC_WMOM_U"); return e ? atoi(e) : 8; }();      // tuning hook
+    if (wm_u == 4) hipLaunchKernelGGL(weighted_moments_kernel<4>, dim3((unsigned)((A.nx + 255) / 256), (unsigned)A.ny), dim3(256), 0, st, W);
+    else hipLaunchKernelGGL(weighted_moments_kernel<8>, dim3((unsigned)((A.nx + 255) / 256), (unsigned)A.ny), dim3(256), 0, st, W);
     A.status = d_status;
     return 1;
 }
