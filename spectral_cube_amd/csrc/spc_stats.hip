@@ -364,9 +364,9 @@ struct ArgArgs {
 template <int VEC, bool ARR>
 __global__ __launch_bounds__(256) void arg_march_kernel(const ArgArgs B) {
     const StatArgs& A = B.s;
-    constexpr int ZW = 4, U = 4;
+    constexpr int ZW = 4, U = VEC == 4 ? 8 : 4;
     __shared__ ArgAcc s_acc[ZW - 1][64][VEC];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t x = ((int64_t)blockIdx.x * 64 + lane) * VEC;
     const int64_t o = blockIdx.y;
     const bool live = x < A.nx;
@@ -376,29 +376,34 @@ __global__ __launch_bounds__(256) void arg_march_kernel(const ArgArgs B) {
     ArgAcc a[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) a[c] = arg_zero();
-    for (int64_t k0 = w; k0 < A.n_march; k0 += ZW * U) {
+    auto fetch = [&](int64_t k, float (&v)[VEC], unsigned (&mk)[VEC]) {
+        if (VEC == 4) {
+            const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + k * A.march_stride));
+            const uint32_t m = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm + k * A.m_march_stride)) : 0x01010101u;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) { v[c] = q[c]; mk[c] = (m >> (8 * c)) & 0xffu; }
+        } else {
+            v[0] = p[k * A.march_stride];
+            mk[0] = ARR ? pm[k * A.m_march_stride] : 1u;
+        }
+    };
+    int64_t k0 = w;
+    for (; k0 + (int64_t)(U - 1) * ZW < A.n_march; k0 += ZW * U) {      // U planes (stride ZW) in flight per lane
         float v[U][VEC];
         unsigned mk[U][VEC];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t k = min(k0 + (int64_t)u * ZW, A.n_march - 1);
-            if (VEC == 4) {
-                const f32x4 q = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + k * A.march_stride));
-                const uint32_t m = ARR ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(pm + k * A.m_march_stride)) : 0x01010101u;
+        for (int u = 0; u < U; ++u) fetch(k0 + (int64_t)u * ZW, v[u], mk[u]);
 #pragma unroll
-                for (int c = 0; c < VEC; ++c) { v[u][c] = q[c]; mk[u][c] = (m >> (8 * c)) & 0xffu; }
-            } else {
-                v[u][0] = p[k * A.march_stride];
-                mk[u][0] = ARR ? pm[k * A.m_march_stride] : 1u;
-            }
-        }
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * ZW;
-            const bool in = k < A.n_march;
+            for (int c = 0; c < VEC; ++c) arg_add(a[c], v[u][c], included(A.mask, v[u][c], mk[u][c]), (int)(k0 + (int64_t)u * ZW));
+    }
+    for (; k0 < A.n_march; k0 += ZW) {
+        float v[VEC];
+        unsigned mk[VEC];
+        fetch(k0, v, mk);
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) arg_add(a[c], v[u][c], in && included(A.mask, v[u][c], mk[u][c]), (int)k);
-        }
+        for (int c = 0; c < VEC; ++c) arg_add(a[c], v[c], included(A.mask, v[c], mk[c]), (int)k0);
     }
     if (w > 0) {
 #pragma unroll
