@@ -373,3 +373,92 @@ def test_moments_f64_kernel_against_the_oracle(gpu, shape):
                 W.simplefilter("ignore")
                 assert np.array_equal(r["vmax"].get(), np.nanmax(filled, axis=0), equal_nan=True)
                 assert np.array_equal(r["vmin"].get(), np.nanmin(filled, axis=0), equal_nan=True)
+
+
+# ---- the moment kernel's template space (round 4: predicate form, sums only / + count, waves per block, XCD grouping) ----
+_MOM_MASKS = {
+    "none": lambda d, arr: (0, 0.0, 0.0, None, ~np.isnan(d)),
+    "isfinite": lambda d, arr: (_lib.MASK_FINITE, 0.0, 0.0, None, np.isfinite(d)),
+    "array": lambda d, arr: (0, 0.0, 0.0, arr, arr & ~np.isnan(d)),
+    "array + isfinite + (lo, hi]": lambda d, arr: (_lib.MASK_FINITE | _lib.MASK_GT | _lib.MASK_LE, -0.25, 3.0, arr,
+                                                   arr & np.isfinite(d) & (np.nan_to_num(d) > np.float32(-0.25)) & (np.nan_to_num(d) <= np.float32(3.0))),
+    "[lo, hi)": lambda d, arr: (_lib.MASK_GE | _lib.MASK_LT, 0.5, 2.5, None,
+                                ~np.isnan(d) & (np.nan_to_num(d, nan=-9.0) >= np.float32(0.5)) & (np.nan_to_num(d, nan=9.0) < np.float32(2.5))),
+}
+
+
+@pytest.mark.parametrize("mask_kind", sorted(_MOM_MASKS))
+@pytest.mark.parametrize("launch", [{}, {"SPC_MOMENTS_ZW": "8"}, {"SPC_MOMENTS_ZW": "8", "SPC_MOMENTS_U": "2", "SPC_MOMENTS_XCD": "1"},
+                                    {"SPC_MOMENTS_ZW": "4", "SPC_MOMENTS_U": "4", "SPC_MOMENTS_XCD": "1", "SPC_MOMENTS_NSPLIT": "3"},
+                                    {"SPC_MOMENTS_ZW": "1", "SPC_MOMENTS_NSPLIT": "1"}])
+@pytest.mark.parametrize("shape", [(640, 24, 136), (77, 13, 52), (530, 9, 50)])
+def test_moment_kernel_template_space(gpu, monkeypatch, shape, launch, mask_kind):
+    """spc_moments_f32 with the three sums alone (EXT = 0: an any-valid bit instead of the count), with the count, for every
+    predicate form (none / isfinite: one compare; thresholds: the canonical three), with and without a mask array, for 1 / 4 / 8
+    waves per block, z splits with the combine kernel, XCD grouping with block counts that are no multiple of 8, 16-byte and
+    2-lane rows (nx = 50): against the oracle (float64 sums: 1e-12 of the scale), NaN pattern and counts exact."""
+    from spectral_cube_amd import synth
+    for k, v in launch.items():
+        monkeypatch.setenv(k, v)
+    nz, ny, nx = shape
+    rng = np.random.default_rng(nz + nx)
+    d = synth.gaussian_line_cube(shape, 40 + nz)
+    d[rng.random(shape) < 0.01] = np.nan
+    if mask_kind in ("isfinite", "array + isfinite + (lo, hi]"):
+        d[rng.random(shape) < 0.003] = np.inf
+    d[:, 1, 3:9] = np.nan                                    # rays without a valid sample
+    arr = rng.random(shape) < 0.7
+    arr[:, 2, 10:20] = False
+    flags, lo, hi, marr, inc = _MOM_MASKS[mask_kind](d, arr)
+    spec = ops.MaskSpec(flags | (_lib.MASK_ARRAY if marr is not None else 0), lo, hi,
+                        DeviceArray.from_numpy(marr.astype(np.uint8)) if marr is not None else None)
+    v = synth.spectral_axis(nz)
+    cen = v - v[0]
+    cref = cen[nz // 2]
+    dcube, dcen = DeviceArray.from_numpy(d), DeviceArray.from_numpy(cen - cref)
+    e0, e1, e2 = O.moments012(d, inc, cen, 500.0, v[0])
+    nval = inc.sum(axis=0)
+    for want in (("m0", "m1", "m2"), ("m0", "m1", "m2", "nvalid"), ("m0",)):
+        r = ops.moments(dcube, dcen, dv=500.0, m1_add=cref + v[0], mask=spec, want=want)
+        with np.errstate(all="ignore"):
+            m0 = r["m0"].get()
+            assert np.array_equal(np.isnan(m0), nval == 0), (want, "all-bad rays are NaN, no others")
+            assert_close(m0, e0, atol=1e-12 * np.nanmax(np.abs(e0)), what="m0")
+            if "m1" in want:
+                assert_close(r["m1"].get(), e1, atol=1e-9 * 500.0 * nz, what="m1")
+                m2, okm = r["m2"].get(), np.isfinite(e2) & (np.abs(e0) > 1e-3 * np.nanmax(np.abs(e0)))
+                assert np.array_equal(np.isnan(m2), np.isnan(e2))
+                assert np.all(np.abs(m2[okm] - e2[okm]) <= 1e-8 * (500.0 * nz) ** 2)
+        if "nvalid" in want:
+            assert np.array_equal(r["nvalid"].get(), nval)
+
+
+@pytest.mark.parametrize("shape", [(40, 96, 257), (64, 128, 256), (3, 50, 1366)])
+@pytest.mark.parametrize("kind", ["none", "array", "array + thresholds", "isfinite"])
+def test_stats_global_linear_groups_and_ragged_end(gpu, shape, kind):
+    """statistics() of a contiguous cube through the round-4 kernel: whole 8-chunk groups (wave-wide popcount, four accumulator
+    sets, NaN-substituted extrema), the last partial group (whole chunks, then a ragged chunk through the per-lane
+    accumulators) and the scalar tail, with one compare (no threshold term) and with the canonical three: count and extrema
+    exact, sums to 1e-12 (float64 sums of the same float32 samples in another order)."""
+    rng = np.random.default_rng(shape[2])
+    d = (rng.standard_normal(shape) * 3).astype(np.float32)
+    d[rng.random(shape) < 0.01] = np.nan
+    d[rng.random(shape) < 0.002] = -np.inf
+    arr = rng.random(shape) < 0.6
+    if kind == "none":
+        spec, inc = None, ~np.isnan(d)
+    elif kind == "isfinite":
+        spec, inc = ops.MaskSpec(_lib.MASK_FINITE), np.isfinite(d)
+    elif kind == "array":
+        spec, inc = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(arr.astype(np.uint8))), arr & ~np.isnan(d)
+    else:
+        spec = ops.MaskSpec(_lib.MASK_ARRAY | _lib.MASK_GE | _lib.MASK_LT, -2.0, 4.5, DeviceArray.from_numpy(arr.astype(np.uint8)))
+        with np.errstate(invalid="ignore"):
+            inc = arr & (d >= np.float32(-2.0)) & (d < np.float32(4.5))
+    st = ops.stats_global(DeviceArray.from_numpy(d), mask=spec)
+    sel = d[inc].astype(np.float64)
+    assert st["npts"] == sel.size and st["min"] == sel.min() and st["max"] == sel.max()
+    if np.isfinite(sel.sum()):
+        assert st["sum"] == pytest.approx(sel.sum(), rel=1e-12, abs=1e-9) and st["sumsq"] == pytest.approx((sel * sel).sum(), rel=1e-12)
+    else:
+        assert st["sum"] == sel.sum()                        # -inf samples under a mask that keeps them: the sum is -inf, like numpy's
