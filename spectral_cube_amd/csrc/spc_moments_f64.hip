@@ -20,23 +20,36 @@ namespace {
 
 constexpr int kLanes = 64;
 constexpr int kZW = 8;                  // waves per block, each takes every 8th channel
-constexpr int kU = 4;                   // loads in flight per lane
+constexpr int kU = 8;                   // loads in flight per lane (round 4: 4 -> 8, like the float32 kernel)
 
 struct MaskDev64 {
     uint32_t flags;
-    double lo, hi;
+    double lo, hi;               // the thresholds as given
     const uint8_t* arr;
     int64_t row_stride, plane_stride;
+    double clim, clo, chi;       // canonical form: |v| <= clim && !(v <= clo) && !(v >= chi)  (canonical64)
 };
 
-__device__ __forceinline__ bool pred64(const MaskDev64& m, double v) {
-    bool inc = true;
-    if (m.flags & SPC_MASK_FINITE) inc = inc & (fabs(v) <= 1.7976931348623157e308);     // false for NaN / inf
-    if (m.flags & SPC_MASK_GT) inc = inc & (v > m.lo);
-    if (m.flags & SPC_MASK_GE) inc = inc & (v >= m.lo);
-    if (m.flags & SPC_MASK_LT) inc = inc & (v < m.hi);
-    if (m.flags & SPC_MASK_LE) inc = inc & (v <= m.hi);
-    return inc;
+// the float64 twin of spc_canonical_pred (spc_common.h): three compares whatever the flags, NaN samples never pass; an absent bound
+// is NaN, >= / <= become strict compares against the neighbouring double, a NaN threshold rejects everything
+static inline void canonical64(uint32_t f, double thr_lo, double thr_hi, double* lim, double* lo, double* hi) {
+    *lim = (f & SPC_MASK_FINITE) ? 1.7976931348623157e308 : INFINITY;
+    *lo = NAN;
+    *hi = NAN;
+    if (f & (SPC_MASK_GT | SPC_MASK_GE)) {
+        if (thr_lo != thr_lo) *lim = -1.0;
+        else if (f & SPC_MASK_GT) *lo = thr_lo;
+        else *lo = (thr_lo == -INFINITY) ? NAN : nextafter(thr_lo, -INFINITY);
+    }
+    if (f & (SPC_MASK_LT | SPC_MASK_LE)) {
+        if (thr_hi != thr_hi) *lim = -1.0;
+        else if (f & SPC_MASK_LT) *hi = thr_hi;
+        else *hi = (thr_hi == INFINITY) ? NAN : nextafter(thr_hi, INFINITY);
+    }
+}
+
+__device__ __forceinline__ bool pred64(const MaskDev64& m, double v) {      // mask predicate AND "not NaN"
+    return (fabs(v) <= m.clim) & !(v <= m.clo) & !(v >= m.chi);
 }
 
 struct Mom64Args {
@@ -85,7 +98,7 @@ template <int VEC, bool ARR, bool EXT, int ORDER>
 __global__ __launch_bounds__(kLanes * kZW) void moments_f64_kernel(const Mom64Args A) {
     using F = typename Vec64<VEC>::F;
     using M = typename Vec64<VEC>::M;
-    const int lane = threadIdx.x, w = threadIdx.y;
+    const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane(threadIdx.y);   // blockDim.x = 64: a plane's coordinate is a scalar load
     const int64_t g = (int64_t)blockIdx.x * kLanes + lane;
     const bool live = g < A.ngroups;
     const int64_t gg = live ? g : 0;
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(kLanes * kZW) void moments_f64_kernel(const Mom64Ar
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const double val = vget(v, i);
-            bool ok = pred64(A.mask, val) & (val == val);
+            bool ok = pred64(A.mask, val);
             if (ARR) ok = ok & (mget(m, i) != 0);
             const double wd = ok ? val : 0.0;
             if (ORDER) {
@@ -210,9 +223,11 @@ int check_cube64(const spc_cube_f64* c) {
 int mask64_to_dev(const spc_mask_f64* m, const spc_cube_f64* c, MaskDev64* out) {
     out->flags = 0; out->lo = 0.0; out->hi = 0.0; out->arr = nullptr;
     out->row_stride = c->row_stride; out->plane_stride = c->plane_stride;
+    canonical64(0u, 0.0, 0.0, &out->clim, &out->clo, &out->chi);
     if (!m) return SPC_OK;
     SPC_REQUIRE((m->flags & ~63u) == 0, "unknown mask flags 0x%x", m->flags);
     out->flags = m->flags; out->lo = m->thr_lo; out->hi = m->thr_hi;
+    canonical64(m->flags, m->thr_lo, m->thr_hi, &out->clim, &out->clo, &out->chi);
     if (m->flags & SPC_MASK_ARRAY) {
         SPC_REQUIRE(m->d_array != nullptr, "SPC_MASK_ARRAY set but d_array is NULL");
         out->arr = m->d_array;
