@@ -188,6 +188,11 @@ __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
     const float* p = A.cube + y * A.row_stride + x;
     const uint8_t* pm = ARR ? A.mask.arr + y * A.mask.row_stride + x : nullptr;
     const float lim = A.lim, lo = A.lo, hi = A.hi;
+    // the channel coordinates through the constant address space: a uniform index is then ALWAYS a scalar load (left in the
+    // global address space the ZW = 8 instantiation fell back to eight per-lane loads per iteration - the no-clobber analysis
+    // that licenses a scalar load of global memory gives up on the larger kernel)
+    typedef const double __attribute__((address_space(4))) cdouble;
+    cdouble* cenp = (cdouble*)A.cen;
 
     Acc acc[VEC];
 #pragma unroll
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t zz = z + (int64_t)u * ZW;
-                const double c = A.cen[zz];                      // uniform address: a scalar load
+                const double c = cenp[zz];                       // uniform index: a scalar load
                 const double c2 = c * c;
 #pragma unroll
                 for (int i = 0; i < VEC; ++i) {
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(kLanes * ZW) void moments_kernel(const MomArgs A) {
             const F v = *reinterpret_cast<const F*>(p + z * A.plane_stride);
             M m = 0;
             if (ARR) m = *reinterpret_cast<const M*>(pm + z * A.mask.plane_stride);
-            const double c = A.cen[z];
+            const double c = cenp[z];
             const double c2 = c * c;
 #pragma unroll
             for (int i = 0; i < VEC; ++i) {

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kLanes * kZW) void moments_f64_kernel(const Mom64Ar
         mu[i] = (ORDER && live) ? A.mu[y * A.out_row_stride + x + i] : 0.0;
     }
     auto take = [&](const F& v, const M& m, int64_t z) {
-        const double c = A.cen[z];
+        const double c = ((const double __attribute__((address_space(4)))*)A.cen)[z];   // uniform index: a scalar load
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
             const double val = vget(v, i);

@@ -61,7 +61,7 @@ OPS = {
 only = os.environ.get("STRESS_ONLY")
 total_bad = 0
 for name, fn in OPS.items():
-    if only and only not in name:
+    if only and not any(o in name for o in only.split(",")):
         continue
     try:
         ref = fn()
