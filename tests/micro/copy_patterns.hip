@@ -45,6 +45,20 @@ __global__ __launch_bounds__(256) void zmarch(const float* __restrict__ in, floa
     }
 }
 
+// z-march copy with separate plane strides (is a power-of-two plane stride what holds the march at 5.0 TB/s?)
+template <int U>
+__global__ __launch_bounds__(256) void zmarch_pad(const float* __restrict__ in, float* __restrict__ out, long nz, long plane, long ps_in, long ps_out) {
+    const long g = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (g >= plane) return;
+    for (long z = 0; z + U <= nz; z += U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load((const f4*)(in + (z + u) * ps_in + g));
+#pragma unroll
+        for (int u = 0; u < U; ++u) __builtin_nontemporal_store(v[u] * 1.5f, (f4*)(out + (z + u) * ps_out + g));
+    }
+}
+
 // read-only forms for the ceiling
 template <int U>
 __global__ __launch_bounds__(256) void lin_read(const f4* __restrict__ in, float* sink, long n4) {
@@ -143,6 +157,15 @@ int main(int argc, char** argv) {
         timeit(name, rw, [&] { zmarch<8, 1><<<grid, 256>>>(in, o2, nz, plane); });
         snprintf(name, 128, "lin copy U8 nt 8/CU, out + %ld B", off);
         timeit(name, rw, [&] { lin<8, 1><<<2048, 256>>>((const f4*)in, (f4*)o2, n4); });
+    }
+    {   // padded plane strides: 1000 planes so that the padded cubes fit the same allocations
+        const long nzp = 1000;
+        dim3 grid((unsigned)(plane / 4 / 256), 1);
+        for (long pi : {0L, 1088L}) for (long po : {0L, 1088L, 16384L + 1088}) {
+            snprintf(name, 128, "zmarch copy U8 nt, plane stride + %ld in / + %ld out", pi, po);
+            timeit(name, 2.0 * nzp * plane * 4, [&] { zmarch_pad<8><<<grid, 256>>>(in, out, nzp, plane, plane + pi, plane + po); });
+        }
+        timeit("zmarch copy U4 nt, + 1088 / + 1088", 2.0 * nzp * plane * 4, [&] { zmarch_pad<4><<<grid, 256>>>(in, out, nzp, plane, plane + 1088, plane + 1088); });
     }
     return 0;
 }
