@@ -1,3 +1,4 @@
+// build + run: hipcc --offload-arch=gfx950 -O3 -o tests/micro/mask_patterns tests/micro/mask_patterns.hip && gpurun -- tests/micro/mask_patterns
 // Microbenchmark: the moment kernel's two streams (float32 cube + uint8 mask), read-only, no arithmetic.
 //   A<ZW,U>    : the kernel's pattern - a wave reads 1 KiB of data + 256 B of mask per plane, ZW waves on interleaved planes
 //   B<ZW,U,K>  : a wave reads K consecutive KiB of data + K x 256 B of mask per plane (lane l owns columns 4l + 256k .. + 3)

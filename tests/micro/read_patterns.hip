@@ -1,3 +1,4 @@
+// build + run: hipcc --offload-arch=gfx950 -O3 -o tests/micro/read_patterns tests/micro/read_patterns.hip && gpurun -- tests/micro/read_patterns
 // Microbenchmark: why does the moment kernel's z-march read 6.0 - 6.5 TB/s when a linear float4 read of the same
 // bytes reaches 7.1 - 7.2 TB/s (tests/micro/copy_patterns.hip)?  Read-only variants of the march:
 //   zm<LB,ZW,U> : a block of 64 x ZW lanes; ZW waves take interleaved planes of the same 64 x LB/4 columns
