@@ -2,6 +2,7 @@
 # command (configs[1], the north-star record, the configs[2..4] records, the next rows), then FETCH_SIZE / WRITE_SIZE in
 # separate --pmc passes OF THE SAME COMMAND (MI355X_MICROARCH.md: one counter per pass, FETCH_SIZE x 2 on gfx950), summarised
 # per bench record by tests/prof_bench_summary_r04.py.  Everything lands in gpurun_out/prof_r04/.
+# (gpurun MERGES gpurun_out/ back: remove the local gpurun_out/prof_r04 before a new run, or the summary re-run locally mixes runs)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r04

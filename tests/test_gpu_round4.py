@@ -462,3 +462,36 @@ def test_stats_global_linear_groups_and_ragged_end(gpu, shape, kind):
         assert st["sum"] == pytest.approx(sel.sum(), rel=1e-12, abs=1e-9) and st["sumsq"] == pytest.approx((sel * sel).sum(), rel=1e-12)
     else:
         assert st["sum"] == sel.sum()                        # -inf samples under a mask that keeps them: the sum is -inf, like numpy's
+
+
+@pytest.mark.parametrize("shape", [(100, 131), (16, 64), (257, 70)])
+@pytest.mark.parametrize("kind", ["gauss29", "gauss33 x gauss9", "row 1 x 9", "column 9 x 1", "rotated (not an outer product)", "gauss35 (too wide)"])
+def test_map_conv2d_separable_form(gpu, monkeypatch, shape, kind):
+    """spc_map_conv2d_f64 (the algebraic spatial_smooth -> moment path convolves the moment sums, not the planes): an outer-product
+    kernel of up to 33 x 33 taps takes the two-pass LDS form; it must agree with the direct form (SPC_MAP_CONV_DIRECT=1) to float64
+    rounding and with scipy's zero-boundary convolution of the normalised kernel; other kernels keep the direct form."""
+    from scipy.signal import convolve2d
+    rng = np.random.default_rng(shape[1])
+    g = lambda s, n: np.exp(-0.5 * ((np.arange(n) - n // 2) / s) ** 2)      # noqa: E731
+    if kind == "gauss29":
+        k = np.outer(g(3.4, 29), g(3.4, 29))
+    elif kind == "gauss33 x gauss9":
+        k = np.outer(g(4.0, 33), g(1.2, 9) * (1 + 0.1 * np.arange(9)))      # asymmetric along x: the flip matters
+    elif kind == "row 1 x 9":
+        k = (g(1.5, 9) * (1 + 0.2 * np.arange(9)))[None, :]
+    elif kind == "column 9 x 1":
+        k = g(1.5, 9)[:, None]
+    elif kind == "gauss35 (too wide)":
+        k = np.outer(g(4.2, 35), g(4.2, 35))
+    else:
+        yy, xx = np.mgrid[-7:8, -7:8]
+        k = np.exp(-0.5 * (((xx + 0.7 * yy) / 3.0) ** 2 + ((yy - 0.7 * xx) / 1.5) ** 2))
+    m = rng.standard_normal(shape) * 100.0
+    dm = DeviceArray.from_numpy(m)
+    got = ops.map_conv2d(dm, k).get()
+    monkeypatch.setenv("SPC_MAP_CONV_DIRECT", "1")
+    direct = ops.map_conv2d(dm, k).get()
+    exp = convolve2d(m, k / k.sum(), mode="same", boundary="fill", fillvalue=0.0)
+    scale = np.abs(exp).max()
+    assert np.abs(got - direct).max() <= 1e-13 * scale
+    assert np.abs(got - exp).max() <= 1e-12 * scale
