@@ -768,7 +768,7 @@ def next_rows_records(cube, maskd, tile, tmask, device):
     sel = tile[inc].astype(np.float64)
     assert st["npts"] == sel.size and st["min"] == sel.min() and st["max"] == sel.max(), "statistics(): count / extrema"
     assert abs(st["sum"] - sel.sum()) <= 1e-10 * np.abs(sel).sum() and abs(st["sumsq"] - (sel * sel).sum()) <= 1e-10 * (sel * sel).sum()
-    out["f1_statistics"] = cfg_record("f1 statistics(): npts / min / max / sum / sumsq in one pass, 1024^3 + uint8 mask", "stats_global_kernel<ARR> (the timed call also brings 80 KiB of block records to the host and finishes there: ~0.04 ms on top of the kernel)", ms,
+    out["f1_statistics"] = cfg_record("f1 statistics(): npts / min / max / sum / sumsq in one pass, 1024^3 + uint8 mask", "stats_global_kernel<ARR> (followed by stats_finish_kernel; the timed call also waits for the 40-byte record on the host)", ms,
                                       vox * 5, vox, {"rows_checked": rows, "npts_min_max": "exact", "sum_sumsq_rel_err": "<= 1e-10"},
                                       "4 B data + 1 B mask read per voxel")
     # f4: median along the spectral axis, rays resident in registers
