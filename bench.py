@@ -274,8 +274,8 @@ PMC_ON = True         # (set False by a run at non-default shapes: the committed
 
 def pmc_traffic(record):
     """(HBM bytes per launch, source) of the bench record `record` from the PMC passes committed under profiles/:
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command at THIS shape (tests/prof_bench_r04.sh,
-    summarised per (kernel, grid) = per record by tests/prof_bench_summary_r04.py; FETCH_SIZE x 2: the gfx950 correction of
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of THIS command at THIS shape (tools/prof_bench_r04.sh,
+    summarised per (kernel, grid) = per record by tools/prof_bench_summary_r04.py; FETCH_SIZE x 2: the gfx950 correction of
     MI355X_MICROARCH.md).  (None, None) for a record the file does not hold, or at other shapes than the default."""
     global _PMC
     if not PMC_ON:

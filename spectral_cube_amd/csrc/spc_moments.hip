@@ -17,7 +17,7 @@
 // splits z further when the map is too small to fill 256 CUs, with a second
 // tiny combine kernel over fp64 partial sums.
 //
-// Issue budget (round 4, tests/micro/read_patterns.hip): this march reads 6.7 - 7.1 TB/s when nothing is
+// Issue budget (round 4, tools/micro/read_patterns.hip): this march reads 6.7 - 7.1 TB/s when nothing is
 // computed, so the instructions per voxel decide whether the kernel is bound by HBM or by issue.  The mask
 // predicate is therefore a template parameter in the canonical form of spc_canonical_pred (one compare when
 // the mask has no threshold term, three otherwise - never the five flag-guarded compares of spc_pred), the
@@ -25,7 +25,7 @@
 // include select happens in float32 before the widening, the channel coordinate of a plane is a scalar load
 // (the wave index goes through readfirstlane, so a plane's address and coordinate are provably uniform).
 // 27.7 -> 12.4 instructions per voxel; the kernel now runs within 2 - 7 % of the same two streams read with no
-// arithmetic at all (tests/micro/mask_patterns.hip), which is what is left of the 8 TB/s in this access pattern
+// arithmetic at all (tools/micro/mask_patterns.hip), which is what is left of the 8 TB/s in this access pattern
 // (profiles/r04_moments_issue.log).  SPC_MOMENTS_XCD=1 hands the blocks of one XCD neighbouring column groups
 // (+3 % on the bare read, nothing on the kernel: off).
 #include "spc_common.h"
@@ -448,7 +448,7 @@ Plan make_plan(const spc_cube_f32* c, const MaskDev& m, bool ext) {
     if (vec != 1 && vec != 2 && vec != 4) vec = 4;
     while (vec > 1 && !aligned(vec)) vec >>= 1;
     p.vec = vec;
-    // MI355X sweeps at 1024^3 (tests/tune_moments.py; profiles/r01_tune_moments.log, r04_moments_issue.log)
+    // MI355X sweeps at 1024^3 (tools/tune_moments.py; profiles/r01_tune_moments.log, r04_moments_issue.log)
     const bool arr_ = (m.flags & SPC_MASK_ARRAY) != 0;
     (void)arr_;
     p.u = env_int("SPC_MOMENTS_U", ext ? 2 : 8);

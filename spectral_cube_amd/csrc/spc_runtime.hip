@@ -9,7 +9,7 @@ static thread_local char g_err[512] = "";
 // ---- device buffer pool behind spc_malloc / spc_free ------------------------------------------
 // Cube-sized hipMalloc calls are the slowest thing a pipeline of operators meets on this stack:
 // usually ~0.2 ms, but every few calls of >= 4 GiB one takes 0.7 - 3.8 s (measured, MI355X /
-// ROCm 7.2: tests/bench_alloc.py), two orders of magnitude more than the kernel that fills the
+// ROCm 7.2: tools/bench_alloc.py), two orders of magnitude more than the kernel that fills the
 // buffer.  Freed blocks are therefore kept per device and handed out again for requests of
 // (nearly) the same size - operator pipelines allocate the same few cube / map sizes over and
 // over.  Semantics stay those of hipMalloc / hipFree: spc_free drains the device before the

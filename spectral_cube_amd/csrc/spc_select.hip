@@ -404,7 +404,7 @@ __device__ __forceinline__ int sel_load_keys_impl(const float* cube, int64_t pla
     // loads in flight per lane: the raw samples land in the key registers themselves (converted in place), so a whole
     // group costs no registers beyond the mask bytes.  Round 2 / 3a kept 8 in flight (2 KB per wave, 40 KB per CU): the
     // load phase ran at 2.1 TB/s - latency-bound - and made up 2.0 of the kernel's 2.9 ms at 1024^3.
-    // 512-thread blocks (round 4, tests/bench_select_bt.py at 1024^3): 16 / 32 / 64 in flight - no mask 1.95 / 1.87 / 1.93 ms against 2.00,
+    // 512-thread blocks (round 4, tools/bench_select_bt.py at 1024^3): 16 / 32 / 64 in flight - no mask 1.95 / 1.87 / 1.93 ms against 2.00,
     // uint8 mask 2.18 / 2.33 ms against 2.24 (its bytes wait in registers of their own); the 256-thread table loses with more than 8.
     constexpr int kWant = BT == 512 ? (ARR ? 16 : SPC_SEL_INFLIGHT_WIDE) : SPC_SEL_INFLIGHT;
     constexpr int U = KPL < kWant ? KPL : kWant;
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip
         // ---- valid count, sum, sum of squares of the ray (what spc_stats_axis_f32 gives the unfused path)
         // (the previous iteration's descent ends with lanes reading S.nextkey[r] behind its last barrier: without this barrier a
         //  wave that is already here resets the word under them - the upper of an even count's two middle samples came back as
-        //  the "excluded" key in one launch out of four, tests/stress_clip_determinism.py)
+        //  the "excluded" key in one launch out of four, tools/stress_clip_determinism.py)
         if (it > 0) __syncthreads();
         sel_reset<TS, BT>(S);
         int cnt = 0, low = 0;
@@ -1046,7 +1046,7 @@ extern "C" int spc_percentile_axis0_f32(int device, void* stream, const spc_cube
         // Blocks of 512 threads (round 3): the lanes of a wave cover 64 / 32 / 16 / 8 ADJACENT spaxels for rays of up to 512 /
         // 1024 / 2048 / 4096 samples - a plane's samples of a block are one 256 / 128 / 64 / 32-byte run.  With 256 threads
         // (16 spaxels, 64-byte runs at 1024 channels) the one read of the cube ran at 2.1 TB/s and made up 2.0 of the 2.9 ms
-        // at 1024^3 (timing-only ablation, tests/bench_select_ablate.py); 32 spaxels: 0.92 ms.  SPC_SELECT_BT=256: the former table.
+        // at 1024^3 (timing-only ablation, tools/bench_select_ablate.py); 32 spaxels: 0.92 ms.  SPC_SELECT_BT=256: the former table.
         {
             const char* be = getenv("SPC_SELECT_BT");
             // (rays of up to 256 samples keep the 256-thread table - 32 spaxels per block already, and the per-ray costs of the

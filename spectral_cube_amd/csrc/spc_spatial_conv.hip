@@ -569,7 +569,10 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
                     (A.out_plane_stride % 4 == 0) && (((uintptr_t)d_out) % 16 == 0);
     A.status = nullptr;
     A.inv_ksum = (float)(1.0 / sum);
+    // den == 0 means "centre excluded" (NaN from 0 * 1/0) only for non-negative taps with a positive centre: signed taps can
+    // cancel to den == 0 over a valid centre, and then astropy's filled-centre rule needs the lookup
     A.centre_zero = (A.ky[R / 2] * A.kx[R / 2] == 0.f) ? 1 : 0;
+    for (int i = 0; i < R; ++i) if (A.ky[i] < 0.f || A.kx[i] < 0.f) A.centre_zero = 1;
     { const char* xe = getenv("SPC_XCD_SWIZZLE"); A.xcd_swizzle = xe ? (atoi(xe) != 0) : 1; }
     canonical_pred(A);
     // (the 49- and 65-tap rings - 35 to 65 taps - have an all-valid kernel for isotropic kernels only: two sets of

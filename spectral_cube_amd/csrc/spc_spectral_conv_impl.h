@@ -23,7 +23,7 @@
 // map and keeps ill-conditioned moments of the smoothed cube inside 1e-5.
 //
 // What bounds it: VALU issue, not HBM.  Measured on MI355X
-// (tests/micro/valu_rate.hip): a wave64 VALU instruction occupies its SIMD for
+// (tools/micro/valu_rate.hip): a wave64 VALU instruction occupies its SIMD for
 // ~4 cycles whether it is v_fmac_f32, v_pk_fma_f32 or v_fma_f64.  Hence:
 //   * the FMAs are in-place `v_fma_f64` inline asm with the weight in an SGPR pair:
 //     left alone, LLVM sinks each slot's FMA chain to its emission point (R-long

@@ -77,7 +77,7 @@ struct StatArgs {
 };
 
 // ---- whole cube -------------------------------------------------------------------------
-// Round 4: a global reduction is free to read the cube LINEARLY (7.1 TB/s, tests/micro/copy_patterns.hip), so what it costs
+// Round 4: a global reduction is free to read the cube LINEARLY (7.1 TB/s, tools/micro/copy_patterns.hip), so what it costs
 // per sample decides the rate.  One accumulator set per vector component (four independent float64 chains instead of one
 // serial chain of 16 dependent additions per iteration), the excluded sample becomes a NaN that v_min / v_max ignore (one
 // select instead of two), the valid count is a scalar population count of the compare mask (per wave, not per lane), the

@@ -20,6 +20,7 @@ arrive as NaN, so no mask is passed to the kernels.  Empty chunks are passed
 through like the reference's wrappers do (:600-610).
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -74,6 +75,29 @@ class _ThreadStage:
                 _lib.call("spc_host_free", C.c_void_p(self.ptr))
         except Exception:
             pass
+
+
+
+def _host_result_budget():
+    """bytes a cube -> cube result may take in host RAM: half of MemAvailable (SPC_DASK_RESULT_RAM_MB overrides)"""
+    env = os.environ.get("SPC_DASK_RESULT_RAM_MB")
+    if env:
+        return int(env) << 20
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) * 1024 // 2
+    except OSError:
+        pass
+    return 1 << 62
+
+
+def _unlink_quiet(path):
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
 
 
 def _ctx(device):
@@ -319,8 +343,22 @@ class DaskCubeOps:
 
     def _to_dask(self, pending):
         import dask.array as da
-        out = np.empty(tuple(pending.shape), dtype=np.float32)
-        _prefault(out)
+        shape = tuple(pending.shape)
+        nbytes = 4 * int(np.prod(shape))
+        # The reference keeps these results lazy; here calling the method already runs the strip pipeline, and the
+        # result has to land somewhere.  In RAM while it fits beside what else lives there (half of MemAvailable);
+        # beyond that in a memory-mapped .npy under SPC_DASK_SPILL_DIR (default: the temp dir), so a cube larger than
+        # host memory stays out of core instead of ending in the OOM killer.
+        if nbytes > _host_result_budget():
+            import tempfile, uuid as _uuid
+            d = os.environ.get("SPC_DASK_SPILL_DIR") or tempfile.gettempdir()
+            path = os.path.join(d, "spc-dask-result-%d-%s.npy" % (os.getpid(), _uuid.uuid4().hex))
+            out = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=shape)
+            import weakref
+            weakref.finalize(out, _unlink_quiet, path)
+        else:
+            out = np.empty(shape, dtype=np.float32)
+            _prefault(out)
         pending.stream_into(out)
         chunks = self._chunks if (self._chunks is not None and tuple(pending.shape) == self._shape) else "auto"
         # (an explicit name: by default from_array HASHES the array's contents for its task name - 1.5 s for 4 GiB)

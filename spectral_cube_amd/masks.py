@@ -13,9 +13,13 @@ bookkeeping, out of scope).
 """
 import operator
 
+import threading
+
 import numpy as np
 
 from . import _lib
+
+_substitute = threading.local()     # .host = (data identity, host array) while lower_mask() evaluates a host term
 
 
 class MaskBase:
@@ -138,6 +142,12 @@ class LazyMask(MaskBase):
             raise ValueError("Either a cube or (data & wcs) is required.")
 
     def _own_data(self):
+        # lower_mask() evaluating on behalf of a view of the SAME data (cube._WideView: the float64 samples of a wide
+        # FITS image) hands its host array over here, so that the predicate is decided on the samples the kernel will
+        # read and not on the cube's float32-narrowed copy
+        sub = getattr(_substitute, "host", None)
+        if sub is not None and getattr(self._data_ref, "_data_id", self._data_ref) is sub[0]:
+            return sub[1]
         return self._data_ref._host_data()
 
     def _include(self, data=None, view=()):
@@ -259,7 +269,12 @@ def lower_mask(mask, data, shape):
     if terms is None:
         # host form: FunctionMask and friends index the voxel ARRAY (masks.py:760-803), not the cube object
         host = data._host_data() if hasattr(data, "_host_data") else data
-        inc = np.asarray(mask.include(data=host))
+        ident = getattr(data, "_data_id", None)
+        _substitute.host = (ident, host) if ident is not None else None
+        try:
+            inc = np.asarray(mask.include(data=host))
+        finally:
+            _substitute.host = None
         terms = (0, -np.inf, np.inf, np.broadcast_to(inc, shape))
     flags, lo, hi, m = terms
     arr = None

@@ -109,7 +109,6 @@ class DaskSource:
         self.preferred_chunk_mb = 64          # (measured at 1024^3, chunks (-1, 256, 256): 16 MiB windows 11 GB/s, 32: 21, 64: 25, 128: 15)
 
     def read_into(self, view_u8, z0, z1, y0, y1):
-        import dask
         import dask.array as da
         nz, ny, nx = self.shape
         n = (z1 - z0) * (y1 - y0) * nx
@@ -117,8 +116,9 @@ class DaskSource:
         piece = self.data[z0:z1, y0:y1]
         if piece.dtype != self.out_dtype:
             piece = piece.astype(self.out_dtype)
-        with dask.config.set(scheduler="synchronous"):
-            da.store(piece, dst, lock=False, compute=True)
+        # the scheduler goes with THIS call: dask.config.set is process-global and its enter / exit is not thread-safe,
+        # and read_into runs on the pipeline's reader threads
+        da.store(piece, dst, lock=False, compute=True, scheduler="synchronous")
         return n * self.sample_bytes
 
     def release(self):
@@ -564,9 +564,21 @@ class FitsSink:
         # be the very file the strips are read from (cube.write(path, overwrite=True) of a streamed cube read from path:
         # O_TRUNC on it would destroy the input before the first strip is read), and a failed run leaves no half-written
         # file under the target's name.
-        self.path = os.fspath(path)
+        # A symlinked target is written THROUGH the link (the rename lands on the file the link names), an existing
+        # target keeps its permission bits, and part files a killed run of this process id left behind are swept.
+        self.path = os.path.realpath(os.fspath(path))
+        mode = 0o644
+        try:
+            mode = os.stat(self.path).st_mode & 0o7777
+        except OSError:
+            pass
+        self._sweep_stale_parts()
         self.part = "%s.spc-part-%d-%x" % (self.path, os.getpid(), id(self) & 0xffffff)
         self.fd = os.open(self.part, os.O_RDWR | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            os.fchmod(self.fd, mode)
+        except OSError:
+            pass
         size = self.base + total + (-total) % io_fits.BLOCK                       # zero padding included
         try:
             os.pwrite(self.fd, text.encode("ascii"), 0)
@@ -578,7 +590,7 @@ class FitsSink:
                 os.ftruncate(self.fd, size)
             # The strips arrive as one piece per plane (rows x nx samples): with the 64-row strips of a 2 GiB test budget that is
             # 256 KiB per os.pwrite, 32768 calls for 8 GiB, each under the file's write lock: 4.7 GB/s where 64 MiB writes reach
-            # 15 - 20 GB/s on the same file system (tests/bench_filewrite.py, bench_stream_parts.py).  A shared mapping
+            # 15 - 20 GB/s on the same file system (tools/bench_filewrite.py, bench_stream_parts.py).  A shared mapping
             # (SPC_FITS_SINK_MMAP=1) lets the writer threads copy side by side, but a fresh file then costs a page-cache fault
             # per 4 KiB: 4.1 GB/s - no better, so the pwrite form stays the default.  The pieces grow with the strip: a cube
             # that is out of core for 288 GB of HBM has strips of hundreds of rows (10+ MiB per piece).
@@ -590,6 +602,32 @@ class FitsSink:
         except BaseException:
             self.abort()
             raise
+
+    def _sweep_stale_parts(self):
+        """part files beside the target whose writer is gone (the pid in the name is not alive): a hard kill leaves them"""
+        d, base = os.path.dirname(self.path) or ".", os.path.basename(self.path) + ".spc-part-"
+        try:
+            names = [n for n in os.listdir(d) if n.startswith(base)]
+        except OSError:
+            return
+        for n in names:
+            try:
+                pid = int(n[len(base):].split("-")[0])
+            except ValueError:
+                continue
+            if pid == os.getpid():
+                continue
+            try:
+                os.kill(pid, 0)                      # signal 0: existence check only
+                continue                             # alive (or not ours to judge): leave it
+            except ProcessLookupError:
+                pass
+            except OSError:
+                continue
+            try:
+                os.unlink(os.path.join(d, n))
+            except OSError:
+                pass
 
     def write(self, view_u8, z0, z1, y0, y1):
         nz, ny, nx = self.shape

@@ -575,7 +575,7 @@ def test_spatial_conv_nonseparable_tiled(gpu, monkeypatch, nk):
 
 
 def test_randomised_cross_check_against_oracle(gpu):
-    """tests/stress_random.py: random shapes (down to 1 x 1 x 1), NaN densities and mask kinds
+    """tools/stress_random.py: random shapes (down to 1 x 1 x 1), NaN densities and mask kinds
     through every kernel family (moments, argmax, statistics, order statistics, spectral ring /
     generic / fused, separable and non-separable spatial, lerp, bilinear) against the oracle."""
     import os
