@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 5
+#define SPC_ABI_VERSION 6
 
 typedef enum {
     SPC_OK = 0,
@@ -483,6 +483,24 @@ int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc_cube_f32* 
                                   float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
                                   double dv, double* d_m0, int64_t m0_row_stride,
                                   void* d_workspace, size_t workspace_bytes);
+
+/* (ABI 6) The same operator with moments 1 / 2 of the smoothed cube as well, and - for both entry points, wherever nx and
+ * the strides are multiples of 4 and the bases 16-byte aligned - a third form in which EVERY product runs on
+ * v_mfma_f32_16x16x32_f16: the masked samples go in as fp16 hi + lo under one power-of-two scale per step of 16 rows
+ * (the running maximum of the wave's channel), the taps as fp16 hi + lo, the x-pass result is split again for the y pass
+ * (spc_spatial_split.hip; <= 1e-6 of the data range against float64).  Moments follow spc_moments_f32's conventions:
+ *   d_cen  nz doubles in device memory = pix_cen[z] - c_ref;  m1 = S1 / S0 + m1_add,  m2 = S2 / S0 - (S1 / S0)^2,
+ *   S_n = nansum over channels of c^n * smoothed value under the ORIGINAL mask (dask_spectral_cube.py:1083-1104 on the
+ *   lazily smoothed cube of :962-993); rays without a contribution: m0 NaN, m1 / m2 NaN (0 / 0).
+ * Any of d_out, d_m0, d_m1, d_m2 may be NULL (not all).  Workspace: spc_workspace_bytes(SPC_WS_SPATIAL_CONV_MFMA, nz, ny,
+ * nx, 3, 0) when d_m1 or d_m2 is asked for.  SPC_ERR_UNSUPPORTED as above, and for moments 1 / 2 where the third form
+ * does not apply. */
+int spc_spatial_conv_sep_mfma_moments_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                          const double* h_ky, int nky, const double* h_kx, int nkx,
+                                          float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
+                                          const double* d_cen, double dv, double m1_add,
+                                          double* d_m0, double* d_m1, double* d_m2, int64_t map_row_stride,
+                                          void* d_workspace, size_t workspace_bytes);
 
 /* ---- resampling -----------------------------------------------------------
  * spectral lerp: replaces interp_wrapper / scipy interp1d(kind='linear') of

@@ -22,7 +22,7 @@ SPC_ERR_COMM = -5
 MASK_NONE, MASK_ARRAY, MASK_FINITE = 0, 1, 2
 MASK_GT, MASK_GE, MASK_LT, MASK_LE = 4, 8, 16, 32
 COMM_ID_BYTES = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
@@ -113,6 +113,8 @@ SIGNATURES = {
     "spc_wcs_pixel_map_f64": (_i, [_i, _vp, _P(SpcCelestialWcs), _P(SpcCelestialWcs), _P(C.c_double), _i64, _i64, _vp, _vp]),
     "spc_spatial_conv_sep_mfma_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _i, _P(C.c_double), _i, _vp, _i64, _i64,
                                            _d, _vp, _i64, _vp, _sz]),
+    "spc_spatial_conv_sep_mfma_moments_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _i, _P(C.c_double), _i, _vp, _i64,
+                                                   _i64, _vp, _d, _d, _vp, _vp, _vp, _i64, _vp, _sz]),
     "spc_map_check": (_i, [_i, _vp, _vp, C.c_int32, _vp, _i64, _vp]),
     "spc_resample_spline_f32": (_i, [_i, _vp, _P(SpcCube), _i, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz]),
     "spc_stats_planes_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(C.c_double), _vp, _sz]),

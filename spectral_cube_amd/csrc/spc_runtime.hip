@@ -110,7 +110,7 @@ size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t
         case SPC_WS_STATS_GLOBAL: case SPC_WS_STATS_PLANES: case SPC_WS_MAP_CONV2D: case SPC_WS_CLIP_OUTSIDE:
             return spc_ws_stats(kind, nz, ny, nx, p0, p1);
         case SPC_WS_PERCENTILE_GLOBAL: return spc_ws_percentile_global();
-        case SPC_WS_SPATIAL_CONV_MFMA: return spc_ws_spatial_conv_mfma(nz, ny, nx);
+        case SPC_WS_SPATIAL_CONV_MFMA: return spc_ws_spatial_conv_mfma(nz, ny, nx, p0);    /* p0 = 3: with moments 1 / 2 */
     }
     return 0;
 }

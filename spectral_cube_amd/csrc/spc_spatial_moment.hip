@@ -777,19 +777,30 @@ inline int chunk_planes(int64_t nz, int64_t ny, int64_t nx) {
 
 }  // namespace
 
-size_t spc_ws_spatial_conv_mfma(int64_t nz, int64_t ny, int64_t nx) {
+// third form (round 5): every product on the fp16 matrix instruction - spc_spatial_split.hip
+bool spc_spatial_split_takes(const spc_cube_f32* cube, const MaskDev& md);
+size_t spc_ws_spatial_split(int64_t nz, int64_t ny, int64_t nx, int nsum);
+int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky29, const float* kx29,
+                             float sy, float sx, float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
+                             int nsum, double dv, double m1_add, const double* d_cen, double* d_m0, double* d_m1, double* d_m2,
+                             int64_t map_row_stride, void* d_workspace, size_t workspace_bytes);
+
+size_t spc_ws_spatial_conv_mfma(int64_t nz, int64_t ny, int64_t nx, int64_t nsum) {
     const int64_t zc = chunk_planes(nz, ny, nx), nchunk = (nz + zc - 1) / zc;
-    return spc_ws_round((size_t)nchunk * ny * nx * sizeof(float)) + spc_ws_round((size_t)nchunk * ny * nx) + 512;
+    const size_t older = spc_ws_round((size_t)nchunk * ny * nx * sizeof(float)) + spc_ws_round((size_t)nchunk * ny * nx) + 512;
+    return std::max(older, spc_ws_spatial_split(nz, ny, nx, nsum == 3 ? 3 : 1));
 }
 
-extern "C" int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
-                                             const double* h_ky, int nky, const double* h_kx, int nkx, float* d_out,
-                                             int64_t out_row_stride, int64_t out_plane_stride, double dv, double* d_m0,
-                                             int64_t m0_row_stride, void* d_workspace, size_t workspace_bytes) {
+static int mfma_entry(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                      const double* h_ky, int nky, const double* h_kx, int nkx, float* d_out,
+                      int64_t out_row_stride, int64_t out_plane_stride, double dv, double* d_m0,
+                      int64_t m0_row_stride, void* d_workspace, size_t workspace_bytes,
+                      const double* d_cen, double m1_add, double* d_m1, double* d_m2) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     SPC_REQUIRE(h_ky && h_kx && nky > 0 && nkx > 0 && (nky & 1) && (nkx & 1), "kernels must have an odd, positive number of taps");
-    SPC_REQUIRE(d_out || d_m0, "nothing to compute: d_out and d_m0 are both NULL");
+    SPC_REQUIRE(d_out || d_m0 || d_m1 || d_m2, "nothing to compute: d_out and the moment maps are all NULL");
+    SPC_REQUIRE(!(d_m1 || d_m2) || d_cen, "moments 1 / 2 need the channel coordinates (d_cen)");
     MaskDev md{};
     rc = spc_mask_to_dev(mask, cube, &md);
     if (rc) return rc;
@@ -829,6 +840,13 @@ extern "C" int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc
     if (cube->ny * cube->row_stride * 4 >= (1ll << 32) || ((md.flags & SPC_MASK_ARRAY) && cube->ny * md.row_stride >= (1ll << 32)))
         SPC_UNSUPPORTED("spatial_conv_sep_mfma: a plane must stay below 4 GiB (buffer addressing)");
     hipStream_t st = (hipStream_t)stream;
+    const int form = [] { const char* e = getenv("SPC_SPATIAL_MFMA_FORM"); return e ? atoi(e) : 3; }();
+    const int nsum = (d_m1 || d_m2) ? 3 : (d_m0 ? 1 : 0);
+    const bool out_ok = !d_out || (((A.out_row_stride | A.out_plane_stride) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0);
+    if ((form == 3 || form == 0) && out_ok && spc_spatial_split_takes(cube, md))
+        return spc_spatial_split_launch(st, cube, md, A.ky, A.kx, A.sy, A.sx, d_out, A.out_row_stride, A.out_plane_stride, nsum, dv, m1_add,
+                                        d_cen, d_m0, d_m1, d_m2, m0_row_stride, d_workspace, workspace_bytes);
+    if (nsum == 3) SPC_UNSUPPORTED("spatial_conv_sep_mfma: moments 1 / 2 need the split form (nx and the strides multiples of 4, 16-byte base)");
     if (d_m0) {
         SpcWorkspace ws(d_workspace, workspace_bytes);
         SPC_WS_TAKE(d_partial, ws, float, (size_t)A.nchunk * cube->ny * cube->nx);
@@ -883,4 +901,23 @@ extern "C" int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc
         SPC_LAUNCH_CHECK();
     }
     return SPC_OK;
+}
+
+extern "C" int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                             const double* h_ky, int nky, const double* h_kx, int nkx, float* d_out,
+                                             int64_t out_row_stride, int64_t out_plane_stride, double dv, double* d_m0,
+                                             int64_t m0_row_stride, void* d_workspace, size_t workspace_bytes) {
+    return mfma_entry(device, stream, cube, mask, h_ky, nky, h_kx, nkx, d_out, out_row_stride, out_plane_stride, dv, d_m0, m0_row_stride,
+                      d_workspace, workspace_bytes, nullptr, 0.0, nullptr, nullptr);
+}
+
+// the same with moments 1 / 2 of the smoothed cube (ABI 6): m1 = S1 / S0 + m1_add, m2 = S2 / S0 - (S1 / S0)^2 with the
+// channel coordinates d_cen (nz doubles, device) - spc_moments_f32's conventions
+extern "C" int spc_spatial_conv_sep_mfma_moments_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                                     const double* h_ky, int nky, const double* h_kx, int nkx, float* d_out,
+                                                     int64_t out_row_stride, int64_t out_plane_stride, const double* d_cen, double dv,
+                                                     double m1_add, double* d_m0, double* d_m1, double* d_m2, int64_t map_row_stride,
+                                                     void* d_workspace, size_t workspace_bytes) {
+    return mfma_entry(device, stream, cube, mask, h_ky, nky, h_kx, nkx, d_out, out_row_stride, out_plane_stride, dv, d_m0, map_row_stride,
+                      d_workspace, workspace_bytes, d_cen, m1_add, d_m1, d_m2);
 }

@@ -1,0 +1,498 @@
+// Third form of the masked separable spatial_smooth (+ moment 0 / 1 / 2 of the smoothed cube), round 5: BOTH convolutions
+// on the fp16 matrix instruction (reference: dask_spectral_cube.py:962-993 - the per-channel astropy convolution with
+// boundary='fill', nan_treatment='interpolate' - then the nansum of :1083-1104 under the ORIGINAL mask).
+//
+//   out[z, y, x] = sum_ij ky[i] kx[j] d m / sum_ij ky[i] kx[j] m            (m: validity, 0 / 1; outside the plane: d = 0, m = 1)
+//
+// The second form (spc_spatial_moment.hip) ran the numerator on v_mfma_f32_16x16x4_f32, which issues at the VECTOR rate
+// (32 cycles per 1024 multiply-adds) and fetched x3 the cube (wave-private 32 x 128 regions with a 28-row / 28-column halo,
+// loaded four bytes per lane).  Here every product is a v_mfma_f32_16x16x32_f16 (16 cycles per 8192 multiply-adds):
+//
+//   data     d m  = hi + lo   two fp16 under ONE power-of-two scale per step (the running maximum of the wave's channel:
+//                             fp16 needs the range, the products keep 2^-22 of every sample's own magnitude)
+//   taps     k    = hi + lo   two fp16 under a power-of-two scale that keeps the far Gaussian tail a normal number
+//   x pass   Z    = D Tx      hi.hi + lo.hi + hi.lo (numerator), v.hi + v.lo (denominator; v = the 0 / 1 validity, exact)
+//   y pass   O^T  = Z^T Ty^T  Z (float32 accumulators) split hi + lo again: three products each
+//
+// with banded Toeplitz blocks of the taps as the constant operands (from LDS).  A wave owns 16 NRT output rows x 64
+// output columns and walks a chunk of channels alone (no barriers in the channel loop); per channel it marches down its
+// NRT + 2 input row tiles of 16 rows x 96 columns - six 16-column UNITS, lane (m, g) = row m, columns 4 g .. 4 g + 3 of
+// each unit: one 16-byte load per unit and lane, 64 contiguous bytes per row and instruction.  The x pass leaves
+// Z[row 4 g + r][column m] in lane (m, g) - which IS the A operand of the transposed y pass - and the y pass leaves
+// out[row m][columns 4 g + r] there, i.e. the lane that loaded exactly those four samples and mask bytes one step
+// earlier: the original mask of the moment needs no exchange, and the smoothed cube is stored 16 bytes per lane.
+// The y pass runs in scatter form: the new Z tile and the previous one make one K = 32 operand (their order alternates
+// with the step, the Toeplitz constants come in both orders), two output row tiles are pending per column tile.
+#include "spc_common.h"
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int R = 29, H = 14;
+constexpr int kThreads = 256, kWaves = 4;
+constexpr int kOC = 64, kCT = 4;              // output columns / column tiles per wave
+constexpr int kUnits = 6;                     // 16-column input units per wave and step (kOC + 32 columns)
+
+// constant operands in LDS: [set][hi / lo][lane]; a set = the two Toeplitz blocks of the K = 32 operand's halves
+enum { XE0 = 0, XE1, XO0, XO1, YN0, YN1, YS0, YS1, kSets };
+// x pass, even column tile n:  (units n, n + 1) . [T0; T1]  +  (units n + 2, n + 3) . [T2; 0]
+//         odd  column tile n:  (units n - 1, n) . [0; T0]   +  (units n + 1, n + 2) . [T1; T2]      (unit pairs (0,1) (2,3) (4,5) only)
+// y pass, operand (previous, new):  pending row tile j - 1 += [T0; T1],  row tile j - 2 += [0; T2]
+//         operand (new, previous):  pending row tile j - 1 += [T1; T0],  row tile j - 2 += [T2; 0]
+__device__ __forceinline__ int set_block(int set, int half) {          // Toeplitz block index b (0 / 1 / 2) or -1 (zeros)
+    switch (set) {
+        case XE0: case YN0: return half;                 // [T0; T1]
+        case XE1: case YS1: return half == 0 ? 2 : -1;   // [T2; 0]
+        case XO0: return half == 0 ? -1 : 0;             // [0; T0]
+        case XO1: return half + 1;                       // [T1; T2]
+        case YN1: return half == 0 ? -1 : 2;             // [0; T2]
+        default: return 1 - half;                        // YS0: [T1; T0]
+    }
+}
+
+struct Sm3Args {
+    const float* cube;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+    const uint8_t* marr;                      // uint8 mask array or nullptr
+    int64_t mrow_stride, mplane_stride;
+    float* out;                               // smoothed cube or nullptr
+    int64_t out_row_stride, out_plane_stride;
+    float* partial;                           // (nsum, nchunk, ny, nx) float32 sums of a chunk, or nullptr
+    unsigned char* seen;                      // (nchunk, ny, nx) "a channel contributed"
+    const double* cen;                        // channel coordinates about the reference (moments 1 / 2): nz doubles, device
+    int nstrips, nbands, zchunk, nchunk;
+    float lim;                                // FLT_MAX under isfinite, +inf otherwise (NaN fails |v| <= lim either way)
+    float sy, sx;                             // power-of-two scales of the fp16 taps
+    float ky[32], kx[32];
+};
+
+__device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
+
+// two float32 (times the uniform power-of-two scale s) -> packed fp16 hi and packed fp16 residual
+__device__ __forceinline__ void split_pair(float a, float b, float s, unsigned& hi, unsigned& lo) {
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "s"(s), "v"(h));
+    hi = h; lo = l;
+}
+
+// the same for values that come out of a matrix instruction: the FIRST reads of the accumulators are instructions the
+// compiler sees (it pads the MFMA -> VALU wait states; it pads nothing in front of inline asm: read too early, an
+// accumulator lacks its last products - the lo terms - or holds garbage)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_acc(float a, float b, float s, unsigned& hi, unsigned& lo) {
+    const float as = a * s, bs = b * s;
+    const half2v h2 = {(_Float16)as, (_Float16)bs};
+    const unsigned h = __builtin_bit_cast(unsigned, h2);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(as), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(bs), "v"(h));
+    hi = h; lo = l;
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));     // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));     // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));     // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));     // row_shr:8: lane 15 of a row holds the row's maximum
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1 and 3
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2 and 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// 2^k for a wave-uniform k (scalar arithmetic; below the normal range: 0)
+__device__ __forceinline__ float exp2i(int k) { return k < -126 ? 0.f : __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }
+__device__ __forceinline__ u32x4 scale_h8(u32x4 v, _Float16 r) { return __builtin_bit_cast(u32x4, __builtin_bit_cast(half8, v) * r); }
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
+
+// NSUM: 0 (no moment), 1 (sum of the smoothed values), 3 (+ sum c v, sum c^2 v)
+// INC: which output voxels the moment sums over - 0: all (no mask), 1: those valid for the convolution (mask byte and / or
+// finite sample: the mask holds isfinite), 2: the mask BYTE alone (a NaN under a true byte is interpolated over and summed)
+template <int NRT, bool ARR, int INC, bool STORE, int NSUM>
+__global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Args A) {
+    __shared__ half8 cB[kSets * 2 * 64];                                              // 16 KB
+    __shared__ f32x4 msum[NSUM ? kWaves * NSUM * NRT * kCT * 64 : 1];                 // NSUM x 16 NRT KB
+    constexpr int NST = NRT + 2;              // input row tiles (steps) per channel
+
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);      // (provably uniform: scalar branches, scalar addresses)
+    const int lm = lane & 15, lg = lane >> 4;
+    // (chunk, strip, band): blocks are dealt round-robin to the 8 XCDs; every XCD gets a contiguous range of work items with
+    // the band running fastest, so the bands that share halo rows of a plane run on one L2 at about the same time
+    int chunk, strip, band;
+    {
+        const int64_t n = (int64_t)gridDim.x, b = blockIdx.x;
+        const int64_t q = n / 8, r = n % 8, xcd = b % 8, i = b / 8;
+        const int64_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        band = (int)(w % A.nbands);
+        strip = (int)((w / A.nbands) % A.nstrips);
+        chunk = (int)(w / ((int64_t)A.nbands * A.nstrips));
+    }
+    const int ny = (int)A.ny, nx = (int)A.nx;
+    const int y0 = band * (16 * NRT);
+    const int xw = strip * (kWaves * kOC) + wave * kOC;       // first output column of this wave
+
+    // ---- constant operands: thread t builds (set, hi / lo) pairs t / 64 * 4 .. + 3 for its lane
+    for (int q = wave * 4; q < wave * 4 + 4; ++q) {
+        const int set = q >> 1, lo = q & 1;
+        const bool isx = set < YN0;
+        half8 op;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int b = set_block(set, e >> 2);
+            const int idx = 30 + lm - 16 * b - (4 * lg + (e & 3));
+            float w = 0.f;
+            if (b >= 0 && idx >= 0 && idx < R) w = isx ? A.kx[idx] * A.sx : A.ky[idx] * A.sy;
+            const _Float16 h = (_Float16)w;
+            op[e] = lo ? (_Float16)(w - (float)h) : h;
+        }
+        cB[q * 64 + lane] = op;
+    }
+    if (NSUM) {
+        f32x4* mz = msum + (size_t)wave * NSUM * NRT * kCT * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NSUM * NRT * kCT; ++i) mz[i * 64] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (xw >= nx) return;                                      // (no barrier below: a whole wave may leave)
+    const int z_begin = chunk * A.zchunk, z_end = (int)min((int64_t)z_begin + A.zchunk, A.nz);
+    if (z_begin >= z_end) return;
+
+    // ---- addressing: per-lane column byte offsets of the six units (clamped into the row), the row of step j is scalar + lane
+    const unsigned rbytes = (unsigned)(A.row_stride * 4), mrbytes = (unsigned)A.mrow_stride;
+    unsigned coff[kUnits];
+    unsigned colin = 0;                                        // bit u: this lane's four columns of unit u lie inside the plane
+#pragma unroll
+    for (int u = 0; u < kUnits; ++u) {
+        const int c = xw - 16 + 16 * u + 4 * lg;
+        colin |= ((c >= 0 && c + 3 < nx) ? 1u : 0u) << u;
+        coff[u] = (unsigned)min(max(c, 0), nx - 4);
+    }
+    const bool cols_inside = (xw - 16 >= 0) && (xw + kOC + 16 <= nx);                // uniform
+    const bool rows_inside = (y0 - 16 >= 0) && (y0 + 16 * NRT + 16 <= ny);           // uniform
+
+    f32x4 raw[kUnits];
+    unsigned mk[kUnits];
+    auto issue_loads = [&](int z, int j) {
+        const auto rs = spc_plane_srd(A.cube + (int64_t)z * A.plane_stride);
+        const auto rm = spc_plane_srd(ARR ? (const void*)(A.marr + (int64_t)z * A.mplane_stride) : (const void*)A.cube);
+        const int row = min(max(y0 - 16 + 16 * j + lm, 0), ny - 1);
+        const unsigned ro = (unsigned)row * rbytes, mo = (unsigned)row * mrbytes;
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + coff[u] * 4u), 0, 0));
+            if (ARR) mk[u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rm, (int)(mo + coff[u]), 0, 0);
+        }
+    };
+
+    // ---- state
+    u32x4 za[kCT][4];                         // y-pass A operands per column tile: numerator hi, lo, denominator hi, lo; (.x,.y) = slot 0, (.z,.w) = slot 1
+    f32x4 Pn[2][kCT], Pd[2][kCT];             // pending output row tiles (numerator, denominator), slot = row tile & 1
+    unsigned incsave[2][kCT];                 // one byte per output column: "included by the ORIGINAL mask", for the centre units of a step (slot = step & 1)
+    unsigned long long seen = 0;              // bit (i * kCT + n) * 4 + k: a channel contributed to output (row tile i, column tile n, column k)
+#pragma unroll
+    for (int n = 0; n < kCT; ++n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) za[n][q] = u32x4{0u, 0u, 0u, 0u};
+        Pn[0][n] = Pn[1][n] = Pd[0][n] = Pd[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        incsave[0][n] = incsave[1][n] = 0u;
+    }
+    f32x4* macc = msum + (size_t)wave * NSUM * NRT * kCT * 64 + lane;
+    const bool tile_cols_inside = cols_inside;
+    int E = -128;                              // 2^E bounds every sample of the channel seen so far (the pending numerators carry 2^-E)
+    float cz = 0.f, cz2 = 0.f;
+    int zcur = z_begin;
+
+    // one step = one input row tile (16 rows x 96 columns) of the channel; PAR = parity of the step (static: it names the
+    // operand slot the new Z tile goes to and the slots of the pending row tiles)
+    auto step = [&](auto par, const int j) {
+        constexpr int PAR = decltype(par)::value;
+        const int z = zcur;
+        // ================= classification of the step's samples: d = valid ? sample : 0, validity as fp16 0 / 1
+        const int rowj = y0 - 16 + 16 * j + lm;
+        const bool row_in = (rowj >= 0) && (rowj < ny);
+        const bool tile_inside = tile_cols_inside && (y0 - 16 + 16 * j >= 0) && (y0 + 16 * j <= ny);     // uniform
+        float d[kUnits][4];
+        u32x2 vh[kUnits];
+        float mx = 0.f;
+#pragma unroll
+        for (int u = 0; u < kUnits; ++u) {
+            f32x4 r = raw[u];
+            unsigned m = ARR ? mk[u] : 0x01010101u;
+            if (!tile_inside) {                  // samples outside the plane are VALID ZEROS (boundary='fill', fill_value=0)
+                const bool in = row_in & (((colin >> u) & 1u) != 0);
+                r.x = in ? r.x : 0.f; r.y = in ? r.y : 0.f; r.z = in ? r.z : 0.f; r.w = in ? r.w : 0.f;
+                m = in ? m : 0x01010101u;
+            }
+            bool o0 = __builtin_fabsf(r.x) <= A.lim, o1 = __builtin_fabsf(r.y) <= A.lim;
+            bool o2 = __builtin_fabsf(r.z) <= A.lim, o3 = __builtin_fabsf(r.w) <= A.lim;
+            if (ARR) { o0 = o0 & ((m & 0xffu) != 0); o1 = o1 & ((m & 0xff00u) != 0); o2 = o2 & ((m & 0xff0000u) != 0); o3 = o3 & ((m & 0xff000000u) != 0); }
+            d[u][0] = o0 ? r.x : 0.f; d[u][1] = o1 ? r.y : 0.f; d[u][2] = o2 ? r.z : 0.f; d[u][3] = o3 ? r.w : 0.f;
+            vh[u].x = (o0 ? 0x3C00u : 0u) | (o1 ? 0x3C000000u : 0u);
+            vh[u].y = (o2 ? 0x3C00u : 0u) | (o3 ? 0x3C000000u : 0u);
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[u][0]), __builtin_fabsf(d[u][1])),
+                                                     __builtin_fmaxf(__builtin_fabsf(d[u][2]), __builtin_fabsf(d[u][3]))));
+            // what the moment's include test needs one step later: unit u = n + 1 holds output column tile n of row tile j - 1
+            if (NSUM && u >= 1 && u <= kCT) {
+                if (INC == 1) incsave[PAR][u - 1] = __builtin_amdgcn_perm(vh[u].y, vh[u].x, 0x07050301u);   // byte 1 of every fp16: 0x3C / 0
+                else if (INC == 2) incsave[PAR][u - 1] = mk[u];     // the array term alone: a NaN under a true byte is interpolated over AND summed
+            }
+        }
+        // ================= the step's scale
+        const unsigned mb = wave_max_u32(__builtin_bit_cast(unsigned, mx));
+        int e = (int)(mb >> 23) - 126;                                                 // max < 2^e
+        e = min(max(e, -100), 127);
+        if (e > E) {
+            if (j > 0) {
+                const float r = exp2i(E - e);
+#pragma unroll
+                for (int n = 0; n < kCT; ++n) {
+                    Pn[0][n] = Pn[0][n] * r; Pn[1][n] = Pn[1][n] * r;
+                    // (the previous Z tile in the y-pass operand carries the old scale too; fp16 times a power of two)
+                    za[n][0] = scale_h8(za[n][0], (_Float16)r); za[n][1] = scale_h8(za[n][1], (_Float16)r);
+                }
+            }
+            E = e;
+        }
+        const float s = exp2i(15 - e);                                                 // samples -> below 2^15
+        const float fz = exp2i(e - E - 15);                                            // x-pass numerators -> below 2^15, common scale 2^-E
+        const float escale = exp2i(E);
+        // ================= fp16 operands of the x pass: three unit pairs, hi / lo / validity
+        u32x4 hiP[3], loP[3], vhP[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int u = 2 * p + q;
+                split_pair(d[u][0], d[u][1], s, h[2 * q], l[2 * q]);
+                split_pair(d[u][2], d[u][3], s, h[2 * q + 1], l[2 * q + 1]);
+            }
+            hiP[p] = u32x4{h[0], h[1], h[2], h[3]};
+            loP[p] = u32x4{l[0], l[1], l[2], l[3]};
+            vhP[p] = u32x4{vh[2 * p].x, vh[2 * p].y, vh[2 * p + 1].x, vh[2 * p + 1].y};
+        }
+        // ================= the next step's loads fly during the matrix work
+        if (j + 1 < NST) issue_loads(z, j + 1);
+        else if (z + 1 < z_end) issue_loads(z + 1, 0);
+        // ================= x pass, split, y pass (scatter), epilogue of the completed row tile - per column tile
+#pragma unroll
+        for (int n = 0; n < kCT; ++n) {
+            const int pA = (n & 1) ? (n - 1) / 2 : n / 2, pB = pA + 1;
+            const int s0 = (n & 1) ? XO0 : XE0, s1 = (n & 1) ? XO1 : XE1;
+            const half8 c0h = cB[(s0 * 2 + 0) * 64 + lane], c0l = cB[(s0 * 2 + 1) * 64 + lane];
+            const half8 c1h = cB[(s1 * 2 + 0) * 64 + lane], c1l = cB[(s1 * 2 + 1) * 64 + lane];
+            f32x4 zn = {0.f, 0.f, 0.f, 0.f}, zd = {0.f, 0.f, 0.f, 0.f};
+            zn = MFMA(as_half8(hiP[pA]), c0h, zn);
+            zd = MFMA(as_half8(vhP[pA]), c0h, zd);
+            zn = MFMA(as_half8(loP[pA]), c0h, zn);
+            zd = MFMA(as_half8(vhP[pA]), c0l, zd);
+            zn = MFMA(as_half8(hiP[pA]), c0l, zn);
+            zd = MFMA(as_half8(vhP[pB]), c1h, zd);
+            zn = MFMA(as_half8(hiP[pB]), c1h, zn);
+            zd = MFMA(as_half8(vhP[pB]), c1l, zd);
+            zn = MFMA(as_half8(loP[pB]), c1h, zn);
+            zn = MFMA(as_half8(hiP[pB]), c1l, zn);
+            // lane (m = output column, g): zn / zd [r] = row 4 g + r of input row tile j
+            unsigned nh0, nl0, nh1, nl1, dh0, dl0, dh1, dl1;
+            split_pair_acc(zn.x, zn.y, fz, nh0, nl0);
+            split_pair_acc(zn.z, zn.w, fz, nh1, nl1);
+            split_pair_acc(zd.x, zd.y, 1.0f, dh0, dl0);
+            split_pair_acc(zd.z, zd.w, 1.0f, dh1, dl1);
+            if (PAR == 0) { za[n][0].x = nh0; za[n][0].y = nh1; za[n][1].x = nl0; za[n][1].y = nl1; za[n][2].x = dh0; za[n][2].y = dh1; za[n][3].x = dl0; za[n][3].y = dl1; }
+            else          { za[n][0].z = nh0; za[n][0].w = nh1; za[n][1].z = nl0; za[n][1].w = nl1; za[n][2].z = dh0; za[n][2].w = dh1; za[n][3].z = dl0; za[n][3].w = dl1; }
+            if (j >= 1) {
+                // operand order: (slot 0, slot 1) = (previous, new) on odd steps, (new, previous) on even ones
+                constexpr int y0s = PAR ? YN0 : YS0, y1s = PAR ? YN1 : YS1;
+                const half8 anh = as_half8(za[n][0]), anl = as_half8(za[n][1]), adh = as_half8(za[n][2]), adl = as_half8(za[n][3]);
+                if (j <= NRT) {                     // first two blocks of output row tile j - 1
+                    const half8 b0h = cB[(y0s * 2 + 0) * 64 + lane], b0l = cB[(y0s * 2 + 1) * 64 + lane];
+                    f32x4 pn = {0.f, 0.f, 0.f, 0.f}, pd = {0.f, 0.f, 0.f, 0.f};
+                    pn = MFMA(anh, b0h, pn);
+                    pd = MFMA(adh, b0h, pd);
+                    pn = MFMA(anl, b0h, pn);
+                    pd = MFMA(adl, b0h, pd);
+                    pn = MFMA(anh, b0l, pn);
+                    pd = MFMA(adh, b0l, pd);
+                    Pn[1 - PAR][n] = pn; Pd[1 - PAR][n] = pd;          // slot (j - 1) & 1
+                }
+                if (j >= 2) {                       // last block of output row tile j - 2, then its epilogue
+                    const int i = j - 2;
+                    const half8 b1h = cB[(y1s * 2 + 0) * 64 + lane], b1l = cB[(y1s * 2 + 1) * 64 + lane];
+                    f32x4 pn = Pn[PAR][n], pd = Pd[PAR][n];             // slot (j - 2) & 1
+                    pn = MFMA(anh, b1h, pn);
+                    pd = MFMA(adh, b1h, pd);
+                    pn = MFMA(anl, b1h, pn);
+                    pd = MFMA(adl, b1h, pd);
+                    pn = MFMA(anh, b1l, pn);
+                    pd = MFMA(adh, b1l, pd);
+                    // lane (m = output row, g): pn / pd [r] = output column 4 g + r of column tile n, row tile i
+                    f32x4 val;
+                    val.x = pn.x * (escale * __builtin_amdgcn_rcpf(pd.x));          // den = 0 (empty window): 0 * inf = NaN
+                    val.y = pn.y * (escale * __builtin_amdgcn_rcpf(pd.y));
+                    val.z = pn.z * (escale * __builtin_amdgcn_rcpf(pd.z));
+                    val.w = pn.w * (escale * __builtin_amdgcn_rcpf(pd.w));
+                    const int yo = y0 + 16 * i + lm, xo = xw + 16 * n + 4 * lg;
+                    const bool inside = (yo < ny) & (xo < nx);
+                    if (STORE && inside) {
+                        float* po = A.out + (int64_t)z * A.out_plane_stride + (int64_t)yo * A.out_row_stride + xo;
+                        *reinterpret_cast<f32x4*>(po) = val;
+                    }
+                    if (NSUM) {
+                        const unsigned w = INC ? incsave[1 - PAR][n] : 0xffffffffu;    // saved by step j - 1
+                        bool i0 = (w & 0xffu) != 0, i1 = (w & 0xff00u) != 0, i2 = (w & 0xff0000u) != 0, i3 = (w & 0xff000000u) != 0;
+                        i0 = i0 & inside & (val.x == val.x); i1 = i1 & inside & (val.y == val.y);        // nansum: a NaN value is skipped
+                        i2 = i2 & inside & (val.z == val.z); i3 = i3 & inside & (val.w == val.w);
+                        const f32x4 add = {i0 ? val.x : 0.f, i1 ? val.y : 0.f, i2 ? val.z : 0.f, i3 ? val.w : 0.f};
+                        f32x4* slot = macc + (size_t)((i * kCT + n) * NSUM) * 64;
+                        slot[0] = slot[0] + add;
+                        if (NSUM == 3) { slot[64] = slot[64] + add * cz; slot[128] = slot[128] + add * cz2; }
+                        const unsigned nib = (i0 ? 1u : 0u) | (i1 ? 2u : 0u) | (i2 ? 4u : 0u) | (i3 ? 8u : 0u);
+                        seen |= (unsigned long long)nib << ((i * kCT + n) * 4);
+                    }
+                }
+            }
+        }
+    };
+
+    issue_loads(z_begin, 0);
+    for (zcur = z_begin; zcur < z_end; ++zcur) {
+        E = -128;
+        if (NSUM == 3) { cz = (float)A.cen[zcur]; cz2 = cz * cz; }
+#pragma unroll 1
+        for (int jj = 0; jj < NST; jj += 2) {
+            step(std::integral_constant<int, 0>{}, jj);
+            if (jj + 1 < NST) step(std::integral_constant<int, 1>{}, jj + 1);
+        }
+    }
+
+    if (NSUM) {
+        const int64_t plane = (int64_t)A.ny * A.nx;
+#pragma unroll
+        for (int i = 0; i < NRT; ++i) {
+            const int yo = y0 + 16 * i + lm;
+#pragma unroll
+            for (int n = 0; n < kCT; ++n) {
+                const int xo = xw + 16 * n + 4 * lg;
+                if (yo < ny && xo < nx) {
+                    const int64_t at = (int64_t)chunk * plane + (int64_t)yo * A.nx + xo;
+#pragma unroll
+                    for (int q = 0; q < NSUM; ++q)
+                        *reinterpret_cast<f32x4*>(A.partial + (int64_t)q * A.nchunk * plane + at) = macc[(size_t)((i * kCT + n) * NSUM + q) * 64];
+                    const unsigned sb = (unsigned)(seen >> ((i * kCT + n) * 4)) & 15u;
+                    *reinterpret_cast<unsigned*>(A.seen + at) = (sb & 1u) | ((sb & 2u) << 7) | ((sb & 4u) << 14) | ((sb & 8u) << 21);
+                }
+            }
+        }
+    }
+}
+
+// moments of the smoothed cube from the chunk sums (float64 across chunks): m0 = dv S0 (NaN where no channel contributed:
+// nansum_allbadtonan, dask_spectral_cube.py:54-59), m1 = S1 / S0 + m1_add, m2 = S2 / S0 - (S1 / S0)^2   (:1083-1104)
+__global__ __launch_bounds__(256) void split_finish_kernel(const float* partial, const unsigned char* seen, int nsum, int nchunk,
+                                                            int64_t ny, int64_t nx, double dv, double m1_add,
+                                                            double* m0, double* m1, double* m2, int64_t map_row_stride) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t plane = ny * nx;
+    if (i >= plane) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    unsigned any = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        s0 += (double)partial[(int64_t)c * plane + i];
+        if (nsum == 3) {
+            s1 += (double)partial[((int64_t)nchunk + c) * plane + i];
+            s2 += (double)partial[((int64_t)2 * nchunk + c) * plane + i];
+        }
+        any |= seen[(int64_t)c * plane + i];
+    }
+    const int64_t y = i / nx, x = i - y * nx;
+    const int64_t o = y * map_row_stride + x;
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    if (m0) m0[o] = any ? dv * s0 : nan;
+    if (m1 || m2) {
+        const double mu = s1 / s0;                             // 0 / 0 = NaN for rays without a contribution, like the reference
+        if (m1) m1[o] = mu + m1_add;
+        if (m2) m2[o] = s2 / s0 - mu * mu;
+    }
+}
+
+inline int split_chunk_planes(int64_t nz, int64_t tiles) {
+    // enough blocks to fill the chip several times over, chunks of at most 64 channels (float32 sums inside a chunk)
+    int64_t want_chunks = std::max<int64_t>(1, (2048 + tiles - 1) / tiles);
+    int64_t zc = std::max<int64_t>(1, (nz + want_chunks - 1) / want_chunks);
+    return (int)std::min<int64_t>(zc, 64);
+}
+
+constexpr int kNRT1 = 4, kNRT3 = 1;
+
+}  // namespace
+
+bool spc_spatial_split_takes(const spc_cube_f32* cube, const MaskDev& md) {
+    if ((cube->nx & 3) || (cube->row_stride & 3) || (cube->plane_stride & 3) || (((uintptr_t)cube->d_data) & 15)) return false;
+    if ((md.flags & SPC_MASK_ARRAY) && ((md.row_stride & 3) || (md.plane_stride & 3) || (((uintptr_t)md.arr) & 3))) return false;
+    if (cube->ny * cube->row_stride * 4 >= (1ll << 32)) return false;
+    return true;
+}
+
+size_t spc_ws_spatial_split(int64_t nz, int64_t ny, int64_t nx, int nsum) {
+    const int nrt = nsum == 3 ? kNRT3 : kNRT1;
+    const int64_t tiles = ((ny + 16 * nrt - 1) / (16 * nrt)) * ((nx + kWaves * kOC - 1) / (kWaves * kOC));
+    const int64_t zc = split_chunk_planes(nz, tiles), nchunk = (nz + zc - 1) / zc;
+    return spc_ws_round((size_t)nsum * nchunk * ny * nx * sizeof(float)) + spc_ws_round((size_t)nchunk * ny * nx) + 512;
+}
+
+// launches the split kernel (+ the finish kernel); the caller has validated the kernel taps (non-negative, positive centre,
+// at most 29 per axis) and the mask terms (array / isfinite only).  nsum = 0 / 1 / 3.
+int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky29, const float* kx29,
+                             float sy, float sx, float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
+                             int nsum, double dv, double m1_add, const double* d_cen, double* d_m0, double* d_m1, double* d_m2,
+                             int64_t map_row_stride, void* d_workspace, size_t workspace_bytes) {
+    Sm3Args A{};
+    A.cube = cube->d_data; A.nz = cube->nz; A.ny = cube->ny; A.nx = cube->nx;
+    A.row_stride = cube->row_stride; A.plane_stride = cube->plane_stride;
+    A.marr = (md.flags & SPC_MASK_ARRAY) ? md.arr : nullptr;
+    A.mrow_stride = md.row_stride; A.mplane_stride = md.plane_stride;
+    A.out = d_out; A.out_row_stride = out_row_stride; A.out_plane_stride = out_plane_stride;
+    A.cen = d_cen;
+    A.lim = (md.flags & SPC_MASK_FINITE) ? 3.402823466e+38f : INFINITY;
+    A.sy = sy; A.sx = sx;
+    for (int i = 0; i < 32; ++i) { A.ky[i] = i < R ? ky29[i] : 0.f; A.kx[i] = i < R ? kx29[i] : 0.f; }
+    const int nrt = nsum == 3 ? kNRT3 : kNRT1;
+    A.nstrips = (int)((cube->nx + kWaves * kOC - 1) / (kWaves * kOC));
+    A.nbands = (int)((cube->ny + 16 * nrt - 1) / (16 * nrt));
+    A.zchunk = split_chunk_planes(cube->nz, (int64_t)A.nstrips * A.nbands);
+    A.nchunk = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
+    const int64_t nblocks = (int64_t)A.nstrips * A.nbands * A.nchunk;
+    SPC_REQUIRE(nblocks < (1ll << 31), "too many blocks");
+    if (nsum) {
+        SpcWorkspace ws(d_workspace, workspace_bytes);
+        SPC_WS_TAKE(d_partial, ws, float, (size_t)nsum * A.nchunk * cube->ny * cube->nx);
+        SPC_WS_TAKE(d_seen, ws, unsigned char, (size_t)A.nchunk * cube->ny * cube->nx);
+        A.partial = d_partial; A.seen = d_seen;
+    }
+    const bool arr = A.marr != nullptr, fin = (md.flags & SPC_MASK_FINITE) != 0, store = d_out != nullptr;
+    dim3 grid((unsigned)nblocks), block(kThreads);
+#define SPC_S3(NRT_, ARR_, INC_, STORE_, NSUM_) hipLaunchKernelGGL((spatial_split_kernel<NRT_, ARR_, INC_, STORE_, NSUM_>), grid, block, 0, st, A)
+#define SPC_S3_MASK(NRT_, STORE_, NSUM_) do { if (arr && fin) SPC_S3(NRT_, true, 1, STORE_, NSUM_); else if (arr) SPC_S3(NRT_, true, 2, STORE_, NSUM_); \
+                                              else if (fin) SPC_S3(NRT_, false, 1, STORE_, NSUM_); else SPC_S3(NRT_, false, 0, STORE_, NSUM_); } while (0)
+    if (nsum == 3) { if (store) SPC_S3_MASK(kNRT3, true, 3); else SPC_S3_MASK(kNRT3, false, 3); }
+    else if (nsum == 1) { if (store) SPC_S3_MASK(kNRT1, true, 1); else SPC_S3_MASK(kNRT1, false, 1); }
+    else SPC_S3_MASK(kNRT1, true, 0);
+    SPC_LAUNCH_CHECK();
+    if (nsum) {
+        const int64_t n = cube->ny * cube->nx;
+        hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A.partial, A.seen, nsum, A.nchunk,
+                           cube->ny, cube->nx, dv, m1_add, d_m0, d_m1, d_m2, map_row_stride ? map_row_stride : cube->nx);
+        SPC_LAUNCH_CHECK();
+    }
+    return SPC_OK;
+}

@@ -775,6 +775,10 @@ class SpectralCube:
             fused = self._fused_masked_smooth_moment0(parent, spec, lz.kernel)
             if fused is not None:
                 return {"m0": fused}
+        elif set(want) <= {"m0", "m1", "m2"} and parent._stream_source() is None and spec.array is not None:
+            fused = self._fused_masked_smooth_moments(parent, spec, lz.kernel, want)
+            if fused is not None:
+                return fused
         if spec.array is not None or (spec.flags & ~_lib.MASK_FINITE):
             return None
         nz = self._shape[0]
@@ -812,6 +816,21 @@ class SpectralCube:
         if not all(np.isfinite(m.sum()) for m in out.values()):
             return None
         return out
+
+    def _fused_masked_smooth_moments(self, parent, spec, kernel2d, want):
+        """masked spatial_smooth -> moment 1 / 2 (and 0) in ONE kernel, like _fused_masked_smooth_moment0: the split form of
+        spc_spatial_conv_sep_mfma_moments_f32 keeps sum v, sum c v, sum c^2 v of the smoothed values per spaxel
+        (dask_spectral_cube.py:962-993 then :1083-1104).  None when the kernel does not take the case."""
+        nz = self._shape[0]
+        cen = self._pix_cen_axis(0)
+        cref = cen[nz // 2]
+        d_cen = DeviceArray.from_numpy(cen - cref, self.device)
+        try:
+            _, maps = ops.spatial_conv_mfma_moments(parent._device_data(), kernel2d, d_cen, dv=self._pix_size_slice(0),
+                                                    m1_add=cref + self.spectral_axis[0], mask=spec, want=tuple(want))
+        except _lib.HipUnsupported:
+            return None
+        return {k: v.get() for k, v in maps.items()}
 
     def _fused_masked_smooth_moment0(self, parent, spec, kernel2d):
         """masked spatial_smooth -> moment0 in ONE kernel that never writes the smoothed cube (the lazy Dask graph of the

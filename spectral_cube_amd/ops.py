@@ -521,6 +521,33 @@ def spatial_conv_mfma(cube, kernel2d, mask=None, stream=None, out=None, want_cub
     return (out if want_cube else None), (m0 if want_m0 else None)
 
 
+def spatial_conv_mfma_moments(cube, kernel2d, d_cen, dv=1.0, m1_add=0.0, mask=None, want=("m0", "m1", "m2"), stream=None,
+                              out=None, want_cube=False):
+    """masked separable spatial_smooth fused with moments 0 / 1 / 2 of the smoothed cube under the ORIGINAL mask
+    (spc_spatial_conv_sep_mfma_moments_f32): the smoothed cube is never written unless want_cube.  *d_cen*: DeviceArray of
+    nz doubles (channel coordinates about the reference, as for moments()).  Returns (cube or None, {"m0": ..}) with
+    float64 DeviceArray maps.  HipUnsupported as spatial_conv_mfma, and where the split form does not apply."""
+    k = np.asarray(kernel2d, dtype=np.float64)
+    fac = separable_factors(k)
+    if fac is None:
+        raise _lib.HipUnsupported("spatial_conv_mfma: the kernel is not an outer product")
+    ky, kx = (np.ascontiguousarray(f, dtype=np.float64) for f in fac)
+    dev = cube.device
+    nz, ny, nx = cube.shape
+    if want_cube and out is None:
+        out = DeviceArray((nz, ny, nx), np.float32, dev)
+    maps = {w: DeviceArray((ny, nx), np.float64, dev) for w in want}
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    higher = ("m1" in maps) or ("m2" in maps)
+    ws, wsn = workspace(dev, stream, _lib.WS_SPATIAL_CONV_MFMA, nz, ny, nx, 3 if higher else 1)
+    ptr = lambda w: C.c_void_p(maps[w].ptr) if w in maps else None
+    _lib.call("spc_spatial_conv_sep_mfma_moments_f32", dev, _sh(stream), C.byref(c), C.byref(m),
+              ky.ctypes.data_as(C.POINTER(C.c_double)), len(ky), kx.ctypes.data_as(C.POINTER(C.c_double)), len(kx),
+              C.c_void_p(out.ptr) if want_cube else None, 0, 0, C.c_void_p(d_cen.ptr), float(dv), float(m1_add),
+              ptr("m0"), ptr("m1"), ptr("m2"), 0, ws, wsn)
+    return (out if want_cube else None), maps
+
+
 def map_check(counts=None, expect=0, values=None, stream=None):
     """device-side checks of the algebraic smooth -> moment paths (spc_map_check): bit 0 = a count differs from *expect*, bit 1 = a
     value is not finite.  Returns the flags (an int; reads back four bytes)."""
