@@ -160,7 +160,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
     if (NSUM) {
         f32x4* mz = msum + (size_t)wave * NSUM * NRT * kCT * 64 + lane;
 #pragma unroll
-        for (int i = 0; i < NSUM * NRT * kCT; ++i) mz[i * 64] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NSUM * NRT * kCT; ++i) mz[i * 64] = f32x4{-0.f, -0.f, -0.f, -0.f};       // -0.0: "nothing added yet" (see the epilogue)
     }
     __syncthreads();
     if (xw >= nx) return;                                      // (no barrier below: a whole wave may leave)
@@ -198,7 +198,6 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
     u32x4 za[kCT][4];                         // y-pass A operands per column tile: numerator hi, lo, denominator hi, lo; (.x,.y) = slot 0, (.z,.w) = slot 1
     f32x4 Pn[2][kCT], Pd[2][kCT];             // pending output row tiles (numerator, denominator), slot = row tile & 1
     unsigned incsave[2][kCT];                 // one byte per output column: "included by the ORIGINAL mask", for the centre units of a step (slot = step & 1)
-    unsigned long long seen = 0;              // bit (i * kCT + n) * 4 + k: a channel contributed to output (row tile i, column tile n, column k)
 #pragma unroll
     for (int n = 0; n < kCT; ++n) {
 #pragma unroll
@@ -281,10 +280,8 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
             loP[p] = u32x4{l[0], l[1], l[2], l[3]};
             vhP[p] = u32x4{vh[2 * p].x, vh[2 * p].y, vh[2 * p + 1].x, vh[2 * p + 1].y};
         }
-        // ================= the next step's loads fly during the matrix work
-        if (j + 1 < NST) issue_loads(z, j + 1);
-        else if (z + 1 < z_end) issue_loads(z + 1, 0);
-        // ================= x pass, split, y pass (scatter), epilogue of the completed row tile - per column tile
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= x pass and split of its result, per column tile
 #pragma unroll
         for (int n = 0; n < kCT; ++n) {
             const int pA = (n & 1) ? (n - 1) / 2 : n / 2, pB = pA + 1;
@@ -310,6 +307,15 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
             split_pair_acc(zd.z, zd.w, 1.0f, dh1, dl1);
             if (PAR == 0) { za[n][0].x = nh0; za[n][0].y = nh1; za[n][1].x = nl0; za[n][1].y = nl1; za[n][2].x = dh0; za[n][2].y = dh1; za[n][3].x = dl0; za[n][3].y = dl1; }
             else          { za[n][0].z = nh0; za[n][0].w = nh1; za[n][1].z = nl0; za[n][1].w = nl1; za[n][2].z = dh0; za[n][2].w = dh1; za[n][3].z = dl0; za[n][3].w = dl1; }
+            __builtin_amdgcn_sched_barrier(0);        // (one column tile at a time: interleaved, the tiles' accumulators and constants do not fit 256 registers)
+        }
+        // ================= the next step's loads fly during the y pass and the epilogues (the x-pass operands are dead by now:
+        // issued before the x pass, the 30 registers of the loads in flight pushed the kernel over 256 and into scratch)
+        if (j + 1 < NST) issue_loads(z, j + 1);
+        else if (z + 1 < z_end) issue_loads(z + 1, 0);
+        // ================= y pass (scatter) and the epilogue of the completed row tile, per column tile
+#pragma unroll
+        for (int n = 0; n < kCT; ++n) {
             if (j >= 1) {
                 // operand order: (slot 0, slot 1) = (previous, new) on odd steps, (new, previous) on even ones
                 constexpr int y0s = PAR ? YN0 : YS0, y1s = PAR ? YN1 : YS1;
@@ -336,11 +342,14 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                     pn = MFMA(anh, b1l, pn);
                     pd = MFMA(adh, b1l, pd);
                     // lane (m = output row, g): pn / pd [r] = output column 4 g + r of column tile n, row tile i
+                    // den = 0 (empty window): 0 * inf = NaN.  The + 0.0 rides in the FMA and turns a -0.0 result into +0.0: the moment
+                    // sums start at -0.0 and excluded voxels add -0.0, so a sum that is still -0.0 at the end says "no channel
+                    // contributed" (nansum_allbadtonan) without a separate record of who was seen
                     f32x4 val;
-                    val.x = pn.x * (escale * __builtin_amdgcn_rcpf(pd.x));          // den = 0 (empty window): 0 * inf = NaN
-                    val.y = pn.y * (escale * __builtin_amdgcn_rcpf(pd.y));
-                    val.z = pn.z * (escale * __builtin_amdgcn_rcpf(pd.z));
-                    val.w = pn.w * (escale * __builtin_amdgcn_rcpf(pd.w));
+                    val.x = __builtin_fmaf(pn.x, escale * __builtin_amdgcn_rcpf(pd.x), 0.f);
+                    val.y = __builtin_fmaf(pn.y, escale * __builtin_amdgcn_rcpf(pd.y), 0.f);
+                    val.z = __builtin_fmaf(pn.z, escale * __builtin_amdgcn_rcpf(pd.z), 0.f);
+                    val.w = __builtin_fmaf(pn.w, escale * __builtin_amdgcn_rcpf(pd.w), 0.f);
                     const int yo = y0 + 16 * i + lm, xo = xw + 16 * n + 4 * lg;
                     const bool inside = (yo < ny) & (xo < nx);
                     if (STORE && inside) {
@@ -350,17 +359,18 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                     if (NSUM) {
                         const unsigned w = INC ? incsave[1 - PAR][n] : 0xffffffffu;    // saved by step j - 1
                         bool i0 = (w & 0xffu) != 0, i1 = (w & 0xff00u) != 0, i2 = (w & 0xff0000u) != 0, i3 = (w & 0xff000000u) != 0;
-                        i0 = i0 & inside & (val.x == val.x); i1 = i1 & inside & (val.y == val.y);        // nansum: a NaN value is skipped
-                        i2 = i2 & inside & (val.z == val.z); i3 = i3 & inside & (val.w == val.w);
-                        const f32x4 add = {i0 ? val.x : 0.f, i1 ? val.y : 0.f, i2 ? val.z : 0.f, i3 ? val.w : 0.f};
+                        i0 = i0 & inside; i1 = i1 & inside; i2 = i2 & inside; i3 = i3 & inside;
+                        if (INC != 1) {             // nansum: a NaN value is skipped (INC 1: an included voxel is a valid centre sample, its window is not empty)
+                            i0 = i0 & (val.x == val.x); i1 = i1 & (val.y == val.y); i2 = i2 & (val.z == val.z); i3 = i3 & (val.w == val.w);
+                        }
+                        const f32x4 add = {i0 ? val.x : -0.f, i1 ? val.y : -0.f, i2 ? val.z : -0.f, i3 ? val.w : -0.f};
                         f32x4* slot = macc + (size_t)((i * kCT + n) * NSUM) * 64;
                         slot[0] = slot[0] + add;
                         if (NSUM == 3) { slot[64] = slot[64] + add * cz; slot[128] = slot[128] + add * cz2; }
-                        const unsigned nib = (i0 ? 1u : 0u) | (i1 ? 2u : 0u) | (i2 ? 4u : 0u) | (i3 ? 8u : 0u);
-                        seen |= (unsigned long long)nib << ((i * kCT + n) * 4);
                     }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -388,8 +398,6 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
 #pragma unroll
                     for (int q = 0; q < NSUM; ++q)
                         *reinterpret_cast<f32x4*>(A.partial + (int64_t)q * A.nchunk * plane + at) = macc[(size_t)((i * kCT + n) * NSUM + q) * 64];
-                    const unsigned sb = (unsigned)(seen >> ((i * kCT + n) * 4)) & 15u;
-                    *reinterpret_cast<unsigned*>(A.seen + at) = (sb & 1u) | ((sb & 2u) << 7) | ((sb & 4u) << 14) | ((sb & 8u) << 21);
                 }
             }
         }
@@ -407,12 +415,13 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const float* partial,
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     unsigned any = 0;
     for (int c = 0; c < nchunk; ++c) {
-        s0 += (double)partial[(int64_t)c * plane + i];
+        const float p0 = partial[(int64_t)c * plane + i];
+        any |= (__float_as_uint(p0) != 0x80000000u) ? 1u : 0u;      // still -0.0: nothing was added in this chunk
+        s0 += (double)p0;
         if (nsum == 3) {
             s1 += (double)partial[((int64_t)nchunk + c) * plane + i];
             s2 += (double)partial[((int64_t)2 * nchunk + c) * plane + i];
         }
-        any |= seen[(int64_t)c * plane + i];
     }
     const int64_t y = i / nx, x = i - y * nx;
     const int64_t o = y * map_row_stride + x;
