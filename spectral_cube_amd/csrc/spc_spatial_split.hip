@@ -223,29 +223,33 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         float d[kUnits][4];
         u32x2 vh[kUnits];
         float mx = 0.f;
+        if (!tile_inside) {                      // samples outside the plane are VALID ZEROS (boundary='fill', fill_value=0): in place,
+#pragma unroll                                   // one uniform branch (per unit inside the loop below it cost the interior five moves per unit)
+            for (int u = 0; u < kUnits; ++u) {
+                const bool in = row_in & (((colin >> u) & 1u) != 0);
+                raw[u].x = in ? raw[u].x : 0.f; raw[u].y = in ? raw[u].y : 0.f; raw[u].z = in ? raw[u].z : 0.f; raw[u].w = in ? raw[u].w : 0.f;
+                if (ARR) mk[u] = in ? mk[u] : 0x01010101u;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
-            f32x4 r = raw[u];
-            unsigned m = ARR ? mk[u] : 0x01010101u;
-            if (!tile_inside) {                  // samples outside the plane are VALID ZEROS (boundary='fill', fill_value=0)
-                const bool in = row_in & (((colin >> u) & 1u) != 0);
-                r.x = in ? r.x : 0.f; r.y = in ? r.y : 0.f; r.z = in ? r.z : 0.f; r.w = in ? r.w : 0.f;
-                m = in ? m : 0x01010101u;
-            }
+            const f32x4 r = raw[u];
+            const unsigned m = ARR ? mk[u] : 0x01010101u;
             bool o0 = __builtin_fabsf(r.x) <= A.lim, o1 = __builtin_fabsf(r.y) <= A.lim;
             bool o2 = __builtin_fabsf(r.z) <= A.lim, o3 = __builtin_fabsf(r.w) <= A.lim;
             if (ARR) { o0 = o0 & ((m & 0xffu) != 0); o1 = o1 & ((m & 0xff00u) != 0); o2 = o2 & ((m & 0xff0000u) != 0); o3 = o3 & ((m & 0xff000000u) != 0); }
             d[u][0] = o0 ? r.x : 0.f; d[u][1] = o1 ? r.y : 0.f; d[u][2] = o2 ? r.z : 0.f; d[u][3] = o3 ? r.w : 0.f;
             vh[u].x = (o0 ? 0x3C00u : 0u) | (o1 ? 0x3C000000u : 0u);
             vh[u].y = (o2 ? 0x3C00u : 0u) | (o3 ? 0x3C000000u : 0u);
-            mx = __builtin_fmaxf(mx, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[u][0]), __builtin_fabsf(d[u][1])),
-                                                     __builtin_fmaxf(__builtin_fabsf(d[u][2]), __builtin_fabsf(d[u][3]))));
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][0])), __builtin_fabsf(d[u][1]));       // (v_max3_f32 with |.| modifiers)
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][2])), __builtin_fabsf(d[u][3]));
             // what the moment's include test needs one step later: unit u = n + 1 holds output column tile n of row tile j - 1
             if (NSUM && u >= 1 && u <= kCT) {
                 if (INC == 1) incsave[PAR][u - 1] = __builtin_amdgcn_perm(vh[u].y, vh[u].x, 0x07050301u);   // byte 1 of every fp16: 0x3C / 0
                 else if (INC == 2) incsave[PAR][u - 1] = mk[u];     // the array term alone: a NaN under a true byte is interpolated over AND summed
             }
         }
+        __builtin_amdgcn_sched_barrier(0);           // (the validity words are built HERE: sunk below the scale they keep 24 lane masks in SGPRs, and those spill)
         // ================= the step's scale
         const unsigned mb = wave_max_u32(__builtin_bit_cast(unsigned, mx));
         int e = (int)(mb >> 23) - 126;                                                 // max < 2^e
@@ -357,7 +361,8 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                         *reinterpret_cast<f32x4*>(po) = val;
                     }
                     if (NSUM) {
-                        const unsigned w = INC ? incsave[1 - PAR][n] : 0xffffffffu;    // saved by step j - 1
+                        unsigned w = INC ? incsave[1 - PAR][n] : 0xffffffffu;          // saved by step j - 1
+                        if (INC) asm volatile("" : "+v"(w));           // (tested HERE: hoisted to the top of the step, the 16 lane masks of the four tiles spill)
                         bool i0 = (w & 0xffu) != 0, i1 = (w & 0xff00u) != 0, i2 = (w & 0xff0000u) != 0, i3 = (w & 0xff000000u) != 0;
                         i0 = i0 & inside; i1 = i1 & inside; i2 = i2 & inside; i3 = i3 & inside;
                         if (INC != 1) {             // nansum: a NaN value is skipped (INC 1: an included voxel is a valid centre sample, its window is not empty)
