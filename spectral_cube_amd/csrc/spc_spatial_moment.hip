@@ -795,7 +795,7 @@ static int mfma_entry(int device, void* stream, const spc_cube_f32* cube, const 
                       const double* h_ky, int nky, const double* h_kx, int nkx, float* d_out,
                       int64_t out_row_stride, int64_t out_plane_stride, double dv, double* d_m0,
                       int64_t m0_row_stride, void* d_workspace, size_t workspace_bytes,
-                      const double* d_cen, double m1_add, double* d_m1, double* d_m2) {
+                      const double* d_cen, double m1_add, double* d_m1, double* d_m2, bool split_only = false) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
     SPC_REQUIRE(h_ky && h_kx && nky > 0 && nkx > 0 && (nky & 1) && (nkx & 1), "kernels must have an odd, positive number of taps");
@@ -846,6 +846,7 @@ static int mfma_entry(int device, void* stream, const spc_cube_f32* cube, const 
     if ((form == 3 || form == 0) && out_ok && spc_spatial_split_takes(cube, md))
         return spc_spatial_split_launch(st, cube, md, A.ky, A.kx, A.sy, A.sx, d_out, A.out_row_stride, A.out_plane_stride, nsum, dv, m1_add,
                                         d_cen, d_m0, d_m1, d_m2, m0_row_stride, d_workspace, workspace_bytes);
+    if (split_only) SPC_UNSUPPORTED("spatial_conv_sep_mfma: the split form does not take this cube (nx and the strides multiples of 4, 16-byte bases)");
     if (nsum == 3) SPC_UNSUPPORTED("spatial_conv_sep_mfma: moments 1 / 2 need the split form (nx and the strides multiples of 4, 16-byte base)");
     if (d_m0) {
         SpcWorkspace ws(d_workspace, workspace_bytes);
@@ -920,4 +921,15 @@ extern "C" int spc_spatial_conv_sep_mfma_moments_f32(int device, void* stream, c
                                                      void* d_workspace, size_t workspace_bytes) {
     return mfma_entry(device, stream, cube, mask, h_ky, nky, h_kx, nkx, d_out, out_row_stride, out_plane_stride, dv, d_m0, map_row_stride,
                       d_workspace, workspace_bytes, d_cen, m1_add, d_m1, d_m2);
+}
+
+// cube -> cube only, and only through the split form: what spc_spatial_conv_sep_f32 tries first for a mask ARRAY (the ring
+// kernels carry numerator and denominator through the vector ALU: 57.7 ms at C4 against 50.8).  SPC_ERR_UNSUPPORTED: the caller
+// goes on with the ring kernel.
+int spc_spatial_conv_split_store(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, const double* h_ky, int nky,
+                                 const double* h_kx, int nkx, float* d_out, int64_t out_row_stride, int64_t out_plane_stride) {
+    const char* e = getenv("SPC_SPATIAL_MFMA_FORM");
+    if (e && atoi(e) != 3 && atoi(e) != 0) { spc_set_error("split form switched off"); return SPC_ERR_UNSUPPORTED; }
+    return mfma_entry(device, stream, cube, mask, h_ky, nky, h_kx, nkx, d_out, out_row_stride, out_plane_stride, 0.0, nullptr, 0, nullptr, 0,
+                      nullptr, 0.0, nullptr, nullptr, true);
 }

@@ -20,13 +20,14 @@ def _case(shape, seed, valid=0.8, nan_frac=0.0):
     return d, m
 
 
-@pytest.mark.parametrize("form", [2, 1])
+@pytest.mark.parametrize("form", [3, 2, 1])
 @pytest.mark.parametrize("shape, fwhm, valid", [((3, 40, 64), 8.0, 0.8), ((5, 33, 130), 8.0, 0.5), ((2, 70, 962), 8.0, 0.05),
                                                  ((4, 16, 480), 4.0, 0.9), ((3, 50, 1000), 8.0, 1.0), ((5, 33, 144), 8.0, 0.5),
                                                  ((2, 70, 976), 8.0, 0.05), ((3, 97, 1040), 8.0, 1.0)])
 def test_mfma_smoothed_cube_against_the_oracle(gpu, shape, fwhm, valid, form, monkeypatch):
-    # form 2 (both convolutions on the matrix pipe) takes widths that are multiples of 16; form 1 (numerator on the vector ALU)
-    # any even width - and is what the entry point falls back to
+    # form 3 (round 5: every product on the fp16 matrix instruction) takes widths that are multiples of 4, form 2 (numerator
+    # on the float32 matrix instruction) multiples of 16; form 1 (numerator on the vector ALU) any even width - and is what
+    # the entry point falls back to
     monkeypatch.setenv("SPC_SPATIAL_MFMA_FORM", str(form))
     """the smoothed cube itself (d_out): 1e-5 of the data range, NaN pattern identical; includes partial strips, bands
     that cross both plane edges, a sparse mask (windows with ONE valid far-tail sample: the fp16 hi/lo denominator must
@@ -39,7 +40,7 @@ def test_mfma_smoothed_cube_against_the_oracle(gpu, shape, fwhm, valid, form, mo
     assert_close(out.get(), exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="mfma smooth %s" % (shape,))
 
 
-@pytest.mark.parametrize("form, nx", [(2, 528), (1, 530), (1, 528)])
+@pytest.mark.parametrize("form, nx", [(3, 528), (3, 532), (2, 528), (1, 530), (1, 528)])
 def test_mfma_fused_moment0_against_the_oracle(gpu, form, nx, monkeypatch):
     """d_m0 without d_out: dv * nansum over channels of the smoothed cube under the ORIGINAL mask; all-masked spaxels NaN;
     NaN samples under a true mask bit are interpolated over by the convolution AND counted by the (array-only) mask"""

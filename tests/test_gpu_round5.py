@@ -1,0 +1,197 @@
+"""GPU, round 5: the split form of the masked spatial stencil (spc_spatial_split.hip: every product on v_mfma_f32_16x16x32_f16,
+samples and taps as fp16 hi + lo) and its fused moments 0 / 1 / 2; launch-to-launch determinism of every operator that combines
+through LDS; the headline kernel at the north-star shape.  Oracle: oracle_np (astropy semantics, float64)."""
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close
+from spectral_cube_amd import Gaussian1DKernel, Gaussian2DKernel, _lib, ops, synth
+from spectral_cube_amd.device import DeviceArray
+
+pytestmark = pytest.mark.gpu
+K8 = Gaussian2DKernel(8 / 2.3548200450309493).array
+
+
+def _case(shape, seed, valid=0.8, nan_frac=0.0, scale=1.0, offset=2.0):
+    rng = np.random.default_rng(seed)
+    d = ((rng.standard_normal(shape) + offset) * scale).astype(np.float32)
+    m = rng.random(shape) < valid
+    if nan_frac:
+        d[rng.random(shape) < nan_frac] = np.nan
+    return d, m
+
+
+def _dev(d, m):
+    return DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 3e7])
+def test_split_form_keeps_1e5_over_the_float_range(gpu, scale):
+    """fp16 operands need a scale: it is taken from the data (running maximum per wave and channel), so the result must
+    not depend on the cube's units - Jy/beam maps of 1e-6 and counts of 3e7 alike"""
+    d, m = _case((3, 100, 260), 21, valid=0.6, scale=scale)
+    cube, mk = _dev(d, m)
+    out, _ = ops.spatial_conv_mfma(cube, K8, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk))
+    exp = O.spatial_smooth(d, m, K8)
+    assert_close(out.get(), exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="split form, scale %g" % scale)
+
+
+def test_split_form_dynamic_range_inside_a_wave_region(gpu):
+    """a bright compact source on a faint background, and rows of very different magnitude inside one 64 x 64 region: the
+    per-step scale changes DURING a channel (pending output tiles and the previous x-pass tile are rescaled), and faint
+    samples beside bright ones keep their own 2^-22"""
+    rng = np.random.default_rng(5)
+    d = (rng.standard_normal((2, 128, 192)) * 1e-3).astype(np.float32)
+    d[:, 40:43, 90:93] += 5e3
+    d[:, 70:90] *= 1e4                       # bright rows below faint ones: the scale grows mid-channel
+    d[1, 10:30] *= 1e-5                      # and a region 1e-8 of the maximum
+    m = rng.random(d.shape) < 0.85
+    cube, mk = _dev(d, m)
+    out, _ = ops.spatial_conv_mfma(cube, K8, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk))
+    exp = O.spatial_smooth(d, m, K8)
+    got = out.get()
+    assert_close(got, exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="dynamic range")
+    # the faint part on its own scale: far from the bright source / rows the error is relative to the LOCAL magnitude
+    far = (slice(0, 1), slice(0, 20), slice(0, 60))
+    assert np.abs(got[far] - exp[far]).max() <= 1e-5 * np.abs(exp[far]).max()
+
+
+@pytest.mark.parametrize("flags", [_lib.MASK_ARRAY, _lib.MASK_ARRAY | _lib.MASK_FINITE])
+def test_split_form_fused_moments_012_against_the_oracle(gpu, flags):
+    """moments 0 / 1 / 2 of the smoothed cube under the ORIGINAL mask from one kernel (three sums per spaxel), with NaN
+    samples, fully masked spaxels (m0 NaN: no channel contributed; m1 / m2 NaN: 0 / 0) and several channel chunks"""
+    shape = (90, 45, 200)
+    d, m = _case(shape, 9, valid=0.7, nan_frac=0.01)
+    m[:, 3:6, 10:14] = False
+    cube, mk = _dev(d, m)
+    inc = m & np.isfinite(d) if flags & _lib.MASK_FINITE else m
+    cen = (np.arange(shape[0]) - shape[0] // 2) * 500.0
+    _, maps = ops.spatial_conv_mfma_moments(cube, K8, DeviceArray.from_numpy(cen), dv=500.0, m1_add=77.0, mask=ops.MaskSpec(flags, array=mk))
+    sm = O.spatial_smooth(d, m, K8)
+    filled = np.where(inc, sm, np.nan)
+    e0 = 500.0 * np.nansum(filled, axis=0)
+    e0[np.all(np.isnan(filled), axis=0)] = np.nan
+    f0 = np.nan_to_num(filled, nan=0.0)
+    s0, s1, s2 = f0.sum(0), (f0 * cen[:, None, None]).sum(0), (f0 * (cen ** 2)[:, None, None]).sum(0)
+    with np.errstate(all="ignore"):
+        e1, e2 = s1 / s0 + 77.0, s2 / s0 - (s1 / s0) ** 2
+    assert np.isnan(e0).sum() >= 12
+    assert_close(maps["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="fused m0")
+    assert_close(maps["m1"].get(), e1, atol=1e-5 * 500.0 * shape[0], what="fused m1")
+    assert_close(maps["m2"].get(), e2, atol=1e-5 * np.nanmax(np.abs(e2)), what="fused m2")
+
+
+def test_split_form_zero_sums_are_not_taken_for_unseen_spaxels(gpu):
+    """the moment sums start at -0.0 ('nothing added yet'): a spaxel whose included values are all exactly zero - or all
+    exactly -0.0 - has moment 0 = 0, not NaN; only spaxels without an included voxel are NaN"""
+    d = np.zeros((6, 32, 64), np.float32)
+    d[:, 16:] = -0.0
+    d[:, :, 40:] = 1.5
+    m = np.ones(d.shape, bool)
+    m[:, 5:9, 5:9] = False
+    cube, mk = _dev(d, m)
+    _, m0 = ops.spatial_conv_mfma(cube, K8, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk), want_cube=False, want_m0=True, dv=2.0)
+    got = m0.get()
+    assert np.isnan(got[5:9, 5:9]).all() and np.isnan(got).sum() == 16
+    assert (got[:, :20][~np.isnan(got[:, :20])] == 0.0).all()
+    sm = O.spatial_smooth(d, m, K8)
+    exp = 2.0 * np.nansum(np.where(m, sm, np.nan), axis=0)
+    exp[5:9, 5:9] = np.nan
+    assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="zero sums")
+
+
+def test_masked_spatial_conv_entry_takes_the_split_form_and_the_ring_kernel_agrees(gpu, monkeypatch):
+    """spc_spatial_conv_sep_f32 with a mask ARRAY goes through the split form first; SPC_SPATIAL_RING=1 keeps the ring
+    kernel: both within 1e-5 of the oracle (and therefore of each other)"""
+    d, m = _case((4, 150, 300), 31, valid=0.75)
+    cube, mk = _dev(d, m)
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=mk)
+    exp = O.spatial_smooth(d, m, K8)
+    a = ops.spatial_conv(cube, K8, mask=spec).get()
+    monkeypatch.setenv("SPC_SPATIAL_RING", "1")
+    b = ops.spatial_conv(cube, K8, mask=spec).get()
+    tol = 1e-5 * np.nanmax(np.abs(exp))
+    assert_close(a, exp.astype(np.float32), atol=tol, what="entry, split form")
+    assert_close(b, exp.astype(np.float32), atol=tol, what="entry, ring kernel")
+    assert not np.array_equal(a, b), "both runs took the same kernel"
+
+
+# ---- launch-to-launch determinism (round-4 verdict: a race survived two green rounds; tools/stress_determinism.py is not
+# collected by pytest) - every operator that combines partial results through LDS, 10 launches at a grid that fills the
+# 256 CUs, bit-identical results
+def _launches(fn, n=10):
+    first = fn()
+    for i in range(n - 1):
+        again = fn()
+        for a, b in zip(first, again):
+            assert np.array_equal(a, b, equal_nan=True), "launch %d differs from launch 0" % (i + 1)
+
+
+@pytest.fixture(scope="module")
+def big(gpu):
+    shape = (192, 256, 512)
+    d = synth.gaussian_line_cube(shape, 77)
+    m = synth.boolean_mask(d, 77).astype(bool) | (np.random.default_rng(3).random(shape) < 0.3)
+    cube, mk = _dev(d, m)
+    return cube, mk, ops.MaskSpec(_lib.MASK_ARRAY, array=mk), shape
+
+
+def test_determinism_moments_argmax_statistics(big):
+    cube, mk, spec, shape = big
+    cen = DeviceArray.from_numpy((np.arange(shape[0]) - shape[0] // 2) * 500.0)
+
+    def moments():
+        r = ops.moments(cube, cen, dv=500.0, mask=spec, want=("m0", "m1", "m2", "argmax", "argmin", "nvalid"))
+        return [r[k].get() for k in ("m0", "m1", "m2", "argmax", "argmin", "nvalid")]
+    _launches(moments)
+    _launches(lambda: [np.asarray(list(ops.stats_global(cube, mask=spec).values()), dtype=np.float64)])
+
+
+def test_determinism_stencils(big):
+    cube, mk, spec, shape = big
+    k1 = Gaussian1DKernel(4.0).array
+    cen = DeviceArray.from_numpy((np.arange(shape[0]) - shape[0] // 2) * 500.0)
+    _launches(lambda: [ops.spectral_conv(cube, k1, mask=spec).get()], n=6)
+    _launches(lambda: [v.get() for v in ops.spectral_conv_moments(cube, k1, cen, dv=500.0, mask=spec, want=("m0", "m1", "m2")).values()], n=6)
+    _launches(lambda: [ops.spatial_conv(cube, K8, mask=spec).get()], n=6)
+    _launches(lambda: [ops.spatial_conv_mfma(cube, K8, mask=spec, want_cube=False, want_m0=True, dv=500.0)[1].get()])
+    _launches(lambda: [v.get() for v in ops.spatial_conv_mfma_moments(cube, K8, cen, dv=500.0, mask=spec)[1].values()], n=6)
+
+
+def test_determinism_order_statistics(big):
+    cube, mk, spec, shape = big
+    _launches(lambda: [ops.percentile_axis0(cube, 50.0, mask=spec).get()])
+    _launches(lambda: [ops.sigma_clip_axis0(cube, 3.0, mask=spec).get()], n=6)
+
+
+def test_moments012_argmax_at_the_north_star_shape(gpu):
+    """the headline kernel's ZW = 4 instantiation (planes of 16 MiB) at 4096 x 2048 x 2048 + uint8 mask - verified inside bench.py
+    only until round 5: rows of a seeded 16-row tile repeat along y, so every row block must reproduce the oracle's maps of
+    the tile (first, a middle and the LAST block), and the maps must be periodic"""
+    import bench
+    from spectral_cube_amd.device import device_info
+    shape = (4096, 2048, 2048)
+    if device_info(0)["free_mem"] < shape[0] * shape[1] * shape[2] * 5 * 1.05:
+        pytest.skip("needs 86 GiB of free HBM")
+    cube, maskd, tile, tmask = bench.tiled_strip_on_device(shape, synth.SEEDS["C4"], 0)
+    v = synth.spectral_axis(shape[0])
+    cen = v - v[0]
+    cref = cen[shape[0] // 2]
+    r = ops.moments(cube, DeviceArray.from_numpy(cen - cref), dv=500.0, m1_add=cref + v[0], mask=ops.MaskSpec(_lib.MASK_ARRAY, array=maskd),
+                    want=("m0", "m1", "m2", "argmax"))
+    rows = tile.shape[1]
+    inc = tmask.astype(bool)
+    e0, e1, e2 = O.moments012(tile, inc, cen, 500.0, v[0])
+    ea = O.argmax(tile, inc)
+    got = {k: r[k].get() for k in ("m0", "m1", "m2", "argmax")}
+    for y0 in (0, (shape[1] // 2 // rows) * rows, shape[1] - rows):
+        blk = slice(y0, y0 + rows)
+        assert_close(got["m0"][blk], e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="north star m0 rows %d" % y0)
+        assert_close(got["m1"][blk], e1, atol=1e-5 * 500.0 * shape[0], what="north star m1 rows %d" % y0)
+        ok = np.isfinite(e2)
+        assert_close(got["m2"][blk], e2, atol=1e-5 * np.abs(e2[ok]).max(), what="north star m2 rows %d" % y0)
+        assert np.array_equal(got["argmax"][blk], ea), "north star argmax rows %d" % y0
+    for k in ("m0", "m1", "m2", "argmax"):
+        a = got[k].reshape(shape[1] // rows, rows, shape[2])
+        assert np.array_equal(a, np.broadcast_to(a[0], a.shape), equal_nan=True), k + " is not periodic in y"
