@@ -775,7 +775,8 @@ class SpectralCube:
             fused = self._fused_masked_smooth_moment0(parent, spec, lz.kernel)
             if fused is not None:
                 return {"m0": fused}
-        elif set(want) <= {"m0", "m1", "m2"} and parent._stream_source() is None and spec.array is not None:
+        elif (set(want) <= {"m0", "m1", "m2"} and parent._stream_source() is None and spec.array is not None
+              and self._prefer_fused_higher_moments()):
             fused = self._fused_masked_smooth_moments(parent, spec, lz.kernel, want)
             if fused is not None:
                 return fused
@@ -816,6 +817,18 @@ class SpectralCube:
         if not all(np.isfinite(m.sum()) for m in out.values()):
             return None
         return out
+
+    def _prefer_fused_higher_moments(self):
+        """Three sums per spaxel fit the LDS only for 16-row wave regions (three times the halo work of moment 0's 64 rows):
+        measured at 4096 x 2048^2 the fused moments 0 / 1 / 2 take 75 ms against 51 + 14 ms for smoothing into a second cube and
+        reducing that.  So the fused form is for cubes whose smoothed copy does not fit beside them in HBM
+        (SPC_FUSED_SMOOTH_MOMENTS=1 / 0 forces / forbids it)."""
+        env = os.environ.get("SPC_FUSED_SMOOTH_MOMENTS")
+        if env is not None:
+            return env == "1"
+        from .device import device_info
+        nz, ny, nx = self._shape
+        return device_info(self.device)["free_mem"] < 1.05 * 4 * nz * ny * nx
 
     def _fused_masked_smooth_moments(self, parent, spec, kernel2d, want):
         """masked spatial_smooth -> moment 1 / 2 (and 0) in ONE kernel, like _fused_masked_smooth_moment0: the split form of

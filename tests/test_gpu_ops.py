@@ -582,7 +582,7 @@ def test_randomised_cross_check_against_oracle(gpu):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "stress_random.py"), "10", "3"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(here), "tools", "stress_random.py"), "10", "3"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "failures 0" in r.stdout, r.stdout[-3000:]

@@ -195,3 +195,35 @@ def test_moments012_argmax_at_the_north_star_shape(gpu):
     for k in ("m0", "m1", "m2", "argmax"):
         a = got[k].reshape(shape[1] // rows, rows, shape[2])
         assert np.array_equal(a, np.broadcast_to(a[0], a.shape), equal_nan=True), k + " is not periodic in y"
+
+
+def test_cube_level_masked_spatial_smooth_moment1_fused_when_asked(gpu, monkeypatch):
+    """SpectralCube.spatial_smooth(k).moment1() / moment2() with a mask array: materialised by default (faster while the
+    smoothed copy fits in HBM), one fused kernel under SPC_FUSED_SMOOTH_MOMENTS=1 - the same maps either way, equal to the
+    oracle's smooth-every-plane-then-reduce"""
+    import warnings
+    from spectral_cube_amd import SpectralCube
+    shape = (24, 70, 132)
+    d, m = _case(shape, 41, valid=0.65)
+    m[:, 30:33, 50:54] = False
+    hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 0.5, "CUNIT3": "km/s",
+           "CRPIX1": 1, "CRPIX2": 1, "CRPIX3": 1, "CRVAL1": 10.0, "CRVAL2": 20.0, "CRVAL3": -16.0, "BUNIT": "K"}
+    k = Gaussian2DKernel(8 / 2.3548200450309493)
+    sm = O.spatial_smooth(d, m, k.array)
+    ref = SpectralCube.read(d, hdr)
+    e0, e1, e2 = O.moments012(sm, m, ref._pix_cen_axis(0), ref._pix_size_slice(0), ref.spectral_axis[0])
+    calls = []
+    real = ops.spatial_conv_mfma_moments
+    monkeypatch.setattr(ops, "spatial_conv_mfma_moments", lambda *a, **kw: (calls.append(1), real(*a, **kw))[1])
+    span = abs(ref.spectral_axis[-1] - ref.spectral_axis[0])
+    for env, fused in (("0", False), ("1", True)):
+        monkeypatch.setenv("SPC_FUSED_SMOOTH_MOMENTS", env)
+        del calls[:]
+        smc = SpectralCube.read(d, hdr).with_mask(m).spatial_smooth(k)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m1, m2 = np.asarray(smc.moment1()), np.asarray(smc.moment2())
+        assert bool(calls) == fused
+        assert_close(m1, e1, atol=1e-5 * span, what="cube-level moment1, fused %s" % fused)
+        ok = np.isfinite(e2)
+        assert_close(m2, e2, atol=1e-5 * np.abs(e2[ok]).max(), what="cube-level moment2, fused %s" % fused)
