@@ -392,7 +392,8 @@ def driver_visible_summary(line):
                             "algorithmic_bytes": r["algorithmic_bytes"], "achieved": r["achieved"], "unit": "GB/s", "frac": r["frac"],
                             "target_frac": ns.get("target_frac"), "traffic_over_algorithmic": r.get("traffic_over_algorithmic"),
                             "traffic_source": r.get("traffic_source"), "mvoxel_per_s": ns["value"],
-                            "verify_max_scaled_err": (ns.get("verify") or {}).get("max_scaled_err"),
+                            "verify_max_scaled_err_m0_m1_m2": (ns.get("verify") or {}).get("max_scaled_err_m0_m1_m2"),
+                            "verify_nan_pattern": (ns.get("verify") or {}).get("nan_pattern"),
                             "mask_valid_fraction": ns.get("mask_valid_fraction"),
                             "strip_kernel_ms": {str(t["n_gpus_modelled"]): {"kernel_ms": t["kernel_ms"], "over_t1_over_n": t["kernel_over_t1_over_n"],
                                                                               "four_block_ms": t["four_block_ms"]}
@@ -733,6 +734,7 @@ def config_c4(device, scale):
     replicate_planes(maskd, tmask)
     mspec = ops.MaskSpec(_lib.MASK_ARRAY, array=maskd)
     inc = tmask[sub].astype(bool)
+    os.environ["SPC_SPATIAL_RING"] = "1"                     # (the entry point takes the split form first since round 5: this record is the ring kernel)
     ms_s = event_ms(lambda: ops.spatial_conv(cube, k2, mask=mspec, out=sm), device, n=5, warm=1)
     ver = check_cube_windows(sm, tmask, "C4 smooth masked")
     recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 mask (ring kernel, vector ALU)", "spatial_sep_grouped_kernel<29,true,false,true,256,true,0> (ARR, ISO, 256 threads, SYM)", ms_s, vox * 9, vox, ver,
@@ -742,7 +744,7 @@ def config_c4(device, scale):
     ver = check_cube_windows(sm, tmask, "C4 smooth masked, split form")
     recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 mask, matrix cores (fp16 hi / lo split form)", "spatial_split_kernel<4,true,2,true,0> (ARR, STORE)", ms_x, vox * 9, vox, ver,
                            "4 + 1 read + 4 written", mask_valid_fraction=float(tmask.mean())))
-    ops.spatial_conv(cube, k2, mask=mspec, out=sm)            # (the materialised pipeline below reduces the ring kernel's cube)
+    del os.environ["SPC_SPATIAL_RING"]
 
     # the pipeline of the config: spatial_smooth -> moment0 (the smoothed cube keeps the ORIGINAL mask)
     cen = DeviceArray.from_numpy(np.zeros(nz), device)
@@ -756,7 +758,7 @@ def config_c4(device, scale):
     ms = event_ms(pipeline_masked, device, n=5, warm=1)
     ver = check_m0_windows(o0["m0"].get(), tmask, 500.0, "C4 moment0 masked")
     recs.append(cfg_record("C4 pipeline spatial_smooth(29x29) -> moment0, uint8 mask (materialised)",
-                           "spatial_sep_grouped_kernel<29,true,false,true,256,true,0> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "spatial_split_kernel<4,true,2,true,0> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
                            "fused ideal: 4 + 1 read + 8 B/spaxel out (the materialised form moves 9 + 5 B/voxel)",
                            mask_valid_fraction=float(tmask.mean())))
 
@@ -801,7 +803,9 @@ def config_c4(device, scale):
     yy_, xx_ = np.mgrid[0:ny, 0:nx]
     smask = np.stack([(np.sin(xx_ / 37.0) * np.cos(yy_ / 53.0) > 0.2), (np.sin(xx_ / 41.0 + 1.0) * np.cos(yy_ / 47.0) > 0.2)]).view(np.uint8)
     replicate_planes(maskd, smask)
+    os.environ["SPC_SPATIAL_RING"] = "1"
     ms_sig = event_ms(lambda: ops.spatial_conv(cube, k2, mask=mspec, out=sm), device, n=5, warm=1)
+    del os.environ["SPC_SPATIAL_RING"]
     ver = check_cube_windows(sm, smask, "C4 smooth signal mask")
     recs.append(cfg_record("C4 spatial_smooth(29x29), uint8 SIGNAL mask (coherent regions)", "spatial_sep_grouped_kernel<29,true,false,true,256,true,0>",
                            ms_sig, vox * 9, vox, ver, "4 + 1 read + 4 written", mask_valid_fraction=float(smask.mean())))

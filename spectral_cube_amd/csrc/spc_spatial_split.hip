@@ -70,6 +70,7 @@ struct Sm3Args {
     int nstrips, nbands, zchunk, nchunk;
     float lim;                                // FLT_MAX under isfinite, +inf otherwise (NaN fails |v| <= lim either way)
     float sy, sx;                             // power-of-two scales of the fp16 taps
+    int mirror, sync;                         // odd bands march upwards / one rendezvous of the block's waves per channel
     float ky[32], kx[32];
 };
 
@@ -139,6 +140,13 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
     }
     const int ny = (int)A.ny, nx = (int)A.nx;
     const int y0 = band * (16 * NRT);
+    // Odd bands march UPWARDS (their rows are taken in mirrored order, the y taps reversed): a band's last two input row
+    // tiles are the first two of the band below it, and with both marching down the two reads of those 32 rows lie four
+    // steps apart - longer than the L2 keeps them (fetch x2.1 of the cube measured).  Mirrored, neighbouring bands - which
+    // run at the same time on one XCD - touch their shared rows in the same step.
+    const bool mir = A.mirror && (band & 1);
+    const int ymir = y0 + 16 * NRT - 1;        // local row q of a mirrored band is the plane's row ymir - q
+    auto plane_row = [&](int q) { return mir ? ymir - q : y0 + q; };
     const int xw = strip * (kWaves * kOC) + wave * kOC;       // first output column of this wave
 
     // ---- constant operands: thread t builds (set, hi / lo) pairs t / 64 * 4 .. + 3 for its lane
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
             const int b = set_block(set, e >> 2);
             const int idx = 30 + lm - 16 * b - (4 * lg + (e & 3));
             float w = 0.f;
-            if (b >= 0 && idx >= 0 && idx < R) w = isx ? A.kx[idx] * A.sx : A.ky[idx] * A.sy;
+            if (b >= 0 && idx >= 0 && idx < R) w = isx ? A.kx[idx] * A.sx : A.ky[mir ? R - 1 - idx : idx] * A.sy;
             const _Float16 h = (_Float16)w;
             op[e] = lo ? (_Float16)(w - (float)h) : h;
         }
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
     auto issue_loads = [&](int z, int j) {
         const auto rs = spc_plane_srd(A.cube + (int64_t)z * A.plane_stride);
         const auto rm = spc_plane_srd(ARR ? (const void*)(A.marr + (int64_t)z * A.mplane_stride) : (const void*)A.cube);
-        const int row = min(max(y0 - 16 + 16 * j + lm, 0), ny - 1);
+        const int row = min(max(plane_row(-16 + 16 * j + lm), 0), ny - 1);
         const unsigned ro = (unsigned)row * rbytes, mo = (unsigned)row * mrbytes;
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
@@ -217,9 +225,10 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         constexpr int PAR = decltype(par)::value;
         const int z = zcur;
         // ================= classification of the step's samples: d = valid ? sample : 0, validity as fp16 0 / 1
-        const int rowj = y0 - 16 + 16 * j + lm;
+        const int rowj = plane_row(-16 + 16 * j + lm);
         const bool row_in = (rowj >= 0) && (rowj < ny);
-        const bool tile_inside = tile_cols_inside && (y0 - 16 + 16 * j >= 0) && (y0 + 16 * j <= ny);     // uniform
+        const int ra = plane_row(-16 + 16 * j), rb = plane_row(-16 + 16 * j + 15);
+        const bool tile_inside = tile_cols_inside && (min(ra, rb) >= 0) && (max(ra, rb) < ny);            // uniform
         float d[kUnits][4];
         u32x2 vh[kUnits];
         float mx = 0.f;
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                     val.y = __builtin_fmaf(pn.y, escale * __builtin_amdgcn_rcpf(pd.y), 0.f);
                     val.z = __builtin_fmaf(pn.z, escale * __builtin_amdgcn_rcpf(pd.z), 0.f);
                     val.w = __builtin_fmaf(pn.w, escale * __builtin_amdgcn_rcpf(pd.w), 0.f);
-                    const int yo = y0 + 16 * i + lm, xo = xw + 16 * n + 4 * lg;
+                    const int yo = plane_row(16 * i + lm), xo = xw + 16 * n + 4 * lg;
                     const bool inside = (yo < ny) & (xo < nx);
                     if (STORE && inside) {
                         float* po = A.out + (int64_t)z * A.out_plane_stride + (int64_t)yo * A.out_row_stride + xo;
@@ -381,6 +390,9 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
 
     issue_loads(z_begin, 0);
     for (zcur = z_begin; zcur < z_end; ++zcur) {
+        // (one rendezvous per channel keeps the block's four waves - neighbours in x, 32 shared columns each - in the same
+        //  channel; waves that left above do not count)
+        if (A.sync) __builtin_amdgcn_s_barrier();
         E = -128;
         if (NSUM == 3) { cz = (float)A.cen[zcur]; cz2 = cz * cz; }
 #pragma unroll 1
@@ -394,7 +406,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         const int64_t plane = (int64_t)A.ny * A.nx;
 #pragma unroll
         for (int i = 0; i < NRT; ++i) {
-            const int yo = y0 + 16 * i + lm;
+            const int yo = plane_row(16 * i + lm);
 #pragma unroll
             for (int n = 0; n < kCT; ++n) {
                 const int xo = xw + 16 * n + 4 * lg;
@@ -479,6 +491,10 @@ int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const Mas
     A.cen = d_cen;
     A.lim = (md.flags & SPC_MASK_FINITE) ? 3.402823466e+38f : INFINITY;
     A.sy = sy; A.sx = sx;
+    // measured at 256 x 2048^2 + uint8 mask (profiles/r05_split_fetch_ab.txt): fetch / algorithmic x1.97 as built first, x1.52 with
+    // mirrored odd bands, x1.43 with the rendezvous per channel as well; the time does not move (the kernel is bound by issue).
+    // The three-sum form (16-row regions, three times the steps per channel) loses 8 % to the rendezvous: not there.
+    { const char* e = getenv("SPC_SPLIT_MIRROR"); A.mirror = e ? atoi(e) : 1; e = getenv("SPC_SPLIT_SYNC"); A.sync = e ? atoi(e) : (nsum != 3); }
     for (int i = 0; i < 32; ++i) { A.ky[i] = i < R ? ky29[i] : 0.f; A.kx[i] = i < R ? kx29[i] : 0.f; }
     const int nrt = nsum == 3 ? kNRT3 : kNRT1;
     A.nstrips = (int)((cube->nx + kWaves * kOC - 1) / (kWaves * kOC));
