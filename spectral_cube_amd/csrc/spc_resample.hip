@@ -27,6 +27,7 @@ struct LerpArgs {
     float* out;
     int64_t out_row_stride, out_plane_stride;
     int64_t jchunk;
+    int nt_store;
 };
 
 __device__ __forceinline__ float load_filled(const float* p, const uint8_t* pm, const MaskDev& m, int64_t off, int64_t moff) {
@@ -46,11 +47,11 @@ __device__ __forceinline__ void lset(float& v, int, float x) { v = x; }
 __device__ __forceinline__ void lset(f32x4& v, int i, float x) { v[i] = x; }
 
 // VEC consecutive x per lane (16-byte loads/stores when the rows allow it)
-template <int VEC>
+template <int VEC, bool NT = true>
 __device__ __forceinline__ typename LV<VEC>::F load_filled_v(const float* p, const uint8_t* pm, const MaskDev& m,
                                                              int64_t off, int64_t moff) {
     using F = typename LV<VEC>::F;
-    F v = __builtin_nontemporal_load(reinterpret_cast<const F*>(p + off));
+    F v = NT ? __builtin_nontemporal_load(reinterpret_cast<const F*>(p + off)) : *reinterpret_cast<const F*>(p + off);
     if (m.flags) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -115,8 +116,67 @@ __global__ __launch_bounds__(256) void spectral_lerp_kernel(const LerpArgs A) {
                     lset(res, i, (float)((double)diff * wj + (double)lget(a[u], i)));
                 }
             }
-            __builtin_nontemporal_store(res, reinterpret_cast<F*>(po + j * A.out_plane_stride));
+            if (A.nt_store) __builtin_nontemporal_store(res, reinterpret_cast<F*>(po + j * A.out_plane_stride));
+            else *reinterpret_cast<F*>(po + j * A.out_plane_stride) = res;
         }
+    }
+}
+
+// Round 5: the same operator as SHORT-LIVED blocks.  tools/micro/copy_ceiling.hip: a textbook copy - one 16-byte load and store per
+// lane, a block per 4 KiB - reaches 6.3 - 6.6 TB/s where every persistent form (this march included: 4.7 - 5.1 TB/s) stays
+// below 5.5; tools/micro/lerp_patterns.hip: blocks that own one 4-KiB row segment of JC = 4 consecutive output channels - the
+// three input planes they need requested together, then four stores, then the block ends - interpolate 2048 -> 4096 channels
+// in 4.46 ms against the march's 5.1 (the input planes are fetched x1.5, from the L2 / Infinity Cache the second time).
+// A block = 256 lanes x 16 bytes of ONE row x JC output channels (grid: x = row segments, y = channel groups, x fastest: the
+// blocks in flight cover whole planes of one group).  lo[] is monotone: the planes base, base + 1, base + 2 serve every output
+// of the group whose lo is base or base + 1; an output beyond that (down-sampling grids) starts the next batch of three.
+template <int JC>
+__global__ __launch_bounds__(256) void spectral_lerp_tiles_kernel(const LerpArgs A, int blocks_per_row) {
+    const int y = (int)(blockIdx.x / (unsigned)blocks_per_row);                    // (scalar arithmetic)
+    const int bx = (int)blockIdx.x - y * blocks_per_row;
+    const int x = (bx * 256 + (int)threadIdx.x) * 4;
+    if (x >= A.nx) return;
+    const int64_t j0 = (int64_t)blockIdx.y * JC;
+    const float* p = A.cube + (int64_t)y * A.row_stride + x;
+    const uint8_t* pm = (A.mask.flags & SPC_MASK_ARRAY) ? A.mask.arr + (int64_t)y * A.mask.row_stride + x : nullptr;
+    float* po = A.out + (int64_t)y * A.out_row_stride + x;
+    int los[JC];
+    double wj[JC];
+#pragma unroll
+    for (int u = 0; u < JC; ++u) {
+        const int64_t j = min(j0 + u, A.nz_out - 1);
+        los[u] = A.lo[j];
+        wj[u] = A.inv_dx[j] * A.t[j];
+    }
+    int base = -2;
+    f32x4 p0{}, p1{}, p2{};
+    auto emit = [&](const f32x4& a, const f32x4& b, int u) {
+        // scipy: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x_new - x_lo) + y_lo
+        f32x4 res;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float diff = b[i] - a[i];                               // float32 like numpy's f32 - f32
+            res[i] = (float)((double)diff * wj[u] + (double)a[i]);
+        }
+        *reinterpret_cast<f32x4*>(po + (j0 + u) * A.out_plane_stride) = res;
+    };
+#pragma unroll
+    for (int u = 0; u < JC; ++u) {
+        if (j0 + u >= A.nz_out) break;
+        const int lo = los[u];                                            // wave-uniform
+        if (lo < 0) {
+            *reinterpret_cast<f32x4*>(po + (j0 + u) * A.out_plane_stride) = f32x4{A.fill, A.fill, A.fill, A.fill};
+            continue;
+        }
+        if (base < 0 || lo > base + 1 || lo < base) {
+            base = lo;
+            const int64_t l2 = min((int64_t)lo + 2, A.nz - 1);
+            p0 = load_filled_v<4, false>(p, pm, A.mask, (int64_t)lo * A.plane_stride, (int64_t)lo * A.mask.plane_stride);
+            p1 = load_filled_v<4, false>(p, pm, A.mask, (int64_t)(lo + 1) * A.plane_stride, (int64_t)(lo + 1) * A.mask.plane_stride);
+            p2 = load_filled_v<4, false>(p, pm, A.mask, l2 * A.plane_stride, l2 * A.mask.plane_stride);
+        }
+        if (lo == base) emit(p0, p1, u);
+        else emit(p1, p2, u);
     }
 }
 
@@ -774,7 +834,22 @@ int spc_spectral_lerp_f32(int device, void* stream, const spc_cube_f32* cube, co
     int nsplit = 1;
     if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, nz_out / 16));
     A.jchunk = (nz_out + nsplit - 1) / nsplit;
+    A.nt_store = 1;
+    { const char* e = getenv("SPC_LERP_JCHUNK"); if (e && atoi(e) > 0) A.jchunk = atoi(e); e = getenv("SPC_LERP_NT"); if (e) A.nt_store = atoi(e); }
     nsplit = (int)((nz_out + A.jchunk - 1) / A.jchunk);
+    SPC_REQUIRE(nsplit <= 65535, "too many channel groups for one launch");
+    {   // short-lived blocks (see spectral_lerp_tiles_kernel): 16-byte rows, enough work to fill the chip; SPC_LERP_TILES=0 keeps the march
+        const char* e = getenv("SPC_LERP_TILES");
+        const int want = e ? atoi(e) : 1;
+        constexpr int JC = 4;
+        const int64_t bpr = (cube->nx / 4 + 255) / 256, groups = (nz_out + JC - 1) / JC;
+        if (want && v4 && cube->nz >= 3 && groups <= 65535 && bpr * cube->ny < (1ll << 31) && bpr * cube->ny * groups >= 4096) {
+            hipLaunchKernelGGL((spectral_lerp_tiles_kernel<JC>), dim3((unsigned)(bpr * cube->ny), (unsigned)groups), dim3(256), 0,
+                               (hipStream_t)stream, A, (int)bpr);
+            SPC_LAUNCH_CHECK();
+            return SPC_OK;
+        }
+    }
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
     if (v4) hipLaunchKernelGGL((spectral_lerp_kernel<4, 1>), grid, dim3(256), 0, (hipStream_t)stream, A);
     else hipLaunchKernelGGL((spectral_lerp_kernel<1, 1>), grid, dim3(256), 0, (hipStream_t)stream, A);
