@@ -443,6 +443,7 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
         nsplit = std::max(nsplit, 1);
     }
     A.zchunk = (cube->nz + nsplit - 1) / nsplit;
+    { const char* sd = getenv("SPC_SPECTRAL_SKIP_DEAD"); A.skip_dead = sd ? atoi(sd) : 1; }
     nsplit = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
     dim3 grid((unsigned)nblocks, (unsigned)nsplit);
     hipStream_t st = (hipStream_t)stream;
@@ -557,6 +558,7 @@ int spc_spectral_conv_moments_f32(int device, void* stream, const spc_cube_f32* 
         if (worst <= 1e-13 * std::max(span, 1e-300)) { A.cen_linear = 1; A.cen_c0 = c0; A.cen_dc = dc; }
     }
     A.zchunk = cube->nz;
+    { const char* sd = getenv("SPC_SPECTRAL_SKIP_DEAD"); A.skip_dead = sd ? atoi(sd) : 1; }
     const int vec = pick_vec(cube, A.mask, nullptr, 0, 0);
     if (try_weighted_moments(A, cube, h_kernel, ntaps, st, d_status, d_w)) {
         SPC_LAUNCH_CHECK();

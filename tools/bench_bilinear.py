@@ -1,7 +1,7 @@
 """Scratch: C5 reproject (4096 x 1024^2, 30-degree rotated grid) only, for kernel experiments."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np
 from spectral_cube_amd import ops, synth
@@ -17,13 +17,12 @@ hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CRVAL1": 150.0, "CRVAL2": 2.
        "CDELT1": -1 / 3600, "CDELT2": 1 / 3600, "NAXIS": 2}
 out = DeviceArray(shape, np.float32)
 ref = None
-for deg in (30.0, 7.0, 45.0):
+for deg in (30.0,):
     c, s_ = np.cos(np.radians(deg)), np.sin(np.radians(deg))
     w_in, w_out = SimpleWCS(hdr, naxis=2), SimpleWCS(dict(hdr, PC1_1=c, PC1_2=-s_, PC2_1=s_, PC2_2=c), naxis=2)
     xs, ys = reproject_pixel_map(w_in, w_out, (1024, 1024))
-    for label, env in [("tile 64", {"SPC_BILINEAR_TILE": "64"}), ("tile 32", {"SPC_BILINEAR_TILE": "32"}),
-                       ("tile 64 z128", {"SPC_BILINEAR_TILE": "64", "SPC_BILINEAR_ZCHUNK": "128"}),
-                       ("tile 64 z512", {"SPC_BILINEAR_TILE": "64", "SPC_BILINEAR_ZCHUNK": "512"})]:
+    for label, env in [("tile 64", {"SPC_BILINEAR_TILE": "64"})] + [("tile 64 z%d" % z, {"SPC_BILINEAR_TILE": "64", "SPC_BILINEAR_ZCHUNK": str(z)}) for z in (8, 16, 32, 64, 128)] + \
+                      [("tile 32 z%d" % z, {"SPC_BILINEAR_TILE": "32", "SPC_BILINEAR_ZCHUNK": str(z)}) for z in (16, 64, 256)]:
         for k in ("SPC_BILINEAR_ZCHUNK", "SPC_BILINEAR_TILE"): os.environ.pop(k, None)
         os.environ.update(env)
         ts = []
