@@ -240,27 +240,72 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                 if (ARR) mk[u] = in ? mk[u] : 0x01010101u;
             }
         }
+        // Two classifications.  FAST (a mask array whose bytes are all 0 / 1 in this step, no NaN among the included samples,
+        // and - where the mask holds isfinite - no infinity): the validity of a sample is bit 0 of its mask byte, sign-extended
+        // to a word (v_bfe_i32), ANDed onto the sample and onto the fp16 1.0 pattern - 4 vector instructions per sample and no
+        // lane masks, against 5.6 and two lane masks per sample of the general form below (compare, byte test, two selects).
+        // Whether it applies is decided per wave and step: the OR of the six mask dwords, one v_cmp_u per PAIR of masked
+        // samples, and the step's maximum (an infinity shows there).
+        bool use_fast = false;
+        if (ARR) {
+            const unsigned mor = mk[0] | mk[1] | mk[2] | mk[3] | mk[4] | mk[5];
+            use_fast = !__any((mor & 0xfefefefeu) != 0u);
+        }
+        unsigned mb = 0u;
+        {
+            if (use_fast) {
+                unsigned long long nanmask = 0ull;
 #pragma unroll
-        for (int u = 0; u < kUnits; ++u) {
-            const f32x4 r = raw[u];
-            const unsigned m = ARR ? mk[u] : 0x01010101u;
-            bool o0 = __builtin_fabsf(r.x) <= A.lim, o1 = __builtin_fabsf(r.y) <= A.lim;
-            bool o2 = __builtin_fabsf(r.z) <= A.lim, o3 = __builtin_fabsf(r.w) <= A.lim;
-            if (ARR) { o0 = o0 & ((m & 0xffu) != 0); o1 = o1 & ((m & 0xff00u) != 0); o2 = o2 & ((m & 0xff0000u) != 0); o3 = o3 & ((m & 0xff000000u) != 0); }
-            d[u][0] = o0 ? r.x : 0.f; d[u][1] = o1 ? r.y : 0.f; d[u][2] = o2 ? r.z : 0.f; d[u][3] = o3 ? r.w : 0.f;
-            vh[u].x = (o0 ? 0x3C00u : 0u) | (o1 ? 0x3C000000u : 0u);
-            vh[u].y = (o2 ? 0x3C00u : 0u) | (o3 ? 0x3C000000u : 0u);
-            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][0])), __builtin_fabsf(d[u][1]));       // (v_max3_f32 with |.| modifiers)
-            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][2])), __builtin_fabsf(d[u][3]));
-            // what the moment's include test needs one step later: unit u = n + 1 holds output column tile n of row tile j - 1
-            if (NSUM && u >= 1 && u <= kCT) {
+                for (int u = 0; u < kUnits; ++u) {
+                    const f32x4 r = raw[u];
+                    const unsigned m = mk[u];
+                    const unsigned w0 = (unsigned)__builtin_amdgcn_sbfe((int)m, 0, 1), w1 = (unsigned)__builtin_amdgcn_sbfe((int)m, 8, 1);
+                    const unsigned w2 = (unsigned)__builtin_amdgcn_sbfe((int)m, 16, 1), w3 = (unsigned)__builtin_amdgcn_sbfe((int)m, 24, 1);
+                    // (copies first: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the element - clang 19 / ROCm 7.2)
+                    const float rx = r.x, ry = r.y, rz = r.z, rw = r.w;
+                    d[u][0] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rx) & w0);
+                    d[u][1] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, ry) & w1);
+                    d[u][2] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rz) & w2);
+                    d[u][3] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, rw) & w3);
+                    vh[u].x = (w0 & 0x3C00u) | (w1 & 0x3C000000u);
+                    vh[u].y = (w2 & 0x3C00u) | (w3 & 0x3C000000u);
+                    nanmask |= __builtin_amdgcn_ballot_w64(__builtin_isunordered(d[u][0], d[u][1])) | __builtin_amdgcn_ballot_w64(__builtin_isunordered(d[u][2], d[u][3]));
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][0])), __builtin_fabsf(d[u][1]));
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][2])), __builtin_fabsf(d[u][3]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mb = wave_max_u32(__builtin_bit_cast(unsigned, mx));
+                // a NaN under a true byte, or an infinity the mask's isfinite term must reject: the general form decides
+                if (nanmask != 0ull || (INC == 1 && mb >= 0x7f800000u)) use_fast = false;
+            }
+            if (!use_fast) {
+                mx = 0.f;
+#pragma unroll
+                for (int u = 0; u < kUnits; ++u) {
+                    const f32x4 r = raw[u];
+                    const unsigned m = ARR ? mk[u] : 0x01010101u;
+                    bool o0 = __builtin_fabsf(r.x) <= A.lim, o1 = __builtin_fabsf(r.y) <= A.lim;
+                    bool o2 = __builtin_fabsf(r.z) <= A.lim, o3 = __builtin_fabsf(r.w) <= A.lim;
+                    if (ARR) { o0 = o0 & ((m & 0xffu) != 0); o1 = o1 & ((m & 0xff00u) != 0); o2 = o2 & ((m & 0xff0000u) != 0); o3 = o3 & ((m & 0xff000000u) != 0); }
+                    d[u][0] = o0 ? r.x : 0.f; d[u][1] = o1 ? r.y : 0.f; d[u][2] = o2 ? r.z : 0.f; d[u][3] = o3 ? r.w : 0.f;
+                    vh[u].x = (o0 ? 0x3C00u : 0u) | (o1 ? 0x3C000000u : 0u);
+                    vh[u].y = (o2 ? 0x3C00u : 0u) | (o3 ? 0x3C000000u : 0u);
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][0])), __builtin_fabsf(d[u][1]));       // (v_max3_f32 with |.| modifiers)
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(d[u][2])), __builtin_fabsf(d[u][3]));
+                }
+                __builtin_amdgcn_sched_barrier(0);       // (the validity words are built HERE: sunk below the scale they keep 24 lane masks in SGPRs, and those spill)
+                mb = wave_max_u32(__builtin_bit_cast(unsigned, mx));
+            }
+        }
+        // what the moment's include test needs one step later: unit u = n + 1 holds output column tile n of row tile j - 1
+        if (NSUM) {
+#pragma unroll
+            for (int u = 1; u <= kCT; ++u) {
                 if (INC == 1) incsave[PAR][u - 1] = __builtin_amdgcn_perm(vh[u].y, vh[u].x, 0x07050301u);   // byte 1 of every fp16: 0x3C / 0
                 else if (INC == 2) incsave[PAR][u - 1] = mk[u];     // the array term alone: a NaN under a true byte is interpolated over AND summed
             }
         }
-        __builtin_amdgcn_sched_barrier(0);           // (the validity words are built HERE: sunk below the scale they keep 24 lane masks in SGPRs, and those spill)
         // ================= the step's scale
-        const unsigned mb = wave_max_u32(__builtin_bit_cast(unsigned, mx));
         int e = (int)(mb >> 23) - 126;                                                 // max < 2^e
         e = min(max(e, -100), 127);
         if (e > E) {
@@ -295,12 +340,18 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         }
         __builtin_amdgcn_sched_barrier(0);
         // ================= x pass and split of its result, per column tile
+        // (column tiles in the order 0, 2, 1, 3: the even ones share their four constant operands, the odd ones theirs - read from
+        //  LDS once per pair: read per tile, every tile's first matrix instruction waited out an LDS round trip)
+        half8 c0h{}, c0l{}, c1h{}, c1l{};
 #pragma unroll
-        for (int n = 0; n < kCT; ++n) {
+        for (int nn = 0; nn < kCT; ++nn) {
+            const int n = 2 * (nn & 1) + (nn >> 1);          // 0, 2, 1, 3
             const int pA = (n & 1) ? (n - 1) / 2 : n / 2, pB = pA + 1;
-            const int s0 = (n & 1) ? XO0 : XE0, s1 = (n & 1) ? XO1 : XE1;
-            const half8 c0h = cB[(s0 * 2 + 0) * 64 + lane], c0l = cB[(s0 * 2 + 1) * 64 + lane];
-            const half8 c1h = cB[(s1 * 2 + 0) * 64 + lane], c1l = cB[(s1 * 2 + 1) * 64 + lane];
+            if (nn == 0 || nn == 2) {
+                const int s0 = (n & 1) ? XO0 : XE0, s1 = (n & 1) ? XO1 : XE1;
+                c0h = cB[(s0 * 2 + 0) * 64 + lane]; c0l = cB[(s0 * 2 + 1) * 64 + lane];
+                c1h = cB[(s1 * 2 + 0) * 64 + lane]; c1l = cB[(s1 * 2 + 1) * 64 + lane];
+            }
             f32x4 zn = {0.f, 0.f, 0.f, 0.f}, zd = {0.f, 0.f, 0.f, 0.f};
             zn = MFMA(as_half8(hiP[pA]), c0h, zn);
             zd = MFMA(as_half8(vhP[pA]), c0h, zd);
@@ -327,33 +378,35 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         if (j + 1 < NST) issue_loads(z, j + 1);
         else if (z + 1 < z_end) issue_loads(z + 1, 0);
         // ================= y pass (scatter) and the epilogue of the completed row tile, per column tile
+        // operand order: (slot 0, slot 1) = (previous, new) on odd steps, (new, previous) on even ones; the four constant operands of
+        // the y pass are the same for every column tile: read once per step
+        constexpr int y0s = PAR ? YN0 : YS0, y1s = PAR ? YN1 : YS1;
+        half8 b0h{}, b0l{}, b1h{}, b1l{};
+        if (j >= 1 && j <= NRT) { b0h = cB[(y0s * 2 + 0) * 64 + lane]; b0l = cB[(y0s * 2 + 1) * 64 + lane]; }
+        if (j >= 2) { b1h = cB[(y1s * 2 + 0) * 64 + lane]; b1l = cB[(y1s * 2 + 1) * 64 + lane]; }
 #pragma unroll
         for (int n = 0; n < kCT; ++n) {
             if (j >= 1) {
-                // operand order: (slot 0, slot 1) = (previous, new) on odd steps, (new, previous) on even ones
-                constexpr int y0s = PAR ? YN0 : YS0, y1s = PAR ? YN1 : YS1;
                 const half8 anh = as_half8(za[n][0]), anl = as_half8(za[n][1]), adh = as_half8(za[n][2]), adl = as_half8(za[n][3]);
                 if (j <= NRT) {                     // first two blocks of output row tile j - 1
-                    const half8 b0h = cB[(y0s * 2 + 0) * 64 + lane], b0l = cB[(y0s * 2 + 1) * 64 + lane];
                     f32x4 pn = {0.f, 0.f, 0.f, 0.f}, pd = {0.f, 0.f, 0.f, 0.f};
-                    pn = MFMA(anh, b0h, pn);
                     pd = MFMA(adh, b0h, pd);
-                    pn = MFMA(anl, b0h, pn);
+                    pn = MFMA(anh, b0h, pn);
                     pd = MFMA(adl, b0h, pd);
-                    pn = MFMA(anh, b0l, pn);
+                    pn = MFMA(anl, b0h, pn);
                     pd = MFMA(adh, b0l, pd);
+                    pn = MFMA(anh, b0l, pn);
                     Pn[1 - PAR][n] = pn; Pd[1 - PAR][n] = pd;          // slot (j - 1) & 1
                 }
                 if (j >= 2) {                       // last block of output row tile j - 2, then its epilogue
                     const int i = j - 2;
-                    const half8 b1h = cB[(y1s * 2 + 0) * 64 + lane], b1l = cB[(y1s * 2 + 1) * 64 + lane];
                     f32x4 pn = Pn[PAR][n], pd = Pd[PAR][n];             // slot (j - 2) & 1
+                    pd = MFMA(adh, b1h, pd);                        // (the denominator's chain ends first: its reciprocals run under the numerator's last product)
                     pn = MFMA(anh, b1h, pn);
-                    pd = MFMA(adh, b1h, pd);
-                    pn = MFMA(anl, b1h, pn);
                     pd = MFMA(adl, b1h, pd);
-                    pn = MFMA(anh, b1l, pn);
+                    pn = MFMA(anl, b1h, pn);
                     pd = MFMA(adh, b1l, pd);
+                    pn = MFMA(anh, b1l, pn);
                     // lane (m = output row, g): pn / pd [r] = output column 4 g + r of column tile n, row tile i
                     // den = 0 (empty window): 0 * inf = NaN.  The + 0.0 rides in the FMA and turns a -0.0 result into +0.0: the moment
                     // sums start at -0.0 and excluded voxels add -0.0, so a sum that is still -0.0 at the end says "no channel

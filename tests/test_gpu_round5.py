@@ -227,3 +227,24 @@ def test_cube_level_masked_spatial_smooth_moment1_fused_when_asked(gpu, monkeypa
         assert_close(m1, e1, atol=1e-5 * span, what="cube-level moment1, fused %s" % fused)
         ok = np.isfinite(e2)
         assert_close(m2, e2, atol=1e-5 * np.abs(e2[ok]).max(), what="cube-level moment2, fused %s" % fused)
+
+
+def test_split_form_mask_bytes_other_than_0_and_1_and_nonfinite_samples(gpu):
+    """the fast classification reads bit 0 of a mask byte; bytes such as 2 or 255, a NaN under a true byte and (with isfinite
+    in the mask) an infinity send the wave's step through the general classification - same results"""
+    shape = (4, 80, 192)
+    d, m = _case(shape, 13, valid=0.7)
+    d[0, 10, 20] = np.nan; d[1, 30, 100] = np.inf; d[2, 50, 150] = -np.inf; d[3, 70, 60] = np.nan
+    mb = m.astype(np.uint8)
+    mb[0][m[0]] = 255
+    mb[1][m[1]] = 2
+    mb[2, 40:, :][m[2, 40:, :]] = 128
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(mb)
+    fin = np.isfinite(d)
+    exp = O.spatial_smooth(np.where(fin, d, np.nan), m & fin, K8)
+    out, m0 = ops.spatial_conv_mfma(cube, K8, mask=ops.MaskSpec(_lib.MASK_ARRAY | _lib.MASK_FINITE, array=mk), want_cube=True, want_m0=True, dv=3.0)
+    assert_close(out.get(), exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="odd mask bytes, smoothed cube")
+    filled = np.where(m & fin, exp, np.nan)
+    e0 = 3.0 * np.nansum(filled, axis=0)
+    e0[np.all(np.isnan(filled), axis=0)] = np.nan
+    assert_close(m0.get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="odd mask bytes, moment 0")
