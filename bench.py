@@ -268,7 +268,7 @@ class Workload:
         return {"rows_checked": int(rows), "max_scaled_err_m0_m1_m2": errs, "nan_pattern": "identical"}
 
 
-PMC_FILE = os.path.join("profiles", "r04_pmc_traffic_by_record.json")
+PMC_FILE = os.path.join("profiles", "r05_pmc_traffic_by_record.json")
 _PMC = None
 PMC_ON = True         # (set False by a run at non-default shapes: the committed counters were taken at the default ones)
 
@@ -861,7 +861,7 @@ def config_c5(device, scale):
     exp, _ = O.spectral_interpolate(tile, None, v, grid)
     got = fetch_rows(out, ny - 2, ny)
     ver = {"max_scaled_err": _close(got, exp, float(np.nanmax(np.abs(exp))), "C5 lerp"), "voxels_checked": int(exp.size)}
-    recs.append(cfg_record("C5 spectral_interpolate 2048 -> 4096 channels", "spectral_lerp_kernel<4>", ms, (nz + nzo) * ny * nx * 4,
+    recs.append(cfg_record("C5 spectral_interpolate 2048 -> 4096 channels", "spectral_lerp_tiles_kernel<4>", ms, (nz + nzo) * ny * nx * 4,
                            nzo * ny * nx, ver, "4 B x nz_in + 4 B x nz_out per spaxel"))
     del cube
     # reproject: rotated TAN header, device pixel map, bilinear

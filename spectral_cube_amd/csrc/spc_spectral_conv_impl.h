@@ -57,7 +57,7 @@ struct ConvArgs {
     float* out;
     int64_t out_row_stride, out_plane_stride;
     int64_t zchunk;            // outputs per gridDim.y slice
-    int skip_dead;             // general ring kernel: skip the arithmetic of steps / outputs without a valid sample in the wave
+    int skip_dead;             // general ring kernel with a mask array: revolutions without an included sample in the wave are skipped
     // fused-moment part
     const double* cen;
     double cen_c0, cen_dc;     // linear-axis form c[z] = c0 + z*dc when cen_linear
@@ -236,11 +236,13 @@ __global__ __launch_bounds__(general_block(ARR, FUSE), FUSE ? 3 : 1) void spectr
     for (int m = 0; m < R; ++m) num[m] = 0.0;
     unsigned bad_lo = 0u, bad_hi = 0u;   // invalid bit of the last 33 inputs, bit 0 = newest (what lies before the slice start is never emitted)
     unsigned inc_lo = 0u;                // include bit of the last 32 inputs (the fused reduction asks for the one of age H <= 16)
-    // Round 5: a signal mask (data > n sigma) leaves long runs of channels in which NO lane of the wave holds a valid sample.
-    // Such a step adds zeros: its R multiply-adds are skipped (one scalar branch on the lane mask the classification made
-    // anyway); and once R such steps lie behind the wave, every lane's window is empty - NaN without the table lookup, the
-    // division and (fused) the moment update.  `run` counts them in a scalar register.
-    int run = 0;
+    // Round 5: a signal mask (data > n sigma) leaves long runs of channels in which NO lane of the wave has its mask byte set.
+    // A revolution (R channels) whose mask bytes are all zero, behind another such revolution, is skipped whole: its outputs'
+    // windows lie inside the two - NaN, nothing for the moment sums - and the numerator slots it would open already hold the
+    // zeros the previous dead revolution left.  Decided once per revolution from the OR of its R mask bytes (R vector
+    // instructions); a first version that tested every STEP cut the hot loop into R basic blocks and cost the noise-level
+    // mask of the bench 15 % (19.5 -> 22.7 ms at C3).
+    bool prev_dead = false;
     MomState ms;
     const int pbytes = (int)(A.plane_stride * 4), mbytes = ARR ? (int)A.mask.plane_stride : 0;
     const int obytes = FUSE ? 0 : (int)(A.out_plane_stride * 4);
@@ -275,6 +277,22 @@ __global__ __launch_bounds__(general_block(ARR, FUSE), FUSE ? 3 : 1) void spectr
         const int ob = max(i0 - H, 0);
         const auto ro = plane_srd(FUSE ? (const void*)A.cube : (const void*)(A.out + (int64_t)ob * A.out_plane_stride));
         const bool emit_all = (i0 - H >= zb) && (i0 + R - 1 - H < ze);          // uniform
+        if (ARR && A.skip_dead) {
+            unsigned anym = 0u;
+#pragma unroll
+            for (int s = 0; s < R; ++s) anym |= mk[s];
+            const bool dead = !edge && !__any(anym != 0u);                      // uniform: no lane includes any sample of this revolution
+            if (dead && prev_dead && emit_all) {
+                if (!FUSE) {
+#pragma unroll
+                    for (int s = 0; s < R; ++s)
+                        __builtin_amdgcn_raw_buffer_store_b32(0x7fc00000u, ro, voff_out, (int)((unsigned)(i0 + s - H - ob) * (unsigned)obytes), 0);
+                }
+                bad_lo = 0xffffffffu; bad_hi = 0xffffffffu; inc_lo = 0u;          // R invalid, excluded samples went by
+                continue;
+            }
+            prev_dead = dead;
+        }
         // fused reduction: the R channel coordinates of this revolution's outputs in ONE vector load (lane l holds
         // c[i0 - H + l]); a step takes its own with two v_readlane - a scalar load per output would put a memory
         // round trip (and a wait on the counter the table reads share) on every step
@@ -292,38 +310,27 @@ __global__ __launch_bounds__(general_block(ARR, FUSE), FUSE ? 3 : 1) void spectr
             const bool inc = FUSE ? (ok || (!has_pred && arrbit)) : ok;       // (mask logic: scalar and / or of the lane masks)
             float xs = ok ? vs : 0.f;                                 // (an out-of-range sample was loaded as 0: it adds nothing)
             unsigned badbit = ok ? 0u : 1u, incbit = inc ? 1u : 0u;   // as VECTOR integers: no lane mask stays live
-            bool step_dead = __any(ok ? 1 : 0) == 0;                 // uniform: every lane's sample is INVALID (not a valid zero)
-            const bool step_any = !step_dead || !A.skip_dead;        // uniform: some lane brings a valid sample (or the skipping is off)
             if (edge) {                                               // uniform, and kept a BRANCH (the empty asm cannot be
                 asm volatile("");                                     // speculated): interior revolutions pay one s_cbranch
-                if (!((i0 + s >= 0) && (i0 + s < nz))) { badbit = 0u; incbit = 0u; step_dead = false; }   // uniform: a valid zero, not part of the cube
+                if (!((i0 + s >= 0) && (i0 + s < nz))) { badbit = 0u; incbit = 0u; }   // uniform: a valid zero, not part of the cube
             }
-            run = (step_dead && A.skip_dead) ? run + 1 : 0;
             asm volatile("" : "+v"(xs));                              // select in float32, THEN widen (one v_cndmask, not two)
             const double xd = (double)xs;
             bad_hi = __builtin_amdgcn_alignbit(bad_hi, bad_lo, 31);
             bad_lo = (bad_lo << 1) | badbit;
             if (FUSE) inc_lo = (inc_lo << 1) | incbit;
-            if (step_any) {
 #pragma unroll
-                for (int m = 0; m < R; ++m) {
-                    const int a = (s - m + R) % R;          // age of the output living in slot m
-                    // symmetric kernels: half the distinct weights, all of them stay in SGPRs
-                    const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
-                    if (a == 0) mul_w(num[m], A, j, xd);
-                    else fma_w(num[m], A, j, xd);
-                }
-            } else {
-                num[s] = 0.0;                               // (the slot this step opens: w * 0)
+            for (int m = 0; m < R; ++m) {
+                const int a = (s - m + R) % R;          // age of the output living in slot m
+                // symmetric kernels: half the distinct weights, all of them stay in SGPRs
+                const int j = SYM ? (a <= H ? a : 2 * H - a) : 2 * H - a;
+                if (a == 0) mul_w(num[m], A, j, xd);
+                else fma_w(num[m], A, j, xd);
             }
             // ---- the output that just received its last contribution
             const int e = (s + 1) % R;
             const int o = i0 + s - H;
-            if (run >= R) {
-                // every window of the wave is empty: NaN (0 / 0 of the looked-up form), nothing for the moment sums
-                if (!FUSE && (emit_all || (o >= zb && o < ze)))
-                    __builtin_amdgcn_raw_buffer_store_b32(0x7fc00000u, ro, voff_out, (int)((unsigned)(o - ob) * (unsigned)obytes), 0);
-            } else if (emit_all || (o >= zb && o < ze)) {
+            if (emit_all || (o >= zb && o < ze)) {
                 // every sample of this output's window valid, in every lane: the denominator is the whole kernel.  Tested
                 // only without a mask array (the dirty tiles of the all-valid pass: sparse NaNs in mostly clean data) - a
                 // cube that brings its own mask array practically never has 64 clean windows side by side, and the test
