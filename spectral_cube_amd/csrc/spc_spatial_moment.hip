@@ -842,7 +842,8 @@ static int mfma_entry(int device, void* stream, const spc_cube_f32* cube, const 
     hipStream_t st = (hipStream_t)stream;
     const int form = [] { const char* e = getenv("SPC_SPATIAL_MFMA_FORM"); return e ? atoi(e) : 3; }();
     const int nsum = (d_m1 || d_m2) ? 3 : (d_m0 ? 1 : 0);
-    const bool out_ok = !d_out || (((A.out_row_stride | A.out_plane_stride) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0);
+    const bool out_ok = !d_out || (((A.out_row_stride | A.out_plane_stride) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0 &&
+                                   cube->ny * A.out_row_stride * 4 < 0xfffffff0ll);      // (32-bit byte offsets inside an output plane)
     if ((form == 3 || form == 0) && out_ok && spc_spatial_split_takes(cube, md))
         return spc_spatial_split_launch(st, cube, md, A.ky, A.kx, A.sy, A.sx, d_out, A.out_row_stride, A.out_plane_stride, nsum, dv, m1_add,
                                         d_cen, d_m0, d_m1, d_m2, m0_row_stride, d_workspace, workspace_bytes);
