@@ -418,12 +418,11 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                     val.w = __builtin_fmaf(pn.w, escale * __builtin_amdgcn_rcpf(pd.w), 0.f);
                     const int yo = plane_row(16 * i + lm), xo = xw + 16 * n + 4 * lg;
                     const bool inside = (yo < ny) & (xo < nx);
-                    if (STORE) {
-                        // one descriptor per plane, a 32-bit byte offset per lane; lanes outside the plane store beyond the
-                        // descriptor's range (dropped by the hardware) instead of branching
+                    if (STORE && inside) {
+                        // one descriptor per plane, a 32-bit byte offset per lane
                         const auto ro = spc_plane_srd(A.out + (int64_t)z * A.out_plane_stride);
                         const unsigned off = ((unsigned)yo * (unsigned)A.out_row_stride + (unsigned)xo) * 4u;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ro, (int)(inside ? off : 0xfffffff8u), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ro, (int)off, 0, 0);
                     }
                     if (NSUM) {
                         unsigned w = INC ? incsave[1 - PAR][n] : 0xffffffffu;          // saved by step j - 1
