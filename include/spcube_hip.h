@@ -475,7 +475,7 @@ int spc_spatial_conv2d_f32(int device, void* stream, const spc_cube_f32* cube,
  *   d_out  (may be NULL): the smoothed cube (nz, ny, nx), float32.
  *   d_m0   (may be NULL): moment 0 of the smoothed cube under the ORIGINAL mask, dv * nansum over channels, NaN where no
  *          channel contributes (float64 (ny, nx), row stride m0_row_stride or nx) - the cube is then never written.
- * SPC_ERR_UNSUPPORTED (the caller falls back to spc_spatial_conv_sep_f32 + spc_moments_f32): more than 29 taps per
+ * SPC_ERR_UNSUPPORTED (the caller falls back to spc_spatial_conv_sep_f32 + spc_moments_f32): more than 29 (third form: 33) taps per
  * axis, a negative tap or a zero centre tap, mask terms other than SPC_MASK_ARRAY / SPC_MASK_FINITE, odd nx or strides.
  * (ABI 4) */
 int spc_spatial_conv_sep_mfma_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,

@@ -35,7 +35,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int R = 29, H = 14;
+constexpr int R = 33, H = 16;               // up to 33 taps: offsets of -16 .. 16 columns / rows = three 16-wide Toeplitz blocks
 constexpr int kThreads = 256, kWaves = 4;
 constexpr int kOC = 64, kCT = 4;              // output columns / column tiles per wave
 constexpr int kUnits = 6;                     // 16-column input units per wave and step (kOC + 32 columns)
@@ -71,7 +71,7 @@ struct Sm3Args {
     float lim;                                // FLT_MAX under isfinite, +inf otherwise (NaN fails |v| <= lim either way)
     float sy, sx;                             // power-of-two scales of the fp16 taps
     int mirror, sync;                         // odd bands march upwards / one rendezvous of the block's waves per channel
-    float ky[32], kx[32];
+    float ky[36], kx[36];
 };
 
 __device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int b = set_block(set, e >> 2);
-            const int idx = 30 + lm - 16 * b - (4 * lg + (e & 3));
+            const int idx = H + 16 + lm - 16 * b - (4 * lg + (e & 3));
             float w = 0.f;
             if (b >= 0 && idx >= 0 && idx < R) w = isx ? A.kx[idx] * A.sx : A.ky[mir ? R - 1 - idx : idx] * A.sy;
             const _Float16 h = (_Float16)w;
@@ -533,7 +533,7 @@ size_t spc_ws_spatial_split(int64_t nz, int64_t ny, int64_t nx, int nsum) {
 
 // launches the split kernel (+ the finish kernel); the caller has validated the kernel taps (non-negative, positive centre,
 // at most 29 per axis) and the mask terms (array / isfinite only).  nsum = 0 / 1 / 3.
-int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky29, const float* kx29,
+int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky33, const float* kx33,
                              float sy, float sx, float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
                              int nsum, double dv, double m1_add, const double* d_cen, double* d_m0, double* d_m1, double* d_m2,
                              int64_t map_row_stride, void* d_workspace, size_t workspace_bytes) {
@@ -550,7 +550,7 @@ int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const Mas
     // mirrored odd bands, x1.43 with the rendezvous per channel as well; the time does not move (the kernel is bound by issue).
     // The three-sum form (16-row regions, three times the steps per channel) loses 8 % to the rendezvous: not there.
     { const char* e = getenv("SPC_SPLIT_MIRROR"); A.mirror = e ? atoi(e) : 1; e = getenv("SPC_SPLIT_SYNC"); A.sync = e ? atoi(e) : (nsum != 3); }
-    for (int i = 0; i < 32; ++i) { A.ky[i] = i < R ? ky29[i] : 0.f; A.kx[i] = i < R ? kx29[i] : 0.f; }
+    for (int i = 0; i < 36; ++i) { A.ky[i] = i < R ? ky33[i] : 0.f; A.kx[i] = i < R ? kx33[i] : 0.f; }
     const int nrt = nsum == 3 ? kNRT3 : kNRT1;
     A.nstrips = (int)((cube->nx + kWaves * kOC - 1) / (kWaves * kOC));
     A.nbands = (int)((cube->ny + 16 * nrt - 1) / (16 * nrt));

@@ -248,3 +248,20 @@ def test_split_form_mask_bytes_other_than_0_and_1_and_nonfinite_samples(gpu):
     e0 = 3.0 * np.nansum(filled, axis=0)
     e0[np.all(np.isnan(filled), axis=0)] = np.nan
     assert_close(m0.get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="odd mask bytes, moment 0")
+
+
+@pytest.mark.parametrize("stddev, taps", [(4.0, 33), (3.7, 31), (1.0, 9)])
+def test_split_form_takes_up_to_33_taps(gpu, stddev, taps):
+    """three 16-wide Toeplitz blocks cover offsets of -16 .. 16: Gaussian2DKernel(4) = 33 x 33 taps runs in the split form too
+    (forms 1 / 2 stop at 29); checked against the oracle for the smoothed cube and the fused moment 0"""
+    k2 = Gaussian2DKernel(stddev).array
+    assert k2.shape == (taps, taps)
+    d, m = _case((5, 90, 200), 51, valid=0.7)
+    cube, mk = _dev(d, m)
+    out, m0 = ops.spatial_conv_mfma(cube, k2, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk), want_cube=True, want_m0=True, dv=1.5)
+    exp = O.spatial_smooth(d, m, k2)
+    assert_close(out.get(), exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="%d taps, smoothed cube" % taps)
+    filled = np.where(m, exp, np.nan)
+    e0 = 1.5 * np.nansum(filled, axis=0)
+    e0[np.all(np.isnan(filled), axis=0)] = np.nan             # nansum_allbadtonan
+    assert_close(m0.get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="%d taps, moment 0" % taps)
