@@ -499,7 +499,7 @@ int spc_spatial_conv_sep_f32(int device, void* stream, const spc_cube_f32* cube,
                 "The kernel can't be normalized, because its sum is close to zero");
     // a mask ARRAY (and nothing but the array / isfinite) with a kernel of up to 29 non-negative taps: the split form on the
     // matrix cores first (spc_spatial_split.hip); whatever it does not take stays with the ring kernels below
-    if (mask && (mask->flags & SPC_MASK_ARRAY) && !(mask->flags & ~(uint32_t)(SPC_MASK_ARRAY | SPC_MASK_FINITE)) && std::max(nky, nkx) <= 33 && d_out) {
+    if (mask && (mask->flags & SPC_MASK_ARRAY) && !(mask->flags & ~(uint32_t)(SPC_MASK_ARRAY | SPC_MASK_FINITE)) && std::max(nky, nkx) <= 65 && d_out) {
         const char* ring = getenv("SPC_SPATIAL_RING");
         if (!(ring && atoi(ring) == 1)) {
             rc = spc_spatial_conv_split_store(device, stream, cube, mask, h_ky, nky, h_kx, nkx, d_out, out_row_stride, out_plane_stride);

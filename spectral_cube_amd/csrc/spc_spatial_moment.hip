@@ -780,8 +780,8 @@ inline int chunk_planes(int64_t nz, int64_t ny, int64_t nx) {
 // third form (round 5): every product on the fp16 matrix instruction - spc_spatial_split.hip
 bool spc_spatial_split_takes(const spc_cube_f32* cube, const MaskDev& md);
 size_t spc_ws_spatial_split(int64_t nz, int64_t ny, int64_t nx, int nsum);
-constexpr int kSplitTaps = 33;
-int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky33, const float* kx33,
+constexpr int kSplitTaps = 65;              // (33 entries for kernels of up to 33 taps - three Toeplitz blocks - else 65: five)
+int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky, const float* kx, int ntaps,
                              float sy, float sx, float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
                              int nsum, double dv, double m1_add, const double* d_cen, double* d_m0, double* d_m1, double* d_m2,
                              int64_t map_row_stride, void* d_workspace, size_t workspace_bytes);
@@ -808,22 +808,24 @@ static int mfma_entry(int device, void* stream, const spc_cube_f32* cube, const 
 #define SPC_UNSUPPORTED(...) do { spc_set_error(__VA_ARGS__); return SPC_ERR_UNSUPPORTED; } while (0)
     const int form = [] { const char* e = getenv("SPC_SPATIAL_MFMA_FORM"); return e ? atoi(e) : 3; }();
     const int nsum = (d_m1 || d_m2) ? 3 : (d_m0 ? 1 : 0);
-    // ---- the split form (round 5) first: up to 33 taps per axis (three 16-wide Toeplitz blocks cover offsets of -16 .. 16)
+    // ---- the split form (round 5) first: up to 33 taps per axis (three 16-wide Toeplitz blocks cover offsets of -16 .. 16), or up
+    // to 65 (five blocks: half the output columns per wave)
     if ((form == 3 || form == 0) && nky <= kSplitTaps && nkx <= kSplitTaps && !(md.flags & ~(uint32_t)(SPC_MASK_ARRAY | SPC_MASK_FINITE)) &&
         spc_spatial_split_takes(cube, md)) {
+        const int ntaps = std::max(nky, nkx) <= 33 ? 33 : 65;
         float ky[kSplitTaps] = {}, kx[kSplitTaps] = {};
         double sumy = 0.0, sumx = 0.0;
-        bool ok = true;
-        for (int i = 0; i < nky; ++i) { ok = ok && (h_ky[i] >= 0.0); ky[(kSplitTaps - nky) / 2 + i] = (float)h_ky[i]; sumy += h_ky[i]; }
-        for (int i = 0; i < nkx; ++i) { ok = ok && (h_kx[i] >= 0.0); kx[(kSplitTaps - nkx) / 2 + i] = (float)h_kx[i]; sumx += h_kx[i]; }
-        ok = ok && (ky[kSplitTaps / 2] > 0.f) && (kx[kSplitTaps / 2] > 0.f) && (sumy > 0.0) && (sumx > 0.0) && std::isfinite(sumy) && std::isfinite(sumx);
+        bool ok = !(ntaps == 65 && nsum == 3);
+        for (int i = 0; i < nky; ++i) { ok = ok && (h_ky[i] >= 0.0); ky[(ntaps - nky) / 2 + i] = (float)h_ky[i]; sumy += h_ky[i]; }
+        for (int i = 0; i < nkx; ++i) { ok = ok && (h_kx[i] >= 0.0); kx[(ntaps - nkx) / 2 + i] = (float)h_kx[i]; sumx += h_kx[i]; }
+        ok = ok && (ky[ntaps / 2] > 0.f) && (kx[ntaps / 2] > 0.f) && (sumy > 0.0) && (sumx > 0.0) && std::isfinite(sumy) && std::isfinite(sumx);
         const int64_t ors = out_row_stride ? out_row_stride : cube->nx, ops = out_plane_stride ? out_plane_stride : cube->ny * ors;
         ok = ok && (!d_out || (((ors | ops) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0 && cube->ny * ors * 4 < 0xfffffff0ll));   // (32-bit byte offsets inside an output plane)
         if (ok) {
             SPC_DEVICE(device);
             // fp16 range: the sum of the scaled taps (the largest x-pass denominator) stays below 2^15
             const float sy = (float)std::exp2(std::floor(std::log2(32768.0 / sumy))), sx = (float)std::exp2(std::floor(std::log2(32768.0 / sumx)));
-            return spc_spatial_split_launch((hipStream_t)stream, cube, md, ky, kx, sy, sx, d_out, ors, ops, nsum, dv, m1_add, d_cen, d_m0, d_m1, d_m2,
+            return spc_spatial_split_launch((hipStream_t)stream, cube, md, ky, kx, ntaps, sy, sx, d_out, ors, ops, nsum, dv, m1_add, d_cen, d_m0, d_m1, d_m2,
                                             m0_row_stride, d_workspace, workspace_bytes);
         }
     }

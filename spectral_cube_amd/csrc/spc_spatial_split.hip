@@ -35,26 +35,41 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int R = 33, H = 16;               // up to 33 taps: offsets of -16 .. 16 columns / rows = three 16-wide Toeplitz blocks
+// NB = number of 16-wide Toeplitz blocks a window spans: 3 (up to 33 taps: offsets of -16 .. 16 columns / rows) or 5 (up to 65
+// taps).  Either way a wave loads six 16-column units per step: 4 + 2 halo units for NB = 3 (64 output columns), 2 + 4 for NB = 5
+// (32 output columns); the y pass keeps NB - 1 output row tiles pending per column tile.
 constexpr int kThreads = 256, kWaves = 4;
-constexpr int kOC = 64, kCT = 4;              // output columns / column tiles per wave
-constexpr int kUnits = 6;                     // 16-column input units per wave and step (kOC + 32 columns)
+constexpr int kUnits = 6;                     // 16-column input units per wave and step
+constexpr int kMaxTaps = 65;
+template <int NB> struct Geo {
+    static constexpr int HB = (NB - 1) / 2;   // halo units (= halo row tiles) on each side
+    static constexpr int H = 16 * HB, R = 2 * H + 1;
+    static constexpr int CT = kUnits - 2 * HB;           // output column tiles per wave
+    static constexpr int OC = 16 * CT;
+    static constexpr int NQ = (NB + 1) / 2;   // K = 32 operands (pairs of blocks) per window
+    static constexpr int NP = NB - 1;         // pending output row tiles per column tile = period of the step's static pattern
+    static constexpr int SETS = 4 * NQ;       // constant operand sets: x pass 2 tile parities x NQ, y pass 2 slot orders x NQ
+};
 
-// constant operands in LDS: [set][hi / lo][lane]; a set = the two Toeplitz blocks of the K = 32 operand's halves
-enum { XE0 = 0, XE1, XO0, XO1, YN0, YN1, YS0, YS1, kSets };
-// x pass, even column tile n:  (units n, n + 1) . [T0; T1]  +  (units n + 2, n + 3) . [T2; 0]
-//         odd  column tile n:  (units n - 1, n) . [0; T0]   +  (units n + 1, n + 2) . [T1; T2]      (unit pairs (0,1) (2,3) (4,5) only)
-// y pass, operand (previous, new):  pending row tile j - 1 += [T0; T1],  row tile j - 2 += [0; T2]
-//         operand (new, previous):  pending row tile j - 1 += [T1; T0],  row tile j - 2 += [T2; 0]
-__device__ __forceinline__ int set_block(int set, int half) {          // Toeplitz block index b (0 / 1 / 2) or -1 (zeros)
-    switch (set) {
-        case XE0: case YN0: return half;                 // [T0; T1]
-        case XE1: case YS1: return half == 0 ? 2 : -1;   // [T2; 0]
-        case XO0: return half == 0 ? -1 : 0;             // [0; T0]
-        case XO1: return half + 1;                       // [T1; T2]
-        case YN1: return half == 0 ? -1 : 2;             // [0; T2]
-        default: return 1 - half;                        // YS0: [T1; T0]
+// constant operands in LDS: [set][hi / lo][lane]; a set = the two Toeplitz blocks T_b of the K = 32 operand's halves (or zeros)
+// x pass, column tile n of parity par, operand q = unit pair (n - par) / 2 + q (only the pairs (0,1) (2,3) (4,5) are ever formed):
+//         blocks (2 q - par, 2 q + 1 - par), zeros where that leaves 0 .. NB - 1          set = par NQ + q
+//         NB = 3:  even  [T0; T1] [T2; 0]   odd  [0; T0] [T1; T2]          NB = 5:  even  [T0; T1] [T2; T3] [T4; 0]   odd  [0; T0] [T1; T2] [T3; T4]
+// y pass (scatter), operand (previous, new) Z tile, product m: blocks (2 m, 2 m + 1) into the row tile 2 m + 1 steps back, the last
+//         one (0, T_{NB-1}) into the row tile NB - 1 steps back, which is then complete; and the same with the halves exchanged
+//         for the steps whose operand reads (new, previous)                              set = 2 NQ + order NQ + m
+template <int NB>
+__device__ __forceinline__ int set_block(int set, int half) {          // Toeplitz block index b or -1 (zeros)
+    using G = Geo<NB>;
+    if (set < 2 * G::NQ) {
+        const int par = set / G::NQ, q = set % G::NQ;
+        const int b = 2 * q - par + half;
+        return (b >= 0 && b < NB) ? b : -1;
     }
+    const int order = (set - 2 * G::NQ) / G::NQ, m = (set - 2 * G::NQ) % G::NQ;
+    const bool full = 2 * m + 1 <= NB - 1;
+    const int bp = full ? 2 * m : -1, bc = full ? 2 * m + 1 : NB - 1;
+    return (half == order) ? bp : bc;                     // order 0: (previous, new); order 1: (new, previous)
 }
 
 struct Sm3Args {
@@ -71,7 +86,7 @@ struct Sm3Args {
     float lim;                                // FLT_MAX under isfinite, +inf otherwise (NaN fails |v| <= lim either way)
     float sy, sx;                             // power-of-two scales of the fp16 taps
     int mirror, sync;                         // odd bands march upwards / one rendezvous of the block's waves per channel
-    float ky[36], kx[36];
+    float ky[kMaxTaps + 3], kx[kMaxTaps + 3];
 };
 
 __device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
@@ -119,11 +134,13 @@ __device__ __forceinline__ u32x4 scale_h8(u32x4 v, _Float16 r) { return __builti
 // NSUM: 0 (no moment), 1 (sum of the smoothed values), 3 (+ sum c v, sum c^2 v)
 // INC: which output voxels the moment sums over - 0: all (no mask), 1: those valid for the convolution (mask byte and / or
 // finite sample: the mask holds isfinite), 2: the mask BYTE alone (a NaN under a true byte is interpolated over and summed)
-template <int NRT, bool ARR, int INC, bool STORE, int NSUM>
+template <int NB, int NRT, bool ARR, int INC, bool STORE, int NSUM>
 __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Args A) {
-    __shared__ half8 cB[kSets * 2 * 64];                                              // 16 KB
-    __shared__ f32x4 msum[NSUM ? kWaves * NSUM * NRT * kCT * 64 : 1];                 // NSUM x 16 NRT KB
-    constexpr int NST = NRT + 2;              // input row tiles (steps) per channel
+    using G = Geo<NB>;
+    constexpr int kCT = G::CT, kOC = G::OC, HB = G::HB, H = G::H, R = G::R, NQ = G::NQ, NP = G::NP, kSets = G::SETS;
+    __shared__ half8 cB[kSets * 2 * 64];                                              // 16 / 24 KB
+    __shared__ f32x4 msum[NSUM ? kWaves * NSUM * NRT * kCT * 64 : 1];                 // NSUM x NRT x CT KB per wave
+    constexpr int NST = NRT + 2 * HB;         // input row tiles (steps) per channel
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);      // (provably uniform: scalar branches, scalar addresses)
     const int lm = lane & 15, lg = lane >> 4;
@@ -149,15 +166,15 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
     auto plane_row = [&](int q) { return mir ? ymir - q : y0 + q; };
     const int xw = strip * (kWaves * kOC) + wave * kOC;       // first output column of this wave
 
-    // ---- constant operands: thread t builds (set, hi / lo) pairs t / 64 * 4 .. + 3 for its lane
-    for (int q = wave * 4; q < wave * 4 + 4; ++q) {
+    // ---- constant operands: the waves share the (set, hi / lo) pairs, every thread builds them for its lane
+    for (int q = wave * (2 * kSets / kWaves); q < (wave + 1) * (2 * kSets / kWaves); ++q) {
         const int set = q >> 1, lo = q & 1;
-        const bool isx = set < YN0;
+        const bool isx = set < 2 * NQ;
         half8 op;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int b = set_block(set, e >> 2);
-            const int idx = H + 16 + lm - 16 * b - (4 * lg + (e & 3));
+            const int b = set_block<NB>(set, e >> 2);
+            const int idx = 2 * H + lm - 16 * b - (4 * lg + (e & 3));       // tap index of (output lm, input 16 (b - HB) + 4 lg + (e & 3))
             float w = 0.f;
             if (b >= 0 && idx >= 0 && idx < R) w = isx ? A.kx[idx] * A.sx : A.ky[mir ? R - 1 - idx : idx] * A.sy;
             const _Float16 h = (_Float16)w;
@@ -181,19 +198,18 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
     unsigned colin = 0;                                        // bit u: this lane's four columns of unit u lie inside the plane
 #pragma unroll
     for (int u = 0; u < kUnits; ++u) {
-        const int c = xw - 16 + 16 * u + 4 * lg;
+        const int c = xw - 16 * HB + 16 * u + 4 * lg;
         colin |= ((c >= 0 && c + 3 < nx) ? 1u : 0u) << u;
         coff[u] = (unsigned)min(max(c, 0), nx - 4);
     }
-    const bool cols_inside = (xw - 16 >= 0) && (xw + kOC + 16 <= nx);                // uniform
-    const bool rows_inside = (y0 - 16 >= 0) && (y0 + 16 * NRT + 16 <= ny);           // uniform
+    const bool cols_inside = (xw - 16 * HB >= 0) && (xw + kOC + 16 * HB <= nx);      // uniform
 
     f32x4 raw[kUnits];
     unsigned mk[kUnits];
     auto issue_loads = [&](int z, int j) {
         const auto rs = spc_plane_srd(A.cube + (int64_t)z * A.plane_stride);
         const auto rm = spc_plane_srd(ARR ? (const void*)(A.marr + (int64_t)z * A.mplane_stride) : (const void*)A.cube);
-        const int row = min(max(plane_row(-16 + 16 * j + lm), 0), ny - 1);
+        const int row = min(max(plane_row(-16 * HB + 16 * j + lm), 0), ny - 1);
         const unsigned ro = (unsigned)row * rbytes, mo = (unsigned)row * mrbytes;
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
@@ -204,14 +220,14 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
 
     // ---- state
     u32x4 za[kCT][4];                         // y-pass A operands per column tile: numerator hi, lo, denominator hi, lo; (.x,.y) = slot 0, (.z,.w) = slot 1
-    f32x4 Pn[2][kCT], Pd[2][kCT];             // pending output row tiles (numerator, denominator), slot = row tile & 1
-    unsigned incsave[2][kCT];                 // one byte per output column: "included by the ORIGINAL mask", for the centre units of a step (slot = step & 1)
+    f32x4 Pn[NP][kCT], Pd[NP][kCT];           // pending output row tiles (numerator, denominator), slot = row tile mod NP
+    unsigned incsave[NP][kCT];                // one byte per output column: "included by the ORIGINAL mask", for the centre units of a step (slot = step mod NP)
 #pragma unroll
     for (int n = 0; n < kCT; ++n) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) za[n][q] = u32x4{0u, 0u, 0u, 0u};
-        Pn[0][n] = Pn[1][n] = Pd[0][n] = Pd[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        incsave[0][n] = incsave[1][n] = 0u;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { Pn[q][n] = Pd[q][n] = f32x4{0.f, 0.f, 0.f, 0.f}; incsave[q][n] = 0u; }
     }
     f32x4* macc = msum + (size_t)wave * NSUM * NRT * kCT * 64 + lane;
     const bool tile_cols_inside = cols_inside;
@@ -222,12 +238,13 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
     // one step = one input row tile (16 rows x 96 columns) of the channel; PAR = parity of the step (static: it names the
     // operand slot the new Z tile goes to and the slots of the pending row tiles)
     auto step = [&](auto par, const int j) {
-        constexpr int PAR = decltype(par)::value;
+        constexpr int PARN = decltype(par)::value;           // j mod NP
+        constexpr int PAR = PARN & 1;                         // slot of the new Z tile in the y-pass operands
         const int z = zcur;
         // ================= classification of the step's samples: d = valid ? sample : 0, validity as fp16 0 / 1
-        const int rowj = plane_row(-16 + 16 * j + lm);
+        const int rowj = plane_row(-16 * HB + 16 * j + lm);
         const bool row_in = (rowj >= 0) && (rowj < ny);
-        const int ra = plane_row(-16 + 16 * j), rb = plane_row(-16 + 16 * j + 15);
+        const int ra = plane_row(-16 * HB + 16 * j), rb = plane_row(-16 * HB + 16 * j + 15);
         const bool tile_inside = tile_cols_inside && (min(ra, rb) >= 0) && (max(ra, rb) < ny);            // uniform
         float d[kUnits][4];
         u32x2 vh[kUnits];
@@ -297,12 +314,12 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                 mb = wave_max_u32(__builtin_bit_cast(unsigned, mx));
             }
         }
-        // what the moment's include test needs one step later: unit u = n + 1 holds output column tile n of row tile j - 1
+        // what the moment's include test needs HB steps later: unit u = n + HB holds output column tile n of row tile j - HB
         if (NSUM) {
 #pragma unroll
-            for (int u = 1; u <= kCT; ++u) {
-                if (INC == 1) incsave[PAR][u - 1] = __builtin_amdgcn_perm(vh[u].y, vh[u].x, 0x07050301u);   // byte 1 of every fp16: 0x3C / 0
-                else if (INC == 2) incsave[PAR][u - 1] = mk[u];     // the array term alone: a NaN under a true byte is interpolated over AND summed
+            for (int u = HB; u < HB + kCT; ++u) {
+                if (INC == 1) incsave[PARN][u - HB] = __builtin_amdgcn_perm(vh[u].y, vh[u].x, 0x07050301u);   // byte 1 of every fp16: 0x3C / 0
+                else if (INC == 2) incsave[PARN][u - HB] = mk[u];   // the array term alone: a NaN under a true byte is interpolated over AND summed
             }
         }
         // ================= the step's scale
@@ -313,7 +330,8 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                 const float r = exp2i(E - e);
 #pragma unroll
                 for (int n = 0; n < kCT; ++n) {
-                    Pn[0][n] = Pn[0][n] * r; Pn[1][n] = Pn[1][n] * r;
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) Pn[q][n] = Pn[q][n] * r;
                     // (the previous Z tile in the y-pass operand carries the old scale too; fp16 times a power of two)
                     za[n][0] = scale_h8(za[n][0], (_Float16)r); za[n][1] = scale_h8(za[n][1], (_Float16)r);
                 }
@@ -340,29 +358,30 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         }
         __builtin_amdgcn_sched_barrier(0);
         // ================= x pass and split of its result, per column tile
-        // (column tiles in the order 0, 2, 1, 3: the even ones share their four constant operands, the odd ones theirs - read from
-        //  LDS once per pair: read per tile, every tile's first matrix instruction waited out an LDS round trip)
-        half8 c0h{}, c0l{}, c1h{}, c1l{};
+        // (column tiles in the order even ones, odd ones: tiles of one parity share their constant operands - read from LDS once
+        //  per parity: read per tile, every tile's first matrix instruction waited out an LDS round trip)
+        half8 ch[NQ], cl[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { ch[q] = half8{}; cl[q] = half8{}; }
 #pragma unroll
         for (int nn = 0; nn < kCT; ++nn) {
-            const int n = 2 * (nn & 1) + (nn >> 1);          // 0, 2, 1, 3
-            const int pA = (n & 1) ? (n - 1) / 2 : n / 2, pB = pA + 1;
-            if (nn == 0 || nn == 2) {
-                const int s0 = (n & 1) ? XO0 : XE0, s1 = (n & 1) ? XO1 : XE1;
-                c0h = cB[(s0 * 2 + 0) * 64 + lane]; c0l = cB[(s0 * 2 + 1) * 64 + lane];
-                c1h = cB[(s1 * 2 + 0) * 64 + lane]; c1l = cB[(s1 * 2 + 1) * 64 + lane];
+            constexpr int kEven = (kCT + 1) / 2;
+            const int n = nn < kEven ? 2 * nn : 2 * (nn - kEven) + 1;          // 0, 2, 1, 3  /  0, 1
+            const int par = n & 1, p0 = (n - par) / 2;
+            if (nn == 0 || nn == kEven) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) { ch[q] = cB[((par * NQ + q) * 2 + 0) * 64 + lane]; cl[q] = cB[((par * NQ + q) * 2 + 1) * 64 + lane]; }
             }
             f32x4 zn = {0.f, 0.f, 0.f, 0.f}, zd = {0.f, 0.f, 0.f, 0.f};
-            zn = MFMA(as_half8(hiP[pA]), c0h, zn);
-            zd = MFMA(as_half8(vhP[pA]), c0h, zd);
-            zn = MFMA(as_half8(loP[pA]), c0h, zn);
-            zd = MFMA(as_half8(vhP[pA]), c0l, zd);
-            zn = MFMA(as_half8(hiP[pA]), c0l, zn);
-            zd = MFMA(as_half8(vhP[pB]), c1h, zd);
-            zn = MFMA(as_half8(hiP[pB]), c1h, zn);
-            zd = MFMA(as_half8(vhP[pB]), c1l, zd);
-            zn = MFMA(as_half8(loP[pB]), c1h, zn);
-            zn = MFMA(as_half8(hiP[pB]), c1l, zn);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int p = p0 + q;                      // unit pair (2 p, 2 p + 1)
+                zn = MFMA(as_half8(hiP[p]), ch[q], zn);
+                zd = MFMA(as_half8(vhP[p]), ch[q], zd);
+                zn = MFMA(as_half8(loP[p]), ch[q], zn);
+                zd = MFMA(as_half8(vhP[p]), cl[q], zd);
+                zn = MFMA(as_half8(hiP[p]), cl[q], zn);
+            }
             // lane (m = output column, g): zn / zd [r] = row 4 g + r of input row tile j
             unsigned nh0, nl0, nh1, nl1, dh0, dl0, dh1, dl1;
             split_pair_acc(zn.x, zn.y, fz, nh0, nl0);
@@ -378,35 +397,49 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         if (j + 1 < NST) issue_loads(z, j + 1);
         else if (z + 1 < z_end) issue_loads(z + 1, 0);
         // ================= y pass (scatter) and the epilogue of the completed row tile, per column tile
-        // operand order: (slot 0, slot 1) = (previous, new) on odd steps, (new, previous) on even ones; the four constant operands of
-        // the y pass are the same for every column tile: read once per step
-        constexpr int y0s = PAR ? YN0 : YS0, y1s = PAR ? YN1 : YS1;
-        half8 b0h{}, b0l{}, b1h{}, b1l{};
-        if (j >= 1 && j <= NRT) { b0h = cB[(y0s * 2 + 0) * 64 + lane]; b0l = cB[(y0s * 2 + 1) * 64 + lane]; }
-        if (j >= 2) { b1h = cB[(y1s * 2 + 0) * 64 + lane]; b1l = cB[(y1s * 2 + 1) * 64 + lane]; }
+        // operand order: (slot 0, slot 1) = (previous, new) on odd steps, (new, previous) on even ones; the constant operands of
+        // the y pass are the same for every column tile: read once per step.  Product m adds blocks (2 m, 2 m + 1) to the row tile
+        // TB(m) = 2 m + 1 steps back (the last product: block NB - 1 alone, NB - 1 steps back - that row tile is then complete)
+        constexpr int order = PAR ? 0 : 1;
+        auto TB = [](int m) { return 2 * m + 1 <= NB - 1 ? 2 * m + 1 : NB - 1; };
+        half8 bh[NQ], bl[NQ];
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) {
+            bh[m] = half8{}; bl[m] = half8{};
+            const int i = j - TB(m);
+            if (i >= 0 && i < NRT) { bh[m] = cB[((2 * NQ + order * NQ + m) * 2 + 0) * 64 + lane]; bl[m] = cB[((2 * NQ + order * NQ + m) * 2 + 1) * 64 + lane]; }
+        }
 #pragma unroll
         for (int n = 0; n < kCT; ++n) {
             if (j >= 1) {
                 const half8 anh = as_half8(za[n][0]), anl = as_half8(za[n][1]), adh = as_half8(za[n][2]), adl = as_half8(za[n][3]);
-                if (j <= NRT) {                     // first two blocks of output row tile j - 1
-                    f32x4 pn = {0.f, 0.f, 0.f, 0.f}, pd = {0.f, 0.f, 0.f, 0.f};
-                    pd = MFMA(adh, b0h, pd);
-                    pn = MFMA(anh, b0h, pn);
-                    pd = MFMA(adl, b0h, pd);
-                    pn = MFMA(anl, b0h, pn);
-                    pd = MFMA(adh, b0l, pd);
-                    pn = MFMA(anh, b0l, pn);
-                    Pn[1 - PAR][n] = pn; Pd[1 - PAR][n] = pd;          // slot (j - 1) & 1
+#pragma unroll
+                for (int m = 0; m < NQ - 1; ++m) {          // all but the completing product
+                    const int i = j - TB(m);
+                    constexpr int dummy = 0; (void)dummy;
+                    if (i >= 0 && i < NRT) {
+                        const int slot = ((PARN - TB(m)) % NP + NP) % NP;                 // row tile i mod NP (static)
+                        f32x4 pn = m == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : Pn[slot][n], pd = m == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : Pd[slot][n];
+                        pd = MFMA(adh, bh[m], pd);
+                        pn = MFMA(anh, bh[m], pn);
+                        pd = MFMA(adl, bh[m], pd);
+                        pn = MFMA(anl, bh[m], pn);
+                        pd = MFMA(adh, bl[m], pd);
+                        pn = MFMA(anh, bl[m], pn);
+                        Pn[slot][n] = pn; Pd[slot][n] = pd;
+                    }
                 }
-                if (j >= 2) {                       // last block of output row tile j - 2, then its epilogue
-                    const int i = j - 2;
-                    f32x4 pn = Pn[PAR][n], pd = Pd[PAR][n];             // slot (j - 2) & 1
-                    pd = MFMA(adh, b1h, pd);                        // (the denominator's chain ends first: its reciprocals run under the numerator's last product)
-                    pn = MFMA(anh, b1h, pn);
-                    pd = MFMA(adl, b1h, pd);
-                    pn = MFMA(anl, b1h, pn);
-                    pd = MFMA(adh, b1l, pd);
-                    pn = MFMA(anh, b1l, pn);
+                if (j >= NB - 1) {                  // last block of output row tile j - (NB - 1), then its epilogue
+                    constexpr int ml = NQ - 1;
+                    constexpr int slot = ((PARN - (NB - 1)) % NP + NP) % NP;
+                    const int i = j - (NB - 1);
+                    f32x4 pn = Pn[slot][n], pd = Pd[slot][n];
+                    pd = MFMA(adh, bh[ml], pd);                     // (the denominator's chain ends first: its reciprocals run under the numerator's last product)
+                    pn = MFMA(anh, bh[ml], pn);
+                    pd = MFMA(adl, bh[ml], pd);
+                    pn = MFMA(anl, bh[ml], pn);
+                    pd = MFMA(adh, bl[ml], pd);
+                    pn = MFMA(anh, bl[ml], pn);
                     // lane (m = output row, g): pn / pd [r] = output column 4 g + r of column tile n, row tile i
                     // den = 0 (empty window): 0 * inf = NaN.  The + 0.0 rides in the FMA and turns a -0.0 result into +0.0: the moment
                     // sums start at -0.0 and excluded voxels add -0.0, so a sum that is still -0.0 at the end says "no channel
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ro, (int)off, 0, 0);
                     }
                     if (NSUM) {
-                        unsigned w = INC ? incsave[1 - PAR][n] : 0xffffffffu;          // saved by step j - 1
+                        unsigned w = INC ? incsave[((PARN - HB) % NP + NP) % NP][n] : 0xffffffffu;   // saved by step j - HB (the centre row tile of i)
                         if (INC) asm volatile("" : "+v"(w));           // (tested HERE: hoisted to the top of the step, the 16 lane masks of the four tiles spill)
                         bool i0 = (w & 0xffu) != 0, i1 = (w & 0xff00u) != 0, i2 = (w & 0xff0000u) != 0, i3 = (w & 0xff000000u) != 0;
                         i0 = i0 & inside; i1 = i1 & inside; i2 = i2 & inside; i3 = i3 & inside;
@@ -451,9 +484,13 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         E = -128;
         if (NSUM == 3) { cz = (float)A.cen[zcur]; cz2 = cz * cz; }
 #pragma unroll 1
-        for (int jj = 0; jj < NST; jj += 2) {
+        for (int jj = 0; jj < NST; jj += NP) {
             step(std::integral_constant<int, 0>{}, jj);
             if (jj + 1 < NST) step(std::integral_constant<int, 1>{}, jj + 1);
+            if (NP > 2) {
+                if (jj + 2 < NST) step(std::integral_constant<int, 2 % NP>{}, jj + 2);
+                if (jj + 3 < NST) step(std::integral_constant<int, 3 % NP>{}, jj + 3);
+            }
         }
     }
 
@@ -513,7 +550,13 @@ inline int split_chunk_planes(int64_t nz, int64_t tiles) {
     return (int)std::min<int64_t>(zc, 64);
 }
 
-constexpr int kNRT1 = 4, kNRT3 = 1;
+// output row tiles per wave: what the LDS holds next to the constant operands at two blocks per CU (80 KB each)
+//   NB = 3 (16 KB of constants):  one sum 4 x 4 KB per wave (64 rows), three sums 1 x 12 KB (16 rows)
+//   NB = 5 (24 KB of constants):  one sum 7 x 2 KB per wave (112 rows); three sums: not built
+constexpr int kNRT1 = 4, kNRT3 = 1, kNRT1w = 7;
+
+struct SplitGeo { int nrt, oc; };
+inline SplitGeo split_geo(int nb, int nsum) { return nb == 3 ? SplitGeo{nsum == 3 ? kNRT3 : kNRT1, Geo<3>::OC} : SplitGeo{kNRT1w, Geo<5>::OC}; }
 
 }  // namespace
 
@@ -525,15 +568,20 @@ bool spc_spatial_split_takes(const spc_cube_f32* cube, const MaskDev& md) {
 }
 
 size_t spc_ws_spatial_split(int64_t nz, int64_t ny, int64_t nx, int nsum) {
-    const int nrt = nsum == 3 ? kNRT3 : kNRT1;
-    const int64_t tiles = ((ny + 16 * nrt - 1) / (16 * nrt)) * ((nx + kWaves * kOC - 1) / (kWaves * kOC));
-    const int64_t zc = split_chunk_planes(nz, tiles), nchunk = (nz + zc - 1) / zc;
-    return spc_ws_round((size_t)nsum * nchunk * ny * nx * sizeof(float)) + spc_ws_round((size_t)nchunk * ny * nx) + 512;
+    size_t need = 0;
+    for (int nb : {3, 5}) {
+        if (nb == 5 && nsum == 3) continue;
+        const SplitGeo g = split_geo(nb, nsum);
+        const int64_t tiles = ((ny + 16 * g.nrt - 1) / (16 * g.nrt)) * ((nx + kWaves * g.oc - 1) / (kWaves * g.oc));
+        const int64_t zc = split_chunk_planes(nz, tiles), nchunk = (nz + zc - 1) / zc;
+        need = std::max(need, spc_ws_round((size_t)nsum * nchunk * ny * nx * sizeof(float)) + spc_ws_round((size_t)nchunk * ny * nx) + 512);
+    }
+    return need;
 }
 
 // launches the split kernel (+ the finish kernel); the caller has validated the kernel taps (non-negative, positive centre,
-// at most 29 per axis) and the mask terms (array / isfinite only).  nsum = 0 / 1 / 3.
-int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky33, const float* kx33,
+// centred in arrays of `ntaps` = 33 or 65 entries) and the mask terms (array / isfinite only).  nsum = 0 / 1 / 3.
+int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const MaskDev& md, const float* ky, const float* kx, int ntaps,
                              float sy, float sx, float* d_out, int64_t out_row_stride, int64_t out_plane_stride,
                              int nsum, double dv, double m1_add, const double* d_cen, double* d_m0, double* d_m1, double* d_m2,
                              int64_t map_row_stride, void* d_workspace, size_t workspace_bytes) {
@@ -550,9 +598,13 @@ int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const Mas
     // mirrored odd bands, x1.43 with the rendezvous per channel as well; the time does not move (the kernel is bound by issue).
     // The three-sum form (16-row regions, three times the steps per channel) loses 8 % to the rendezvous: not there.
     { const char* e = getenv("SPC_SPLIT_MIRROR"); A.mirror = e ? atoi(e) : 1; e = getenv("SPC_SPLIT_SYNC"); A.sync = e ? atoi(e) : (nsum != 3); }
-    for (int i = 0; i < 36; ++i) { A.ky[i] = i < R ? ky33[i] : 0.f; A.kx[i] = i < R ? kx33[i] : 0.f; }
-    const int nrt = nsum == 3 ? kNRT3 : kNRT1;
-    A.nstrips = (int)((cube->nx + kWaves * kOC - 1) / (kWaves * kOC));
+    SPC_REQUIRE(ntaps == Geo<3>::R || ntaps == Geo<5>::R, "internal: the split form takes taps padded to 33 or 65 entries");
+    const int nb = ntaps == Geo<3>::R ? 3 : 5;
+    if (nb == 5 && nsum == 3) { spc_set_error("spatial_conv_sep_mfma: moments 1 / 2 of kernels with more than 33 taps are not fused"); return SPC_ERR_UNSUPPORTED; }
+    for (int i = 0; i < kMaxTaps + 3; ++i) { A.ky[i] = i < ntaps ? ky[i] : 0.f; A.kx[i] = i < ntaps ? kx[i] : 0.f; }
+    const SplitGeo geo = split_geo(nb, nsum);
+    const int nrt = geo.nrt;
+    A.nstrips = (int)((cube->nx + kWaves * geo.oc - 1) / (kWaves * geo.oc));
     A.nbands = (int)((cube->ny + 16 * nrt - 1) / (16 * nrt));
     A.zchunk = split_chunk_planes(cube->nz, (int64_t)A.nstrips * A.nbands);
     A.nchunk = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
@@ -566,12 +618,17 @@ int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const Mas
     }
     const bool arr = A.marr != nullptr, fin = (md.flags & SPC_MASK_FINITE) != 0, store = d_out != nullptr;
     dim3 grid((unsigned)nblocks), block(kThreads);
-#define SPC_S3(NRT_, ARR_, INC_, STORE_, NSUM_) hipLaunchKernelGGL((spatial_split_kernel<NRT_, ARR_, INC_, STORE_, NSUM_>), grid, block, 0, st, A)
-#define SPC_S3_MASK(NRT_, STORE_, NSUM_) do { if (arr && fin) SPC_S3(NRT_, true, 1, STORE_, NSUM_); else if (arr) SPC_S3(NRT_, true, 2, STORE_, NSUM_); \
-                                              else if (fin) SPC_S3(NRT_, false, 1, STORE_, NSUM_); else SPC_S3(NRT_, false, 0, STORE_, NSUM_); } while (0)
-    if (nsum == 3) { if (store) SPC_S3_MASK(kNRT3, true, 3); else SPC_S3_MASK(kNRT3, false, 3); }
-    else if (nsum == 1) { if (store) SPC_S3_MASK(kNRT1, true, 1); else SPC_S3_MASK(kNRT1, false, 1); }
-    else SPC_S3_MASK(kNRT1, true, 0);
+#define SPC_S3(NB_, NRT_, ARR_, INC_, STORE_, NSUM_) hipLaunchKernelGGL((spatial_split_kernel<NB_, NRT_, ARR_, INC_, STORE_, NSUM_>), grid, block, 0, st, A)
+#define SPC_S3_MASK(NB_, NRT_, STORE_, NSUM_) do { if (arr && fin) SPC_S3(NB_, NRT_, true, 1, STORE_, NSUM_); else if (arr) SPC_S3(NB_, NRT_, true, 2, STORE_, NSUM_); \
+                                                   else if (fin) SPC_S3(NB_, NRT_, false, 1, STORE_, NSUM_); else SPC_S3(NB_, NRT_, false, 0, STORE_, NSUM_); } while (0)
+    if (nb == 3) {
+        if (nsum == 3) { if (store) SPC_S3_MASK(3, kNRT3, true, 3); else SPC_S3_MASK(3, kNRT3, false, 3); }
+        else if (nsum == 1) { if (store) SPC_S3_MASK(3, kNRT1, true, 1); else SPC_S3_MASK(3, kNRT1, false, 1); }
+        else SPC_S3_MASK(3, kNRT1, true, 0);
+    } else {
+        if (nsum == 1) { if (store) SPC_S3_MASK(5, kNRT1w, true, 1); else SPC_S3_MASK(5, kNRT1w, false, 1); }
+        else SPC_S3_MASK(5, kNRT1w, true, 0);
+    }
     SPC_LAUNCH_CHECK();
     if (nsum) {
         const int64_t n = cube->ny * cube->nx;

@@ -78,7 +78,7 @@ def test_mfma_refuses_what_it_does_not_do(gpu):
     cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
     spec = ops.MaskSpec(_lib.MASK_ARRAY, array=mk)
     with pytest.raises(_lib.HipUnsupported):
-        ops.spatial_conv_mfma(cube, Gaussian2DKernel(5.0).array, mask=spec)                  # 41 taps
+        ops.spatial_conv_mfma(cube, Gaussian2DKernel(10.0).array, mask=spec)                 # 81 taps (the split form takes up to 65)
     with pytest.raises(_lib.HipUnsupported):
         ops.spatial_conv_mfma(cube, Gaussian2DKernel(2.0).array, mask=ops.MaskSpec(_lib.MASK_ARRAY | _lib.MASK_GT, 0.5, 0.0, mk))
     neg = np.outer([-0.1, 1.0, -0.1], [0.2, 1.0, 0.2])

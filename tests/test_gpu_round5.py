@@ -250,13 +250,14 @@ def test_split_form_mask_bytes_other_than_0_and_1_and_nonfinite_samples(gpu):
     assert_close(m0.get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="odd mask bytes, moment 0")
 
 
-@pytest.mark.parametrize("stddev, taps", [(4.0, 33), (3.7, 31), (1.0, 9)])
-def test_split_form_takes_up_to_33_taps(gpu, stddev, taps):
-    """three 16-wide Toeplitz blocks cover offsets of -16 .. 16: Gaussian2DKernel(4) = 33 x 33 taps runs in the split form too
-    (forms 1 / 2 stop at 29); checked against the oracle for the smoothed cube and the fused moment 0"""
+@pytest.mark.parametrize("stddev, taps", [(4.0, 33), (3.7, 31), (1.0, 9), (4.3, 35), (5.0, 41), (6.0, 49), (8.0, 65)])
+def test_split_form_takes_up_to_65_taps(gpu, stddev, taps):
+    """three 16-wide Toeplitz blocks cover offsets of -16 .. 16 (Gaussian2DKernel(4) = 33 x 33 taps; forms 1 / 2 stop at 29), five
+    blocks offsets of -32 .. 32 (65 taps: half the output columns per wave, four pending row tiles): the smoothed cube and the
+    fused moment 0 against the oracle, planes smaller and larger than a wave region"""
     k2 = Gaussian2DKernel(stddev).array
     assert k2.shape == (taps, taps)
-    d, m = _case((5, 90, 200), 51, valid=0.7)
+    d, m = _case((5, 150, 200) if taps > 33 else (5, 90, 200), 51, valid=0.7)
     cube, mk = _dev(d, m)
     out, m0 = ops.spatial_conv_mfma(cube, k2, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk), want_cube=True, want_m0=True, dv=1.5)
     exp = O.spatial_smooth(d, m, k2)
