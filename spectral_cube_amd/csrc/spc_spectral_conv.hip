@@ -32,6 +32,8 @@ extern template int launch<17>(const ConvArgs&, hipStream_t, int, bool);
 extern template int launch<33>(const ConvArgs&, hipStream_t, int, bool);
 extern template int launch_fast_only<49>(const ConvArgs&, hipStream_t);
 extern template int launch_fast_only<65>(const ConvArgs&, hipStream_t);
+extern template int launch_ring_wide<49>(const ConvArgs&, hipStream_t);
+extern template int launch_ring_wide<65>(const ConvArgs&, hipStream_t);
 }
 using namespace spc_sconv;
 
@@ -468,9 +470,9 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
         const int Rf = ntaps <= 49 ? 49 : 65;
         bool sym = (ntaps & 1) && ntaps <= 65 && h_kernel[ntaps / 2] != 0.0;
         for (int i = 0; sym && i < ntaps / 2; ++i) sym = h_kernel[i] == h_kernel[ntaps - 1 - i];
+        const bool fits = wide && sym && ring_fits(Rf, cube, mask, A.out_row_stride, A.out_plane_stride);
         const char* fenv = getenv("SPC_CONV_FAST");
-        if (wide && sym && (fenv ? atoi(fenv) != 0 : true) && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0 &&
-            ring_fits(Rf, cube, mask, A.out_row_stride, A.out_plane_stride)) {
+        if (fits && (fenv ? atoi(fenv) != 0 : true) && (A.mask.flags & ~(uint32_t)SPC_MASK_FINITE) == 0) {
             rc = fill_common(A, cube, mask, h_kernel, ntaps, Rf);            // taps centred in the ring, kernel sum
             if (rc) return rc;
             SPC_WS_TAKE(d_status, ws, unsigned char, (ncols + 127) / 128);
@@ -481,6 +483,18 @@ int spc_spectral_conv_f32(int device, void* stream, const spc_cube_f32* cube, co
             rc = Rf == 49 ? spc_sconv::launch_fast_only<49>(A, st) : spc_sconv::launch_fast_only<65>(A, st);
             if (rc) return rc;
             A.zchunk = keep;
+        }
+        // tiles with invalid samples / cubes that bring a mask: the general form of the same rings (round 5), for
+        // non-negative taps (an empty window then means an invalid centre sample: NaN, which is what 0 / 0 gives)
+        bool nonneg = true;
+        for (int i = 0; i < ntaps; ++i) nonneg = nonneg && h_kernel[i] >= 0.0;
+        const char* renv = getenv("SPC_SPECTRAL_RING_WIDE");
+        if (fits && nonneg && (renv ? atoi(renv) != 0 : true)) {
+            unsigned char* keep_status = A.status;
+            rc = fill_common(A, cube, mask, h_kernel, ntaps, Rf);
+            if (rc) return rc;
+            A.status = keep_status;
+            return Rf == 49 ? spc_sconv::launch_ring_wide<49>(A, st) : spc_sconv::launch_ring_wide<65>(A, st);
         }
     }
     if (wide) {

@@ -390,6 +390,181 @@ __global__ __launch_bounds__(general_block(ARR, FUSE), FUSE ? 3 : 1) void spectr
     }
 }
 
+// ---- general kernel of the 49- / 65-tap rings (masks / NaNs, symmetric kernels; round 5) ---------------------------
+// The ring of spectral_conv_kernel with what 49 / 65 float64 numerators per lane leave room for (2 waves per SIMD):
+//   * the inputs of a revolution arrive in FOUR chunks (13 13 13 10 / 17 17 17 14 samples) through two alternating
+//     sets of staging registers - the chunk after the one being consumed is in flight, across the revolution boundary
+//     as well - instead of R staged samples + R mask bytes;
+//   * the validity history is 65 bits in three words; the denominator tables take 10 bits each (5 / 7 tables of
+//     1024 float64 sums: 40 / 56 KB, two blocks per CU);
+//   * the distinct taps (25 / 33 SGPR pairs) exist for symmetric kernels only: others stay with the runs-of-16 kernel.
+// Honours the tile flags of the all-valid ring pass.  Not fused.  Before: spectral_conv_wide_kernel, 13.5 / 16.1 ms per
+// 1024^3 at 49 / 65 taps (two FMAs per tap and voxel, a (ntaps - 1)-plane halo per run of 16).
+constexpr int kWideLutBits = 10;
+constexpr int wide_chunk(int R) { return (R + 3) / 4; }
+
+// 32 history bits starting at bit P (b0: bits 0..31, b1: 32..63, b2: 64..)
+template <int P>
+__device__ __forceinline__ unsigned hist_from(unsigned b0, unsigned b1, unsigned b2) {
+    if (P == 0) return b0;
+    if (P < 32) return __builtin_amdgcn_alignbit(b1, b0, P);
+    if (P == 32) return b1;
+    if (P < 64) return __builtin_amdgcn_alignbit(b2, b1, P - 32);
+    return b2;
+}
+
+template <int R, int T>
+__device__ __forceinline__ double wide_lut_term(const double* lut, unsigned b0, unsigned b1, unsigned b2) {
+    constexpr int LB = kWideLutBits, P = LB * T, bits = (R - P) < LB ? (R - P) : LB;
+    constexpr unsigned m = ((1u << bits) - 1u) << 3;
+    const unsigned off = (P >= 3) ? (hist_from<(P >= 3 ? P - 3 : 0)>(b0, b1, b2) & m) : ((b0 << 3) & m);
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(lut) + (T << LB) * 8 + off);
+}
+
+template <int R>
+__device__ __forceinline__ double wide_lut_den(const double* lut, unsigned b0, unsigned b1, unsigned b2) {
+    constexpr int NT = (R + kWideLutBits - 1) / kWideLutBits;
+    double den = wide_lut_term<R, 0>(lut, b0, b1, b2);
+    den += wide_lut_term<R, 1>(lut, b0, b1, b2);
+    den += wide_lut_term<R, 2>(lut, b0, b1, b2);
+    den += wide_lut_term<R, 3>(lut, b0, b1, b2);
+    den += wide_lut_term<R, 4>(lut, b0, b1, b2);
+    if (NT > 5) den += wide_lut_term<R, (NT > 5 ? 5 : 0)>(lut, b0, b1, b2);
+    if (NT > 6) den += wide_lut_term<R, (NT > 6 ? 6 : 0)>(lut, b0, b1, b2);
+    return den;
+}
+
+// loads of N samples starting at input channel ch0 (clamped into the cube: what lies outside is fixed up by the consumer)
+template <int G, int N, bool ARR>
+__device__ __forceinline__ void wide_load(const ConvArgs& A, float (&v)[G], unsigned (&mk)[G], int ch0, int nz, int voff, int moff,
+                                          int pbytes, int mbytes) {
+    const int pb = min(max(ch0, 0), nz - 1);
+    const auto rs = plane_srd(A.cube + (int64_t)pb * A.plane_stride);
+    const auto rm = plane_srd(ARR ? (const void*)(A.mask.arr + (int64_t)pb * A.mask.plane_stride) : (const void*)A.cube);
+    if (ch0 >= 0 && ch0 + N <= nz) {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)u * (unsigned)pbytes), /*nt*/ 2));
+            if (ARR) mk[u] = __builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)u * (unsigned)mbytes), 2);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < N; ++u) {
+            const int dz = min(max(ch0 + u, 0), nz - 1) - pb;
+            v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (int)((unsigned)dz * (unsigned)pbytes), /*nt*/ 2));
+            if (ARR) mk[u] = __builtin_amdgcn_raw_buffer_load_b8(rm, moff, (int)((unsigned)dz * (unsigned)mbytes), 2);
+        }
+    }
+}
+
+template <int R, bool ARR>
+__global__ __launch_bounds__(256, 2) void spectral_conv_ring_wide_kernel(const ConvArgs A) {
+    constexpr int H = R / 2, LB = kWideLutBits, NT = (R + LB - 1) / LB, G = wide_chunk(R), NC = 4;
+    static_assert(R > 40 && R <= 65 && G * (NC - 1) < R && NT >= 5 && NT <= 7, "49- and 65-tap rings");
+    __shared__ double lut[NT << LB];
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = (col < A.ny * A.nx) &&
+                      !(A.status && spc_flag_get(A.status + __builtin_amdgcn_readfirstlane((int)(min(col, A.ny * A.nx - 1) >> 7))) == 0);
+    if (!__syncthreads_or(live ? 1 : 0)) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        for (int w = threadIdx.x; w < (1 << LB); w += blockDim.x) {
+            double acc = 0.0;
+#pragma unroll
+            for (int b = 0; b < LB; ++b)
+                if (LB * t + b < R) acc += ((w >> b) & 1) ? 0.0 : A.k[(LB * t + b) <= H ? (LB * t + b) : 2 * H - (LB * t + b)];
+            lut[(t << LB) + w] = acc;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const int64_t y = col / A.nx, x = col - y * A.nx;
+    const int nz = (int)A.nz;
+    const int zb = (int)(blockIdx.y * A.zchunk);
+    const int ze = min(nz, zb + (int)A.zchunk);
+    const int voff_out = (int)((y * A.out_row_stride + x) * 4);
+    const float plim = A.pred_lim, plo = A.pred_lo, phi = A.pred_hi;
+    const int voff = (int)((y * A.row_stride + x) * 4);
+    const int moff = ARR ? (int)(y * A.mask.row_stride + x) : 0;
+    const int pbytes = (int)(A.plane_stride * 4), mbytes = ARR ? (int)A.mask.plane_stride : 0;
+    const int obytes = (int)(A.out_plane_stride * 4);
+    double num[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) num[m] = 0.0;
+    unsigned b0 = 0u, b1 = 0u, b2 = 0u;          // invalid bit of the last 65 inputs, bit 0 = newest
+    float va[G], vb[G];
+    unsigned ma[G], mb[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) { va[u] = 0.f; vb[u] = 0.f; ma[u] = 1u; mb[u] = 1u; }
+
+    const int T = (ze - zb) + 2 * H;
+    wide_load<G, G, ARR>(A, va, ma, zb - H, nz, voff, moff, pbytes, mbytes);
+    for (int t0 = 0; t0 < T; t0 += R) {
+        const int i0 = __builtin_amdgcn_readfirstlane(zb - H + t0);
+        const bool edge = (i0 < 0) || (i0 + R > nz);
+        const int ob = max(i0 - H, 0);
+        const auto ro = plane_srd((const void*)(A.out + (int64_t)ob * A.out_plane_stride));
+        const bool emit_all = (i0 - H >= zb) && (i0 + R - 1 - H < ze);
+#pragma unroll
+        for (int s = 0; s < R; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int c = s / G, u = s % G;
+            if (u == 0) {
+                // the chunk after this one: into the other set of staging registers
+                if (c == 0) wide_load<G, G, ARR>(A, vb, mb, i0 + G, nz, voff, moff, pbytes, mbytes);
+                else if (c == 1) wide_load<G, G, ARR>(A, va, ma, i0 + 2 * G, nz, voff, moff, pbytes, mbytes);
+                else if (c == 2) wide_load<G, R - 3 * G, ARR>(A, vb, mb, i0 + 3 * G, nz, voff, moff, pbytes, mbytes);
+                else if (t0 + R < T) wide_load<G, G, ARR>(A, va, ma, i0 + R, nz, voff, moff, pbytes, mbytes);
+            }
+            const float vs = (c & 1) ? vb[u] : va[u];
+            const bool arrbit = ARR ? (((c & 1) ? mb[u] : ma[u]) != 0) : true;
+            const bool ok = arrbit && (__builtin_fabsf(vs) <= plim) && !(vs <= plo) && !(vs >= phi);
+            float xs = ok ? vs : 0.f;
+            unsigned badbit = ok ? 0u : 1u;
+            if (edge) {
+                asm volatile("");
+                if (!((i0 + s >= 0) && (i0 + s < nz))) { badbit = 0u; xs = 0.f; }   // outside the cube: a valid zero
+            }
+            asm volatile("" : "+v"(xs));
+            const double xd = (double)xs;
+            if (R > 64) b2 = __builtin_amdgcn_alignbit(b2, b1, 31);
+            b1 = __builtin_amdgcn_alignbit(b1, b0, 31);
+            b0 = (b0 << 1) | badbit;
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+                const int a = (s - m + R) % R;
+                const int j = a <= H ? a : 2 * H - a;
+                if (a == 0) mul_w(num[m], A, j, xd);
+                else fma_w(num[m], A, j, xd);
+            }
+            const int e = (s + 1) % R;
+            const int o = i0 + s - H;
+            if (emit_all || (o >= zb && o < ze)) {
+                const unsigned anybad = (R > 64) ? (b0 | b1 | (b2 & 1u)) : (b0 | (b1 & (unsigned)((1ull << (R - 32)) - 1ull)));
+                float res;
+                if (!ARR && __all(anybad == 0u)) {
+                    res = (float)div_ksum(num[e], A);
+                    asm volatile("; whole kernel" : "+v"(res));
+                } else {
+                    res = (float)div_den(num[e], wide_lut_den<R>(lut, b0, b1, b2));
+                    asm volatile("; looked-up denominator" : "+v"(res));
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res), ro, voff_out, (int)((unsigned)(o - ob) * (unsigned)obytes), 0);
+            }
+        }
+    }
+}
+
+template <int R>
+int launch_ring_wide(const ConvArgs& A, hipStream_t st) {
+    const int64_t ncols = A.ny * A.nx;
+    const dim3 grid((unsigned)((ncols + 255) / 256), (unsigned)((A.nz + A.zchunk - 1) / A.zchunk)), block(256);
+    if (A.mask.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL((spectral_conv_ring_wide_kernel<R, true>), grid, block, 0, st, A);
+    else hipLaunchKernelGGL((spectral_conv_ring_wide_kernel<R, false>), grid, block, 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
 // ---- all-valid fast kernel ------------------------------------------------------------
 // Speculative first pass for data WITHOUT invalid samples (the common case: cubes whose
 // only NaNs are blanked edges): numerators only, out = num / sum(k) exactly like

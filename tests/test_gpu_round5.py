@@ -266,3 +266,58 @@ def test_split_form_takes_up_to_65_taps(gpu, stddev, taps):
     e0 = 1.5 * np.nansum(filled, axis=0)
     e0[np.all(np.isnan(filled), axis=0)] = np.nan             # nansum_allbadtonan
     assert_close(m0.get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="%d taps, moment 0" % taps)
+
+
+def _bit_level(out, exp, what):
+    assert out.dtype == np.float32 and exp.dtype == np.float32
+    assert np.array_equal(np.isnan(out), np.isnan(exp)), what
+    ok = np.isfinite(exp)
+    differ = out[ok] != exp[ok]
+    assert differ.mean() <= 1e-4, (what, int(differ.sum()))
+    if differ.any():
+        assert np.all(np.abs(out[ok][differ] - exp[ok][differ]) <= np.spacing(np.abs(exp[ok][differ]))), what
+
+
+@pytest.mark.parametrize("stddev, taps", [(4.5, 37), (5.0, 41), (6.0, 49), (7.0, 57), (8.0, 65)])
+@pytest.mark.parametrize("shape", [(300, 6, 70), (700, 4, 64), (40, 5, 9)])
+def test_masked_spectral_smooth_35_to_65_taps_bit_level(gpu, monkeypatch, stddev, taps, shape):
+    """Gaussian1DKernel(4.25 .. 8) on data with invalid samples: the general form of the 49- / 65-tap rings
+    (spectral_conv_ring_wide_kernel: float64 numerators, denominators looked up from 65 validity bits) must give astropy's
+    float32 results bit for bit like the 33-tap ring does, with and without a mask array / predicate terms, across z slices
+    (700 channels on a 4 x 64 map are split) and for rays shorter than the kernel; the runs-of-16 kernel it replaces agrees"""
+    k = Gaussian1DKernel(stddev).array
+    assert len(k) == taps
+    rng = np.random.default_rng(5)
+    d = (rng.standard_normal(shape) * 3 + 1).astype(np.float32)
+    d[3:5, 1, 1] = np.nan
+    d[:, 2, 3] = np.nan
+    inc = rng.random(shape) > 0.3
+    inc[10:10 + taps + 3, 3, 4] = False
+    inc[:, 0, 0] = False
+    mk = DeviceArray.from_numpy(inc.astype(np.uint8))
+    cube = DeviceArray.from_numpy(d)
+    for tag, m, spec in (("no mask", None, None), ("uint8 mask", inc, ops.MaskSpec(_lib.MASK_ARRAY, array=mk)),
+                         ("uint8 mask & data > -1", inc & (d > -1), ops.MaskSpec(_lib.MASK_ARRAY | _lib.MASK_GT, thr_lo=-1.0, array=mk))):
+        exp = O.spectral_smooth(d, m, k)
+        out = ops.spectral_conv(cube, k, mask=spec).get()
+        _bit_level(out, exp, "%d taps, %s" % (taps, tag))
+        monkeypatch.setenv("SPC_SPECTRAL_RING_WIDE", "0")
+        old = ops.spectral_conv(cube, k, mask=spec).get()
+        monkeypatch.delenv("SPC_SPECTRAL_RING_WIDE")
+        _bit_level(old, exp, "%d taps, %s, runs-of-16 kernel" % (taps, tag))
+
+
+def test_masked_spectral_smooth_wide_kernels_that_have_no_ring(gpu):
+    """asymmetric kernels and kernels with negative taps of 35 - 65 taps stay with the runs-of-16 kernel"""
+    rng = np.random.default_rng(8)
+    shape = (200, 5, 64)
+    d = rng.standard_normal(shape).astype(np.float32)
+    inc = rng.random(shape) > 0.3
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
+    asym = np.hanning(47)[1:-1] + np.linspace(0.01, 0.3, 45)
+    neg = Gaussian1DKernel(6.0).array - 0.3 * Gaussian1DKernel(3.0, x_size=49).array
+    neg[24] += 1.0
+    for k in (asym, neg):
+        exp = O.spectral_smooth(d, inc, k)
+        out = ops.spectral_conv(DeviceArray.from_numpy(d), k, mask=spec).get()
+        assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="wide kernel without a ring")
