@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 6
+#define SPC_ABI_VERSION 7
 
 typedef enum {
     SPC_OK = 0,
@@ -151,7 +151,8 @@ typedef enum {
     SPC_WS_MAP_CONV2D = 8,            /* spc_map_conv2d_f64, (ny,nx) = map, p0 = nky, p1 = nkx */
     SPC_WS_CLIP_OUTSIDE = 9,          /* spc_clip_outside_f32 */
     SPC_WS_PERCENTILE_GLOBAL = 10,    /* spc_percentile_global_f32 */
-    SPC_WS_SPATIAL_CONV_MFMA = 11     /* spc_spatial_conv_sep_mfma_f32 */
+    SPC_WS_SPATIAL_CONV_MFMA = 11,    /* spc_spatial_conv_sep_mfma_f32 */
+    SPC_WS_SIGMA_CLIP = 12            /* spc_sigma_clip_axis0_f32 (ABI 7) */
 } spc_ws_kind;
 size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 
@@ -359,10 +360,14 @@ int spc_fill_masked_f32(int device, void* stream, const spc_cube_f32* cube, cons
  * mad_std (1.4826 x the median of |x - median|, a second selection per iteration): the rays stay in
  * registers across the iterations, the cube is read once and the clipped copy written once (d_out: (nz,ny,nx)
  * C-contiguous float32; masked and clipped samples NaN).  maxiters < 0: until nothing changes.  Same arithmetic as
- * the pieces above (float64 sums, float32 centre and bounds).  Rays of more than 4096 channels: SPC_ERR_UNSUPPORTED. */
+ * the pieces above (float64 sums, float32 centre and bounds).  Rays of more than 4096 channels: SPC_ERR_UNSUPPORTED.
+ * (ABI 7) d_workspace / workspace_bytes: spc_workspace_bytes(SPC_WS_SIGMA_CLIP, nz, ny, nx, 0, 0) bytes of caller-owned
+ * scratch, or NULL / 0.  With it the kernel's block shape follows the mask (a probe counts the valid samples of 64 rays: rays
+ * of at most 128 valid samples - signal masks - are packed and clipped by one wave each, in blocks whose runs per plane are
+ * twice as wide); without it the shape is the one that suits dense rays. */
 int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                              double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
-                             int spread_is_mad, float* d_out);
+                             int spread_is_mad, float* d_out, void* d_workspace, size_t workspace_bytes);
 /* The include map of a mask evaluated on the cube it is bound to, as a uint8 (nz,ny,nx) array in
  * HBM: d_out = included ? 1 : 0 (MaskBase.include, masks.py:105-116).  For masks that belong to
  * ANOTHER cube's data - a smoothed cube keeps its parent's mask object (dask_spectral_cube.py:836-840):

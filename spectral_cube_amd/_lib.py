@@ -22,11 +22,11 @@ SPC_ERR_COMM = -5
 MASK_NONE, MASK_ARRAY, MASK_FINITE = 0, 1, 2
 MASK_GT, MASK_GE, MASK_LT, MASK_LE = 4, 8, 16, 32
 COMM_ID_BYTES = 128
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
- WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL, WS_SPATIAL_CONV_MFMA) = range(12)
+ WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL, WS_SPATIAL_CONV_MFMA, WS_SIGMA_CLIP) = range(13)
 
 
 class HipLibraryError(RuntimeError):
@@ -162,7 +162,7 @@ SIGNATURES = {
     "spc_percentile_axis2_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
     "spc_mask_include_u8": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp]),
     "spc_fill_masked_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _vp, _i64, _i64]),
-    "spc_sigma_clip_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _d, _i, _i, _i, _vp]),
+    "spc_sigma_clip_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _d, _i, _i, _i, _vp, _vp, _sz]),
     "spc_clip_outside_f32": (_i, [_i, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _P(C.c_uint64), _vp, _sz]),
     "spc_map_conv2d_f64": (_i, [_i, _vp, _vp, _i64, _i64, _P(_d), _i, _i, _vp, _vp, _sz]),
     "spc_map_arith_f64": (_i, [_i, _vp, _i, _vp, _vp, _vp, _d, _vp, _i64]),

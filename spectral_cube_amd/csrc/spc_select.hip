@@ -719,6 +719,69 @@ __device__ __forceinline__ float sel_value(uint32_t key_lo, uint32_t key_hi, dou
     return (float)(((median && a == bb) ? a : (frac == 0.5 ? 0.5 * (a + bb) : a + (bb - a) * frac)) * scale);
 }
 
+// ---- rays with few valid samples (round 5) ---------------------------------------------------------------
+// A signal mask (data > n sigma on narrow lines: the SURVEY's mask rule leaves 4 - 5 % of a cube) keeps a few dozen of a
+// ray's 1024 samples, yet every digit pass and every statistics sweep walked all KPL key registers of every lane.  When NO
+// ray of the block holds more than kCompactKeys x (lanes per ray) valid samples, the valid keys of a ray are packed into LDS -
+// in sample order: per-lane counts, an exclusive prefix over the lanes of the ray, every lane writes its keys behind its
+// prefix, so the packed order does not depend on scheduling - and dealt out again, kCompactKeys per lane; the descent and the
+// clip loop then run on those instead of on KPL registers.  The packed set holds the same keys: the selection is identical, the
+// clip loop's float64 sums are taken in another (fixed) order.
+constexpr int kCompactKeys = 8;
+template <int TS, int BT>
+struct SelCompact {
+    uint32_t keys[TS][kCompactKeys * (BT / TS)];       // a ray's valid keys in sample order
+    uint32_t sorted[TS][kCompactKeys * (BT / TS)];     // ... ascending (clip_packed_waves)
+    double ps[TS][BT / TS], pq[TS][BT / TS];           // lane partials of a ray's sums (clip_packed_waves)
+    int cnt[TS][BT / TS];
+    int tot[TS];
+    uint32_t win[TS][2];
+    int any_big;
+};
+template <int KPL, int TS, int BT>
+constexpr bool sel_compactable() { return KPL >= 4 * kCompactKeys && (BT / TS) >= 8; }
+
+// all threads of the block; true: ck holds this lane's share of the ray's n valid keys (block-uniform result)
+template <int TS, int KPL, int BT>
+__device__ __forceinline__ bool sel_compact(SelCompact<TS, BT>& Q, const uint32_t (&key)[KPL], int mine, int r, int j,
+                                            uint32_t (&ck)[kCompactKeys], int& n) {
+    constexpr int L = BT / TS, CAP = kCompactKeys * L;
+    Q.cnt[r][j] = mine;
+    if (threadIdx.x == 0) Q.any_big = 0;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll 4
+    for (int l = 0; l < L; ++l) {
+        const int c = Q.cnt[r][l];
+        base += (l < j) ? c : 0;
+        tot += c;
+    }
+    n = tot;
+    if (j == 0) Q.tot[r] = tot;
+    if (tot > CAP && j == 0) Q.any_big = 1;
+    __syncthreads();
+    if (Q.any_big) return false;
+    int idx = base;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        if (key[i] != 0xffffffffu) { Q.keys[r][idx] = key[i]; ++idx; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kCompactKeys; ++i) {
+        const int sidx = j + L * i;
+        ck[i] = sidx < tot ? Q.keys[r][sidx] : 0xffffffffu;
+    }
+    return true;
+}
+
+// (LDS traffic between the lanes of ONE wave: the LDS serves a wave's operations in order, the fence keeps the compiler
+//  from reordering them)
+__device__ __forceinline__ void sel_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int TS, int KPL, bool ARR, bool DESC, int BT = 256>
 __global__ __launch_bounds__(BT, BT == 256 ? (KPL == 128 ? 2 : 5) : (BT == 512 ? 4 : 1)) void select_reg_kernel(const SelArgs A) {
     __shared__ SelShared<TS> S;
@@ -783,6 +846,8 @@ struct ClipRegArgs {
     int spread_mad;             // spread: 0 std, 1 mad_std
     uint32_t key_min, key_span;            // sel_key_range of the mask's predicate terms (filled by the launcher)
     int xcd_group;              // tiles of a row kept on one XCD (sel_tile_of_block)
+    int compact;                // rays with few valid samples are packed (sel_compact; SPC_SELECT_COMPACT=0: off)
+    const int* probe;           // NULL, or the largest valid count among the sampled rays (clip_probe_kernel): which block shape runs
 };
 
 // |x - centre| of the samples inside the clip window (the MAD's keys)
@@ -795,30 +860,18 @@ struct KeyAbsDevWin {
     }
 };
 
-template <int TS, int KPL, bool ARR, bool MAD, bool DESC, int BT = 256>
-__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
-    __shared__ SelShared<TS> S;
-    __shared__ SelCache<TS> C;
+// the clip loop over one set of resident keys (all KPL registers of the lane, or its share of a packed sparse ray): narrows
+// the window [wlo, wlo + wspan) of the keys that are kept
+template <int TS, int KPL, bool MAD, int BT>
+__device__ __forceinline__ void clip_iterate(const ClipRegArgs& A, SelShared<TS>& S, SelCache<TS>& C, double (*part_s)[BT / TS],
+                                             double (*part_q)[BT / TS], uint32_t (&key)[KPL], int r, int j, uint32_t& wlo, uint32_t& wspan) {
     constexpr int kLanesPerRay = BT / TS;
-    __shared__ double part_s[TS][kLanesPerRay], part_q[TS][kLanesPerRay];
-    const int t = threadIdx.x;
-    const int r = t % TS, j = t / TS;
-    const int64_t tiles_x = (A.nx + TS - 1) / TS;
-    const int64_t tile = sel_tile_of_block(blockIdx.x, gridDim.x, A.xcd_group);
-    const int64_t y = tile / tiles_x, x0 = (tile % tiles_x) * TS;
-    const int nz = (int)A.nz;
-    const bool col_in = x0 + r < A.nx;
-    uint32_t key[KPL];
-    sel_load_keys<TS, KPL, ARR, DESC, BT>(A.cube, A.plane_stride, 1, y * A.row_stride + x0, A.mask.arr, A.mask.plane_stride, 1,
-                                ARR ? y * A.mask.row_stride + x0 : 0, col_in ? r : (int)(A.nx - 1 - x0), j, nz,
-                                col_in, A.key_min, A.key_span, false, 0.f, key);
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     // The keys stay as loaded.  Clipping v < lo || v > hi removes the two ENDS of a ray's sorted samples, so what is left
     // is a window of keys [wlo, wlo + wspan): an iteration counts and sums the samples inside it, asks the resident key
     // set for the rank (samples below the window) + (n - 1) / 2 - a descent that resumes from the cached bins of the
     // earlier iterations' descents, the median moving by a few ranks only (round 3a re-ran all four passes over keys it
     // had overwritten: 1.9 ms per iteration at 1024^3) - and narrows the window.
-    uint32_t wlo = 0u, wspan = 0xff800001u;                      // every valid key (the excluded one lies above)
     int n_prev = -1;
     bool cached = false;                                         // block-uniform: C holds an earlier iteration's descent
 #pragma unroll 1
@@ -921,6 +974,196 @@ __global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip
             wspan = nhi >= nlo ? nhi - nlo + 1u : 0u;
         }
     }
+}
+
+// The clip loop over PACKED rays (sel_compact: no ray of the block holds more than 128 valid samples), every wave on its own:
+// what an iteration costs on 8 keys per lane is not arithmetic but the block's rendezvous - ~20 barriers per iteration, three
+// LDS histogram rounds per digit pass: 0.75 ms per iteration at 1024^3 whether a lane walks 64 keys or 8.  With 16 lanes per ray
+// a wave takes four whole rays instead: it sorts each once (every lane ranks its <= 8 keys against the ray's, ties by sample
+// index - n^2 / 16 compares per lane, n ~ 50 under a signal mask), after which the median of any clip window is two LDS reads
+// (the window removes the two ends of the sorted keys), counts come from a 16-lane butterfly and the float64 sums from lane
+// partials added in a fixed order.  No barrier, no atomics, no descent; a wave stops when none of ITS rays changes.  The
+// arithmetic of the bounds is clip_iterate's (astropy's): the same windows up to the order of the float64 additions.
+// (its own function, not inlined: in line, the sort's registers on top of the 64 resident keys made the allocator spill 57 VGPRs and
+//  the DENSE loop of the same kernel went from 7.7 to 9.4 ms)
+struct ClipScalars { double lo_s, hi_s; int maxiters, cen_mean; };
+template <int TS, int BT>
+__device__ __attribute__((noinline)) void clip_packed_waves(const ClipScalars A, SelCompact<TS, BT> __attribute__((address_space(3)))* Qp) {
+    static_assert(BT / TS == 16, "16 lanes per ray: four rays per wave");
+    auto& Q = *Qp;                                                   // (an LDS pointer: ds_read / ds_write, not flat accesses)
+    constexpr int KC = kCompactKeys;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rr = 4 * w + (lane >> 4), jl = lane & 15;
+    const int n_all = Q.tot[rr];
+    const int nmax = max(max(__builtin_amdgcn_readlane(n_all, 0), __builtin_amdgcn_readlane(n_all, 16)),
+                         max(__builtin_amdgcn_readlane(n_all, 32), __builtin_amdgcn_readlane(n_all, 48)));
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    // ---- sort: position of a key = keys below it (ties: earlier samples first).  Candidates four at a time (one 16-byte LDS
+    // read), two reads in flight; slots past a ray's count compare as the largest key.
+    unsigned long long mine64[KC];
+    int pos[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+        const int idx = jl + 16 * i;
+        const uint32_t k = idx < n_all ? Q.keys[rr][idx] : 0xffffffffu;
+        mine64[i] = ((unsigned long long)k << 32) | (unsigned)idx;
+        pos[i] = 0;
+    }
+    const u32x4 __attribute__((address_space(3)))* cand = reinterpret_cast<const u32x4 __attribute__((address_space(3)))*>(&Q.keys[rr][0]);
+    for (int m0 = 0; m0 < nmax; m0 += 8) {
+        const u32x4 c0 = cand[m0 / 4], c1 = cand[m0 / 4 + 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = m0 + u;
+            const uint32_t raw = u < 4 ? c0[u & 3] : c1[u & 3];
+            const uint32_t o = m < n_all ? raw : 0xffffffffu;
+            const unsigned long long o64 = ((unsigned long long)o << 32) | (unsigned)m;
+#pragma unroll
+            for (int i = 0; i < KC; ++i)
+                if (16 * i < nmax) pos[i] += (o64 < mine64[i]) ? 1 : 0;      // (wave-uniform guard)
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KC; ++i)
+        if (jl + 16 * i < n_all) Q.sorted[rr][pos[i]] = (uint32_t)(mine64[i] >> 32);
+    sel_wave_sync();
+    uint32_t sk[KC];
+#pragma unroll
+    for (int i = 0; i < KC; ++i) sk[i] = (jl + 16 * i < n_all) ? Q.sorted[rr][jl + 16 * i] : 0xffffffffu;
+    // ---- iterate
+    uint32_t wlo = 0u, wspan = 0xff800001u;
+    int n_prev = -1;
+#pragma unroll 1
+    for (int it = 0; A.maxiters < 0 || it < A.maxiters; ++it) {
+        int cnt = 0, low = 0;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+            if (16 * i < nmax) {
+                const bool ok = (sk[i] - wlo) < wspan;
+                const double v = ok ? (double)funkey(sk[i]) : 0.0;
+                cnt += ok ? 1 : 0;
+                low += (sk[i] < wlo) ? 1 : 0;
+                s += v;
+                ss = fma(v, v, ss);
+            }
+        }
+        Q.ps[rr][jl] = s;
+        Q.pq[rr][jl] = ss;
+        int both = cnt | (low << 16);                                   // (<= 128 each)
+        both += __builtin_amdgcn_ds_swizzle(both, 0x041f);               // butterfly over the 16 lanes of the ray: xor 1, 2, 4, 8
+        both += __builtin_amdgcn_ds_swizzle(both, 0x081f);
+        both += __builtin_amdgcn_ds_swizzle(both, 0x101f);
+        both += __builtin_amdgcn_ds_swizzle(both, 0x201f);
+        sel_wave_sync();
+        double sum = 0.0, ssq = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) { sum += Q.ps[rr][l]; ssq += Q.pq[rr][l]; }
+        sel_wave_sync();
+        const int n = both & 0xffff, nl = both >> 16;
+        if (it > 0 && __builtin_amdgcn_ballot_w64(n != n_prev) == 0ull) break;    // none of this wave's rays lost a sample
+        n_prev = n;
+        double mean = nan, sd = nan;
+        if (n > 0) {
+            mean = sum / (double)n;
+            const double var = __dsub_rn(ssq / (double)n, __dmul_rn(mean, mean));
+            sd = (var != var) ? nan : sqrt(var > 0.0 ? var : 0.0);
+        }
+        double cen = mean;
+        if (!A.cen_mean) {
+            float med = NAN;
+            if (n > 0) {
+                const double p = 0.5 * (double)(n - 1), fl = floor(p);
+                const uint32_t key_lo = Q.sorted[rr][nl + (int)fl], key_hi = Q.sorted[rr][nl + min((int)ceil(p), n - 1)];
+                med = sel_value(key_lo, key_hi, p - fl, 1.0);
+            }
+            cen = (double)med;
+        }
+        const float lo = (float)__dsub_rn(cen, __dmul_rn(A.lo_s, sd));
+        const float hi = (float)__dadd_rn(cen, __dmul_rn(A.hi_s, sd));
+        if (wspan != 0u) {
+            const uint32_t klo = (lo == lo) ? fkey(lo == 0.f ? -0.f : lo) : 0u;
+            const uint32_t khi = (hi == hi) ? fkey(hi == 0.f ? 0.f : hi) : 0xff800000u;
+            const uint32_t nlo = max(wlo, klo), nhi = min(wlo + (wspan - 1u), khi);
+            wlo = nlo;
+            wspan = nhi >= nlo ? nhi - nlo + 1u : 0u;
+        }
+    }
+    if (jl == 0) { Q.win[rr][0] = wlo; Q.win[rr][1] = wspan; }
+}
+
+// Which block shape suits the cube is a property of its mask: packed rays (<= 128 valid samples each) iterate for free, so the
+// 512-thread blocks' wider runs per plane win (read + write floor 2.4 against 3.3 ms at 1024^3); rays that stay in the registers
+// iterate faster in 256-thread blocks.  The host cannot know without waiting for the device: a probe kernel counts the valid
+// samples of 64 rays spread over the map and leaves the largest count in the caller's workspace, BOTH shapes are launched, and
+// the blocks of the one the count does not select retire at once (an empty grid of 65536 blocks: ~20 us).
+constexpr int kProbeRays = 64, kProbeSparse = 96;
+template <bool ARR>
+__global__ __launch_bounds__(256) void clip_probe_kernel(const ClipRegArgs A, int* d_max) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const int64_t nsp = A.ny * A.nx;
+    const int64_t sp = min(nsp - 1, (int64_t)blockIdx.x * (nsp / kProbeRays) + nsp / (2 * kProbeRays));
+    const int64_t y = sp / A.nx, x = sp - y * A.nx;
+    int c = 0;
+    for (int64_t z = threadIdx.x; z < A.nz; z += 256) {
+        const uint32_t k = fkey_bits(__float_as_uint(A.cube[z * A.plane_stride + y * A.row_stride + x]));
+        bool ok = (k - A.key_min) < A.key_span;
+        if (ARR) ok = ok && A.mask.arr[z * A.mask.plane_stride + y * A.mask.row_stride + x] != 0;
+        c += ok ? 1 : 0;
+    }
+    if (c) atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(d_max, total);
+}
+
+template <int TS, int KPL, bool ARR, bool MAD, bool DESC, int BT = 256>
+__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+    if (A.probe != nullptr && ((*A.probe <= kProbeSparse) != (BT == 512))) return;   // the other block shape runs this cube
+    __shared__ SelShared<TS> S;
+    __shared__ SelCache<TS> C;
+    constexpr int kLanesPerRay = BT / TS;
+    __shared__ double part_s[TS][kLanesPerRay], part_q[TS][kLanesPerRay];
+    const int t = threadIdx.x;
+    const int r = t % TS, j = t / TS;
+    const int64_t tiles_x = (A.nx + TS - 1) / TS;
+    const int64_t tile = sel_tile_of_block(blockIdx.x, gridDim.x, A.xcd_group);
+    const int64_t y = tile / tiles_x, x0 = (tile % tiles_x) * TS;
+    const int nz = (int)A.nz;
+    const bool col_in = x0 + r < A.nx;
+    uint32_t key[KPL];
+    const int mine = sel_load_keys<TS, KPL, ARR, DESC, BT>(A.cube, A.plane_stride, 1, y * A.row_stride + x0, A.mask.arr, A.mask.plane_stride, 1,
+                                ARR ? y * A.mask.row_stride + x0 : 0, col_in ? r : (int)(A.nx - 1 - x0), j, nz,
+                                col_in, A.key_min, A.key_span, false, 0.f, key);
+    uint32_t wlo = 0u, wspan = 0xff800001u;                      // every valid key (the excluded one lies above)
+    bool packed = false;
+    if constexpr (sel_compactable<KPL, TS, BT>()) {
+        // (a probe that met a ray of more than 128 valid samples: a dense cube, whose blocks need not even ask)
+        if (A.compact && (A.probe == nullptr || *A.probe <= kCompactKeys * (BT / TS))) {
+            __shared__ SelCompact<TS, BT> Q;
+            uint32_t ck[kCompactKeys];
+            int nc = 0;
+            packed = sel_compact<TS, KPL, BT>(Q, key, mine, r, j, ck, nc);
+            if (packed) {
+                if constexpr (!MAD && BT / TS == 16) {
+                    if (A.compact >= 2) {
+                        clip_packed_waves<TS, BT>(ClipScalars{A.lo_s, A.hi_s, A.maxiters, A.cen_mean}, (SelCompact<TS, BT> __attribute__((address_space(3)))*)&Q);
+                        __syncthreads();
+                        wlo = Q.win[r][0];
+                        wspan = Q.win[r][1];
+                    } else {
+                        clip_iterate<TS, kCompactKeys, MAD, BT>(A, S, C, part_s, part_q, ck, r, j, wlo, wspan);
+                    }
+                } else {
+                    clip_iterate<TS, kCompactKeys, MAD, BT>(A, S, C, part_s, part_q, ck, r, j, wlo, wspan);
+                }
+            }
+        }
+    }
+    if (!packed) clip_iterate<TS, KPL, MAD, BT>(A, S, C, part_s, part_q, key, r, j, wlo, wspan);
+    (void)mine;
     // ---- the clipped rays, written once
     if (col_in) {
         float* q = A.out + y * A.nx + x0 + r + (int64_t)j * A.ny * A.nx;
@@ -1285,7 +1528,7 @@ extern "C" int spc_percentile_axis2_f32(int device, void* stream, const spc_cube
 // caller iterates spc_percentile_axis0_f32 / spc_stats_axis_f32 / spc_clip_outside_f32 instead).
 extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
                                         double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
-                                        int spread_is_mad, float* d_out) {
+                                        int spread_is_mad, float* d_out, void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube_any_order(cube);
     if (rc) return rc;
     SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
@@ -1308,6 +1551,7 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
     //  for its neighbour.  1024^3: the clip kernel's read + write floor 4.21 -> 3.28 ms, the 256-thread selection 2.97 -> 2.65 ms;
     //  groups of 2 / 4 / 8: 3.95 / 3.54 / 3.32 - 3.6 ms; no effect on the 512-thread selection.  SPC_XCD_GROUP=0: block = tile)
     { const char* xg = getenv("SPC_XCD_GROUP"); A.xcd_group = xg ? atoi(xg) : 16; }
+    { const char* ce = getenv("SPC_SELECT_COMPACT"); A.compact = ce ? atoi(ce) : 2; }   // 0: off, 1: packed rays through the block's loop, 2: every wave on its own
     const bool arr = (A.mask.flags & SPC_MASK_ARRAY) != 0;
     hipStream_t st = (hipStream_t)stream;
     // 256-thread blocks for the median forms: with 512 threads (wider runs per plane, see spc_percentile_axis0_f32) the read +
@@ -1319,13 +1563,23 @@ extern "C" int spc_sigma_clip_axis0_f32(int device, void* stream, const spc_cube
         const char* be = getenv("SPC_SIGMA_BT");
         const int force = be ? atoi(be) : 0;
         const bool wide = force == 512 || (force != 256 && (A.cen_mean || A.maxiters == 1));
-        if (wide && cube->nz > 512 && cube->nz <= 1024 && !A.spread_mad &&
-            sel_desc_fits(32, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1, 512)) {
+        const bool wide_ok = cube->nz > 512 && cube->nz <= 1024 && !A.spread_mad &&
+                             sel_desc_fits(32, std::max(cube->plane_stride, arr ? A.mask.plane_stride : 0), 1, 512);
+        // neither forced nor decided by the form: the mask decides (clip_probe_kernel), given a workspace word to decide in
+        if (!wide && wide_ok && force == 0 && A.compact >= 2 && d_workspace != nullptr && workspace_bytes >= sizeof(int) &&
+            cube->ny * cube->nx >= 4 * kProbeRays && spc_env_on("SPC_SIGMA_PROBE")) {
+            int* d_max = static_cast<int*>(d_workspace);
+            SPC_HIP(hipMemsetAsync(d_max, 0, sizeof(int), st));
+            if (arr) hipLaunchKernelGGL(clip_probe_kernel<true>, dim3(kProbeRays), dim3(256), 0, st, A, d_max);
+            else hipLaunchKernelGGL(clip_probe_kernel<false>, dim3(kProbeRays), dim3(256), 0, st, A, d_max);
+            A.probe = d_max;
+        }
+        if ((wide || A.probe != nullptr) && wide_ok) {
             dim3 grid2((unsigned)(cube->ny * ((cube->nx + 31) / 32)));
             if (arr) hipLaunchKernelGGL((sigma_clip_reg_kernel<32, 64, true, false, true, 512>), grid2, dim3(512), 0, st, A);
             else hipLaunchKernelGGL((sigma_clip_reg_kernel<32, 64, false, false, true, 512>), grid2, dim3(512), 0, st, A);
             SPC_LAUNCH_CHECK();
-            return SPC_OK;
+            if (A.probe == nullptr) return SPC_OK;
         }
     }
     // short rays: few lanes per ray (see spc_percentile_axis0_f32): 2 for 65 .. 128 samples, 4 up to 256
@@ -1426,6 +1680,8 @@ extern "C" int spc_key_histogram_f32(int device, void* stream, const spc_cube_f3
     SPC_HIP(e);
     return SPC_OK;
 }
+
+size_t spc_ws_sigma_clip(void) { return 256; }
 
 extern "C" float spc_key_to_f32(uint32_t key) {
     const uint32_t u = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;

@@ -793,10 +793,11 @@ def sigma_clip_axis0(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxite
     if cube.shape[0] <= 4096 and os.environ.get("SPC_SIGMA_CLIP_FUSED", "1") != "0":
         out = DeviceArray(cube.shape, np.float32, cube.device)
         c, m = _cube_c(cube), _mask_c(mask, cube)
+        ws, wsn = workspace(cube.device, stream, _lib.WS_SIGMA_CLIP, *cube.shape)
         try:
             _lib.call("spc_sigma_clip_axis0_f32", cube.device, _sh(stream), C.byref(c), C.byref(m), float(lo_s), float(hi_s),
                       -1 if maxiters is None else int(maxiters), 1 if cenfunc == "mean" else 0, 1 if stdfunc == "mad_std" else 0,
-                      C.c_void_p(out.ptr))
+                      C.c_void_p(out.ptr), ws, wsn)
             return out
         except _lib.HipUnsupported:
             del out                    # planes beyond what the register-resident kernel addresses: the loop of kernels below

@@ -321,3 +321,73 @@ def test_masked_spectral_smooth_wide_kernels_that_have_no_ring(gpu):
         exp = O.spectral_smooth(d, inc, k)
         out = ops.spectral_conv(DeviceArray.from_numpy(d), k, mask=spec).get()
         assert_close(out, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="wide kernel without a ring")
+
+
+def _clip_case(nz, ny, nx, seed, counts):
+    """rays whose number of valid samples is prescribed per spaxel (counts: (ny, nx) ints), Gaussian noise + outliers"""
+    rng = np.random.default_rng(seed)
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[rng.random((nz, ny, nx)) < 0.03] *= 12.0                      # outliers for the clip to find
+    inc = np.zeros((nz, ny, nx), bool)
+    for y in range(ny):
+        for x in range(nx):
+            inc[rng.permutation(nz)[:counts[y, x]], y, x] = True
+    return d, inc
+
+
+@pytest.mark.parametrize("cen", ["median", "mean"])
+def test_sigma_clip_packed_rays_against_the_oracle_and_the_unpacked_kernel(gpu, monkeypatch, cen):
+    """rays of at most 128 valid samples are packed and clipped by one wave each (clip_packed_waves): 0, 1, 2, 3 valid samples,
+    exactly 128, ties (quantised data), even and odd counts; one block that holds a ray of 129 takes the loop over the registers"""
+    nz, ny, nx = 1024, 4, 64
+    rng = np.random.default_rng(3)
+    counts = rng.integers(20, 90, size=(ny, nx))
+    counts[0, :6] = (0, 1, 2, 3, 128, 127)
+    counts[2, 40] = 129                                             # its block of 16 / 32 spaxels cannot pack
+    d, inc = _clip_case(nz, ny, nx, 17, counts)
+    d[:, 1, :] = np.round(d[:, 1, :] * 2) / 2                       # many equal samples
+    cube, mk = _dev(d, inc)
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=mk)
+    exp = O.sigma_clip(d, inc, 3.0, cenfunc=cen)
+    res = {}
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("SPC_SELECT_COMPACT", mode)
+        res[mode] = ops.sigma_clip_axis0(cube, sigma=3.0, mask=spec, cenfunc=cen).get()
+    monkeypatch.delenv("SPC_SELECT_COMPACT")
+
+    def same(a, b, what):
+        # (the float64 sums of a packed ray are taken in another order: a float32 bound may land on the neighbouring value)
+        assert np.mean(np.isnan(a) != np.isnan(b)) < 2e-4, what
+        both = ~np.isnan(a) & ~np.isnan(b)
+        assert np.array_equal(a[both], b[both]), what
+    for mode in ("2", "1"):
+        same(res[mode], res["0"], "packing mode %s against the loop over the registers" % mode)
+    same(res["2"], exp, "packed rays against the oracle")
+    # rays the clip must not touch: nothing valid / one / two samples
+    assert np.all(np.isnan(res["2"][:, 0, 0])) and np.sum(~np.isnan(res["2"][:, 0, 1])) == 1 and np.sum(~np.isnan(res["2"][:, 0, 2])) == 2
+    # and from launch to launch
+    for _ in range(3):
+        again = ops.sigma_clip_axis0(cube, sigma=3.0, mask=spec, cenfunc=cen).get()
+        assert np.array_equal(again, res["2"], equal_nan=True)
+
+
+def test_sigma_clip_block_shape_follows_the_mask(gpu, monkeypatch):
+    """with a workspace the entry point probes 64 rays and launches both block shapes (ABI 7): sparse and dense masks must give
+    what the fixed shape gives (SPC_SIGMA_PROBE=0), at a map large enough for the probe (>= 256 spaxels)"""
+    nz, ny, nx = 700, 8, 64
+    for frac, seed in ((0.05, 1), (0.8, 2)):
+        rng = np.random.default_rng(seed)
+        d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+        d[rng.random((nz, ny, nx)) < 0.02] += 9.0
+        inc = rng.random((nz, ny, nx)) < frac
+        cube, mk = _dev(d, inc)
+        spec = ops.MaskSpec(_lib.MASK_ARRAY, array=mk)
+        got = ops.sigma_clip_axis0(cube, sigma=3.0, mask=spec).get()
+        monkeypatch.setenv("SPC_SIGMA_PROBE", "0")
+        ref = ops.sigma_clip_axis0(cube, sigma=3.0, mask=spec).get()
+        monkeypatch.delenv("SPC_SIGMA_PROBE")
+        assert np.array_equal(got, ref, equal_nan=True), frac
+        exp = O.sigma_clip(d, inc, 3.0)
+        assert np.mean(np.isnan(got) != np.isnan(exp)) < 2e-4
+        both = ~np.isnan(got) & ~np.isnan(exp)
+        assert np.array_equal(got[both], exp[both])
