@@ -143,4 +143,95 @@ for it in range(max(nround // 5, 2)):
     k = np.abs(rng.standard_normal(nt)) + 0.05
     if rng.random() < 0.5: k = k + k[::-1]
     close(ops.spectral_conv(dd, k, mask=spec).get(), O.spectral_smooth(d, inc, k), 1e-5, tag + " sconv%d" % nt)
+
+# round-5 kernels: the split form of the masked spatial stencil (3 / 5 Toeplitz blocks, cube -> cube, fused moment 0 and
+# moments 0 / 1 / 2), the wide masked spectral rings (35 - 65 taps) and the packed rays of the sigma clip
+def gauss(nt, sig):
+    x = np.arange(nt) - nt // 2
+    g = np.exp(-0.5 * (x / sig) ** 2)
+    return g / g.sum()
+
+for it in range(max(nround // 2, 3)):
+    nz, ny, nx = int(rng.integers(1, 7)), int(rng.integers(1, 330)), int(rng.integers(1, 420))
+    if rng.random() < 0.75: nx = 4 * int(rng.integers(1, 110))           # the split form wants 16-byte rows
+    d = (rng.standard_normal((nz, ny, nx)) * float(rng.choice([1e-3, 1.0, 3e4])) + float(rng.choice([0.0, 2.0]))).astype(np.float32)
+    if rng.random() < 0.5: d[rng.random(d.shape) < 0.01] = np.nan
+    if rng.random() < 0.3: d[rng.random(d.shape) < 1e-3] *= 1e4
+    dens = float(rng.choice([0.03, 0.5, 0.8, 1.0]))
+    inc = rng.random(d.shape) < dens
+    if rng.random() < 0.3: inc[:, : ny // 2] = False                     # dead regions: empty windows
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=dev(inc.astype(np.uint8)))
+    inc_f = inc & np.isfinite(d)
+    nt = int(rng.choice([3, 9, 17, 29, 31, 33, 35, 41, 49, 57, 65]))
+    g = gauss(nt, nt / 6.0 + rng.uniform(0, 2)); k2 = np.outer(g, g)
+    tag = "split%d %s taps%d dens%.2f" % (it, (nz, ny, nx), nt, dens)
+    dd = dev(d)
+    exp = O.spatial_smooth(d, inc, k2)
+    close(ops.spatial_conv(dd, k2, mask=spec).get(), exp, 1e-5, tag + " spatial_conv")
+    cen = np.cumsum(rng.uniform(0.5, 1.5, nz)); cref = cen[nz // 2]
+    try:
+        oc, m0 = ops.spatial_conv_mfma(dd, k2, mask=spec, want_cube=True, want_m0=True, dv=1.3)
+        close(oc.get(), exp, 1e-5, tag + " mfma cube")
+        scale = np.nanmax(np.abs(exp)) if np.isfinite(exp).any() else 1.0
+        e0 = O.moment(exp, inc, 0, cen, 1.3)
+        g0 = m0.get()
+        if (np.isnan(g0) != np.isnan(e0)).any() or (np.isfinite(e0).any() and np.nanmax(np.abs(g0 - e0)) > 1e-5 * scale * 1.3 * nz):
+            fails += 1; print("FAIL", tag, "fused m0", int((np.isnan(g0) != np.isnan(e0)).sum()), flush=True)
+        _, mm = ops.spatial_conv_mfma_moments(dd, k2, dev(cen - cref), dv=1.3, m1_add=cref, mask=spec, want=("m0", "m1", "m2"))
+        g0b = mm["m0"].get()
+        if (np.isnan(g0b) != np.isnan(e0)).any() or (np.isfinite(e0).any() and np.nanmax(np.abs(g0b - e0)) > 1e-5 * scale * 1.3 * nz):
+            fails += 1; print("FAIL", tag, "fused m012: m0", flush=True)
+        e1 = O.moment(exp, inc, 1, cen, 1.3)
+        okm = np.isfinite(e1) & (np.abs(e0) > 1e-2 * np.nanmax(np.abs(e0)))
+        g1 = mm["m1"].get()
+        if okm.any() and np.max(np.abs(g1[okm] - e1[okm])) > 1e-3 * (cen[-1] - cen[0] + 1.0):
+            fails += 1; print("FAIL", tag, "fused m012: m1", float(np.max(np.abs(g1[okm] - e1[okm]))), flush=True)
+    except _lib.HipUnsupported as e:
+        print("(unsupported)", tag, str(e)[:80], flush=True)
+
+for it in range(max(nround // 2, 3)):
+    nz, ny, nx = int(rng.integers(40, 400)), int(rng.integers(1, 9)), int(rng.integers(1, 700))
+    d = (rng.standard_normal((nz, ny, nx)) * 2 + float(rng.choice([0.0, 5.0]))).astype(np.float32)
+    if rng.random() < 0.5: d[rng.random(d.shape) < 0.01] = np.nan
+    dens = float(rng.choice([0.03, 0.5, 0.8, 1.0]))
+    inc = rng.random(d.shape) < dens
+    if rng.random() < 0.3: inc[nz // 3: nz // 3 + 80] = False
+    kind = int(rng.integers(0, 3))
+    if kind == 0: spec = ops.MaskSpec(_lib.MASK_ARRAY, array=dev(inc.astype(np.uint8)))
+    elif kind == 1: inc = None; spec = None
+    else: inc = (d > 0.5) & np.isfinite(d); spec = ops.MaskSpec(_lib.MASK_GT | _lib.MASK_FINITE, 0.5)
+    nt = int(rng.choice([35, 37, 41, 47, 49, 51, 57, 63, 65, 67, 81]))
+    k = gauss(nt, nt / 6.0 + rng.uniform(0, 3))
+    if rng.random() < 0.15: k = np.abs(rng.standard_normal(nt)) + 0.05      # asymmetric: the runs-of-16 kernel
+    tag = "wide%d %s taps%d kind%d" % (it, (nz, ny, nx), nt, kind)
+    got = ops.spectral_conv(dev(d), k, mask=spec).get()
+    exp64 = O.spectral_smooth(d, inc, k)
+    close(got, exp64, 1e-6, tag + " sconv")
+
+for it in range(max(nround // 2, 3)):
+    nz, ny, nx = int(rng.integers(200, 2100)), int(rng.integers(1, 5)), int(rng.integers(1, 200))
+    d = (rng.standard_normal((nz, ny, nx)) * 2).astype(np.float32)
+    d[rng.random(d.shape) < 0.03] *= 9.0
+    if rng.random() < 0.5: d = np.round(d * 2) / 2
+    dens = float(rng.choice([0.0, 0.005, 0.03, 0.06, 0.12]))
+    inc = rng.random(d.shape) < dens
+    if rng.random() < 0.3: inc[:, 0, : max(nx // 8, 1)] = rng.random((nz, max(nx // 8, 1))) < 0.5   # a few dense rays among the sparse
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=dev(inc.astype(np.uint8)))
+    tag = "packed%d %s dens%.3f" % (it, (nz, ny, nx), dens)
+    dd = dev(d)
+    kw = dict(sigma=float(rng.uniform(1.2, 3.5)), maxiters=[1, 3, 5, None][int(rng.integers(0, 4))], cenfunc=str(rng.choice(["median", "mean"])),
+              stdfunc=str(rng.choice(["std", "mad_std"])))
+    got = ops.sigma_clip_axis0(dd, mask=spec, **kw).get()
+    os.environ["SPC_SIGMA_CLIP_FUSED"] = "0"
+    ref = ops.sigma_clip_axis0(dd, mask=spec, **kw).get()
+    os.environ.pop("SPC_SIGMA_CLIP_FUSED")
+    nd = int((np.isnan(got) != np.isnan(ref)).sum())
+    if nd > 2e-4 * got.size or not np.array_equal(got[~np.isnan(got) & ~np.isnan(ref)], ref[~np.isnan(got) & ~np.isnan(ref)]):
+        fails += 1; print("FAIL", tag, "sigma_clip fused != loop", kw, nd, flush=True)
+    eo = O.sigma_clip(d, inc & ~np.isnan(d), **kw)
+    if np.mean(np.isnan(got) != np.isnan(eo)) > 5e-4: fails += 1; print("FAIL", tag, "sigma_clip vs oracle", kw, float(np.mean(np.isnan(got) != np.isnan(eo))), flush=True)
+    fz = np.where(inc, d, np.nan).astype(np.float32)
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        close(ops.percentile_axis0(dd, 50.0, mask=spec).get(), np.nanmedian(fz, axis=0), 0.0, tag + " median")
 print("rounds", nround, "failures", fails)
