@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPC_ABI_VERSION 7
+#define SPC_ABI_VERSION 8
 
 typedef enum {
     SPC_OK = 0,
@@ -152,7 +152,8 @@ typedef enum {
     SPC_WS_CLIP_OUTSIDE = 9,          /* spc_clip_outside_f32 */
     SPC_WS_PERCENTILE_GLOBAL = 10,    /* spc_percentile_global_f32 */
     SPC_WS_SPATIAL_CONV_MFMA = 11,    /* spc_spatial_conv_sep_mfma_f32 */
-    SPC_WS_SIGMA_CLIP = 12            /* spc_sigma_clip_axis0_f32 (ABI 7) */
+    SPC_WS_SIGMA_CLIP = 12,           /* spc_sigma_clip_axis0_f32 (ABI 7) */
+    SPC_WS_RESAMPLE_BILINEAR_LERP = 13 /* spc_resample_bilinear_lerp_f32, nz = INPUT channels, p0 = ny_out, p1 = nx_out (ABI 8) */
 } spc_ws_kind;
 size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 
@@ -574,6 +575,28 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
                               int64_t out_plane_stride, uint8_t* d_footprint,
                               int order, uint32_t* d_any_valid,
                               void* d_workspace, size_t workspace_bytes);
+
+/* spatial resample with the spectral interpolation folded in (ABI 8): ONE pass for what the reference does as
+ * spectral_interpolate (dask_spectral_cube.py:1342-1353) followed by reproject (spectral_cube.py:2700-2732), and for
+ * reproject onto a cube header whose spectral axis differs from the cube's (reproject_interp's single trilinear call for
+ * a separable WCS, spectral_cube.py:2726-2732).  Output channel j (nz_out of them) is
+ *   out[j] = (R[lo+1] - R[lo]) * d_inv_dx[j] * d_t[j] + R[lo],   lo = d_lo[j],
+ * where R[k] is input channel k resampled exactly as spc_resample_bilinear_f32 does (mask, fill, order, footprint as there)
+ * and the blend is spc_spectral_lerp_f32's arithmetic - both operators are linear interpolations with NaN propagation,
+ * so they commute: a value is NaN iff one of its eight source samples is excluded / NaN or the pixel lies outside the
+ * footprint, as in the two-pass form; finite values agree with it to float32 rounding (each input plane is read and
+ * resampled ONCE, nz instead of nz_out gathers, and the intermediate cube is never written).  d_lo[j] < 0 marks channels
+ * outside the input range (NaN planes).  Precondition: the non-negative entries of d_lo ascend and are contiguous in j
+ * (an ascending output grid on ascending input channels; the host flips / falls back otherwise); cube->nz >= 2.
+ * Workspace: spc_workspace_bytes(SPC_WS_RESAMPLE_BILINEAR_LERP, nz, ny, nx, ny_out, nx_out). */
+int spc_resample_bilinear_lerp_f32(int device, void* stream, const spc_cube_f32* cube,
+                                   const spc_mask* mask, float fill, int64_t ny_out,
+                                   int64_t nx_out, const double* d_xs, const double* d_ys,
+                                   int64_t nz_out, const int32_t* d_lo, const double* d_t,
+                                   const double* d_inv_dx, float* d_out, int64_t out_row_stride,
+                                   int64_t out_plane_stride, uint8_t* d_footprint,
+                                   int order, uint32_t* d_any_valid,
+                                   void* d_workspace, size_t workspace_bytes);
 
 /* spline resample: reproject_interp(order='biquadratic' | 'bicubic') for channels that map onto themselves
  * (spectral_cube.py:2667-2676 documents the orders; :2726-2732 is the call).  order 2 / 3 =

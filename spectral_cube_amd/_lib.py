@@ -22,11 +22,12 @@ SPC_ERR_COMM = -5
 MASK_NONE, MASK_ARRAY, MASK_FINITE = 0, 1, 2
 MASK_GT, MASK_GE, MASK_LT, MASK_LE = 4, 8, 16, 32
 COMM_ID_BYTES = 128
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
- WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL, WS_SPATIAL_CONV_MFMA, WS_SIGMA_CLIP) = range(13)
+ WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL, WS_SPATIAL_CONV_MFMA, WS_SIGMA_CLIP,
+ WS_RESAMPLE_BILINEAR_LERP) = range(14)
 
 
 class HipLibraryError(RuntimeError):
@@ -158,6 +159,8 @@ SIGNATURES = {
                                    _vp, _i64, _i64]),
     "spc_resample_bilinear_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _i64, _i64, _vp, _vp,
                                        _vp, _i64, _i64, _vp, _i, _vp, _vp, _sz]),
+    "spc_resample_bilinear_lerp_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _f, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
+                                            _vp, _i64, _i64, _vp, _i, _vp, _vp, _sz]),
     "spc_percentile_axis0_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
     "spc_percentile_axis2_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _d, _vp, _f, _vp]),
     "spc_mask_include_u8": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp]),

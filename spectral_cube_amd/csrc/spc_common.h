@@ -98,6 +98,7 @@ size_t spc_ws_spectral_conv(int64_t nz, int64_t ny, int64_t nx, int64_t ntaps, b
 size_t spc_ws_spatial_conv_sep(int64_t nz, int64_t ny, int64_t nx, int64_t nky, int64_t nkx);
 size_t spc_ws_spatial_conv2d(int64_t nz, int64_t ny, int64_t nx, int64_t nky, int64_t nkx);
 size_t spc_ws_resample_bilinear(int64_t ny_out, int64_t nx_out);
+size_t spc_ws_resample_bilinear_lerp(int64_t nz, int64_t ny_out, int64_t nx_out);
 size_t spc_ws_stats(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 size_t spc_ws_percentile_global(void);
 size_t spc_ws_sigma_clip(void);

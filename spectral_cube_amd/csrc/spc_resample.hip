@@ -199,11 +199,45 @@ struct BilArgs {
     int64_t zchunk_lds;
     int nearest;               // order 0: the nearest sample alone (scipy map_coordinates order=0)
     unsigned int* any_valid;   // optional device word: set to 1 by a block that wrote a non-NaN value
+    // LERP (spc_resample_bilinear_lerp_f32): the spectral interpolation folded in.  Output channel j is the linear blend of the
+    // RESAMPLED input planes lo[j] and lo[j] + 1 (spectral_lerp_kernel's arithmetic); jfirst[z] = the first output channel
+    // whose left bracket is >= z (jfirst[0] = j_begin, jfirst[nz - 1] = j_end: lerp_index_kernel), channels outside
+    // [j_begin, j_end) have lo < 0 and are NaN planes.
+    int64_t nz_out;
+    const int32_t* lo;
+    const double* t;
+    const double* inv_dx;
+    const int32_t* jfirst;     // nz entries
 };
+
+// jfirst[] of a lerp plan whose non-negative lo[] ascend (one block; nz and nz_out are a few thousand)
+__global__ __launch_bounds__(256) void lerp_index_kernel(const int32_t* lo, int nz_out, int nz, int32_t* jfirst) {
+    __shared__ int s_ja, s_jb;
+    if (threadIdx.x == 0) { s_ja = nz_out; s_jb = 0; }
+    __syncthreads();
+    int ja = nz_out, jb = 0;
+    for (int j = threadIdx.x; j < nz_out; j += blockDim.x)
+        if (lo[j] >= 0) { ja = min(ja, j); jb = max(jb, j + 1); }
+    atomicMin(&s_ja, ja); atomicMax(&s_jb, jb);
+    __syncthreads();
+    ja = s_ja; jb = max(s_jb, s_ja);
+    for (int z = threadIdx.x; z < nz; z += blockDim.x) {
+        int a = ja, b = jb;                    // first j in [ja, jb) with lo[j] >= z
+        while (a < b) { const int mid = (a + b) >> 1; if (lo[mid] >= z) b = mid; else a = mid + 1; }
+        jfirst[z] = (z == nz - 1) ? jb : a;
+    }
+}
+
+// one output value of the folded-in spectral interpolation: scipy's slope form, as spectral_lerp_kernel
+__device__ __forceinline__ float bil_lerp(float a, float b, double wj) {
+    const float diff = b - a;
+    return (float)((double)diff * wj + (double)a);
+}
 
 // Lane <-> output pixel of a 16 x 4 tile per wavefront (a 64 x 16 tile per block): the
 // source footprint of a compact tile touches ~3x fewer cache lines per gather than a
 // 64-pixel output row does for a rotated grid, while stores stay 64 B contiguous per row.
+template <bool LERP>
 __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tiles_x = (A.nx_out + 63) / 64;
@@ -217,10 +251,16 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const bool inside = (xs >= -0.5) && (xs <= (double)A.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.ny - 0.5);
     if (blockIdx.y == 0 && A.footprint) A.footprint[pix] = inside ? 1 : 0;
     const int64_t zb = (int64_t)blockIdx.y * A.zchunk;
-    const int64_t ze = min(A.nz, zb + A.zchunk);
+    const int64_t ze = min(LERP ? A.nz - 1 : A.nz, zb + A.zchunk);       // LERP: the left brackets [zb, ze) this block serves
     float* po = A.out + yo * A.out_row_stride + xo;
+    if (LERP && blockIdx.y == 0) {                                        // channels outside the input range
+        const int64_t ja = A.jfirst[0], jb = A.jfirst[A.nz - 1];
+        for (int64_t j = 0; j < ja; ++j) po[j * A.out_plane_stride] = NAN;
+        for (int64_t j = jb; j < A.nz_out; ++j) po[j * A.out_plane_stride] = NAN;
+    }
     if (!inside) {
-        for (int64_t z = zb; z < ze; ++z) po[z * A.out_plane_stride] = NAN;
+        if (LERP) { for (int64_t j = A.jfirst[zb]; j < A.jfirst[ze]; ++j) po[j * A.out_plane_stride] = NAN; }
+        else for (int64_t z = zb; z < ze; ++z) po[z * A.out_plane_stride] = NAN;
         return;
     }
     // reproject's resampler: scipy map_coordinates(order=1) on the image padded by one
@@ -240,6 +280,36 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
     const bool anymask = A.mask.flags != 0;
     constexpr int U = 4;                      // channels in flight per lane (8 measured slower)
     bool anyv = false;
+    if (LERP) {
+        // (the path of the tiles the LDS pass could not take: one input plane at a time)
+        const bool anymask_l = anymask;
+        auto plane = [&](int64_t z) {
+            const float* p = A.cube + z * A.plane_stride;
+            float aa = p[o00], bb = p[o01], cc = p[o10], dd = p[o11];
+            if (anymask_l) {
+                const uint8_t* pm = arr ? A.mask.arr + z * A.mask.plane_stride : nullptr;
+                bool i0 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, aa);
+                bool i1 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, bb);
+                bool i2 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, cc);
+                bool i3 = spc_pred(A.mask.flags, A.mask.thr_lo, A.mask.thr_hi, dd);
+                if (arr) { i0 = i0 && pm[m00]; i1 = i1 && pm[m01]; i2 = i2 && pm[m10]; i3 = i3 && pm[m11]; }
+                aa = i0 ? aa : A.fill; bb = i1 ? bb : A.fill; cc = i2 ? cc : A.fill; dd = i3 ? dd : A.fill;
+            }
+            return A.nearest ? aa : fmaf(w11, dd, fmaf(w10, cc, fmaf(w01, bb, w00 * aa)));
+        };
+        float prev = plane(zb);
+        for (int64_t z = zb + 1; z <= ze; ++z) {
+            const float cur = plane(z);
+            for (int64_t j = A.jfirst[z - 1]; j < A.jfirst[z]; ++j) {
+                const float r = bil_lerp(prev, cur, A.inv_dx[j] * A.t[j]);
+                anyv = anyv || (r == r);
+                __builtin_nontemporal_store(r, po + j * A.out_plane_stride);
+            }
+            prev = cur;
+        }
+        if (A.any_valid && __any(anyv) && lane == 0) atomicOr(A.any_valid, 1u);
+        return;
+    }
     for (int64_t zq = zb; zq < ze; zq += U) {
         float a[U], b[U], c[U], d[U];
 #pragma unroll
@@ -296,7 +366,7 @@ template <> struct BilTile<64> {
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int TILE, bool ARR, bool ANYMASK>
+template <int TILE, bool ARR, bool ANYMASK, bool LERP = false>
 __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(const BilArgs A) {
     using G = BilTile<TILE>;
     constexpr int kTile = TILE, kRowsMax = G::kRowsMax, kElemsMax = G::kElemsMax, kStageU = G::kStageU;
@@ -406,9 +476,10 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
             l1[q] = s_off[r + dy[q]] + x0[q] - s_xmin[r + dy[q]];
         }
     }
+    // LERP: this block serves the output channels whose left bracket lies in [zb, zb + zchunk_lds) and stages one plane more
     const int64_t zb = (int64_t)blockIdx.y * A.zchunk_lds;
-    const int64_t ze = min(A.nz, zb + A.zchunk_lds);
-    if (zb >= ze) return;
+    const int64_t ze = LERP ? min(A.nz, zb + A.zchunk_lds + 1) : min(A.nz, zb + A.zchunk_lds);
+    if (zb >= (LERP ? A.nz - 1 : ze)) return;
     const bool vec_ok = (xo + 4 <= A.nx_out) && (A.out_row_stride % 4 == 0) && (A.out_plane_stride % 4 == 0) &&
                         ((((uintptr_t)A.out) & 15) == 0);
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -440,6 +511,23 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
     };
     fetch(zb);
     bool anyv = false;
+    float prev[4] = {NAN, NAN, NAN, NAN};
+    auto put = [&](int64_t plane, const float (&r4)[4]) {
+        float* po = A.out + plane * A.out_plane_stride + yo * A.out_row_stride + xo;
+        if (yo < A.ny_out) {
+            if (vec_ok) __builtin_nontemporal_store(f32x4{r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<f32x4*>(po));
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (xo + q < A.nx_out) po[q] = r4[q];
+            }
+        }
+    };
+    if (LERP && blockIdx.y == 0) {                                        // channels outside the input range
+        const float nan4[4] = {NAN, NAN, NAN, NAN};
+        const int64_t ja = A.jfirst[0], jb = A.jfirst[A.nz - 1];
+        for (int64_t j = 0; j < ja; ++j) put(j, nan4);
+        for (int64_t j = jb; j < A.nz_out; ++j) put(j, nan4);
+    }
     for (int64_t zq = zb; zq < ze; zq += kStageU) {
 #pragma unroll
         for (int u = 0; u < kStageU; ++u)
@@ -459,15 +547,22 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
                 const float aa = sp[l0[q]], bb = sp[l0[q] + dx[q]], cc = sp[l1[q]], dd = sp[l1[q] + dx[q]];
                 const float r = A.nearest ? aa : fmaf(w11[q], dd, fmaf(w10[q], cc, fmaf(w01[q], bb, w00[q] * aa)));
                 r4[q] = inside[q] ? r : NAN;
-                anyv = anyv || (r4[q] == r4[q]);
+                if (!LERP) anyv = anyv || (r4[q] == r4[q]);
             }
-            float* po = A.out + z * A.out_plane_stride + yo * A.out_row_stride + xo;
-            if (yo < A.ny_out) {
-                if (vec_ok) __builtin_nontemporal_store(f32x4{r4[0], r4[1], r4[2], r4[3]}, reinterpret_cast<f32x4*>(po));
-                else {
+            if (!LERP) put(z, r4);
+            else {
+                if (z > zb) {
+                    const int j1 = A.jfirst[z];                           // (block-uniform: scalar loads)
+                    for (int j = A.jfirst[z - 1]; j < j1; ++j) {
+                        const double wj = A.inv_dx[j] * A.t[j];
+                        float o4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) if (xo + q < A.nx_out) po[q] = r4[q];
+                        for (int q = 0; q < 4; ++q) { o4[q] = bil_lerp(prev[q], r4[q], wj); anyv = anyv || (o4[q] == o4[q]); }
+                        put(j, o4);
+                    }
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) prev[q] = r4[q];
             }
         }
         lds_only_barrier();
@@ -914,16 +1009,24 @@ int spc_resample_spline_f32(int device, void* stream, const spc_cube_f32* cube, 
     return SPC_OK;
 }
 
-int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
-                              float fill, int64_t ny_out, int64_t nx_out, const double* d_xs,
-                              const double* d_ys, float* d_out, int64_t out_row_stride,
-                              int64_t out_plane_stride, uint8_t* d_footprint, int order, uint32_t* d_any_valid,
-                              void* d_workspace, size_t workspace_bytes) {
+// spc_resample_bilinear_f32 (nz_out = 0) and spc_resample_bilinear_lerp_f32 (the spectral interpolation folded in)
+static int bilinear_launch(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                           float fill, int64_t ny_out, int64_t nx_out, const double* d_xs,
+                           const double* d_ys, int64_t nz_out, const int32_t* d_lo, const double* d_t, const double* d_inv_dx,
+                           float* d_out, int64_t out_row_stride,
+                           int64_t out_plane_stride, uint8_t* d_footprint, int order, uint32_t* d_any_valid,
+                           void* d_workspace, size_t workspace_bytes) {
     int rc = spc_check_cube(cube);
     if (rc) return rc;
+    const bool lerp = nz_out > 0;
     SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
     SPC_REQUIRE(d_xs && d_ys && d_out, "NULL pointer argument");
     SPC_REQUIRE(order == 0 || order == 1, "order must be 1 (bilinear) or 0 (nearest neighbour), got %d", order);
+    if (lerp) {
+        SPC_REQUIRE(d_lo && d_t && d_inv_dx, "NULL pointer argument (lerp plan)");
+        SPC_REQUIRE(cube->nz >= 2, "the spectral interpolation needs at least two input channels");
+        SPC_REQUIRE(cube->nz < (1ll << 30) && nz_out < (1ll << 30), "too many channels");
+    }
     BilArgs A{};
     rc = spc_mask_to_dev(mask, cube, &A.mask);
     if (rc) return rc;
@@ -937,13 +1040,22 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
     A.out_plane_stride = out_plane_stride ? out_plane_stride : ny_out * A.out_row_stride;
     A.footprint = d_footprint;
     A.nearest = order == 0; A.any_valid = d_any_valid;
-    if (d_any_valid) SPC_HIP(hipMemsetAsync(d_any_valid, 0, sizeof(uint32_t), (hipStream_t)stream));
+    A.nz_out = nz_out; A.lo = d_lo; A.t = d_t; A.inv_dx = d_inv_dx;
+    hipStream_t st = (hipStream_t)stream;
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    if (lerp) {
+        SPC_WS_TAKE(d_jfirst, ws, int32_t, cube->nz);
+        hipLaunchKernelGGL(lerp_index_kernel, dim3(1), dim3(256), 0, st, d_lo, (int)nz_out, (int)cube->nz, d_jfirst);
+        SPC_LAUNCH_CHECK();
+        A.jfirst = d_jfirst;
+    }
+    const int64_t nzw = lerp ? cube->nz - 1 : cube->nz;                     // units of work along z: planes, or left brackets
+    if (d_any_valid) SPC_HIP(hipMemsetAsync(d_any_valid, 0, sizeof(uint32_t), st));
     const int64_t nblocks = ((nx_out + 63) / 64) * ((ny_out + 3) / 4);      // 64 x 4 pixel tiles
     int nsplit = 1;
-    if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, cube->nz / 8));
-    A.zchunk = (cube->nz + nsplit - 1) / nsplit;
-    nsplit = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
-    hipStream_t st = (hipStream_t)stream;
+    if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, nzw / 8));
+    A.zchunk = (nzw + nsplit - 1) / nsplit;
+    nsplit = (int)((nzw + A.zchunk - 1) / A.zchunk);
     // LDS-staged pass over 32 x 32 tiles first; the gather kernel then only does flagged tiles
     const char* env = getenv("SPC_BILINEAR_LDS");
     const bool want = env ? atoi(env) != 0 : true;
@@ -961,39 +1073,60 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
         A.ntiles32 = ntiles;
         int ns = 1;
         const int64_t want_blocks = tile == 64 ? 1024 : 4096;
-        if (ntiles < want_blocks) ns = (int)std::max<int64_t>(1, std::min<int64_t>((want_blocks + ntiles - 1) / ntiles, cube->nz / 64));
+        if (ntiles < want_blocks) ns = (int)std::max<int64_t>(1, std::min<int64_t>((want_blocks + ntiles - 1) / ntiles, nzw / 64));
         // at most 256 channels per block (C5, 32 x 32 tiles: 9.4 ms with 1024-channel chunks, 8.5 ms with 128 - 256, 9.4 with 64
         // where the per-block footprint set-up starts to show).  The gain is scheduling - more, shorter blocks even out the
         // tail - not cache reuse: FETCH_SIZE did not move (profiles/r01_pmc_traffic.txt).
-        A.zchunk_lds = std::min<int64_t>((cube->nz + ns - 1) / ns, 256);
+        A.zchunk_lds = std::min<int64_t>((nzw + ns - 1) / ns, 256);
         if (const char* zc = getenv("SPC_BILINEAR_ZCHUNK")) A.zchunk_lds = std::max(8, atoi(zc));
         A.zchunk_lds = ((A.zchunk_lds + kStageU - 1) / kStageU) * kStageU;
-        ns = (int)((cube->nz + A.zchunk_lds - 1) / A.zchunk_lds);
-        SpcWorkspace ws(d_workspace, workspace_bytes);
+        ns = (int)((nzw + A.zchunk_lds - 1) / A.zchunk_lds);
         SPC_WS_TAKE(d_status, ws, unsigned char, ntiles);
         SPC_HIP(spc_flags_clear(d_status, (size_t)ntiles, st));
         A.status = d_status;
         dim3 g((unsigned)(((ntiles + 7) / 8) * 8), (unsigned)ns);
-        if (tile == 64) {
-            dim3 b(BilTile<64>::kThreads);
-            if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<64, true, true>), g, b, 0, st, A);
-            else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<64, false, true>), g, b, 0, st, A);
-            else hipLaunchKernelGGL((bilinear_lds_kernel<64, false, false>), g, b, 0, st, A);
-        } else {
-            dim3 b(BilTile<32>::kThreads);
-            if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<32, true, true>), g, b, 0, st, A);
-            else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<32, false, true>), g, b, 0, st, A);
-            else hipLaunchKernelGGL((bilinear_lds_kernel<32, false, false>), g, b, 0, st, A);
-        }
+#define SPC_BIL_LAUNCH(T_, L_)                                                                                       \
+        do {                                                                                                         \
+            dim3 b(BilTile<T_>::kThreads);                                                                           \
+            if (arr) hipLaunchKernelGGL((bilinear_lds_kernel<T_, true, true, L_>), g, b, 0, st, A);                   \
+            else if (A.mask.flags) hipLaunchKernelGGL((bilinear_lds_kernel<T_, false, true, L_>), g, b, 0, st, A);    \
+            else hipLaunchKernelGGL((bilinear_lds_kernel<T_, false, false, L_>), g, b, 0, st, A);                     \
+        } while (0)
+        if (tile == 64) { if (lerp) SPC_BIL_LAUNCH(64, true); else SPC_BIL_LAUNCH(64, false); }
+        else { if (lerp) SPC_BIL_LAUNCH(32, true); else SPC_BIL_LAUNCH(32, false); }
+#undef SPC_BIL_LAUNCH
         SPC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
+    if (lerp) hipLaunchKernelGGL(bilinear_kernel<true>, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(bilinear_kernel<false>, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
+}
+
+int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                              float fill, int64_t ny_out, int64_t nx_out, const double* d_xs,
+                              const double* d_ys, float* d_out, int64_t out_row_stride,
+                              int64_t out_plane_stride, uint8_t* d_footprint, int order, uint32_t* d_any_valid,
+                              void* d_workspace, size_t workspace_bytes) {
+    return bilinear_launch(device, stream, cube, mask, fill, ny_out, nx_out, d_xs, d_ys, 0, nullptr, nullptr, nullptr, d_out,
+                           out_row_stride, out_plane_stride, d_footprint, order, d_any_valid, d_workspace, workspace_bytes);
+}
+
+int spc_resample_bilinear_lerp_f32(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask,
+                                   float fill, int64_t ny_out, int64_t nx_out, const double* d_xs, const double* d_ys,
+                                   int64_t nz_out, const int32_t* d_lo, const double* d_t, const double* d_inv_dx,
+                                   float* d_out, int64_t out_row_stride, int64_t out_plane_stride, uint8_t* d_footprint,
+                                   int order, uint32_t* d_any_valid, void* d_workspace, size_t workspace_bytes) {
+    SPC_REQUIRE(nz_out > 0, "nz_out must be positive");
+    return bilinear_launch(device, stream, cube, mask, fill, ny_out, nx_out, d_xs, d_ys, nz_out, d_lo, d_t, d_inv_dx, d_out,
+                           out_row_stride, out_plane_stride, d_footprint, order, d_any_valid, d_workspace, workspace_bytes);
 }
 
 }  // extern "C"
 
 size_t spc_ws_resample_bilinear(int64_t ny_out, int64_t nx_out) {
     return spc_ws_round((size_t)(((nx_out + 31) / 32) * ((ny_out + 31) / 32))) + 256;     // tile flags (32 x 32: the finer grid)
+}
+size_t spc_ws_resample_bilinear_lerp(int64_t nz, int64_t ny_out, int64_t nx_out) {
+    return spc_ws_resample_bilinear(ny_out, nx_out) + spc_ws_round(sizeof(int32_t) * (size_t)nz) + 256;     // + jfirst[]
 }

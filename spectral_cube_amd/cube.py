@@ -101,6 +101,13 @@ class _WideView:
         return c._device_data64().get()
 
 
+_ALL_NAN = ("All values in reprojected cube are nan.  This can be caused"
+            " by an error in which coordinates do not 'round-trip'.  Try "
+            "setting ``roundtrip_coords=False``.  You might also check "
+            "whether the WCS transformation produces valid pixel->world "
+            "and world->pixel coordinates in each axis.")
+
+
 class SmoothingWarning(UserWarning):
     pass
 
@@ -1354,6 +1361,7 @@ class SpectralCube:
         newwcs = self._wcs.with_spectral(crval, cdelt, 1.0)
         thunk = _Thunk(run)
         thunk.parent = parent
+        thunk.lerp = (plan, fill)          # (a following reproject folds the interpolation into its resampling kernel)
         thunk.strip_fn = lambda dev, mspec, stream: ops.spectral_lerp(dev, plan[0], plan[1], plan[2], fill, mask=mspec, stream=stream)
         out = self._new_cube_with(lazy=thunk, shape=(len(grid),) + self._shape[1:], wcs=newwcs,
                                   mask=False)
@@ -1435,7 +1443,30 @@ class SpectralCube:
             out._mask = M.BooleanArrayMask(footprint[None], newwcs, shape=shape)
             out._footprint = footprint
             return out
+        folded = self._pending_interpolation(order) if zs is None else None
+        if folded is not None:
+            # spectral_interpolate(...).reproject(...): both are linear interpolations with NaN propagation, so they commute -
+            # every INPUT plane is resampled once and the output channels are blended from neighbouring resampled planes in
+            # the same kernel (ops.resample_bilinear_lerp): one read of the parent, one write of the result, the
+            # interpolated cube is never formed
+            parent, plan = folded
+            flag = DeviceArray((1,), np.uint32, self.device)
+            dev, foot = ops.resample_bilinear_lerp(parent._device_data(), xs, ys, plan[0], plan[1], plan[2], fill=np.nan,
+                                                   mask=parent._mask_spec(), order=order, any_valid=flag)
+            footprint = foot.get().astype(bool)
+            if int(flag.get()[0]) == 0:
+                raise ValueError(_ALL_NAN)
+            out = self._new_cube_with(dev=dev, wcs=newwcs, mask=False, shape=dev.shape)
+            out._mask = M.BooleanArrayMask(footprint[None], newwcs, shape=dev.shape)
+            out._footprint = footprint
+            return out
         mask = self._mask_spec() if filled else None
+        if filled and not np.isnan(float(self._fill_value)) and self._mask is not None and M.contains(self._mask, M.NotNaNMask) \
+                and not M.contains(self._mask, M.InvertedMask):
+            # ~isnan(data) lowers to nothing (NaN samples never take part in a reduction), but HERE the excluded voxels are
+            # replaced by a fill value that is a number (spectral_cube.py:2709-2712): the NaN samples must be named
+            inc = ops.mask_include(self._device_data(), mask, nan_excluded=True)
+            mask = ops.MaskSpec(_lib.MASK_ARRAY, 0.0, 0.0, inc)
         flag = DeviceArray((1,), np.uint32, self.device)
         if order >= 2:
             # scipy's recursive spline prefilter (which reproject_interp runs along all three axes of the NaN-filled cube)
@@ -1453,21 +1484,32 @@ class SpectralCube:
             dev, foot = ops.resample_spline(src, xs, ys, order)
             flag = None
         else:
-            dev, foot = ops.resample_bilinear(self._device_data(), xs, ys, fill=float(self._fill_value),
-                                              mask=mask, order=order, any_valid=flag)
+            zfold = False
+            if zs is not None:
+                # reproject_separable: channel positions inside [-0.5, nz - 0.5] are clipped to the cube,
+                # each output channel is the linear blend of the two resampled planes around it
+                inside = (zs >= -0.5) & (zs <= nz - 0.5)
+                zc = np.clip(np.where(inside, zs, 0.0), 0.0, nz - 1.0)
+                z0 = np.minimum(np.floor(zc).astype(np.int64), nz - 2)
+                zlo = np.where(inside, z0, -1).astype(np.int32)
+                zfold = ops.lerp_plan_is_foldable(zlo) and os.environ.get("SPC_REPROJECT_FOLD", "1") != "0"
+            if zfold:
+                # ascending target channels: the blend rides in the resampling kernel (one pass, no resampled copy of the cube)
+                dev, foot = ops.resample_bilinear_lerp(self._device_data(), xs, ys, zlo, zc - z0, np.ones(len(zs)),
+                                                       fill=float(self._fill_value), mask=mask, order=order, any_valid=flag)
+            else:
+                dev, foot = ops.resample_bilinear(self._device_data(), xs, ys, fill=float(self._fill_value),
+                                                  mask=mask, order=order, any_valid=flag)
         footprint = foot.get().astype(bool)
         valid3d = footprint[None]
         if zs is not None:
-            # reproject_separable: channel positions inside [-0.5, nz - 0.5] are clipped to the cube,
-            # each output channel is the linear blend of the two resampled planes around it
-            inside = (zs >= -0.5) & (zs <= nz - 0.5)
-            zc = np.clip(np.where(inside, zs, 0.0), 0.0, nz - 1.0)
-            z0 = np.minimum(np.floor(zc).astype(np.int64), nz - 2)
-            lo = np.where(inside, z0, -1).astype(np.int32)
-            dev = ops.spectral_lerp(dev, lo, zc - z0, np.ones(len(zs)), np.nan)
             if not inside.all():
                 valid3d = footprint[None] & inside[:, None, None]
-            nothing = (not inside.any()) or ops.stats_global(dev)["npts"] == 0
+            if zfold:
+                nothing = (not inside.any()) or int(flag.get()[0]) == 0
+            else:
+                dev = ops.spectral_lerp(dev, zlo, zc - z0, np.ones(len(zs)), np.nan)
+                nothing = (not inside.any()) or ops.stats_global(dev)["npts"] == 0
         elif flag is None:
             nothing = not footprint.any()
         else:
@@ -1482,6 +1524,25 @@ class SpectralCube:
         out._mask = M.BooleanArrayMask(valid3d, newwcs, shape=dev.shape)
         out._footprint = footprint
         return out
+
+    def _pending_interpolation(self, order):
+        """(parent, plan) when this cube is a spectral_interpolate result that has not been formed yet and a reprojection of
+        order 0 / 1 may fold the interpolation in: the parent is resident (or fits), nothing replaced the NaN fill or the
+        ~isnan mask in between, the plan's channels ascend"""
+        lz = self._lazy
+        if self._dev is not None or lz is None or getattr(lz, "lerp", None) is None or order not in (0, 1):
+            return None
+        if os.environ.get("SPC_REPROJECT_FOLD", "1") == "0":
+            return None
+        plan, fill = lz.lerp
+        parent = lz.parent
+        if not (np.isnan(fill) and np.isnan(float(self._fill_value))) or parent._stream_source() is not None:
+            return None
+        if not (isinstance(self._mask, M.NotNaNMask) and self._mask._data_ref._is_same_data(self)):
+            return None
+        if parent._shape[0] < 2 or not ops.lerp_plan_is_foldable(plan[0]):
+            return None
+        return parent, plan
 
     def _reproject_streamed_with_spectral_axis(self, newwcs, zs, shape_yx, order, filled):
         """reproject of a cube above the HBM budget onto a CUBE header whose spectral axis differs from this cube's: the

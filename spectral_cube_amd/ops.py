@@ -496,6 +496,61 @@ def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_fo
     return out, foot
 
 
+def lerp_plan_is_foldable(lo):
+    """True when a spectral_lerp plan can ride in the resampling kernel (resample_bilinear_lerp): its non-negative
+    entries ascend and are contiguous (an ascending grid on ascending channels)"""
+    lo = np.asarray(lo)
+    ok = np.nonzero(lo >= 0)[0]
+    if len(ok) == 0:
+        return False
+    return bool(ok[-1] - ok[0] + 1 == len(ok) and np.all(np.diff(lo[ok]) >= 0))
+
+
+def resample_bilinear_lerp(cube, xs, ys, lo, t, inv_dx, fill=np.nan, mask=None, stream=None, want_footprint=True, out=None,
+                           order=1, any_valid=None):
+    """resample_bilinear with the spectral interpolation folded in (spc_resample_bilinear_lerp_f32): output channel j is the
+    linear blend (spectral_lerp's plan *lo*, *t*, *inv_dx*) of the RESAMPLED input planes lo[j], lo[j] + 1 - one read of the
+    cube, one write of the result, for spectral_interpolate(...).reproject(...) (dask_spectral_cube.py:1342-1353 +
+    spectral_cube.py:2700-2732) and for reproject onto a cube header with its own spectral axis.  Channels with lo < 0 are
+    NaN planes.  Returns (cube of len(lo) channels, footprint)."""
+    dev = cube.device
+    lo = np.ascontiguousarray(lo, dtype=np.int32)
+    if not lerp_plan_is_foldable(lo):
+        raise _lib.HipUnsupported("resample_bilinear_lerp: the plan's channels must ascend (flip the axis or run the two passes)")
+    if cube.shape[0] < 2:
+        raise _lib.HipUnsupported("resample_bilinear_lerp: at least two input channels")
+    if isinstance(xs, DeviceArray) and isinstance(ys, DeviceArray):
+        if xs.dtype != np.float64 or ys.dtype != np.float64 or xs.shape != ys.shape or len(xs.shape) != 2:
+            raise ValueError("xs, ys must be 2-D float64 maps of identical shape")
+        d_xs, d_ys = xs, ys
+        ny_out, nx_out = xs.shape
+    else:
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        if xs.shape != ys.shape or xs.ndim != 2:
+            raise ValueError("xs, ys must be 2-D maps of identical shape")
+        ny_out, nx_out = xs.shape
+        d_xs, d_ys = DeviceArray.from_numpy(xs, dev), DeviceArray.from_numpy(ys, dev)
+    nz_out = len(lo)
+    d_lo = DeviceArray.from_numpy(lo, dev)
+    d_t = DeviceArray.from_numpy(np.asarray(t, dtype=np.float64), dev)
+    d_inv = DeviceArray.from_numpy(np.asarray(inv_dx, dtype=np.float64), dev)
+    if out is None:
+        out = DeviceArray((nz_out, ny_out, nx_out), np.float32, dev)
+    elif out.shape != (nz_out, ny_out, nx_out) or out.dtype != np.float32 or getattr(out, "_is_view", False):
+        raise ValueError("out must be a contiguous float32 (nz_out, ny_out, nx_out) DeviceArray")
+    foot = DeviceArray((ny_out, nx_out), np.uint8, dev) if want_footprint else None
+    c, m = _cube_c(cube), _mask_c(mask, cube)
+    ws, wsn = workspace(dev, stream, _lib.WS_RESAMPLE_BILINEAR_LERP, *cube.shape, ny_out, nx_out)
+    _lib.call("spc_resample_bilinear_lerp_f32", dev, _sh(stream), C.byref(c), C.byref(m), float(fill),
+              ny_out, nx_out, C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr), nz_out, C.c_void_p(d_lo.ptr), C.c_void_p(d_t.ptr),
+              C.c_void_p(d_inv.ptr), C.c_void_p(out.ptr), 0, 0,
+              C.c_void_p(foot.ptr) if foot is not None else None, int(order),
+              C.c_void_p(any_valid.ptr) if any_valid is not None else None, ws, wsn)
+    out._plan = (d_xs, d_ys, d_lo, d_t, d_inv)
+    return out, foot
+
+
 def spatial_conv_mfma(cube, kernel2d, mask=None, stream=None, out=None, want_cube=True, want_m0=False, dv=1.0, m0=None):
     """masked separable spatial_smooth with the denominator on the matrix cores (spc_spatial_conv_sep_mfma_f32), optionally
     fused with moment 0 of the smoothed cube under the ORIGINAL mask (the cube is then never written when want_cube is

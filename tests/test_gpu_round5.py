@@ -391,3 +391,162 @@ def test_sigma_clip_block_shape_follows_the_mask(gpu, monkeypatch):
         assert np.mean(np.isnan(got) != np.isnan(exp)) < 2e-4
         both = ~np.isnan(got) & ~np.isnan(exp)
         assert np.array_equal(got[both], exp[both])
+
+
+# ---- spectral interpolation folded into the resampling kernel (spc_resample_bilinear_lerp_f32, ABI 8) -------------------------
+def _rot_map(nyo, nxo, ny, nx, deg, scale=1.0, shift=(0.0, 0.0)):
+    yy, xx = np.mgrid[0:nyo, 0:nxo].astype(np.float64)
+    a = np.deg2rad(deg)
+    xs = scale * (np.cos(a) * (xx - nxo / 2) - np.sin(a) * (yy - nyo / 2)) + nx / 2 + shift[0]
+    ys = scale * (np.sin(a) * (xx - nxo / 2) + np.cos(a) * (yy - nyo / 2)) + ny / 2 + shift[1]
+    return xs, ys
+
+
+@pytest.mark.parametrize("case", [
+    dict(shape=(17, 90, 130), out=(40, 150, 170), deg=30.0, mask="array"),          # 64 x 64 tiles, up-sampling 17 -> 40
+    dict(shape=(33, 60, 70), out=(9, 50, 45), deg=-75.0, mask=None),                # 32 x 32 tiles, down-sampling
+    dict(shape=(12, 200, 180), out=(30, 140, 160), deg=12.0, mask="pred", scale=3.5),   # tiles whose footprint does not fit: gather
+    dict(shape=(2, 40, 50), out=(7, 64, 64), deg=45.0, mask="array", order=0),      # two channels, nearest neighbour
+    dict(shape=(25, 33, 47), out=(60, 31, 29), deg=200.0, mask=None, beyond=True),  # output channels beyond both ends
+])
+def test_bilinear_with_the_spectral_interpolation_folded_in(gpu, case):
+    """one pass = interpolate, then resample (the oracle's order, dask_spectral_cube.py:1342-1353 then spectral_cube.py:2726-2732)
+    = resample, then interpolate (the device's two-pass forms): NaN patterns identical, values to 1e-5 of the range"""
+    rng = np.random.default_rng(90 + case["shape"][0])
+    nz, ny, nx = case["shape"]
+    nzo, nyo, nxo = case["out"]
+    d = (rng.standard_normal(case["shape"]) * 2 + 1).astype(np.float32)
+    d[rng.random(d.shape) < 0.01] = np.nan
+    inc, spec = None, None
+    if case["mask"] == "array":
+        inc = rng.random(d.shape) > 0.15
+        spec = ops.MaskSpec(_lib.MASK_ARRAY, array=DeviceArray.from_numpy(inc.astype(np.uint8)))
+    elif case["mask"] == "pred":
+        inc = (d > -1.5) & np.isfinite(d)
+        spec = ops.MaskSpec(_lib.MASK_GT | _lib.MASK_FINITE, -1.5)
+    xs, ys = _rot_map(nyo, nxo, ny, nx, case["deg"], case.get("scale", 1.0), (1.3, -0.7))
+    xin = np.cumsum(rng.uniform(0.5, 1.5, nz))
+    xout = np.linspace(xin[0] - 2.0, xin[-1] + 2.0, nzo) if case.get("beyond") else np.linspace(xin[0], xin[-1], nzo)
+    lo, t, inv, _, _, _ = ops.lerp_plan(xin, xout)
+    order = case.get("order", 1)
+    cube = DeviceArray.from_numpy(d)
+    got, foot = ops.resample_bilinear_lerp(cube, xs, ys, lo, t, inv, mask=spec, order=order)
+    got = got.get()
+    assert got.shape == (nzo, nyo, nxo)
+    r1, foot1 = ops.resample_bilinear(cube, xs, ys, fill=np.nan, mask=spec, order=order)
+    two = ops.spectral_lerp(r1, lo, t, inv, np.nan).get()
+    assert np.array_equal(foot.get(), foot1.get())
+    assert np.array_equal(np.isnan(got), np.isnan(two))
+    fin = ~np.isnan(two)
+    assert np.abs(got[fin] - two[fin]).max() <= 2e-6 * np.abs(two[fin]).max()
+    if case.get("beyond"):
+        assert np.isnan(got[0]).all() and np.isnan(got[-1]).all()
+    if order == 1:
+        ei, _ = O.spectral_interpolate(d, inc, xin, xout)
+        exp, _ = O.resample_bilinear(ei, xs, ys)
+        assert_close(got, exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="folded interpolation vs oracle")
+
+
+def test_bilinear_lerp_refuses_plans_it_cannot_fold(gpu):
+    d = DeviceArray.from_numpy(np.zeros((4, 8, 8), np.float32))
+    xs, ys = _rot_map(8, 8, 8, 8, 10.0)
+    with pytest.raises(_lib.HipUnsupported):
+        ops.resample_bilinear_lerp(d, xs, ys, np.array([2, 1, 0], np.int32), np.zeros(3), np.ones(3))         # descending
+    with pytest.raises(_lib.HipUnsupported):
+        ops.resample_bilinear_lerp(d, xs, ys, np.array([0, -1, 1], np.int32), np.zeros(3), np.ones(3))        # a hole
+    one = DeviceArray.from_numpy(np.zeros((1, 8, 8), np.float32))
+    with pytest.raises(_lib.HipUnsupported):
+        ops.resample_bilinear_lerp(one, xs, ys, np.array([0], np.int32), np.zeros(1), np.ones(1))
+
+
+def _cube_hdr(nz, ny, nx, **kw):
+    h = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CTYPE3": "VRAD", "CDELT1": -1e-3, "CDELT2": 1e-3, "CDELT3": 500.0,
+         "CUNIT3": "m/s", "CRPIX1": nx / 2 + 0.5, "CRPIX2": ny / 2 + 0.5, "CRPIX3": 1, "CRVAL1": 40.0, "CRVAL2": 10.0,
+         "CRVAL3": -3000.0, "NAXIS": 3, "NAXIS1": nx, "NAXIS2": ny, "NAXIS3": nz}
+    h.update(kw)
+    return h
+
+
+def test_cube_level_interpolate_then_reproject_is_one_pass(gpu, monkeypatch):
+    """SpectralCube.spectral_interpolate(grid).reproject(header): the pending interpolation rides in the resampling kernel
+    (the interpolated cube is never formed) unless something replaced its NaN fill or its ~isnan mask in between; same
+    result as the two passes (SPC_REPROJECT_FOLD=0), same as the oracle"""
+    from spectral_cube_amd import SpectralCube
+    rng = np.random.default_rng(77)
+    nz, ny, nx = 21, 70, 90
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[5, 20:24, 30:33] = np.nan
+    hdr = _cube_hdr(nz, ny, nx)
+    cube = SpectralCube.read(d, hdr)
+    cube = cube.with_mask(cube > -1.2)
+    v = cube.spectral_axis
+    grid = np.linspace(v[0], v[-1], 50)
+    a = np.deg2rad(30.0)
+    tgt = {k: hdr[k] for k in ("CTYPE1", "CTYPE2", "CDELT1", "CDELT2", "CRVAL1", "CRVAL2")}
+    tgt.update(NAXIS=2, NAXIS1=80, NAXIS2=76, CRPIX1=40.5, CRPIX2=38.5, PC1_1=np.cos(a), PC1_2=-np.sin(a), PC2_1=np.sin(a), PC2_2=np.cos(a))
+    calls = []
+    real = ops.resample_bilinear_lerp
+    monkeypatch.setattr(ops, "resample_bilinear_lerp", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+    up = cube.spectral_interpolate(grid, suppress_smooth_warning=True)
+    res = up.reproject(tgt)
+    assert calls == [1] and up._dev is None                       # folded: the interpolated cube was not materialised
+    got = res._device_data().get()
+    monkeypatch.setenv("SPC_REPROJECT_FOLD", "0")
+    res2 = cube.spectral_interpolate(grid, suppress_smooth_warning=True).reproject(tgt)
+    two = res2._device_data().get()
+    assert calls == [1]
+    assert np.array_equal(np.isnan(got), np.isnan(two)) and np.array_equal(res._footprint, res2._footprint)
+    fin = ~np.isnan(two)
+    assert np.abs(got[fin] - two[fin]).max() <= 2e-6 * np.abs(two[fin]).max()
+    np.testing.assert_allclose(res.spectral_axis, grid, rtol=1e-12, atol=1e-9)
+    inc = (d > -1.2)
+    ei, _ = O.spectral_interpolate(d, inc, v, grid)
+    xs, ys = ops.wcs_pixel_map(cube.wcs, res.wcs, (76, 80))
+    exp, _ = O.resample_bilinear(ei, xs.get(), ys.get())
+    assert_close(got, exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="cube-level folded chain vs oracle")
+    monkeypatch.delenv("SPC_REPROJECT_FOLD")
+    # a fill value set in between turns the interpolated cube's NaNs into numbers before they are resampled: two passes
+    up0 = cube.spectral_interpolate(grid, suppress_smooth_warning=True).with_fill_value(0.0)
+    r0 = up0.reproject(tgt)
+    assert calls == [1]
+    assert np.isfinite(r0._device_data().get()[:, res._footprint]).all()
+    # a descending grid: the plan's channels descend, the two passes run
+    rd = cube.spectral_interpolate(grid[::-1].copy(), suppress_smooth_warning=True).reproject(tgt)
+    assert calls == [1]
+    gd = rd._device_data().get()
+    assert np.array_equal(np.isnan(gd[::-1]), np.isnan(two))
+
+
+def test_reproject_onto_a_cube_header_resamples_all_three_axes_in_one_pass(gpu, monkeypatch):
+    """spectral_cube.py:2726-2732 with a cube header whose channels differ from the cube's: the blend between resampled planes
+    rides in the resampling kernel for ascending target channels; identical NaNs, values to float32 rounding against the
+    two-pass form (SPC_REPROJECT_FOLD=0), 1e-5 against the oracle's reproject_separable"""
+    from spectral_cube_amd import SpectralCube
+    from spectral_cube_amd.wcs import SimpleWCS
+    rng = np.random.default_rng(78)
+    nz, ny, nx = 15, 64, 72
+    d = rng.standard_normal((nz, ny, nx)).astype(np.float32)
+    d[7, 30:33, 12:16] = np.nan
+    hdr = _cube_hdr(nz, ny, nx)
+    cube = SpectralCube.read(d, hdr)
+    a = np.deg2rad(-20.0)
+    tgt = _cube_hdr(26, 70, 66, CDELT3=270.0, CRVAL3=-3200.0, PC1_1=np.cos(a), PC1_2=-np.sin(a), PC2_1=np.sin(a), PC2_2=np.cos(a))
+    calls = []
+    real = ops.resample_bilinear_lerp
+    monkeypatch.setattr(ops, "resample_bilinear_lerp", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+    out = cube.reproject(tgt)
+    assert calls == [1] and out.shape == (26, 70, 66)
+    got = out._device_data().get()
+    monkeypatch.setenv("SPC_REPROJECT_FOLD", "0")
+    out2 = cube.reproject(tgt)
+    two = out2._device_data().get()
+    assert calls == [1]
+    assert np.array_equal(np.isnan(got), np.isnan(two))
+    assert np.array_equal(out.mask.include(), out2.mask.include())
+    fin = ~np.isnan(two)
+    assert np.abs(got[fin] - two[fin]).max() <= 2e-6 * np.abs(two[fin]).max()
+    xs, ys = ops.wcs_pixel_map(cube.wcs, SimpleWCS(tgt), (70, 66))
+    zs = ((-3200.0 + 270.0 * np.arange(26)) - (-3000.0)) / 500.0
+    exp, foot = O.reproject_separable(d, xs.get(), ys.get(), zs)
+    assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="3-D reproject, one pass")
+    assert np.array_equal(out.mask.include(), np.broadcast_to(foot, got.shape))

@@ -23,7 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libspcube_hip.so does not export %s" % name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.spc_abi_version() == 7
+    assert lib.spc_abi_version() == 8
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout 1200 python tools/stress_random.py 150 12 > gpurun_out/r05s6_stress_random.txt 2>&1
-tail -40 gpurun_out/r05s6_stress_random.txt
+timeout 900 python -m pytest tests/test_gpu_round5.py tests/test_gpu_round2.py tests/test_gpu_cube.py -x -q 2>&1 | tail -30 > gpurun_out/r05s6_t.txt
+cat gpurun_out/r05s6_t.txt
