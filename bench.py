@@ -863,7 +863,6 @@ def config_c5(device, scale):
     ver = {"max_scaled_err": _close(got, exp, float(np.nanmax(np.abs(exp))), "C5 lerp"), "voxels_checked": int(exp.size)}
     recs.append(cfg_record("C5 spectral_interpolate 2048 -> 4096 channels", "spectral_lerp_tiles_kernel<4>", ms, (nz + nzo) * ny * nx * 4,
                            nzo * ny * nx, ver, "4 B x nz_in + 4 B x nz_out per spaxel"))
-    del cube
     # reproject: rotated TAN header, device pixel map, bilinear
     hdr = {"CTYPE1": "RA---TAN", "CTYPE2": "DEC--TAN", "CRVAL1": 150.0, "CRVAL2": 2.0, "CRPIX1": nx / 2 + 0.5, "CRPIX2": ny / 2 + 0.5,
            "CDELT1": -1 / 3600, "CDELT2": 1 / 3600, "NAXIS": 2, "NAXIS1": nx, "NAXIS2": ny}
@@ -881,6 +880,17 @@ def config_c5(device, scale):
            "pixel_map": "spc_wcs_pixel_map_f64 on the device"}
     recs.append(cfg_record("C5 reproject 4096 x 1024^2 onto the grid rotated by 30 deg (bilinear)", "bilinear_lds_kernel<64>", ms,
                            nzo * ny * nx * 8, nzo * ny * nx, ver, "~4 read + 4 written per output voxel"))
+    # the pipeline in ONE pass (what cube.spectral_interpolate(grid).reproject(header) runs): every input plane resampled once,
+    # output channels blended from neighbouring resampled planes in the same kernel; checked against the oracle's resampling of
+    # the (oracle-checked) interpolated planes above
+    ms = event_ms(lambda: ops.resample_bilinear_lerp(cube, xs, ys, lo, t, inv, out=rep, want_footprint=False), device, n=5, warm=1)
+    got = np.stack([rep.planes(c_, c_ + 1).get()[0] for c_ in chans])
+    ver = {"max_scaled_err": _close(got, exp, float(np.nanmax(np.abs(src))), "C5 one pass"), "voxels_checked": int(exp.size),
+           "pixel_map": "spc_wcs_pixel_map_f64 on the device"}
+    recs.append(cfg_record("C5 pipeline spectral_interpolate 2048 -> 4096 channels -> reproject (rotated 30 deg), ONE pass (the interpolated cube is never formed)",
+                           "bilinear_lds_kernel<64, LERP>", ms, (nz + nzo) * ny * nx * 4, nzo * ny * nx, ver,
+                           "4 B x nz_in read + 4 B x nz_out written per spaxel"))
+    del cube
     return recs
 
 

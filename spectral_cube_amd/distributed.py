@@ -296,7 +296,7 @@ def reproject_source_rows(wcs_in, shape_in, header_out, rank, world_size, device
     return max(0, int(np.floor(lo)) - 1), min(ny_in, int(np.ceil(hi)) + 2)
 
 
-def sharded_reproject(src_rows, r0, wcs_in, shape_in, header_out, rank, world_size, mask=None, fill=np.nan):
+def sharded_reproject(src_rows, r0, wcs_in, shape_in, header_out, rank, world_size, mask=None, fill=np.nan, lerp=None):
     """Reproject the rank's strip of OUTPUT rows (spectral_cube.py:2649-2746 sharded by output rows).
 
     src_rows: (nz, r1 - r0, nx_in) float32 DeviceArray = rows [r0, r1) of the source cube as given by
@@ -304,18 +304,23 @@ def sharded_reproject(src_rows, r0, wcs_in, shape_in, header_out, rank, world_si
     rows of the full map with r0 subtracted from the row coordinate (exact in float64), so the result
     is bit-identical to the same rows of the unsharded reprojection.  Returns (out, footprint,
     (y0, y1)): (nz, y1 - y0, nx_out) float32 + (y1 - y0, nx_out) uint8 DeviceArrays; ranks whose
-    strip sees no source pixel get NaN rows and a zero footprint."""
+    strip sees no source pixel get NaN rows and a zero footprint.  *lerp*: (lo, t, inv_dx) of ops.lerp_plan - the
+    spectral interpolation of config C5's first half folded into the same pass (ops.resample_bilinear_lerp: the rank
+    reads its source rows once and writes its len(lo) output channels once)."""
     from . import ops
     device = src_rows.device
     xs, ys, (y0, y1), (ny_out, nx_out), _ = _strip_pixel_map(wcs_in, header_out, rank, world_size, device)
-    nz = src_rows.shape[0]
+    nz = src_rows.shape[0] if lerp is None else len(lerp[0])
     if y1 == y0:
         return DeviceArray((nz, 0, nx_out), np.float32, device), DeviceArray((0, nx_out), np.uint8, device), (y0, y1)
     ys_local = DeviceArray.from_numpy(ys.get() - float(r0), device)        # a few MB; exact subtraction
     if src_rows.shape[1] == 0:
         out = DeviceArray.from_numpy(np.full((nz, y1 - y0, nx_out), np.nan, np.float32), device)
         return out, DeviceArray.zeros((y1 - y0, nx_out), np.uint8, device), (y0, y1)
-    out, foot = ops.resample_bilinear(src_rows, xs, ys_local, fill=fill, mask=mask)
+    if lerp is not None:
+        out, foot = ops.resample_bilinear_lerp(src_rows, xs, ys_local, lerp[0], lerp[1], lerp[2], fill=fill, mask=mask)
+    else:
+        out, foot = ops.resample_bilinear(src_rows, xs, ys_local, fill=fill, mask=mask)
     return out, foot, (y0, y1)
 
 

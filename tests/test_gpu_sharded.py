@@ -7,7 +7,7 @@ import pytest
 
 import oracle_np as O
 from conftest import assert_close, golden
-from spectral_cube_amd import SpectralCube, SimpleWCS, Gaussian1DKernel, synth
+from spectral_cube_amd import SpectralCube, SimpleWCS, Gaussian1DKernel, ops, synth
 from spectral_cube_amd import distributed as D
 from spectral_cube_amd.device import DeviceArray
 
@@ -87,7 +87,8 @@ def test_sharded_spectral_smooth_moment_c3(gpu, ws, masked):
 def test_sharded_interpolate_then_reproject_c5(gpu, ws):
     """configs[4] on output-row strips: every rank loads only the source rows its strip of the rotated
     grid touches, interpolates them spectrally (per spaxel, no exchange) and resamples; the stitched
-    strips equal the unsharded spectral_interpolate -> reproject bit for bit."""
+    strips equal the unsharded spectral_interpolate -> reproject bit for bit (both in one pass: the interpolation folded
+    into the resampling kernel; the two-pass strips agree to float32 rounding)."""
     g = golden("wcs.npz")
     rng = np.random.default_rng(12)
     nz, ny, nx = 12, 96, 80
@@ -102,19 +103,27 @@ def test_sharded_interpolate_then_reproject_c5(gpu, ws):
     whole = cube.spectral_interpolate(grid, suppress_smooth_warning=True).reproject(hout)
     exp, efoot = whole._device_data().get(), whole._footprint
     assert np.isfinite(exp).any() and not efoot.all()
-    outs, foots, loaded = [], [], []
+    outs, outs2, foots, loaded = [], [], [], []
+    lo, t, inv, _, _, _ = ops.lerp_plan(cube.spectral_axis, grid)
     for r in range(ws):
         r0, r1 = D.reproject_source_rows(cube.wcs, cube.shape, hout, r, ws)
         loaded.append(r1 - r0)
         src = _strip_cube(d, None, hin, r0, r1)                        # "load" rows [r0, r1) only
-        up = D.sharded_spectral_interpolate(src, grid, suppress_smooth_warning=True)
-        out, foot, (y0, y1) = D.sharded_reproject(up._device_data(), r0, cube.wcs, cube.shape, hout, r, ws,
-                                                  mask=up._mask_spec(), fill=np.nan)
+        out, foot, (y0, y1) = D.sharded_reproject(src._device_data(), r0, cube.wcs, cube.shape, hout, r, ws,
+                                                  mask=src._mask_spec(), fill=np.nan, lerp=(lo, t, inv))
         assert out.shape == (2 * nz, y1 - y0, 70)
         outs.append(out.get()); foots.append(foot.get())
+        up = D.sharded_spectral_interpolate(src, grid, suppress_smooth_warning=True)
+        out2, foot2, _ = D.sharded_reproject(up._device_data(), r0, cube.wcs, cube.shape, hout, r, ws,
+                                             mask=up._mask_spec(), fill=np.nan)
+        assert np.array_equal(foot2.get(), foot.get())
+        outs2.append(out2.get())
     got, gfoot = np.concatenate(outs, axis=1), np.concatenate(foots, axis=0).astype(bool)
     assert np.array_equal(gfoot, efoot)
     assert np.array_equal(got, exp, equal_nan=True)
+    two = np.concatenate(outs2, axis=1)
+    assert np.array_equal(np.isnan(two), np.isnan(exp))
+    assert np.nanmax(np.abs(two - exp)) <= 2e-6 * np.nanmax(np.abs(exp))
     if ws > 1:
         assert max(loaded) < ny, "a strip of a 30-degree rotated grid does not need every source row"
 

@@ -1,3 +1,4 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_round5.py tests/test_gpu_round2.py tests/test_gpu_cube.py -x -q 2>&1 | tail -30 > gpurun_out/r05s6_t.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|^FAILED|assert" | tail -8 > gpurun_out/r05s6_t.txt
 cat gpurun_out/r05s6_t.txt
+timeout 900 python bench.py --configs-only C5 > gpurun_out/r05s6_bench_c5.txt 2>&1; tail -c 3000 gpurun_out/r05s6_bench_c5.txt
