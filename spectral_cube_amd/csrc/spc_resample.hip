@@ -1077,7 +1077,8 @@ static int bilinear_launch(int device, void* stream, const spc_cube_f32* cube, c
         // at most 256 channels per block (C5, 32 x 32 tiles: 9.4 ms with 1024-channel chunks, 8.5 ms with 128 - 256, 9.4 with 64
         // where the per-block footprint set-up starts to show).  The gain is scheduling - more, shorter blocks even out the
         // tail - not cache reuse: FETCH_SIZE did not move (profiles/r01_pmc_traffic.txt).
-        A.zchunk_lds = std::min<int64_t>((nzw + ns - 1) / ns, 256);
+        // (LERP: 512 input planes per block - C5 in one pass 6.6 / 6.2 / 6.17 / 6.1 ms with 64 / 128 / 256 / 512)
+        A.zchunk_lds = std::min<int64_t>((nzw + ns - 1) / ns, lerp ? 512 : 256);
         if (const char* zc = getenv("SPC_BILINEAR_ZCHUNK")) A.zchunk_lds = std::max(8, atoi(zc));
         A.zchunk_lds = ((A.zchunk_lds + kStageU - 1) / kStageU) * kStageU;
         ns = (int)((nzw + A.zchunk_lds - 1) / A.zchunk_lds);

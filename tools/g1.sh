@@ -1,4 +1,3 @@
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|^FAILED|assert" | tail -8 > gpurun_out/r05s6_t.txt
-cat gpurun_out/r05s6_t.txt
-timeout 900 python bench.py --configs-only C5 > gpurun_out/r05s6_bench_c5.txt 2>&1; tail -c 3000 gpurun_out/r05s6_bench_c5.txt
+timeout 900 python tools/test_bilinear_lerp.py time > gpurun_out/r05s6_bilinear_lerp2.txt 2>&1
+tail -15 gpurun_out/r05s6_bilinear_lerp2.txt

@@ -18,7 +18,7 @@ def cmp(a, b, tol, what):
     ok = nanbad == 0 and err <= tol
     if not ok: fails += 1
     print("%s %s: nan mismatches %d, max err / scale %.2e" % ("ok  " if ok else "FAIL", what, nanbad, err), flush=True)
-for it in range(24):
+for it in range(24 if 'time' not in sys.argv else 0):
     nz, ny, nx = int(rng.integers(2, 60)), int(rng.integers(2, 150)), int(rng.integers(2, 200))
     d = (rng.standard_normal((nz, ny, nx)) * 2 + 1).astype(np.float32)
     d[rng.random(d.shape) < rng.choice([0.0, 0.01, 0.2])] = np.nan
@@ -83,6 +83,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "time":
         for _ in range(n):
             e0, e1 = Event(), Event(); e0.record(); fn(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_ms(e1))
         return float(np.median(ts))
+    os.environ["SPC_BILINEAR_TILE"] = "32"
+    for zc in (None, "128", "512"):
+        if zc: os.environ["SPC_BILINEAR_ZCHUNK"] = zc
+        else: os.environ.pop("SPC_BILINEAR_ZCHUNK", None)
+        tf = timeit(lambda: ops.resample_bilinear_lerp(cube, dxs, dys, lo, t, inv, out=out, want_footprint=False))
+        print("32 x 32 tiles, zchunk %s: fused interpolate + reproject %.3f ms" % (zc, tf), flush=True)
+    os.environ.pop("SPC_BILINEAR_TILE")
     for zc in (None, "64", "128", "512"):
         if zc: os.environ["SPC_BILINEAR_ZCHUNK"] = zc
         else: os.environ.pop("SPC_BILINEAR_ZCHUNK", None)
