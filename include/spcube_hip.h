@@ -153,7 +153,11 @@ typedef enum {
     SPC_WS_PERCENTILE_GLOBAL = 10,    /* spc_percentile_global_f32 */
     SPC_WS_SPATIAL_CONV_MFMA = 11,    /* spc_spatial_conv_sep_mfma_f32 */
     SPC_WS_SIGMA_CLIP = 12,           /* spc_sigma_clip_axis0_f32 (ABI 7) */
-    SPC_WS_RESAMPLE_BILINEAR_LERP = 13 /* spc_resample_bilinear_lerp_f32, nz = INPUT channels, p0 = ny_out, p1 = nx_out (ABI 8) */
+    SPC_WS_RESAMPLE_BILINEAR_LERP = 13, /* spc_resample_bilinear_lerp_f32, nz = INPUT channels, p0 = ny_out, p1 = nx_out (ABI 8) */
+    SPC_WS_STATS_GLOBAL_F64 = 14,     /* spc_stats_global_f64 (ABI 8) */
+    SPC_WS_SPECTRAL_CONV_F64 = 15,    /* spc_spectral_conv_f64, p0 = ntaps (ABI 8) */
+    SPC_WS_SPATIAL_CONV_F64 = 16      /* spc_spatial_conv_f64, p0 = nky, p1 = nkx: the taps + the (num, den) planes of a slab of at
+                                       * most 1 GiB (a smaller workspace is accepted as long as one plane fits) (ABI 8) */
 } spc_ws_kind;
 size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 
@@ -236,6 +240,48 @@ int spc_moment_order_f64(int device, void* stream, const spc_cube_f64* cube,
                          const spc_mask_f64* mask, const double* d_cen, int order,
                          const double* d_mu, const double* d_s0, double* d_out,
                          int64_t out_row_stride);
+
+/* ---- the other operators for float64 cubes (ABI 8) ---------------------------
+ * The reference keeps a float64 source in float64 through every operator (np.result_type(dtype, 0.0),
+ * spectral_cube/masks.py:225; the Dask class keeps the chunk dtype, dask_spectral_cube.py:829).  Same semantics and
+ * arithmetic as the float32 entry points of the same name - astropy's convolve (float64 top / bot, one division),
+ * scipy's interp1d slope form, nansum_allbadtonan - without the rounding of samples or results to float32; mask
+ * thresholds are compared in float64.  Plain HBM streams, not tuned like the float32 kernels.
+ *   spc_stats_global_f64: h_stats (HOST, 5 doubles) = {npts, min, max, sum, sumsq} (dask_spectral_cube.py:769-814);
+ *                         synchronises the stream.  Workspace SPC_WS_STATS_GLOBAL_F64.
+ *   spc_stats_axis_f64:   maps with the reduced axis removed, (ny,nx) / (nz,nx) / (nz,ny); NULL outputs are skipped; a
+ *                         ray without an included sample gives count 0 and NaN (:641-767).
+ *   spc_spectral_conv_f64 / spc_spatial_conv_f64: spectral_smooth / spatial_smooth (:880-917, :962-993); host taps.
+ *                         spatial: separable != 0 takes the two factors h_ky (nky) and h_kx (nkx) of an outer-product
+ *                         kernel; separable == 0 takes h_ky = the (nky, nkx) table, row-major, and ignores h_kx.
+ *   spc_spectral_lerp_f64: spectral_interpolate (:1342-1353), the plan of spc_spectral_lerp_f32.
+ *   spc_narrow_f64_to_f32: the float32 copy of a float64 cube (what an operator without a float64 form is given).
+ *   spc_mask_include_f64: spc_mask_include_u8 on a float64 cube. */
+typedef struct spc_stats_outputs_f64 {
+    int32_t* d_count;
+    double* d_min;
+    double* d_max;
+    double* d_sum;
+    double* d_sumsq;
+} spc_stats_outputs_f64;
+int spc_stats_global_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
+                         double* h_stats, void* d_workspace, size_t workspace_bytes);
+int spc_stats_axis_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
+                       int axis, const spc_stats_outputs_f64* out);
+int spc_spectral_conv_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
+                          const double* h_kernel, int ntaps, double* d_out, int64_t out_row_stride,
+                          int64_t out_plane_stride, void* d_workspace, size_t workspace_bytes);
+int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
+                         const double* h_ky, int nky, const double* h_kx, int nkx, int separable,
+                         double* d_out, int64_t out_row_stride, int64_t out_plane_stride,
+                         void* d_workspace, size_t workspace_bytes);
+int spc_spectral_lerp_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
+                          int64_t nz_out, const int32_t* d_lo, const double* d_t, const double* d_inv_dx,
+                          double fill, double* d_out, int64_t out_row_stride, int64_t out_plane_stride);
+int spc_narrow_f64_to_f32(int device, void* stream, const spc_cube_f64* cube, float* d_out,
+                          int64_t out_row_stride, int64_t out_plane_stride);
+int spc_mask_include_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
+                         int nan_excluded, uint8_t* d_out);
 
 /* ---- FITS payload -> float32 -------------------
  * Converts n raw big-endian FITS image samples (already in HBM) to native

@@ -27,7 +27,7 @@ MAP_MUL, MAP_SECOND_MOMENT_SUM, MAP_DIV_ADD, MAP_DIV_SUB_SQ = 0, 1, 2, 3
 # spc_ws_kind
 (WS_MOMENTS, WS_SPECTRAL_CONV, WS_SPECTRAL_CONV_MOMENTS, WS_SPATIAL_CONV_SEP, WS_SPATIAL_CONV2D, WS_RESAMPLE_BILINEAR,
  WS_STATS_GLOBAL, WS_STATS_PLANES, WS_MAP_CONV2D, WS_CLIP_OUTSIDE, WS_PERCENTILE_GLOBAL, WS_SPATIAL_CONV_MFMA, WS_SIGMA_CLIP,
- WS_RESAMPLE_BILINEAR_LERP) = range(14)
+ WS_RESAMPLE_BILINEAR_LERP, WS_STATS_GLOBAL_F64, WS_SPECTRAL_CONV_F64, WS_SPATIAL_CONV_F64) = range(17)
 
 
 class HipLibraryError(RuntimeError):
@@ -147,6 +147,13 @@ SIGNATURES = {
     # (spc_cube_f64 has the layout of spc_cube_f32: a pointer and five int64)
     "spc_moments_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _vp, _d, _d, _P(SpcMomentOutputs64)]),
     "spc_moment_order_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _vp, _i, _vp, _vp, _vp, _i64]),
+    "spc_stats_global_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _P(_d), _vp, _sz]),
+    "spc_stats_axis_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _i, _P(SpcStatsOutputs)]),
+    "spc_spectral_conv_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _P(_d), _i, _vp, _i64, _i64, _vp, _sz]),
+    "spc_spatial_conv_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _P(_d), _i, _P(_d), _i, _i, _vp, _i64, _i64, _vp, _sz]),
+    "spc_spectral_lerp_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _i64, _vp, _vp, _vp, _d, _vp, _i64, _i64]),
+    "spc_narrow_f64_to_f32": (_i, [_i, _vp, _P(SpcCube), _vp, _i64, _i64]),
+    "spc_mask_include_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _i, _vp]),
     "spc_moments_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _d, _vp, _vp, _vp]),
     "spc_moment_order_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _i, _vp, _vp]),
     "spc_spectral_conv_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _P(_d), _i, _vp, _i64, _i64, _vp, _sz]),

@@ -102,6 +102,7 @@ size_t spc_ws_resample_bilinear_lerp(int64_t nz, int64_t ny_out, int64_t nx_out)
 size_t spc_ws_stats(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 size_t spc_ws_percentile_global(void);
 size_t spc_ws_sigma_clip(void);
+size_t spc_ws_wide(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 size_t spc_ws_spatial_conv_mfma(int64_t nz, int64_t ny, int64_t nx, int64_t nsum);
 int spc_spatial_conv_split_store(int device, void* stream, const spc_cube_f32* cube, const spc_mask* mask, const double* h_ky, int nky,
                                  const double* h_kx, int nkx, float* d_out, int64_t out_row_stride, int64_t out_plane_stride);

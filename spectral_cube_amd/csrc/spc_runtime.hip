@@ -113,6 +113,8 @@ size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t
         case SPC_WS_SPATIAL_CONV_MFMA: return spc_ws_spatial_conv_mfma(nz, ny, nx, p0);    /* p0 = 3: with moments 1 / 2 */
         case SPC_WS_SIGMA_CLIP: return spc_ws_sigma_clip();
         case SPC_WS_RESAMPLE_BILINEAR_LERP: return spc_ws_resample_bilinear_lerp(nz, p0, p1);
+        case SPC_WS_STATS_GLOBAL_F64: case SPC_WS_SPECTRAL_CONV_F64: case SPC_WS_SPATIAL_CONV_F64:
+            return spc_ws_wide(kind, nz, ny, nx, p0, p1);
     }
     return 0;
 }

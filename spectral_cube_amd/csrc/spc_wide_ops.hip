@@ -1,0 +1,513 @@
+// spc_wide_ops.hip - the operators next to the moments for float64 cubes (gfx950).
+//
+// The reference keeps a float64 source in float64 through every operator (np.result_type(dtype, 0.0),
+// spectral_cube/masks.py:225; the Dask class keeps the chunk dtype, dask_spectral_cube.py:829): statistics() and the
+// nan-reductions (dask_spectral_cube.py:641-814), spectral_smooth (:880-917), spatial_smooth (:962-993),
+// spectral_interpolate (:1342-1353).  Rounds 1 - 4 narrowed such cubes to float32 on their way to HBM for everything but
+// the spectral moments (spc_moments_f64.hip).  These kernels read and write the samples as they are: 8 bytes per voxel,
+// thresholds compared in float64, sums in float64 - the arithmetic of the float32 kernels (astropy's convolve: float64
+// top / bot, one division; scipy's interp1d slope form) without the final rounding to float32.
+//
+// They are plain HBM streams (lanes along x) and NOT tuned like the float32 stencils: float64 cubes are outside
+// BASELINE.json's configurations; what matters here is that a float64 cube gives the reference's float64 values.
+#include "spc_common.h"
+#include "spc_wide.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace {
+
+struct Cube64 {
+    const double* p;
+    int64_t nz, ny, nx, row_stride, plane_stride;
+};
+
+__device__ __forceinline__ bool inc64(const Cube64& c, const MaskDev64& m, int64_t z, int64_t y, int64_t x, double& v) {
+    v = c.p[z * c.plane_stride + y * c.row_stride + x];
+    bool ok = pred64(m, v);
+    if (m.flags & SPC_MASK_ARRAY) ok = ok && m.arr[z * m.plane_stride + y * m.row_stride + x] != 0;
+    return ok;
+}
+
+// ---- statistics ---------------------------------------------------------------------------------------------
+struct Rec64 { double n, mn, mx, s, q; };
+__device__ __forceinline__ void rec_add(Rec64& r, double v) {
+    r.n += 1.0; r.mn = fmin(r.mn, v); r.mx = fmax(r.mx, v); r.s += v; r.q = fma(v, v, r.q);
+}
+__device__ __forceinline__ void rec_merge(Rec64& a, const Rec64& b) {
+    a.n += b.n; a.mn = fmin(a.mn, b.mn); a.mx = fmax(a.mx, b.mx); a.s += b.s; a.q += b.q;
+}
+__device__ __forceinline__ Rec64 rec_empty() { return Rec64{0.0, INFINITY, -INFINITY, 0.0, 0.0}; }
+__device__ __forceinline__ Rec64 rec_shfl_down(const Rec64& r, int d) {
+    return Rec64{__shfl_down(r.n, d, 64), __shfl_down(r.mn, d, 64), __shfl_down(r.mx, d, 64), __shfl_down(r.s, d, 64), __shfl_down(r.q, d, 64)};
+}
+// block of 256: lane partials -> one record in thread 0 (fixed order: the result does not depend on scheduling)
+__device__ __forceinline__ Rec64 rec_block_reduce(Rec64 r, Rec64* sh) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const Rec64 o = rec_shfl_down(r, d); rec_merge(r, o); }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) for (int k = 1; k < (int)(blockDim.x >> 6); ++k) rec_merge(r, sh[k]);
+    return r;
+}
+
+// rows of the cube (nz * ny of them) dealt to the blocks round robin; partial[b] = the block's record
+__global__ __launch_bounds__(256) void stats64_global_kernel(const Cube64 C, const MaskDev64 M, Rec64* partial) {
+    __shared__ Rec64 sh[4];
+    Rec64 r = rec_empty();
+    const int64_t nrows = C.nz * C.ny;
+    for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int64_t z = row / C.ny, y = row - z * C.ny;
+        for (int64_t x = threadIdx.x; x < C.nx; x += blockDim.x) {
+            double v;
+            if (inc64(C, M, z, y, x, v)) rec_add(r, v);
+        }
+    }
+    r = rec_block_reduce(r, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void stats64_finish_kernel(const Rec64* partial, int nblocks, double* out) {
+    __shared__ Rec64 sh[4];
+    Rec64 r = rec_empty();
+    for (int k = threadIdx.x; k < nblocks; k += blockDim.x) rec_merge(r, partial[k]);
+    r = rec_block_reduce(r, sh);
+    if (threadIdx.x == 0) {
+        out[0] = r.n; out[1] = r.n > 0 ? r.mn : NAN; out[2] = r.n > 0 ? r.mx : NAN; out[3] = r.s; out[4] = r.q;
+    }
+}
+
+struct StatOut64 {
+    int32_t* count; double* mn; double* mx; double* sum; double* sumsq;
+};
+__device__ __forceinline__ void stat_store(const StatOut64& O, int64_t o, const Rec64& r) {
+    const bool any = r.n > 0;
+    if (O.count) O.count[o] = (int32_t)r.n;
+    if (O.mn) O.mn[o] = any ? r.mn : NAN;
+    if (O.mx) O.mx[o] = any ? r.mx : NAN;
+    if (O.sum) O.sum[o] = any ? r.s : NAN;              // nansum_allbadtonan (dask_spectral_cube.py:54-59)
+    if (O.sumsq) O.sumsq[o] = any ? r.q : NAN;
+}
+// AXIS 0: a lane per (y, x), marching z; AXIS 1: a lane per (z, x), marching y - lanes along x either way
+template <int AXIS>
+__global__ __launch_bounds__(256) void stats64_march_kernel(const Cube64 C, const MaskDev64 M, const StatOut64 O) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nouter = AXIS == 0 ? C.ny : C.nz;
+    if (g >= nouter * C.nx) return;
+    const int64_t a = g / C.nx, x = g - a * C.nx;
+    const int64_t n = AXIS == 0 ? C.nz : C.ny;
+    Rec64 r = rec_empty();
+    for (int64_t k = 0; k < n; ++k) {
+        double v;
+        const bool ok = AXIS == 0 ? inc64(C, M, k, a, x, v) : inc64(C, M, a, k, x, v);
+        if (ok) rec_add(r, v);
+    }
+    stat_store(O, g, r);
+}
+// AXIS 2: a wave per row (z, y)
+__global__ __launch_bounds__(256) void stats64_rows_kernel(const Cube64 C, const MaskDev64 M, const StatOut64 O) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= C.nz * C.ny) return;
+    const int64_t z = row / C.ny, y = row - z * C.ny;
+    Rec64 r = rec_empty();
+    for (int64_t x = threadIdx.x & 63; x < C.nx; x += 64) {
+        double v;
+        if (inc64(C, M, z, y, x, v)) rec_add(r, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const Rec64 o = rec_shfl_down(r, d); rec_merge(r, o); }
+    if ((threadIdx.x & 63) == 0) stat_store(O, row, r);
+}
+
+// ---- spectral_smooth ------------------------------------------------------------------------------------------
+// astropy.convolution.convolve(boundary='fill', fill_value=0, nan_treatment='interpolate', normalize_kernel=True) along z:
+// out = sum k d [valid] / sum k [valid], samples outside the cube are VALID zeros, taps equal to 0 are skipped (astropy's loop
+// multiplies them: 0 x finite = 0 there too; an infinite sample under a zero tap is the one case kept apart), an empty
+// window gives the filled centre sample.  A lane owns one spaxel and produces RUN consecutive channels at a time from the
+// ntaps + RUN - 1 input planes of the run (each read once per run; the halo of the next run comes from the L2).
+constexpr int kRun = 16;
+struct Conv64Args {
+    Cube64 c;
+    MaskDev64 m;
+    double* out;
+    int64_t out_row_stride, out_plane_stride;
+    const double* kern;      // ntaps
+    int ntaps;
+};
+__global__ __launch_bounds__(256) void spectral_conv64_kernel(const Conv64Args A) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.c.ny * A.c.nx) return;
+    const int64_t y = g / A.c.nx, x = g - y * A.c.nx;
+    const int H = A.ntaps / 2;
+    const int64_t o0 = (int64_t)blockIdx.y * kRun;
+    double num[kRun], den[kRun];
+#pragma unroll
+    for (int u = 0; u < kRun; ++u) { num[u] = 0.0; den[u] = 0.0; }
+    // astropy's order: the flipped kernel is walked from its first element, i.e. the inputs of an output from the lowest channel up
+    for (int64_t i = o0 - H; i <= o0 + kRun - 1 + H; ++i) {
+        double v = 0.0, w = 1.0;
+        if (i >= 0 && i < A.c.nz) {
+            const bool ok = inc64(A.c, A.m, i, y, x, v);
+            if (!ok) { v = 0.0; w = 0.0; }
+        }
+#pragma unroll
+        for (int u = 0; u < kRun; ++u) {
+            const int64_t j = (o0 + u) - i + H;                 // weight kern[o - i + H] (true convolution)
+            if (j >= 0 && j < A.ntaps) {                        // (wave-uniform)
+                const double kw = A.kern[j];
+                if (kw != 0.0) { num[u] = fma(kw, v, num[u]); den[u] = fma(kw, w, den[u]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kRun; ++u) {
+        const int64_t o = o0 + u;
+        if (o >= A.c.nz) break;
+        double res;
+        if (den[u] != 0.0) res = num[u] / den[u];
+        else { double cv; res = inc64(A.c, A.m, o, y, x, cv) ? cv : NAN; }
+        A.out[o * A.out_plane_stride + y * A.out_row_stride + x] = res;
+    }
+}
+
+// ---- spatial_smooth -------------------------------------------------------------------------------------------
+// Per channel, the same convolution in 2-D.  An outer-product kernel runs as two passes over a slab of planes: the x pass
+// leaves (sum kx d [valid], sum kx [valid]) per voxel in the caller's workspace, the y pass combines them and divides;
+// any other kernel is summed directly (nky x nkx taps per output, neighbours from the caches).
+struct Sp64Args {
+    Cube64 c;
+    MaskDev64 m;
+    double* out;
+    int64_t out_row_stride, out_plane_stride;
+    const double* ky; const double* kx;     // separable: the two factors; direct: ky = the 2-D table, kx unused
+    int nky, nkx;
+    double* tmp;                            // (planes, ny, nx, 2) of the slab
+    int64_t z0;                             // first plane of the slab
+};
+__global__ __launch_bounds__(256) void spatial64_xpass_kernel(const Sp64Args A) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t y = blockIdx.y, zl = blockIdx.z, z = A.z0 + zl;
+    if (x >= A.c.nx) return;
+    const int H = A.nkx / 2;
+    double num = 0.0, den = 0.0;
+    for (int j = 0; j < A.nkx; ++j) {                            // astropy's order along the fast axis
+        const double kw = A.kx[A.nkx - 1 - j];                   // flipped kernel, input x - H + j
+        if (kw == 0.0) continue;
+        const int64_t i = x - H + j;
+        double v = 0.0, w = 1.0;
+        if (i >= 0 && i < A.c.nx) {
+            if (!inc64(A.c, A.m, z, y, i, v)) { v = 0.0; w = 0.0; }
+        }
+        num = fma(kw, v, num); den = fma(kw, w, den);
+    }
+    double* t = A.tmp + ((zl * A.c.ny + y) * A.c.nx + x) * 2;
+    t[0] = num; t[1] = den;
+}
+__global__ __launch_bounds__(256) void spatial64_ypass_kernel(const Sp64Args A) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t y = blockIdx.y, zl = blockIdx.z, z = A.z0 + zl;
+    if (x >= A.c.nx) return;
+    const int H = A.nky / 2;
+    // a row outside the image is a row of valid zeros: its x-pass denominator is the whole x kernel
+    double ksx = 0.0;
+    for (int j = 0; j < A.nkx; ++j) ksx += A.kx[j];
+    double num = 0.0, den = 0.0;
+    for (int j = 0; j < A.nky; ++j) {
+        const double kw = A.ky[A.nky - 1 - j];
+        if (kw == 0.0) continue;
+        const int64_t i = y - H + j;
+        double tn = 0.0, td = ksx;
+        if (i >= 0 && i < A.c.ny) {
+            const double* t = A.tmp + ((zl * A.c.ny + i) * A.c.nx + x) * 2;
+            tn = t[0]; td = t[1];
+        }
+        num = fma(kw, tn, num); den = fma(kw, td, den);
+    }
+    double res;
+    if (den != 0.0) res = num / den;
+    else { double cv; res = inc64(A.c, A.m, z, y, x, cv) ? cv : NAN; }
+    A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
+}
+__global__ __launch_bounds__(256) void spatial64_direct_kernel(const Sp64Args A) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t y = blockIdx.y, z = A.z0 + blockIdx.z;
+    if (x >= A.c.nx) return;
+    const int Hy = A.nky / 2, Hx = A.nkx / 2;
+    double num = 0.0, den = 0.0;
+    for (int jy = 0; jy < A.nky; ++jy) {
+        const int64_t iy = y - Hy + jy;
+        for (int jx = 0; jx < A.nkx; ++jx) {
+            const double kw = A.ky[(A.nky - 1 - jy) * A.nkx + (A.nkx - 1 - jx)];
+            if (kw == 0.0) continue;
+            const int64_t ix = x - Hx + jx;
+            double v = 0.0, w = 1.0;
+            if (iy >= 0 && iy < A.c.ny && ix >= 0 && ix < A.c.nx) {
+                if (!inc64(A.c, A.m, z, iy, ix, v)) { v = 0.0; w = 0.0; }
+            }
+            num = fma(kw, v, num); den = fma(kw, w, den);
+        }
+    }
+    double res;
+    if (den != 0.0) res = num / den;
+    else { double cv; res = inc64(A.c, A.m, z, y, x, cv) ? cv : NAN; }
+    A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
+}
+
+// ---- spectral_interpolate -------------------------------------------------------------------------------------
+struct Lerp64Args {
+    Cube64 c;
+    MaskDev64 m;
+    int64_t nz_out;
+    const int32_t* lo; const double* t; const double* inv_dx;
+    double fill;
+    double* out;
+    int64_t out_row_stride, out_plane_stride, jchunk;
+};
+__global__ __launch_bounds__(256) void spectral_lerp64_kernel(const Lerp64Args A) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= A.c.ny * A.c.nx) return;
+    const int64_t y = g / A.c.nx, x = g - y * A.c.nx;
+    const int64_t jb = (int64_t)blockIdx.y * A.jchunk, je = min(A.nz_out, jb + A.jchunk);
+    int cur = -2;
+    double ylo = NAN, yhi = NAN;
+    for (int64_t j = jb; j < je; ++j) {
+        const int lo = A.lo[j];
+        double res = A.fill;
+        if (lo >= 0) {
+            if (lo != cur) {
+                double v;
+                if (lo == cur + 1) ylo = yhi; else ylo = inc64(A.c, A.m, lo, y, x, v) ? v : NAN;
+                yhi = inc64(A.c, A.m, lo + 1, y, x, v) ? v : NAN;
+                cur = lo;
+            }
+            // scipy: slope = (y_hi - y_lo) / (x_hi - x_lo); y = slope * (x_new - x_lo) + y_lo
+            res = (yhi - ylo) * A.inv_dx[j] * A.t[j] + ylo;
+        }
+        A.out[j * A.out_plane_stride + y * A.out_row_stride + x] = res;
+    }
+}
+
+// ---- small elementwise helpers --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void narrow64_kernel(const Cube64 C, float* out, int64_t out_row_stride, int64_t out_plane_stride) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t y = blockIdx.y, z = blockIdx.z;
+    if (x >= C.nx) return;
+    out[z * out_plane_stride + y * out_row_stride + x] = (float)C.p[z * C.plane_stride + y * C.row_stride + x];
+}
+__global__ __launch_bounds__(256) void include64_kernel(const Cube64 C, const MaskDev64 M, int nan_excluded, uint8_t* out) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t y = blockIdx.y, z = blockIdx.z;
+    if (x >= C.nx) return;
+    double v;
+    bool ok = inc64(C, M, z, y, x, v);
+    if (!nan_excluded && !(M.flags & ~SPC_MASK_ARRAY) && v != v) {
+        // (without a predicate a NaN sample is included when its mask byte says so: the mask, not the data, is reported)
+        ok = (M.flags & SPC_MASK_ARRAY) ? M.arr[z * M.plane_stride + y * M.row_stride + x] != 0 : true;
+    }
+    out[(z * C.ny + y) * C.nx + x] = ok ? 1 : 0;
+}
+
+static int cube64_args(const spc_cube_f64* cube, const spc_mask_f64* mask, Cube64* C, MaskDev64* M) {
+    int rc = check_cube64(cube);
+    if (rc) return rc;
+    rc = mask64_to_dev(mask, cube, M);
+    if (rc) return rc;
+    C->p = cube->d_data; C->nz = cube->nz; C->ny = cube->ny; C->nx = cube->nx;
+    C->row_stride = cube->row_stride; C->plane_stride = cube->plane_stride;
+    return SPC_OK;
+}
+
+}  // namespace
+
+size_t spc_ws_wide(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1) {
+    switch (kind) {
+        case SPC_WS_STATS_GLOBAL_F64: return spc_ws_round(sizeof(Rec64) * 4096) + spc_ws_round(5 * sizeof(double)) + 256;
+        case SPC_WS_SPECTRAL_CONV_F64: return spc_ws_round(sizeof(double) * (size_t)std::max<int64_t>(p0, 1)) + 256;
+        case SPC_WS_SPATIAL_CONV_F64: {
+            // taps + the (num, den) planes of a slab: at most 1 GiB, at least one plane
+            const size_t plane = (size_t)ny * (size_t)nx * 2 * sizeof(double);
+            const size_t slab = std::max<size_t>(plane, std::min<size_t>((size_t)nz * plane, (size_t)1 << 30));
+            return spc_ws_round(sizeof(double) * (size_t)(std::max<int64_t>(p0, 1) * std::max<int64_t>(p1, 1) + p0 + p1)) + spc_ws_round(slab) + 512;
+        }
+    }
+    return 0;
+}
+
+extern "C" {
+
+int spc_stats_global_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, double* h_stats,
+                         void* d_workspace, size_t workspace_bytes) {
+    Cube64 C; MaskDev64 M;
+    int rc = cube64_args(cube, mask, &C, &M);
+    if (rc) return rc;
+    SPC_REQUIRE(h_stats != nullptr, "h_stats is NULL");
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    const int nblocks = (int)std::min<int64_t>(4096, C.nz * C.ny);
+    SPC_WS_TAKE(d_partial, ws, Rec64, 4096);
+    SPC_WS_TAKE(d_out, ws, double, 5);
+    hipLaunchKernelGGL(stats64_global_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, C, M, d_partial);
+    SPC_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stats64_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, nblocks, d_out);
+    SPC_LAUNCH_CHECK();
+    SPC_HIP(hipMemcpyAsync(h_stats, d_out, 5 * sizeof(double), hipMemcpyDeviceToHost, st));
+    SPC_HIP(hipStreamSynchronize(st));
+    return SPC_OK;
+}
+
+int spc_stats_axis_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, int axis,
+                       const spc_stats_outputs_f64* out) {
+    Cube64 C; MaskDev64 M;
+    int rc = cube64_args(cube, mask, &C, &M);
+    if (rc) return rc;
+    SPC_REQUIRE(out != nullptr, "outputs struct is NULL");
+    SPC_REQUIRE(axis >= 0 && axis <= 2, "axis must be 0, 1 or 2, got %d", axis);
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    const StatOut64 O{out->d_count, out->d_min, out->d_max, out->d_sum, out->d_sumsq};
+    if (axis == 2) {
+        const int64_t nb = (C.nz * C.ny + 3) / 4;
+        SPC_REQUIRE(nb < (1LL << 31), "too many rows for one launch");
+        hipLaunchKernelGGL(stats64_rows_kernel, dim3((unsigned)nb), dim3(256), 0, st, C, M, O);
+    } else {
+        const int64_t n = (axis == 0 ? C.ny : C.nz) * C.nx, nb = (n + 255) / 256;
+        SPC_REQUIRE(nb < (1LL << 31), "map too large for one launch");
+        if (axis == 0) hipLaunchKernelGGL(stats64_march_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, C, M, O);
+        else hipLaunchKernelGGL(stats64_march_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, C, M, O);
+    }
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_spectral_conv_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, const double* h_kernel,
+                          int ntaps, double* d_out, int64_t out_row_stride, int64_t out_plane_stride, void* d_workspace,
+                          size_t workspace_bytes) {
+    Conv64Args A{};
+    int rc = cube64_args(cube, mask, &A.c, &A.m);
+    if (rc) return rc;
+    SPC_REQUIRE(h_kernel && d_out, "NULL pointer argument");
+    SPC_REQUIRE(ntaps >= 1 && (ntaps & 1) && ntaps <= 8191, "the kernel needs an odd number of taps in [1, 8191], got %d", ntaps);
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    SPC_WS_TAKE(d_k, ws, double, ntaps);
+    SPC_HIP(spc_table_upload(d_k, h_kernel, sizeof(double) * (size_t)ntaps, st));
+    A.kern = d_k; A.ntaps = ntaps; A.out = d_out;
+    A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
+    const int64_t nb = (cube->ny * cube->nx + 255) / 256, runs = (cube->nz + kRun - 1) / kRun;
+    SPC_REQUIRE(nb < (1LL << 31) && runs <= 65535, "cube too large for one launch (convolve a slab of channels / rows)");
+    hipLaunchKernelGGL(spectral_conv64_kernel, dim3((unsigned)nb, (unsigned)runs), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, const double* h_ky, int nky,
+                         const double* h_kx, int nkx, int separable, double* d_out, int64_t out_row_stride, int64_t out_plane_stride,
+                         void* d_workspace, size_t workspace_bytes) {
+    Sp64Args A{};
+    int rc = cube64_args(cube, mask, &A.c, &A.m);
+    if (rc) return rc;
+    SPC_REQUIRE(h_ky && d_out && (!separable || h_kx), "NULL pointer argument");
+    SPC_REQUIRE(nky >= 1 && (nky & 1) && nkx >= 1 && (nkx & 1) && nky <= 1023 && nkx <= 1023,
+                "kernel axes must be odd and at most 1023 (got %d x %d)", nky, nkx);
+    SPC_REQUIRE(cube->ny <= 65535, "too many rows for one launch");
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    SpcWorkspace ws(d_workspace, workspace_bytes);
+    const size_t ntab = separable ? (size_t)(nky + nkx) : (size_t)nky * (size_t)nkx;
+    SPC_WS_TAKE(d_k, ws, double, ntab);
+    if (separable) {
+        SPC_HIP(spc_table_upload(d_k, h_ky, sizeof(double) * (size_t)nky, st));
+        SPC_HIP(spc_table_upload(d_k + nky, h_kx, sizeof(double) * (size_t)nkx, st));
+        A.ky = d_k; A.kx = d_k + nky;
+    } else {
+        SPC_HIP(spc_table_upload(d_k, h_ky, sizeof(double) * ntab, st));
+        A.ky = d_k; A.kx = nullptr;
+    }
+    A.nky = nky; A.nkx = nkx; A.out = d_out;
+    A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
+    const unsigned gx = (unsigned)((cube->nx + 255) / 256);
+    if (!separable) {
+        for (int64_t z0 = 0; z0 < cube->nz; z0 += 65535) {
+            A.z0 = z0;
+            const unsigned gz = (unsigned)std::min<int64_t>(65535, cube->nz - z0);
+            hipLaunchKernelGGL(spatial64_direct_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
+            SPC_LAUNCH_CHECK();
+        }
+        return SPC_OK;
+    }
+    const size_t plane = (size_t)cube->ny * (size_t)cube->nx * 2 * sizeof(double);
+    const size_t avail = ws.size > ws.used + 512 ? ws.size - ws.used - 512 : 0;
+    const int64_t planes = (int64_t)std::min<size_t>(std::min<size_t>(avail / plane, (size_t)cube->nz), 65535);
+    SPC_REQUIRE(planes >= 1, "d_workspace too small: the (num, den) planes of one channel need %zu bytes more (spc_workspace_bytes)", plane);
+    SPC_WS_TAKE(d_tmp, ws, double, (size_t)planes * (size_t)cube->ny * (size_t)cube->nx * 2);
+    A.tmp = d_tmp;
+    for (int64_t z0 = 0; z0 < cube->nz; z0 += planes) {
+        A.z0 = z0;
+        const unsigned gz = (unsigned)std::min<int64_t>(planes, cube->nz - z0);
+        hipLaunchKernelGGL(spatial64_xpass_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
+        SPC_LAUNCH_CHECK();
+        hipLaunchKernelGGL(spatial64_ypass_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
+        SPC_LAUNCH_CHECK();
+    }
+    return SPC_OK;
+}
+
+int spc_spectral_lerp_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, int64_t nz_out,
+                          const int32_t* d_lo, const double* d_t, const double* d_inv_dx, double fill, double* d_out,
+                          int64_t out_row_stride, int64_t out_plane_stride) {
+    Lerp64Args A{};
+    int rc = cube64_args(cube, mask, &A.c, &A.m);
+    if (rc) return rc;
+    SPC_REQUIRE(nz_out > 0 && d_lo && d_t && d_inv_dx && d_out, "NULL pointer argument / nz_out must be positive");
+    SPC_DEVICE(device);
+    A.nz_out = nz_out; A.lo = d_lo; A.t = d_t; A.inv_dx = d_inv_dx; A.fill = fill; A.out = d_out;
+    A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
+    const int64_t nb = (cube->ny * cube->nx + 255) / 256;
+    SPC_REQUIRE(nb < (1LL << 31), "map too large for one launch");
+    int nsplit = 1;
+    if (nb < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nb - 1) / nb, nz_out / 8));
+    A.jchunk = (nz_out + nsplit - 1) / nsplit;
+    nsplit = (int)((nz_out + A.jchunk - 1) / A.jchunk);
+    hipLaunchKernelGGL(spectral_lerp64_kernel, dim3((unsigned)nb, (unsigned)nsplit), dim3(256), 0, (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_narrow_f64_to_f32(int device, void* stream, const spc_cube_f64* cube, float* d_out, int64_t out_row_stride,
+                          int64_t out_plane_stride) {
+    Cube64 C; MaskDev64 M;
+    int rc = cube64_args(cube, nullptr, &C, &M);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    SPC_REQUIRE(cube->ny <= 65535 && cube->nz <= 65535, "too many rows / channels for one launch");
+    SPC_DEVICE(device);
+    const int64_t rs = out_row_stride ? out_row_stride : cube->nx, ps = out_plane_stride ? out_plane_stride : cube->ny * rs;
+    hipLaunchKernelGGL(narrow64_kernel, dim3((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)cube->nz), dim3(256), 0,
+                       (hipStream_t)stream, C, d_out, rs, ps);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_mask_include_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, int nan_excluded,
+                         uint8_t* d_out) {
+    Cube64 C; MaskDev64 M;
+    int rc = cube64_args(cube, mask, &C, &M);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    SPC_REQUIRE(cube->ny <= 65535 && cube->nz <= 65535, "too many rows / channels for one launch");
+    SPC_DEVICE(device);
+    hipLaunchKernelGGL(include64_kernel, dim3((unsigned)((cube->nx + 255) / 256), (unsigned)cube->ny, (unsigned)cube->nz), dim3(256), 0,
+                       (hipStream_t)stream, C, M, nan_excluded, d_out);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+}  // extern "C"

@@ -237,6 +237,102 @@ def moment_order_f64(cube, cen, order, mu, s0, mask=None, stream=None):
     return out
 
 
+# ---- the other operators of a float64 cube (spc_wide_ops.hip; the reference keeps float64, masks.py:225) -------------------
+def stats_global_f64(cube, mask=None, stream=None):
+    """stats_global of a float64 cube (spc_stats_global_f64): min / max are float64 samples, thresholds compared in float64"""
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    h = (C.c_double * 5)()
+    ws, wsn = workspace(cube.device, stream, _lib.WS_STATS_GLOBAL_F64, *cube.shape)
+    _lib.call("spc_stats_global_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), h, ws, wsn)
+    return {"npts": h[0], "min": h[1], "max": h[2], "sum": h[3], "sumsq": h[4]}
+
+
+def stats_axis_f64(cube, axis, mask=None, want=("count", "min", "max", "sum", "sumsq"), stream=None):
+    """stats_axis of a float64 cube (spc_stats_axis_f64): every map but the int32 count is float64"""
+    if axis not in (0, 1, 2):
+        raise ValueError("axis must be 0, 1 or 2")
+    shp = tuple(n for i, n in enumerate(cube.shape) if i != axis)
+    res = {k: DeviceArray(shp, np.int32 if k == "count" else np.float64, cube.device) for k in want}
+    o = _lib.SpcStatsOutputs()
+    for k in want:
+        setattr(o, "d_" + k, res[k].ptr)
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    _lib.call("spc_stats_axis_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), int(axis), C.byref(o))
+    return res
+
+
+def spectral_conv_f64(cube, kernel1d, mask=None, out=None, stream=None):
+    """spectral_conv of a float64 cube: float64 in, float64 out (the Dask class keeps the chunk dtype,
+    dask_spectral_cube.py:829, :880-917)"""
+    if out is None:
+        out = DeviceArray(cube.shape, np.float64, cube.device)
+    k = np.ascontiguousarray(kernel1d, dtype=np.float64)
+    if k.ndim != 1:
+        raise ValueError("kernel must be 1-D")
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_SPECTRAL_CONV_F64, *cube.shape, len(k))
+    _lib.call("spc_spectral_conv_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), k.ctypes.data_as(C.POINTER(C.c_double)),
+              len(k), C.c_void_p(out.ptr), 0, 0, ws, wsn)
+    return out
+
+
+def spatial_conv_f64(cube, kernel2d, mask=None, out=None, stream=None):
+    """spatial_conv of a float64 cube (dask_spectral_cube.py:962-993): an outer-product kernel in two passes, any other
+    kernel summed directly"""
+    if out is None:
+        out = DeviceArray(cube.shape, np.float64, cube.device)
+    k2 = np.ascontiguousarray(kernel2d, dtype=np.float64)
+    if k2.ndim != 2:
+        raise ValueError("kernel must be 2-D")
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    sep = separable_factors(k2)
+    ws, wsn = workspace(cube.device, stream, _lib.WS_SPATIAL_CONV_F64, *cube.shape, k2.shape[0], k2.shape[1])
+    if sep is not None:
+        ky, kx = (np.ascontiguousarray(f, dtype=np.float64) for f in sep)
+        _lib.call("spc_spatial_conv_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), ky.ctypes.data_as(C.POINTER(C.c_double)),
+                  len(ky), kx.ctypes.data_as(C.POINTER(C.c_double)), len(kx), 1, C.c_void_p(out.ptr), 0, 0, ws, wsn)
+    else:
+        _lib.call("spc_spatial_conv_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), k2.ctypes.data_as(C.POINTER(C.c_double)),
+                  k2.shape[0], None, k2.shape[1], 0, C.c_void_p(out.ptr), 0, 0, ws, wsn)
+    return out
+
+
+def spectral_lerp_f64(cube, lo, t, inv_dx, fill=np.nan, mask=None, out=None, stream=None):
+    """spectral_lerp of a float64 cube (scipy's interp1d on float64 samples, dask_spectral_cube.py:1342-1353)"""
+    nz_out = len(lo)
+    dev = cube.device
+    d_lo = DeviceArray.from_numpy(np.asarray(lo, dtype=np.int32), dev)
+    d_t = DeviceArray.from_numpy(np.asarray(t, dtype=np.float64), dev)
+    d_inv = DeviceArray.from_numpy(np.asarray(inv_dx, dtype=np.float64), dev)
+    if out is None:
+        out = DeviceArray((nz_out,) + cube.shape[1:], np.float64, dev)
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    _lib.call("spc_spectral_lerp_f64", dev, _sh(stream), C.byref(c), C.byref(m), nz_out, C.c_void_p(d_lo.ptr), C.c_void_p(d_t.ptr),
+              C.c_void_p(d_inv.ptr), float(fill), C.c_void_p(out.ptr), 0, 0)
+    out._plan = (d_lo, d_t, d_inv)
+    return out
+
+
+def narrow_f64(cube, stream=None):
+    """float32 copy of a float64 DeviceArray (for the operators without a float64 form)"""
+    out = DeviceArray(cube.shape, np.float32, cube.device)
+    nz = cube.shape[0]
+    for z0 in range(0, nz, 65535):
+        z1 = min(nz, z0 + 65535)
+        c = _cube_c64(cube.planes(z0, z1) if (z0, z1) != (0, nz) else cube)
+        _lib.call("spc_narrow_f64_to_f32", cube.device, _sh(stream), C.byref(c),
+                  C.c_void_p(out.ptr + z0 * cube.shape[1] * cube.shape[2] * 4), 0, 0)
+    return out
+
+
+def mask_include_f64(cube, mask=None, nan_excluded=False, stream=None):
+    """mask_include on a float64 cube (spc_mask_include_f64)"""
+    out = DeviceArray(cube.shape, np.uint8, cube.device)
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    _lib.call("spc_mask_include_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), 1 if nan_excluded else 0, C.c_void_p(out.ptr))
+    return out
+
+
 def _given(out, name, shape, dtype, device):
     """out[name] when the caller preallocated it (checked), else a new DeviceArray"""
     a = out.get(name) if out else None
