@@ -77,12 +77,14 @@ class _DataToken:
     with_fill_value, with_spectral_unit): lazy masks compare it (``_is_same_data``), and a wide source keeps what its
     float64 path needs here - the FITS image the samples come from, the float64 device copy, whether the narrowing to
     float32 has been announced."""
-    __slots__ = ("wide_file", "dev64", "warned")
+    __slots__ = ("wide_file", "dev64", "warned", "lazy64", "derived64")
 
     def __init__(self):
         self.wide_file = None        # (path, hdu, bitpix) of a resident BITPIX = -64 / 32 / 64 image
         self.dev64 = None            # float64 DeviceArray, staged by the first spectral moment
         self.warned = False
+        self.lazy64 = None           # pending float64 operator of a cube DERIVED from a wide one (spectral_smooth, ...)
+        self.derived64 = False       # the values exist as a float64 DeviceArray only (dev64 / lazy64): no host array, no file
 
 
 class _WideView:
@@ -96,7 +98,7 @@ class _WideView:
 
     def _host_data(self):
         c = self._cube
-        if c._data_id.wide_file is None:
+        if c._data_id.wide_file is None and c._data is not None:
             return c._data
         return c._device_data64().get()
 
@@ -466,7 +468,12 @@ class SpectralCube:
     # ---- identity used by lazy masks -------------------------------------------
     def _host_data(self):
         if self._data is None:
-            self._data = self._device_data().get()
+            if self._data_id.derived64 or (self._data_id.wide_file is not None and self._dev is None and self._wide_resident()):
+                # the result of a float64 operator / a resident BITPIX = -64 / 32 / 64 image: float64 on the host as well
+                # (what the reference holds, masks.py:225 - host-evaluated mask terms compare these samples)
+                self._data = self._device_data64().get()
+            else:
+                self._data = self._device_data().get()
         return self._data
 
     def _stream_source(self):
@@ -612,7 +619,7 @@ class SpectralCube:
 
     # ---- wide sources (float64 arrays, BITPIX = -64 / 32 / 64 images): the spectral moments in their own precision ------
     def _is_wide(self):
-        if self._data_id.wide_file is not None:
+        if self._data_id.wide_file is not None or self._data_id.derived64:
             return True
         return self._data is not None and _is_wide_dtype(self._data.dtype)
 
@@ -624,12 +631,16 @@ class SpectralCube:
         tok.warned = True
         if tok.wide_file is not None:
             _warn_if_narrowed(bitpix=tok.wide_file[2], stacklevel=stacklevel)
+        elif tok.derived64:
+            _warn_if_narrowed(dtype=np.float64, stacklevel=stacklevel)
         else:
             _warn_if_narrowed(dtype=self._data.dtype, stacklevel=stacklevel)
 
     def _wide_resident(self):
         """True when the spectral moments of this cube run on its float64 samples: a wide source whose values this cube
         still is (no pending operator) and whose float64 copy fits the HBM budget"""
+        if self._data_id.derived64:
+            return True
         if not self._is_wide() or (self._lazy is not None and self._data_id.wide_file is None):
             return False
         if self._data_id.dev64 is not None:
@@ -643,7 +654,10 @@ class SpectralCube:
         tok = self._data_id
         if tok.dev64 is None:
             _lib.require_gpu()
-            if tok.wide_file is not None:
+            if tok.lazy64 is not None:
+                tok.dev64 = tok.lazy64()
+                tok.lazy64 = None
+            elif tok.wide_file is not None:
                 from . import io_fits
                 path, hdu, _ = tok.wide_file
                 tok.dev64 = io_fits.load_cube(path, device=self.device, hdu=hdu, dtype=np.float64)[0]
@@ -654,10 +668,45 @@ class SpectralCube:
     def _mask_spec64(self):
         """the mask lowered for the float64 kernels: thresholds in float64, host-evaluated terms on the float64 samples"""
         if self._mask64_cache is None:
-            flags, lo, hi, arr = M.lower_mask(self._mask, _WideView(self), self._shape)
-            darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
-            self._mask64_cache = ops.MaskSpec(flags, lo, hi, darr)
+            owner = M.foreign_owner(self._mask) if self._mask is not None else None
+            if (owner is not None and not owner._is_same_data(self) and tuple(owner._shape) == tuple(self._shape)
+                    and getattr(owner, "_wide_resident", lambda: False)() and self._mask._device_terms(_WideView(owner)) is not None):
+                # every lazy term belongs to ANOTHER float64 cube's data (a smoothed cube keeps its parent's mask):
+                # evaluated there, on the device, on the float64 samples (as _mask_spec does for float32 cubes)
+                flags, lo, hi, arr = M.lower_mask(self._mask, _WideView(owner), self._shape)
+                darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
+                inc = ops.mask_include_f64(owner._device_data64(), ops.MaskSpec(flags, lo, hi, darr),
+                                           nan_excluded=M.contains(self._mask, M.NotNaNMask))
+                self._mask64_cache = ops.MaskSpec(_lib.MASK_ARRAY, 0.0, 0.0, inc)
+            else:
+                flags, lo, hi, arr = M.lower_mask(self._mask, _WideView(self), self._shape)
+                darr = DeviceArray.from_numpy(arr, self.device) if arr is not None else None
+                self._mask64_cache = ops.MaskSpec(flags, lo, hi, darr)
         return self._mask64_cache
+
+    def _runs_wide(self):
+        """True when a cube -> cube operator of this cube runs on float64 samples: a wide cube that is resident (or fits).
+        Decided without a device where it can be (a float32 cube never asks); no device at all = the float32 plan, which
+        raises when it is run"""
+        if not self._is_wide():
+            return False
+        try:
+            return self._stream_source() is None and self._wide_resident()
+        except _lib.HipLibraryError:
+            return False
+
+    def _new_wide_cube(self, fn64, shape=None, wcs=None, mask=None):
+        """the result of a float64 operator on this (wide, resident) cube: a cube whose values exist as a float64 DeviceArray
+        (pending until first used; the Dask class keeps the chunk dtype, dask_spectral_cube.py:829).  Its spectral moments,
+        reductions, statistics() and further smoothing / interpolation run in float64; an operator without a float64 form
+        narrows it with a PrecisionWarning, like a float64 source."""
+        holder = []
+        narrow = _Thunk(lambda: ops.narrow_f64(holder[0]._device_data64()))
+        out = self._new_cube_with(lazy=narrow, shape=tuple(shape) if shape is not None else self._shape, wcs=wcs, mask=mask)
+        out._data_id.lazy64 = fn64
+        out._data_id.derived64 = True
+        holder.append(out)
+        return out
 
     def _mask_spec(self):
         """lower the mask tree once and keep the uint8 array resident in HBM."""
@@ -1019,6 +1068,8 @@ class SpectralCube:
             if self._stream_source() is not None:
                 from . import streaming
                 st = streaming.statistics(self)
+            elif self._wide_resident():
+                st = ops.stats_global_f64(self._device_data64(), mask=self._mask_spec64())
             else:
                 st = ops.stats_global(self._device_data(), mask=self._mask_spec())
             n = st["npts"]
@@ -1034,7 +1085,8 @@ class SpectralCube:
                 return self._reduce(op, axes[0], ddof)
             if len(axes) != 2 or any(a not in (0, 1, 2) for a in axes):
                 raise ValueError("axis must be None, 0, 1, 2 or a tuple of these")
-            if axes == [1, 2]:                           # per channel (spectra): one dedicated pass, nz records
+            if axes == [1, 2] and not (self._stream_source() is None and self._wide_resident()):
+                # per channel (spectra): one dedicated pass, nz records (a float64 cube: its rows on the device, the rest here)
                 if self._stream_source() is not None:
                     from . import streaming
                     vals = streaming.stats_planes(self)
@@ -1067,6 +1119,8 @@ class SpectralCube:
         if self._stream_source() is not None:          # out of core: strips (axis 0) or slabs of planes (axis 1 / 2)
             from . import streaming
             return streaming.stats_axis(self, axis, need)
+        if self._wide_resident():
+            return ops.stats_axis_f64(self._device_data64(), axis, mask=self._mask_spec64(), want=need)
         return ops.stats_axis(self._device_data(), axis, mask=self._mask_spec(), want=need)
 
     def _finish_reduce(self, op, vals, axis, ddof=0):
@@ -1198,7 +1252,10 @@ class SpectralCube:
         if self._stream_source() is not None:
             from . import streaming
             return streaming.statistics(self)           # per-strip records, combined (same formulae)
-        st = ops.stats_global(self._device_data(), mask=self._mask_spec())
+        if self._wide_resident():
+            st = ops.stats_global_f64(self._device_data64(), mask=self._mask_spec64())
+        else:
+            st = ops.stats_global(self._device_data(), mask=self._mask_spec())
         n = st["npts"]
         with np.errstate(invalid="ignore", divide="ignore"):
             st["mean"] = st["sum"] / n if n else np.nan
@@ -1214,6 +1271,9 @@ class SpectralCube:
         karr = kernel_array(kernel, 1)
         _check_convolve(convolve)
         parent = self
+        if self._runs_wide():
+            # a float64 cube stays float64 (the Dask class keeps the chunk dtype, dask_spectral_cube.py:829)
+            return self._new_wide_cube(lambda: ops.spectral_conv_f64(parent._device_data64(), karr, mask=parent._mask_spec64()))
 
         class _Lazy:
             op = "spectral_smooth"
@@ -1238,6 +1298,8 @@ class SpectralCube:
         karr = kernel_array(kernel, 2)
         _check_convolve(convolve)
         parent = self
+        if self._runs_wide():
+            return self._new_wide_cube(lambda: ops.spatial_conv_f64(parent._device_data64(), karr, mask=parent._mask_spec64()))
 
         class _Lazy:
             op = "spatial_smooth"
@@ -1359,6 +1421,12 @@ class SpectralCube:
         crval = g_sorted[0] if not rout else g_sorted[-1]
         cdelt = outdiff if not rout else -outdiff
         newwcs = self._wcs.with_spectral(crval, cdelt, 1.0)
+        if self._runs_wide():
+            out = self._new_wide_cube(lambda: ops.spectral_lerp_f64(parent._device_data64(), plan[0], plan[1], plan[2], fill,
+                                                                    mask=parent._mask_spec64()),
+                                      shape=(len(grid),) + self._shape[1:], wcs=newwcs, mask=False)
+            out._mask = M.NotNaNMask(out)
+            return out
         thunk = _Thunk(run)
         thunk.parent = parent
         thunk.lerp = (plan, fill)          # (a following reproject folds the interpolation into its resampling kernel)

@@ -550,3 +550,75 @@ def test_reproject_onto_a_cube_header_resamples_all_three_axes_in_one_pass(gpu, 
     exp, foot = O.reproject_separable(d, xs.get(), ys.get(), zs)
     assert_close(got, exp, atol=1e-5 * np.nanmax(np.abs(exp)), what="3-D reproject, one pass")
     assert np.array_equal(out.mask.include(), np.broadcast_to(foot, got.shape))
+
+
+# ---- float64 cubes through the operators next to the moments (spc_wide_ops.hip, ABI 8) ---------------------------------------
+@pytest.mark.parametrize("source", ["file", "array"])
+def test_float64_cube_stays_float64_through_the_other_operators(gpu, tmp_path, source):
+    """A BITPIX = -64 cube (a 2 mK .. 1 K line on a 1000 K baseline) read as the reference reads it (float64, masks.py:225):
+    spectral_smooth, spatial_smooth, spectral_interpolate, statistics() and the nan-reductions against the REFERENCE's own
+    float64 results (tests/golden/wide_ops.npz from the Dask class, which keeps the chunk dtype, dask_spectral_cube.py:829),
+    without and with a `cube > threshold` mask whose threshold float32 cannot represent: 1e-12 of the range, float64 arrays
+    on the host, no PrecisionWarning on the way; and the chain spectral_smooth -> moment (float64 sums of float64 smoothed
+    samples).  An operator without a float64 form narrows the result - and says so."""
+    import warnings as W
+    from spectral_cube_amd import PrecisionWarning, SpectralCube, io_fits
+    from conftest import golden
+    g, g0 = golden("wide_ops.npz"), golden("moments_f64.npz")
+    path = str(tmp_path / "f64.fits")
+    with open(path, "wb") as f:
+        f.write(g0["f64_file"].tobytes())
+    k1, k2, grid, thr = g["k1"], g["k2"], g["grid"], float(g["thr"])
+
+    def close(got, exp, what, rtol=1e-12):
+        got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+        assert got.shape == exp.shape and np.array_equal(np.isnan(got), np.isnan(exp)), what
+        ok = ~np.isnan(exp)
+        if ok.any():
+            assert np.abs(got[ok] - exp[ok]).max() <= rtol * np.abs(exp[ok]).max(), (what, np.abs(got[ok] - exp[ok]).max())
+
+    with W.catch_warnings():
+        W.simplefilter("error", PrecisionWarning)
+        if source == "file":
+            cube = SpectralCube.read(path)
+        else:
+            cube = SpectralCube.read(g["data"], io_fits.cube_header(io_fits.find_image(path)))
+        for tag, c in (("u", cube), ("m", cube.with_mask(cube > thr))):
+            sm = c.spectral_smooth(k1)
+            got = sm.unmasked_data
+            assert got.dtype == np.float64
+            close(got, g["spectral_smooth_" + tag], "spectral_smooth " + tag)
+            assert np.array_equal(sm.mask.include(), g["include_" + tag].astype(bool))           # the mask is the parent's
+            sp = c.spatial_smooth(k2)
+            assert sp.unmasked_data.dtype == np.float64
+            close(sp.unmasked_data, g["spatial_smooth_" + tag], "spatial_smooth " + tag)
+            it = c.spectral_interpolate(grid, suppress_smooth_warning=True)
+            assert it.unmasked_data.dtype == np.float64 and it.shape[0] == len(grid)
+            close(it.unmasked_data, g["spectral_interpolate_" + tag], "spectral_interpolate " + tag, rtol=1e-13)
+            st = c.statistics()
+            assert st["npts"] == int(g["stat_npts_" + tag]) and st["min"] == float(g["stat_min_" + tag]) and st["max"] == float(g["stat_max_" + tag])
+            for key in ("sum", "sumsq", "mean", "rms"):
+                assert abs(st[key] - float(g["stat_%s_%s" % (key, tag)])) <= 1e-12 * abs(float(g["stat_%s_%s" % (key, tag)])), key
+            # sigma = sqrt(sumsq / n - mean^2 ...) of samples around 1000 with a spread of < 1: cancellation costs (1000 / sigma)^2 ulps
+            assert abs(st["sigma"] - float(g["stat_sigma_" + tag])) <= 1e-6 * float(g["stat_sigma_" + tag])
+            for op in ("sum", "mean", "max", "min"):
+                for ax in (None, 0, 1, 2):
+                    close(getattr(c, op)(axis=ax), g["%s_ax%s_%s" % (op, "N" if ax is None else ax, tag)], "%s axis %s %s" % (op, ax, tag))
+            close(c.mean(axis=(1, 2)), np.asarray(O.reduce(g["data"], g["include_" + tag].astype(bool), "mean", axis=(1, 2))), "mean spectrum " + tag)
+            # the chain: moments of the smoothed cube, float64 all the way
+            for order in (0, 1):
+                close(sm.moment(order=order), g["smooth_mom%d_%s" % (order, tag)], "smooth -> moment%d %s" % (order, tag), rtol=1e-11)
+            # ... and two operators in a row
+            close(sm.spatial_smooth(k2).unmasked_data, O.spatial_smooth(g["spectral_smooth_" + tag], g["include_" + tag].astype(bool), k2),
+                  "spectral_smooth -> spatial_smooth " + tag)
+        assert cube._dev is None                                  # nothing was staged as float32
+    # an operator without a float64 form narrows the smoothed cube, with the warning
+    sm = cube.spectral_smooth(k1)
+    with pytest.warns(PrecisionWarning, match="narrowed to float32"):
+        med = np.asarray(sm.median(axis=0))
+    exp = np.nanmedian(np.where(g["include_u"].astype(bool), g["spectral_smooth_u"], np.nan).astype(np.float32), axis=0)
+    assert np.array_equal(med, exp, equal_nan=True)
+    # what the narrowing would have cost: the smoothed line against float32's ulp at the baseline
+    narrow = ops.spectral_conv(DeviceArray.from_numpy(g["data"].astype(np.float32)), k1).get().astype(np.float64)
+    ok = np.isfinite(g["spectral_smooth_u"])
+    assert np.abs(narrow[ok] - g["spectral_smooth_u"][ok]).max() > 1e-6

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout 900 python tools/test_wide_ops.py > gpurun_out/r05s6_wide_ops.txt 2>&1
-grep -v "^ok" gpurun_out/r05s6_wide_ops.txt | tail -40; grep -c "^ok" gpurun_out/r05s6_wide_ops.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error|Error|^FAILED|assert" | tail -8 > gpurun_out/r05s6_t.txt
+cat gpurun_out/r05s6_t.txt
