@@ -278,6 +278,13 @@ int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, con
 int spc_spectral_lerp_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
                           int64_t nz_out, const int32_t* d_lo, const double* d_t, const double* d_inv_dx,
                           double fill, double* d_out, int64_t out_row_stride, int64_t out_plane_stride);
+/* spc_resample_bilinear_f32 on a float64 cube: float64 weights and results (reproject_interp computes in float64), gather
+ * form; spc_scale_f64: d_data[i] *= factor (the Jy/beam area ratio of convolve_to, dask_spectral_cube.py:1445-1464). */
+int spc_resample_bilinear_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
+                              double fill, int64_t ny_out, int64_t nx_out, const double* d_xs, const double* d_ys,
+                              double* d_out, int64_t out_row_stride, int64_t out_plane_stride,
+                              uint8_t* d_footprint, int order, uint32_t* d_any_valid);
+int spc_scale_f64(int device, void* stream, double* d_data, int64_t n, double factor);
 int spc_narrow_f64_to_f32(int device, void* stream, const spc_cube_f64* cube, float* d_out,
                           int64_t out_row_stride, int64_t out_plane_stride);
 int spc_mask_include_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,

@@ -290,6 +290,66 @@ __global__ __launch_bounds__(256) void spectral_lerp64_kernel(const Lerp64Args A
     }
 }
 
+// ---- reproject: bilinear / nearest resampling --------------------------------------------------------------------
+// bilinear_kernel's semantics (scipy map_coordinates(order = 1 | 0) on the edge-replicated image, NaN outside [-0.5, n - 0.5],
+// a NaN neighbour propagates even with weight 0) with float64 samples, float64 weights and a float64 result.  Gather form:
+// a lane per output pixel of a compact 16 x 4 tile per wave, marching the channels.
+struct Bil64Args {
+    Cube64 c;
+    MaskDev64 m;
+    double fill;
+    int64_t ny_out, nx_out;
+    const double* xs; const double* ys;
+    double* out;
+    int64_t out_row_stride, out_plane_stride, zchunk;
+    uint8_t* footprint;
+    int nearest;
+    unsigned int* any_valid;
+};
+__global__ __launch_bounds__(256) void bilinear64_kernel(const Bil64Args A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tiles_x = (A.nx_out + 63) / 64;
+    const int64_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int64_t xo = bx * 64 + (wave * 16) + (lane & 15), yo = by * 4 + (lane >> 4);
+    if (xo >= A.nx_out || yo >= A.ny_out) return;
+    const int64_t pix = yo * A.nx_out + xo;
+    const double xs = A.xs[pix], ys = A.ys[pix];
+    const bool inside = (xs >= -0.5) && (xs <= (double)A.c.nx - 0.5) && (ys >= -0.5) && (ys <= (double)A.c.ny - 0.5);
+    if (blockIdx.y == 0 && A.footprint) A.footprint[pix] = inside ? 1 : 0;
+    const int64_t zb = (int64_t)blockIdx.y * A.zchunk, ze = min(A.c.nz, zb + A.zchunk);
+    double* po = A.out + yo * A.out_row_stride + xo;
+    if (!inside) {
+        for (int64_t z = zb; z < ze; ++z) po[z * A.out_plane_stride] = NAN;
+        return;
+    }
+    const double xf = A.nearest ? floor(xs + 0.5) : floor(xs), yf = A.nearest ? floor(ys + 0.5) : floor(ys);
+    const int64_t x0 = min(max((int64_t)xf, (int64_t)0), A.c.nx - 1), y0 = min(max((int64_t)yf, (int64_t)0), A.c.ny - 1);
+    const int64_t x1 = A.nearest ? x0 : min((int64_t)xf + 1, A.c.nx - 1), y1 = A.nearest ? y0 : min((int64_t)yf + 1, A.c.ny - 1);
+    const double fx = xs - xf, fy = ys - yf;
+    const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
+    bool anyv = false;
+    for (int64_t z = zb; z < ze; ++z) {
+        // excluded voxels are replaced by the cube's fill value (spectral_cube.py:2709-2712); a NaN sample that an array-only
+        // mask includes stays what it is (np.where(include, data, fill))
+        auto get = [&](int64_t yy, int64_t xx) {
+            double v;
+            bool ok = inc64(A.c, A.m, z, yy, xx, v);
+            if (!ok && v != v && !(A.m.flags & ~SPC_MASK_ARRAY))
+                ok = !(A.m.flags & SPC_MASK_ARRAY) || A.m.arr[z * A.m.plane_stride + yy * A.m.row_stride + xx] != 0;
+            return (A.m.flags && !ok) ? A.fill : v;
+        };
+        const double a = get(y0, x0), b = get(y0, x1), c = get(y1, x0), d = get(y1, x1);
+        const double r = A.nearest ? a : (a * w00 + b * w01 + c * w10 + d * w11);
+        anyv = anyv || (r == r);
+        po[z * A.out_plane_stride] = r;
+    }
+    if (A.any_valid && __any(anyv) && lane == 0) atomicOr(A.any_valid, 1u);
+}
+__global__ __launch_bounds__(256) void scale64_kernel(double* p, int64_t n, double f) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] *= f;
+}
+
 // ---- small elementwise helpers --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void narrow64_kernel(const Cube64 C, float* out, int64_t out_row_stride, int64_t out_plane_stride) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -477,6 +537,44 @@ int spc_spectral_lerp_f64(int device, void* stream, const spc_cube_f64* cube, co
     A.jchunk = (nz_out + nsplit - 1) / nsplit;
     nsplit = (int)((nz_out + A.jchunk - 1) / A.jchunk);
     hipLaunchKernelGGL(spectral_lerp64_kernel, dim3((unsigned)nb, (unsigned)nsplit), dim3(256), 0, (hipStream_t)stream, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_resample_bilinear_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, double fill,
+                              int64_t ny_out, int64_t nx_out, const double* d_xs, const double* d_ys, double* d_out,
+                              int64_t out_row_stride, int64_t out_plane_stride, uint8_t* d_footprint, int order,
+                              uint32_t* d_any_valid) {
+    Bil64Args A{};
+    int rc = cube64_args(cube, mask, &A.c, &A.m);
+    if (rc) return rc;
+    SPC_REQUIRE(ny_out > 0 && nx_out > 0, "output shape must be positive");
+    SPC_REQUIRE(d_xs && d_ys && d_out, "NULL pointer argument");
+    SPC_REQUIRE(order == 0 || order == 1, "order must be 1 (bilinear) or 0 (nearest neighbour), got %d", order);
+    SPC_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    A.fill = fill; A.ny_out = ny_out; A.nx_out = nx_out; A.xs = d_xs; A.ys = d_ys; A.out = d_out;
+    A.out_row_stride = out_row_stride ? out_row_stride : nx_out;
+    A.out_plane_stride = out_plane_stride ? out_plane_stride : ny_out * A.out_row_stride;
+    A.footprint = d_footprint; A.nearest = order == 0; A.any_valid = d_any_valid;
+    if (d_any_valid) SPC_HIP(hipMemsetAsync(d_any_valid, 0, sizeof(uint32_t), st));
+    const int64_t nblocks = ((nx_out + 63) / 64) * ((ny_out + 3) / 4);
+    SPC_REQUIRE(nblocks < (1LL << 31), "output map too large for one launch");
+    int nsplit = 1;
+    if (nblocks < 2048) nsplit = (int)std::max<int64_t>(1, std::min<int64_t>((2048 + nblocks - 1) / nblocks, cube->nz / 8));
+    A.zchunk = (cube->nz + nsplit - 1) / nsplit;
+    nsplit = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
+    hipLaunchKernelGGL(bilinear64_kernel, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+int spc_scale_f64(int device, void* stream, double* d_data, int64_t n, double factor) {
+    SPC_REQUIRE(d_data != nullptr && n >= 0, "NULL pointer / negative count");
+    SPC_DEVICE(device);
+    const int64_t nb = (n + 255) / 256;
+    SPC_REQUIRE(nb < (1LL << 31), "array too large for one launch");
+    if (nb) hipLaunchKernelGGL(scale64_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, d_data, n, factor);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }

@@ -1358,6 +1358,13 @@ class SpectralCube:
         karr = beam.deconvolve(self.beam).as_kernel(pixscale)
         is_jybm = str(self._unit).replace(" ", "").upper() in ("JY/BEAM", "JYBEAM-1", "JY/BM")
         ratio = beam.sr / self.beam.sr if is_jybm else 1.0
+        if self._runs_wide():
+            parent = self
+
+            def run64():
+                res = ops.spatial_conv_f64(parent._device_data64(), karr, mask=parent._mask_spec64())
+                return ops.scale_inplace_f64(res, ratio) if ratio != 1.0 else res
+            return self._new_wide_cube(run64).with_beam(beam, raise_error_jybm=False)
         if self._stream_source() is not None:
             # out of core: one kernel for every channel, so slabs of whole planes; pending until write() / stream_into()
             parent = self
@@ -1509,6 +1516,34 @@ class SpectralCube:
             shape = (nz, ny_out, nx_out)
             out = self._new_cube_with(lazy=thunk, wcs=newwcs, mask=False, shape=shape)
             out._mask = M.BooleanArrayMask(footprint[None], newwcs, shape=shape)
+            out._footprint = footprint
+            return out
+        if order in (0, 1) and self._runs_wide():
+            # a float64 cube: float64 weights and results (reproject_interp computes in float64); a cube header's own spectral
+            # axis is blended from the resampled float64 planes afterwards
+            flag = DeviceArray((1,), np.uint32, self.device)
+            mask64 = self._mask_spec64() if filled else None
+            fillv = float(self._fill_value)
+            if filled and not np.isnan(fillv) and self._mask is not None and M.contains(self._mask, M.NotNaNMask) \
+                    and not M.contains(self._mask, M.InvertedMask):
+                inc = ops.mask_include_f64(self._device_data64(), mask64, nan_excluded=True)
+                mask64 = ops.MaskSpec(_lib.MASK_ARRAY, 0.0, 0.0, inc)
+            dev64, foot = ops.resample_bilinear_f64(self._device_data64(), xs, ys, fill=fillv, mask=mask64, order=order, any_valid=flag)
+            footprint = foot.get().astype(bool)
+            valid3d = footprint[None]
+            nothing = int(flag.get()[0]) == 0
+            if zs is not None:
+                inside = (zs >= -0.5) & (zs <= nz - 0.5)
+                zc = np.clip(np.where(inside, zs, 0.0), 0.0, nz - 1.0)
+                z0 = np.minimum(np.floor(zc).astype(np.int64), nz - 2)
+                dev64 = ops.spectral_lerp_f64(dev64, np.where(inside, z0, -1).astype(np.int32), zc - z0, np.ones(len(zs)), np.nan)
+                if not inside.all():
+                    valid3d = footprint[None] & inside[:, None, None]
+                nothing = nothing or not inside.any()
+            if nothing:
+                raise ValueError(_ALL_NAN)
+            out = self._new_wide_cube(lambda: dev64, shape=dev64.shape, wcs=newwcs, mask=False)
+            out._mask = M.BooleanArrayMask(valid3d, newwcs, shape=dev64.shape)
             out._footprint = footprint
             return out
         folded = self._pending_interpolation(order) if zs is None else None

@@ -313,6 +313,34 @@ def spectral_lerp_f64(cube, lo, t, inv_dx, fill=np.nan, mask=None, out=None, str
     return out
 
 
+def resample_bilinear_f64(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_footprint=True, order=1, any_valid=None):
+    """resample_bilinear of a float64 cube (spc_resample_bilinear_f64): float64 weights, float64 result"""
+    dev = cube.device
+    if isinstance(xs, DeviceArray) and isinstance(ys, DeviceArray):
+        d_xs, d_ys = xs, ys
+        ny_out, nx_out = xs.shape
+    else:
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        ny_out, nx_out = xs.shape
+        d_xs, d_ys = DeviceArray.from_numpy(xs, dev), DeviceArray.from_numpy(ys, dev)
+    out = DeviceArray((cube.shape[0], ny_out, nx_out), np.float64, dev)
+    foot = DeviceArray((ny_out, nx_out), np.uint8, dev) if want_footprint else None
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    _lib.call("spc_resample_bilinear_f64", dev, _sh(stream), C.byref(c), C.byref(m), float(fill), ny_out, nx_out,
+              C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr), C.c_void_p(out.ptr), 0, 0,
+              C.c_void_p(foot.ptr) if foot is not None else None, int(order),
+              C.c_void_p(any_valid.ptr) if any_valid is not None else None)
+    out._plan = (d_xs, d_ys)
+    return out, foot
+
+
+def scale_inplace_f64(arr, factor, stream=None):
+    """arr *= factor for a float64 DeviceArray (spc_scale_f64)"""
+    _lib.call("spc_scale_f64", arr.device, _sh(stream), C.c_void_p(arr.ptr), int(np.prod(arr.shape, dtype=np.int64)), float(factor))
+    return arr
+
+
 def narrow_f64(cube, stream=None):
     """float32 copy of a float64 DeviceArray (for the operators without a float64 form)"""
     out = DeviceArray(cube.shape, np.float32, cube.device)

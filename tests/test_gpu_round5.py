@@ -622,3 +622,60 @@ def test_float64_cube_stays_float64_through_the_other_operators(gpu, tmp_path, s
     narrow = ops.spectral_conv(DeviceArray.from_numpy(g["data"].astype(np.float32)), k1).get().astype(np.float64)
     ok = np.isfinite(g["spectral_smooth_u"])
     assert np.abs(narrow[ok] - g["spectral_smooth_u"][ok]).max() > 1e-6
+
+
+def test_float64_cube_reproject_and_convolve_to_stay_float64(gpu):
+    """reproject (orders 0 / 1, celestial and cube headers) and convolve_to of a float64 cube: float64 weights and results
+    (reproject_interp and astropy's convolve compute in float64; the reference hands them the float64 samples, masks.py:225),
+    against the oracle on the float64 samples: 1e-13"""
+    import warnings as W
+    from spectral_cube_amd import PrecisionWarning, SpectralCube
+    from spectral_cube_amd.wcs import SimpleWCS
+    from spectral_cube_amd.beam import Beam
+    rng = np.random.default_rng(81)
+    nz, ny, nx = 9, 48, 56
+    d = 1000.0 + 1e-5 * rng.standard_normal((nz, ny, nx))
+    d[4, 20:23, 30:33] = np.nan
+    hdr = _cube_hdr(nz, ny, nx, BUNIT="K")
+    a = np.deg2rad(25.0)
+    tgt2 = {k: hdr[k] for k in ("CTYPE1", "CTYPE2", "CDELT1", "CDELT2", "CRVAL1", "CRVAL2")}
+    tgt2.update(NAXIS=2, NAXIS1=50, NAXIS2=44, CRPIX1=25.5, CRPIX2=22.5, PC1_1=np.cos(a), PC1_2=-np.sin(a), PC2_1=np.sin(a), PC2_2=np.cos(a))
+    tgt3 = _cube_hdr(14, 44, 50, CDELT3=300.0, CRVAL3=-3100.0, CRPIX1=25.5, CRPIX2=22.5, PC1_1=np.cos(a), PC1_2=-np.sin(a), PC2_1=np.sin(a), PC2_2=np.cos(a))
+    with W.catch_warnings():
+        W.simplefilter("error", PrecisionWarning)
+        cube = SpectralCube.read(d, hdr)
+        xs, ys = ops.wcs_pixel_map(cube.wcs, SimpleWCS(tgt2), (44, 50))
+        hx, hy = xs.get(), ys.get()
+        for order, fn in ((1, O.resample_bilinear), (0, O.resample_nearest)):
+            out = cube.reproject(tgt2, order={1: "bilinear", 0: "nearest-neighbor"}[order])
+            got = out.unmasked_data
+            exp, foot = fn(d, hx, hy)
+            assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(out._footprint, foot[0])
+            ok = ~np.isnan(exp)
+            assert np.abs(got[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max(), order
+        out3 = cube.reproject(tgt3)
+        zs = ((-3100.0 + 300.0 * np.arange(14)) - (-3000.0)) / 500.0
+        exp, foot = O.reproject_separable(d, hx, hy, zs)
+        got = out3.unmasked_data
+        assert got.dtype == np.float64 and got.shape == (14, 44, 50) and np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.abs(got[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max()
+        assert np.array_equal(out3.mask.include(), np.broadcast_to(foot, got.shape))
+        # a masked cube with a numeric fill value: excluded voxels enter as the fill value
+        cm = cube.with_mask(cube > 1000.0 - 5e-6).with_fill_value(999.0)
+        inc = (d > 1000.0 - 5e-6)
+        exp, _ = O.resample_bilinear(O.filled(d, inc, 999.0), hx, hy)
+        got = cm.reproject(tgt2).unmasked_data
+        ok = ~np.isnan(exp)
+        assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.abs(got[ok] - exp[ok]).max() <= 1e-13 * 1000.0
+        # convolve_to: Jy/beam data scaled by the ratio of the beam areas
+        jy = SpectralCube.read(d, dict(hdr, BUNIT="Jy/beam", BMAJ=3e-3, BMIN=3e-3, BPA=0.0))
+        target = Beam(5e-3, 4e-3, 30.0)
+        res = jy.convolve_to(target)
+        got = res.unmasked_data
+        assert got.dtype == np.float64
+        psm = jy.wcs.pixel_scale_matrix
+        karr = target.deconvolve(jy.beam).as_kernel(np.sqrt(abs(psm[0, 0] * psm[1, 1] - psm[0, 1] * psm[1, 0])))
+        exp = O.spatial_smooth(d, np.isfinite(d), karr) * (target.sr / jy.beam.sr)
+        ok = ~np.isnan(exp)
+        assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.abs(got[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max()
