@@ -380,6 +380,17 @@ class SpectralCube:
         ``_get_filled_data(fill=self._fill_value)``) what goes to disk is the FILLED data: excluded
         voxels carry the fill value (NaN by default).  ``filled=False`` writes the raw voxels."""
         from . import io_fits
+        if self._runs_wide():
+            # a float64 cube goes to disk as BITPIX = -64 (the reference writes the array it holds, io/fits.py:262-294)
+            path = os.fspath(filename)
+            if os.path.exists(path) and not overwrite:
+                raise OSError("File %r already exists (use overwrite=True)" % path)
+            data = self._host_data()
+            if filled and self._mask is not None:
+                data = self._mask._filled(data, fill=self._fill_value)
+            hdr = {k: v for k, v in self._header.items() if k != "WCSAXES"}
+            io_fits.write_fits(path, np.asarray(data, dtype=np.float64), header=hdr)
+            return
         plan = self._strip_plan(filled)
         if plan is not None:             # out of core: strips in, operator, strips out (streaming.map_strips / map_slabs)
             from . import streaming

@@ -612,6 +612,19 @@ def test_float64_cube_stays_float64_through_the_other_operators(gpu, tmp_path, s
             close(sm.spatial_smooth(k2).unmasked_data, O.spatial_smooth(g["spectral_smooth_" + tag], g["include_" + tag].astype(bool), k2),
                   "spectral_smooth -> spatial_smooth " + tag)
         assert cube._dev is None                                  # nothing was staged as float32
+        # write(): a float64 cube goes to disk as BITPIX = -64 (filled data), and reads back as the same float64 samples
+        out_path = str(tmp_path / "smoothed.fits")
+        sm = cube.with_mask(cube > thr).spectral_smooth(k1)
+        sm.write(out_path)
+        assert io_fits.find_image(out_path).bitpix == -64
+        back = SpectralCube.read(out_path)
+        exp = np.where(g["include_m"].astype(bool), g["spectral_smooth_m"], np.nan)
+        got = back.unmasked_data
+        assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        assert np.abs(got[ok] - exp[ok]).max() <= 1e-12 * np.abs(exp[ok]).max()
+        with pytest.raises(OSError):
+            sm.write(out_path)
     # an operator without a float64 form narrows the smoothed cube, with the warning
     sm = cube.spectral_smooth(k1)
     with pytest.warns(PrecisionWarning, match="narrowed to float32"):

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out
-timeout 300 tools/micro/vmcnt_pipeline > gpurun_out/r05s6_vmcnt.txt 2>&1
-cat gpurun_out/r05s6_vmcnt.txt
+timeout 900 python -m pytest tests/test_gpu_round5.py -x -q -k "float64" 2>&1 | tail -30 > gpurun_out/r05s6_t.txt
+cat gpurun_out/r05s6_t.txt
