@@ -582,7 +582,7 @@ def mad_std(data, include=None, axis=0):
 
 
 def sigma_clip(data, include=None, sigma=3.0, maxiters=5, cenfunc="median", stdfunc="std",
-               sigma_lower=None, sigma_upper=None):
+               sigma_lower=None, sigma_upper=None, out_dtype=np.float32):
     """``astropy.stats.sigma_clip(array, sigma, axis=0, masked=False, copy=True)`` as called by
     ``sigma_clip_spectrally`` (spectral_cube/dask_spectral_cube.py:851-878): iterate
     bounds = centre -/+ sigma*std per ray (nan-aware), values outside -> NaN, until a pass
@@ -605,7 +605,7 @@ def sigma_clip(data, include=None, sigma=3.0, maxiters=5, cenfunc="median", stdf
             if not out.any():
                 break
             f[out] = np.nan
-    return f.astype(np.float32)
+    return f.astype(out_dtype)
 
 
 # --------------------------------------------------------------------------

@@ -45,6 +45,17 @@ inline int check_cube64(const spc_cube_f64* c) {
     return SPC_OK;
 }
 
+// for kernels that only ever form z * plane_stride + y * row_stride + x: also a view whose first two axes are exchanged
+inline int check_cube64_any_order(const spc_cube_f64* c) {
+    SPC_REQUIRE(c != nullptr && c->d_data != nullptr, "cube pointer is NULL");
+    SPC_REQUIRE(c->nz > 0 && c->ny > 0 && c->nx > 0, "cube shape must be positive (got %lld,%lld,%lld)",
+                (long long)c->nz, (long long)c->ny, (long long)c->nx);
+    SPC_REQUIRE(c->row_stride >= c->nx && c->plane_stride >= c->nx, "row / plane stride smaller than nx");
+    SPC_REQUIRE(c->plane_stride >= c->row_stride * (c->ny - 1) + c->nx ||
+                c->row_stride >= c->plane_stride * (c->nz - 1) + c->nx, "overlapping rows and planes");
+    return SPC_OK;
+}
+
 inline int mask64_to_dev(const spc_mask_f64* m, const spc_cube_f64* c, MaskDev64* out) {
     out->flags = 0; out->lo = 0.0; out->hi = 0.0; out->arr = nullptr;
     out->row_stride = c->row_stride; out->plane_stride = c->plane_stride;

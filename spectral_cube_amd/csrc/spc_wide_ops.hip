@@ -350,6 +350,138 @@ __global__ __launch_bounds__(256) void scale64_kernel(double* p, int64_t n, doub
     if (i < n) p[i] *= f;
 }
 
+// ---- order statistics along the spectral axis ------------------------------------------------------------------------------
+// median / percentile / mad_std (dask_spectral_cube.py:657-731) and sigma_clip_spectrally (:851-878, centre = median | mean,
+// spread = std) of float64 rays of up to 4096 samples.  No register-resident radix descent like the float32 kernels: a block sorts
+// its TS = 16384 / NZP adjacent rays (order-preserving 64-bit keys, excluded / NaN samples last) in 128 KB of LDS with a bitonic
+// network, then one lane per ray reads what it needs from the sorted ray - the order statistics directly (numpy's linear rule,
+// its `_lerp` form), the clip loop as a shrinking window [a, b) of the sorted samples (clipping removes the two ends of a sorted ray;
+// mean and std of a window are two scans of it, nanstd's two-pass form).  The clipped cube is written in a last sweep over the
+// rays: a sample survives when its key lies between the window's end keys.
+constexpr int kSortKeys = 16384;
+constexpr unsigned long long kExcl = ~0ull;
+__device__ __forceinline__ unsigned long long fkey64(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double funkey64(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
+struct Sort64Args {
+    Cube64 c;
+    MaskDev64 m;
+    int nzp, ts;                 // padded ray length (power of two), rays per block
+    double q, scale;
+    const double* center;        // NULL, or (ny, nx): keys of |x - center|
+    double* out;                 // MODE 0: (ny, nx); MODE 1: (nz, ny, nx) C-contiguous
+    double lo_s, hi_s;
+    int maxiters, cen_mean;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void sort64_kernel(const Sort64Args A) {
+    __shared__ unsigned long long keys[kSortKeys];           // [sample][ray]: consecutive lanes = consecutive rays
+    __shared__ unsigned long long s_wlo[64], s_whi[64];
+    const int t = threadIdx.x, TS = A.ts, NZP = A.nzp, L = 256 / TS;
+    const int64_t tiles_x = (A.c.nx + TS - 1) / TS;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
+    const int r = t % TS, jz = t / TS;
+    const bool col_in = x0 + r < A.c.nx;
+    const double cen = (A.center && col_in) ? A.center[y * A.c.nx + x0 + r] : 0.0;
+    auto key_of = [&](int64_t z) {
+        double v;
+        bool ok = inc64(A.c, A.m, z, y, x0 + r, v);
+        if (A.center) { v = fabs(v - cen); ok = ok && (v == v); }
+        return ok ? fkey64(v) : kExcl;
+    };
+    for (int z = jz; z < NZP; z += L) keys[z * TS + r] = (col_in && z < A.c.nz) ? key_of(z) : kExcl;
+    __syncthreads();
+    const int half = (TS * NZP) >> 1;
+    for (int k = 2; k <= NZP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = t; idx < half; idx += 256) {
+                const int ray = idx % TS, p = idx / TS;
+                const int i = ((p / j) * 2 * j) + (p % j), l = i + j;
+                const bool up = (i & k) == 0;
+                const unsigned long long a = keys[i * TS + ray], b = keys[l * TS + ray];
+                if ((a > b) == up) { keys[i * TS + ray] = b; keys[l * TS + ray] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (t < TS && x0 + t < A.c.nx) {
+        const int ray = t;
+        int lo = 0, hi = NZP;                                  // n = number of keys below the excluded one
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid * TS + ray] == kExcl) hi = mid; else lo = mid + 1; }
+        const int n = lo;
+        auto val = [&](int i) { return funkey64(keys[i * TS + ray]); };
+        auto quantile = [&](int a, int cnt, double q) {        // numpy: virtual index q / 100 (cnt - 1), _lerp between its neighbours
+            if (q == 50.0) {
+                const int m = a + (cnt - 1) / 2;
+                return (cnt & 1) ? val(m) : 0.5 * (val(m) + val(m + 1));
+            }
+            const double vi = q / 100.0 * (double)(cnt - 1);
+            int p = (int)floor(vi);
+            p = min(max(p, 0), cnt - 1);
+            const int p1 = min(p + 1, cnt - 1);
+            const double g = vi - (double)p, va = val(a + p), vb = val(a + p1), d = vb - va;
+            return g >= 0.5 ? vb - d * (1.0 - g) : va + d * g;
+        };
+        if (MODE == 0) {
+            A.out[y * A.c.nx + x0 + ray] = n > 0 ? quantile(0, n, A.q) * A.scale : NAN;
+        } else {
+            int a = 0, b = n, it = 0;
+            while (b > a && (A.maxiters < 0 || it < A.maxiters)) {
+                ++it;
+                const int cnt = b - a;
+                double sum = 0.0;
+                for (int i = a; i < b; ++i) sum += val(i);
+                const double mean = sum / (double)cnt;
+                double ss = 0.0;
+                for (int i = a; i < b; ++i) { const double dv = val(i) - mean; ss = fma(dv, dv, ss); }
+                const double sd = sqrt(ss / (double)cnt);
+                const double c = A.cen_mean ? mean : quantile(a, cnt, 50.0);
+                const double lob = c - A.lo_s * sd, hib = c + A.hi_s * sd;
+                int na = a, nb = b;
+                while (na < nb && val(na) < lob) ++na;
+                while (nb > na && val(nb - 1) > hib) --nb;
+                // (a NaN bound - an infinite sample in the window - clips nothing: the comparisons are false, as numpy's)
+                if (na == a && nb == b) break;
+                a = na; b = nb;
+            }
+            s_wlo[ray] = b > a ? keys[a * TS + ray] : 1ull;      // empty window: lo > hi, nothing survives
+            s_whi[ray] = b > a ? keys[(b - 1) * TS + ray] : 0ull;
+        }
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        if (col_in) {
+            const unsigned long long wlo = s_wlo[r], whi = s_whi[r];
+            for (int z = jz; z < A.c.nz; z += L) {
+                double v;
+                const bool ok = inc64(A.c, A.m, z, y, x0 + r, v);
+                const unsigned long long k = ok ? fkey64(v) : kExcl;
+                A.out[((int64_t)z * A.c.ny + y) * A.c.nx + x0 + r] = (k >= wlo && k <= whi) ? v : NAN;
+            }
+        }
+    }
+}
+
+static int sort64_launch(Sort64Args& A, const spc_cube_f64* cube, bool clip, hipStream_t st) {
+    if (cube->nz > 4096) {
+        spc_set_error("rays of more than 4096 samples have no float64 order statistics (got %lld)", (long long)cube->nz);
+        return SPC_ERR_UNSUPPORTED;
+    }
+    int nzp = 2;
+    while (nzp < cube->nz) nzp <<= 1;
+    A.nzp = nzp; A.ts = std::min(64, kSortKeys / nzp);
+    const int64_t nb = ((cube->nx + A.ts - 1) / A.ts) * cube->ny;
+    SPC_REQUIRE(nb < (1LL << 31), "map too large for one launch");
+    if (clip) hipLaunchKernelGGL(sort64_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL(sort64_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
 // ---- small elementwise helpers --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void narrow64_kernel(const Cube64 C, float* out, int64_t out_row_stride, int64_t out_plane_stride) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,8 +502,8 @@ __global__ __launch_bounds__(256) void include64_kernel(const Cube64 C, const Ma
     out[(z * C.ny + y) * C.nx + x] = ok ? 1 : 0;
 }
 
-static int cube64_args(const spc_cube_f64* cube, const spc_mask_f64* mask, Cube64* C, MaskDev64* M) {
-    int rc = check_cube64(cube);
+static int cube64_args(const spc_cube_f64* cube, const spc_mask_f64* mask, Cube64* C, MaskDev64* M, bool any_order = false) {
+    int rc = any_order ? check_cube64_any_order(cube) : check_cube64(cube);
     if (rc) return rc;
     rc = mask64_to_dev(mask, cube, M);
     if (rc) return rc;
@@ -577,6 +709,30 @@ int spc_scale_f64(int device, void* stream, double* d_data, int64_t n, double fa
     if (nb) hipLaunchKernelGGL(scale64_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, d_data, n, factor);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
+}
+
+int spc_percentile_axis0_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, double q,
+                             const double* d_center, double scale, double* d_out) {
+    Sort64Args A{};
+    int rc = cube64_args(cube, mask, &A.c, &A.m, true);       // (rays along y: the view with the first two axes exchanged)
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    SPC_REQUIRE(q >= 0.0 && q <= 100.0, "percentile must lie in [0, 100], got %g", q);
+    SPC_DEVICE(device);
+    A.q = q; A.scale = scale; A.center = d_center; A.out = d_out;
+    return sort64_launch(A, cube, false, (hipStream_t)stream);
+}
+
+int spc_sigma_clip_axis0_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, double sigma_lower,
+                             double sigma_upper, int maxiters, int center_is_mean, double* d_out) {
+    Sort64Args A{};
+    int rc = cube64_args(cube, mask, &A.c, &A.m);
+    if (rc) return rc;
+    SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
+    SPC_DEVICE(device);
+    A.lo_s = sigma_lower; A.hi_s = sigma_upper; A.maxiters = maxiters; A.cen_mean = center_is_mean; A.out = d_out;
+    A.q = 50.0; A.scale = 1.0;
+    return sort64_launch(A, cube, true, (hipStream_t)stream);
 }
 
 int spc_narrow_f64_to_f32(int device, void* stream, const spc_cube_f64* cube, float* d_out, int64_t out_row_stride,

@@ -1174,6 +1174,12 @@ class SpectralCube:
     def _order_stat(self, q, axis, what, center=None, scale=1.0):
         if axis not in (0, 1, 2):
             raise ValueError("axis must be None, 0, 1 or 2")
+        if axis in (0, 1) and self._shape[axis] <= 4096 and self._runs_wide():
+            # a float64 cube: sorted rays of float64 keys (spc_percentile_axis0_f64), a float64 map
+            d64, ms = self._device_data64(), self._mask_spec64()
+            if axis == 1:
+                d64, ms = d64.swap01(), ms.swap01()
+            return ops.percentile_axis0_f64(d64, q, mask=ms, center=center, scale=scale)
         if axis in (1, 2) and self._stream_source() is not None:
             # out of core: the rays along y / x are whole in a slab of channels; row z of the (nz, nx) / (nz, ny) map per slab row
             from . import streaming
@@ -1254,6 +1260,10 @@ class SpectralCube:
             thunk.parent = parent
             thunk.strip_fn = lambda dev, mspec, stream: ops.sigma_clip_axis0(dev, sigma=sig, mask=mspec, stream=stream, **kwargs)
             return self._new_cube_with(lazy=thunk, shape=self._shape)
+        if kwargs.get("stdfunc", "std") == "std" and self._shape[0] <= 4096 and self._runs_wide():
+            parent, kw = self, {k: v for k, v in kwargs.items() if k != "stdfunc"}
+            return self._new_wide_cube(lambda: ops.sigma_clip_axis0_f64(parent._device_data64(), sigma=float(threshold),
+                                                                        mask=parent._mask_spec64(), **kw))
         dev = ops.sigma_clip_axis0(self._device_data(), sigma=float(threshold), mask=self._mask_spec(), **kwargs)
         return self._new_cube_with(dev=dev)
 

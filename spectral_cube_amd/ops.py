@@ -341,6 +341,30 @@ def scale_inplace_f64(arr, factor, stream=None):
     return arr
 
 
+def percentile_axis0_f64(cube, q, mask=None, center=None, scale=1.0, stream=None):
+    """percentile_axis0 of a float64 cube (spc_percentile_axis0_f64): float64 map; *center* a float64 (ny, nx) DeviceArray.
+    Rays along y: the swap01() view (as for the float32 kernel).  HipUnsupported beyond 4096 samples per ray."""
+    nz, ny, nx = cube.shape
+    out = DeviceArray((ny, nx), np.float64, cube.device)
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    _lib.call("spc_percentile_axis0_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), float(q),
+              C.c_void_p(center.ptr) if center is not None else None, float(scale), C.c_void_p(out.ptr))
+    return out
+
+
+def sigma_clip_axis0_f64(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc="median", mask=None, stream=None):
+    """sigma_clip_axis0 of a float64 cube for stdfunc = 'std' (spc_sigma_clip_axis0_f64): float64 centre, spread and bounds"""
+    if cenfunc not in ("median", "mean"):
+        raise ValueError("cenfunc must be 'median' or 'mean'")
+    out = DeviceArray(cube.shape, np.float64, cube.device)
+    c, m = _cube_c64(cube), _mask_c64(mask, cube)
+    lo = float(sigma if sigma_lower is None else sigma_lower)
+    hi = float(sigma if sigma_upper is None else sigma_upper)
+    _lib.call("spc_sigma_clip_axis0_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), lo, hi,
+              -1 if maxiters is None else int(maxiters), 1 if cenfunc == "mean" else 0, C.c_void_p(out.ptr))
+    return out
+
+
 def narrow_f64(cube, stream=None):
     """float32 copy of a float64 DeviceArray (for the operators without a float64 form)"""
     out = DeviceArray(cube.shape, np.float32, cube.device)

@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     SYM(spc_spectral_conv_f32); SYM(spc_spectral_conv_moments_f32); SYM(spc_spatial_conv_sep_f32);
     SYM(spc_spatial_conv2d_f32); SYM(spc_spectral_lerp_f32); SYM(spc_resample_bilinear_f32); SYM(spc_resample_bilinear_lerp_f32); SYM(spc_resample_spline_f32); SYM(spc_map_check); SYM(spc_spatial_conv_sep_mfma_f32); SYM(spc_spatial_conv_sep_mfma_moments_f32);
     SYM(spc_stats_global_f32); SYM(spc_stats_axis_f32); SYM(spc_fits_to_f32); SYM(spc_map_conv2d_f64); SYM(spc_map_arith_f64); SYM(spc_percentile_axis0_f32); SYM(spc_percentile_axis2_f32); SYM(spc_fill_masked_f32); SYM(spc_sigma_clip_axis0_f32); SYM(spc_moment_order_spatial_f32); SYM(spc_mask_include_u8); SYM(spc_clip_outside_f32); SYM(spc_scale_f32);
-    SYM(spc_argextrema_axis_f32); SYM(spc_percentile_global_f32); SYM(spc_key_histogram_f32); SYM(spc_key_to_f32); SYM(spc_fill_masked_transpose_f32); SYM(spc_pool_trim); SYM(spc_pool_stats); SYM(spc_clip_bounds_f32); SYM(spc_wcs_pixel_map_f64); SYM(spc_stats_planes_f32); SYM(spc_moments_f64); SYM(spc_moment_order_f64); SYM(spc_fits_to_f64); SYM(spc_stats_global_f64); SYM(spc_stats_axis_f64); SYM(spc_spectral_conv_f64); SYM(spc_spatial_conv_f64); SYM(spc_spectral_lerp_f64); SYM(spc_resample_bilinear_f64); SYM(spc_scale_f64); SYM(spc_narrow_f64_to_f32); SYM(spc_mask_include_f64);
+    SYM(spc_argextrema_axis_f32); SYM(spc_percentile_global_f32); SYM(spc_key_histogram_f32); SYM(spc_key_to_f32); SYM(spc_fill_masked_transpose_f32); SYM(spc_pool_trim); SYM(spc_pool_stats); SYM(spc_clip_bounds_f32); SYM(spc_wcs_pixel_map_f64); SYM(spc_stats_planes_f32); SYM(spc_moments_f64); SYM(spc_moment_order_f64); SYM(spc_fits_to_f64); SYM(spc_stats_global_f64); SYM(spc_stats_axis_f64); SYM(spc_spectral_conv_f64); SYM(spc_spatial_conv_f64); SYM(spc_spectral_lerp_f64); SYM(spc_resample_bilinear_f64); SYM(spc_scale_f64); SYM(spc_narrow_f64_to_f32); SYM(spc_percentile_axis0_f64); SYM(spc_sigma_clip_axis0_f64); SYM(spc_mask_include_f64);
     SYM(spc_comm_unique_id); SYM(spc_comm_init); SYM(spc_comm_destroy); SYM(spc_allgather_rows); SYM(spc_allgather_rows_batch);
 
     int (*ver)(void) = (int (*)(void))dlsym(lib, "spc_abi_version");

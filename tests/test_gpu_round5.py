@@ -625,11 +625,28 @@ def test_float64_cube_stays_float64_through_the_other_operators(gpu, tmp_path, s
         assert np.abs(got[ok] - exp[ok]).max() <= 1e-12 * np.abs(exp[ok]).max()
         with pytest.raises(OSError):
             sm.write(out_path)
+        # order statistics along the spectral axis and along y: sorted float64 rays, bit-exact with numpy on the float64 samples
+        with np.errstate(all="ignore"), W.catch_warnings():
+            W.simplefilter("ignore", RuntimeWarning)
+            fz = np.where(g["include_m"].astype(bool), g["data"], np.nan)
+            cm = cube.with_mask(cube > thr)
+            for ax in (0, 1):
+                med = np.asarray(cm.median(axis=ax))
+                assert med.dtype == np.float64 and np.array_equal(med, np.nanmedian(fz, axis=ax), equal_nan=True)
+                close(cm.percentile(30.0, axis=ax), np.nanpercentile(fz, 30.0, axis=ax), "percentile axis %d" % ax, rtol=1e-15)
+            mad = 1.482602218505602 * np.nanmedian(np.abs(fz - np.nanmedian(fz, axis=0)), axis=0)
+            close(cm.mad_std(axis=0), mad, "mad_std", rtol=1e-15)
+            clipped = cm.sigma_clip_spectrally(2.0, maxiters=3)
+            got = clipped.unmasked_data
+            exp = O.sigma_clip(g["data"], g["include_m"].astype(bool) & ~np.isnan(g["data"]), sigma=2.0, maxiters=3, out_dtype=np.float64)
+            assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)])
     # an operator without a float64 form narrows the smoothed cube, with the warning
     sm = cube.spectral_smooth(k1)
     with pytest.warns(PrecisionWarning, match="narrowed to float32"):
-        med = np.asarray(sm.median(axis=0))
-    exp = np.nanmedian(np.where(g["include_u"].astype(bool), g["spectral_smooth_u"], np.nan).astype(np.float32), axis=0)
+        med = np.asarray(sm.median(axis=2))
+    with np.errstate(all="ignore"), W.catch_warnings():
+        W.simplefilter("ignore", RuntimeWarning)
+        exp = np.nanmedian(np.where(g["include_u"].astype(bool), g["spectral_smooth_u"], np.nan).astype(np.float32), axis=2)
     assert np.array_equal(med, exp, equal_nan=True)
     # what the narrowing would have cost: the smoothed line against float32's ulp at the baseline
     narrow = ops.spectral_conv(DeviceArray.from_numpy(g["data"].astype(np.float32)), k1).get().astype(np.float64)
