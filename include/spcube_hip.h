@@ -650,7 +650,8 @@ int spc_resample_bilinear_f32(int device, void* stream, const spc_cube_f32* cube
  * footprint, as in the two-pass form; finite values agree with it to float32 rounding (each input plane is read and
  * resampled ONCE, nz instead of nz_out gathers, and the intermediate cube is never written).  d_lo[j] < 0 marks channels
  * outside the input range (NaN planes).  Precondition: the non-negative entries of d_lo ascend and are contiguous in j
- * (an ascending output grid on ascending input channels; the host flips / falls back otherwise); cube->nz >= 2.
+ * (an ascending output grid on ascending input channels; a descending plan is run reversed, with d_out at its LAST plane and
+ * a negative out_plane_stride: the strides are signed); cube->nz >= 2.
  * Workspace: spc_workspace_bytes(SPC_WS_RESAMPLE_BILINEAR_LERP, nz, ny, nx, ny_out, nx_out). */
 int spc_resample_bilinear_lerp_f32(int device, void* stream, const spc_cube_f32* cube,
                                    const spc_mask* mask, float fill, int64_t ny_out,

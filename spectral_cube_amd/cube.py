@@ -1616,7 +1616,7 @@ class SpectralCube:
                 zc = np.clip(np.where(inside, zs, 0.0), 0.0, nz - 1.0)
                 z0 = np.minimum(np.floor(zc).astype(np.int64), nz - 2)
                 zlo = np.where(inside, z0, -1).astype(np.int32)
-                zfold = ops.lerp_plan_is_foldable(zlo) and os.environ.get("SPC_REPROJECT_FOLD", "1") != "0"
+                zfold = ops.lerp_plan_folds(zlo) and os.environ.get("SPC_REPROJECT_FOLD", "1") != "0"
             if zfold:
                 # ascending target channels: the blend rides in the resampling kernel (one pass, no resampled copy of the cube)
                 dev, foot = ops.resample_bilinear_lerp(self._device_data(), xs, ys, zlo, zc - z0, np.ones(len(zs)),
@@ -1664,7 +1664,7 @@ class SpectralCube:
             return None
         if not (isinstance(self._mask, M.NotNaNMask) and self._mask._data_ref._is_same_data(self)):
             return None
-        if parent._shape[0] < 2 or not ops.lerp_plan_is_foldable(plan[0]):
+        if parent._shape[0] < 2 or not ops.lerp_plan_folds(plan[0]):
             return None
         return parent, plan
 

@@ -644,6 +644,12 @@ def resample_bilinear(cube, xs, ys, fill=np.nan, mask=None, stream=None, want_fo
     return out, foot
 
 
+def lerp_plan_folds(lo):
+    """a plan resample_bilinear_lerp accepts: monotone either way (a descending one is run reversed)"""
+    lo = np.asarray(lo)
+    return lerp_plan_is_foldable(lo) or lerp_plan_is_foldable(lo[::-1])
+
+
 def lerp_plan_is_foldable(lo):
     """True when a spectral_lerp plan can ride in the resampling kernel (resample_bilinear_lerp): its non-negative
     entries ascend and are contiguous (an ascending grid on ascending channels)"""
@@ -663,8 +669,14 @@ def resample_bilinear_lerp(cube, xs, ys, lo, t, inv_dx, fill=np.nan, mask=None, 
     NaN planes.  Returns (cube of len(lo) channels, footprint)."""
     dev = cube.device
     lo = np.ascontiguousarray(lo, dtype=np.int32)
+    t, inv_dx = np.asarray(t, dtype=np.float64), np.asarray(inv_dx, dtype=np.float64)
+    flip = False
     if not lerp_plan_is_foldable(lo):
-        raise _lib.HipUnsupported("resample_bilinear_lerp: the plan's channels must ascend (flip the axis or run the two passes)")
+        # a descending plan (a reversed output grid, or a reversed input axis): the same kernel on the reversed plan, its
+        # output planes written from the last one down (a negative plane stride)
+        if not lerp_plan_is_foldable(lo[::-1]):
+            raise _lib.HipUnsupported("resample_bilinear_lerp: the plan's channels must be monotone and contiguous (run the two passes)")
+        lo, t, inv_dx, flip = lo[::-1].copy(), t[::-1].copy(), inv_dx[::-1].copy(), True
     if cube.shape[0] < 2:
         raise _lib.HipUnsupported("resample_bilinear_lerp: at least two input channels")
     if isinstance(xs, DeviceArray) and isinstance(ys, DeviceArray):
@@ -690,9 +702,10 @@ def resample_bilinear_lerp(cube, xs, ys, lo, t, inv_dx, fill=np.nan, mask=None, 
     foot = DeviceArray((ny_out, nx_out), np.uint8, dev) if want_footprint else None
     c, m = _cube_c(cube), _mask_c(mask, cube)
     ws, wsn = workspace(dev, stream, _lib.WS_RESAMPLE_BILINEAR_LERP, *cube.shape, ny_out, nx_out)
+    plane = ny_out * nx_out
     _lib.call("spc_resample_bilinear_lerp_f32", dev, _sh(stream), C.byref(c), C.byref(m), float(fill),
               ny_out, nx_out, C.c_void_p(d_xs.ptr), C.c_void_p(d_ys.ptr), nz_out, C.c_void_p(d_lo.ptr), C.c_void_p(d_t.ptr),
-              C.c_void_p(d_inv.ptr), C.c_void_p(out.ptr), 0, 0,
+              C.c_void_p(d_inv.ptr), C.c_void_p(out.ptr + ((nz_out - 1) * plane * 4 if flip else 0)), nx_out, -plane if flip else plane,
               C.c_void_p(foot.ptr) if foot is not None else None, int(order),
               C.c_void_p(any_valid.ptr) if any_valid is not None else None, ws, wsn)
     out._plan = (d_xs, d_ys, d_lo, d_t, d_inv)

@@ -408,6 +408,7 @@ def _rot_map(nyo, nxo, ny, nx, deg, scale=1.0, shift=(0.0, 0.0)):
     dict(shape=(12, 200, 180), out=(30, 140, 160), deg=12.0, mask="pred", scale=3.5),   # tiles whose footprint does not fit: gather
     dict(shape=(2, 40, 50), out=(7, 64, 64), deg=45.0, mask="array", order=0),      # two channels, nearest neighbour
     dict(shape=(25, 33, 47), out=(60, 31, 29), deg=200.0, mask=None, beyond=True),  # output channels beyond both ends
+    dict(shape=(19, 70, 66), out=(41, 130, 140), deg=33.0, mask="array", beyond=True, descending=True),   # a reversed output grid
 ])
 def test_bilinear_with_the_spectral_interpolation_folded_in(gpu, case):
     """one pass = interpolate, then resample (the oracle's order, dask_spectral_cube.py:1342-1353 then spectral_cube.py:2726-2732)
@@ -427,7 +428,11 @@ def test_bilinear_with_the_spectral_interpolation_folded_in(gpu, case):
     xs, ys = _rot_map(nyo, nxo, ny, nx, case["deg"], case.get("scale", 1.0), (1.3, -0.7))
     xin = np.cumsum(rng.uniform(0.5, 1.5, nz))
     xout = np.linspace(xin[0] - 2.0, xin[-1] + 2.0, nzo) if case.get("beyond") else np.linspace(xin[0], xin[-1], nzo)
-    lo, t, inv, _, _, _ = ops.lerp_plan(xin, xout)
+    lo, t, inv, _, rout, _ = ops.lerp_plan(xin, xout[::-1] if case.get("descending") else xout)
+    if case.get("descending"):
+        assert rout
+        lo, t, inv = lo[::-1].copy(), t[::-1].copy(), inv[::-1].copy()          # the plan in the order of the descending grid
+        xout = xout[::-1].copy()
     order = case.get("order", 1)
     cube = DeviceArray.from_numpy(d)
     got, foot = ops.resample_bilinear_lerp(cube, xs, ys, lo, t, inv, mask=spec, order=order)
@@ -450,8 +455,10 @@ def test_bilinear_with_the_spectral_interpolation_folded_in(gpu, case):
 def test_bilinear_lerp_refuses_plans_it_cannot_fold(gpu):
     d = DeviceArray.from_numpy(np.zeros((4, 8, 8), np.float32))
     xs, ys = _rot_map(8, 8, 8, 8, 10.0)
+    got, _ = ops.resample_bilinear_lerp(d, xs, ys, np.array([2, 1, 0], np.int32), np.zeros(3), np.ones(3))  # descending: run reversed
+    assert got.shape == (3, 8, 8)
     with pytest.raises(_lib.HipUnsupported):
-        ops.resample_bilinear_lerp(d, xs, ys, np.array([2, 1, 0], np.int32), np.zeros(3), np.ones(3))         # descending
+        ops.resample_bilinear_lerp(d, xs, ys, np.array([0, 2, 1], np.int32), np.zeros(3), np.ones(3))         # not monotone
     with pytest.raises(_lib.HipUnsupported):
         ops.resample_bilinear_lerp(d, xs, ys, np.array([0, -1, 1], np.int32), np.zeros(3), np.ones(3))        # a hole
     one = DeviceArray.from_numpy(np.zeros((1, 8, 8), np.float32))
@@ -510,11 +517,13 @@ def test_cube_level_interpolate_then_reproject_is_one_pass(gpu, monkeypatch):
     r0 = up0.reproject(tgt)
     assert calls == [1]
     assert np.isfinite(r0._device_data().get()[:, res._footprint]).all()
-    # a descending grid: the plan's channels descend, the two passes run
+    # a descending grid: the plan's channels descend - the same kernel on the reversed plan, output planes written last to first
     rd = cube.spectral_interpolate(grid[::-1].copy(), suppress_smooth_warning=True).reproject(tgt)
-    assert calls == [1]
+    assert calls == [1, 1]
     gd = rd._device_data().get()
     assert np.array_equal(np.isnan(gd[::-1]), np.isnan(two))
+    assert np.abs(gd[::-1][fin] - two[fin]).max() <= 2e-6 * np.abs(two[fin]).max()
+    np.testing.assert_allclose(rd.spectral_axis, grid[::-1], rtol=1e-12, atol=1e-9)
 
 
 def test_reproject_onto_a_cube_header_resamples_all_three_axes_in_one_pass(gpu, monkeypatch):
