@@ -288,13 +288,13 @@ int spc_scale_f64(int device, void* stream, double* d_data, int64_t n, double fa
 /* Order statistics of float64 rays along the first axis of the view (spc_percentile_axis0_f32 / spc_sigma_clip_axis0_f32 on the
  * float64 samples; dask_spectral_cube.py:657-731, :851-878): q-th percentile with numpy's linear rule (q = 50: the median, the
  * mean of two middle samples), of |x - d_center| when d_center (a (ny,nx) float64 map) is given, times scale (mad_std); and the
- * whole sigma-clip loop for centre = median | mean and spread = std (float64 centre and bounds; d_out (nz,ny,nx) C-contiguous
+ * whole sigma-clip loop for centre = median | mean and spread = std | mad_std (float64 centre and bounds; d_out (nz,ny,nx) C-contiguous
  * float64, masked and clipped samples NaN).  Rays of up to 4096 samples (sorted in LDS), else SPC_ERR_UNSUPPORTED. */
 int spc_percentile_axis0_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
                              double q, const double* d_center, double scale, double* d_out);
 int spc_sigma_clip_axis0_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,
                              double sigma_lower, double sigma_upper, int maxiters, int center_is_mean,
-                             double* d_out);
+                             int spread_is_mad, double* d_out);
 int spc_narrow_f64_to_f32(int device, void* stream, const spc_cube_f64* cube, float* d_out,
                           int64_t out_row_stride, int64_t out_plane_stride);
 int spc_mask_include_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask,

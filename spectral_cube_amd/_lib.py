@@ -155,7 +155,7 @@ SIGNATURES = {
     "spc_resample_bilinear_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _d, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _i, _vp]),
     "spc_scale_f64": (_i, [_i, _vp, _vp, _i64, _d]),
     "spc_percentile_axis0_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _d, _vp, _d, _vp]),
-    "spc_sigma_clip_axis0_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _d, _d, _i, _i, _vp]),
+    "spc_sigma_clip_axis0_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _d, _d, _i, _i, _i, _vp]),
     "spc_narrow_f64_to_f32": (_i, [_i, _vp, _P(SpcCube), _vp, _i64, _i64]),
     "spc_mask_include_f64": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask64), _i, _vp]),
     "spc_moments_spatial_f32": (_i, [_i, _vp, _P(SpcCube), _P(SpcMask), _i, _vp, _d, _vp, _vp, _vp]),

@@ -375,7 +375,7 @@ struct Sort64Args {
     const double* center;        // NULL, or (ny, nx): keys of |x - center|
     double* out;                 // MODE 0: (ny, nx); MODE 1: (nz, ny, nx) C-contiguous
     double lo_s, hi_s;
-    int maxiters, cen_mean;
+    int maxiters, cen_mean, spread_mad;
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void sort64_kernel(const Sort64Args A) {
@@ -426,6 +426,23 @@ __global__ __launch_bounds__(256) void sort64_kernel(const Sort64Args A) {
             const double g = vi - (double)p, va = val(a + p), vb = val(a + p1), d = vb - va;
             return g >= 0.5 ? vb - d * (1.0 - g) : va + d * g;
         };
+        // median of |x - med| over the window: the deviations below and above the median are two ascending sequences (walking
+        // away from it) - their merge is walked up to the middle ranks
+        auto mad = [&](int a, int cnt, double med) {
+            int lo = a, hi = a + cnt;                          // first entry above the median
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (val(mid) > med) hi = mid; else lo = mid + 1; }
+            int i = lo - 1, j = lo;                            // i walks down (<= med), j walks up (> med)
+            const int r1 = (cnt - 1) / 2, r2 = cnt / 2;
+            double d1 = 0.0, d2 = 0.0;
+            for (int rank = 0; rank <= r2; ++rank) {
+                const double dl = i >= a ? med - val(i) : INFINITY, dh = j < a + cnt ? val(j) - med : INFINITY;
+                double d;
+                if (dl <= dh) { d = dl; --i; } else { d = dh; ++j; }
+                if (rank == r1) d1 = d;
+                if (rank == r2) d2 = d;
+            }
+            return (cnt & 1) ? d1 : 0.5 * (d1 + d2);
+        };
         if (MODE == 0) {
             A.out[y * A.c.nx + x0 + ray] = n > 0 ? quantile(0, n, A.q) * A.scale : NAN;
         } else {
@@ -438,8 +455,9 @@ __global__ __launch_bounds__(256) void sort64_kernel(const Sort64Args A) {
                 const double mean = sum / (double)cnt;
                 double ss = 0.0;
                 for (int i = a; i < b; ++i) { const double dv = val(i) - mean; ss = fma(dv, dv, ss); }
-                const double sd = sqrt(ss / (double)cnt);
-                const double c = A.cen_mean ? mean : quantile(a, cnt, 50.0);
+                const double medw = quantile(a, cnt, 50.0);
+                const double sd = A.spread_mad ? 1.482602218505602 * mad(a, cnt, medw) : sqrt(ss / (double)cnt);
+                const double c = A.cen_mean ? mean : medw;
                 const double lob = c - A.lo_s * sd, hib = c + A.hi_s * sd;
                 int na = a, nb = b;
                 while (na < nb && val(na) < lob) ++na;
@@ -724,13 +742,13 @@ int spc_percentile_axis0_f64(int device, void* stream, const spc_cube_f64* cube,
 }
 
 int spc_sigma_clip_axis0_f64(int device, void* stream, const spc_cube_f64* cube, const spc_mask_f64* mask, double sigma_lower,
-                             double sigma_upper, int maxiters, int center_is_mean, double* d_out) {
+                             double sigma_upper, int maxiters, int center_is_mean, int spread_is_mad, double* d_out) {
     Sort64Args A{};
     int rc = cube64_args(cube, mask, &A.c, &A.m);
     if (rc) return rc;
     SPC_REQUIRE(d_out != nullptr, "d_out is NULL");
     SPC_DEVICE(device);
-    A.lo_s = sigma_lower; A.hi_s = sigma_upper; A.maxiters = maxiters; A.cen_mean = center_is_mean; A.out = d_out;
+    A.lo_s = sigma_lower; A.hi_s = sigma_upper; A.maxiters = maxiters; A.cen_mean = center_is_mean; A.spread_mad = spread_is_mad; A.out = d_out;
     A.q = 50.0; A.scale = 1.0;
     return sort64_launch(A, cube, true, (hipStream_t)stream);
 }

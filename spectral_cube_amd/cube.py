@@ -1260,8 +1260,8 @@ class SpectralCube:
             thunk.parent = parent
             thunk.strip_fn = lambda dev, mspec, stream: ops.sigma_clip_axis0(dev, sigma=sig, mask=mspec, stream=stream, **kwargs)
             return self._new_cube_with(lazy=thunk, shape=self._shape)
-        if kwargs.get("stdfunc", "std") == "std" and self._shape[0] <= 4096 and self._runs_wide():
-            parent, kw = self, {k: v for k, v in kwargs.items() if k != "stdfunc"}
+        if self._shape[0] <= 4096 and self._runs_wide():
+            parent, kw = self, dict(kwargs)
             return self._new_wide_cube(lambda: ops.sigma_clip_axis0_f64(parent._device_data64(), sigma=float(threshold),
                                                                         mask=parent._mask_spec64(), **kw))
         dev = ops.sigma_clip_axis0(self._device_data(), sigma=float(threshold), mask=self._mask_spec(), **kwargs)

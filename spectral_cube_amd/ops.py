@@ -352,16 +352,17 @@ def percentile_axis0_f64(cube, q, mask=None, center=None, scale=1.0, stream=None
     return out
 
 
-def sigma_clip_axis0_f64(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc="median", mask=None, stream=None):
-    """sigma_clip_axis0 of a float64 cube for stdfunc = 'std' (spc_sigma_clip_axis0_f64): float64 centre, spread and bounds"""
-    if cenfunc not in ("median", "mean"):
-        raise ValueError("cenfunc must be 'median' or 'mean'")
+def sigma_clip_axis0_f64(cube, sigma=3.0, sigma_lower=None, sigma_upper=None, maxiters=5, cenfunc="median", stdfunc="std", mask=None,
+                         stream=None):
+    """sigma_clip_axis0 of a float64 cube (spc_sigma_clip_axis0_f64): float64 centre, spread and bounds"""
+    if cenfunc not in ("median", "mean") or stdfunc not in ("std", "mad_std"):
+        raise ValueError("cenfunc must be 'median' or 'mean', stdfunc 'std' or 'mad_std'")
     out = DeviceArray(cube.shape, np.float64, cube.device)
     c, m = _cube_c64(cube), _mask_c64(mask, cube)
     lo = float(sigma if sigma_lower is None else sigma_lower)
     hi = float(sigma if sigma_upper is None else sigma_upper)
     _lib.call("spc_sigma_clip_axis0_f64", cube.device, _sh(stream), C.byref(c), C.byref(m), lo, hi,
-              -1 if maxiters is None else int(maxiters), 1 if cenfunc == "mean" else 0, C.c_void_p(out.ptr))
+              -1 if maxiters is None else int(maxiters), 1 if cenfunc == "mean" else 0, 1 if stdfunc == "mad_std" else 0, C.c_void_p(out.ptr))
     return out
 
 

@@ -645,10 +645,11 @@ def test_float64_cube_stays_float64_through_the_other_operators(gpu, tmp_path, s
                 close(cm.percentile(30.0, axis=ax), np.nanpercentile(fz, 30.0, axis=ax), "percentile axis %d" % ax, rtol=1e-15)
             mad = 1.482602218505602 * np.nanmedian(np.abs(fz - np.nanmedian(fz, axis=0)), axis=0)
             close(cm.mad_std(axis=0), mad, "mad_std", rtol=1e-15)
-            clipped = cm.sigma_clip_spectrally(2.0, maxiters=3)
-            got = clipped.unmasked_data
-            exp = O.sigma_clip(g["data"], g["include_m"].astype(bool) & ~np.isnan(g["data"]), sigma=2.0, maxiters=3, out_dtype=np.float64)
-            assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)])
+            for stdf in ("std", "mad_std"):
+                clipped = cm.sigma_clip_spectrally(2.0, maxiters=3, stdfunc=stdf)
+                got = clipped.unmasked_data
+                exp = O.sigma_clip(g["data"], g["include_m"].astype(bool) & ~np.isnan(g["data"]), sigma=2.0, maxiters=3, stdfunc=stdf, out_dtype=np.float64)
+                assert got.dtype == np.float64 and np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)]), stdf
     # an operator without a float64 form narrows the smoothed cube, with the warning
     sm = cube.spectral_smooth(k1)
     with pytest.warns(PrecisionWarning, match="narrowed to float32"):

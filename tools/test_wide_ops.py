@@ -80,16 +80,16 @@ for it in range(16):
         mad = 1.482602218505602 * np.nanmedian(np.abs(fz - med), axis=0)
         gm = ops.percentile_axis0_f64(dd, 50.0, mask=spec)
         cmp(ops.percentile_axis0_f64(dd, 50.0, mask=spec, center=gm, scale=1.482602218505602).get(), mad, 1e-15, tag + " mad_std")
-        for cenf in ("median", "mean"):
+        for cenf, stdf in (("median", "std"), ("mean", "std"), ("median", "mad_std"), ("mean", "mad_std")):
             mi = [1, 3, 5, None][int(rng.integers(0, 4))]
             sg = float(rng.uniform(1.5, 3.5))
-            got = ops.sigma_clip_axis0_f64(dd, sigma=sg, maxiters=mi, cenfunc=cenf, mask=spec).get()
-            exp = O.sigma_clip(d, (np.ones(d.shape, bool) if inc is None else inc) & ~np.isnan(d), sigma=sg, maxiters=mi, cenfunc=cenf, out_dtype=np.float64)
+            got = ops.sigma_clip_axis0_f64(dd, sigma=sg, maxiters=mi, cenfunc=cenf, stdfunc=stdf, mask=spec).get()
+            exp = O.sigma_clip(d, (np.ones(d.shape, bool) if inc is None else inc) & ~np.isnan(d), sigma=sg, maxiters=mi, cenfunc=cenf, stdfunc=stdf, out_dtype=np.float64)
             bad = np.mean(np.isnan(got) != np.isnan(exp))
             same = ~np.isnan(got) & ~np.isnan(exp)
             okc = bad <= 2e-4 and np.array_equal(got[same], exp[same])
             if not okc: fails += 1
-            print("%s %s sigma_clip %s maxiters %s: NaN-pattern mismatch fraction %.1e" % ("ok  " if okc else "FAIL", tag, cenf, mi, bad), flush=True)
+            print("%s %s sigma_clip %s / %s maxiters %s: NaN-pattern mismatch fraction %.1e" % ("ok  " if okc else "FAIL", tag, cenf, stdf, mi, bad), flush=True)
     nar = ops.narrow_f64(dd).get()
     if not np.array_equal(nar, d.astype(np.float32), equal_nan=True): fails += 1; print("FAIL narrow", tag)
     gi = ops.mask_include_f64(dd, spec).get().astype(bool)
