@@ -520,6 +520,14 @@ __global__ __launch_bounds__(256) void include64_kernel(const Cube64 C, const Ma
     out[(z * C.ny + y) * C.nx + x] = ok ? 1 : 0;
 }
 
+// astropy: "The kernel can't be normalized, because its sum is close to zero" (convolve.py; the float32 entry points' check_kernel)
+static int check_kernel_sum(const double* k, size_t n) {
+    double sum = 0.0;
+    for (size_t i = 0; i < n; ++i) sum += k[i];
+    SPC_REQUIRE(!(sum < 1e-8 && sum > -1e-8) && sum >= 1.0 / 1e8, "The kernel can't be normalized, because its sum is close to zero");
+    return SPC_OK;
+}
+
 static int cube64_args(const spc_cube_f64* cube, const spc_mask_f64* mask, Cube64* C, MaskDev64* M, bool any_order = false) {
     int rc = any_order ? check_cube64_any_order(cube) : check_cube64(cube);
     if (rc) return rc;
@@ -601,6 +609,8 @@ int spc_spectral_conv_f64(int device, void* stream, const spc_cube_f64* cube, co
     if (rc) return rc;
     SPC_REQUIRE(h_kernel && d_out, "NULL pointer argument");
     SPC_REQUIRE(ntaps >= 1 && (ntaps & 1) && ntaps <= 8191, "the kernel needs an odd number of taps in [1, 8191], got %d", ntaps);
+    rc = check_kernel_sum(h_kernel, (size_t)ntaps);
+    if (rc) return rc;
     SPC_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     SpcWorkspace ws(d_workspace, workspace_bytes);
@@ -626,6 +636,16 @@ int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, con
     SPC_REQUIRE(nky >= 1 && (nky & 1) && nkx >= 1 && (nkx & 1) && nky <= 1023 && nkx <= 1023,
                 "kernel axes must be odd and at most 1023 (got %d x %d)", nky, nkx);
     SPC_REQUIRE(cube->ny <= 65535, "too many rows for one launch");
+    if (separable) {                                            // (the sum of an outer product is the product of the sums)
+        double sy = 0.0, sx = 0.0;
+        for (int i = 0; i < nky; ++i) sy += h_ky[i];
+        for (int i = 0; i < nkx; ++i) sx += h_kx[i];
+        const double prod = sy * sx;
+        rc = check_kernel_sum(&prod, 1);
+    } else {
+        rc = check_kernel_sum(h_ky, (size_t)nky * (size_t)nkx);
+    }
+    if (rc) return rc;
     SPC_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     SpcWorkspace ws(d_workspace, workspace_bytes);

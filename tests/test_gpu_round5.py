@@ -719,3 +719,14 @@ def test_float64_cube_reproject_and_convolve_to_stay_float64(gpu):
         exp = O.spatial_smooth(d, np.isfinite(d), karr) * (target.sr / jy.beam.sr)
         ok = ~np.isnan(exp)
         assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.abs(got[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max()
+
+
+def test_float64_convolutions_refuse_kernels_that_cannot_be_normalised(gpu):
+    """astropy: "The kernel can't be normalized, because its sum is close to zero" - the float64 entry points say so too"""
+    d = DeviceArray.from_numpy(np.ones((5, 6, 7)))
+    with pytest.raises(_lib.HipInvalidArgument, match="can't be normalized"):
+        ops.spectral_conv_f64(d, np.array([1.0, 0.0, -1.0]))
+    with pytest.raises(_lib.HipInvalidArgument, match="can't be normalized"):
+        ops.spatial_conv_f64(d, np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 0.0], [0.0, -1.0, 0.0]]))
+    with pytest.raises(_lib.HipInvalidArgument, match="can't be normalized"):
+        ops.spectral_conv_f64(d, np.zeros(1))

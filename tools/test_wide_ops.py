@@ -6,7 +6,7 @@ import numpy as np
 import oracle_np as O
 from spectral_cube_amd import ops, _lib
 from spectral_cube_amd.device import DeviceArray
-rng = np.random.default_rng(5)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 5)
 dev = DeviceArray.from_numpy
 fails = 0
 def cmp(a, b, tol, what):
@@ -19,7 +19,7 @@ def cmp(a, b, tol, what):
     ok = nanbad == 0 and err <= tol
     if not ok: fails += 1
     print("%s %s: nan mismatches %d, max err / scale %.2e" % ("ok  " if ok else "FAIL", what, nanbad, err), flush=True)
-for it in range(16):
+for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
     nz, ny, nx = int(rng.integers(1, 70)), int(rng.integers(1, 60)), int(rng.integers(1, 200))
     d = 1000.0 + rng.standard_normal((nz, ny, nx)) * 10.0 ** rng.uniform(-6, 1)          # float32 cannot hold these
     d[rng.random(d.shape) < rng.choice([0.0, 0.02, 0.3])] = np.nan
@@ -47,7 +47,7 @@ for it in range(16):
         if not np.array_equal(ra["count"].get(), cnt): fails += 1; print("FAIL", tag, "count ax%d" % ax)
     nt = int(rng.choice([1, 3, 9, 17, 33, 41, 81]))
     k = np.abs(rng.standard_normal(nt)) + 0.05
-    if it % 3 == 0: k[rng.integers(0, nt)] = 0.0
+    if it % 3 == 0 and nt > 1: k[rng.integers(0, nt)] = 0.0
     cmp(ops.spectral_conv_f64(dd, k, mask=spec).get(), O.spectral_smooth(d, inc, k), 1e-13, tag + " sconv%d" % nt)
     ky = int(rng.choice([3, 9, 17, 29])); g = np.exp(-0.5 * (np.arange(-(ky // 2), ky // 2 + 1) / (ky / 6.0)) ** 2)
     k2 = np.outer(g, g)
