@@ -90,7 +90,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "time":
         tf = timeit(lambda: ops.resample_bilinear_lerp(cube, dxs, dys, lo, t, inv, out=out, want_footprint=False))
         print("32 x 32 tiles, zchunk %s: fused interpolate + reproject %.3f ms" % (zc, tf), flush=True)
     os.environ.pop("SPC_BILINEAR_TILE")
-    for zc in (None, "64", "128", "512"):
+    for zc in (None, "256", "1024", "2048"):
         if zc: os.environ["SPC_BILINEAR_ZCHUNK"] = zc
         else: os.environ.pop("SPC_BILINEAR_ZCHUNK", None)
         tf = timeit(lambda: ops.resample_bilinear_lerp(cube, dxs, dys, lo, t, inv, out=out, want_footprint=False))
