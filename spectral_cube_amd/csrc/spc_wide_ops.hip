@@ -135,6 +135,7 @@ struct Conv64Args {
     double* out;
     int64_t out_row_stride, out_plane_stride;
     const double* kern;      // ntaps
+    const double* kpad;      // kpad[15 + j] = kern[j], 15 zeros on either side
     int ntaps;
 };
 __global__ __launch_bounds__(256) void spectral_conv64_kernel(const Conv64Args A) {
@@ -144,6 +145,49 @@ __global__ __launch_bounds__(256) void spectral_conv64_kernel(const Conv64Args A
     const int H = A.ntaps / 2;
     const int64_t o0 = (int64_t)blockIdx.y * kRun;
     double num[kRun], den[kRun];
+#pragma unroll
+    for (int u = 0; u < kRun; ++u) { num[u] = 0.0; den[u] = 0.0; }
+    // Fast form: the weights of input i for the run's 16 outputs are 16 CONSECUTIVE entries of the zero-padded tap table
+    // (wave-uniform: scalar loads), no test per (input, output) pair - ~40 instead of ~200 issue slots per input.  A padding zero
+    // times an infinite sample would be NaN where astropy has no product at all: a run that meets an infinity is redone below.
+    bool inf_seen = false;
+    {
+        // (eight inputs requested together, their channels clamped into the cube: one load at a time, a run waited out
+        //  ntaps + 15 memory latencies - 9.5 ms per 5e8 voxels)
+        constexpr int kIn = 8;
+        const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+        const int64_t i0 = o0 - H, nin = 2 * (int64_t)H + kRun;
+        const double* pd = A.c.p + y * A.c.row_stride + x;
+        const uint8_t* pmk = arr ? A.m.arr + y * A.m.row_stride + x : nullptr;
+        for (int64_t c0 = 0; c0 < nin; c0 += kIn) {
+            double vv[kIn];
+            unsigned mk[kIn];
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) {
+                const int64_t ic = min(max(i0 + c0 + q, (int64_t)0), A.c.nz - 1);
+                vv[q] = pd[ic * A.c.plane_stride];
+                mk[q] = arr ? pmk[ic * A.m.plane_stride] : 1u;
+            }
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) {
+                const int64_t i = i0 + c0 + q;
+                if (c0 + q < nin) {                                 // (uniform)
+                    const bool inr = i >= 0 && i < A.c.nz;          // (uniform) outside the cube: a valid zero
+                    const bool ok = pred64(A.m, vv[q]) && mk[q] != 0u;
+                    const double v = (inr && ok) ? vv[q] : 0.0, w = inr ? (ok ? 1.0 : 0.0) : 1.0;
+                    inf_seen = inf_seen || (fabs(v) == INFINITY);
+                    const double* kp = A.kpad + 15 + (o0 - i + H);  // kp[u] = kern[(o0 + u) - i + H], or a padding zero
+#pragma unroll
+                    for (int u = 0; u < kRun; ++u) {
+                        const double kw = kp[u];
+                        num[u] = fma(kw, v, num[u]);
+                        den[u] = fma(kw, w, den[u]);
+                    }
+                }
+            }
+        }
+    }
+    if (!__any(inf_seen)) goto emit;
 #pragma unroll
     for (int u = 0; u < kRun; ++u) { num[u] = 0.0; den[u] = 0.0; }
     // astropy's order: the flipped kernel is walked from its first element, i.e. the inputs of an output from the lowest channel up
@@ -162,6 +206,7 @@ __global__ __launch_bounds__(256) void spectral_conv64_kernel(const Conv64Args A
             }
         }
     }
+emit:
 #pragma unroll
     for (int u = 0; u < kRun; ++u) {
         const int64_t o = o0 + u;
@@ -193,15 +238,31 @@ __global__ __launch_bounds__(256) void spatial64_xpass_kernel(const Sp64Args A) 
     if (x >= A.c.nx) return;
     const int H = A.nkx / 2;
     double num = 0.0, den = 0.0;
-    for (int j = 0; j < A.nkx; ++j) {                            // astropy's order along the fast axis
-        const double kw = A.kx[A.nkx - 1 - j];                   // flipped kernel, input x - H + j
-        if (kw == 0.0) continue;
-        const int64_t i = x - H + j;
-        double v = 0.0, w = 1.0;
-        if (i >= 0 && i < A.c.nx) {
-            if (!inc64(A.c, A.m, z, y, i, v)) { v = 0.0; w = 0.0; }
+    const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+    const double* pd = A.c.p + z * A.c.plane_stride + y * A.c.row_stride;
+    const uint8_t* pmk = arr ? A.m.arr + z * A.m.plane_stride + y * A.m.row_stride : nullptr;
+    constexpr int kIn = 8;                                       // loads requested together (clamped into the row)
+    for (int j0 = 0; j0 < A.nkx; j0 += kIn) {                    // astropy's order along the fast axis
+        double vv[kIn];
+        unsigned mk[kIn];
+#pragma unroll
+        for (int q = 0; q < kIn; ++q) {
+            const int64_t ic = min(max(x - H + j0 + q, (int64_t)0), A.c.nx - 1);
+            vv[q] = pd[ic];
+            mk[q] = arr ? pmk[ic] : 1u;
         }
-        num = fma(kw, v, num); den = fma(kw, w, den);
+#pragma unroll
+        for (int q = 0; q < kIn; ++q) {
+            const int j = j0 + q;
+            if (j < A.nkx) {                                     // (uniform)
+                const double kw = A.kx[A.nkx - 1 - j];           // flipped kernel, input x - H + j
+                const int64_t i = x - H + j;
+                const bool inr = i >= 0 && i < A.c.nx;
+                const bool ok = pred64(A.m, vv[q]) && mk[q] != 0u;
+                const double v = (inr && ok) ? vv[q] : 0.0, w = inr ? (ok ? 1.0 : 0.0) : 1.0;
+                if (kw != 0.0) { num = fma(kw, v, num); den = fma(kw, w, den); }
+            }
+        }
     }
     double* t = A.tmp + ((zl * A.c.ny + y) * A.c.nx + x) * 2;
     t[0] = num; t[1] = den;
@@ -215,16 +276,26 @@ __global__ __launch_bounds__(256) void spatial64_ypass_kernel(const Sp64Args A) 
     double ksx = 0.0;
     for (int j = 0; j < A.nkx; ++j) ksx += A.kx[j];
     double num = 0.0, den = 0.0;
-    for (int j = 0; j < A.nky; ++j) {
-        const double kw = A.ky[A.nky - 1 - j];
-        if (kw == 0.0) continue;
-        const int64_t i = y - H + j;
-        double tn = 0.0, td = ksx;
-        if (i >= 0 && i < A.c.ny) {
-            const double* t = A.tmp + ((zl * A.c.ny + i) * A.c.nx + x) * 2;
-            tn = t[0]; td = t[1];
+    constexpr int kIn = 8;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    for (int j0 = 0; j0 < A.nky; j0 += kIn) {
+        f64x2 tt[kIn];
+#pragma unroll
+        for (int q = 0; q < kIn; ++q) {
+            const int64_t ic = min(max(y - H + j0 + q, (int64_t)0), A.c.ny - 1);
+            tt[q] = *reinterpret_cast<const f64x2*>(A.tmp + ((zl * A.c.ny + ic) * A.c.nx + x) * 2);
         }
-        num = fma(kw, tn, num); den = fma(kw, td, den);
+#pragma unroll
+        for (int q = 0; q < kIn; ++q) {
+            const int j = j0 + q;
+            if (j < A.nky) {
+                const double kw = A.ky[A.nky - 1 - j];
+                const int64_t i = y - H + j;
+                const bool inr = i >= 0 && i < A.c.ny;           // (uniform) a row outside the image: valid zeros
+                const double tn = inr ? tt[q].x : 0.0, td = inr ? tt[q].y : ksx;
+                if (kw != 0.0) { num = fma(kw, tn, num); den = fma(kw, td, den); }
+            }
+        }
     }
     double res;
     if (den != 0.0) res = num / den;
@@ -543,7 +614,7 @@ static int cube64_args(const spc_cube_f64* cube, const spc_mask_f64* mask, Cube6
 size_t spc_ws_wide(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1) {
     switch (kind) {
         case SPC_WS_STATS_GLOBAL_F64: return spc_ws_round(sizeof(Rec64) * 4096) + spc_ws_round(5 * sizeof(double)) + 256;
-        case SPC_WS_SPECTRAL_CONV_F64: return spc_ws_round(sizeof(double) * (size_t)std::max<int64_t>(p0, 1)) + 256;
+        case SPC_WS_SPECTRAL_CONV_F64: return spc_ws_round(sizeof(double) * (size_t)(2 * std::max<int64_t>(p0, 1) + 30)) + 256;   // taps + the zero-padded table
         case SPC_WS_SPATIAL_CONV_F64: {
             // taps + the (num, den) planes of a slab: at most 1 GiB, at least one plane
             const size_t plane = (size_t)ny * (size_t)nx * 2 * sizeof(double);
@@ -614,9 +685,13 @@ int spc_spectral_conv_f64(int device, void* stream, const spc_cube_f64* cube, co
     SPC_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     SpcWorkspace ws(d_workspace, workspace_bytes);
-    SPC_WS_TAKE(d_k, ws, double, ntaps);
-    SPC_HIP(spc_table_upload(d_k, h_kernel, sizeof(double) * (size_t)ntaps, st));
-    A.kern = d_k; A.ntaps = ntaps; A.out = d_out;
+    SPC_WS_TAKE(d_k, ws, double, 2 * ntaps + 30);
+    {
+        std::vector<double> hk((size_t)(2 * ntaps + 30), 0.0);
+        for (int i = 0; i < ntaps; ++i) { hk[(size_t)i] = h_kernel[i]; hk[(size_t)(ntaps + 15 + i)] = h_kernel[i]; }
+        SPC_HIP(spc_table_upload(d_k, hk.data(), sizeof(double) * hk.size(), st));
+    }
+    A.kern = d_k; A.kpad = d_k + ntaps; A.ntaps = ntaps; A.out = d_out;
     A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
     A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
     const int64_t nb = (cube->ny * cube->nx + 255) / 256, runs = (cube->nz + kRun - 1) / kRun;
