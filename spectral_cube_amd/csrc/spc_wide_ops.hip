@@ -60,11 +60,24 @@ __global__ __launch_bounds__(256) void stats64_global_kernel(const Cube64 C, con
     __shared__ Rec64 sh[4];
     Rec64 r = rec_empty();
     const int64_t nrows = C.nz * C.ny;
+    const bool arr = (M.flags & SPC_MASK_ARRAY) != 0;
+    constexpr int kIn = 4;                                       // samples requested together per lane (clamped into the row)
     for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
         const int64_t z = row / C.ny, y = row - z * C.ny;
-        for (int64_t x = threadIdx.x; x < C.nx; x += blockDim.x) {
-            double v;
-            if (inc64(C, M, z, y, x, v)) rec_add(r, v);
+        const double* pd = C.p + z * C.plane_stride + y * C.row_stride;
+        const uint8_t* pm = arr ? M.arr + z * M.plane_stride + y * M.row_stride : nullptr;
+        for (int64_t x0 = threadIdx.x; x0 < C.nx; x0 += (int64_t)blockDim.x * kIn) {
+            double vv[kIn];
+            unsigned mk[kIn];
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) {
+                const int64_t xc = min(x0 + (int64_t)q * blockDim.x, C.nx - 1);
+                vv[q] = pd[xc];
+                mk[q] = arr ? pm[xc] : 1u;
+            }
+#pragma unroll
+            for (int q = 0; q < kIn; ++q)
+                if (x0 + (int64_t)q * blockDim.x < C.nx && pred64(M, vv[q]) && mk[q] != 0u) rec_add(r, vv[q]);
         }
     }
     r = rec_block_reduce(r, sh);
@@ -100,10 +113,23 @@ __global__ __launch_bounds__(256) void stats64_march_kernel(const Cube64 C, cons
     const int64_t a = g / C.nx, x = g - a * C.nx;
     const int64_t n = AXIS == 0 ? C.nz : C.ny;
     Rec64 r = rec_empty();
-    for (int64_t k = 0; k < n; ++k) {
-        double v;
-        const bool ok = AXIS == 0 ? inc64(C, M, k, a, x, v) : inc64(C, M, a, k, x, v);
-        if (ok) rec_add(r, v);
+    const bool arr = (M.flags & SPC_MASK_ARRAY) != 0;
+    const int64_t dstep = AXIS == 0 ? C.plane_stride : C.row_stride, mstep = AXIS == 0 ? M.plane_stride : M.row_stride;
+    const double* pd = C.p + (AXIS == 0 ? a * C.row_stride : a * C.plane_stride) + x;
+    const uint8_t* pm = arr ? M.arr + (AXIS == 0 ? a * M.row_stride : a * M.plane_stride) + x : nullptr;
+    constexpr int kIn = 8;                                       // samples requested together per lane (clamped into the ray)
+    for (int64_t k0 = 0; k0 < n; k0 += kIn) {
+        double vv[kIn];
+        unsigned mk[kIn];
+#pragma unroll
+        for (int q = 0; q < kIn; ++q) {
+            const int64_t kc = min(k0 + q, n - 1);
+            vv[q] = pd[kc * dstep];
+            mk[q] = arr ? pm[kc * mstep] : 1u;
+        }
+#pragma unroll
+        for (int q = 0; q < kIn; ++q)
+            if (k0 + q < n && pred64(M, vv[q]) && mk[q] != 0u) rec_add(r, vv[q]);
     }
     stat_store(O, g, r);
 }
