@@ -484,13 +484,33 @@ __global__ __launch_bounds__(256) void sort64_kernel(const Sort64Args A) {
     const int r = t % TS, jz = t / TS;
     const bool col_in = x0 + r < A.c.nx;
     const double cen = (A.center && col_in) ? A.center[y * A.c.nx + x0 + r] : 0.0;
-    auto key_of = [&](int64_t z) {
-        double v;
-        bool ok = inc64(A.c, A.m, z, y, x0 + r, v);
-        if (A.center) { v = fabs(v - cen); ok = ok && (v == v); }
-        return ok ? fkey64(v) : kExcl;
-    };
-    for (int z = jz; z < NZP; z += L) keys[z * TS + r] = (col_in && z < A.c.nz) ? key_of(z) : kExcl;
+    {   // (eight samples requested together per lane, their channels clamped into the ray)
+        constexpr int kIn = 8;
+        const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+        const int64_t xc = col_in ? x0 + r : A.c.nx - 1;
+        const double* pd = A.c.p + y * A.c.row_stride + xc;
+        const uint8_t* pmk = arr ? A.m.arr + y * A.m.row_stride + xc : nullptr;
+        for (int z0 = jz; z0 < NZP; z0 += L * kIn) {
+            double vv[kIn];
+            unsigned mk[kIn];
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) {
+                const int64_t zc = min((int64_t)(z0 + q * L), A.c.nz - 1);
+                vv[q] = pd[zc * A.c.plane_stride];
+                mk[q] = arr ? pmk[zc * A.m.plane_stride] : 1u;
+            }
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) {
+                const int z = z0 + q * L;
+                if (z < NZP) {
+                    double v = vv[q];
+                    bool ok = col_in && z < A.c.nz && pred64(A.m, v) && mk[q] != 0u;
+                    if (A.center) { v = fabs(v - cen); ok = ok && (v == v); }
+                    keys[z * TS + r] = ok ? fkey64(v) : kExcl;
+                }
+            }
+        }
+    }
     __syncthreads();
     const int half = (TS * NZP) >> 1;
     for (int k = 2; k <= NZP; k <<= 1) {
