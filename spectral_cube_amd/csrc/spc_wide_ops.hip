@@ -449,13 +449,14 @@ __global__ __launch_bounds__(256) void scale64_kernel(double* p, int64_t n, doub
 
 // ---- order statistics along the spectral axis ------------------------------------------------------------------------------
 // median / percentile / mad_std (dask_spectral_cube.py:657-731) and sigma_clip_spectrally (:851-878, centre = median | mean,
-// spread = std) of float64 rays of up to 4096 samples.  No register-resident radix descent like the float32 kernels: a block sorts
-// its TS = 16384 / NZP adjacent rays (order-preserving 64-bit keys, excluded / NaN samples last) in 128 KB of LDS with a bitonic
+// spread = std | mad_std) of float64 rays of up to 4096 samples.  No register-resident radix descent like the float32 kernels: a block sorts
+// its TS = 4096 / NZP adjacent rays (order-preserving 64-bit keys, excluded / NaN samples last) in 32 KB of LDS with a bitonic
 // network, then one lane per ray reads what it needs from the sorted ray - the order statistics directly (numpy's linear rule,
 // its `_lerp` form), the clip loop as a shrinking window [a, b) of the sorted samples (clipping removes the two ends of a sorted ray;
 // mean and std of a window are two scans of it, nanstd's two-pass form).  The clipped cube is written in a last sweep over the
 // rays: a sample survives when its key lies between the window's end keys.
-constexpr int kSortKeys = 16384;
+constexpr int kSortKeys = 4096;          // 32 KB of keys per block: four or five blocks per CU (16384 keys, one block: 41 ms per 5e8 voxels;
+                                         // 8192: 21.8; 4096: 14.7 - the network's barriers and LDS round trips want other blocks to run beside them)
 constexpr unsigned long long kExcl = ~0ull;
 __device__ __forceinline__ unsigned long long fkey64(double v) {
     const unsigned long long u = (unsigned long long)__double_as_longlong(v);
