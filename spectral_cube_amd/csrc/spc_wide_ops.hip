@@ -328,6 +328,78 @@ __global__ __launch_bounds__(256) void spatial64_ypass_kernel(const Sp64Args A) 
     else { double cv; res = inc64(A.c, A.m, z, y, x, cv) ? cv : NAN; }
     A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
 }
+// The two passes through LDS: a block of the x pass stages its row segment once (256 outputs + the halo; the untiled pass asks the
+// texture path for 58 samples per output), a block of the y pass a tile of 16 rows x 64 columns of (num, den) pairs + the halo rows
+// (464 bytes of L2 traffic per output otherwise).  Same arithmetic, same order.
+constexpr int kSpHaloMax = 511, kSpYRows = 16, kSpYHalo = 24;     // (y tiles of up to 64 rows x 64 columns x 16 bytes = 64 KB of dynamic LDS)
+__global__ __launch_bounds__(256) void spatial64_xpass_lds_kernel(const Sp64Args A) {
+    __shared__ double sv[256 + 2 * kSpHaloMax];
+    __shared__ float sw[256 + 2 * kSpHaloMax];
+    __shared__ double sk[2 * kSpHaloMax + 1];                   // the flipped taps (a scalar load per tap waited out its latency in every lane's loop)
+    const int t = threadIdx.x, H = A.nkx / 2;
+    for (int j = t; j < A.nkx; j += 256) sk[j] = A.kx[A.nkx - 1 - j];
+    const int64_t x0 = (int64_t)blockIdx.x * 256, y = blockIdx.y, zl = blockIdx.z, z = A.z0 + zl;
+    const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+    const double* pd = A.c.p + z * A.c.plane_stride + y * A.c.row_stride;
+    const uint8_t* pmk = arr ? A.m.arr + z * A.m.plane_stride + y * A.m.row_stride : nullptr;
+    for (int e = t; e < 256 + 2 * H; e += 256) {
+        const int64_t i = x0 - H + e, ic = min(max(i, (int64_t)0), A.c.nx - 1);
+        const double v = pd[ic];
+        const bool inr = i >= 0 && i < A.c.nx, ok = pred64(A.m, v) && (!arr || pmk[ic] != 0);
+        sv[e] = (inr && ok) ? v : 0.0;
+        sw[e] = inr ? (ok ? 1.f : 0.f) : 1.f;                    // outside the image: a valid zero
+    }
+    __syncthreads();
+    const int64_t x = x0 + t;
+    if (x >= A.c.nx) return;
+    double num = 0.0, den = 0.0;
+    for (int j = 0; j < A.nkx; ++j) {                            // astropy's order along the fast axis
+        const double kw = sk[j];                                 // flipped kernel, input x - H + j
+        if (kw != 0.0) { num = fma(kw, sv[t + j], num); den = fma(kw, (double)sw[t + j], den); }
+    }
+    double* o = A.tmp + ((zl * A.c.ny + y) * A.c.nx + x) * 2;
+    o[0] = num; o[1] = den;
+}
+__global__ __launch_bounds__(256) void spatial64_ypass_lds_kernel(const Sp64Args A) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ f64x2 tile[];                              // (kSpYRows + 2 H) x 64 pairs: sized by the launch
+    __shared__ double sk[2 * kSpYHalo + 1];
+    const int t = threadIdx.x, col = t & 63, rg = t >> 6, H = A.nky / 2;
+    if (t < A.nky) sk[t] = A.ky[A.nky - 1 - t];
+    const int64_t x = (int64_t)blockIdx.x * 64 + col, y0 = (int64_t)blockIdx.y * kSpYRows, zl = blockIdx.z, z = A.z0 + zl;
+    double ksx = 0.0;                                            // a row outside the image: valid zeros under the whole x kernel
+    for (int j = 0; j < A.nkx; ++j) ksx += A.kx[j];
+    const int64_t xc = min(x, A.c.nx - 1);
+    for (int r0 = rg; r0 < kSpYRows + 2 * H; r0 += 16) {         // (four rows per lane requested together, clamped into the image)
+        f64x2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t ic = min(max(y0 - H + r0 + 4 * q, (int64_t)0), A.c.ny - 1);
+            v[q] = *reinterpret_cast<const f64x2*>(A.tmp + ((zl * A.c.ny + ic) * A.c.nx + xc) * 2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = r0 + 4 * q;
+            const int64_t i = y0 - H + rr;
+            if (rr < kSpYRows + 2 * H) tile[rr * 64 + col] = (i >= 0 && i < A.c.ny) ? v[q] : f64x2{0.0, ksx};
+        }
+    }
+    __syncthreads();
+    if (x >= A.c.nx) return;
+    for (int ro = rg; ro < kSpYRows; ro += 4) {
+        const int64_t y = y0 + ro;
+        if (y >= A.c.ny) break;
+        double num = 0.0, den = 0.0;
+        for (int j = 0; j < A.nky; ++j) {
+            const double kw = sk[j];
+            if (kw != 0.0) { const f64x2 tv = tile[(ro + j) * 64 + col]; num = fma(kw, tv.x, num); den = fma(kw, tv.y, den); }
+        }
+        double res;
+        if (den != 0.0) res = num / den;
+        else { double cv; res = inc64(A.c, A.m, z, y, x, cv) ? cv : NAN; }
+        A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
+    }
+}
 __global__ __launch_bounds__(256) void spatial64_direct_kernel(const Sp64Args A) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t y = blockIdx.y, z = A.z0 + blockIdx.z;
@@ -803,9 +875,17 @@ int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, con
     for (int64_t z0 = 0; z0 < cube->nz; z0 += planes) {
         A.z0 = z0;
         const unsigned gz = (unsigned)std::min<int64_t>(planes, cube->nz - z0);
-        hipLaunchKernelGGL(spatial64_xpass_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
+        static const bool tiled = [] { const char* e = getenv("SPC_SPATIAL64_LDS"); return e ? atoi(e) != 0 : true; }();
+        if (tiled && nkx / 2 <= kSpHaloMax)
+            hipLaunchKernelGGL(spatial64_xpass_lds_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
+        else
+            hipLaunchKernelGGL(spatial64_xpass_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
         SPC_LAUNCH_CHECK();
-        hipLaunchKernelGGL(spatial64_ypass_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
+        if (tiled && nky / 2 <= kSpYHalo && (cube->ny + kSpYRows - 1) / kSpYRows <= 65535)
+            hipLaunchKernelGGL(spatial64_ypass_lds_kernel, dim3((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + kSpYRows - 1) / kSpYRows), gz),
+                               dim3(256), (size_t)(kSpYRows + 2 * (nky / 2)) * 64 * 16, st, A);
+        else
+            hipLaunchKernelGGL(spatial64_ypass_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
         SPC_LAUNCH_CHECK();
     }
     return SPC_OK;
