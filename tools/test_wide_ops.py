@@ -49,7 +49,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 16):
     k = np.abs(rng.standard_normal(nt)) + 0.05
     if it % 3 == 0 and nt > 1: k[rng.integers(0, nt)] = 0.0
     cmp(ops.spectral_conv_f64(dd, k, mask=spec).get(), O.spectral_smooth(d, inc, k), 1e-13, tag + " sconv%d" % nt)
-    ky = int(rng.choice([3, 9, 17, 29])); g = np.exp(-0.5 * (np.arange(-(ky // 2), ky // 2 + 1) / (ky / 6.0)) ** 2)
+    ky = int(rng.choice([3, 9, 17, 29, 51])); g = np.exp(-0.5 * (np.arange(-(ky // 2), ky // 2 + 1) / (ky / 6.0)) ** 2)
     k2 = np.outer(g, g)
     small, sinc = d[:min(nz, 3)], (None if inc is None else inc[:min(nz, 3)])
     sspec = None if spec is None else (ops.MaskSpec(_lib.MASK_ARRAY, array=dev(sinc.astype(np.uint8))) if kind == 1 else spec)
