@@ -528,12 +528,25 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
         for (int64_t j = 0; j < ja; ++j) put(j, nan4);
         for (int64_t j = jb; j < A.nz_out; ++j) put(j, nan4);
     }
+    // LERP: the output channels of a group's planes and their blend weights go through LDS with the group's samples - read as
+    // scalar loads inside the loop below they sit behind the stores (the compiler must assume the stores alias them: every
+    // output waited out a scalar round trip)
+    constexpr int kWj = 256;
+    __shared__ double s_wj[LERP ? kWj : 1];
+    __shared__ int s_jf[LERP ? kStageU + 1 : 1];
     for (int64_t zq = zb; zq < ze; zq += kStageU) {
 #pragma unroll
         for (int u = 0; u < kStageU; ++u)
 #pragma unroll
             for (int k = 0; k < kFill; ++k)
                 if (kThreads * k < E && foff[k] >= 0) stage[u * kElemsMax + t + kThreads * k] = pre[u][k];
+        if (LERP) {
+            // s_jf[u] = first output channel whose left bracket is plane zq + u - 1 (u = 0 .. kStageU); weights of the group's outputs
+            if (t <= kStageU) s_jf[t] = A.jfirst[min(max(zq + t - 1, (int64_t)0), A.nz - 1)];
+            const int jlo = A.jfirst[min(max(zq - 1, (int64_t)0), A.nz - 1)];
+            const int jhi = A.jfirst[min(zq + kStageU - 1, A.nz - 1)];
+            for (int i = t; i < min(jhi - jlo, kWj); i += kThreads) s_wj[i] = A.inv_dx[jlo + i] * A.t[jlo + i];
+        }
         lds_only_barrier();
         if (zq + kStageU < ze) fetch(zq + kStageU);        // in flight while this group is resampled
 #pragma unroll
@@ -552,9 +565,9 @@ __global__ __launch_bounds__(BilTile<TILE>::kThreads) void bilinear_lds_kernel(c
             if (!LERP) put(z, r4);
             else {
                 if (z > zb) {
-                    const int j1 = A.jfirst[z];                           // (block-uniform: scalar loads)
-                    for (int j = A.jfirst[z - 1]; j < j1; ++j) {
-                        const double wj = A.inv_dx[j] * A.t[j];
+                    const int jbase = s_jf[0], j1 = s_jf[u + 1];
+                    for (int j = s_jf[u]; j < j1; ++j) {
+                        const double wj = (j - jbase < kWj) ? s_wj[j - jbase] : A.inv_dx[j] * A.t[j];
                         float o4[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { o4[q] = bil_lerp(prev[q], r4[q], wj); anyv = anyv || (o4[q] == o4[q]); }
