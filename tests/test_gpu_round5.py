@@ -409,6 +409,8 @@ def _rot_map(nyo, nxo, ny, nx, deg, scale=1.0, shift=(0.0, 0.0)):
     dict(shape=(2, 40, 50), out=(7, 64, 64), deg=45.0, mask="array", order=0),      # two channels, nearest neighbour
     dict(shape=(25, 33, 47), out=(60, 31, 29), deg=200.0, mask=None, beyond=True),  # output channels beyond both ends
     dict(shape=(19, 70, 66), out=(41, 130, 140), deg=33.0, mask="array", beyond=True, descending=True),   # a reversed output grid
+    dict(shape=(3, 40, 50), out=(1500, 130, 136), deg=15.0, mask=None),             # 750 output channels per input plane: more than the staged weights hold
+    dict(shape=(3, 30, 40), out=(1200, 40, 36), deg=-40.0, mask="array"),           # ... with 32 x 32 tiles
 ])
 def test_bilinear_with_the_spectral_interpolation_folded_in(gpu, case):
     """one pass = interpolate, then resample (the oracle's order, dask_spectral_cube.py:1342-1353 then spectral_cube.py:2726-2732)
