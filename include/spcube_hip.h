@@ -157,7 +157,7 @@ typedef enum {
     SPC_WS_STATS_GLOBAL_F64 = 14,     /* spc_stats_global_f64 (ABI 8) */
     SPC_WS_SPECTRAL_CONV_F64 = 15,    /* spc_spectral_conv_f64, p0 = ntaps (ABI 8) */
     SPC_WS_SPATIAL_CONV_F64 = 16      /* spc_spatial_conv_f64, p0 = nky, p1 = nkx: the taps + the (num, den) planes of a slab of at
-                                       * most 1 GiB (a smaller workspace is accepted as long as one plane fits) (ABI 8) */
+                                       * most 256 MiB (a smaller workspace is accepted as long as one plane fits) (ABI 8) */
 } spc_ws_kind;
 size_t spc_workspace_bytes(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1);
 

@@ -735,9 +735,9 @@ size_t spc_ws_wide(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int
         case SPC_WS_STATS_GLOBAL_F64: return spc_ws_round(sizeof(Rec64) * 4096) + spc_ws_round(5 * sizeof(double)) + 256;
         case SPC_WS_SPECTRAL_CONV_F64: return spc_ws_round(sizeof(double) * (size_t)(2 * std::max<int64_t>(p0, 1) + 30)) + 256;   // taps + the zero-padded table
         case SPC_WS_SPATIAL_CONV_F64: {
-            // taps + the (num, den) planes of a slab: at most 1 GiB, at least one plane
+            // taps + the (num, den) planes of a slab: at most 256 MiB (the caller keeps its scratch), at least one plane
             const size_t plane = (size_t)ny * (size_t)nx * 2 * sizeof(double);
-            const size_t slab = std::max<size_t>(plane, std::min<size_t>((size_t)nz * plane, (size_t)1 << 30));
+            const size_t slab = std::max<size_t>(plane, std::min<size_t>((size_t)nz * plane, (size_t)1 << 28));
             return spc_ws_round(sizeof(double) * (size_t)(std::max<int64_t>(p0, 1) * std::max<int64_t>(p1, 1) + p0 + p1)) + spc_ws_round(slab) + 512;
         }
     }
