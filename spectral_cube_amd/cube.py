@@ -706,14 +706,15 @@ class SpectralCube:
         except _lib.HipLibraryError:
             return False
 
-    def _new_wide_cube(self, fn64, shape=None, wcs=None, mask=None):
+    def _new_wide_cube(self, fn64, shape=None, wcs=None, mask=None, plain=False):
         """the result of a float64 operator on this (wide, resident) cube: a cube whose values exist as a float64 DeviceArray
         (pending until first used; the Dask class keeps the chunk dtype, dask_spectral_cube.py:829).  Its spectral moments,
         reductions, statistics() and further smoothing / interpolation run in float64; an operator without a float64 form
         narrows it with a PrecisionWarning, like a float64 source."""
         holder = []
         narrow = _Thunk(lambda: ops.narrow_f64(holder[0]._device_data64()))
-        out = self._new_cube_with(lazy=narrow, shape=tuple(shape) if shape is not None else self._shape, wcs=wcs, mask=mask)
+        make = (lambda **kw: SpectralCube._new_cube_with(self, **kw)) if plain else self._new_cube_with      # plain: not the subclass's (beams)
+        out = make(lazy=narrow, shape=tuple(shape) if shape is not None else self._shape, wcs=wcs, mask=mask)
         out._data_id.lazy64 = fn64
         out._data_id.derived64 = True
         holder.append(out)
@@ -1843,6 +1844,30 @@ class VaryingResolutionSpectralCube(SpectralCube):
                 a = b
             return out
 
+        if self._runs_wide():
+            # a float64 cube: the same runs on the float64 samples (a pass-through channel = the 1 x 1 kernel: the filled sample)
+            parent, dev_ = self, self.device
+
+            def run64():
+                src, spec = parent._device_data64(), parent._mask_spec64()
+                n = src.shape[0]
+                out = DeviceArray(src.shape, np.float64, dev_)
+                a = 0
+                while a < n:
+                    b = a + 1
+                    while b < n and plans[b] is plans[a]:
+                        b += 1
+                    o, m = out.planes(a, b), (spec.planes(a, b) if spec is not None else None)
+                    if plans[a] is None:
+                        ops.spatial_conv_f64(src.planes(a, b), np.ones((1, 1)), mask=m, out=o)
+                    else:
+                        _, karr, ratio = plans[a]
+                        ops.spatial_conv_f64(src.planes(a, b), karr, mask=m, out=o)
+                        if ratio != 1.0:
+                            ops.scale_inplace_f64(o, ratio)
+                    a = b
+                return out
+            return self._new_wide_cube(run64, plain=True).with_beam(beam, raise_error_jybm=False)
         if self._stream_source() is not None:
             # out of core: slabs of whole planes (every channel has its own kernel, the slab knows its first channel);
             # pending until write() / stream_into()

@@ -732,3 +732,34 @@ def test_float64_convolutions_refuse_kernels_that_cannot_be_normalised(gpu):
         ops.spatial_conv_f64(d, np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 0.0], [0.0, -1.0, 0.0]]))
     with pytest.raises(_lib.HipInvalidArgument, match="can't be normalized"):
         ops.spectral_conv_f64(d, np.zeros(1))
+
+
+def test_float64_varying_resolution_convolve_to(gpu, tmp_path):
+    """VaryingResolutionSpectralCube.convolve_to (dask_spectral_cube.py:1511-1630) of float64 samples: every channel with its own
+    deconvolved kernel on the float64 samples, float64 out (a pass-through channel = the filled samples); the golden cube of
+    tests/golden/beams_cube.npz lifted onto a 1000-unit baseline that float32 cannot hold beside the signal"""
+    import warnings as W
+    from conftest import golden
+    from spectral_cube_amd import PrecisionWarning, SpectralCube, VaryingResolutionSpectralCube, Beam
+    g = golden("beams_cube.npz")
+    p = tmp_path / "beams.fits"
+    p.write_bytes(g["file_arcsec"].tobytes())
+    with W.catch_warnings():
+        W.simplefilter("ignore")
+        ref = SpectralCube.read(str(p))
+    d = 1000.0 + 1e-4 * g["data"].astype(np.float64)
+    tgt = Beam(*g["target"])
+    with W.catch_warnings():
+        W.simplefilter("ignore")
+        W.simplefilter("error", PrecisionWarning)
+        cube = VaryingResolutionSpectralCube(d, header=ref.header, beams=list(ref.unmasked_beams), goodbeams_mask=np.asarray(ref.goodbeams_mask))
+        out = cube.convolve_to(tgt)
+        got = out.unmasked_data
+    assert type(out) is SpectralCube and out.beam == tgt and got.dtype == np.float64
+    for k in (0, 1, 2, 5):
+        ratio = tgt.sr / ref.unmasked_beams[k].sr                          # Jy/beam data
+        exp = O.spatial_smooth(d[k:k + 1], np.isfinite(d[k:k + 1]), g["kernel_%d" % k])[0] * ratio
+        ok = ~np.isnan(exp)
+        assert np.array_equal(np.isnan(got[k]), np.isnan(exp)) and np.abs(got[k][ok] - exp[ok]).max() <= 1e-12 * np.abs(exp[ok]).max(), k
+    assert np.array_equal(got[3], d[3], equal_nan=True)                     # beam == target: untouched float64 samples
+    assert np.isnan(got[4]).all()                                           # masked-out layer
