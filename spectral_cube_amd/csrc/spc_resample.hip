@@ -358,10 +358,10 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const BilArgs A) {
 // (x1.3) at the price of one 1024-thread block per CU and 4 instead of 8 staged channels.
 template <int TILE> struct BilTile;
 template <> struct BilTile<32> {
-    static constexpr int kThreads = 256, kRowsMax = 64, kElemsMax = 2048, kStageU = 8, kShift = 5;
+    static constexpr int kThreads = 256, kRowsMax = 64, kElemsMax = 2048, kStageU = 8;
 };
 template <> struct BilTile<64> {
-    static constexpr int kThreads = 1024, kRowsMax = 128, kElemsMax = 6144, kStageU = 4, kShift = 6;
+    static constexpr int kThreads = 1024, kRowsMax = 128, kElemsMax = 6144, kStageU = 4;
 };
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
