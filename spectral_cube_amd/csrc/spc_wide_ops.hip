@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void spatial64_ypass_kernel(const Sp64Args A) 
 // The two passes through LDS: a block of the x pass stages its row segment once (256 outputs + the halo; the untiled pass asks the
 // texture path for 58 samples per output), a block of the y pass a tile of 16 rows x 64 columns of (num, den) pairs + the halo rows
 // (464 bytes of L2 traffic per output otherwise).  Same arithmetic, same order.
-constexpr int kSpHaloMax = 511, kSpYRows = 16, kSpYHalo = 24;     // (y tiles of up to 64 rows x 64 columns x 16 bytes = 64 KB of dynamic LDS)
+constexpr int kSpHaloMax = 511, kSpYRows = 16, kSpYHalo = 23;     // (y tiles of up to 62 rows x 64 columns x 16 bytes = 62 KB of dynamic LDS + the taps: inside the 64 KB a launch gets without hipFuncSetAttribute; 49 y taps and more take the untiled pass)
 __global__ __launch_bounds__(256) void spatial64_xpass_lds_kernel(const Sp64Args A) {
     __shared__ double sv[256 + 2 * kSpHaloMax];
     __shared__ float sw[256 + 2 * kSpHaloMax];

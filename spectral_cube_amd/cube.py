@@ -87,6 +87,15 @@ class _DataToken:
         self.derived64 = False       # the values exist as a float64 DeviceArray only (dev64 / lazy64): no host array, no file
 
 
+def _token_dev64(tok):
+    """the float64 DeviceArray of a DERIVED wide cube's data token (pending operator run once)"""
+    if tok.dev64 is None:
+        _lib.require_gpu()
+        tok.dev64 = tok.lazy64()
+        tok.lazy64 = None
+    return tok.dev64
+
+
 class _WideView:
     """what a mask is lowered against for the float64 kernels: the cube's identity (lazy masks bound to the cube stay
     device terms), ``_wide`` (comparison thresholds keep their float64 value: numpy compares a float64 cube in float64),
@@ -385,7 +394,12 @@ class SpectralCube:
             path = os.fspath(filename)
             if os.path.exists(path) and not overwrite:
                 raise OSError("File %r already exists (use overwrite=True)" % path)
-            data = self._host_data()
+            # the float64 samples explicitly: _host_data() returns the float32-narrowed copy once a float32-only operator has
+            # staged one, and the written precision must not depend on the call history
+            if self._data is not None and getattr(self._data, "dtype", None) == np.float64:
+                data = self._data
+            else:
+                data = self._device_data64().get()
             if filled and self._mask is not None:
                 data = self._mask._filled(data, fill=self._fill_value)
             hdr = {k: v for k, v in self._header.items() if k != "WCSAXES"}
@@ -711,13 +725,15 @@ class SpectralCube:
         (pending until first used; the Dask class keeps the chunk dtype, dask_spectral_cube.py:829).  Its spectral moments,
         reductions, statistics() and further smoothing / interpolation run in float64; an operator without a float64 form
         narrows it with a PrecisionWarning, like a float64 source."""
-        holder = []
-        narrow = _Thunk(lambda: ops.narrow_f64(holder[0]._device_data64()))
+        # the narrowing thunk holds the result's DATA TOKEN, never the cube: out._lazy -> thunk -> out was a reference cycle
+        # that kept a dropped float64 cube (8 B / voxel of HBM) and its parent alive until a generation-2 collection
+        tokens = []
+        narrow = _Thunk(lambda: ops.narrow_f64(_token_dev64(tokens[0])))
         make = (lambda **kw: SpectralCube._new_cube_with(self, **kw)) if plain else self._new_cube_with      # plain: not the subclass's (beams)
         out = make(lazy=narrow, shape=tuple(shape) if shape is not None else self._shape, wcs=wcs, mask=mask)
         out._data_id.lazy64 = fn64
         out._data_id.derived64 = True
-        holder.append(out)
+        tokens.append(out._data_id)
         return out
 
     def _mask_spec(self):

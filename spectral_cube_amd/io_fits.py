@@ -338,10 +338,19 @@ def write_fits(path, data, header=None, bitpix=None, bscale=None, bzero=None, bl
     text = "".join(cards)
     text += " " * ((-len(text)) % BLOCK)
     payload = data.astype(data.dtype.newbyteorder(">")).tobytes()
-    with open(path, "wb") as f:
-        f.write(text.encode("ascii"))
-        f.write(payload)
-        f.write(b"\0" * ((-len(payload)) % BLOCK))
+    part = "%s.part-%d" % (path, os.getpid())              # a failed write never leaves a truncated target (like FitsSink)
+    try:
+        with open(part, "wb") as f:
+            f.write(text.encode("ascii"))
+            f.write(payload)
+            f.write(b"\0" * ((-len(payload)) % BLOCK))
+        os.replace(part, path)
+    except BaseException:
+        try:
+            os.unlink(part)
+        except OSError:
+            pass
+        raise
 
 
 def save_cube(path, dev, header=None, chunk_bytes=128 << 20, nbuffers=4, overwrite=False):

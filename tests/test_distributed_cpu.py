@@ -213,10 +213,79 @@ def test_bench_launches_its_own_ranks():
     import json
     p = _bench(["--gpus", "4", "--steps", "3"], SPC_BENCH_DRYRUN="1")
     assert p.returncode == 0, p.stderr
-    rec = json.loads(p.stdout.strip().splitlines()[-1])
-    assert rec["dryrun"] and rec["n_gpus"] == 4 and rec["steps"] == 3 and rec["bcast"] == "id-from-rank-0"
-    assert [r[:2] for r in rec["ranks"]] == [[i, i] for i in range(4)]
-    assert len({r[2] for r in rec["ranks"]}) == 4, "one process per rank"
+    last = p.stdout.strip().splitlines()[-1]
+    rec = json.loads(last)
+    dr = rec["dryrun"]
+    assert rec["n_gpus"] == 4 and rec["steps"] == 3 and dr["bcast"] == "id-from-rank-0" and dr["gpus_arg"] == 4
+    assert [r[:2] for r in dr["ranks"]] == [[i, i] for i in range(4)]
+    assert len({r[2] for r in dr["ranks"]}) == 4, "one process per rank"
+    _check_line(rec, last)
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes",
+                 "traffic_over_algorithmic", "traffic_source", "arithmetic")
+
+
+def _check_line(rec, text):
+    """round-5 verdict, item 1: the final stdout line stays small enough for the driver to parse (it keeps ~8 KB; the
+    round-5 line was 31.6 KB and BENCH_r05.parsed came out null) and carries the contract's keys at the top level"""
+    assert len(text) < 8000, len(text)
+    for k in CONTRACT_KEYS:
+        assert k in rec, k
+    for k in ROOFLINE_KEYS:
+        assert k in rec["roofline"], k
+    assert "4096x2048x2048" in rec["config"]["workload"], "the same cube at every N"
+    assert rec["scaling"] == "strong" and rec["unit"] == "Mvoxel/s" and rec["roofline"]["bound"] == "hbm"
+    assert abs(rec["roofline"]["frac"] - rec["roofline"]["achieved"] / rec["roofline"]["peak"]) < 1e-3
+
+
+def test_bench_line_is_small_and_round_trips(tmp_path):
+    """the compact line from canned full records (every record key of a real run, names and kernels at their real
+    lengths): < 8000 bytes, json round trip, every record reachable under its short key; the full records land in the
+    records file"""
+    import json
+    sys.path.insert(0, REPO)
+    import bench
+    args = bench.parse([])
+    for world in (1, 2, 8):
+        detail = bench.canned_detail(world, args)
+        rf = tmp_path / ("records_%d.json" % world)
+        line = bench.emit(detail, str(rf))
+        text = json.dumps(line)
+        assert json.loads(text) == line
+        _check_line(line, text)
+        full = json.loads(rf.read_text())
+        assert full["line"] == line and full["headline"]["roofline"]["kernel_ms_stats"]["n"] == 5
+        if world == 1:
+            assert set(line["records"]) == set(bench.CANNED_KEYS)
+            assert all(len(v) == 3 for v in line["records"].values())
+            assert line["cpu_baseline"]["cores"] == 64 and line["roofline"]["configs1"]["frac"] > 0
+            assert set(line["roofline"]["strip_kernel_ms_at_n"]) == {"2", "4", "8"}
+    # a line that would not fit sheds its rows, never its contract keys
+    detail = bench.canned_detail(1, args)
+    detail["wide"] = [dict(detail["wide"][0], key="k%03d_%s" % (i, "x" * 40)) for i in range(200)]
+    line = bench.compact_line(detail)
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT and "dropped" in line["records"] and "roofline" in line
+
+
+def test_bench_eight_rank_dry_run_line():
+    """an 8-rank launch of the spawner (no GPU work): rank 0's last stdout line satisfies the same size bound"""
+    import json
+    p = _bench(["--gpus", "8", "--steps", "2"], SPC_BENCH_DRYRUN="1")
+    assert p.returncode == 0, p.stderr
+    last = p.stdout.strip().splitlines()[-1]
+    rec = json.loads(last)
+    assert rec["n_gpus"] == 8 and len(rec["dryrun"]["ranks"]) == 8 and "per_call" in rec
+    _check_line(rec, last)
+
+
+def test_chunked_moments_picks_blocks_from_the_strip_height():
+    """round-5 verdict, item 5: 64-row blocks cost the headline kernel 19 %, 128-row ones 6 %: blocks of >= 128 rows"""
+    from spectral_cube_amd.distributed import ChunkedMoments
+    assert [ChunkedMoments.pick_chunks(2048 // n) for n in (1, 2, 4, 8, 16)] == [4, 4, 4, 2, 1]
+    assert ChunkedMoments.pick_chunks(384) == 3 and ChunkedMoments.pick_chunks(130) == 1
 
 
 def test_bench_launch_fails_when_a_rank_fails():
@@ -228,7 +297,7 @@ def test_bench_launch_fails_when_a_rank_fails():
 
 
 def test_bench_without_gpu_fails_loudly_not_silently():
-    p = _bench(["--gpus", "1", "--steps", "1", "--no-north-star", "--no-cpu-baseline"])
+    p = _bench(["--gpus", "1", "--steps", "1", "--no-configs1", "--no-cpu-baseline"])
     assert p.returncode != 0 and "no HIP device" in p.stderr and not p.stdout.strip()
 
 
