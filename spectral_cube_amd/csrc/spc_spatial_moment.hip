@@ -815,7 +815,7 @@ static int mfma_entry(int device, void* stream, const spc_cube_f32* cube, const 
         const int ntaps = std::max(nky, nkx) <= 33 ? 33 : 65;
         float ky[kSplitTaps] = {}, kx[kSplitTaps] = {};
         double sumy = 0.0, sumx = 0.0;
-        bool ok = !(ntaps == 65 && nsum == 3);
+        bool ok = true;
         for (int i = 0; i < nky; ++i) { ok = ok && (h_ky[i] >= 0.0); ky[(ntaps - nky) / 2 + i] = (float)h_ky[i]; sumy += h_ky[i]; }
         for (int i = 0; i < nkx; ++i) { ok = ok && (h_kx[i] >= 0.0); kx[(ntaps - nkx) / 2 + i] = (float)h_kx[i]; sumx += h_kx[i]; }
         ok = ok && (ky[ntaps / 2] > 0.f) && (kx[ntaps / 2] > 0.f) && (sumy > 0.0) && (sumx > 0.0) && std::isfinite(sumy) && std::isfinite(sumx);

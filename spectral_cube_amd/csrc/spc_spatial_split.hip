@@ -80,9 +80,10 @@ struct Sm3Args {
     float* out;                               // smoothed cube or nullptr
     int64_t out_row_stride, out_plane_stride;
     float* partial;                           // (nsum, nchunk, ny, nx) float32 sums of a chunk, or nullptr
-    unsigned char* seen;                      // (nchunk, ny, nx) "a channel contributed"
     const double* cen;                        // channel coordinates about the reference (moments 1 / 2): nz doubles, device
+    const float* dlt;                         // (three sums) nchunk * zchunk floats: channel coordinate about the chunk's middle channel, 0 beyond nz
     int nstrips, nbands, zchunk, nchunk;
+    int nrt;                                  // output row tiles per band (the NRT = 0 instantiations: set by the launch; else = NRT)
     float lim;                                // FLT_MAX under isfinite, +inf otherwise (NaN fails |v| <= lim either way)
     float sy, sx;                             // power-of-two scales of the fp16 taps
     int mirror, sync;                         // odd bands march upwards / one rendezvous of the block's waves per channel
@@ -134,13 +135,35 @@ __device__ __forceinline__ u32x4 scale_h8(u32x4 v, _Float16 r) { return __builti
 // NSUM: 0 (no moment), 1 (sum of the smoothed values), 3 (+ sum c v, sum c^2 v)
 // INC: which output voxels the moment sums over - 0: all (no mask), 1: those valid for the convolution (mask byte and / or
 // finite sample: the mask holds isfinite), 2: the mask BYTE alone (a NaN under a true byte is interpolated over and summed)
+// NRT: output row tiles per band; 0 (cube -> cube only: no sums in LDS) = A.nrt, a launch-time count - the wave marches down a
+// band of ANY height, the whole column if the launch says so: the y halo (2 HB of NRT + 2 HB steps) all but disappears
+//
+// NSUM = 1: as round 5 - four waves side by side in x, every wave its own sums of a band of NRT = 4 row tiles (4 x 4 KB).
+// NSUM = 3 (round 6): the block is EIGHT waves on the SAME 16 NRT rows x 16 CT columns of the map, wave w walking the channels
+// z_begin + w, + 8, ... of the chunk, all in the same step at the same time.  A wave leaves the values of a completed row
+// tile (the excluded ones as -0.0) in an exchange buffer in LDS; after one barrier per step two / four of the waves add the
+// eight contributions, in wave order, to the band's ONE set of sums.  One set per block instead of one per wave: bands of
+// 6 row tiles (16 for kernels of 35 - 65 taps) in 152 KB of LDS at one block per CU, where a wave-private set left 1: 8 steps
+// per 6 output row tiles instead of 18.  The order of the additions is fixed: the sums are reproducible bit for bit.
+// (The same form for ONE sum - bands of 16 row tiles, 18 steps instead of 24 - was built and measured: 40.5 ms at C4 against
+//  39.6 ms of the wave-private form.  Without its barrier 36.6 ms: eight waves in the same step at the same time cost what the
+//  shorter march wins - profiles/r06_split_shared_sums.txt.)
+// Three sums: S0 = sum v, S1' = sum v d, S2' = sum v d^2 with d = the channel coordinate about the CHUNK's middle channel
+// (float32: |d| is at most 32 channel widths); the finish kernel shifts the chunks' sums to the map's mean in float64
+// (round-5 advisor: sums about the reference channel in float32 lost moment 2 of a narrow line far from it to cancellation).
 template <int NB, int NRT, bool ARR, int INC, bool STORE, int NSUM>
-__global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Args A) {
+__global__ __launch_bounds__(NSUM == 3 ? 512 : kThreads, NSUM == 3 ? 1 : 2) void spatial_split_kernel(const Sm3Args A) {
     using G = Geo<NB>;
     constexpr int kCT = G::CT, kOC = G::OC, HB = G::HB, H = G::H, R = G::R, NQ = G::NQ, NP = G::NP, kSets = G::SETS;
+    static_assert(NRT > 0 || NSUM == 0, "the moment sums of a band live in LDS: their row tile count is static");
+    constexpr bool SH = NSUM == 3;            // channel-parallel waves, shared sums
+    constexpr int kW = SH ? 8 : kWaves;       // waves per block
+    constexpr int ZSTEP = SH ? kW : 1;        // channels between two channels of one wave
     __shared__ half8 cB[kSets * 2 * 64];                                              // 16 / 24 KB
-    __shared__ f32x4 msum[NSUM ? kWaves * NSUM * NRT * kCT * 64 : 1];                 // NSUM x NRT x CT KB per wave
-    constexpr int NST = NRT + 2 * HB;         // input row tiles (steps) per channel
+    __shared__ f32x4 msum[NSUM ? (SH ? 1 : kWaves) * NSUM * NRT * kCT * 64 : 1];      // NSUM x NRT x CT KB per BLOCK (three sums) / per wave
+    __shared__ f32x4 xch[SH ? 2 * kW * kCT * 64 : 1];                                 // exchange: 2 buffers x 8 waves x CT KB
+    const int nrt = NRT > 0 ? NRT : A.nrt;    // output row tiles of this band
+    const int NST = nrt + 2 * HB;             // input row tiles (steps) per channel
 
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);      // (provably uniform: scalar branches, scalar addresses)
     const int lm = lane & 15, lg = lane >> 4;
@@ -156,18 +179,19 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         chunk = (int)(w / ((int64_t)A.nbands * A.nstrips));
     }
     const int ny = (int)A.ny, nx = (int)A.nx;
-    const int y0 = band * (16 * NRT);
+    const int y0 = band * (16 * nrt);
     // Odd bands march UPWARDS (their rows are taken in mirrored order, the y taps reversed): a band's last two input row
     // tiles are the first two of the band below it, and with both marching down the two reads of those 32 rows lie four
     // steps apart - longer than the L2 keeps them (fetch x2.1 of the cube measured).  Mirrored, neighbouring bands - which
     // run at the same time on one XCD - touch their shared rows in the same step.
-    const bool mir = A.mirror && (band & 1);
-    const int ymir = y0 + 16 * NRT - 1;        // local row q of a mirrored band is the plane's row ymir - q
+    const bool mir = !SH && A.mirror && (band & 1);       // (not with sums: bands of 16 / 6 row tiles share 2 of 18 / 8 steps' rows, and the code path costs registers)
+    const int ymir = y0 + 16 * nrt - 1;        // local row q of a mirrored band is the plane's row ymir - q
     auto plane_row = [&](int q) { return mir ? ymir - q : y0 + q; };
-    const int xw = strip * (kWaves * kOC) + wave * kOC;       // first output column of this wave
+    const int xw = SH ? strip * kOC : strip * (kWaves * kOC) + wave * kOC;       // first output column of this wave
 
     // ---- constant operands: the waves share the (set, hi / lo) pairs, every thread builds them for its lane
-    for (int q = wave * (2 * kSets / kWaves); q < (wave + 1) * (2 * kSets / kWaves); ++q) {
+    static_assert((2 * kSets) % kW == 0, "the waves share the constant operands evenly");
+    for (int q = wave * (2 * kSets / kW); q < (wave + 1) * (2 * kSets / kW); ++q) {
         const int set = q >> 1, lo = q & 1;
         const bool isx = set < 2 * NQ;
         half8 op;
@@ -183,12 +207,10 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         cB[q * 64 + lane] = op;
     }
     if (NSUM) {
-        f32x4* mz = msum + (size_t)wave * NSUM * NRT * kCT * 64 + lane;
-#pragma unroll
-        for (int i = 0; i < NSUM * NRT * kCT; ++i) mz[i * 64] = f32x4{-0.f, -0.f, -0.f, -0.f};       // -0.0: "nothing added yet" (see the epilogue)
+        for (int i = t; i < (SH ? 1 : kWaves) * NSUM * NRT * kCT * 64; i += 64 * kW) msum[i] = f32x4{-0.f, -0.f, -0.f, -0.f};       // -0.0: "nothing added yet" (see the epilogue)
     }
     __syncthreads();
-    if (xw >= nx) return;                                      // (no barrier below: a whole wave may leave)
+    if (xw >= nx) return;                                      // (NSUM = 0: no barrier below, a whole wave may leave; NSUM > 0: the block leaves)
     const int z_begin = chunk * A.zchunk, z_end = (int)min((int64_t)z_begin + A.zchunk, A.nz);
     if (z_begin >= z_end) return;
 
@@ -229,11 +251,55 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
 #pragma unroll
         for (int q = 0; q < NP; ++q) { Pn[q][n] = Pd[q][n] = f32x4{0.f, 0.f, 0.f, 0.f}; incsave[q][n] = 0u; }
     }
-    f32x4* macc = msum + (size_t)wave * NSUM * NRT * kCT * 64 + lane;
+    f32x4* const macc = msum + (SH ? (size_t)0 : (size_t)wave * NSUM * NRT * kCT * 64) + lane;     // (one sum) this wave's sums
     const bool tile_cols_inside = cols_inside;
     int E = -128;                              // 2^E bounds every sample of the channel seen so far (the pending numerators carry 2^-E)
-    float cz = 0.f, cz2 = 0.f;
-    int zcur = z_begin;
+    int zcur = z_begin, zround_next = z_begin;
+    bool alive = true;                         // (NSUM > 0) this wave has a channel in the current round of eight
+    int zround = z_begin;                      // first channel of the current round of eight
+
+    // the block's sums: after ONE barrier the contributions of the eight waves to the row tile completed in step jp are added, in
+    // wave order, by the waves of one group (CT waves, a different group every step).  Writes and additions alternate in every
+    // wave; the buffer is the parity of the row tile - of the step, a compile-time constant of every copy of the step's code
+    // (NRT is even: the parity starts over with every channel): a buffer is written again two writes later, behind the barrier
+    // of the write in between - which every wave reaches after ITS reads of this one
+    static_assert(!SH || (NRT % 2 == 0 && (NB - 1) % 2 == 0 && NP % 2 == 0), "the exchange buffer of a row tile is the parity of its step");
+    auto reduce_tile = [&](auto buf, const int jp) {
+        constexpr int bw = decltype(buf)::value;
+        // (three sums) the eight channel coordinates of the round: scalar loads, in flight across the barrier
+        float dls[kW];
+#pragma unroll
+        for (int w = 0; w < kW; ++w) dls[w] = NSUM == 3 ? A.dlt[zround + w] : 0.f;
+        // (LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier; __syncthreads() would also drain vmcnt - the loads of the next
+        //  step or channel that are in flight, and the stores of the smoothed cube)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int i = jp - (NB - 1);
+        constexpr int kGroups = kW / kCT;
+        if ((wave / kCT) == (i % kGroups)) {        // uniform
+            const int n = wave % kCT;
+            f32x4* const sums = msum + (size_t)((i * kCT + n) * NSUM) * 64 + lane;
+            const f32x4* const src = xch + (size_t)(bw * kW * kCT + n) * 64 + lane;
+            f32x4 s0 = sums[0], s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (NSUM == 3) { s1 = sums[64]; s2 = sums[128]; }
+#pragma unroll
+            for (int w = 0; w < kW; w += 2) {            // (two contributions in flight: all eight at once spill)
+                const f32x4 a = src[(size_t)w * kCT * 64], b = src[(size_t)(w + 1) * kCT * 64];
+                s0 = s0 + a;
+                s0 = s0 + b;
+                if (NSUM == 3) {
+                    const float da = dls[w], db = dls[w + 1];
+                    const f32x4 ad = a * da, bd = b * db;
+                    s1 = s1 + ad; s2 = s2 + ad * da;
+                    s1 = s1 + bd; s2 = s2 + bd * db;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sums[0] = s0;
+            if (NSUM == 3) { sums[64] = s1; sums[128] = s2; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // one step = one input row tile (16 rows x 96 columns) of the channel; PAR = parity of the step (static: it names the
     // operand slot the new Z tile goes to and the slots of the pending row tiles)
@@ -340,7 +406,6 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         }
         const float s = exp2i(15 - e);                                                 // samples -> below 2^15
         const float fz = exp2i(e - E - 15);                                            // x-pass numerators -> below 2^15, common scale 2^-E
-        const float escale = exp2i(E);
         // ================= fp16 operands of the x pass: three unit pairs, hi / lo / validity
         u32x4 hiP[3], loP[3], vhP[3];
 #pragma unroll
@@ -392,10 +457,14 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
             else          { za[n][0].z = nh0; za[n][0].w = nh1; za[n][1].z = nl0; za[n][1].w = nl1; za[n][2].z = dh0; za[n][2].w = dh1; za[n][3].z = dl0; za[n][3].w = dl1; }
             __builtin_amdgcn_sched_barrier(0);        // (one column tile at a time: interleaved, the tiles' accumulators and constants do not fit 256 registers)
         }
+        // ================= the block's sums (NSUM > 0): the row tile completed in the PREVIOUS step.  Here - the x-pass operands
+        // are dead, the next loads not yet issued - the additions have the registers they need
+        if (SH && j >= NB) reduce_tile(std::integral_constant<int, PAR ^ 1>{}, j - 1);
+        const float escale = exp2i(E);
         // ================= the next step's loads fly during the y pass and the epilogues (the x-pass operands are dead by now:
         // issued before the x pass, the 30 registers of the loads in flight pushed the kernel over 256 and into scratch)
         if (j + 1 < NST) issue_loads(z, j + 1);
-        else if (z + 1 < z_end) issue_loads(z + 1, 0);
+        else if (zround_next < z_end) issue_loads(SH ? min(zround_next + wave, z_end - 1) : zround_next, 0);
         // ================= y pass (scatter) and the epilogue of the completed row tile, per column tile
         // operand order: (slot 0, slot 1) = (previous, new) on odd steps, (new, previous) on even ones; the constant operands of
         // the y pass are the same for every column tile: read once per step.  Product m adds blocks (2 m, 2 m + 1) to the row tile
@@ -407,7 +476,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         for (int m = 0; m < NQ; ++m) {
             bh[m] = half8{}; bl[m] = half8{};
             const int i = j - TB(m);
-            if (i >= 0 && i < NRT) { bh[m] = cB[((2 * NQ + order * NQ + m) * 2 + 0) * 64 + lane]; bl[m] = cB[((2 * NQ + order * NQ + m) * 2 + 1) * 64 + lane]; }
+            if (i >= 0 && i < nrt) { bh[m] = cB[((2 * NQ + order * NQ + m) * 2 + 0) * 64 + lane]; bl[m] = cB[((2 * NQ + order * NQ + m) * 2 + 1) * 64 + lane]; }
         }
 #pragma unroll
         for (int n = 0; n < kCT; ++n) {
@@ -417,7 +486,7 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                 for (int m = 0; m < NQ - 1; ++m) {          // all but the completing product
                     const int i = j - TB(m);
                     constexpr int dummy = 0; (void)dummy;
-                    if (i >= 0 && i < NRT) {
+                    if (i >= 0 && i < nrt) {
                         const int slot = ((PARN - TB(m)) % NP + NP) % NP;                 // row tile i mod NP (static)
                         f32x4 pn = m == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : Pn[slot][n], pd = m == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : Pd[slot][n];
                         pd = MFMA(adh, bh[m], pd);
@@ -461,14 +530,14 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                         unsigned w = INC ? incsave[((PARN - HB) % NP + NP) % NP][n] : 0xffffffffu;   // saved by step j - HB (the centre row tile of i)
                         if (INC) asm volatile("" : "+v"(w));           // (tested HERE: hoisted to the top of the step, the 16 lane masks of the four tiles spill)
                         bool i0 = (w & 0xffu) != 0, i1 = (w & 0xff00u) != 0, i2 = (w & 0xff0000u) != 0, i3 = (w & 0xff000000u) != 0;
-                        i0 = i0 & inside; i1 = i1 & inside; i2 = i2 & inside; i3 = i3 & inside;
+                        const bool live = inside & (!SH || alive);     // (a wave without a channel of its own in the chunk's last round repeats the last channel and adds nothing)
+                        i0 = i0 & live; i1 = i1 & live; i2 = i2 & live; i3 = i3 & live;
                         if (INC != 1) {             // nansum: a NaN value is skipped (INC 1: an included voxel is a valid centre sample, its window is not empty)
                             i0 = i0 & (val.x == val.x); i1 = i1 & (val.y == val.y); i2 = i2 & (val.z == val.z); i3 = i3 & (val.w == val.w);
                         }
                         const f32x4 add = {i0 ? val.x : -0.f, i1 ? val.y : -0.f, i2 ? val.z : -0.f, i3 ? val.w : -0.f};
-                        f32x4* slot = macc + (size_t)((i * kCT + n) * NSUM) * 64;
-                        slot[0] = slot[0] + add;
-                        if (NSUM == 3) { slot[64] = slot[64] + add * cz; slot[128] = slot[128] + add * cz2; }
+                        if (SH) xch[(size_t)((PAR * kW + wave) * kCT + n) * 64 + lane] = add;      // this wave's slot of the step's exchange buffer
+                        else { f32x4* const slot = macc + (size_t)(i * kCT + n) * 64; *slot = *slot + add; }
                     }
                 }
             }
@@ -476,13 +545,18 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
         }
     };
 
-    issue_loads(z_begin, 0);
-    for (zcur = z_begin; zcur < z_end; ++zcur) {
-        // (one rendezvous per channel keeps the block's four waves - neighbours in x, 32 shared columns each - in the same
-        //  channel; waves that left above do not count)
-        if (A.sync) __builtin_amdgcn_s_barrier();
+    issue_loads(SH ? min(z_begin + wave, z_end - 1) : z_begin, 0);
+    for (int zr = z_begin; zr < z_end; zr += ZSTEP) {
+        // (NSUM > 0) a wave whose channel of this round lies beyond the chunk repeats the chunk's last channel - the same steps, the
+        // same barriers - and adds nothing
+        alive = !SH || zr + wave < z_end;
+        zcur = SH ? min(zr + wave, z_end - 1) : zr;
+        zround_next = zr + ZSTEP;
+        // (NSUM = 0: one rendezvous per channel keeps the block's four waves - neighbours in x, 32 shared columns each - in the
+        //  same channel; waves that left above do not count)
+        if (!SH && A.sync) __builtin_amdgcn_s_barrier();
         E = -128;
-        if (NSUM == 3) { cz = (float)A.cen[zcur]; cz2 = cz * cz; }
+        zround = zr;
 #pragma unroll 1
         for (int jj = 0; jj < NST; jj += NP) {
             step(std::integral_constant<int, 0>{}, jj);
@@ -492,44 +566,56 @@ __global__ __launch_bounds__(kThreads, 2) void spatial_split_kernel(const Sm3Arg
                 if (jj + 3 < NST) step(std::integral_constant<int, 3 % NP>{}, jj + 3);
             }
         }
+        if (SH) reduce_tile(std::integral_constant<int, 1>{}, NST - 1);      // the round's last row tile (NRT - 1: odd)
     }
 
-    if (NSUM) {
+    if (NSUM == 1) {
         const int64_t plane = (int64_t)A.ny * A.nx;
 #pragma unroll
-        for (int i = 0; i < NRT; ++i) {
-            const int yo = plane_row(16 * i + lm);
+        for (int tt = 0; tt < NRT * kCT; ++tt) {
+            const int i = tt / kCT, n = tt % kCT;
+            const int yo = plane_row(16 * i + lm), xo = xw + 16 * n + 4 * lg;
+            if (yo < ny && xo < nx)
+                *reinterpret_cast<f32x4*>(A.partial + (int64_t)chunk * plane + (int64_t)yo * A.nx + xo) = macc[(size_t)(i * kCT + n) * 64];
+        }
+    }
+    if (SH) {
+        __syncthreads();                                   // the last step's additions
+        const int64_t plane = (int64_t)A.ny * A.nx;
+        for (int tt = wave; tt < NRT * kCT; tt += kW) {    // the band's tiles, dealt to the waves
+            const int i = tt / kCT, n = tt % kCT;
+            const int yo = plane_row(16 * i + lm), xo = xw + 16 * n + 4 * lg;
+            if (yo < ny && xo < nx) {
+                const int64_t at = (int64_t)chunk * plane + (int64_t)yo * A.nx + xo;
 #pragma unroll
-            for (int n = 0; n < kCT; ++n) {
-                const int xo = xw + 16 * n + 4 * lg;
-                if (yo < ny && xo < nx) {
-                    const int64_t at = (int64_t)chunk * plane + (int64_t)yo * A.nx + xo;
-#pragma unroll
-                    for (int q = 0; q < NSUM; ++q)
-                        *reinterpret_cast<f32x4*>(A.partial + (int64_t)q * A.nchunk * plane + at) = macc[(size_t)((i * kCT + n) * NSUM + q) * 64];
-                }
+                for (int q = 0; q < NSUM; ++q)
+                    *reinterpret_cast<f32x4*>(A.partial + (int64_t)q * A.nchunk * plane + at) = msum[(size_t)((i * kCT + n) * NSUM + q) * 64 + lane];
             }
         }
     }
 }
 
 // moments of the smoothed cube from the chunk sums (float64 across chunks): m0 = dv S0 (NaN where no channel contributed:
-// nansum_allbadtonan, dask_spectral_cube.py:54-59), m1 = S1 / S0 + m1_add, m2 = S2 / S0 - (S1 / S0)^2   (:1083-1104)
-__global__ __launch_bounds__(256) void split_finish_kernel(const float* partial, const unsigned char* seen, int nsum, int nchunk,
+// nansum_allbadtonan, dask_spectral_cube.py:54-59), m1 = S1 / S0 + m1_add, m2 = sum v (c - m1)^2 / S0   (:1083-1104).
+// A chunk's sums S1', S2' are about ITS middle channel c_k (float32: |c - c_k| is at most 32 channel widths); here, in float64,
+//   S1 = sum_k S1'_k + c_k S0_k,      m2 S0 = sum_k S2'_k + 2 (c_k - mu) S1'_k + (c_k - mu)^2 S0_k
+// - the second moment about the mean, chunk by chunk: what float32 rounding of a chunk's sums costs is bounded by the chunk's
+// width, not by the distance of the line from the reference channel.
+__global__ __launch_bounds__(256) void split_finish_kernel(const float* partial, const double* cen, int nsum, int nchunk, int zchunk, int64_t nz,
                                                             int64_t ny, int64_t nx, double dv, double m1_add,
                                                             double* m0, double* m1, double* m2, int64_t map_row_stride) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t plane = ny * nx;
     if (i >= plane) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    double s0 = 0.0, s1 = 0.0;
     unsigned any = 0;
     for (int c = 0; c < nchunk; ++c) {
         const float p0 = partial[(int64_t)c * plane + i];
         any |= (__float_as_uint(p0) != 0x80000000u) ? 1u : 0u;      // still -0.0: nothing was added in this chunk
         s0 += (double)p0;
         if (nsum == 3) {
-            s1 += (double)partial[((int64_t)nchunk + c) * plane + i];
-            s2 += (double)partial[((int64_t)2 * nchunk + c) * plane + i];
+            const double ck = cen[min((int64_t)c * zchunk + zchunk / 2, nz - 1)];
+            s1 += (double)partial[((int64_t)nchunk + c) * plane + i] + ck * (double)p0;
         }
     }
     const int64_t y = i / nx, x = i - y * nx;
@@ -539,24 +625,48 @@ __global__ __launch_bounds__(256) void split_finish_kernel(const float* partial,
     if (m1 || m2) {
         const double mu = s1 / s0;                             // 0 / 0 = NaN for rays without a contribution, like the reference
         if (m1) m1[o] = mu + m1_add;
-        if (m2) m2[o] = s2 / s0 - mu * mu;
+        if (m2) {
+            double s2 = 0.0;
+            for (int c = 0; c < nchunk; ++c) {
+                const double d = cen[min((int64_t)c * zchunk + zchunk / 2, nz - 1)] - mu;
+                s2 += (double)partial[((int64_t)2 * nchunk + c) * plane + i] + d * (2.0 * (double)partial[((int64_t)nchunk + c) * plane + i]
+                                                                                   + d * (double)partial[(int64_t)c * plane + i]);
+            }
+            m2[o] = s2 / s0;
+        }
     }
 }
 
-inline int split_chunk_planes(int64_t nz, int64_t tiles) {
-    // enough blocks to fill the chip several times over, chunks of at most 64 channels (float32 sums inside a chunk)
-    int64_t want_chunks = std::max<int64_t>(1, (2048 + tiles - 1) / tiles);
+// (three sums) channel coordinate about the middle channel of the channel's chunk, as float32; zeros beyond nz
+__global__ __launch_bounds__(256) void split_delta_kernel(const double* cen, float* dlt, int64_t nz, int zchunk, int64_t n) {
+    const int64_t z = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (z >= n) return;
+    const int64_t zm = min((z / zchunk) * zchunk + zchunk / 2, nz - 1);
+    dlt[z] = z < nz ? (float)(cen[z] - cen[zm]) : 0.f;
+}
+
+inline int split_chunk_planes(int64_t nz, int64_t tiles, int nsum) {
+    // enough blocks to fill the chip several times over, chunks of at most 64 channels (float32 sums inside a chunk); with sums a
+    // block walks eight channels at a time: whole rounds of eight
+    int64_t want_chunks = std::max<int64_t>(1, ((nsum == 3 ? 1024 : 2048) + tiles - 1) / tiles);
     int64_t zc = std::max<int64_t>(1, (nz + want_chunks - 1) / want_chunks);
+    if (nsum == 3) zc = (zc + 7) / 8 * 8;
     return (int)std::min<int64_t>(zc, 64);
 }
 
-// output row tiles per wave: what the LDS holds next to the constant operands at two blocks per CU (80 KB each)
-//   NB = 3 (16 KB of constants):  one sum 4 x 4 KB per wave (64 rows), three sums 1 x 12 KB (16 rows)
-//   NB = 5 (24 KB of constants):  one sum 7 x 2 KB per wave (112 rows); three sums: not built
-constexpr int kNRT1 = 4, kNRT3 = 1, kNRT1w = 7;
+// output row tiles per band of the forms with sums
+//   one sum: what the LDS holds next to the constant operands at two blocks per CU (80 KB each), every wave its own sums
+//     NB = 3 (16 KB of constants): 4 x 4 KB per wave (64 rows)        NB = 5 (24 KB): 7 x 2 KB per wave (112 rows)
+//   three sums: what the LDS of a CU (160 KB, one block of eight waves) holds next to the constant operands and the two
+//   exchange buffers (2 x 8 waves x CT KB), one set of sums per block
+//     NB = 3 (16 KB + 64 KB): 6 x 12 KB (96 rows: 152 KB)             NB = 5 (24 KB + 32 KB): 16 x 6 KB (256 rows: 152 KB)
+constexpr int kNRT1 = 4, kNRT3 = 6, kNRT1w = 7, kNRT3w = 16;
 
-struct SplitGeo { int nrt, oc; };
-inline SplitGeo split_geo(int nb, int nsum) { return nb == 3 ? SplitGeo{nsum == 3 ? kNRT3 : kNRT1, Geo<3>::OC} : SplitGeo{kNRT1w, Geo<5>::OC}; }
+struct SplitGeo { int nrt, oc, waves_x; };     // waves_x: waves of a block side by side in x (4; the three-sum form: 1)
+inline SplitGeo split_geo(int nb, int nsum) {
+    const int wx = nsum == 3 ? 1 : kWaves;
+    return nb == 3 ? SplitGeo{nsum == 3 ? kNRT3 : kNRT1, Geo<3>::OC, wx} : SplitGeo{nsum == 3 ? kNRT3w : kNRT1w, Geo<5>::OC, wx};
+}
 
 }  // namespace
 
@@ -570,11 +680,10 @@ bool spc_spatial_split_takes(const spc_cube_f32* cube, const MaskDev& md) {
 size_t spc_ws_spatial_split(int64_t nz, int64_t ny, int64_t nx, int nsum) {
     size_t need = 0;
     for (int nb : {3, 5}) {
-        if (nb == 5 && nsum == 3) continue;
         const SplitGeo g = split_geo(nb, nsum);
-        const int64_t tiles = ((ny + 16 * g.nrt - 1) / (16 * g.nrt)) * ((nx + kWaves * g.oc - 1) / (kWaves * g.oc));
-        const int64_t zc = split_chunk_planes(nz, tiles), nchunk = (nz + zc - 1) / zc;
-        need = std::max(need, spc_ws_round((size_t)nsum * nchunk * ny * nx * sizeof(float)) + spc_ws_round((size_t)nchunk * ny * nx) + 512);
+        const int64_t tiles = ((ny + 16 * g.nrt - 1) / (16 * g.nrt)) * ((nx + g.waves_x * g.oc - 1) / (g.waves_x * g.oc));
+        const int64_t zc = split_chunk_planes(nz, tiles, nsum), nchunk = (nz + zc - 1) / zc;
+        need = std::max(need, spc_ws_round((size_t)nsum * nchunk * ny * nx * sizeof(float)) + spc_ws_round((size_t)nchunk * zc * sizeof(float)) + 512);
     }
     return need;
 }
@@ -597,43 +706,56 @@ int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const Mas
     // measured at 256 x 2048^2 + uint8 mask (profiles/r05_split_fetch_ab.txt): fetch / algorithmic x1.97 as built first, x1.52 with
     // mirrored odd bands, x1.43 with the rendezvous per channel as well; the time does not move (the kernel is bound by issue).
     // The three-sum form (16-row regions, three times the steps per channel) loses 8 % to the rendezvous: not there.
-    { const char* e = getenv("SPC_SPLIT_MIRROR"); A.mirror = e ? atoi(e) : 1; e = getenv("SPC_SPLIT_SYNC"); A.sync = e ? atoi(e) : (nsum != 3); }
+    { const char* e = getenv("SPC_SPLIT_MIRROR"); A.mirror = e ? atoi(e) : 1; e = getenv("SPC_SPLIT_SYNC"); A.sync = e ? atoi(e) : 1; }
     SPC_REQUIRE(ntaps == Geo<3>::R || ntaps == Geo<5>::R, "internal: the split form takes taps padded to 33 or 65 entries");
     const int nb = ntaps == Geo<3>::R ? 3 : 5;
-    if (nb == 5 && nsum == 3) { spc_set_error("spatial_conv_sep_mfma: moments 1 / 2 of kernels with more than 33 taps are not fused"); return SPC_ERR_UNSUPPORTED; }
     for (int i = 0; i < kMaxTaps + 3; ++i) { A.ky[i] = i < ntaps ? ky[i] : 0.f; A.kx[i] = i < ntaps ? kx[i] : 0.f; }
     const SplitGeo geo = split_geo(nb, nsum);
-    const int nrt = geo.nrt;
-    A.nstrips = (int)((cube->nx + kWaves * geo.oc - 1) / (kWaves * geo.oc));
+    int nrt = geo.nrt;
+    if (nsum == 0) {
+        // cube -> cube: nothing of a band lives in LDS, so a wave marches down the WHOLE column (round 6): NRT + 2 HB steps for NRT
+        // output row tiles - 130 for 128 at 2048 rows, where the 64-row bands took 192 (SPC_SPLIT_BAND_TILES: row tiles per band)
+        static const int env_tiles = [] { const char* e = getenv("SPC_SPLIT_BAND_TILES"); return e ? atoi(e) : 0; }();
+        const int64_t all = (cube->ny + 15) / 16;
+        nrt = (int)(env_tiles > 0 ? std::min<int64_t>(env_tiles, all) : all);
+    }
+    A.nrt = nrt;
+    A.nstrips = (int)((cube->nx + geo.waves_x * geo.oc - 1) / (geo.waves_x * geo.oc));
     A.nbands = (int)((cube->ny + 16 * nrt - 1) / (16 * nrt));
-    A.zchunk = split_chunk_planes(cube->nz, (int64_t)A.nstrips * A.nbands);
+    A.zchunk = split_chunk_planes(cube->nz, (int64_t)A.nstrips * A.nbands, nsum);
     A.nchunk = (int)((cube->nz + A.zchunk - 1) / A.zchunk);
     const int64_t nblocks = (int64_t)A.nstrips * A.nbands * A.nchunk;
     SPC_REQUIRE(nblocks < (1ll << 31), "too many blocks");
     if (nsum) {
         SpcWorkspace ws(d_workspace, workspace_bytes);
         SPC_WS_TAKE(d_partial, ws, float, (size_t)nsum * A.nchunk * cube->ny * cube->nx);
-        SPC_WS_TAKE(d_seen, ws, unsigned char, (size_t)A.nchunk * cube->ny * cube->nx);
-        A.partial = d_partial; A.seen = d_seen;
+        SPC_WS_TAKE(d_dlt, ws, float, (size_t)A.nchunk * A.zchunk);
+        A.partial = d_partial; A.dlt = d_dlt;
+        if (nsum == 3) {
+            const int64_t n = (int64_t)A.nchunk * A.zchunk;
+            hipLaunchKernelGGL(split_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_cen, d_dlt, cube->nz, A.zchunk, n);
+            SPC_LAUNCH_CHECK();
+        }
     }
     const bool arr = A.marr != nullptr, fin = (md.flags & SPC_MASK_FINITE) != 0, store = d_out != nullptr;
-    dim3 grid((unsigned)nblocks), block(kThreads);
+    dim3 grid((unsigned)nblocks), block(nsum == 3 ? 512 : kThreads);
 #define SPC_S3(NB_, NRT_, ARR_, INC_, STORE_, NSUM_) hipLaunchKernelGGL((spatial_split_kernel<NB_, NRT_, ARR_, INC_, STORE_, NSUM_>), grid, block, 0, st, A)
 #define SPC_S3_MASK(NB_, NRT_, STORE_, NSUM_) do { if (arr && fin) SPC_S3(NB_, NRT_, true, 1, STORE_, NSUM_); else if (arr) SPC_S3(NB_, NRT_, true, 2, STORE_, NSUM_); \
                                                    else if (fin) SPC_S3(NB_, NRT_, false, 1, STORE_, NSUM_); else SPC_S3(NB_, NRT_, false, 0, STORE_, NSUM_); } while (0)
     if (nb == 3) {
         if (nsum == 3) { if (store) SPC_S3_MASK(3, kNRT3, true, 3); else SPC_S3_MASK(3, kNRT3, false, 3); }
         else if (nsum == 1) { if (store) SPC_S3_MASK(3, kNRT1, true, 1); else SPC_S3_MASK(3, kNRT1, false, 1); }
-        else SPC_S3_MASK(3, kNRT1, true, 0);
+        else SPC_S3_MASK(3, 0, true, 0);
     } else {
-        if (nsum == 1) { if (store) SPC_S3_MASK(5, kNRT1w, true, 1); else SPC_S3_MASK(5, kNRT1w, false, 1); }
-        else SPC_S3_MASK(5, kNRT1w, true, 0);
+        if (nsum == 3) { if (store) SPC_S3_MASK(5, kNRT3w, true, 3); else SPC_S3_MASK(5, kNRT3w, false, 3); }
+        else if (nsum == 1) { if (store) SPC_S3_MASK(5, kNRT1w, true, 1); else SPC_S3_MASK(5, kNRT1w, false, 1); }
+        else SPC_S3_MASK(5, 0, true, 0);
     }
     SPC_LAUNCH_CHECK();
     if (nsum) {
         const int64_t n = cube->ny * cube->nx;
-        hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A.partial, A.seen, nsum, A.nchunk,
-                           cube->ny, cube->nx, dv, m1_add, d_m0, d_m1, d_m2, map_row_stride ? map_row_stride : cube->nx);
+        hipLaunchKernelGGL(split_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A.partial, A.cen, nsum, A.nchunk, A.zchunk,
+                           cube->nz, cube->ny, cube->nx, dv, m1_add, d_m0, d_m1, d_m2, map_row_stride ? map_row_stride : cube->nx);
         SPC_LAUNCH_CHECK();
     }
     return SPC_OK;

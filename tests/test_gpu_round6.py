@@ -1,0 +1,142 @@
+"""GPU, round 6: the masked spatial stencil's cube -> cube form marching whole columns (bands of any height), the three-sum
+form with eight channel-parallel waves and one set of sums per block (chunk-centred float32 sums, shifted in float64), its
+65-tap instantiation, reproducibility of the exchange through LDS; bench.py's float64 records.
+Oracle: oracle_np (astropy semantics, float64)."""
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import assert_close
+from spectral_cube_amd import Gaussian2DKernel, _lib, ops
+from spectral_cube_amd.device import DeviceArray
+
+pytestmark = pytest.mark.gpu
+K8 = Gaussian2DKernel(8 / 2.3548200450309493).array
+
+
+def _case(shape, seed, valid=0.8, nan_frac=0.0):
+    rng = np.random.default_rng(seed)
+    d = (rng.standard_normal(shape) + 2.0).astype(np.float32)
+    m = rng.random(shape) < valid
+    if nan_frac:
+        d[rng.random(shape) < nan_frac] = np.nan
+    return d, m
+
+
+def _dev(d, m):
+    return DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+
+
+def _moments_oracle(d, m, inc, k2, cen, dv, m1_add):
+    sm = O.spatial_smooth(d, m, k2)
+    filled = np.where(inc, sm, np.nan)
+    e0 = dv * np.nansum(filled, axis=0)
+    e0[np.all(np.isnan(filled), axis=0)] = np.nan
+    f0 = np.nan_to_num(filled, nan=0.0)
+    c = cen[:, None, None]
+    with np.errstate(all="ignore"):
+        s0 = f0.sum(0)
+        mu = (f0 * c).sum(0) / s0
+        e2 = (f0 * (c - mu) ** 2).sum(0) / s0             # about the mean: the reference's own form (_moments.py:185-193)
+    return e0, mu + m1_add, e2
+
+
+@pytest.mark.parametrize("shape", [(3, 300, 130), (5, 33, 64), (2, 1000, 72), (4, 17, 260)])
+def test_cube_to_cube_form_marches_whole_columns(gpu, shape):
+    """round 6: the cube -> cube split form takes a band of ANY height - by default the whole column (nrt = ceil(ny / 16) row
+    tiles, the last one partial): tall planes, planes shorter than the halo, heights that are no multiple of 16"""
+    d, m = _case(shape, 61, valid=0.6, nan_frac=0.01)
+    cube, mk = _dev(d, m)
+    out, _ = ops.spatial_conv_mfma(cube, K8, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk), want_cube=True, want_m0=False)
+    exp = O.spatial_smooth(d, m, K8)
+    assert_close(out.get(), exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="whole-column march %r" % (shape,))
+
+
+@pytest.mark.parametrize("flags", [_lib.MASK_ARRAY, _lib.MASK_ARRAY | _lib.MASK_FINITE])
+@pytest.mark.parametrize("shape", [(90, 45, 200), (8, 200, 64), (13, 97, 68), (70, 100, 132)])
+def test_three_sum_form_shared_sums_against_the_oracle(gpu, shape, flags):
+    """eight waves per block walk eight channels at a time and add into one set of sums: chunks that end inside a round of
+    eight (90 = 11 x 8 + 2, 13, 70), several bands of 96 rows and a partial one, partial column strips, NaN samples, fully
+    masked spaxels.  Moment 2 is compared with the second moment ABOUT THE MEAN, per pixel."""
+    d, m = _case(shape, 9, valid=0.7, nan_frac=0.01)
+    m[:, 3:6, 10:14] = False
+    cube, mk = _dev(d, m)
+    inc = m & np.isfinite(d) if flags & _lib.MASK_FINITE else m
+    cen = (np.arange(shape[0]) - shape[0] // 2) * 500.0
+    _, maps = ops.spatial_conv_mfma_moments(cube, K8, DeviceArray.from_numpy(cen), dv=500.0, m1_add=77.0, mask=ops.MaskSpec(flags, array=mk))
+    e0, e1, e2 = _moments_oracle(d, m, inc, K8, cen, 500.0, 77.0)
+    assert np.isnan(e0).sum() >= 12
+    assert_close(maps["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="m0")
+    assert_close(maps["m1"].get(), e1, atol=1e-5 * 500.0 * shape[0], what="m1")
+    assert_close(maps["m2"].get(), e2, atol=1e-5 * np.nanmax(np.abs(e2)), what="m2")
+
+
+@pytest.mark.parametrize("stddev, taps", [(5.0, 41), (8.0, 65)])
+def test_three_sum_form_takes_up_to_65_taps(gpu, stddev, taps):
+    """round 6: moments 1 / 2 of kernels of 35 - 65 taps are fused as well (five Toeplitz blocks, bands of 16 row tiles)"""
+    k2 = Gaussian2DKernel(stddev).array
+    assert k2.shape == (taps, taps)
+    shape = (19, 150, 100)
+    d, m = _case(shape, 52, valid=0.7)
+    cube, mk = _dev(d, m)
+    cen = (np.arange(shape[0]) - 5) * 2.0
+    _, maps = ops.spatial_conv_mfma_moments(cube, k2, DeviceArray.from_numpy(cen), dv=2.0, m1_add=-3.0, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk))
+    e0, e1, e2 = _moments_oracle(d, m, m, k2, cen, 2.0, -3.0)
+    assert_close(maps["m0"].get(), e0, atol=1e-5 * np.nanmax(np.abs(e0)), what="%d taps m0" % taps)
+    assert_close(maps["m1"].get(), e1, atol=1e-5 * 2.0 * shape[0], what="%d taps m1" % taps)
+    assert_close(maps["m2"].get(), e2, atol=1e-5 * np.nanmax(np.abs(e2)), what="%d taps m2" % taps)
+
+
+def test_three_sum_form_keeps_moment2_of_a_narrow_line_far_from_the_reference_channel(gpu):
+    """round-5 advisor: S1 = sum v c and S2 = sum v c^2 about the REFERENCE channel in float32 lost moment 2 of a narrow line
+    far from it to cancellation (10 % at nz = 4096, sigma = 2 channels).  The sums are now kept about each chunk's middle channel
+    and shifted to the map's mean in float64: a line of sigma = 2 channels at channel 3900 of 4096 (reference channel 2048),
+    chunks of 64 channels, random mask - moment 1 to 1e-4 channel, moment 2 to 1e-4 RELATIVE, per pixel."""
+    nz, ny, nx = 4096, 384, 256
+    z = np.arange(nz)
+    line = np.exp(-0.5 * ((z - 3900.3) / 2.0) ** 2).astype(np.float32)
+    rng = np.random.default_rng(77)
+    mrow = rng.random((nz, 1, nx)) < 0.7                       # a mask that varies along z and x (constant in y: cheap to build)
+    d = np.broadcast_to(line[:, None, None], (nz, 8, nx)).copy()
+    cube, mk = DeviceArray((nz, ny, nx), np.float32), DeviceArray((nz, ny, nx), np.uint8)
+    import ctypes as C
+    mt = np.ascontiguousarray(np.broadcast_to(mrow, (nz, 8, nx)), dtype=np.uint8)      # (astype of a broadcast view keeps its zero stride: not C order)
+    for dev, host, isz in ((cube, d, 4), (mk, mt, 1)):
+        row = nx * isz
+        _lib.call("spc_memcpy3d_h2d", 0, C.c_void_p(dev.ptr), row, ny * row, host.ctypes.data_as(C.c_void_p), row, 8 * row, row, 8, nz, None)
+        have = 8
+        while have < ny:
+            n = min(have, ny - have)
+            _lib.call("spc_memcpy3d_d2d", 0, C.c_void_p(dev.ptr + have * row), row, ny * row, C.c_void_p(dev.ptr), row, ny * row, row, n, nz, None)
+            have += n
+    cen = (z - nz // 2) * 1.0
+    _, maps = ops.spatial_conv_mfma_moments(cube, K8, DeviceArray.from_numpy(cen), dv=1.0, m1_add=0.0, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk))
+    # every sample of a channel is the same number: the smoothed value IS that number wherever the window holds a valid sample
+    inc = mrow[:, 0, :].astype(np.float64)                     # (nz, nx)
+    f = inc * line[:, None].astype(np.float64)
+    s0 = f.sum(0)
+    mu = (f * cen[:, None]).sum(0) / s0
+    m2 = (f * (cen[:, None] - mu) ** 2).sum(0) / s0
+    # (away from the plane's edges: outside the plane lie valid ZEROS - boundary='fill' - which the windows there average in)
+    g1, g2, mu, m2 = maps["m1"].get()[100:300, 20:-20], maps["m2"].get()[100:300, 20:-20], mu[20:-20], m2[20:-20]
+    assert np.abs(g1 - mu[None, :]).max() <= 1e-4, np.abs(g1 - mu[None, :]).max()
+    rel = np.abs(g2 - m2[None, :]) / m2[None, :]
+    assert rel.max() <= 1e-4, rel.max()
+
+
+def test_three_sum_form_is_reproducible_bit_for_bit(gpu):
+    """the eight waves' contributions are added in wave order behind a barrier: twenty launches, one result (a race in the
+    exchange through LDS shows here: it did, in the first version, for one static copy of the addition code)"""
+    shape = (64, 300, 256)
+    d, m = _case(shape, 5, valid=0.7)
+    cube, mk = _dev(d, m)
+    cen = DeviceArray.from_numpy((np.arange(shape[0]) - 32) * 1.0)
+    ref = None
+    for _ in range(20):
+        _, maps = ops.spatial_conv_mfma_moments(cube, K8, cen, dv=1.0, m1_add=0.0, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk))
+        got = [maps[k].get() for k in ("m0", "m1", "m2")]
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b, equal_nan=True)
