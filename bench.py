@@ -274,7 +274,7 @@ A_SPEC = "f32 samples x f64 taps, f64 accumulate, one rounding to f32 (astropy's
 A_SPEC_ALG = "f64 weights (taps folded into the moment coordinates), f64 sums"
 A_SPAT_F32 = "f32 fma (v_pk_fma_f32), f32 accumulate (reference float64: 1e-5 contract, measured 2.5e-7)"
 A_SPAT_SPLIT = "f16 hi+lo split of the f32 samples on v_mfma_f32_16x16x32_f16, f32 accumulate (1e-5 contract, measured 1e-6)"
-A_FUSED012 = "f64 sums per spaxel about the centre channel"
+A_FUSED012 = "f32 sums per chunk of <= 64 channels about the chunk's middle channel, shifted to the map's mean in f64"
 A_LERP = "f32 difference, f64 blend, one rounding to f32 (numpy's promotion)"
 A_BIL = "f64 pixel map, f32 weights and fma"
 A_STATS = "f64 sums, exact count / extrema"
@@ -821,7 +821,7 @@ def config_c4(device, scale):
     # the same cube -> cube operator in the split form (every product on the fp16 matrix instruction)
     ms_x = event_ms(lambda: ops.spatial_conv_mfma(cube, k2, mask=mspec, out=sm), device, n=5, warm=1)
     ver = check_cube_windows(sm, tmask, "C4 smooth masked, split form")
-    recs.append(cfg_record("c4_mat_mask", A_SPAT_SPLIT, "C4 spatial_smooth(29x29), uint8 mask, matrix cores (fp16 hi / lo split form)", "spatial_split_kernel<4,true,2,true,0> (ARR, STORE)", ms_x, vox * 9, vox, ver,
+    recs.append(cfg_record("c4_mat_mask", A_SPAT_SPLIT, "C4 spatial_smooth(29x29), uint8 mask, matrix cores (fp16 hi / lo split form)", "spatial_split_kernel<3,0,true,2,true,0> (ARR, STORE; whole-column march)", ms_x, vox * 9, vox, ver,
                            "4 + 1 read + 4 written", mask_valid_fraction=float(tmask.mean())))
     del os.environ["SPC_SPATIAL_RING"]
 
@@ -837,7 +837,7 @@ def config_c4(device, scale):
     ms = event_ms(pipeline_masked, device, n=5, warm=1)
     ver = check_m0_windows(o0["m0"].get(), tmask, 500.0, "C4 moment0 masked")
     recs.append(cfg_record("c4_pipe_mask", A_SPAT_SPLIT + "; f64 moment sums", "C4 pipeline spatial_smooth(29x29) -> moment0, uint8 mask (materialised)",
-                           "spatial_split_kernel<4,true,2,true,0> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "spatial_split_kernel<3,0,true,2,true,0> + moments_kernel", ms, vox * 5 + ny * nx * 8, vox, ver,
                            "fused ideal: 4 + 1 read + 8 B/spaxel out (the materialised form moves 9 + 5 B/voxel)",
                            mask_valid_fraction=float(tmask.mean())))
 
@@ -847,7 +847,7 @@ def config_c4(device, scale):
     ms = event_ms(lambda: ops.spatial_conv_mfma(cube, k2, mask=mspec, want_cube=False, want_m0=True, dv=500.0, m0=m0f), device, n=5, warm=1)
     ver = check_m0_windows(m0f.get(), tmask, 500.0, "C4 fused moment0 masked")
     recs.append(cfg_record("c4_fused_mask", A_SPAT_SPLIT + "; f32 channel-chunk sums, f64 map", "C4 pipeline spatial_smooth(29x29) -> moment0, uint8 mask, FUSED (matrix cores, cube never written)",
-                           "spatial_split_kernel<4,true,2,false,1> (ARR, sums) (+ split_finish_kernel)", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "spatial_split_kernel<3,4,true,2,false,1> (ARR, sums) (+ split_finish_kernel)", ms, vox * 5 + ny * nx * 8, vox, ver,
                            "4 + 1 read + 8 B/spaxel out", mask_valid_fraction=float(tmask.mean())))
     # moments 1 and 2 of the smoothed cube from the same kernel (three sums per spaxel instead of one)
     cen_np = (np.arange(nz) - nz // 2) * 500.0
@@ -873,7 +873,7 @@ def config_c4(device, scale):
         worst = max(worst, _close(g1[y0:y0 + WY, x0:x0 + WX], e1, 500.0 * nz, "C4 fused moment1 window (%d, %d)" % (y0, x0)))
         worst = max(worst, _close(g2[y0:y0 + WY, x0:x0 + WX], e2, float(np.nanmax(np.abs(e2))), "C4 fused moment2 window (%d, %d)" % (y0, x0)))
     recs.append(cfg_record("c4_fused012_mask", A_SPAT_SPLIT + "; " + A_FUSED012, "C4 pipeline spatial_smooth(29x29) -> moment0 + moment1 + moment2, uint8 mask, FUSED (matrix cores)",
-                           "spatial_split_kernel<1,true,2,false,3> (ARR, three sums) (+ split_finish_kernel)", ms, vox * 5 + ny * nx * 24, vox,
+                           "spatial_split_kernel<3,6,true,2,false,3> (ARR, three sums, eight channel-parallel waves) (+ split_finish_kernel)", ms, vox * 5 + ny * nx * 24, vox,
                            {"max_scaled_err": worst, "spaxels_checked": int(3 * WY * WX * len(WINDOWS)), "windows": [list(w) for w in WINDOWS]},
                            "4 + 1 read + 24 B/spaxel out", mask_valid_fraction=float(tmask.mean())))
     del mm, g1, g2
@@ -891,7 +891,7 @@ def config_c4(device, scale):
     ms = event_ms(lambda: ops.spatial_conv_mfma(cube, k2, mask=mspec, want_cube=False, want_m0=True, dv=500.0, m0=m0f), device, n=5, warm=1)
     ver = check_m0_windows(m0f.get(), smask, 500.0, "C4 fused moment0 signal mask")
     recs.append(cfg_record("c4_fused_sigmask", A_SPAT_SPLIT + "; f32 channel-chunk sums, f64 map", "C4 pipeline spatial_smooth(29x29) -> moment0, uint8 SIGNAL mask, FUSED (matrix cores)",
-                           "spatial_split_kernel<4,true,2,false,1> (ARR, sums) (+ split_finish_kernel)", ms, vox * 5 + ny * nx * 8, vox, ver,
+                           "spatial_split_kernel<3,4,true,2,false,1> (ARR, sums) (+ split_finish_kernel)", ms, vox * 5 + ny * nx * 8, vox, ver,
                            "4 + 1 read + 8 B/spaxel out", mask_valid_fraction=float(smask.mean())))
 
     # all valid: convolution commutes with the sums along z (algebraic path of SpectralCube.spatial_smooth -> moment0)

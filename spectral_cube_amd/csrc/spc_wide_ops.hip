@@ -400,6 +400,100 @@ __global__ __launch_bounds__(256) void spatial64_ypass_lds_kernel(const Sp64Args
         A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
     }
 }
+// Round 6: the same two passes with FOUR adjacent outputs per thread.  A sample read from LDS feeds up to four accumulators
+// (the outputs x .. x + 3 / the rows y .. y + 3 see it under the taps j .. j - 3, kept in a four-deep register window), so a
+// block reads (nk + 3) samples and taps per four outputs where the one-output passes read nk per output: the passes were bound
+// by LDS traffic (3 reads per tap and output), not by the 2 x nk float64 FMAs.  Every output still adds its taps in astropy's
+// order (j ascending), zero taps skipped: the same float64 results, bit for bit.
+// x pass: a block = 1024 outputs of one row; samples in LDS at s + (s >> 2) - one pad per four - so that the lanes of a wave,
+// four samples apart, read 64-bit words five apart: no bank is asked twice within a half wave.
+constexpr int kSpX4Halo = 127, kSpX4Out = 1024;
+__device__ __forceinline__ int sp64_skew(int s) { return s + (s >> 2); }
+__global__ __launch_bounds__(256) void spatial64_xpass_lds4_kernel(const Sp64Args A) {
+    constexpr int N = kSpX4Out + 2 * kSpX4Halo + 4;
+    __shared__ double sv[N + N / 4 + 1];
+    __shared__ float sw[N + N / 4 + 1];
+    __shared__ double sk[2 * kSpX4Halo + 1];
+    const int t = threadIdx.x, H = A.nkx / 2;
+    for (int j = t; j < A.nkx; j += 256) sk[j] = A.kx[A.nkx - 1 - j];
+    const int64_t x0 = (int64_t)blockIdx.x * kSpX4Out, y = blockIdx.y, zl = blockIdx.z, z = A.z0 + zl;
+    const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+    const double* pd = A.c.p + z * A.c.plane_stride + y * A.c.row_stride;
+    const uint8_t* pmk = arr ? A.m.arr + z * A.m.plane_stride + y * A.m.row_stride : nullptr;
+    for (int e = t; e < kSpX4Out + 2 * H + 3; e += 256) {
+        const int64_t i = x0 - H + e, ic = min(max(i, (int64_t)0), A.c.nx - 1);
+        const double v = pd[ic];
+        const bool inr = i >= 0 && i < A.c.nx, ok = pred64(A.m, v) && (!arr || pmk[ic] != 0);
+        sv[sp64_skew(e)] = (inr && ok) ? v : 0.0;
+        sw[sp64_skew(e)] = inr ? (ok ? 1.f : 0.f) : 1.f;         // outside the image: a valid zero
+    }
+    __syncthreads();
+    const int64_t x = x0 + 4 * t;
+    if (x >= A.c.nx) return;
+    double num[4] = {0.0, 0.0, 0.0, 0.0}, den[4] = {0.0, 0.0, 0.0, 0.0};
+    double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;               // taps i, i - 1, i - 2, i - 3 (0 outside the kernel: skipped like a zero tap)
+    for (int i = 0; i < A.nkx + 3; ++i) {
+        k3 = k2; k2 = k1; k1 = k0; k0 = i < A.nkx ? sk[i] : 0.0;
+        const int p = sp64_skew(4 * t + i);
+        const double v = sv[p], w = (double)sw[p];
+        if (k0 != 0.0) { num[0] = fma(k0, v, num[0]); den[0] = fma(k0, w, den[0]); }
+        if (k1 != 0.0) { num[1] = fma(k1, v, num[1]); den[1] = fma(k1, w, den[1]); }
+        if (k2 != 0.0) { num[2] = fma(k2, v, num[2]); den[2] = fma(k2, w, den[2]); }
+        if (k3 != 0.0) { num[3] = fma(k3, v, num[3]); den[3] = fma(k3, w, den[3]); }
+    }
+    double* o = A.tmp + ((zl * A.c.ny + y) * A.c.nx + x) * 2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (x + q < A.c.nx) { o[2 * q] = num[q]; o[2 * q + 1] = den[q]; }
+}
+// y pass: the tile of kSpYRows + 2 H rows x 64 columns as before; thread (column, row group) takes the rows 4 g .. 4 g + 3
+__global__ __launch_bounds__(256) void spatial64_ypass_lds4_kernel(const Sp64Args A) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ f64x2 tile[];                              // (kSpYRows + 2 H) x 64 pairs: sized by the launch
+    __shared__ double sk[2 * kSpYHalo + 1];
+    const int t = threadIdx.x, col = t & 63, rg = t >> 6, H = A.nky / 2;
+    if (t < A.nky) sk[t] = A.ky[A.nky - 1 - t];
+    const int64_t x = (int64_t)blockIdx.x * 64 + col, y0 = (int64_t)blockIdx.y * kSpYRows, zl = blockIdx.z, z = A.z0 + zl;
+    double ksx = 0.0;                                            // a row outside the image: valid zeros under the whole x kernel
+    for (int j = 0; j < A.nkx; ++j) ksx += A.kx[j];
+    const int64_t xc = min(x, A.c.nx - 1);
+    for (int r0 = rg; r0 < kSpYRows + 2 * H; r0 += 16) {         // (four rows per lane requested together, clamped into the image)
+        f64x2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t ic = min(max(y0 - H + r0 + 4 * q, (int64_t)0), A.c.ny - 1);
+            v[q] = *reinterpret_cast<const f64x2*>(A.tmp + ((zl * A.c.ny + ic) * A.c.nx + xc) * 2);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = r0 + 4 * q;
+            const int64_t i = y0 - H + rr;
+            if (rr < kSpYRows + 2 * H) tile[rr * 64 + col] = (i >= 0 && i < A.c.ny) ? v[q] : f64x2{0.0, ksx};
+        }
+    }
+    __syncthreads();
+    if (x >= A.c.nx) return;
+    static_assert(kSpYRows == 16, "four row groups of four rows");
+    double num[4] = {0.0, 0.0, 0.0, 0.0}, den[4] = {0.0, 0.0, 0.0, 0.0};
+    double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;
+    for (int i = 0; i < A.nky + 3; ++i) {
+        k3 = k2; k2 = k1; k1 = k0; k0 = i < A.nky ? sk[i] : 0.0;
+        const f64x2 tv = tile[(4 * rg + i) * 64 + col];
+        if (k0 != 0.0) { num[0] = fma(k0, tv.x, num[0]); den[0] = fma(k0, tv.y, den[0]); }
+        if (k1 != 0.0) { num[1] = fma(k1, tv.x, num[1]); den[1] = fma(k1, tv.y, den[1]); }
+        if (k2 != 0.0) { num[2] = fma(k2, tv.x, num[2]); den[2] = fma(k2, tv.y, den[2]); }
+        if (k3 != 0.0) { num[3] = fma(k3, tv.x, num[3]); den[3] = fma(k3, tv.y, den[3]); }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t y = y0 + 4 * rg + q;
+        if (y >= A.c.ny) break;
+        double res;
+        if (den[q] != 0.0) res = num[q] / den[q];
+        else { double cv; res = inc64(A.c, A.m, z, y, x, cv) ? cv : NAN; }
+        A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
+    }
+}
 __global__ __launch_bounds__(256) void spatial64_direct_kernel(const Sp64Args A) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t y = blockIdx.y, z = A.z0 + blockIdx.z;
@@ -614,7 +708,7 @@ __global__ __launch_bounds__(256) void sort64_kernel(const Sort64Args A) {
             p = min(max(p, 0), cnt - 1);
             const int p1 = min(p + 1, cnt - 1);
             const double g = vi - (double)p, va = val(a + p), vb = val(a + p1), d = vb - va;
-            return g >= 0.5 ? vb - d * (1.0 - g) : va + d * g;
+            return g >= 0.5 ? __dsub_rn(vb, __dmul_rn(d, 1.0 - g)) : __dadd_rn(va, __dmul_rn(d, g));   // (numpy's _lerp: a product, then a sum - never one fused operation)
         };
         // median of |x - med| over the window: the deviations below and above the median are two ascending sequences (walking
         // away from it) - their merge is walked up to the middle ranks
@@ -674,6 +768,130 @@ __global__ __launch_bounds__(256) void sort64_kernel(const Sort64Args A) {
     }
 }
 
+// Round 6: median / percentile / mad_std of float64 rays WITHOUT a sort.  The bitonic network moved ~720 bytes through LDS per
+// sample (45 barrier-separated stages at 512 channels); here the keys of TS = min(16, 8192 / NZP) adjacent rays go to LDS once
+// (64 KB: 128 contiguous bytes per plane and block at TS = 16) and the lower order statistic of numpy's rule is pinned down one
+// key BYTE at a time: eight passes count, for every ray, the keys that share the bytes found so far by their next byte (LDS
+// atomics on 16 x 128 packed 16-bit counters), 256 / TS threads per ray add the counters up and one of them walks to the bin
+// that holds the rank.  A ninth pass gives the number of keys <= the one found and the smallest key above it: the upper order
+// statistic is one or the other.  The results are the sorted rays' - numpy's `_lerp` of the same two samples - bit for bit.
+constexpr int kSelKeys64 = 8192, kSelRays64 = 16;
+__global__ __launch_bounds__(256) void select64_kernel(const Sort64Args A) {
+    __shared__ unsigned long long keys[kSelKeys64];          // [sample][ray]
+    __shared__ unsigned hist[kSelRays64 * 128];              // [ray][bin & 127]: low half = bins 0 .. 127, high half = bins 128 .. 255
+    __shared__ unsigned s_part[256];                         // [ray][thread of the ray]
+    __shared__ unsigned long long s_prefix[kSelRays64], s_next[kSelRays64];
+    __shared__ int s_rank[kSelRays64], s_n[kSelRays64], s_le[kSelRays64];
+    const int t = threadIdx.x, TS = A.ts, NZP = A.nzp, L = 256 / TS;
+    const int64_t tiles_x = (A.c.nx + TS - 1) / TS;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * TS;
+    const int r = t % TS, jz = t / TS;
+    const bool col_in = x0 + r < A.c.nx;
+    const double cen = (A.center && col_in) ? A.center[y * A.c.nx + x0 + r] : 0.0;
+    {   // (eight samples requested together per lane, their channels clamped into the ray)
+        constexpr int kIn = 8;
+        const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+        const int64_t xc = col_in ? x0 + r : A.c.nx - 1;
+        const double* pd = A.c.p + y * A.c.row_stride + xc;
+        const uint8_t* pmk = arr ? A.m.arr + y * A.m.row_stride + xc : nullptr;
+        for (int z0 = jz; z0 < NZP; z0 += L * kIn) {
+            double vv[kIn];
+            unsigned mk[kIn];
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) {
+                const int64_t zc = min((int64_t)(z0 + q * L), A.c.nz - 1);
+                vv[q] = pd[zc * A.c.plane_stride];
+                mk[q] = arr ? pmk[zc * A.m.plane_stride] : 1u;
+            }
+#pragma unroll
+            for (int q = 0; q < kIn; ++q) {
+                const int z = z0 + q * L;
+                if (z < NZP) {
+                    double v = vv[q];
+                    bool ok = col_in && z < A.c.nz && pred64(A.m, v) && mk[q] != 0u;
+                    if (A.center) { v = fabs(v - cen); ok = ok && (v == v); }
+                    keys[z * TS + r] = ok ? fkey64(v) : kExcl;
+                }
+            }
+        }
+    }
+    if (t < TS) { s_prefix[t] = 0ull; s_rank[t] = 0; s_n[t] = 0; s_le[t] = 0; s_next[t] = kExcl; }
+    const int nkeys = TS * NZP;
+    const int ray_s = t / L, l = t % L;                        // scan: L threads per ray, TS bins each
+    for (int d = 7; d >= 0; --d) {
+        const int shift = 8 * d;
+        for (int i = t; i < TS * 128; i += 256) hist[i] = 0u;
+        __syncthreads();
+        for (int i = t; i < nkeys; i += 256) {
+            const unsigned long long k = keys[i];
+            const int ray = i % TS;
+            // (the bytes above the current one: equal to the prefix found so far; d = 7: every key but the excluded ones)
+            const bool match = k != kExcl && (d == 7 || (k >> (shift + 8)) == (s_prefix[ray] >> (shift + 8)));
+            if (match) {
+                const unsigned b = (unsigned)(k >> shift) & 255u;
+                atomicAdd(&hist[ray * 128 + (b & 127u)], (b & 128u) ? 65536u : 1u);
+            }
+        }
+        __syncthreads();
+        {   // bins [l TS, (l + 1) TS) of ray ray_s: all in one half of the packed counters
+            unsigned sum = 0;
+            const int b0 = l * TS;
+            for (int b = b0; b < b0 + TS; ++b) { const unsigned w = hist[ray_s * 128 + (b & 127)]; sum += (b & 128) ? (w >> 16) : (w & 0xffffu); }
+            s_part[ray_s * L + l] = sum;
+        }
+        __syncthreads();
+        if (l == 0) {
+            int rank = s_rank[ray_s];
+            if (d == 7) {                                      // the ray's count, and the rank of the lower order statistic
+                int n = 0;
+                for (int g = 0; g < L; ++g) n += (int)s_part[ray_s * L + g];
+                s_n[ray_s] = n;
+                if (A.q == 50.0) rank = (n - 1) / 2;
+                else { rank = (int)floor(A.q / 100.0 * (double)(n - 1)); rank = min(max(rank, 0), n - 1); }
+                if (n <= 0) rank = 0;
+            }
+            int g = 0;
+            while (g < L - 1 && rank >= (int)s_part[ray_s * L + g]) { rank -= (int)s_part[ray_s * L + g]; ++g; }
+            int b = g * TS;
+            for (;;) {
+                const unsigned w = hist[ray_s * 128 + (b & 127)];
+                const int c = (int)((b & 128) ? (w >> 16) : (w & 0xffffu));
+                if (rank < c || b == g * TS + TS - 1) break;
+                rank -= c; ++b;
+            }
+            s_rank[ray_s] = rank;
+            s_prefix[ray_s] |= (unsigned long long)b << shift;
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < nkeys; i += 256) {                      // keys <= the one found, and the smallest one above it
+        const unsigned long long k = keys[i];
+        const int ray = i % TS;
+        if (k != kExcl) {
+            if (k <= s_prefix[ray]) atomicAdd(&s_le[ray], 1);
+            else atomicMin(&s_next[ray], k);
+        }
+    }
+    __syncthreads();
+    if (t < TS && x0 + t < A.c.nx) {
+        const int n = s_n[t];
+        double res = NAN;
+        if (n > 0) {
+            const unsigned long long klo = s_prefix[t];
+            int p;
+            double g = 0.0;
+            if (A.q == 50.0) { p = (n - 1) / 2; g = (n & 1) ? 0.0 : 0.5; }
+            else { const double vi = A.q / 100.0 * (double)(n - 1); p = min(max((int)floor(vi), 0), n - 1); g = vi - (double)p; }
+            const int p1 = min(p + 1, n - 1);
+            const unsigned long long khi = (p1 == p || p1 < s_le[t]) ? klo : s_next[t];
+            const double va = funkey64(klo), vb = funkey64(khi);
+            if (A.q == 50.0) res = (n & 1) ? va : 0.5 * (va + vb);
+            else { const double d = vb - va; res = g >= 0.5 ? __dsub_rn(vb, __dmul_rn(d, 1.0 - g)) : __dadd_rn(va, __dmul_rn(d, g)); }   // (numpy's _lerp, unfused)
+        }
+        A.out[y * A.c.nx + x0 + t] = res * A.scale;
+    }
+}
+
 static int sort64_launch(Sort64Args& A, const spc_cube_f64* cube, bool clip, hipStream_t st) {
     if (cube->nz > 4096) {
         spc_set_error("rays of more than 4096 samples have no float64 order statistics (got %lld)", (long long)cube->nz);
@@ -681,10 +899,14 @@ static int sort64_launch(Sort64Args& A, const spc_cube_f64* cube, bool clip, hip
     }
     int nzp = 2;
     while (nzp < cube->nz) nzp <<= 1;
-    A.nzp = nzp; A.ts = std::min(64, kSortKeys / nzp);
+    // (SPC_SELECT64: 0 = the order statistics from sorted rays as in round 5; the clip loop always sorts)
+    static const bool radix = [] { const char* e = getenv("SPC_SELECT64"); return e ? atoi(e) != 0 : true; }();
+    const bool sel = !clip && radix;
+    A.nzp = nzp; A.ts = sel ? std::min(kSelRays64, kSelKeys64 / nzp) : std::min(64, kSortKeys / nzp);
     const int64_t nb = ((cube->nx + A.ts - 1) / A.ts) * cube->ny;
     SPC_REQUIRE(nb < (1LL << 31), "map too large for one launch");
     if (clip) hipLaunchKernelGGL(sort64_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, A);
+    else if (sel) hipLaunchKernelGGL(select64_kernel, dim3((unsigned)nb), dim3(256), 0, st, A);
     else hipLaunchKernelGGL(sort64_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
@@ -875,13 +1097,19 @@ int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, con
     for (int64_t z0 = 0; z0 < cube->nz; z0 += planes) {
         A.z0 = z0;
         const unsigned gz = (unsigned)std::min<int64_t>(planes, cube->nz - z0);
-        static const bool tiled = [] { const char* e = getenv("SPC_SPATIAL64_LDS"); return e ? atoi(e) != 0 : true; }();
-        if (tiled && nkx / 2 <= kSpHaloMax)
+        static const int tiled = [] { const char* e = getenv("SPC_SPATIAL64_LDS"); return e ? atoi(e) : 2; }();
+        // (SPC_SPATIAL64_LDS: 0 = the untiled passes, 1 = LDS tiles with one output per thread (round 5), 2 = four outputs per thread)
+        if (tiled == 2 && nkx / 2 <= kSpX4Halo)
+            hipLaunchKernelGGL(spatial64_xpass_lds4_kernel, dim3((unsigned)((cube->nx + kSpX4Out - 1) / kSpX4Out), (unsigned)cube->ny, gz), dim3(256), 0, st, A);
+        else if (tiled && nkx / 2 <= kSpHaloMax)
             hipLaunchKernelGGL(spatial64_xpass_lds_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
         else
             hipLaunchKernelGGL(spatial64_xpass_kernel, dim3(gx, (unsigned)cube->ny, gz), dim3(256), 0, st, A);
         SPC_LAUNCH_CHECK();
-        if (tiled && nky / 2 <= kSpYHalo && (cube->ny + kSpYRows - 1) / kSpYRows <= 65535)
+        if (tiled == 2 && nky / 2 <= kSpYHalo && (cube->ny + kSpYRows - 1) / kSpYRows <= 65535)
+            hipLaunchKernelGGL(spatial64_ypass_lds4_kernel, dim3((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + kSpYRows - 1) / kSpYRows), gz),
+                               dim3(256), (size_t)(kSpYRows + 2 * (nky / 2)) * 64 * 16, st, A);
+        else if (tiled && nky / 2 <= kSpYHalo && (cube->ny + kSpYRows - 1) / kSpYRows <= 65535)
             hipLaunchKernelGGL(spatial64_ypass_lds_kernel, dim3((unsigned)((cube->nx + 63) / 64), (unsigned)((cube->ny + kSpYRows - 1) / kSpYRows), gz),
                                dim3(256), (size_t)(kSpYRows + 2 * (nky / 2)) * 64 * 16, st, A);
         else

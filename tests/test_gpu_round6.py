@@ -140,3 +140,61 @@ def test_three_sum_form_is_reproducible_bit_for_bit(gpu):
         else:
             for a, b in zip(got, ref):
                 assert np.array_equal(a, b, equal_nan=True)
+
+
+# ---- float64 order statistics without a sort (select64_kernel), float64 spatial passes with four outputs per thread --------------
+@pytest.mark.parametrize("shape", [(512, 9, 70), (37, 20, 33), (1024, 3, 40), (2500, 2, 18), (4096, 2, 5), (5, 40, 64), (1, 7, 9)])
+@pytest.mark.parametrize("q", [50.0, 0.0, 100.0, 30.0, 99.9])
+def test_float64_percentiles_by_radix_selection_are_numpy_s(gpu, shape, q):
+    """round 6: the float64 median / percentile kernel pins the lower order statistic down one key byte at a time in LDS
+    (no sort): rays of 1 .. 4096 samples, duplicates (quantised samples), +-inf, zeros of both signs, masked samples, fully
+    masked rays - bit-identical to np.nanpercentile / np.nanmedian on the float64 samples"""
+    import warnings
+    rng = np.random.default_rng(shape[0] + int(q))
+    d = 1000.0 + rng.standard_normal(shape)
+    d[rng.random(shape) < 0.3] = np.round(d[rng.random(shape) < 0.3].mean(), 1)        # many equal samples
+    d[rng.random(shape) < 0.01] = np.inf
+    d[rng.random(shape) < 0.01] = -np.inf
+    d[rng.random(shape) < 0.01] = 0.0
+    d[rng.random(shape) < 0.01] = -0.0
+    d[rng.random(shape) < 0.02] = np.nan
+    m = rng.random(shape) < 0.8
+    if shape[1] > 3 and shape[2] > 3:
+        m[:, 1, 2] = False
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    got = ops.percentile_axis0_f64(cube, q, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk)).get()
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        f = np.where(m, d, np.nan)
+        exp = np.nanmedian(f, axis=0) if q == 50.0 else np.nanpercentile(f, q, axis=0)
+    assert got.dtype == np.float64 and np.array_equal(got, exp, equal_nan=True)
+
+
+def test_float64_mad_by_radix_selection(gpu):
+    rng = np.random.default_rng(12)
+    d = 5.0 + rng.standard_normal((300, 12, 40))
+    m = rng.random(d.shape) < 0.7
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    spec = ops.MaskSpec(_lib.MASK_ARRAY, array=mk)
+    med = ops.percentile_axis0_f64(cube, 50.0, mask=spec)
+    mad = ops.percentile_axis0_f64(cube, 50.0, mask=spec, center=med, scale=1.482602218505602).get()
+    f = np.where(m, d, np.nan)
+    exp = 1.482602218505602 * np.nanmedian(np.abs(f - np.nanmedian(f, axis=0)), axis=0)
+    assert np.array_equal(mad, exp, equal_nan=True)
+
+
+@pytest.mark.parametrize("shape, stddev", [((3, 50, 1100), 3.0), ((2, 37, 70), 1.0), ((2, 130, 2070), 5.0)])
+def test_float64_spatial_smooth_four_outputs_per_thread_is_bit_identical(gpu, shape, stddev, monkeypatch):
+    """round 6: the float64 spatial passes compute four adjacent outputs per thread from one LDS read of every sample; every
+    output still adds its taps in astropy's order - the same float64 bits as the one-output passes, and the oracle's to 1e-13"""
+    rng = np.random.default_rng(31)
+    d = 1000.0 + rng.standard_normal(shape)
+    d[rng.random(shape) < 0.01] = np.nan
+    m = rng.random(shape) < 0.8
+    k2 = Gaussian2DKernel(stddev).array
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    got = ops.spatial_conv_f64(cube, k2, mask=ops.MaskSpec(_lib.MASK_ARRAY, array=mk)).get()
+    exp = O.spatial_smooth(d, m, k2)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.abs(got[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max()
