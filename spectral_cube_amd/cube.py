@@ -855,6 +855,9 @@ class SpectralCube:
             return None
         parent = lz.parent
         spec = parent._mask_spec()
+        split_ok = getattr(lz, "arithmetic", None) != "f32"        # (asked for float32 multiply-adds: the fused forms are split-form kernels)
+        if not split_ok and spec.array is not None:
+            return None
         if tuple(want) == ("m0",) and parent._stream_source() is None and (spec.array is not None or (spec.flags & ~_lib.MASK_FINITE) == 0):
             fused = self._fused_masked_smooth_moment0(parent, spec, lz.kernel)
             if fused is not None:
@@ -903,10 +906,10 @@ class SpectralCube:
         return out
 
     def _prefer_fused_higher_moments(self):
-        """Three sums per spaxel fit the LDS only for 16-row wave regions (three times the halo work of moment 0's 64 rows):
-        measured at 4096 x 2048^2 the fused moments 0 / 1 / 2 take 75 ms against 51 + 14 ms for smoothing into a second cube and
-        reducing that.  So the fused form is for cubes whose smoothed copy does not fit beside them in HBM
-        (SPC_FUSED_SMOOTH_MOMENTS=1 / 0 forces / forbids it)."""
+        """Measured at 4096 x 2048^2 + uint8 mask (round 6): the fused moments 0 / 1 / 2 take 55 ms (eight channel-parallel
+        waves per block, bands of 96 rows; round 5: 71 ms with 16-row wave regions) against 39 + 14 ms for smoothing into a
+        second cube (whole-column march) and reducing that.  So the fused form remains for cubes whose smoothed copy does not
+        fit beside them in HBM (SPC_FUSED_SMOOTH_MOMENTS=1 / 0 forces / forbids it)."""
         env = os.environ.get("SPC_FUSED_SMOOTH_MOMENTS")
         if env is not None:
             return env == "1"
@@ -1328,13 +1331,18 @@ class SpectralCube:
 
         return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
 
-    def spatial_smooth(self, kernel, convolve=None, raise_error_jybm=True, **kwargs):
+    def spatial_smooth(self, kernel, convolve=None, raise_error_jybm=True, arithmetic=None, **kwargs):
         """Smooth every channel with a 2-D kernel (dask_spectral_cube.py:962-993).  Extra keyword
         arguments are accepted and not used - exactly what the Dask class does with them (its
-        convolve_wrapper only receives ``kernel``, :990-993; spectral_smooth likewise, :912-917)."""
+        convolve_wrapper only receives ``kernel``, :990-993; spectral_smooth likewise, :912-917).
+        ``arithmetic`` (this package's own): None, "f16-split" or "f32" - which arithmetic the MASKED separable stencil of a
+        float32 cube runs in (ops.masked_spatial_arithmetic; DESIGN section 5: both are inside the 1e-5 contract, the
+        reference computes in float64)."""
         self.check_jybeam_smoothing(raise_error_jybm=raise_error_jybm)
         karr = kernel_array(kernel, 2)
         _check_convolve(convolve)
+        if arithmetic is not None and arithmetic not in ops.MASKED_SPATIAL_ARITHMETIC:
+            raise ValueError("arithmetic must be one of %r, got %r" % (ops.MASKED_SPATIAL_ARITHMETIC, arithmetic))
         parent = self
         if self._runs_wide():
             return self._new_wide_cube(lambda: ops.spatial_conv_f64(parent._device_data64(), karr, mask=parent._mask_spec64()))
@@ -1344,15 +1352,15 @@ class SpectralCube:
             fusable = False
 
             def __init__(self):
-                self.parent, self.kernel = parent, karr
+                self.parent, self.kernel, self.arithmetic = parent, karr, arithmetic
 
             def __call__(self):
-                return ops.spatial_conv(parent._device_data(), karr, mask=parent._mask_spec())
+                return ops.spatial_conv(parent._device_data(), karr, mask=parent._mask_spec(), arithmetic=arithmetic)
 
             halo = karr.shape[0] // 2        # rows a strip of an out-of-core parent needs from its neighbours
 
             def strip_fn(self, dev, mspec, stream):
-                return ops.spatial_conv(dev, karr, mask=mspec, stream=stream)
+                return ops.spatial_conv(dev, karr, mask=mspec, stream=stream, arithmetic=arithmetic)
 
             # cube -> cube (write / stream_into) of an out-of-core parent goes in slabs of whole planes instead: no halo rows
             # to read twice (29 x 29 taps, 8 GiB host array: 8.3 GB/s each way in halo strips, the link's rate in slabs); the
@@ -1360,7 +1368,7 @@ class SpectralCube:
             keeps_mask = True
 
             def slab_fn(self, dev, mspec, stream):
-                return ops.spatial_conv(dev, karr, mask=mspec, stream=stream)
+                return ops.spatial_conv(dev, karr, mask=mspec, stream=stream, arithmetic=arithmetic)
 
         return self._new_cube_with(lazy=_Lazy(), shape=self._shape)
 
