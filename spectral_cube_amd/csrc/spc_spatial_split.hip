@@ -174,6 +174,8 @@ __global__ __launch_bounds__(NSUM == 3 ? 512 : kThreads, NSUM == 3 ? 1 : 2) void
         const int64_t n = (int64_t)gridDim.x, b = blockIdx.x;
         const int64_t q = n / 8, r = n % 8, xcd = b % 8, i = b / 8;
         const int64_t w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        // (strips fastest instead - the blocks of an XCD side by side in x, sharing 32 of their 96 columns - measured within 2.5 %
+        //  of this order for all three forms: not kept)
         band = (int)(w % A.nbands);
         strip = (int)((w / A.nbands) % A.nstrips);
         chunk = (int)(w / ((int64_t)A.nbands * A.nstrips));

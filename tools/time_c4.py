@@ -1,6 +1,6 @@
 """scratch: the masked C4 records alone (fused moment0, fused moment 0/1/2, cube -> cube) at nz planes"""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import numpy as np
 from spectral_cube_amd import Gaussian2DKernel, _lib, ops
