@@ -1122,7 +1122,7 @@ def wide_records(device, scale=1):
               rel(res["m2"].get()[:TR], e[2], "f64 moment2", 1e-9))
     recs.append(cfg_record("w_moments_f64", A64 + "; moment 2 as a second pass about moment 1 (the reference's own form)",
                            "float64 moment0 + moment1 + moment2, 512x1024x1024 f64 + uint8 mask (two passes over the cube)",
-                           "moments64_kernel + moment_order64_kernel", ms, vox * 18 + ny * nx * 24, vox, {"rows_checked": TR, "max_rel_err": err},
+                           "moments_f64_kernel<2,true,false,0> + moments_f64_kernel<2,true,false,1>", ms, vox * 18 + ny * nx * 24, vox, {"rows_checked": TR, "max_rel_err": err},
                            "2 x (8 B data + 1 B mask) read per voxel, three f64 maps out"))
     # spectral_smooth, 33 taps
     k1 = Gaussian1DKernel(4).array
@@ -1138,7 +1138,7 @@ def wide_records(device, scale=1):
     exp = O.spatial_smooth(sub, np.tile(inc[:2, :, :WX + PAD], (1, 6, 1)), k2)[:, 16:32, PAD:WX]
     got = np.stack([out.planes(z, z + 1).get()[0, 512 // scale:512 // scale + 16, PAD:WX] for z in range(2)])
     err = rel(got, exp, "f64 spatial_smooth")
-    recs.append(cfg_record("w_spatial_f64", A64, "float64 spatial_smooth(29x29, outer product), 512x1024x1024 f64 + uint8 mask", "spatial64_xpass_lds_kernel + spatial64_ypass_lds_kernel",
+    recs.append(cfg_record("w_spatial_f64", A64, "float64 spatial_smooth(29x29, outer product), 512x1024x1024 f64 + uint8 mask", "spatial64_xpass_lds4_kernel[all] + spatial64_ypass_lds4_kernel[all]",
                            ms, vox * 17, vox, {"voxels_checked": int(exp.size), "max_rel_err": err}, "8 + 1 read, 8 written per voxel (the (num, den) planes between the passes stay in the workspace)"))
     # spectral_interpolate 512 -> 512 channels (shifted grid)
     v = np.arange(nz) * 1.0
@@ -1159,7 +1159,7 @@ def wide_records(device, scale=1):
         warnings.simplefilter("ignore")
         exp = np.nanmedian(np.where(inc, tile, np.nan), axis=0)
     assert np.array_equal(med["m"].get()[:TR], exp, equal_nan=True), "float64 median(axis=0) differs from np.nanmedian"
-    recs.append(cfg_record("w_median_f64", A_SELECT.replace("f32", "f64"), "float64 median(axis=0), 512x1024x1024 f64 + uint8 mask", "percentile64_axis0_kernel", ms,
+    recs.append(cfg_record("w_median_f64", A_SELECT.replace("f32", "f64"), "float64 median(axis=0), 512x1024x1024 f64 + uint8 mask", "select64_kernel", ms,
                            vox * 9 + ny * nx * 8, vox, {"rows_checked": TR, "vs_np_nanmedian": "bit-identical"}, "8 B data + 1 B mask read per voxel, one f64 map out"))
     # sigma clipping
     keep = {}
@@ -1172,7 +1172,7 @@ def wide_records(device, scale=1):
     exp = O.sigma_clip(tile, inc, 3.0, out_dtype=np.float64)
     assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)]), "float64 sigma clip vs oracle"
     keep.clear()
-    recs.append(cfg_record("w_clip_f64", A_CLIP.replace("f32", "f64"), "float64 sigma_clip_spectrally(3), astropy defaults, 512x1024x1024 f64 + uint8 mask", "sigma_clip64_axis0_kernel", ms,
+    recs.append(cfg_record("w_clip_f64", A_CLIP.replace("f32", "f64"), "float64 sigma_clip_spectrally(3), astropy defaults, 512x1024x1024 f64 + uint8 mask", "sort64_kernel<1>", ms,
                            vox * 17, vox, {"rows_checked": TR, "clipped_set_and_kept_values": "identical to the oracle"}, "8 + 1 read, 8 written per voxel"))
     for r in recs:
         r["mask_valid_fraction"] = float(inc.mean())

@@ -87,7 +87,7 @@ for grp in [detail.get("next_rows") or []] + list((detail.get("configs") or {}).
 
 
 def base(kernel):
-    return re.split(r"[<\s(]", kernel.strip())[0]
+    return re.split(r"[<\s(\[]", kernel.strip())[0]
 
 
 def cluster(v, ms):
@@ -132,11 +132,16 @@ for name, kernel, ms, alg in records:
                 chosen = []
                 break
         else:      # a pipeline record: its parts are the groups of single-kernel records already chosen for this cube size
+            if part.endswith("[all]"):      # every (kernel, grid) group of this kernel: a call that launches it once per slab of planes
+                fewest = min(len(v) for _, v in cands)      # a group launched twice per call (two slabs of that size) counts twice
+                for kv in sorted(cands, key=lambda kv: -kv[0][1]):
+                    chosen.extend([kv] * max(1, round(len(kv[1]) / fewest)))
+                continue
             prev = [t for t in table if base(t["kernel_trace_name"]) == base(part)]
-            if not prev:
-                chosen = []
-                break
-            k = max(((p["kernel_trace_name"], p["grid_threads"]) for p in prev), key=lambda kk: kk[1])
+            if prev:
+                k = max(((p["kernel_trace_name"], p["grid_threads"]) for p in prev), key=lambda kk: kk[1])
+            else:                           # no single-kernel record uses it: the group of the largest grid
+                k = max((kk for kk, _ in cands), key=lambda kk: kk[1])
             v = groups[k]
         chosen.append((k, v))
     if not chosen:
