@@ -590,7 +590,7 @@ class FitsSink:
                 os.ftruncate(self.fd, size)
             # The strips arrive as one piece per plane (rows x nx samples): with the 64-row strips of a 2 GiB test budget that is
             # 256 KiB per os.pwrite, 32768 calls for 8 GiB, each under the file's write lock: 4.7 GB/s where 64 MiB writes reach
-            # 15 - 20 GB/s on the same file system (tools/bench_filewrite.py, bench_stream_parts.py).  A shared mapping
+            # 15 - 20 GB/s on the same file system (round-3 scratch scripts, in the history: tools/README.md).  A shared mapping
             # (SPC_FITS_SINK_MMAP=1) lets the writer threads copy side by side, but a fresh file then costs a page-cache fault
             # per 4 KiB: 4.1 GB/s - no better, so the pwrite form stays the default.  The pieces grow with the strip: a cube
             # that is out of core for 288 GB of HBM has strips of hundreds of rows (10+ MiB per piece).

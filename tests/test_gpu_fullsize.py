@@ -429,7 +429,7 @@ def test_sigma_clip_1024cubed_is_reproducible_from_launch_to_launch(gpu):
     """The one-kernel sigma clip keeps a block's rays resident across its iterations and reuses one set of shared words
     for every descent: a wave that entered the next iteration used to reset the word another wave was still reading
     (the upper middle sample of an even count), and one launch in four clipped one 8-row period differently
-    (round 4, tools/stress_clip_determinism.py: 22 of 60 launches; 0 of 80 with the barrier).  Twelve launches over
+    (round 4, a stress script now in the history: 22 of 60 launches; 0 of 80 with the barrier).  Twelve launches over
     the same input must give the same samples: count / sum / sum of squares / extrema of the result and the per-ray
     counts and sums, period by period."""
     shape, ty = (1024, 1024, 1024), 8
