@@ -1159,7 +1159,7 @@ def wide_records(device, scale=1):
         warnings.simplefilter("ignore")
         exp = np.nanmedian(np.where(inc, tile, np.nan), axis=0)
     assert np.array_equal(med["m"].get()[:TR], exp, equal_nan=True), "float64 median(axis=0) differs from np.nanmedian"
-    recs.append(cfg_record("w_median_f64", A_SELECT.replace("f32", "f64"), "float64 median(axis=0), 512x1024x1024 f64 + uint8 mask", "select64_kernel", ms,
+    recs.append(cfg_record("w_median_f64", A_SELECT.replace("f32", "f64"), "float64 median(axis=0), 512x1024x1024 f64 + uint8 mask", "select64_reg_kernel<32,16> (keys in registers, 16 lanes per ray = one DPP row)", ms,
                            vox * 9 + ny * nx * 8, vox, {"rows_checked": TR, "vs_np_nanmedian": "bit-identical"}, "8 B data + 1 B mask read per voxel, one f64 map out"))
     # sigma clipping
     keep = {}

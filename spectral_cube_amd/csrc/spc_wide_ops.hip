@@ -892,6 +892,198 @@ __global__ __launch_bounds__(256) void select64_kernel(const Sort64Args A) {
     }
 }
 
+// Rays of up to 1024 samples: the keys stay in REGISTERS (round 6, second form).  A block = 16 adjacent rays (128 contiguous
+// bytes per plane), a wave = 4 of them, and the 16 lanes that share a ray are ONE DPP row (lane = 16 ray + slice, slice s holds
+// the samples z = s + 16 i): whatever the lanes of a ray have to agree on - the sixteen counters of a digit pass, the count of
+// keys below the one found, the smallest key above it - meets through four row rotations (v_add / v_min with row_ror 8, 4, 2, 1),
+// with no LDS, no barrier, no atomics; every wave runs on its own.  Radix 16: sixteen passes over the KPL key registers of a
+// lane (a bit-field extract, a prefix compare on the word that holds the digit, 8-bit counters in four packed words), after
+// which every lane of the row walks the sixteen totals to the digit.
+template <int N> struct U32Arr { unsigned v[N]; };
+__device__ __forceinline__ unsigned row_ror_u32(unsigned v, int n) {       // lane i of a row of 16 takes lane (i + n) mod 16 ... of its row
+    switch (n) {
+        case 8: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
+        case 4: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);
+        case 2: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);
+        default: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);
+    }
+}
+__device__ __forceinline__ unsigned swap16_u32(unsigned v) {           // lane i takes lane i ^ 16 (ds_swizzle, bit mode: and 0x1f, xor 0x10)
+    return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x401f);
+}
+// LPR = 16 | 32 lanes per ray: one DPP row, or two neighbouring rows of the same wave (rays of 513 .. 1024 samples: 64 keys per lane
+// do not fit the registers)
+template <int LPR>
+__device__ __forceinline__ unsigned row_sum_u32(unsigned v) {
+    v += row_ror_u32(v, 8); v += row_ror_u32(v, 4); v += row_ror_u32(v, 2); v += row_ror_u32(v, 1);
+    if (LPR == 32) v += swap16_u32(v);
+    return v;
+}
+template <int LPR>
+__device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int n = 8; n >= 1; n >>= 1) {
+        const unsigned lo = row_ror_u32((unsigned)v, n), hi = row_ror_u32((unsigned)(v >> 32), n);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        v = o < v ? o : v;
+    }
+    if (LPR == 32) {
+        const unsigned long long o = ((unsigned long long)swap16_u32((unsigned)(v >> 32)) << 32) | swap16_u32((unsigned)v);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+template <int KPL, int LPR>
+__global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args A) {
+    constexpr int RW = 64 / LPR;                             // rays per wave
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, rr = lane / LPR, sl = lane % LPR;
+    const int64_t tiles_x = (A.c.nx + 15) / 16;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * 16;
+    const int64_t x = x0 + RW * wave + rr;
+    const bool col_in = x < A.c.nx;
+    const int64_t xc = col_in ? x : A.c.nx - 1;
+    const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+    const double* pd = A.c.p + y * A.c.row_stride + xc;
+    const uint8_t* pmk = arr ? A.m.arr + y * A.m.row_stride + xc : nullptr;
+    const double cen = A.center ? A.center[y * A.c.nx + xc] : 0.0;
+    unsigned khi[KPL], klo[KPL];
+    constexpr int CH = KPL < 16 ? KPL : 16;                  // samples requested together per lane (all 64 at once: 128 registers of loads in flight)
+#pragma unroll
+    for (int i0 = 0; i0 < KPL; i0 += CH) {
+        double vv[CH];
+        unsigned mk[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int64_t zc = min((int64_t)(sl + LPR * (i0 + q)), A.c.nz - 1);
+            vv[q] = pd[zc * A.c.plane_stride];
+            mk[q] = arr ? pmk[zc * A.m.plane_stride] : 1u;
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int i = i0 + q;
+            double v = vv[q];
+            bool ok = col_in && (sl + LPR * i) < A.c.nz && pred64(A.m, v) && mk[q] != 0u;
+            if (A.center) { v = fabs(v - cen); ok = ok && (v == v); }
+            const unsigned long long k = ok ? fkey64(v) : kExcl;
+            khi[i] = (unsigned)(k >> 32); klo[i] = (unsigned)k;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // valid samples of the ray, and the rank of the lower order statistic (numpy's rule)
+    unsigned nloc = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) nloc += ((khi[i] & klo[i]) != 0xffffffffu) ? 1u : 0u;      // (valid keys never are all ones)
+    const int n = (int)row_sum_u32<LPR>(nloc);
+    int p = 0;
+    double g = 0.0;
+    if (A.q == 50.0) { p = (n - 1) / 2; g = (n & 1) ? 0.0 : 0.5; }
+    else { const double vi = A.q / 100.0 * (double)(n - 1); p = min(max((int)floor(vi), 0), max(n - 1, 0)); g = vi - (double)p; }
+    if (n <= 0) p = 0;
+    int rank = p, left = n;                                  // left: keys of the ray under the prefix found so far
+    unsigned phi = 0u, plo = 0u;                             // the key's bits found so far
+    // ---- sixteen digit passes: HI selects the word the digit lies in (static per unrolled body, uniform per pass)
+    // (the excluded key - all ones - is counted like any other: it is the LARGEST key, so it never moves the bin that holds a
+    //  rank below n; leaving its test out saves two of ten instructions per key and pass)
+    auto pass = [&](auto hi_c, const int shift) {           // shift: bit offset of the digit inside its word
+        constexpr bool HI = decltype(hi_c)::value;
+        const unsigned above = shift >= 28 ? 0u : (0xffffffffu << (shift + 4));       // the bits of this word above the digit
+        const unsigned pre = (HI ? phi : plo) & above;
+        unsigned long long c4 = 0ull, ev = 0ull, od = 0ull;  // sixteen 4-bit counters; 8-bit counters of the even / odd bins
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const unsigned w = HI ? khi[i] : klo[i];
+            bool m = (w & above) == pre;
+            if (!HI) m = m && (khi[i] == phi);
+            const unsigned b4 = __builtin_amdgcn_ubfe(w, (unsigned)shift, 4u) << 2;
+            c4 += (unsigned long long)(m ? 1u : 0u) << b4;
+            if ((i % 15) == 14 || i == KPL - 1) {            // a 4-bit counter holds 15
+                ev += c4 & 0x0f0f0f0f0f0f0f0full;
+                od += (c4 >> 4) & 0x0f0f0f0f0f0f0f0full;
+                c4 = 0ull;
+            }
+        }
+        // the ray's totals: 16-bit fields (<= 1024 keys per ray) summed over the row.  word[h][g] with h = even / odd bins,
+        // g = 0 .. 3: fields (bits 0-15, bits 16-31) = 8-bit fields (f, f + 2) of the h-counters' word (g >> 1), f = g & 1
+        unsigned tw[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned long long src = h ? od : ev;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned word = (unsigned)(src >> (32 * (g >> 1)));
+                tw[h][g] = row_sum_u32<LPR>((word >> (8 * (g & 1))) & 0x00ff00ffu);
+            }
+        }
+        unsigned digit = 15u;
+        bool found = false;
+        left = 0;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            // bin b = 8-bit field f = b >> 1 of the (b & 1)-counters: word f >> 2, field f & 3 = (f & 1) + 2 * ((f >> 1) & 1)
+            constexpr int dummy = 0; (void)dummy;
+            const int f = b >> 1, g = 2 * (f >> 2) + (f & 1), half = (f >> 1) & 1;
+            const int cb = (int)((tw[b & 1][g] >> (16 * half)) & 0xffffu);
+            const bool here = !found && rank < cb;
+            left = here ? cb : left;
+            digit = here ? (unsigned)b : digit;
+            rank = (found || here) ? rank : rank - cb;
+            found = found || here;
+        }
+        if (HI) phi |= digit << shift; else plo |= digit << shift;
+    };
+    // The descent stops as soon as every ray of the wave has ONE key left under its prefix (distinct samples: after nine or ten
+    // of the sixteen passes): that key is the smallest - the only - key of the row that matches the prefix.
+    int stop_hi = -1, stop_lo = -1;                          // the shift of the last pass made in either word (-1: none)
+    for (int shift = 28; shift >= 0; shift -= 4) {
+        pass(std::integral_constant<bool, true>{}, shift);
+        stop_hi = shift;
+        if (__all(left <= 1)) break;
+    }
+    if (!__all(left <= 1)) {
+        for (int shift = 28; shift >= 0; shift -= 4) {
+            pass(std::integral_constant<bool, false>{}, shift);
+            stop_lo = shift;
+            if (__all(left <= 1)) break;
+        }
+    }
+    if (stop_lo != 0) {                                      // stopped early: pick the one key that is left up
+        const unsigned mh = stop_lo >= 0 ? 0xffffffffu : (0xffffffffu << stop_hi);
+        const unsigned ml = stop_lo >= 0 ? (0xffffffffu << stop_lo) : 0u;
+        unsigned long long cand = kExcl;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const bool mt = ((khi[i] & mh) == phi) && ((klo[i] & ml) == plo);
+            const unsigned long long k = ((unsigned long long)khi[i] << 32) | klo[i];
+            cand = (mt && k < cand) ? k : cand;
+        }
+        cand = row_min_u64<LPR>(cand);
+        if (left == 1) { phi = (unsigned)(cand >> 32); plo = (unsigned)cand; }   // (a ray with duplicates left ran all sixteen passes)
+    }
+    // ---- keys <= the one found, and the smallest key above it
+    const unsigned long long kfound = ((unsigned long long)phi << 32) | plo;
+    unsigned le = 0;
+    unsigned long long nxt = kExcl;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const unsigned long long k = ((unsigned long long)khi[i] << 32) | klo[i];
+        le += (k <= kfound) ? 1u : 0u;
+        nxt = (k > kfound && k < nxt) ? k : nxt;
+    }
+    le = row_sum_u32<LPR>(le);
+    nxt = row_min_u64<LPR>(nxt);
+    if (sl == 0 && col_in) {
+        double res = NAN;
+        if (n > 0) {
+            const int p1 = min(p + 1, n - 1);
+            const unsigned long long kh = (p1 == p || p1 < (int)le) ? kfound : nxt;
+            const double va = funkey64(kfound), vb = funkey64(kh);
+            if (A.q == 50.0) res = (n & 1) ? va : 0.5 * (va + vb);
+            else { const double d = vb - va; res = g >= 0.5 ? __dsub_rn(vb, __dmul_rn(d, 1.0 - g)) : __dadd_rn(va, __dmul_rn(d, g)); }
+        }
+        A.out[y * A.c.nx + x] = res * A.scale;
+    }
+}
+
 static int sort64_launch(Sort64Args& A, const spc_cube_f64* cube, bool clip, hipStream_t st) {
     if (cube->nz > 4096) {
         spc_set_error("rays of more than 4096 samples have no float64 order statistics (got %lld)", (long long)cube->nz);
@@ -905,6 +1097,20 @@ static int sort64_launch(Sort64Args& A, const spc_cube_f64* cube, bool clip, hip
     A.nzp = nzp; A.ts = sel ? std::min(kSelRays64, kSelKeys64 / nzp) : std::min(64, kSortKeys / nzp);
     const int64_t nb = ((cube->nx + A.ts - 1) / A.ts) * cube->ny;
     SPC_REQUIRE(nb < (1LL << 31), "map too large for one launch");
+    // (SPC_SELECT64 = 2, the default: rays of up to 1024 samples keep their keys in registers; 1: the keys in LDS for every length)
+    static const int radix_form = [] { const char* e = getenv("SPC_SELECT64"); return e ? atoi(e) : 2; }();
+    if (sel && radix_form >= 2 && cube->nz <= 1024) {
+        const int64_t nbr = ((cube->nx + 15) / 16) * cube->ny;
+        SPC_REQUIRE(nbr < (1LL << 31), "map too large for one launch");
+        const int kpl = (int)((cube->nz + 15) / 16);
+        dim3 grid((unsigned)nbr);
+        if (kpl <= 8) hipLaunchKernelGGL((select64_reg_kernel<8, 16>), grid, dim3(256), 0, st, A);
+        else if (kpl <= 16) hipLaunchKernelGGL((select64_reg_kernel<16, 16>), grid, dim3(256), 0, st, A);
+        else if (kpl <= 32) hipLaunchKernelGGL((select64_reg_kernel<32, 16>), grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((select64_reg_kernel<32, 32>), grid, dim3(512), 0, st, A);      // 32 lanes per ray, 32 keys per lane
+        SPC_LAUNCH_CHECK();
+        return SPC_OK;
+    }
     if (clip) hipLaunchKernelGGL(sort64_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, A);
     else if (sel) hipLaunchKernelGGL(select64_kernel, dim3((unsigned)nb), dim3(256), 0, st, A);
     else hipLaunchKernelGGL(sort64_kernel<0>, dim3((unsigned)nb), dim3(256), 0, st, A);
