@@ -1172,7 +1172,7 @@ def wide_records(device, scale=1):
     exp = O.sigma_clip(tile, inc, 3.0, out_dtype=np.float64)
     assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.array_equal(got[~np.isnan(exp)], exp[~np.isnan(exp)]), "float64 sigma clip vs oracle"
     keep.clear()
-    recs.append(cfg_record("w_clip_f64", A_CLIP.replace("f32", "f64"), "float64 sigma_clip_spectrally(3), astropy defaults, 512x1024x1024 f64 + uint8 mask", "sort64_kernel<1>", ms,
+    recs.append(cfg_record("w_clip_f64", A_CLIP.replace("f32", "f64"), "float64 sigma_clip_spectrally(3), astropy defaults, 512x1024x1024 f64 + uint8 mask", "sigma_clip64_reg_kernel<32,16> (keys in registers, 16 lanes per ray = one DPP row)", ms,
                            vox * 17, vox, {"rows_checked": TR, "clipped_set_and_kept_values": "identical to the oracle"}, "8 + 1 read, 8 written per voxel"))
     for r in recs:
         r["mask_valid_fraction"] = float(inc.mean())

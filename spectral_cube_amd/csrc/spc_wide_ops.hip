@@ -933,20 +933,14 @@ __device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v) 
     }
     return v;
 }
+// the one read of the cube: lane (ray, slice s) takes the samples z = s + LPR i of its ray as order-preserving keys (hi / lo words);
+// excluded, NaN and out-of-range samples become the all-ones key, which no valid sample maps to and which sorts last
 template <int KPL, int LPR>
-__global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args A) {
-    constexpr int RW = 64 / LPR;                             // rays per wave
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, rr = lane / LPR, sl = lane % LPR;
-    const int64_t tiles_x = (A.c.nx + 15) / 16;
-    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * 16;
-    const int64_t x = x0 + RW * wave + rr;
-    const bool col_in = x < A.c.nx;
-    const int64_t xc = col_in ? x : A.c.nx - 1;
+__device__ __forceinline__ void row_load_keys(const Sort64Args& A, int64_t y, int64_t xc, bool col_in, int sl, double cen,
+                                              unsigned (&khi)[KPL], unsigned (&klo)[KPL]) {
     const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
     const double* pd = A.c.p + y * A.c.row_stride + xc;
     const uint8_t* pmk = arr ? A.m.arr + y * A.m.row_stride + xc : nullptr;
-    const double cen = A.center ? A.center[y * A.c.nx + xc] : 0.0;
-    unsigned khi[KPL], klo[KPL];
     constexpr int CH = KPL < 16 ? KPL : 16;                  // samples requested together per lane (all 64 at once: 128 registers of loads in flight)
 #pragma unroll
     for (int i0 = 0; i0 < KPL; i0 += CH) {
@@ -969,21 +963,18 @@ __global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // valid samples of the ray, and the rank of the lower order statistic (numpy's rule)
-    unsigned nloc = 0;
-#pragma unroll
-    for (int i = 0; i < KPL; ++i) nloc += ((khi[i] & klo[i]) != 0xffffffffu) ? 1u : 0u;      // (valid keys never are all ones)
-    const int n = (int)row_sum_u32<LPR>(nloc);
-    int p = 0;
-    double g = 0.0;
-    if (A.q == 50.0) { p = (n - 1) / 2; g = (n & 1) ? 0.0 : 0.5; }
-    else { const double vi = A.q / 100.0 * (double)(n - 1); p = min(max((int)floor(vi), 0), max(n - 1, 0)); g = vi - (double)p; }
-    if (n <= 0) p = 0;
-    int rank = p, left = n;                                  // left: keys of the ray under the prefix found so far
+}
+
+// the key of 0-based rank `rank` (< n = the ray's valid keys) among the keys of the row's lanes: sixteen digit passes, HI selects
+// the word the digit lies in (static per unrolled body, uniform per pass).  The excluded key - all ones - is counted like any
+// other: it is the LARGEST key, so it never moves the bin that holds a rank below n (leaving its test out saves two of ten
+// instructions per key and pass).  The descent stops as soon as every ray of the wave has ONE key left under its prefix
+// (distinct samples: after nine or ten of the sixteen passes): that key is the smallest - the only - key of the row that
+// matches the prefix.  All lanes of the wave call it (wave-uniform control flow); every lane of a row gets the row's key.
+template <int KPL, int LPR>
+__device__ __forceinline__ unsigned long long row_descend(const unsigned (&khi)[KPL], const unsigned (&klo)[KPL], int rank, int n) {
+    int left = n;                                            // keys of the ray under the prefix found so far
     unsigned phi = 0u, plo = 0u;                             // the key's bits found so far
-    // ---- sixteen digit passes: HI selects the word the digit lies in (static per unrolled body, uniform per pass)
-    // (the excluded key - all ones - is counted like any other: it is the LARGEST key, so it never moves the bin that holds a
-    //  rank below n; leaving its test out saves two of ten instructions per key and pass)
     auto pass = [&](auto hi_c, const int shift) {           // shift: bit offset of the digit inside its word
         constexpr bool HI = decltype(hi_c)::value;
         const unsigned above = shift >= 28 ? 0u : (0xffffffffu << (shift + 4));       // the bits of this word above the digit
@@ -1020,7 +1011,6 @@ __global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             // bin b = 8-bit field f = b >> 1 of the (b & 1)-counters: word f >> 2, field f & 3 = (f & 1) + 2 * ((f >> 1) & 1)
-            constexpr int dummy = 0; (void)dummy;
             const int f = b >> 1, g = 2 * (f >> 2) + (f & 1), half = (f >> 1) & 1;
             const int cb = (int)((tw[b & 1][g] >> (16 * half)) & 0xffffu);
             const bool here = !found && rank < cb;
@@ -1031,8 +1021,6 @@ __global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args
         }
         if (HI) phi |= digit << shift; else plo |= digit << shift;
     };
-    // The descent stops as soon as every ray of the wave has ONE key left under its prefix (distinct samples: after nine or ten
-    // of the sixteen passes): that key is the smallest - the only - key of the row that matches the prefix.
     int stop_hi = -1, stop_lo = -1;                          // the shift of the last pass made in either word (-1: none)
     for (int shift = 28; shift >= 0; shift -= 4) {
         pass(std::integral_constant<bool, true>{}, shift);
@@ -1059,18 +1047,55 @@ __global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args
         cand = row_min_u64<LPR>(cand);
         if (left == 1) { phi = (unsigned)(cand >> 32); plo = (unsigned)cand; }   // (a ray with duplicates left ran all sixteen passes)
     }
-    // ---- keys <= the one found, and the smallest key above it
-    const unsigned long long kfound = ((unsigned long long)phi << 32) | plo;
-    unsigned le = 0;
-    unsigned long long nxt = kExcl;
+    return ((unsigned long long)phi << 32) | plo;
+}
+
+// keys <= the one found, and the smallest key above it (the upper order statistic of numpy's rule is one or the other)
+template <int KPL, int LPR>
+__device__ __forceinline__ void row_le_next(const unsigned (&khi)[KPL], const unsigned (&klo)[KPL], unsigned long long kfound,
+                                            unsigned& le, unsigned long long& nxt) {
+    unsigned l = 0;
+    unsigned long long nx = kExcl;
 #pragma unroll
     for (int i = 0; i < KPL; ++i) {
         const unsigned long long k = ((unsigned long long)khi[i] << 32) | klo[i];
-        le += (k <= kfound) ? 1u : 0u;
-        nxt = (k > kfound && k < nxt) ? k : nxt;
+        l += (k <= kfound) ? 1u : 0u;
+        nx = (k > kfound && k < nx) ? k : nx;
     }
-    le = row_sum_u32<LPR>(le);
-    nxt = row_min_u64<LPR>(nxt);
+    le = row_sum_u32<LPR>(l);
+    nxt = row_min_u64<LPR>(nx);
+}
+template <int KPL, int LPR>
+__device__ __forceinline__ int row_count_valid(const unsigned (&khi)[KPL], const unsigned (&klo)[KPL]) {
+    unsigned nloc = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) nloc += ((khi[i] & klo[i]) != 0xffffffffu) ? 1u : 0u;      // (valid keys never are all ones)
+    return (int)row_sum_u32<LPR>(nloc);
+}
+
+template <int KPL, int LPR>
+__global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args A) {
+    constexpr int RW = 64 / LPR;                             // rays per wave
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, rr = lane / LPR, sl = lane % LPR;
+    const int64_t tiles_x = (A.c.nx + 15) / 16;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * 16;
+    const int64_t x = x0 + RW * wave + rr;
+    const bool col_in = x < A.c.nx;
+    const int64_t xc = col_in ? x : A.c.nx - 1;
+    const double cen = A.center ? A.center[y * A.c.nx + xc] : 0.0;
+    unsigned khi[KPL], klo[KPL];
+    row_load_keys<KPL, LPR>(A, y, xc, col_in, sl, cen, khi, klo);
+    // valid samples of the ray, and the rank of the lower order statistic (numpy's rule)
+    const int n = row_count_valid<KPL, LPR>(khi, klo);
+    int p = 0;
+    double g = 0.0;
+    if (A.q == 50.0) { p = (n - 1) / 2; g = (n & 1) ? 0.0 : 0.5; }
+    else { const double vi = A.q / 100.0 * (double)(n - 1); p = min(max((int)floor(vi), 0), max(n - 1, 0)); g = vi - (double)p; }
+    if (n <= 0) p = 0;
+    const unsigned long long kfound = row_descend<KPL, LPR>(khi, klo, p, n);
+    unsigned le;
+    unsigned long long nxt;
+    row_le_next<KPL, LPR>(khi, klo, kfound, le, nxt);
     if (sl == 0 && col_in) {
         double res = NAN;
         if (n > 0) {
@@ -1081,6 +1106,90 @@ __global__ __launch_bounds__(16 * LPR) void select64_reg_kernel(const Sort64Args
             else { const double d = vb - va; res = g >= 0.5 ? __dsub_rn(vb, __dmul_rn(d, 1.0 - g)) : __dadd_rn(va, __dmul_rn(d, g)); }
         }
         A.out[y * A.c.nx + x] = res * A.scale;
+    }
+}
+
+// sigma_clip_spectrally on the same resident keys (centre = median | mean, spread = std): an iteration is the window's count, its
+// mean and its sum of squared deviations (float64 lane partials added over the row in a fixed order: the result does not depend
+// on scheduling), the median by row_descend, astropy's bounds; a clipped sample's key becomes the excluded key.  A wave iterates
+// until none of ITS rays changes (a converged ray recomputes the same bounds and clips nothing) or maxiters is reached.
+template <int LPR>
+__device__ __forceinline__ double row_sum_f64(double v) {
+#pragma unroll
+    for (int n = 8; n >= 1; n >>= 1) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        const unsigned lo = row_ror_u32((unsigned)u, n), hi = row_ror_u32((unsigned)(u >> 32), n);
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    if (LPR == 32) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        v += __longlong_as_double((long long)(((unsigned long long)swap16_u32((unsigned)(u >> 32)) << 32) | swap16_u32((unsigned)u)));
+    }
+    return v;
+}
+template <int KPL, int LPR>
+__global__ __launch_bounds__(16 * LPR) void sigma_clip64_reg_kernel(const Sort64Args A) {
+    constexpr int RW = 64 / LPR;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, rr = lane / LPR, sl = lane % LPR;
+    const int64_t tiles_x = (A.c.nx + 15) / 16;
+    const int64_t y = blockIdx.x / tiles_x, x0 = (blockIdx.x % tiles_x) * 16;
+    const int64_t x = x0 + RW * wave + rr;
+    const bool col_in = x < A.c.nx;
+    const int64_t xc = col_in ? x : A.c.nx - 1;
+    unsigned khi[KPL], klo[KPL];
+    row_load_keys<KPL, LPR>(A, y, xc, col_in, sl, 0.0, khi, klo);
+    int it = 0;
+    for (;;) {
+        if (!(A.maxiters < 0 || it < A.maxiters)) break;     // (uniform)
+        ++it;
+        const int cnt = row_count_valid<KPL, LPR>(khi, klo);
+        double sum = 0.0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const unsigned long long k = ((unsigned long long)khi[i] << 32) | klo[i];
+            sum += (k != kExcl) ? funkey64(k) : 0.0;
+        }
+        const double mean = row_sum_f64<LPR>(sum) / (double)cnt;
+        double ss = 0.0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const unsigned long long k = ((unsigned long long)khi[i] << 32) | klo[i];
+            const double dv = funkey64(k) - mean;
+            ss = (k != kExcl) ? fma(dv, dv, ss) : ss;
+        }
+        const double sd = sqrt(row_sum_f64<LPR>(ss) / (double)cnt);
+        double c = mean;
+        if (!A.cen_mean) {                                   // (uniform)
+            const int p = max((cnt - 1) / 2, 0);
+            const unsigned long long kf = row_descend<KPL, LPR>(khi, klo, p, cnt);
+            unsigned le;
+            unsigned long long nxt;
+            row_le_next<KPL, LPR>(khi, klo, kf, le, nxt);
+            const unsigned long long kh = ((cnt & 1) || p + 1 < (int)le) ? kf : nxt;
+            c = (cnt & 1) ? funkey64(kf) : 0.5 * (funkey64(kf) + funkey64(kh));
+        }
+        const double lob = c - A.lo_s * sd, hib = c + A.hi_s * sd;
+        unsigned changed = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const unsigned long long k = ((unsigned long long)khi[i] << 32) | klo[i];
+            const double v = funkey64(k);
+            // (a NaN bound - an infinite sample in the window - clips nothing: the comparisons are false, as numpy's)
+            const bool out = (k != kExcl) && (cnt > 0) && ((v < lob) || (v > hib));
+            khi[i] = out ? 0xffffffffu : khi[i]; klo[i] = out ? 0xffffffffu : klo[i];
+            changed |= out ? 1u : 0u;
+        }
+        if (!__any(changed != 0u)) break;                    // none of this wave's rays changed
+    }
+    if (col_in) {
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int z = sl + LPR * i;
+            if (z < A.c.nz) {
+                const unsigned long long k = ((unsigned long long)khi[i] << 32) | klo[i];
+                A.out[((int64_t)z * A.c.ny + y) * A.c.nx + x] = (k != kExcl) ? funkey64(k) : NAN;
+            }
+        }
     }
 }
 
@@ -1099,6 +1208,18 @@ static int sort64_launch(Sort64Args& A, const spc_cube_f64* cube, bool clip, hip
     SPC_REQUIRE(nb < (1LL << 31), "map too large for one launch");
     // (SPC_SELECT64 = 2, the default: rays of up to 1024 samples keep their keys in registers; 1: the keys in LDS for every length)
     static const int radix_form = [] { const char* e = getenv("SPC_SELECT64"); return e ? atoi(e) : 2; }();
+    if (clip && radix_form >= 2 && cube->nz <= 1024 && !A.spread_mad) {      // (stdfunc = mad_std: a second descent over |x - median| - the sorted form below)
+        const int64_t nbr = ((cube->nx + 15) / 16) * cube->ny;
+        SPC_REQUIRE(nbr < (1LL << 31), "map too large for one launch");
+        const int kpl = (int)((cube->nz + 15) / 16);
+        dim3 grid((unsigned)nbr);
+        if (kpl <= 8) hipLaunchKernelGGL((sigma_clip64_reg_kernel<8, 16>), grid, dim3(256), 0, st, A);
+        else if (kpl <= 16) hipLaunchKernelGGL((sigma_clip64_reg_kernel<16, 16>), grid, dim3(256), 0, st, A);
+        else if (kpl <= 32) hipLaunchKernelGGL((sigma_clip64_reg_kernel<32, 16>), grid, dim3(256), 0, st, A);
+        else hipLaunchKernelGGL((sigma_clip64_reg_kernel<32, 32>), grid, dim3(512), 0, st, A);
+        SPC_LAUNCH_CHECK();
+        return SPC_OK;
+    }
     if (sel && radix_form >= 2 && cube->nz <= 1024) {
         const int64_t nbr = ((cube->nx + 15) / 16) * cube->ny;
         SPC_REQUIRE(nbr < (1LL << 31), "map too large for one launch");

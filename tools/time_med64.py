@@ -20,3 +20,10 @@ def timeit(fn, n=5):
     return float(np.median(ts))
 t = timeit(lambda: ops.percentile_axis0_f64(cube, 50.0, mask=ms))
 print("SPC_SELECT64=%s nz=%d: median f64 %.3f ms = %.0f GB/s algorithmic" % (os.environ.get("SPC_SELECT64", "default"), nz, t, nz * 1024 * 1024 * 9 / t / 1e6))
+if nz <= 1024:
+    keep = {}
+    def clip():
+        keep["r"] = None
+        keep["r"] = ops.sigma_clip_axis0_f64(cube, sigma=3.0, mask=ms)
+    t = timeit(clip, n=3)
+    print("SPC_SELECT64=%s nz=%d: sigma_clip f64 %.3f ms = %.0f GB/s algorithmic" % (os.environ.get("SPC_SELECT64", "default"), nz, t, nz * 1024 * 1024 * 17 / t / 1e6))
