@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -257,8 +258,10 @@ struct Sp64Args {
     int nky, nkx;
     double* tmp;                            // (planes, ny, nx, 2) of the slab
     int64_t z0;                             // first plane of the slab
+    const unsigned* gate;                   // != nullptr: run only when the word is set (the ring kernel met an infinite valid sample)
 };
 __global__ __launch_bounds__(256) void spatial64_xpass_kernel(const Sp64Args A) {
+    if (A.gate && *A.gate == 0u) return;
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t y = blockIdx.y, zl = blockIdx.z, z = A.z0 + zl;
     if (x >= A.c.nx) return;
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(256) void spatial64_xpass_kernel(const Sp64Args A) 
     t[0] = num; t[1] = den;
 }
 __global__ __launch_bounds__(256) void spatial64_ypass_kernel(const Sp64Args A) {
+    if (A.gate && *A.gate == 0u) return;
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t y = blockIdx.y, zl = blockIdx.z, z = A.z0 + zl;
     if (x >= A.c.nx) return;
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256) void spatial64_ypass_kernel(const Sp64Args A) 
 // (464 bytes of L2 traffic per output otherwise).  Same arithmetic, same order.
 constexpr int kSpHaloMax = 511, kSpYRows = 16, kSpYHalo = 23;     // (y tiles of up to 62 rows x 64 columns x 16 bytes = 62 KB of dynamic LDS + the taps: inside the 64 KB a launch gets without hipFuncSetAttribute; 49 y taps and more take the untiled pass)
 __global__ __launch_bounds__(256) void spatial64_xpass_lds_kernel(const Sp64Args A) {
+    if (A.gate && *A.gate == 0u) return;
     __shared__ double sv[256 + 2 * kSpHaloMax];
     __shared__ float sw[256 + 2 * kSpHaloMax];
     __shared__ double sk[2 * kSpHaloMax + 1];                   // the flipped taps (a scalar load per tap waited out its latency in every lane's loop)
@@ -361,6 +366,7 @@ __global__ __launch_bounds__(256) void spatial64_xpass_lds_kernel(const Sp64Args
     o[0] = num; o[1] = den;
 }
 __global__ __launch_bounds__(256) void spatial64_ypass_lds_kernel(const Sp64Args A) {
+    if (A.gate && *A.gate == 0u) return;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     extern __shared__ f64x2 tile[];                              // (kSpYRows + 2 H) x 64 pairs: sized by the launch
     __shared__ double sk[2 * kSpYHalo + 1];
@@ -410,6 +416,7 @@ __global__ __launch_bounds__(256) void spatial64_ypass_lds_kernel(const Sp64Args
 constexpr int kSpX4Halo = 127, kSpX4Out = 1024;
 __device__ __forceinline__ int sp64_skew(int s) { return s + (s >> 2); }
 __global__ __launch_bounds__(256) void spatial64_xpass_lds4_kernel(const Sp64Args A) {
+    if (A.gate && *A.gate == 0u) return;
     constexpr int N = kSpX4Out + 2 * kSpX4Halo + 4;
     __shared__ double sv[N + N / 4 + 1];
     __shared__ float sw[N + N / 4 + 1];
@@ -448,6 +455,7 @@ __global__ __launch_bounds__(256) void spatial64_xpass_lds4_kernel(const Sp64Arg
 }
 // y pass: the tile of kSpYRows + 2 H rows x 64 columns as before; thread (column, row group) takes the rows 4 g .. 4 g + 3
 __global__ __launch_bounds__(256) void spatial64_ypass_lds4_kernel(const Sp64Args A) {
+    if (A.gate && *A.gate == 0u) return;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     extern __shared__ f64x2 tile[];                              // (kSpYRows + 2 H) x 64 pairs: sized by the launch
     __shared__ double sk[2 * kSpYHalo + 1];
@@ -494,6 +502,157 @@ __global__ __launch_bounds__(256) void spatial64_ypass_lds4_kernel(const Sp64Arg
         A.out[z * A.out_plane_stride + y * A.out_row_stride + x] = res;
     }
 }
+// Third form (round 6): ONE kernel, nothing between the passes.  A block = one plane x a strip of 256 columns x a band of rows;
+// it marches DOWN the band: a row segment (256 + 2 H columns) is classified once into LDS as (valid ? sample : 0, validity)
+// pairs, every thread gathers the x pass of ITS column from there (R reads of 16 bytes, 2 R float64 FMAs, taps in scalar
+// registers), and the y pass runs in SCATTER form on registers: the R outputs the new row still contributes to live in R
+// (numerator, denominator) accumulator pairs that move down one place per row - acc[r] = fma(k[r], X, acc[r + 1]) accumulates
+// AND shifts, no copies - so that acc[0] is the output that has just seen its last row.  The cube is read once and written
+// once (the two-pass forms above move another 32 bytes per voxel through the workspace and re-read the y halo of every
+// 16-row tile: traffic x2.9 of the algorithmic bytes).  Every output adds its taps in the order of the passes above (x taps
+// ascending, then rows ascending): the same float64 values.  Symmetric kernels of up to R taps per axis (zero-padded to R;
+// 17 distinct taps per axis fit the scalar registers, 33 would not); a padded tap times an INFINITE valid sample would be NaN
+// where the passes above skip zero taps, so a block that meets one (only possible when the mask admits infinities) raises
+// a flag and the two-pass kernels - launched behind it, retiring at once while the flag is clear - redo the call.
+template <int R>
+struct Ring64Args {
+    Cube64 c;
+    MaskDev64 m;
+    double* out;
+    int64_t out_row_stride, out_plane_stride;
+    double ky[R / 2 + 1], kx[R / 2 + 1];    // k'[i] = k'[R - 1 - i], i = 0 .. R / 2: the taps centred in R entries
+    double ksx;                             // the x taps' sum: what a row outside the image (valid zeros) gives
+    int nstrips, nbands, band_rows;
+    unsigned* flag;                         // != nullptr: the mask admits infinite samples
+};
+template <int R>
+__global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args<R> A) {
+    constexpr int H = R / 2, W = 256, NS = W + 2 * H;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ f64x2 buf[2][NS];
+    const int t = threadIdx.x;
+    int64_t b = blockIdx.x;                                  // strips fastest: x neighbours (2 H shared columns) run side by side
+    const int strip = (int)(b % A.nstrips); b /= A.nstrips;
+    const int band = (int)(b % A.nbands);
+    const int64_t z = b / A.nbands;
+    const int nx = (int)A.c.nx, ny = (int)A.c.ny;            // (ny <= 65535 and nx < 2^31: checked by the entry point)
+    const int x0 = strip * W;
+    const int ya = band * A.band_rows, yb = min(ya + A.band_rows, ny);
+    const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
+    const bool second = t < 2 * H;                           // this thread also stages element W + t
+    const int c0 = x0 - H + t, c1 = c0 + W;
+    const bool in0 = c0 >= 0 && c0 < nx, in1 = c1 < nx;
+    const unsigned cc0 = (unsigned)min(max(c0, 0), nx - 1), cc1 = (unsigned)min(c1, nx - 1);
+    const double* pd = A.c.p + z * A.c.plane_stride;
+    const uint8_t* pm = arr ? A.m.arr + z * A.m.plane_stride : nullptr;
+    // the ring: logical place r of the row with phase q (= row mod U inside an unrolled group of U rows) is the register pair
+    // q + r, so that a row accumulates IN PLACE (v_fmac_f64) and the places move down by U registers once per U rows
+    // (64 / U v_mov_b64 per row; a place that moves down every row costs 66, or hand-written three-address FMAs the register
+    // allocator answers with scratch)
+    constexpr int U = 4, NR = R + U - 1;
+    double sn[NR], sd[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { sn[r] = 0.0; sd[r] = 0.0; }
+    double r0 = 0.0, r1 = 0.0;
+    unsigned m0 = 1u, m1 = 1u;
+    auto load_row = [&](int u) {                             // (a uniform row pointer + a 32-bit lane offset)
+        const double* q = pd + (int64_t)u * A.c.row_stride;
+        r0 = q[cc0];
+        if (second) r1 = q[cc1];
+        if (arr) {
+            const uint8_t* qm = pm + (int64_t)u * A.m.row_stride;
+            m0 = qm[cc0];
+            if (second) m1 = qm[cc1];
+        }
+    };
+    const int u_begin = ya - H, u_end = yb + H;
+    if (u_begin >= 0) load_row(u_begin);
+    bool seen_inf = false;
+    const int x = x0 + t;
+    double* po = A.out + z * A.out_plane_stride + x;
+    // Software pipeline: the step of row u stages row u, runs the y pass of row u - 1 (Xpn, Xpd: registers only), then the
+    // x pass of row u from LDS.  A row outside the image is staged as valid zeros (its x pass gives (0, sum of the x taps)
+    // like any other row: one code path); the march runs on to a multiple of U rows past the band (nothing is stored there).
+    double Xpn = 0.0, Xpd = 0.0;                             // (before the first row: zeros into an empty ring)
+    auto row_step = [&](auto phase, const int u) {
+        constexpr int Q = decltype(phase)::value;
+        const bool next_in = u + 1 >= 0 && u + 1 < ny;
+        const bool row_in = u >= 0 && u < ny;                // (uniform)
+        f64x2* const Bw = buf[Q & 1];                        // (U is even: the buffer is the phase's parity)
+        {
+            const bool ok = pred64(A.m, r0) && m0 != 0u;
+            Bw[t] = (in0 && row_in) ? (ok ? f64x2{r0, 1.0} : f64x2{0.0, 0.0}) : f64x2{0.0, 1.0};      // outside the image: a valid zero
+            if (A.flag) seen_inf = seen_inf || (ok && in0 && row_in && fabs(r0) == INFINITY);
+        }
+        if (second) {
+            const bool ok = pred64(A.m, r1) && m1 != 0u;
+            Bw[W + t] = (in1 && row_in) ? (ok ? f64x2{r1, 1.0} : f64x2{0.0, 0.0}) : f64x2{0.0, 1.0};
+            if (A.flag) seen_inf = seen_inf || (ok && in1 && row_in && fabs(r1) == INFINITY);
+        }
+        if (next_in) load_row(u + 1);                        // in flight under this row's arithmetic
+        // (one barrier per row: a buffer is written again two rows later, behind the barrier of the row in between)
+        __syncthreads();
+        // y pass of row u - 1: place r takes tap R - 1 - r (symmetric: tap r); place 0 has then seen its last row
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double kk = A.ky[r <= H ? r : R - 1 - r];
+            sn[Q + r] = fma(kk, Xpn, sn[Q + r]);
+            sd[Q + r] = fma(kk, Xpd, sd[Q + r]);
+        }
+        const int y = u - 1 - H;
+        if (y >= ya && y < yb && x < nx) {
+            double res;
+            if (sd[Q] != 0.0) res = sn[Q] / sd[Q];
+            else { double cv; res = inc64(A.c, A.m, z, y, x, cv) ? cv : NAN; }
+            po[(int64_t)y * A.out_row_stride] = res;
+        }
+        // x pass of row u.  Left alone the compiler asks for all R pairs at once - 132 registers beside the ring's 144 - and
+        // sends a part of the ring to scratch (a sched_barrier does not hold the reads back: they are hoisted before the
+        // machine scheduler runs).  The reads of a group's slots therefore go through a pointer that an empty asm statement
+        // "redefines" together with the running sum: they cannot move above the FMAs that emptied their slots.
+        constexpr int kD = 8, kG = 4;                        // pairs in flight, taps per group
+        typedef const f64x2 __attribute__((address_space(3)))* lds_pairs;
+        lds_pairs Bp = (lds_pairs)(Bw + t);
+        double Xn = 0.0, Xd = 0.0;
+        f64x2 sq[kD];
+#pragma unroll
+        for (int j = 0; j < kD; ++j) sq[j] = Bp[j];
+#pragma unroll
+        for (int g = 0; g * kG < R; ++g) {
+#pragma unroll
+            for (int q = 0; q < kG; ++q) {
+                const int j = g * kG + q;
+                if (j < R) {
+                    const double kk = A.kx[j <= H ? j : R - 1 - j];
+                    Xn = fma(kk, sq[j % kD].x, Xn);
+                    Xd = fma(kk, sq[j % kD].y, Xd);
+                }
+            }
+            asm volatile("" : "+v"(Bp), "+v"(Xn), "+v"(Xd));
+#pragma unroll
+            for (int q = 0; q < kG; ++q) {
+                const int j = g * kG + q;
+                if (j + kD < R) sq[j % kD] = Bp[j + kD];
+            }
+        }
+        Xpn = Xn; Xpd = Xd;
+    };
+    static_assert(U == 4, "four phases written out");
+    for (int u0 = u_begin; u0 <= u_end; u0 += U) {
+        row_step(std::integral_constant<int, 0>{}, u0);
+        row_step(std::integral_constant<int, 1>{}, u0 + 1);
+        row_step(std::integral_constant<int, 2>{}, u0 + 2);
+        row_step(std::integral_constant<int, 3>{}, u0 + 3);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            sn[i] = i + U < NR ? sn[i + U] : 0.0;
+            sd[i] = i + U < NR ? sd[i + U] : 0.0;
+        }
+    }
+    if (A.flag && seen_inf) atomicOr(A.flag, 1u);
+}
+
+
 __global__ __launch_bounds__(256) void spatial64_direct_kernel(const Sp64Args A) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t y = blockIdx.y, z = A.z0 + blockIdx.z;
@@ -1279,6 +1438,32 @@ static int cube64_args(const spc_cube_f64* cube, const spc_mask_f64* mask, Cube6
 
 }  // namespace
 
+template <int R>
+int launch_ring64(hipStream_t st, const Sp64Args& S, const double* h_ky, int nky, const double* h_kx, int nkx, unsigned* d_flag) {
+    Ring64Args<R> A{};
+    A.c = S.c; A.m = S.m; A.out = S.out; A.out_row_stride = S.out_row_stride; A.out_plane_stride = S.out_plane_stride;
+    const int py = (R - nky) / 2, px = (R - nkx) / 2;           // the taps centred in R entries; symmetric: the first half names them all
+    for (int i = 0; i <= R / 2; ++i) {
+        A.ky[i] = (i >= py) ? h_ky[i - py] : 0.0;
+        A.kx[i] = (i >= px) ? h_kx[i - px] : 0.0;
+    }
+    double ksx = 0.0;
+    for (int j = 0; j < nkx; ++j) ksx = fma(h_kx[nkx - 1 - j], 1.0, ksx);      // the x pass of a row of valid zeros, in its order
+    A.ksx = ksx;
+    A.flag = d_flag;
+    A.nstrips = (int)((S.c.nx + 255) / 256);
+    // bands: the whole column when the planes and strips alone fill the chip, else bands of >= 64 rows (2 (R / 2) halo rows each)
+    const int64_t base = S.c.nz * A.nstrips;
+    int64_t nb = std::max<int64_t>(1, std::min<int64_t>((2048 + base - 1) / base, (S.c.ny + 63) / 64));
+    A.band_rows = (int)((S.c.ny + nb - 1) / nb);
+    A.nbands = (int)((S.c.ny + A.band_rows - 1) / A.band_rows);
+    const int64_t nblocks = base * A.nbands;
+    SPC_REQUIRE(nblocks < (1ll << 31), "too many blocks");
+    hipLaunchKernelGGL(spatial64_ring_kernel<R>, dim3((unsigned)nblocks), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
 size_t spc_ws_wide(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1) {
     switch (kind) {
         case SPC_WS_STATS_GLOBAL_F64: return spc_ws_round(sizeof(Rec64) * 4096) + spc_ws_round(5 * sizeof(double)) + 256;
@@ -1287,7 +1472,7 @@ size_t spc_ws_wide(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int
             // taps + the (num, den) planes of a slab: at most 256 MiB (the caller keeps its scratch), at least one plane
             const size_t plane = (size_t)ny * (size_t)nx * 2 * sizeof(double);
             const size_t slab = std::max<size_t>(plane, std::min<size_t>((size_t)nz * plane, (size_t)1 << 28));
-            return spc_ws_round(sizeof(double) * (size_t)(std::max<int64_t>(p0, 1) * std::max<int64_t>(p1, 1) + p0 + p1)) + spc_ws_round(slab) + 512;
+            return spc_ws_round(sizeof(double) * (size_t)(std::max<int64_t>(p0, 1) * std::max<int64_t>(p1, 1) + p0 + p1)) + spc_ws_round(slab) + 512 + 256;   // (+ the ring form's flag word)
         }
     }
     return 0;
@@ -1414,6 +1599,25 @@ int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, con
             SPC_LAUNCH_CHECK();
         }
         return SPC_OK;
+    }
+    // symmetric factors of up to 33 taps: the one-kernel ring form (SPC_SPATIAL64_RING=0: the two-pass forms)
+    static const bool ring_on = [] { const char* e = getenv("SPC_SPATIAL64_RING"); return e ? atoi(e) != 0 : true; }();
+    bool ring = ring_on && nky <= 33 && nkx <= 33;
+    for (int i = 0; ring && i < nky / 2; ++i) ring = h_ky[i] == h_ky[nky - 1 - i];
+    for (int i = 0; ring && i < nkx / 2; ++i) ring = h_kx[i] == h_kx[nkx - 1 - i];
+    A.gate = nullptr;
+    if (ring) {
+        unsigned* d_flag = nullptr;
+        if (!(A.m.flags & SPC_MASK_FINITE)) {                   // the mask admits infinite samples: see spatial64_ring_kernel
+            SPC_WS_TAKE(d_f, ws, unsigned, 64);
+            d_flag = d_f;
+            SPC_HIP(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
+        }
+        if (std::max(nky, nkx) <= 17) rc = launch_ring64<17>(st, A, h_ky, nky, h_kx, nkx, d_flag);
+        else rc = launch_ring64<33>(st, A, h_ky, nky, h_kx, nkx, d_flag);
+        if (rc) return rc;
+        if (!d_flag) return SPC_OK;
+        A.gate = d_flag;                                        // the passes below run only if the ring kernel raised the flag
     }
     const size_t plane = (size_t)cube->ny * (size_t)cube->nx * 2 * sizeof(double);
     const size_t avail = ws.size > ws.used + 512 ? ws.size - ws.used - 512 : 0;
