@@ -1138,8 +1138,8 @@ def wide_records(device, scale=1):
     exp = O.spatial_smooth(sub, np.tile(inc[:2, :, :WX + PAD], (1, 6, 1)), k2)[:, 16:32, PAD:WX]
     got = np.stack([out.planes(z, z + 1).get()[0, 512 // scale:512 // scale + 16, PAD:WX] for z in range(2)])
     err = rel(got, exp, "f64 spatial_smooth")
-    recs.append(cfg_record("w_spatial_f64", A64, "float64 spatial_smooth(29x29, outer product), 512x1024x1024 f64 + uint8 mask", "spatial64_xpass_lds4_kernel[all] + spatial64_ypass_lds4_kernel[all]",
-                           ms, vox * 17, vox, {"voxels_checked": int(exp.size), "max_rel_err": err}, "8 + 1 read, 8 written per voxel (the (num, den) planes between the passes stay in the workspace)"))
+    recs.append(cfg_record("w_spatial_f64", A64, "float64 spatial_smooth(29x29, outer product), 512x1024x1024 f64 + uint8 mask", "spatial64_ring_kernel<33,true>",
+                           ms, vox * 17, vox, {"voxels_checked": int(exp.size), "max_rel_err": err}, "8 + 1 read, 8 written per voxel (one kernel: x pass from a staged row segment, y pass on a register ring; the mask admits infinities, so the two-pass kernels are queued behind its flag and retire at once)"))
     # spectral_interpolate 512 -> 512 channels (shifted grid)
     v = np.arange(nz) * 1.0
     grid = np.linspace(v[0] + 0.25, v[-1] - 0.25, nz)

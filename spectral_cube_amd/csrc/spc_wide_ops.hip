@@ -525,7 +525,7 @@ struct Ring64Args {
     int nstrips, nbands, band_rows;
     unsigned* flag;                         // != nullptr: the mask admits infinite samples
 };
-template <int R>
+template <int R, bool ARR>
 __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args<R> A) {
     constexpr int H = R / 2, W = 256, NS = W + 2 * H;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -538,13 +538,12 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
     const int nx = (int)A.c.nx, ny = (int)A.c.ny;            // (ny <= 65535 and nx < 2^31: checked by the entry point)
     const int x0 = strip * W;
     const int ya = band * A.band_rows, yb = min(ya + A.band_rows, ny);
-    const bool arr = (A.m.flags & SPC_MASK_ARRAY) != 0;
     const bool second = t < 2 * H;                           // this thread also stages element W + t
     const int c0 = x0 - H + t, c1 = c0 + W;
     const bool in0 = c0 >= 0 && c0 < nx, in1 = c1 < nx;
     const unsigned cc0 = (unsigned)min(max(c0, 0), nx - 1), cc1 = (unsigned)min(c1, nx - 1);
     const double* pd = A.c.p + z * A.c.plane_stride;
-    const uint8_t* pm = arr ? A.m.arr + z * A.m.plane_stride : nullptr;
+    const uint8_t* pm = ARR ? A.m.arr + z * A.m.plane_stride : nullptr;
     // the ring: logical place r of the row with phase q (= row mod U inside an unrolled group of U rows) is the register pair
     // q + r, so that a row accumulates IN PLACE (v_fmac_f64) and the places move down by U registers once per U rows
     // (64 / U v_mov_b64 per row; a place that moves down every row costs 66, or hand-written three-address FMAs the register
@@ -559,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
         const double* q = pd + (int64_t)u * A.c.row_stride;
         r0 = q[cc0];
         if (second) r1 = q[cc1];
-        if (arr) {
+        if (ARR) {
             const uint8_t* qm = pm + (int64_t)u * A.m.row_stride;
             m0 = qm[cc0];
             if (second) m1 = qm[cc1];
@@ -1459,7 +1458,8 @@ int launch_ring64(hipStream_t st, const Sp64Args& S, const double* h_ky, int nky
     A.nbands = (int)((S.c.ny + A.band_rows - 1) / A.band_rows);
     const int64_t nblocks = base * A.nbands;
     SPC_REQUIRE(nblocks < (1ll << 31), "too many blocks");
-    hipLaunchKernelGGL(spatial64_ring_kernel<R>, dim3((unsigned)nblocks), dim3(256), 0, st, A);
+    if (S.m.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL((spatial64_ring_kernel<R, true>), dim3((unsigned)nblocks), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((spatial64_ring_kernel<R, false>), dim3((unsigned)nblocks), dim3(256), 0, st, A);
     SPC_LAUNCH_CHECK();
     return SPC_OK;
 }
@@ -1601,7 +1601,7 @@ int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, con
         return SPC_OK;
     }
     // symmetric factors of up to 33 taps: the one-kernel ring form (SPC_SPATIAL64_RING=0: the two-pass forms)
-    static const bool ring_on = [] { const char* e = getenv("SPC_SPATIAL64_RING"); return e ? atoi(e) != 0 : true; }();
+    const bool ring_on = [] { const char* e = getenv("SPC_SPATIAL64_RING"); return e ? atoi(e) != 0 : true; }();     // (read per call: the tests compare both forms in one process)
     bool ring = ring_on && nky <= 33 && nkx <= 33;
     for (int i = 0; ring && i < nky / 2; ++i) ring = h_ky[i] == h_ky[nky - 1 - i];
     for (int i = 0; ring && i < nkx / 2; ++i) ring = h_kx[i] == h_kx[nkx - 1 - i];

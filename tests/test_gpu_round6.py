@@ -200,6 +200,68 @@ def test_float64_spatial_smooth_four_outputs_per_thread_is_bit_identical(gpu, sh
     assert np.abs(got[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max()
 
 
+@pytest.mark.parametrize("shape, taps, flags", [((3, 300, 520), (29, 29), "array"), ((2, 700, 300), (15, 9), "array+finite"),
+                                                ((40, 66, 257), (33, 5), "finite"), ((1, 1030, 70), (1, 29), "none"),
+                                                ((2, 90, 600), (31, 31), "array")])
+def test_float64_spatial_smooth_ring_form(gpu, shape, taps, flags, monkeypatch):
+    """round 6: symmetric factors of up to 33 taps run in ONE kernel (a block marches down a band of rows: x pass gathered from a
+    staged row segment, y pass on a register ring) - every output adds its taps in the order of the two-pass forms: the same
+    float64 bits, NaN patterns included; bands of rows for cubes of few planes, strips that end inside the last 256 columns,
+    1-tap axes, every mask kind; and the oracle's values to 1e-13"""
+    rng = np.random.default_rng(sum(shape) + taps[0])
+    d = 1000.0 + 50.0 * rng.standard_normal(shape)
+    d[rng.random(shape) < 0.02] = np.nan
+    m = rng.random(shape) < 0.8
+    m[:, 20:60, 30:64] = False                                  # empty windows: NaN out
+    def g(n):
+        x = np.arange(n) - n // 2
+        w = np.exp(-0.5 * (x / max(n / 8.0, 0.5)) ** 2)
+        return w / w.sum()
+    k2 = np.outer(g(taps[0]), g(taps[1]))
+    cube = DeviceArray.from_numpy(d)
+    mk = DeviceArray.from_numpy(m.astype(np.uint8)) if "array" in flags else None
+    fl = (_lib.MASK_ARRAY if "array" in flags else 0) | (_lib.MASK_FINITE if "finite" in flags else 0)
+    spec = ops.MaskSpec(fl, array=mk) if fl else None
+    monkeypatch.setenv("SPC_SPATIAL64_RING", "1")
+    ring = ops.spatial_conv_f64(cube, k2, mask=spec).get()
+    monkeypatch.setenv("SPC_SPATIAL64_RING", "0")
+    two = ops.spatial_conv_f64(cube, k2, mask=spec).get()
+    assert np.array_equal(ring, two, equal_nan=True)
+    inc = (m if "array" in flags else np.ones(shape, bool)) & ~np.isnan(d)
+    exp = O.spatial_smooth(d, inc, k2)
+    assert np.array_equal(np.isnan(ring), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.abs(ring[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max()
+
+
+def test_float64_spatial_smooth_ring_form_hands_infinite_samples_to_the_two_pass_form(gpu, monkeypatch):
+    """the ring form pads the taps with zeros, and 0 x inf is NaN where the two-pass forms (and astropy) skip a zero tap: a block
+    that meets an infinite VALID sample raises a device flag and the two-pass kernels, queued behind it, redo the call - the
+    result is the two-pass result bit for bit; with the mask's isfinite term the sample is invalid and nothing is handed over"""
+    rng = np.random.default_rng(5)
+    shape = (3, 120, 300)
+    d = 10.0 + rng.standard_normal(shape)
+    d[1, 60, 100] = np.inf
+    d[2, 5, 290] = -np.inf
+    m = rng.random(shape) < 0.9
+    m[1, 60, 100] = m[2, 5, 290] = True
+    k2 = Gaussian2DKernel(2.0).array                            # 17 x 17 taps
+    k2p = np.zeros((21, 21)); k2p[2:-2, 2:-2] = k2               # explicit zero taps as well
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    for kern in (k2, k2p):
+        for fl in (_lib.MASK_ARRAY, _lib.MASK_ARRAY | _lib.MASK_FINITE):
+            spec = ops.MaskSpec(fl, array=mk)
+            monkeypatch.setenv("SPC_SPATIAL64_RING", "1")
+            ring = ops.spatial_conv_f64(cube, kern, mask=spec).get()
+            monkeypatch.setenv("SPC_SPATIAL64_RING", "0")
+            two = ops.spatial_conv_f64(cube, kern, mask=spec).get()
+            assert np.array_equal(ring, two, equal_nan=True)
+            if fl & _lib.MASK_FINITE:
+                assert np.isfinite(ring[1, 55:66, 95:106]).all()
+            else:
+                assert not np.isfinite(ring[1, 60, 100])
+
+
 def test_cube_level_arithmetic_of_the_masked_spatial_stencil_is_selectable(gpu, monkeypatch):
     """round-5 verdict, weak 1: which arithmetic a record was timed in has a name, and the cube-level call can ask for the
     other one: spatial_smooth(kernel, arithmetic="f32") runs the ring kernels (float32 multiply-adds, 2.5e-7 of the range),
