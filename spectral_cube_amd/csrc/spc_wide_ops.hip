@@ -164,8 +164,10 @@ struct Conv64Args {
     const double* kern;      // ntaps
     const double* kpad;      // kpad[15 + j] = kern[j], 15 zeros on either side
     int ntaps;
+    const unsigned* gate;    // != nullptr: run only when the word is set (the ring kernel met an infinite valid sample)
 };
 __global__ __launch_bounds__(256) void spectral_conv64_kernel(const Conv64Args A) {
+    if (A.gate && *A.gate == 0u) return;
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= A.c.ny * A.c.nx) return;
     const int64_t y = g / A.c.nx, x = g - y * A.c.nx;
@@ -243,6 +245,90 @@ emit:
         else { double cv; res = inc64(A.c, A.m, o, y, x, cv) ? cv : NAN; }
         A.out[o * A.out_plane_stride + y * A.out_row_stride + x] = res;
     }
+}
+
+// Second form (round 6): ring streaming, the float32 stencil's layout with float64 places.  A lane owns one spaxel and marches
+// over z: the R outputs the newest sample still contributes to live in R (numerator, denominator) register pairs; every input
+// is read ONCE (the runs of 16 above read ntaps + 15 planes per 16 outputs and spend 3 (ntaps + 15) / 16 FMAs pairs per output
+// where this form spends ntaps).  Place r of the step with phase q (= step mod 4) is the register pair q + r: a step accumulates
+// in place and the places move down four registers once per four steps (as spatial64_ring_kernel's y pass).  The samples are
+// asked for seven steps ahead (a step is ~0.4 us of arithmetic, a fetch from HBM several times that) in straight-line code -
+// eight steps per loop iteration, no branch that holds a load - so that the compiler counts the loads in flight.
+// Every output adds its inputs from the lowest channel up, like the form above: the same float64 bits.  Taken for kernels of
+// up to R taps, none negative, centre tap positive (an empty window then means an invalid centre sample: NaN, no second
+// look at the cube); the taps are centred in R entries, and a padding zero times an INFINITE valid sample would be NaN where
+// the form above skips it: a lane that meets one raises a flag and the runs-of-16 kernel, queued behind it, redoes the call.
+template <int R>
+struct SRing64Args {
+    Cube64 c;
+    MaskDev64 m;
+    double* out;
+    int64_t out_row_stride, out_plane_stride;
+    double k[R];                            // k[j] = weight of input i for output o = i - R / 2 + j  (true convolution)
+    int zchunk;                             // outputs per block along z
+    unsigned* flag;                         // != nullptr: the mask admits infinite samples
+};
+template <int R, bool ARR>
+__global__ __launch_bounds__(256, 2) void spectral64_ring_kernel(const SRing64Args<R> A) {
+    constexpr int H = R / 2, U = 4, NR = R + U - 1, NQ = 8, kPre = NQ - 1;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= A.c.ny * A.c.nx) return;
+    const int64_t y = g / A.c.nx, x = g - y * A.c.nx;
+    const int nz = (int)A.c.nz;
+    const int oa = (int)blockIdx.y * A.zchunk, ob = min(oa + A.zchunk, nz);
+    const double* pd = A.c.p + y * A.c.row_stride + x;
+    const uint8_t* pmk = ARR ? A.m.arr + y * A.m.row_stride + x : nullptr;
+    double* po = A.out + y * A.out_row_stride + x;
+    double sn[NR], sd[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { sn[r] = 0.0; sd[r] = 0.0; }
+    double vq[NQ];
+    unsigned mq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { vq[q] = 0.0; mq[q] = 1u; }
+    auto ask = [&](auto slot, int i) {                       // (channels clamped into the cube: what lies outside is not used)
+        constexpr int S = decltype(slot)::value;
+        const int ic = min(max(i, 0), nz - 1);
+        vq[S] = pd[(int64_t)ic * A.c.plane_stride];
+        if (ARR) mq[S] = pmk[(int64_t)ic * A.m.plane_stride];
+    };
+    bool seen_inf = false;
+    auto step = [&](auto slot, const int i) {
+        constexpr int S = decltype(slot)::value, Q = S % U;
+        const double v0 = vq[S];
+        const bool inr = i >= 0 && i < nz;                   // (uniform) outside the cube: a valid zero
+        const bool ok = pred64(A.m, v0) && mq[S] != 0u;
+        const double v = (inr && ok) ? v0 : 0.0, w = inr ? (ok ? 1.0 : 0.0) : 1.0;
+        if (A.flag) seen_inf = seen_inf || fabs(v) == INFINITY;
+        ask(std::integral_constant<int, (S + kPre) % NQ>{}, i + kPre);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            sn[Q + r] = fma(A.k[r], v, sn[Q + r]);
+            sd[Q + r] = fma(A.k[r], w, sd[Q + r]);
+        }
+        const int o = i - H;                                 // the output that has seen its last input
+        if (o >= oa && o < ob) po[(int64_t)o * A.out_plane_stride] = sd[Q] != 0.0 ? sn[Q] / sd[Q] : NAN;
+        if (Q == U - 1) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                sn[r] = r + U < NR ? sn[r + U] : 0.0;
+                sd[r] = r + U < NR ? sd[r + U] : 0.0;
+            }
+        }
+    };
+    const int i_begin = oa - H, i_end = ob + H;
+    static_assert(NQ == 8, "eight steps written out");
+    ask(std::integral_constant<int, 0>{}, i_begin);     ask(std::integral_constant<int, 1>{}, i_begin + 1);
+    ask(std::integral_constant<int, 2>{}, i_begin + 2); ask(std::integral_constant<int, 3>{}, i_begin + 3);
+    ask(std::integral_constant<int, 4>{}, i_begin + 4); ask(std::integral_constant<int, 5>{}, i_begin + 5);
+    ask(std::integral_constant<int, 6>{}, i_begin + 6);
+    for (int i0 = i_begin; i0 < i_end; i0 += NQ) {
+        step(std::integral_constant<int, 0>{}, i0);     step(std::integral_constant<int, 1>{}, i0 + 1);
+        step(std::integral_constant<int, 2>{}, i0 + 2); step(std::integral_constant<int, 3>{}, i0 + 3);
+        step(std::integral_constant<int, 4>{}, i0 + 4); step(std::integral_constant<int, 5>{}, i0 + 5);
+        step(std::integral_constant<int, 6>{}, i0 + 6); step(std::integral_constant<int, 7>{}, i0 + 7);
+    }
+    if (A.flag && seen_inf) atomicOr(A.flag, 1u);
 }
 
 // ---- spatial_smooth -------------------------------------------------------------------------------------------
@@ -1438,6 +1524,26 @@ static int cube64_args(const spc_cube_f64* cube, const spc_mask_f64* mask, Cube6
 }  // namespace
 
 template <int R>
+int launch_sring64(hipStream_t st, const Conv64Args& S, const double* h_kernel, int ntaps, unsigned* d_flag) {
+    SRing64Args<R> A{};
+    A.c = S.c; A.m = S.m; A.out = S.out; A.out_row_stride = S.out_row_stride; A.out_plane_stride = S.out_plane_stride;
+    const int pad = (R - ntaps) / 2;                            // the taps centred in R entries
+    for (int j = 0; j < R; ++j) A.k[j] = (j >= pad && j < pad + ntaps) ? h_kernel[j - pad] : 0.0;
+    A.flag = d_flag;
+    // the whole spectral axis per block when the map alone fills the chip, else chunks of >= 4 R outputs (R - 1 more inputs each)
+    const int64_t nb = (S.c.ny * S.c.nx + 255) / 256;
+    SPC_REQUIRE(nb < (1LL << 31), "map too large for one launch");
+    int64_t nsplit = std::max<int64_t>(1, std::min<int64_t>((2048 + nb - 1) / nb, S.c.nz / (4 * R)));
+    A.zchunk = (int)((S.c.nz + nsplit - 1) / nsplit);
+    nsplit = (S.c.nz + A.zchunk - 1) / A.zchunk;
+    SPC_REQUIRE(nsplit <= 65535, "too many chunks");
+    if (S.m.flags & SPC_MASK_ARRAY) hipLaunchKernelGGL((spectral64_ring_kernel<R, true>), dim3((unsigned)nb, (unsigned)nsplit), dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((spectral64_ring_kernel<R, false>), dim3((unsigned)nb, (unsigned)nsplit), dim3(256), 0, st, A);
+    SPC_LAUNCH_CHECK();
+    return SPC_OK;
+}
+
+template <int R>
 int launch_ring64(hipStream_t st, const Sp64Args& S, const double* h_ky, int nky, const double* h_kx, int nkx, unsigned* d_flag) {
     Ring64Args<R> A{};
     A.c = S.c; A.m = S.m; A.out = S.out; A.out_row_stride = S.out_row_stride; A.out_plane_stride = S.out_plane_stride;
@@ -1467,7 +1573,7 @@ int launch_ring64(hipStream_t st, const Sp64Args& S, const double* h_ky, int nky
 size_t spc_ws_wide(int kind, int64_t nz, int64_t ny, int64_t nx, int64_t p0, int64_t p1) {
     switch (kind) {
         case SPC_WS_STATS_GLOBAL_F64: return spc_ws_round(sizeof(Rec64) * 4096) + spc_ws_round(5 * sizeof(double)) + 256;
-        case SPC_WS_SPECTRAL_CONV_F64: return spc_ws_round(sizeof(double) * (size_t)(2 * std::max<int64_t>(p0, 1) + 30)) + 256;   // taps + the zero-padded table
+        case SPC_WS_SPECTRAL_CONV_F64: return spc_ws_round(sizeof(double) * (size_t)(2 * std::max<int64_t>(p0, 1) + 30)) + 256 + 256;   // taps + the zero-padded table + the ring form's flag word
         case SPC_WS_SPATIAL_CONV_F64: {
             // taps + the (num, den) planes of a slab: at most 256 MiB (the caller keeps its scratch), at least one plane
             const size_t plane = (size_t)ny * (size_t)nx * 2 * sizeof(double);
@@ -1547,6 +1653,24 @@ int spc_spectral_conv_f64(int device, void* stream, const spc_cube_f64* cube, co
     A.kern = d_k; A.kpad = d_k + ntaps; A.ntaps = ntaps; A.out = d_out;
     A.out_row_stride = out_row_stride ? out_row_stride : cube->nx;
     A.out_plane_stride = out_plane_stride ? out_plane_stride : cube->ny * A.out_row_stride;
+    A.gate = nullptr;
+    // up to 33 taps, none negative, centre positive: the ring form (SPC_SPECTRAL64_RING=0: the runs of 16)
+    const bool ring_on = [] { const char* e = getenv("SPC_SPECTRAL64_RING"); return e ? atoi(e) != 0 : true; }();      // (read per call: the tests compare both forms in one process)
+    bool ring = ring_on && ntaps <= 33 && h_kernel[ntaps / 2] > 0.0;
+    for (int i = 0; ring && i < ntaps; ++i) ring = h_kernel[i] >= 0.0;
+    if (ring) {
+        unsigned* d_flag = nullptr;
+        if (!(A.m.flags & SPC_MASK_FINITE)) {                   // the mask admits infinite samples: see spectral64_ring_kernel
+            SPC_WS_TAKE(d_f, ws, unsigned, 64);
+            d_flag = d_f;
+            SPC_HIP(hipMemsetAsync(d_flag, 0, sizeof(unsigned), st));
+        }
+        if (ntaps <= 17) rc = launch_sring64<17>(st, A, h_kernel, ntaps, d_flag);
+        else rc = launch_sring64<33>(st, A, h_kernel, ntaps, d_flag);
+        if (rc) return rc;
+        if (!d_flag) return SPC_OK;
+        A.gate = d_flag;                                        // the kernel below runs only if the ring kernel raised the flag
+    }
     const int64_t nb = (cube->ny * cube->nx + 255) / 256, runs = (cube->nz + kRun - 1) / kRun;
     SPC_REQUIRE(nb < (1LL << 31) && runs <= 65535, "cube too large for one launch (convolve a slab of channels / rows)");
     hipLaunchKernelGGL(spectral_conv64_kernel, dim3((unsigned)nb, (unsigned)runs), dim3(256), 0, st, A);
