@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -155,6 +156,8 @@ __global__ __launch_bounds__(256) void stats64_rows_kernel(const Cube64 C, const
 // multiplies them: 0 x finite = 0 there too; an infinite sample under a zero tap is the one case kept apart), an empty
 // window gives the filled centre sample.  A lane owns one spaxel and produces RUN consecutive channels at a time from the
 // ntaps + RUN - 1 input planes of the run (each read once per run; the halo of the next run comes from the L2).
+template <class F, int... G>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, G...>) { (f(std::integral_constant<int, G>{}), ...); }
 constexpr int kRun = 16;
 struct Conv64Args {
     Cube64 c;
@@ -624,7 +627,8 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
     const int nx = (int)A.c.nx, ny = (int)A.c.ny;            // (ny <= 65535 and nx < 2^31: checked by the entry point)
     const int x0 = strip * W;
     const int ya = band * A.band_rows, yb = min(ya + A.band_rows, ny);
-    const bool second = t < 2 * H;                           // this thread also stages element W + t
+    const bool second = t < 2 * H;                           // this thread also stages element W + t (the first wave's lanes: R <= 33)
+    const bool wave0 = __builtin_amdgcn_readfirstlane(t >> 6) == 0;
     const int c0 = x0 - H + t, c1 = c0 + W;
     const bool in0 = c0 >= 0 && c0 < nx, in1 = c1 < nx;
     const unsigned cc0 = (unsigned)min(max(c0, 0), nx - 1), cc1 = (unsigned)min(c1, nx - 1);
@@ -638,20 +642,31 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
     double sn[NR], sd[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) { sn[r] = 0.0; sd[r] = 0.0; }
-    double r0 = 0.0, r1 = 0.0;
-    unsigned m0 = 1u, m1 = 1u;
-    auto load_row = [&](int u) {                             // (a uniform row pointer + a 32-bit lane offset)
-        const double* q = pd + (int64_t)u * A.c.row_stride;
-        r0 = q[cc0];
-        if (second) r1 = q[cc1];
+    // the rows' own samples: asked for kPre rows ahead (a row of this wave lasts ~1.5 us, a fetch from HBM under load longer
+    // than that), slot = the row's phase.  Straight-line code - rows clamped into the image, every lane asks for both of
+    // "its" elements - so that the compiler can count the loads in flight (behind a branch it waits for all of them)
+    constexpr int kPre = 3;
+    double rq0[U], rq1[U];
+    unsigned mq0[U], mq1[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) { rq0[q] = 0.0; rq1[q] = 0.0; mq0[q] = 1u; mq1[q] = 1u; }
+    auto load_row = [&](auto slot, int u) {                  // (a uniform row pointer + a 32-bit lane offset)
+        constexpr int S = decltype(slot)::value;
+        const int uc = min(max(u, 0), ny - 1);
+        const double* q = pd + (int64_t)uc * A.c.row_stride;
+        rq0[S] = q[cc0];
+        rq1[S] = q[cc1];
         if (ARR) {
-            const uint8_t* qm = pm + (int64_t)u * A.m.row_stride;
-            m0 = qm[cc0];
-            if (second) m1 = qm[cc1];
+            const uint8_t* qm = pm + (int64_t)uc * A.m.row_stride;
+            mq0[S] = qm[cc0];
+            mq1[S] = qm[cc1];
         }
     };
     const int u_begin = ya - H, u_end = yb + H;
-    if (u_begin >= 0) load_row(u_begin);
+    static_assert(kPre == 3 && U == 4, "the first rows' slots written out");
+    load_row(std::integral_constant<int, 0>{}, u_begin);
+    load_row(std::integral_constant<int, 1>{}, u_begin + 1);
+    load_row(std::integral_constant<int, 2>{}, u_begin + 2);
     bool seen_inf = false;
     const int x = x0 + t;
     double* po = A.out + z * A.out_plane_stride + x;
@@ -661,20 +676,21 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
     double Xpn = 0.0, Xpd = 0.0;                             // (before the first row: zeros into an empty ring)
     auto row_step = [&](auto phase, const int u) {
         constexpr int Q = decltype(phase)::value;
-        const bool next_in = u + 1 >= 0 && u + 1 < ny;
         const bool row_in = u >= 0 && u < ny;                // (uniform)
+        const double r0 = rq0[Q], r1 = rq1[Q];
+        const unsigned m0 = mq0[Q], m1 = mq1[Q];
         f64x2* const Bw = buf[Q & 1];                        // (U is even: the buffer is the phase's parity)
         {
             const bool ok = pred64(A.m, r0) && m0 != 0u;
             Bw[t] = (in0 && row_in) ? (ok ? f64x2{r0, 1.0} : f64x2{0.0, 0.0}) : f64x2{0.0, 1.0};      // outside the image: a valid zero
             if (A.flag) seen_inf = seen_inf || (ok && in0 && row_in && fabs(r0) == INFINITY);
         }
-        if (second) {
+        if (wave0 && second) {                              // (a scalar branch for three of the four waves)
             const bool ok = pred64(A.m, r1) && m1 != 0u;
             Bw[W + t] = (in1 && row_in) ? (ok ? f64x2{r1, 1.0} : f64x2{0.0, 0.0}) : f64x2{0.0, 1.0};
             if (A.flag) seen_inf = seen_inf || (ok && in1 && row_in && fabs(r1) == INFINITY);
         }
-        if (next_in) load_row(u + 1);                        // in flight under this row's arithmetic
+        load_row(std::integral_constant<int, (Q + kPre) % U>{}, u + kPre);      // in flight under the arithmetic of three rows
         // (one barrier per row: a buffer is written again two rows later, behind the barrier of the row in between)
         __syncthreads();
         // y pass of row u - 1: place r takes tap R - 1 - r (symmetric: tap r); place 0 has then seen its last row
@@ -686,10 +702,9 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
         }
         const int y = u - 1 - H;
         if (y >= ya && y < yb && x < nx) {
-            double res;
-            if (sd[Q] != 0.0) res = sn[Q] / sd[Q];
-            else { double cv; res = inc64(A.c, A.m, z, y, x, cv) ? cv : NAN; }
-            po[(int64_t)y * A.out_row_stride] = res;
+            // (no tap negative, centre taps positive: an empty window means an invalid centre sample - NaN, no second look at the cube,
+            //  and no load behind a branch)
+            po[(int64_t)y * A.out_row_stride] = sd[Q] != 0.0 ? sn[Q] / sd[Q] : NAN;
         }
         // x pass of row u.  Left alone the compiler asks for all R pairs at once - 132 registers beside the ring's 144 - and
         // sends a part of the ring to scratch (a sched_barrier does not hold the reads back: they are hoisted before the
@@ -702,8 +717,8 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
         f64x2 sq[kD];
 #pragma unroll
         for (int j = 0; j < kD; ++j) sq[j] = Bp[j];
-#pragma unroll
-        for (int g = 0; g * kG < R; ++g) {
+        auto group = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
 #pragma unroll
             for (int q = 0; q < kG; ++q) {
                 const int j = g * kG + q;
@@ -719,7 +734,8 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
                 const int j = g * kG + q;
                 if (j + kD < R) sq[j % kD] = Bp[j + kD];
             }
-        }
+        };
+        for_each_const(group, std::make_integer_sequence<int, (R + kG - 1) / kG>{});
         Xpn = Xn; Xpd = Xd;
     };
     static_assert(U == 4, "four phases written out");
@@ -1724,11 +1740,12 @@ int spc_spatial_conv_f64(int device, void* stream, const spc_cube_f64* cube, con
         }
         return SPC_OK;
     }
-    // symmetric factors of up to 33 taps: the one-kernel ring form (SPC_SPATIAL64_RING=0: the two-pass forms)
+    // symmetric factors of up to 33 taps, none negative, centre taps positive: the one-kernel ring form (SPC_SPATIAL64_RING=0: the
+    // two-pass forms)
     const bool ring_on = [] { const char* e = getenv("SPC_SPATIAL64_RING"); return e ? atoi(e) != 0 : true; }();     // (read per call: the tests compare both forms in one process)
-    bool ring = ring_on && nky <= 33 && nkx <= 33;
-    for (int i = 0; ring && i < nky / 2; ++i) ring = h_ky[i] == h_ky[nky - 1 - i];
-    for (int i = 0; ring && i < nkx / 2; ++i) ring = h_kx[i] == h_kx[nkx - 1 - i];
+    bool ring = ring_on && nky <= 33 && nkx <= 33 && h_ky[nky / 2] > 0.0 && h_kx[nkx / 2] > 0.0;
+    for (int i = 0; ring && i < nky / 2; ++i) ring = h_ky[i] == h_ky[nky - 1 - i] && h_ky[i] >= 0.0;
+    for (int i = 0; ring && i < nkx / 2; ++i) ring = h_kx[i] == h_kx[nkx - 1 - i] && h_kx[i] >= 0.0;
     A.gate = nullptr;
     if (ring) {
         unsigned* d_flag = nullptr;

@@ -7,7 +7,7 @@ import pytest
 
 import oracle_np as O
 from conftest import assert_close
-from spectral_cube_amd import Gaussian2DKernel, _lib, ops
+from spectral_cube_amd import Gaussian1DKernel, Gaussian2DKernel, _lib, ops
 from spectral_cube_amd.device import DeviceArray
 
 pytestmark = pytest.mark.gpu
@@ -260,6 +260,63 @@ def test_float64_spatial_smooth_ring_form_hands_infinite_samples_to_the_two_pass
                 assert np.isfinite(ring[1, 55:66, 95:106]).all()
             else:
                 assert not np.isfinite(ring[1, 60, 100])
+
+
+@pytest.mark.parametrize("shape, taps, flags", [((700, 20, 33), 33, "array"), ((300, 3, 5), 17, "array+finite"), ((64, 40, 130), 9, "finite"),
+                                                ((1200, 2, 300), 25, "none"), ((40, 7, 9), 33, "array"), ((5, 6, 7), 1, "array")])
+def test_float64_spectral_smooth_ring_form(gpu, shape, taps, flags, monkeypatch):
+    """round 6: float64 spectral_smooth with up to 33 non-negative taps as ring streaming (a lane marches over z, its pending
+    outputs in a register ring, every input read once, chunks of channels for small maps): every output adds its inputs from
+    the lowest channel up like the runs-of-16 kernel - the same float64 bits - and the oracle's values to 1e-13; asymmetric
+    kernels too (one tap set: all 33 fit the scalar registers)"""
+    rng = np.random.default_rng(sum(shape) + taps)
+    d = 1000.0 + 50.0 * rng.standard_normal(shape)
+    d[rng.random(shape) < 0.02] = np.nan
+    m = rng.random(shape) < 0.8
+    m[shape[0] // 3:shape[0] // 3 + min(40, shape[0] // 2), 1, 2] = False      # empty windows: NaN out
+    x = np.arange(taps) - taps // 2
+    k1 = np.exp(-0.5 * (x / max(taps / 8.0, 0.5)) ** 2) * (1.0 + 0.3 * (x > 0))      # asymmetric
+    k1 /= k1.sum()
+    cube = DeviceArray.from_numpy(d)
+    mk = DeviceArray.from_numpy(m.astype(np.uint8)) if "array" in flags else None
+    fl = (_lib.MASK_ARRAY if "array" in flags else 0) | (_lib.MASK_FINITE if "finite" in flags else 0)
+    spec = ops.MaskSpec(fl, array=mk) if fl else None
+    monkeypatch.setenv("SPC_SPECTRAL64_RING", "1")
+    ring = ops.spectral_conv_f64(cube, k1, mask=spec).get()
+    monkeypatch.setenv("SPC_SPECTRAL64_RING", "0")
+    runs = ops.spectral_conv_f64(cube, k1, mask=spec).get()
+    assert np.array_equal(ring, runs, equal_nan=True)
+    inc = (m if "array" in flags else np.ones(shape, bool)) & ~np.isnan(d)
+    exp = O.spectral_smooth(d, inc, k1)
+    assert np.array_equal(np.isnan(ring), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    assert np.abs(ring[ok] - exp[ok]).max() <= 1e-13 * np.abs(exp[ok]).max()
+
+
+def test_float64_spectral_smooth_ring_form_hands_over_what_it_does_not_take(gpu, monkeypatch):
+    """infinite valid samples (a padding zero times infinity would be NaN: device flag, the runs-of-16 kernel redoes the call),
+    negative taps and a zero centre tap (an empty window is then not the same as an invalid centre sample): the result is the
+    runs-of-16 result bit for bit"""
+    rng = np.random.default_rng(8)
+    shape = (200, 6, 40)
+    d = 10.0 + rng.standard_normal(shape)
+    d[100, 3, 20] = np.inf
+    d[5, 0, 39] = -np.inf
+    m = rng.random(shape) < 0.9
+    m[100, 3, 20] = m[5, 0, 39] = True
+    cube, mk = DeviceArray.from_numpy(d), DeviceArray.from_numpy(m.astype(np.uint8))
+    g = Gaussian1DKernel(2.0).array
+    kernels = [g, np.concatenate([[0.0, 0.0], g, [0.0, 0.0]]), np.array([-0.25, 0.0, 1.5, 0.0, -0.25]), np.array([0.5, 0.0, 0.5])]
+    for k1 in kernels:
+        for fl in (_lib.MASK_ARRAY, _lib.MASK_ARRAY | _lib.MASK_FINITE):
+            spec = ops.MaskSpec(fl, array=mk)
+            monkeypatch.setenv("SPC_SPECTRAL64_RING", "1")
+            ring = ops.spectral_conv_f64(cube, k1, mask=spec).get()
+            monkeypatch.setenv("SPC_SPECTRAL64_RING", "0")
+            runs = ops.spectral_conv_f64(cube, k1, mask=spec).get()
+            assert np.array_equal(ring, runs, equal_nan=True)
+            if k1 is g and not (fl & _lib.MASK_FINITE):
+                assert not np.isfinite(ring[100, 3, 20])
 
 
 def test_cube_level_arithmetic_of_the_masked_spatial_stencil_is_selectable(gpu, monkeypatch):
