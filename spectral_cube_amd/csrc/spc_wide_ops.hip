@@ -645,7 +645,9 @@ __global__ __launch_bounds__(256, 2) void spatial64_ring_kernel(const Ring64Args
     const bool wave0 = __builtin_amdgcn_readfirstlane(t >> 6) == 0;
     const int c0 = x0 - H + t, c1 = c0 + W;
     const bool in0 = c0 >= 0 && c0 < nx, in1 = c1 < nx;
-    const unsigned cc0 = (unsigned)min(max(c0, 0), nx - 1), cc1 = (unsigned)min(c1, nx - 1);
+    // (lanes without a second element ask for their first one again - every lane issues both loads, see load_row - instead of
+    //  fetching 256 columns of the NEXT strip: the kernel read 1.8x its input that way, PMC)
+    const unsigned cc0 = (unsigned)min(max(c0, 0), nx - 1), cc1 = second ? (unsigned)min(c1, nx - 1) : cc0;
     const double* pd = A.c.p + z * A.c.plane_stride;
     const uint8_t* pm = ARR ? A.m.arr + z * A.m.plane_stride : nullptr;
     // the ring: logical place r of the row with phase q (= row mod U inside an unrolled group of U rows) is the register pair
