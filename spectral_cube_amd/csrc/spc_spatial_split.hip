@@ -92,29 +92,28 @@ struct Sm3Args {
 
 __device__ __forceinline__ half8 as_half8(u32x4 v) { return __builtin_bit_cast(half8, v); }
 
-// two float32 (times the uniform power-of-two scale s) -> packed fp16 hi and packed fp16 residual
-__device__ __forceinline__ void split_pair(float a, float b, float s, unsigned& hi, unsigned& lo) {
-    unsigned h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a), "s"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(b), "s"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a), "s"(s), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(b), "s"(s), "v"(h));
-    hi = h; lo = l;
+// two float32 (times the uniform power-of-two scale s) -> packed fp16 hi and packed fp16 residual.
+// hi = fp16(a s) (v_cvt_pk_f16_f32: both halves in one instruction), lo = fp16(a s - hi): the difference is EXACT in float32
+// (a s is exact - s is a power of two - and the residual of a rounding to 11 bits fits 24), so v_fma_mix_f32 + one packed
+// conversion give the bits v_fma_mixlo / mixhi_f16 gave - those write half a register each and issue at 8.8 cycles where
+// v_fma_mix_f32, v_pk_mul_f32 and v_cvt_pk_f16_f32 take ~5 (profiles/r05_micro_mfma_valu_rates.txt): 25 instead of 35 cycles
+// per pair (round 6, third session).
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_scaled(float as, float bs, unsigned& hi, unsigned& lo) {
+    const half2v h2 = {(_Float16)as, (_Float16)bs};
+    const unsigned h = __builtin_bit_cast(unsigned, h2);
+    // (in place: the kernel sits at 256 registers, and two more temporaries per pair were answered with scratch)
+    asm("v_fma_mix_f32 %0, %0, 1.0, -%1 op_sel_hi:[0,0,1]" : "+v"(as) : "v"(h));
+    asm("v_fma_mix_f32 %0, %0, 1.0, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(bs) : "v"(h));
+    const half2v l2 = {(_Float16)as, (_Float16)bs};
+    hi = h; lo = __builtin_bit_cast(unsigned, l2);
 }
+__device__ __forceinline__ void split_pair(float a, float b, float s, unsigned& hi, unsigned& lo) { split_scaled(a * s, b * s, hi, lo); }
 
 // the same for values that come out of a matrix instruction: the FIRST reads of the accumulators are instructions the
 // compiler sees (it pads the MFMA -> VALU wait states; it pads nothing in front of inline asm: read too early, an
-// accumulator lacks its last products - the lo terms - or holds garbage)
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split_pair_acc(float a, float b, float s, unsigned& hi, unsigned& lo) {
-    const float as = a * s, bs = b * s;
-    const half2v h2 = {(_Float16)as, (_Float16)bs};
-    const unsigned h = __builtin_bit_cast(unsigned, h2);
-    unsigned l;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(as), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(bs), "v"(h));
-    hi = h; lo = l;
-}
+// accumulator lacks its last products - the lo terms - or holds garbage) - here the multiplications by the scale
+__device__ __forceinline__ void split_pair_acc(float a, float b, float s, unsigned& hi, unsigned& lo) { split_scaled(a * s, b * s, hi, lo); }
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));     // row_shr:1
