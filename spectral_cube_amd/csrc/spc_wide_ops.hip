@@ -1297,14 +1297,40 @@ __device__ __forceinline__ unsigned long long row_descend(const unsigned (&khi)[
         }
         if (HI) phi |= digit << shift; else plo |= digit << shift;
     };
+    // The leading digits EVERY valid key of the ray shares need no pass (positive samples within a factor of a few share their sign,
+    // exponent and then some: the bench's 1000 +- 1 shares five of the ten digits a descent otherwise walks): AND and OR of the
+    // ray's keys differ where its keys do; the wave starts at the first digit that differs in ANY of its rays.
+    int start = 0;
+    {
+        unsigned ah = 0xffffffffu, al = 0xffffffffu, oh = 0u, ol = 0u;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const bool ex = (khi[i] & klo[i]) == 0xffffffffu;      // (the excluded key is all ones: neutral for AND, kept out of OR)
+            ah &= khi[i]; al &= klo[i];
+            oh |= ex ? 0u : khi[i]; ol |= ex ? 0u : klo[i];
+        }
+        ah &= row_ror_u32(ah, 8); al &= row_ror_u32(al, 8); oh |= row_ror_u32(oh, 8); ol |= row_ror_u32(ol, 8);
+        ah &= row_ror_u32(ah, 4); al &= row_ror_u32(al, 4); oh |= row_ror_u32(oh, 4); ol |= row_ror_u32(ol, 4);
+        ah &= row_ror_u32(ah, 2); al &= row_ror_u32(al, 2); oh |= row_ror_u32(oh, 2); ol |= row_ror_u32(ol, 2);
+        ah &= row_ror_u32(ah, 1); al &= row_ror_u32(al, 1); oh |= row_ror_u32(oh, 1); ol |= row_ror_u32(ol, 1);
+        if (LPR == 32) { ah &= swap16_u32(ah); al &= swap16_u32(al); oh |= swap16_u32(oh); ol |= swap16_u32(ol); }
+        const unsigned dh = ah ^ oh, dl = al ^ ol;
+        int shared = dh ? (__builtin_clz(dh) >> 2) : 8 + (dl ? (__builtin_clz(dl) >> 2) : 8);
+        if (n <= 1) shared = 16;                             // nothing to tell apart: this ray holds nobody back
+        start = min(__builtin_amdgcn_readlane(shared, 0), __builtin_amdgcn_readlane(shared, 32));
+        if (LPR == 16) start = min(start, min(__builtin_amdgcn_readlane(shared, 16), __builtin_amdgcn_readlane(shared, 48)));
+        if (start >= 16) return ((unsigned long long)ah << 32) | al;     // every ray of the wave: one distinct key (or none)
+        phi = start >= 8 ? ah : (start > 0 ? (ah & (0xffffffffu << (32 - 4 * start))) : 0u);
+        plo = start > 8 ? (al & (0xffffffffu << (64 - 4 * start))) : 0u;
+    }
     int stop_hi = -1, stop_lo = -1;                          // the shift of the last pass made in either word (-1: none)
-    for (int shift = 28; shift >= 0; shift -= 4) {
+    for (int shift = 28 - 4 * start; shift >= 0; shift -= 4) {          // (start >= 8: no pass in the high word)
         pass(std::integral_constant<bool, true>{}, shift);
         stop_hi = shift;
         if (__all(left <= 1)) break;
     }
-    if (!__all(left <= 1)) {
-        for (int shift = 28; shift >= 0; shift -= 4) {
+    if (start >= 8 || !__all(left <= 1)) {
+        for (int shift = start > 8 ? 28 - 4 * (start - 8) : 28; shift >= 0; shift -= 4) {
             pass(std::integral_constant<bool, false>{}, shift);
             stop_lo = shift;
             if (__all(left <= 1)) break;
