@@ -87,6 +87,7 @@ struct Sm3Args {
     float lim;                                // FLT_MAX under isfinite, +inf otherwise (NaN fails |v| <= lim either way)
     float sy, sx;                             // power-of-two scales of the fp16 taps
     int mirror, sync;                         // odd bands march upwards / one rendezvous of the block's waves per channel
+    int wide_mask;                            // the mask rows of a step in two requests per lane + a transpose over lanes (SPC_SPLIT_WIDE_MASK=0: six dword loads)
     float ky[kMaxTaps + 3], kx[kMaxTaps + 3];
 };
 
@@ -150,8 +151,9 @@ __device__ __forceinline__ u32x4 scale_h8(u32x4 v, _Float16 r) { return __builti
 // Three sums: S0 = sum v, S1' = sum v d, S2' = sum v d^2 with d = the channel coordinate about the CHUNK's middle channel
 // (float32: |d| is at most 32 channel widths); the finish kernel shifts the chunks' sums to the map's mean in float64
 // (round-5 advisor: sums about the reference channel in float32 lost moment 2 of a narrow line far from it to cancellation).
-template <int NB, int NRT, bool ARR, int INC, bool STORE, int NSUM>
+template <int NB, int NRT, bool ARR, int INC, bool STORE, int NSUM, bool WIDE = false>
 __global__ __launch_bounds__(NSUM == 3 ? 512 : kThreads, NSUM == 3 ? 1 : 2) void spatial_split_kernel(const Sm3Args A) {
+    static_assert(ARR || !WIDE, "WIDE is about the mask array's loads");
     using G = Geo<NB>;
     constexpr int kCT = G::CT, kOC = G::OC, HB = G::HB, H = G::H, R = G::R, NQ = G::NQ, NP = G::NP, kSets = G::SETS;
     static_assert(NRT > 0 || NSUM == 0, "the moment sums of a band live in LDS: their row tile count is static");
@@ -226,6 +228,9 @@ __global__ __launch_bounds__(NSUM == 3 ? 512 : kThreads, NSUM == 3 ? 1 : 2) void
         coff[u] = (unsigned)min(max(c, 0), nx - 4);
     }
     const bool cols_inside = (xw - 16 * HB >= 0) && (xw + kOC + 16 * HB <= nx);      // uniform
+    // (WIDE) byte columns of this lane's two mask requests: unit lg whole, and 8 bytes of unit 4 + (lg & 1) (half lg >> 1)
+    const unsigned wcolA = (unsigned)min(max(xw - 16 * HB + 16 * lg, 0), nx - 16);
+    const unsigned wcolB = (unsigned)min(max(xw - 16 * HB + 16 * (4 + (lg & 1)), 0), nx - 16) + 8u * (unsigned)(lg >> 1);
 
     f32x4 raw[kUnits];
     unsigned mk[kUnits];
@@ -237,8 +242,31 @@ __global__ __launch_bounds__(NSUM == 3 ? 512 : kThreads, NSUM == 3 ? 1 : 2) void
 #pragma unroll
         for (int u = 0; u < kUnits; ++u) {
             raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro + coff[u] * 4u), 0, 0));
-            if (ARR) mk[u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rm, (int)(mo + coff[u]), 0, 0);
+            if (ARR && !WIDE) mk[u] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rm, (int)(mo + coff[u]), 0, 0);
         }
+        if (ARR && WIDE) {
+            // The 96 mask bytes of a row in TWO requests per lane instead of six (round 6, third session): a mask dword per unit and
+            // lane is 16 rows x 16 bytes per instruction - six instructions touch 96 half lines for 1.5 KB, and with the mask loads
+            // taken out the three forms ran 11 - 23 % faster, nearly what the four times larger data loads cost
+            // (profiles/r06_split_mask_loads.txt).  Lane (m, g) asks for the 16 bytes of unit g of its row and for 8 bytes of
+            // units 4 / 5 (piece = g with its two bits exchanged); mask_transpose() below hands every lane ITS dword of every unit.
+            // WIDE is launched for nx % 16 == 0: a unit then lies inside the plane or outside it as a whole - a unit outside is
+            // read from a clamped place and replaced by the step's fix-up like before.
+            const unsigned q = (((unsigned)lg & 1u) << 1) | ((unsigned)lg >> 1);
+            const u32x4 a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, (int)(mo + wcolA), 0, 0));
+            const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)(mo + wcolB), 0, 0));
+            (void)q;
+            mk[0] = a.x; mk[1] = a.y; mk[2] = a.z; mk[3] = a.w; mk[4] = b.x; mk[5] = b.y;
+        }
+    };
+    // lane (m, g) holds the four dwords of unit g (mk[0..3]) and two of units 4 / 5: a 4 x 4 transpose over the lanes m, m + 16,
+    // m + 32, m + 48 - two v_permlane32_swap, two v_permlane16_swap - and one more swap leave mk[u] = its own four bytes of unit u
+    auto mask_transpose = [&]() {
+        auto s32 = [](unsigned& x, unsigned& y) { const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); x = r[0]; y = r[1]; };
+        auto s16 = [](unsigned& x, unsigned& y) { const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false); x = r[0]; y = r[1]; };
+        s32(mk[0], mk[2]); s32(mk[1], mk[3]);
+        s16(mk[0], mk[1]); s16(mk[2], mk[3]);
+        s16(mk[4], mk[5]);
     };
 
     // ---- state
@@ -316,6 +344,7 @@ __global__ __launch_bounds__(NSUM == 3 ? 512 : kThreads, NSUM == 3 ? 1 : 2) void
         float d[kUnits][4];
         u32x2 vh[kUnits];
         float mx = 0.f;
+        if (WIDE) mask_transpose();
         if (!tile_inside) {                      // samples outside the plane are VALID ZEROS (boundary='fill', fill_value=0): in place,
 #pragma unroll                                   // one uniform branch (per unit inside the loop below it cost the interior five moves per unit)
             for (int u = 0; u < kUnits; ++u) {
@@ -707,7 +736,8 @@ int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const Mas
     // measured at 256 x 2048^2 + uint8 mask (profiles/r05_split_fetch_ab.txt): fetch / algorithmic x1.97 as built first, x1.52 with
     // mirrored odd bands, x1.43 with the rendezvous per channel as well; the time does not move (the kernel is bound by issue).
     // The three-sum form (16-row regions, three times the steps per channel) loses 8 % to the rendezvous: not there.
-    { const char* e = getenv("SPC_SPLIT_MIRROR"); A.mirror = e ? atoi(e) : 1; e = getenv("SPC_SPLIT_SYNC"); A.sync = e ? atoi(e) : 1; }
+    { const char* e = getenv("SPC_SPLIT_MIRROR"); A.mirror = e ? atoi(e) : 1; e = getenv("SPC_SPLIT_SYNC"); A.sync = e ? atoi(e) : 1;
+      e = getenv("SPC_SPLIT_WIDE_MASK"); A.wide_mask = e ? atoi(e) : 1; }
     SPC_REQUIRE(ntaps == Geo<3>::R || ntaps == Geo<5>::R, "internal: the split form takes taps padded to 33 or 65 entries");
     const int nb = ntaps == Geo<3>::R ? 3 : 5;
     for (int i = 0; i < kMaxTaps + 3; ++i) { A.ky[i] = i < ntaps ? ky[i] : 0.f; A.kx[i] = i < ntaps ? kx[i] : 0.f; }
@@ -740,9 +770,13 @@ int spc_spatial_split_launch(hipStream_t st, const spc_cube_f32* cube, const Mas
     }
     const bool arr = A.marr != nullptr, fin = (md.flags & SPC_MASK_FINITE) != 0, store = d_out != nullptr;
     dim3 grid((unsigned)nblocks), block(nsum == 3 ? 512 : kThreads);
-#define SPC_S3(NB_, NRT_, ARR_, INC_, STORE_, NSUM_) hipLaunchKernelGGL((spatial_split_kernel<NB_, NRT_, ARR_, INC_, STORE_, NSUM_>), grid, block, 0, st, A)
-#define SPC_S3_MASK(NB_, NRT_, STORE_, NSUM_) do { if (arr && fin) SPC_S3(NB_, NRT_, true, 1, STORE_, NSUM_); else if (arr) SPC_S3(NB_, NRT_, true, 2, STORE_, NSUM_); \
-                                                   else if (fin) SPC_S3(NB_, NRT_, false, 1, STORE_, NSUM_); else SPC_S3(NB_, NRT_, false, 0, STORE_, NSUM_); } while (0)
+    // WIDE: the mask rows of a step in two requests per lane (see issue_loads) - for planes whose width is a multiple of 16 columns
+    // and mask rows on 4-byte boundaries (spc_spatial_split_takes); SPC_SPLIT_WIDE_MASK=0: six dword loads per lane as before
+    const bool wide = arr && A.wide_mask && (cube->nx % 16 == 0) && cube->nx >= 16;
+#define SPC_S3(NB_, NRT_, ARR_, INC_, STORE_, NSUM_, WIDE_) hipLaunchKernelGGL((spatial_split_kernel<NB_, NRT_, ARR_, INC_, STORE_, NSUM_, WIDE_>), grid, block, 0, st, A)
+#define SPC_S3_ARR(NB_, NRT_, INC_, STORE_, NSUM_) do { if (wide) SPC_S3(NB_, NRT_, true, INC_, STORE_, NSUM_, true); else SPC_S3(NB_, NRT_, true, INC_, STORE_, NSUM_, false); } while (0)
+#define SPC_S3_MASK(NB_, NRT_, STORE_, NSUM_) do { if (arr && fin) SPC_S3_ARR(NB_, NRT_, 1, STORE_, NSUM_); else if (arr) SPC_S3_ARR(NB_, NRT_, 2, STORE_, NSUM_); \
+                                                   else if (fin) SPC_S3(NB_, NRT_, false, 1, STORE_, NSUM_, false); else SPC_S3(NB_, NRT_, false, 0, STORE_, NSUM_, false); } while (0)
     if (nb == 3) {
         if (nsum == 3) { if (store) SPC_S3_MASK(3, kNRT3, true, 3); else SPC_S3_MASK(3, kNRT3, false, 3); }
         else if (nsum == 1) { if (store) SPC_S3_MASK(3, kNRT1, true, 1); else SPC_S3_MASK(3, kNRT1, false, 1); }

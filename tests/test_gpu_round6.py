@@ -71,6 +71,29 @@ def test_three_sum_form_shared_sums_against_the_oracle(gpu, shape, flags):
     assert_close(maps["m2"].get(), e2, atol=1e-5 * np.nanmax(np.abs(e2)), what="m2")
 
 
+@pytest.mark.parametrize("shape", [(3, 70, 16), (2, 40, 48), (5, 33, 64), (2, 130, 208), (3, 50, 2048)])
+def test_split_form_mask_rows_in_two_requests_per_lane(gpu, shape, monkeypatch):
+    """round 6: for planes whose width is a multiple of 16 columns the split form reads the 96 mask bytes of a row in two requests
+    per lane and hands every lane its dword of every unit by a transpose over lanes (v_permlane32 / 16_swap) - the same bytes as six
+    dword loads: all three forms bit-identical to the six-load kernels (SPC_SPLIT_WIDE_MASK=0), on planes narrower than a strip,
+    strips that end inside the plane, units that lie outside it"""
+    d, m = _case(shape, 23, valid=0.7, nan_frac=0.01)
+    cube, mk = _dev(d, m)
+    cen = DeviceArray.from_numpy((np.arange(shape[0]) - shape[0] // 2) * 500.0)
+    got = {}
+    for flags in (_lib.MASK_ARRAY, _lib.MASK_ARRAY | _lib.MASK_FINITE):
+        spec = ops.MaskSpec(flags, array=mk)
+        for wide in ("1", "0"):
+            monkeypatch.setenv("SPC_SPLIT_WIDE_MASK", wide)
+            out, m0 = ops.spatial_conv_mfma(cube, K8, mask=spec, want_cube=True, want_m0=True, dv=500.0)
+            _, maps = ops.spatial_conv_mfma_moments(cube, K8, cen, dv=500.0, m1_add=0.0, mask=spec)
+            got[wide] = [out.get(), m0.get()] + [maps[k].get() for k in ("m0", "m1", "m2")]
+        for a, b in zip(got["1"], got["0"]):
+            assert np.array_equal(a, b, equal_nan=True)
+    exp = O.spatial_smooth(d, m, K8)
+    assert_close(got["1"][0], exp.astype(np.float32), atol=1e-5 * np.nanmax(np.abs(exp)), what="wide mask requests %r" % (shape,))
+
+
 @pytest.mark.parametrize("stddev, taps", [(5.0, 41), (8.0, 65)])
 def test_three_sum_form_takes_up_to_65_taps(gpu, stddev, taps):
     """round 6: moments 1 / 2 of kernels of 35 - 65 taps are fused as well (five Toeplitz blocks, bands of 16 row tiles)"""

@@ -11,6 +11,9 @@ ny = nx = 2048
 rng = np.random.default_rng(3)
 tile = rng.standard_normal((2, ny, nx), dtype=np.float32) + 2.0
 tm = (rng.random((2, ny, nx), dtype=np.float32) > 0.2).view(np.uint8)
+if len(sys.argv) > 3 and sys.argv[3] == "sig":      # the bench's coherent SIGNAL mask (35 % valid) instead of the random one
+    yy_, xx_ = np.mgrid[0:ny, 0:nx]
+    tm = np.stack([(np.sin(xx_ / 37.0) * np.cos(yy_ / 53.0) > 0.2), (np.sin(xx_ / 41.0 + 1.0) * np.cos(yy_ / 47.0) > 0.2)]).view(np.uint8)
 cube, mask = DeviceArray((nz, ny, nx), np.float32), DeviceArray((nz, ny, nx), np.uint8)
 for dev, host in ((cube, tile), (mask, tm)):
     import ctypes as C
@@ -39,4 +42,4 @@ if "f012" in which.split(","):
     res.append("fused m012 %.3f" % timeit(lambda: ops.spatial_conv_mfma_moments(cube, k2, cen, dv=500.0, m1_add=0.0, mask=ms)))
 if "mat" in which.split(","):
     res.append("cube->cube %.3f" % timeit(lambda: ops.spatial_conv_mfma(cube, k2, mask=ms, out=out)))
-print("nz=%d dbg=%s: " % (nz, os.environ.get("SPC_SPLIT_DBG", "0")) + ", ".join(res) + "  (ms; x%d for 4096 planes)" % (4096 // nz))
+print("nz=%d mask=%s dead-skip=%s: " % (nz, sys.argv[3] if len(sys.argv) > 3 else "random", os.environ.get("SPC_SPLIT_DEAD", "1")) + ", ".join(res) + "  (ms; x%d for 4096 planes)" % (4096 // nz))
