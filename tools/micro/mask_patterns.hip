@@ -40,6 +40,35 @@ __global__ __launch_bounds__(64 * ZW) void rd(const float* __restrict__ in, cons
     if (acc.x + acc.y + acc.z + acc.w == 12345.f || macc == 0x12345u) sink[0] = 1;
 }
 
+// W<ZW,U>: the data as in A (16 bytes per lane and plane); the mask in 16-byte requests - lane l of a quad of lanes reads the quad's
+// 16 mask bytes of plane (u & ~3) + (l & 3): U / 4 mask requests per lane for U planes instead of U (the moment kernel would then
+// hand the four dwords around inside the quad)
+template <int ZW, int U>
+__global__ __launch_bounds__(64 * ZW) void rdw(const float* __restrict__ in, const uint8_t* __restrict__ mk, float* sink, long nz, long ncols, int remap) {
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    long b = blockIdx.x;
+    if (remap) b = xcd_group(b, gridDim.x);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const long col0 = (b * 64 + threadIdx.x) * 4, colq = (b * 64 + (threadIdx.x & ~3)) * 4;
+    if (col0 >= ncols) return;
+    const long zstep = ZW;
+    f4 acc{};
+    u4 macc{};
+    for (long z = w; z + (long)(U - 1) * zstep < nz; z += (long)U * zstep) {
+        f4 v[U];
+        u4 m[U / 4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load((const f4*)(in + (z + u * zstep) * ncols + col0));
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) m[u] = __builtin_nontemporal_load((const u4*)(mk + (z + (4 * u + (threadIdx.x & 3)) * zstep) * ncols + colq));
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) macc += m[u];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f || (macc.x ^ macc.y ^ macc.z ^ macc.w) == 0x12345u) sink[0] = 1;
+}
+
 static hipEvent_t e0, e1;
 template <typename F>
 static void timeit(const char* name, double bytes, F f) {
@@ -72,6 +101,13 @@ int main() {
         hipMemset(in, 0, nz * ncols * 4); hipMemset(mk, 1, nz * ncols);
         hipEventCreate(&e0); hipEventCreate(&e1);
         run<4, 8, 1, false>(in, mk, sink, nz, ncols);
+        for (int remap : {0, 1}) {
+            char name[160];
+            snprintf(name, 160, "16-byte mask requests ZW 4, U 8, 1 KiB + 4 x 1 KiB / 4 planes per wave, xcd grouping %d", remap);
+            timeit(name, (double)nz * ncols * 5, [&] { rdw<4, 8><<<dim3((unsigned)(ncols / 4 / 64)), dim3(64, 4)>>>(in, mk, sink, nz, ncols, remap); });
+            snprintf(name, 160, "16-byte mask requests ZW 8, U 8, xcd grouping %d", remap);
+            timeit(name, (double)nz * ncols * 5, [&] { rdw<8, 8><<<dim3((unsigned)(ncols / 4 / 64)), dim3(64, 8)>>>(in, mk, sink, nz, ncols, remap); });
+        }
         run<8, 8, 1, false>(in, mk, sink, nz, ncols);
         run<4, 4, 1, false>(in, mk, sink, nz, ncols);
         run<4, 4, 2, false>(in, mk, sink, nz, ncols);
