@@ -125,6 +125,11 @@ for name, kernel, ms, alg in records:
         if not cands:
             chosen = []
             break
+        # (the PMC passes run without the strip terms: a group that only the stats pass saw - a rank strip of the same kernel, timed
+        #  within a percent of configs[1] - is no candidate when another one has counters)
+        with_pmc = [(k, v) for k, v in cands if counters["FETCH_SIZE"].get(k) and counters["WRITE_SIZE"].get(k)]
+        if with_pmc:
+            cands = with_pmc
         if len(parts) == 1:
             k, v = min(cands, key=lambda kv: abs(sorted(cluster(kv[1], ms))[len(cluster(kv[1], ms)) // 2] / 1e6 - ms))
             v = cluster(v, ms)
