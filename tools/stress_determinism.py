@@ -57,7 +57,18 @@ OPS = {
     "sigma clip mean / std (uint8 mask)": lambda: [ops.sigma_clip_axis0(cube, 2.5, mask=marr, cenfunc="mean").get()],
     "spectral_interpolate x 2 (uint8 mask)": lambda: [ops.spectral_lerp(cube, lo, t, inv_dx, fill=fill, mask=marr).get()],
     "reproject bilinear 30 deg (uint8 mask)": lambda: [ops.resample_bilinear(cube, xs, ys, mask=marr, want_footprint=False)[0].get()],
+    "spatial_smooth -> moments 0+1+2, three sums (uint8 mask)": lambda: maps(ops.spatial_conv_mfma_moments(cube, k2, cen, dv=500.0, m1_add=0.0, mask=marr)[1]),
+    "float64 spatial_smooth, ring form (uint8 mask)": lambda: [ops.spatial_conv_f64(cube64, k2, mask=marr64).get()],
+    "float64 spectral_smooth, ring form (uint8 mask)": lambda: [ops.spectral_conv_f64(cube64, k1, mask=marr64).get()],
+    "float64 median (uint8 mask)": lambda: [ops.percentile_axis0_f64(cube64, 50.0, mask=marr64).get()],
+    "float64 sigma clip (uint8 mask)": lambda: [ops.sigma_clip_axis0_f64(cube64, sigma=3.0, mask=marr64).get()],
+    "float64 statistics (uint8 mask)": lambda: [np.array([ops.stats_global_f64(cube64, mask=marr64)[k] for k in ("npts", "min", "max", "sum", "sumsq")])],
 }
+# (round 6) a float64 cube of a quarter of the rows for the float64 operators
+n64 = max(16, ny // 4 // 16 * 16)
+cube64 = DeviceArray.from_numpy(np.tile(1000.0 + tile.astype(np.float64), (1, n64 // 16, 1)))
+mask64 = DeviceArray.from_numpy(np.tile(tm, (1, n64 // 16, 1)))
+marr64 = ops.MaskSpec(_lib.MASK_ARRAY, array=mask64)
 only = os.environ.get("STRESS_ONLY")
 total_bad = 0
 for name, fn in OPS.items():
